@@ -1,0 +1,312 @@
+/*
+ * ll_multichannel.c -- CPU ORACLE (test infrastructure): the reference's own sample
+ * flows restated over the liquidlite objects, plus the multi-stage resampler.
+ *
+ *   ll_mcrx_*  follows /root/reference/lib/multichannelrx.cc:
+ *              ctor :45-104 (N syncs; analysis bank K=2N, m=7, As=60; VCO at
+ *              -0.5(N-1)/N*pi), Reset :135-153 (NCO deliberately not reset),
+ *              Execute :155-182 (mix down, step, buffer K samples),
+ *              RunChannelizer :185-195 (analyzer, bins 0..N-1 -> synchronizer i).
+ *   ll_mctx_*  follows /root/reference/lib/multichanneltx.cc:
+ *              ctor :41-100 (N framegens CRC-32/none/Hamming128/QPSK; synthesis bank
+ *              K=2N, m=13), Reset :135-149, IsChannelReadyForData :152-162,
+ *              UpdateData :165-189, GenerateSamples :192-227, GenerateFrameSamples :230-242.
+ *   ll_msresamp_* restates liquid-dsp src/filter/src/{msresamp,resamp.fixed,resamp2}.c as
+ *              called by the reference's front-end pattern (src/flexframe_rx.cc:179,240):
+ *              half-band decimators while r < 0.5, then a 256-branch polyphase arbitrary
+ *              resampler (m=7, fc=min(0.515 r,0.49)) stepped by a 24-bit fixed-point phase.
+ *              Half-band stage design parameters are [UPSTREAM-UNVERIFIED] (m=7 each).
+ */
+#include "liquidlite.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+
+/* ================================================================== multichannelrx */
+struct ll_mcrx_s {
+    unsigned N, M, cp, taper;
+    ll_firpfbch ch;
+    ll_cf *x, *X;
+    unsigned buffer_index;
+    ll_ofdmflexframesync *fs;
+    ll_nco nco;
+};
+
+static float mc_offset(unsigned N)
+{
+    float f = -0.5f * (float)(N - 1) / (float)N;
+    return (float)((double)f * M_PI);
+}
+
+ll_mcrx ll_mcrx_create(unsigned N, unsigned M, unsigned cp, unsigned taper, const unsigned char *p,
+                       void **userdata, ll_framesync_callback *cb)
+{
+    if (N < 1 || M < 8 || cp < 1 || taper > cp) return NULL;
+    ll_mcrx q = (ll_mcrx)calloc(1, sizeof(*q));
+    q->N = N; q->M = M; q->cp = cp; q->taper = taper;
+    q->fs = (ll_ofdmflexframesync *)calloc(N, sizeof(ll_ofdmflexframesync));
+    for (unsigned i = 0; i < N; i++)
+        q->fs[i] = ll_ofdmflexframesync_create(M, cp, taper, p, cb ? cb[i] : NULL, userdata ? userdata[i] : NULL);
+    q->ch = ll_firpfbch_create_kaiser(LL_ANALYZER, 2 * N, 7, 60.0f);
+    q->X = (ll_cf *)calloc(2 * N, sizeof(ll_cf));
+    q->x = (ll_cf *)calloc(2 * N, sizeof(ll_cf));
+    ll_nco_reset(&q->nco);
+    ll_nco_set_frequency(&q->nco, mc_offset(N));
+    ll_mcrx_reset(q);
+    return q;
+}
+void ll_mcrx_destroy(ll_mcrx q)
+{
+    if (!q) return;
+    for (unsigned i = 0; i < q->N; i++) ll_ofdmflexframesync_destroy(q->fs[i]);
+    ll_firpfbch_destroy(q->ch);
+    free(q->fs); free(q->X); free(q->x); free(q);
+}
+void ll_mcrx_reset(ll_mcrx q)
+{
+    for (unsigned i = 0; i < q->N; i++) ll_ofdmflexframesync_reset(q->fs[i]);
+    ll_firpfbch_reset(q->ch);
+    memset(q->X, 0, sizeof(ll_cf) * 2 * q->N);
+    memset(q->x, 0, sizeof(ll_cf) * 2 * q->N);
+    q->buffer_index = 0;
+}
+void ll_mcrx_set_soft(ll_mcrx q, int s)
+{ for (unsigned i = 0; i < q->N; i++) ll_ofdmflexframesync_set_soft(q->fs[i], s); }
+
+void ll_mcrx_execute(ll_mcrx q, const ll_cf *xin, unsigned n)
+{
+    unsigned K = 2 * q->N;
+    for (unsigned i = 0; i < n; i++) {
+        q->x[q->buffer_index] = ll_nco_mix_down(&q->nco, xin[i]);
+        ll_nco_step(&q->nco);
+        if (++q->buffer_index == K) {
+            q->buffer_index = 0;
+            ll_firpfbch_analyzer_execute(q->ch, q->x, q->X);
+            for (unsigned c = 0; c < q->N; c++) ll_ofdmflexframesync_execute(q->fs[c], &q->X[c], 1);
+        }
+    }
+}
+void ll_mcrx_channelize(ll_mcrx q, const ll_cf *xin, unsigned nblocks, ll_cf *out)
+{
+    unsigned K = 2 * q->N;
+    for (unsigned b = 0; b < nblocks; b++) {
+        for (unsigned i = 0; i < K; i++) {
+            q->x[i] = ll_nco_mix_down(&q->nco, xin[(size_t)b * K + i]);
+            ll_nco_step(&q->nco);
+        }
+        ll_firpfbch_analyzer_execute(q->ch, q->x, q->X);
+        memcpy(out + (size_t)b * q->N, q->X, sizeof(ll_cf) * q->N);
+    }
+}
+
+/* ================================================================== multichanneltx */
+struct ll_mctx_s {
+    unsigned N, M, cp, taper;
+    ll_firpfbch ch;
+    ll_cf *X, *x;
+    ll_ofdmflexframegen *fg;
+    ll_cf **fgbuffer;
+    unsigned fgbuffer_len, fgbuffer_index;
+    ll_nco nco;
+};
+
+ll_mctx ll_mctx_create(unsigned N, unsigned M, unsigned cp, unsigned taper, const unsigned char *p)
+{
+    if (N < 1 || M < 8 || cp < 1 || taper > cp) return NULL;
+    ll_mctx q = (ll_mctx)calloc(1, sizeof(*q));
+    q->N = N; q->M = M; q->cp = cp; q->taper = taper;
+    ll_ofdmflexframegenprops props = { LL_CRC_32, LL_FEC_NONE, LL_FEC_HAMMING128, LL_MODEM_QPSK };
+    q->fg = (ll_ofdmflexframegen *)calloc(N, sizeof(ll_ofdmflexframegen));
+    q->fgbuffer = (ll_cf **)calloc(N, sizeof(ll_cf *));
+    q->fgbuffer_len = M + cp;
+    for (unsigned i = 0; i < N; i++) {
+        q->fg[i] = ll_ofdmflexframegen_create(M, cp, taper, p, &props);
+        q->fgbuffer[i] = (ll_cf *)calloc(q->fgbuffer_len, sizeof(ll_cf));
+    }
+    q->ch = ll_firpfbch_create_kaiser(LL_SYNTHESIZER, 2 * N, 13, 60.0f);
+    q->X = (ll_cf *)calloc(2 * N, sizeof(ll_cf));
+    q->x = (ll_cf *)calloc(2 * N, sizeof(ll_cf));
+    ll_nco_reset(&q->nco);
+    ll_nco_set_frequency(&q->nco, mc_offset(N));
+    ll_mctx_reset(q);
+    return q;
+}
+void ll_mctx_destroy(ll_mctx q)
+{
+    if (!q) return;
+    for (unsigned i = 0; i < q->N; i++) { ll_ofdmflexframegen_destroy(q->fg[i]); free(q->fgbuffer[i]); }
+    ll_firpfbch_destroy(q->ch);
+    free(q->fg); free(q->fgbuffer); free(q->X); free(q->x); free(q);
+}
+void ll_mctx_reset(ll_mctx q)
+{
+    for (unsigned i = 0; i < q->N; i++) {
+        ll_ofdmflexframegen_reset(q->fg[i]);
+        memset(q->fgbuffer[i], 0, sizeof(ll_cf) * q->fgbuffer_len);
+    }
+    ll_firpfbch_reset(q->ch);
+    memset(q->X, 0, sizeof(ll_cf) * 2 * q->N);
+    memset(q->x, 0, sizeof(ll_cf) * 2 * q->N);
+    q->fgbuffer_index = q->fgbuffer_len;
+}
+int ll_mctx_is_channel_ready(ll_mctx q, unsigned ch)
+{ if (ch >= q->N) return -1; return ll_ofdmflexframegen_is_assembled(q->fg[ch]) ? 0 : 1; }
+
+int ll_mctx_update_data(ll_mctx q, unsigned ch, const unsigned char *header,
+                        const unsigned char *payload, unsigned payload_len, int mod, int fec0, int fec1)
+{
+    if (ch >= q->N) return -1;
+    if (!ll_mctx_is_channel_ready(q, ch)) return 1;     /* reference: warning + return */
+    ll_ofdmflexframegenprops props = { LL_CRC_32, (unsigned)fec0, (unsigned)fec1, (unsigned)mod };
+    ll_ofdmflexframegen_setprops(q->fg[ch], &props);
+    ll_ofdmflexframegen_assemble(q->fg[ch], header, payload, payload_len);
+    return 0;
+}
+void ll_mctx_generate_samples(ll_mctx q, ll_cf *buf)
+{
+    unsigned K = 2 * q->N;
+    if (q->fgbuffer_index >= q->fgbuffer_len) {
+        for (unsigned i = 0; i < q->N; i++) {
+            if (ll_ofdmflexframegen_is_assembled(q->fg[i])) ll_ofdmflexframegen_writesymbol(q->fg[i], q->fgbuffer[i]);
+            else memset(q->fgbuffer[i], 0, sizeof(ll_cf) * q->fgbuffer_len);
+        }
+        q->fgbuffer_index = 0;
+    }
+    for (unsigned i = 0; i < q->N; i++) q->X[i] = q->fgbuffer[i][q->fgbuffer_index];
+    ll_firpfbch_synthesizer_execute(q->ch, q->X, buf);
+    for (unsigned i = 0; i < K; i++) {
+        buf[i] = ll_nco_mix_up(&q->nco, buf[i]);
+        ll_nco_step(&q->nco);
+    }
+    q->fgbuffer_index++;
+}
+
+/* ================================================================== msresamp */
+#define RS_PHASE_BITS 24
+typedef struct { unsigned m; float *h1; ll_cf *w0, *w1; } ll_resamp2;   /* half-band decimator */
+
+struct ll_msresamp_s {
+    float rate, As;
+    unsigned num_stages;         /* half-band decimation stages (rate < 0.5) */
+    ll_resamp2 *hb;
+    ll_cf *hb_buf; unsigned hb_count;
+    /* arbitrary stage */
+    double rate_arb;
+    unsigned npfb, m, nbits;
+    float *hpfb;                 /* [npfb][2m] reversed per branch */
+    ll_cf *win;                  /* 2m, oldest first */
+    uint32_t phase, step;
+};
+
+static void resamp2_init(ll_resamp2 *r, unsigned m, float As)
+{
+    unsigned h_len = 4 * m + 1;
+    float *h = (float *)malloc(sizeof(float) * h_len);
+    /* fc = 0.25 makes the shared Kaiser routine's sinc(2 fc t) equal sinc(t/2) */
+    ll_firdes_kaiser(h_len, 0.25f, As, 0.0f, h);
+    r->m = m;
+    r->h1 = (float *)malloc(sizeof(float) * 2 * m);
+    unsigned j = 0;
+    for (unsigned i = 1; i < h_len; i += 2) r->h1[j++] = h[h_len - i - 1];
+    r->w0 = (ll_cf *)calloc(2 * m, sizeof(ll_cf));
+    r->w1 = (ll_cf *)calloc(2 * m, sizeof(ll_cf));
+    free(h);
+}
+static ll_cf resamp2_decim(ll_resamp2 *r, ll_cf x0, ll_cf x1)
+{
+    unsigned n = 2 * r->m;
+    memmove(r->w1, r->w1 + 1, sizeof(ll_cf) * (n - 1)); r->w1[n - 1] = x0;
+    ll_cf y1 = { 0, 0 };
+    for (unsigned i = 0; i < n; i++) { y1.re += r->h1[i] * r->w1[i].re; y1.im += r->h1[i] * r->w1[i].im; }
+    memmove(r->w0, r->w0 + 1, sizeof(ll_cf) * (n - 1)); r->w0[n - 1] = x1;
+    ll_cf y0 = r->w0[r->m - 1];
+    ll_cf y = { 0.5f * (y0.re + y1.re), 0.5f * (y0.im + y1.im) };
+    return y;
+}
+
+ll_msresamp ll_msresamp_create(float rate, float As)
+{
+    if (rate <= 0.0f || rate > 1.0f) return NULL;       /* decimating front end only */
+    ll_msresamp q = (ll_msresamp)calloc(1, sizeof(*q));
+    q->rate = rate; q->As = As;
+    q->rate_arb = (double)rate;
+    while (q->rate_arb < 0.5) { q->num_stages++; q->rate_arb *= 2.0; }
+    q->hb = (ll_resamp2 *)calloc(q->num_stages ? q->num_stages : 1, sizeof(ll_resamp2));
+    for (unsigned i = 0; i < q->num_stages; i++) resamp2_init(&q->hb[i], 7, As);
+    q->hb_buf = (ll_cf *)calloc(1u << q->num_stages, sizeof(ll_cf));
+    q->npfb = 256; q->nbits = 8; q->m = 7;
+    float fc = 0.515f * (float)q->rate_arb; if (fc > 0.49f) fc = 0.49f;
+    unsigned n = 2 * q->m * q->npfb + 1;
+    float *hf = (float *)malloc(sizeof(float) * n);
+    ll_firdes_kaiser(n, fc / (float)q->npfb, As, 0.0f, hf);
+    double gain = 0; for (unsigned i = 0; i < n; i++) gain += hf[i];
+    gain = (double)q->npfb / gain;
+    unsigned hs = 2 * q->m;
+    q->hpfb = (float *)malloc(sizeof(float) * q->npfb * hs);
+    for (unsigned b = 0; b < q->npfb; b++)
+        for (unsigned k = 0; k < hs; k++)
+            q->hpfb[b * hs + (hs - 1 - k)] = (float)((double)hf[b + k * q->npfb] * gain);
+    free(hf);
+    q->win = (ll_cf *)calloc(hs, sizeof(ll_cf));
+    q->step = (uint32_t)llrint((double)(1u << RS_PHASE_BITS) / q->rate_arb);
+    ll_msresamp_reset(q);
+    return q;
+}
+void ll_msresamp_destroy(ll_msresamp q)
+{
+    if (!q) return;
+    for (unsigned i = 0; i < q->num_stages; i++) { free(q->hb[i].h1); free(q->hb[i].w0); free(q->hb[i].w1); }
+    free(q->hb); free(q->hb_buf); free(q->hpfb); free(q->win); free(q);
+}
+void ll_msresamp_reset(ll_msresamp q)
+{
+    for (unsigned i = 0; i < q->num_stages; i++) {
+        memset(q->hb[i].w0, 0, sizeof(ll_cf) * 2 * q->hb[i].m);
+        memset(q->hb[i].w1, 0, sizeof(ll_cf) * 2 * q->hb[i].m);
+    }
+    memset(q->win, 0, sizeof(ll_cf) * 2 * q->m);
+    q->hb_count = 0; q->phase = 0;
+}
+float ll_msresamp_get_delay(ll_msresamp q)
+{
+    float d = (float)q->m;                       /* arbitrary stage, in its input samples */
+    for (unsigned i = 0; i < q->num_stages; i++) d = 2.0f * d + (float)(2 * q->hb[i].m - 1);
+    return d;
+}
+static unsigned resamp_arb(ll_msresamp q, ll_cf x, ll_cf *y)
+{
+    unsigned hs = 2 * q->m, n = 0;
+    memmove(q->win, q->win + 1, sizeof(ll_cf) * (hs - 1)); q->win[hs - 1] = x;
+    while (q->phase < (1u << RS_PHASE_BITS)) {
+        unsigned b = q->phase >> (RS_PHASE_BITS - q->nbits);
+        const float *h = q->hpfb + b * hs;
+        ll_cf acc = { 0, 0 };
+        for (unsigned k = 0; k < hs; k++) { acc.re += h[k] * q->win[k].re; acc.im += h[k] * q->win[k].im; }
+        y[n++] = acc;
+        q->phase += q->step;
+    }
+    q->phase -= (1u << RS_PHASE_BITS);
+    return n;
+}
+void ll_msresamp_execute(ll_msresamp q, const ll_cf *x, unsigned nx, ll_cf *y, unsigned *ny)
+{
+    unsigned n = 0, D = 1u << q->num_stages;
+    for (unsigned i = 0; i < nx; i++) {
+        ll_cf v = x[i];
+        if (q->num_stages) {
+            q->hb_buf[q->hb_count++] = v;
+            if (q->hb_count < D) continue;
+            q->hb_count = 0;
+            unsigned cnt = D;
+            for (unsigned s = 0; s < q->num_stages; s++) {
+                for (unsigned k = 0; k < cnt / 2; k++)
+                    q->hb_buf[k] = resamp2_decim(&q->hb[s], q->hb_buf[2 * k], q->hb_buf[2 * k + 1]);
+                cnt /= 2;
+            }
+            v = q->hb_buf[0];
+        }
+        n += resamp_arb(q, v, y + n);
+    }
+    *ny = n;
+}

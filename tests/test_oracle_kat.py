@@ -1,0 +1,164 @@
+"""Pins the CPU oracle's bit-level pieces with standards-level known answers and
+exhaustive code properties (the reference holds no vectors)."""
+import zlib
+
+import numpy as np
+import pytest
+
+
+def test_crc32_matches_ieee(oracle):
+    L = oracle.lib()
+    msg = np.frombuffer(b"123456789", np.uint8).copy()
+    assert L.ll_crc_generate_key(oracle.CRC_32, msg.ctypes.data, 9) == 0xCBF43926
+    rng = np.random.RandomState(0)
+    for n in (0, 1, 7, 64, 1200):
+        m = rng.randint(0, 256, max(n, 1)).astype(np.uint8)
+        assert L.ll_crc_generate_key(oracle.CRC_32, m.ctypes.data, n) == zlib.crc32(bytes(m[:n]))
+
+
+def test_hamming128_corrects_every_single_error(oracle):
+    L = oracle.lib()
+    words = [L.ll_hamming128_encode_symbol(s) for s in range(256)]
+    assert len(set(words)) == 256 and max(words) < 4096
+    # minimum distance 3
+    dmin = min(bin(words[a] ^ words[b]).count("1") for a in range(256) for b in range(a))
+    assert dmin == 3
+    for s in range(256):
+        assert L.ll_hamming128_decode_symbol(words[s]) == s
+        for bit in range(12):
+            assert L.ll_hamming128_decode_symbol(words[s] ^ (1 << bit)) == s
+
+
+def test_golay2412_is_extended_golay(oracle):
+    L = oracle.lib()
+    words = np.array([L.ll_golay2412_encode_symbol(s) for s in range(4096)], np.uint32)
+    wt = np.array([bin(int(w)).count("1") for w in words])
+    # weight enumerator of the extended binary Golay code: 1, 759, 2576, 759, 1
+    assert {int(k): int(v) for k, v in zip(*np.unique(wt, return_counts=True))} == \
+        {0: 1, 8: 759, 12: 2576, 16: 759, 24: 1}
+    assert all((int(w) & 0xfff) == s for s, w in enumerate(words))      # systematic
+    rng = np.random.RandomState(1)
+    for _ in range(3000):
+        s = int(rng.randint(0, 4096))
+        nerr = int(rng.randint(0, 4))
+        e = 0
+        for b in rng.choice(24, nerr, replace=False):
+            e |= 1 << int(b)
+        assert L.ll_golay2412_decode_symbol(int(words[s]) ^ e) == s
+
+
+@pytest.mark.parametrize("scheme,n", [(6, 1), (6, 2), (6, 7), (6, 1204), (7, 1), (7, 2), (7, 3), (7, 18), (7, 1204), (1, 5)])
+def test_fec_block_roundtrip_and_lengths(oracle, scheme, n):
+    L = oracle.lib()
+    rng = np.random.RandomState(n)
+    msg = rng.randint(0, 256, n).astype(np.uint8)
+    k = L.ll_fec_enc_len(scheme, n)
+    bits_in, m_bits, k_bits = 8 * n, {6: 8, 7: 12, 1: 8}[scheme], {6: 12, 7: 24, 1: 8}[scheme]
+    blocks = -(-bits_in // m_bits)
+    assert k == -(-(blocks * k_bits) // 8)                 # liquid fec_block_get_enc_msg_len
+    enc = np.zeros(k, np.uint8)
+    L.ll_fec_encode(scheme, n, msg.ctypes.data, enc.ctypes.data)
+    dec = np.zeros(n, np.uint8)
+    L.ll_fec_decode(scheme, n, enc.ctypes.data, dec.ctypes.data)
+    assert np.array_equal(dec, msg)
+    soft = np.repeat(enc, 8).reshape(-1, 8)
+    soft = ((soft >> (7 - np.arange(8))) & 1).astype(np.uint8) * 255
+    dec2 = np.zeros(n, np.uint8)
+    L.ll_fec_decode_soft(scheme, n, soft.ctypes.data, dec2.ctypes.data)
+    assert np.array_equal(dec2, msg)
+
+
+def test_hamming128_soft_beats_hard_on_weak_double_error(oracle):
+    L = oracle.lib()
+    s = 0xA7
+    c = L.ll_hamming128_encode_symbol(s)
+    bits = np.array([(c >> (11 - k)) & 1 for k in range(12)])
+    soft = np.where(bits == 1, 230, 25).astype(np.uint8)
+    soft[3] = 140 if bits[3] == 0 else 115        # two weak (barely wrong) bits
+    soft[9] = 140 if bits[9] == 0 else 115
+    enc_soft = np.concatenate([soft, np.full(4, 0, np.uint8)])      # one symbol = 2 bytes = 16 soft bits
+    out = np.zeros(1, np.uint8)
+    L.ll_fec_decode_soft(6, 1, enc_soft.ctypes.data, out.ctypes.data)
+    assert out[0] == s
+
+
+@pytest.mark.parametrize("n", [2, 3, 36, 37, 100, 1806, 2409])
+def test_interleaver_is_a_bit_permutation(oracle, n):
+    L = oracle.lib()
+    rng = np.random.RandomState(n)
+    x = rng.randint(0, 256, n).astype(np.uint8)
+    for depth in range(5):
+        y = np.zeros(n, np.uint8)
+        z = np.zeros(n, np.uint8)
+        L.ll_interleaver_encode(n, depth, x.ctypes.data, y.ctypes.data)
+        L.ll_interleaver_decode(n, depth, y.ctypes.data, z.ctypes.data)
+        assert np.array_equal(z, x)
+        assert int(np.unpackbits(y).sum()) == int(np.unpackbits(x).sum())
+        if depth == 0:
+            assert np.array_equal(y, x)
+        # soft de-interleaver moves soft bits exactly like the hard one moves bits
+        soft = np.unpackbits(y).astype(np.uint8) * 200 + 20
+        out = np.zeros(8 * n, np.uint8)
+        L.ll_interleaver_decode_soft(n, depth, soft.ctypes.data, out.ctypes.data)
+        assert np.array_equal(np.packbits(out > 127), x)
+    if n >= 36:
+        y = np.zeros(n, np.uint8)
+        L.ll_interleaver_encode(n, 4, x.ctypes.data, y.ctypes.data)
+        assert not np.array_equal(y, x)
+
+
+def test_scrambler_is_involution(oracle):
+    L = oracle.lib()
+    x = np.arange(37, dtype=np.uint8)
+    y = x.copy()
+    L.ll_scramble(y.ctypes.data, 37)
+    assert np.array_equal(y[:4] ^ x[:4], np.array([0xb4, 0x6a, 0x8b, 0xc5], np.uint8))
+    L.ll_scramble(y.ctypes.data, 37)
+    assert np.array_equal(y, x)
+
+
+@pytest.mark.parametrize("n,fec0,fec1,enc", [(14, 7, 1, 36), (1200, 1, 6, 1806), (1200, 1, 7, 2409),
+                                             (1200, 1, 1, 1204), (0, 1, 6, 6), (5, 6, 7, 30)])
+def test_packetizer_lengths_roundtrip_and_error_correction(oracle, n, fec0, fec1, enc):
+    p = oracle.Packetizer(n, oracle.CRC_32, fec0, fec1)
+    assert p.enc_len == enc
+    rng = np.random.RandomState(n + fec1)
+    msg = rng.randint(0, 256, n).astype(np.uint8)
+    pkt = p.encode(bytes(msg))
+    ok, out = p.decode(pkt)
+    assert ok and np.array_equal(out, msg)
+    soft = (np.unpackbits(pkt) * 255).astype(np.uint8)
+    ok, out = p.decode_soft(soft)
+    assert ok and np.array_equal(out, msg)
+    if fec1 != 1 and enc >= 30:
+        bad = pkt.copy()
+        for pos in rng.choice(enc, 3, replace=False):
+            bad[pos] ^= 1 << int(rng.randint(0, 8))       # interleaving spreads these over codewords
+        ok, out = p.decode(bad)
+        assert ok and np.array_equal(out, msg)
+    if n:
+        bad = pkt.copy()
+        bad[:] ^= 0xff
+        ok, _ = p.decode(bad)
+        assert not ok
+
+
+def test_modems_gray_and_soft_bits(oracle):
+    for scheme, M in ((oracle.MODEM_BPSK, 2), (oracle.MODEM_QPSK, 4), (oracle.MODEM_QAM16, 16), (oracle.MODEM_QAM64, 64)):
+        m = oracle.Modem(scheme)
+        pts = np.array([m.modulate(s) for s in range(M)])
+        assert abs(np.mean(np.abs(pts) ** 2) - 1.0) < 1e-6                 # unit average energy
+        d = np.abs(pts[:, None] - pts[None, :])
+        dmin = d[d > 1e-6].min()
+        for s in range(M):
+            assert m.demodulate(pts[s]) == s
+            s2, soft = m.demodulate_soft(pts[s])
+            assert s2 == s
+            bits = [(s >> (m.bps - 1 - k)) & 1 for k in range(m.bps)]
+            assert all((sb > 127) == bool(b) for sb, b in zip(soft, bits))
+            for t in range(M):                                              # Gray: nearest neighbours differ in 1 bit
+                if t != s and d[s, t] < dmin * 1.01:
+                    assert bin(s ^ t).count("1") == 1
+    q = oracle.Modem(oracle.MODEM_QPSK)
+    s, soft = q.demodulate_soft(np.complex64(0.01 - 0.7j))
+    assert s == 2 and soft[0] == 255 and 120 <= soft[1] <= 127
