@@ -1,0 +1,119 @@
+/*
+ * mcrx_hip.h -- C-ABI of the MI355X-native multichannel OFDM receiver (libmcrx_hip.so).
+ *
+ * Drop-in boundary for liquid-usrp's `multichannelrx` hot path.  Each entry point names
+ * the reference interface it replaces (paths relative to the liquid-usrp tree):
+ *
+ *   mcrx_hip_create          multichannelrx::multichannelrx        lib/multichannelrx.cc:45-104
+ *                            (= N x ofdmflexframesync_create :82, firpfbch_crcf_create_kaiser :91,
+ *                             nco_crcf_create/set_frequency :99-100)
+ *   mcrx_hip_destroy         multichannelrx::~multichannelrx       lib/multichannelrx.cc:107-132
+ *   mcrx_hip_reset           multichannelrx::Reset                 lib/multichannelrx.cc:135-153
+ *   mcrx_hip_execute_host    multichannelrx::Execute               lib/multichannelrx.cc:155-182
+ *   mcrx_hip_execute_device  same, IQ already resident in HBM (synthetic source; replaces the
+ *                            UHD recv loop of src/multichannel_rx.cc:184-212)
+ *   mcrx_hip_flush / _next_frame
+ *                            framesync_callback delivery           include/multichannelrx.h:45,
+ *                                                                  src/multichannel_rx.cc:37-66
+ *   mcrx_hip_channelize      nco_crcf_mix_down + firpfbch_crcf_analyzer_execute
+ *                                                                  lib/multichannelrx.cc:163-164,188
+ *   mcrx_hip_sync            N x ofdmflexframesync_execute         lib/multichannelrx.cc:193-194
+ *
+ * Plain C: pointers and sizes only.  All functions return 0 on success or a negative
+ * MCRX_E* code; nothing throws across this boundary.  One caller thread per handle
+ * (the reference classes are not thread-safe either).
+ */
+#ifndef MCRX_HIP_H
+#define MCRX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCRX_OK          0
+#define MCRX_EINVAL     -1      /* bad argument (reference: fprintf + throw 0) */
+#define MCRX_ENOMEM     -2
+#define MCRX_EHIP       -3      /* HIP runtime error; see mcrx_hip_last_error() */
+#define MCRX_EUNSUPP    -4      /* configuration outside the kernels' supported set */
+#define MCRX_EOVERFLOW  -5      /* frame pool exhausted: frames were dropped */
+
+#define MCRX_TILE 8             /* time samples per (channel, tile) granule = 64 bytes */
+
+typedef struct mcrx_hip_s *mcrx_hip_t;
+
+typedef struct {
+    uint32_t struct_size;        /* sizeof(mcrx_hip_config) */
+    uint32_t max_payload_len;    /* largest decodable payload [bytes]; 0 -> 2048 */
+    uint32_t max_frames;         /* frame records kept between flushes; 0 -> auto */
+    uint32_t payload_soft;       /* 1 = soft-decision payload decoding (default), 0 = hard */
+    uint32_t slab_blocks;        /* channelizer blocks per workgroup slab; 0 -> auto */
+    uint32_t channel_first;      /* synchronizer shard: first channel ...          */
+    uint32_t channel_count;      /* ... and count handled by this handle; 0 -> all  */
+    uint32_t batch_samples;      /* execute_host staging size [wideband samples]; 0 -> auto */
+} mcrx_hip_config;
+
+/* One decoded frame = the arguments of the reference's framesync_callback
+ * (include/multichannelrx.h:45) plus where it ended. */
+typedef struct {
+    uint32_t channel;
+    int32_t  header_valid;
+    int32_t  payload_valid;
+    uint32_t payload_len;
+    uint8_t  header[8];
+    float    evm, rssi, cfo;                 /* framesyncstats_s */
+    uint32_t mod_scheme, mod_bps, check, fec0, fec1;
+    uint32_t num_framesyms;
+    uint64_t end_sample;                     /* channel-rate sample index of the last symbol */
+    const uint8_t *payload;                  /* payload_len bytes   (host memory owned by the handle, */
+    const float   *framesyms;                /* 2*num_framesyms floats   valid until the next flush)  */
+} mcrx_frame;
+
+/* ---- receiver object ---------------------------------------------------------------- */
+int  mcrx_hip_create(mcrx_hip_t *out, unsigned num_channels, unsigned M, unsigned cp_len,
+                     unsigned taper_len, const unsigned char *p, const mcrx_hip_config *cfg);
+int  mcrx_hip_destroy(mcrx_hip_t q);
+int  mcrx_hip_reset(mcrx_hip_t q);
+unsigned mcrx_hip_num_channels(mcrx_hip_t q);
+
+/* push wideband cf32 samples (interleaved re,im).  Any n; partial blocks are buffered. */
+int  mcrx_hip_execute_host(mcrx_hip_t q, const float *iq, size_t nsamples);
+/* same with the samples already in device memory; `stream` is a hipStream_t (NULL = default).
+ * nsamples must be a multiple of 2*num_channels. */
+int  mcrx_hip_execute_device(mcrx_hip_t q, const void *d_iq, size_t nsamples, void *stream);
+
+/* wait for all pushed samples, gather decoded frames (ordered by end time, then channel). */
+int  mcrx_hip_flush(mcrx_hip_t q);
+size_t mcrx_hip_frames_pending(mcrx_hip_t q);
+int  mcrx_hip_next_frame(mcrx_hip_t q, mcrx_frame *out);      /* 1 = frame written, 0 = none */
+uint64_t mcrx_hip_frames_dropped(mcrx_hip_t q);
+
+/* ---- stage level (multi-GPU split, parity tests, benchmarks) ------------------------- */
+/* NCO + analysis bank on `nblocks` blocks of 2N samples.  `first_sample` is the absolute
+ * index of d_iq[0] (NCO phase); d_halo holds the (2m-1)=13 blocks preceding d_iq (NULL = zeros).
+ * Output layout: out[g][tile][c][MCRX_TILE] cf32 with channel = g*(N/groups)+c,
+ * tile = block / MCRX_TILE; nblocks must be a multiple of MCRX_TILE. */
+int  mcrx_hip_channelize(mcrx_hip_t q, const void *d_iq, size_t nblocks, uint64_t first_sample,
+                         const void *d_halo, void *d_out, unsigned groups, void *stream);
+/* run the synchronizer bank of this handle's channel shard over d_chan[tile][c][MCRX_TILE],
+ * holding channel-rate samples [first_sample, first_sample + nsamples).  The buffer must
+ * still contain the M+cp samples preceding the first unconsumed one. */
+int  mcrx_hip_sync(mcrx_hip_t q, const void *d_chan, uint64_t first_sample, size_t nsamples, void *stream);
+
+/* benchmark replay: discard undelivered frames and return the object to its
+ * post-construction state (sample counters and NCO phase zero), asynchronously on `stream`. */
+int  mcrx_hip_restart(mcrx_hip_t q, void *stream);
+
+/* design data, for parity tests against the oracle */
+int  mcrx_hip_get_taps(mcrx_hip_t q, float *h, size_t n);             /* p*K prototype taps */
+uint32_t mcrx_hip_nco_step(mcrx_hip_t q);                             /* 32-bit phase increment */
+int  mcrx_hip_kernel_time_ms(mcrx_hip_t q, float *channelizer_ms, float *sync_ms); /* last launches */
+
+const char *mcrx_hip_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCRX_HIP_H */

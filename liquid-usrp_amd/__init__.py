@@ -1,0 +1,267 @@
+"""liquid_usrp_amd -- MI355X-native drop-in for liquid-usrp's multichannel OFDM receive path.
+
+This package is the Python face of ``lib/libmcrx_hip.so`` (hand-written gfx950 kernels behind
+the C-ABI of ``include/mcrx_hip.h``).  :class:`multichannelrx` mirrors the reference C++ class
+(``include/multichannelrx.h:29-83``): same constructor arguments, ``Execute`` / ``Reset`` /
+``GetNumChannels``, per-channel callbacks with the ``framesync_callback`` argument list.
+
+There is no CPU implementation here: if the HIP library or a GPU is missing, construction
+raises.  (The CPU oracle under ``oracle/`` is test infrastructure and is never imported by
+this package.)
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBPATH = os.path.join(_HERE, "lib", "libmcrx_hip.so")
+
+MCRX_OK, MCRX_EINVAL, MCRX_ENOMEM, MCRX_EHIP, MCRX_EUNSUPP, MCRX_EOVERFLOW = 0, -1, -2, -3, -4, -5
+TILE = 8
+
+LIQUID_CRC_NONE, LIQUID_CRC_32 = 1, 6
+LIQUID_FEC_NONE, LIQUID_FEC_HAMMING128, LIQUID_FEC_GOLAY2412 = 1, 6, 7
+LIQUID_MODEM_QAM16, LIQUID_MODEM_QAM64, LIQUID_MODEM_BPSK, LIQUID_MODEM_QPSK = 27, 29, 39, 40
+
+
+def build(force=False):
+    """Compile the HIP library for gfx950 with the in-tree Makefile (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(_HERE, "csrc")
+    deps = [os.path.join(src, f) for f in os.listdir(src) if f.endswith((".hip", ".h", ".hpp"))]
+    deps.append(os.path.join(_HERE, "..", "include", "mcrx_hip.h"))
+    stale = (not os.path.exists(_LIBPATH)) or any(os.path.getmtime(d) > os.path.getmtime(_LIBPATH) for d in deps)
+    if force or stale:
+        subprocess.check_call(["make", "-C", src, "-s", "-j4"])
+    return _LIBPATH
+
+
+class Config(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("max_payload_len", C.c_uint32), ("max_frames", C.c_uint32),
+                ("payload_soft", C.c_uint32), ("slab_blocks", C.c_uint32), ("channel_first", C.c_uint32),
+                ("channel_count", C.c_uint32), ("batch_samples", C.c_uint32)]
+
+
+class FrameC(C.Structure):
+    _fields_ = [("channel", C.c_uint32), ("header_valid", C.c_int32), ("payload_valid", C.c_int32),
+                ("payload_len", C.c_uint32), ("header", C.c_uint8 * 8),
+                ("evm", C.c_float), ("rssi", C.c_float), ("cfo", C.c_float),
+                ("mod_scheme", C.c_uint32), ("mod_bps", C.c_uint32), ("check", C.c_uint32),
+                ("fec0", C.c_uint32), ("fec1", C.c_uint32), ("num_framesyms", C.c_uint32),
+                ("end_sample", C.c_uint64), ("payload", C.c_void_p), ("framesyms", C.c_void_p)]
+
+
+_EXPORTS = {
+    "mcrx_hip_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p]),
+    "mcrx_hip_destroy": (C.c_int, [C.c_void_p]),
+    "mcrx_hip_reset": (C.c_int, [C.c_void_p]),
+    "mcrx_hip_num_channels": (C.c_uint, [C.c_void_p]),
+    "mcrx_hip_execute_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mcrx_hip_execute_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mcrx_hip_flush": (C.c_int, [C.c_void_p]),
+    "mcrx_hip_frames_pending": (C.c_size_t, [C.c_void_p]),
+    "mcrx_hip_next_frame": (C.c_int, [C.c_void_p, C.POINTER(FrameC)]),
+    "mcrx_hip_frames_dropped": (C.c_uint64, [C.c_void_p]),
+    "mcrx_hip_channelize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p]),
+    "mcrx_hip_sync": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_size_t, C.c_void_p]),
+    "mcrx_hip_restart": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mcrx_hip_get_taps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mcrx_hip_nco_step": (C.c_uint32, [C.c_void_p]),
+    "mcrx_hip_kernel_time_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "mcrx_hip_last_error": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    return sorted(_EXPORTS)
+
+
+def lib():
+    """Load libmcrx_hip.so (raises if it has not been built: there is no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIBPATH):
+            raise RuntimeError("libmcrx_hip.so is not built (run __graft_entry__.build()); "
+                               "liquid_usrp_amd has no CPU fallback")
+        L = C.CDLL(_LIBPATH)
+        for name, (res, args) in _EXPORTS.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+class McrxError(RuntimeError):
+    pass
+
+
+def _check(rc, allow=()):
+    if rc != MCRX_OK and rc not in allow:
+        msg = lib().mcrx_hip_last_error()
+        raise McrxError("mcrx_hip error %d: %s" % (rc, msg.decode() if msg else ""))
+    return rc
+
+
+class Frame(object):
+    """Arguments of one framesync_callback invocation (include/multichannelrx.h:45)."""
+    __slots__ = ("channel", "header", "header_valid", "payload", "payload_valid", "evm", "rssi", "cfo",
+                 "framesyms", "mod_scheme", "mod_bps", "check", "fec0", "fec1", "end_sample")
+
+    def __repr__(self):
+        return "Frame(ch=%d hv=%d pv=%d len=%d evm=%.2f end=%d)" % (
+            self.channel, self.header_valid, self.payload_valid, len(self.payload), self.evm, self.end_sample)
+
+
+def _dptr(t):
+    """Raw device pointer of a torch tensor / int / None."""
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return C.c_void_p(t)
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        return None
+    if isinstance(stream, int):
+        return C.c_void_p(stream)
+    return C.c_void_p(stream.cuda_stream)
+
+
+class multichannelrx(object):
+    """GPU multichannel OFDM receiver with the reference class's interface.
+
+    multichannelrx(num_channels, M, cp_len, taper_len, p, userdata, callback)
+      p         subcarrier allocation (bytes / uint8 array) or None for the default
+      userdata  list of per-channel objects handed back to the callbacks (or None)
+      callback  list of per-channel callables
+                cb(header, header_valid, payload, payload_len, payload_valid, stats, userdata) -> int
+                (stats is the :class:`Frame`: evm, rssi, cfo, framesyms, ...)
+    Callbacks run on the calling thread at flush points (buffer full, Flush(), Reset(), close()),
+    in the reference's order (frame end time, then channel).
+    """
+
+    def __init__(self, num_channels, M, cp_len, taper_len, p=None, userdata=None, callback=None, **cfg):
+        self._h = C.c_void_p()
+        self.N, self.K, self.M, self.cp = num_channels, 2 * num_channels, M, cp_len
+        parr = None if p is None else np.ascontiguousarray(np.frombuffer(bytes(bytearray(p)), np.uint8))
+        c = Config()
+        c.struct_size = C.sizeof(Config)
+        c.payload_soft = 1
+        for k, v in cfg.items():
+            setattr(c, k, v)
+        rc = lib().mcrx_hip_create(C.byref(self._h), num_channels, M, cp_len, taper_len,
+                                   None if parr is None else parr.ctypes.data, C.addressof(c))
+        if rc != MCRX_OK:
+            self._h = C.c_void_p()
+            msg = lib().mcrx_hip_last_error().decode()
+            if rc == MCRX_EINVAL:
+                raise ValueError(msg)           # the reference prints the message and throws
+            raise McrxError("mcrx_hip_create failed (%d): %s" % (rc, msg))
+        self.userdata = list(userdata) if userdata is not None else [None] * num_channels
+        self.callback = list(callback) if callback is not None else [None] * num_channels
+        self.frames = []            # every frame delivered so far (also handed to the callbacks)
+
+    # ---- reference API -----------------------------------------------------------------
+    def GetNumChannels(self):
+        return self.N
+
+    def Execute(self, x, num_samples=None):
+        """Push samples: a complex64 numpy array (host) or a torch complex64 CUDA tensor (HBM)."""
+        if hasattr(x, "is_cuda") and x.is_cuda:
+            n = int(x.numel()) if num_samples is None else int(num_samples)
+            _check(lib().mcrx_hip_execute_device(self._h, _dptr(x), n, None))
+            return
+        a = np.ascontiguousarray(x, np.complex64)
+        n = a.size if num_samples is None else int(num_samples)
+        _check(lib().mcrx_hip_execute_host(self._h, a.ctypes.data, n))
+        self._deliver(flush=False)
+
+    def Reset(self):
+        _check(lib().mcrx_hip_reset(self._h))
+        self._deliver(flush=False)
+
+    # ---- additions -----------------------------------------------------------------------
+    def Flush(self):
+        """Process everything pushed so far and deliver the callbacks."""
+        rc = lib().mcrx_hip_flush(self._h)
+        _check(rc, allow=(MCRX_EOVERFLOW,))
+        self._deliver(flush=False)
+        return rc
+
+    def _deliver(self, flush):
+        f = FrameC()
+        while lib().mcrx_hip_next_frame(self._h, C.byref(f)) == 1:
+            fr = Frame()
+            fr.channel = int(f.channel)
+            fr.header = bytes(bytearray(f.header))
+            fr.header_valid, fr.payload_valid = int(f.header_valid), int(f.payload_valid)
+            fr.payload = C.string_at(f.payload, f.payload_len) if f.payload and f.payload_len else b""
+            fr.evm, fr.rssi, fr.cfo = float(f.evm), float(f.rssi), float(f.cfo)
+            if f.framesyms and f.num_framesyms:
+                buf = (C.c_float * (2 * f.num_framesyms)).from_address(f.framesyms)
+                fr.framesyms = np.frombuffer(buf, np.float32).copy().view(np.complex64)
+            else:
+                fr.framesyms = np.zeros(0, np.complex64)
+            fr.mod_scheme, fr.mod_bps = int(f.mod_scheme), int(f.mod_bps)
+            fr.check, fr.fec0, fr.fec1 = int(f.check), int(f.fec0), int(f.fec1)
+            fr.end_sample = int(f.end_sample)
+            self.frames.append(fr)
+            cb = self.callback[fr.channel] if fr.channel < len(self.callback) else None
+            if cb is not None:
+                cb(fr.header, fr.header_valid, fr.payload, len(fr.payload), fr.payload_valid, fr,
+                   self.userdata[fr.channel])
+
+    # ---- stage level (bench / multi-GPU / parity tests) ------------------------------------
+    def taps(self):
+        h = np.zeros(14 * self.K, np.float32)
+        _check(lib().mcrx_hip_get_taps(self._h, h.ctypes.data, h.size))
+        return h
+
+    def nco_step(self):
+        return int(lib().mcrx_hip_nco_step(self._h))
+
+    def channelize(self, d_iq, nblocks, first_sample, d_out, groups=1, d_halo=None, stream=None):
+        _check(lib().mcrx_hip_channelize(self._h, _dptr(d_iq), nblocks, first_sample, _dptr(d_halo),
+                                         _dptr(d_out), groups, _stream_ptr(stream)))
+
+    def sync(self, d_chan, first_sample, nsamples, stream=None):
+        _check(lib().mcrx_hip_sync(self._h, _dptr(d_chan), first_sample, nsamples, _stream_ptr(stream)))
+
+    def restart(self, stream=None):
+        _check(lib().mcrx_hip_restart(self._h, _stream_ptr(stream)))
+
+    def kernel_time_ms(self):
+        a, b = C.c_float(0), C.c_float(0)
+        _check(lib().mcrx_hip_kernel_time_ms(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def frames_dropped(self):
+        return int(lib().mcrx_hip_frames_dropped(self._h))
+
+    def close(self):
+        if self._h:
+            try:
+                self.Flush()
+            finally:
+                lib().mcrx_hip_destroy(self._h)
+                self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().mcrx_hip_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+
+def tiles_to_channels(chan, nch):
+    """[tile][ch][8] (torch or numpy, complex) -> [ch][time] numpy array (test helper)."""
+    a = chan.cpu().numpy() if hasattr(chan, "cpu") else np.asarray(chan)
+    a = a.reshape(-1, nch, TILE)
+    return np.ascontiguousarray(a.transpose(1, 0, 2)).reshape(nch, -1)

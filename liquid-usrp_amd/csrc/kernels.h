@@ -1,0 +1,113 @@
+// kernels.h -- argument blocks and launch entry points of the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mcrx {
+
+#define MCRX_TILE_S 8            // channel-rate samples per (channel, tile) granule
+#define MCRX_H128_NBD 24         // Hamming(12,8) neighbour slots (matches design.hpp)
+#define MCRX_HDR_SYMS 288        // BPSK header symbols
+#define MCRX_HDR_ENC 36
+#define MCRX_HDR_DEC 14
+
+// ---------------------------------------------------------------- channelizer.hip
+struct ChanArgs {
+    const float2 *x;            // new wideband samples, nblocks * K
+    const float2 *halo;         // 13 blocks preceding x (NULL = zeros: cold start)
+    const float *taps;          // p*K prototype taps
+    float2 *out;                // out[g][tile][c][8]
+    uint32_t nblocks;           // blocks in x (multiple of 8)
+    uint32_t slab_blocks;       // blocks per slab (multiple of 8)
+    uint32_t first_sample_lo;   // absolute sample index of x[0], low 32 bits (NCO phase)
+    uint32_t dtheta;            // NCO phase increment per sample
+    uint32_t ntiles;            // tiles per group in `out`
+    uint32_t cg;                // channels per group
+};
+int channelizer_supported(unsigned K);
+hipError_t channelizer_launch(unsigned K, const ChanArgs &a, hipStream_t st);
+
+// ---------------------------------------------------------------- ofdmsync.hip
+enum { SY_SEEK = 0, SY_S0A, SY_S0B, SY_S1, SY_RX };
+enum { FX_HEADER = 0, FX_PAYLOAD };
+
+// coding tables in device memory (one copy per process)
+struct CodingDev {
+    const uint16_t *h128_enc;       // [256]
+    const uint8_t *h128_nb;         // [256][MCRX_H128_NBD]
+    const uint8_t *h128_nnb;        // [256]
+    const uint32_t *crc_byte;       // [256]
+    const uint32_t *crc_zadv;       // [16][4][256]
+    const uint8_t *qam16_nb;        // [16][4]
+    const uint8_t *qam64_nb;        // [64][4]
+};
+
+// design tables of one (M, cp, allocation)
+struct SyncConsts {
+    int M, M2, cp, L, backoff, M_pilot, M_data, Nen, M_S0, M_S1;
+    int E;                      // elements per lane = ceil(M / 64)
+    int log2M;                  // > 0: power-of-two shuffle FFT; 0: direct DFT
+    float detect_thresh, sync_thresh;
+    const uint8_t *sctype;      // [M]
+    const float *S0, *S1;       // [M]  +-1 / 0
+    const float2 *s0t;          // [M]  time-domain S0
+    const float *Ssm;           // [M][Nen]
+    const float *Pfit;          // [2][M_pilot]
+    const int16_t *data_rank, *pilot_rank, *en_rank;    // [M]
+    const uint8_t *pilot_seq;   // [255]
+    const float2 *dft_tw;       // [M]  W_M^k
+    CodingDev cod;
+    uint32_t max_payload_len, max_enc_len, max_syms;
+    int payload_soft;
+};
+
+// per-channel synchronizer state, persistent across launches
+struct ChanState {
+    int32_t state; uint32_t timer;
+    int64_t cur;                // next channel-rate sample to consume (absolute)
+    uint32_t nco_theta_ref, nco_dtheta; int64_t nco_t_ref;
+    float g0; float2 s_hat_0;
+    uint32_t num_symbols, pilot_count;
+    float phi_prime, p1_prime;
+    int32_t fstate; uint32_t header_symbol_index, payload_symbol_index;
+    float evm_hat, evm;
+    uint32_t payload_len, mod_scheme, bps, check, fec0, fec1, enc_len, mod_len;
+    int32_t header_valid;
+    uint32_t hw[4];             // decoded header bytes 0..13, little-endian words
+};
+
+// one decoded frame (device side); host copies payload / framesyms from the slot arrays
+struct FrameRec {
+    uint32_t channel; int32_t header_valid, payload_valid; uint32_t payload_len;
+    uint8_t header[8];
+    float evm, rssi, cfo;
+    uint32_t mod_scheme, mod_bps, check, fec0, fec1, num_framesyms;
+    int64_t end_sample;
+    uint64_t payload_off, syms_off;     // byte offsets into the frame arena
+};
+
+struct SyncArgs {
+    SyncConsts c;
+    const float2 *chan;         // [tile][chan_stride][8]; my channel c sits at chan_off + c
+    uint32_t chan_stride, chan_off;
+    int64_t buf_first;          // absolute index of chan sample (tile 0, slot 0)
+    int64_t end;                // absolute end (exclusive) of valid samples
+    uint32_t nch;               // channels in this shard
+    uint32_t ch_first;          // global index of shard channel 0 (reported in FrameRec)
+    ChanState *st;              // [nch]
+    uint8_t *hbits;             // [nch][MCRX_HDR_SYMS] hard header bits
+    float2 *R;                  // [nch][M] equaliser
+    uint8_t *soft;              // [nch][8*max_enc_len]
+    uint8_t *tmpa, *tmpb;       // [nch][max_enc_len + 16]
+    float2 *syms;               // [nch][max_syms]
+    // output pool
+    FrameRec *rec; uint8_t *arena;
+    uint32_t *nrec;             // [0] allocated count, [1] dropped count
+    unsigned long long *arena_used;
+    uint64_t arena_cap;
+    uint32_t max_rec;
+};
+hipError_t sync_launch(const SyncArgs &a, hipStream_t st);
+hipError_t sync_reset_launch(ChanState *st, uint32_t nch, int64_t cur, hipStream_t stream);
+
+}  // namespace mcrx

@@ -1,0 +1,471 @@
+// mcrx_hip.hip -- C-ABI implementation (include/mcrx_hip.h): handle management, HBM
+// buffers, streaming glue between the channelizer and the synchronizer bank, frame
+// harvesting.  Host code only; the kernels live in channelizer.hip / ofdmsync.hip.
+#include "../../include/mcrx_hip.h"
+#include "design.hpp"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace mcrx;
+
+#define HIST_BLOCKS 13      /* 2m - 1 blocks of FIR history (m = 7) */
+
+static thread_local std::string g_err;
+static void set_err(const char *what, hipError_t e, const char *file, int line)
+{
+    char buf[512];
+    snprintf(buf, sizeof(buf), "%s: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    g_err = buf;
+}
+static int fail(int code, const char *msg) { g_err = msg; return code; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err(#x, e_, __FILE__, __LINE__); return MCRX_EHIP; } } while (0)
+#define RC(x) do { int rc_ = (x); if (rc_ != MCRX_OK) return rc_; } while (0)
+
+extern "C" const char *mcrx_hip_last_error(void) { return g_err.c_str(); }
+
+// ---------------------------------------------------------------- process-wide coding tables
+static std::mutex g_cod_mu;
+static bool g_cod_ready = false;
+static CodingDev g_cod;
+static_assert(MCRX_H128_NB == MCRX_H128_NBD, "neighbour table width mismatch");
+
+template <class T> static int upload_raw(T **dst, const T *src, size_t n)
+{
+    HIPCHK(hipMalloc((void **)dst, std::max<size_t>(n, 1) * sizeof(T)));
+    if (n) HIPCHK(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return MCRX_OK;
+}
+static int coding_tables(CodingDev *out)
+{
+    std::lock_guard<std::mutex> lk(g_cod_mu);
+    if (!g_cod_ready) {
+        CodingTables *t = new CodingTables();
+        uint16_t *a; uint8_t *b, *c, *f, *g; uint32_t *d, *e;
+        RC(upload_raw(&a, t->h128_enc, 256));
+        RC(upload_raw(&b, &t->h128_nb[0][0], 256 * MCRX_H128_NB));
+        RC(upload_raw(&c, t->h128_nnb, 256));
+        RC(upload_raw(&d, t->crc_byte, 256));
+        RC(upload_raw(&e, &t->crc_zadv[0][0][0], 16 * 4 * 256));
+        RC(upload_raw(&f, &t->qam16_nb[0][0], 64));
+        RC(upload_raw(&g, &t->qam64_nb[0][0], 256));
+        g_cod.h128_enc = a; g_cod.h128_nb = b; g_cod.h128_nnb = c; g_cod.crc_byte = d; g_cod.crc_zadv = e;
+        g_cod.qam16_nb = f; g_cod.qam64_nb = g;
+        delete t;
+        g_cod_ready = true;
+    }
+    *out = g_cod;
+    return MCRX_OK;
+}
+
+// ---------------------------------------------------------------- small kernels
+__global__ void hist_update_kernel(const float2 *old_hist, const float2 *x, uint64_t nx, float2 *new_hist, uint64_t nh)
+{
+    // new_hist = last nh samples of concat(old_hist[nh], x[nx])
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nh) return;
+    uint64_t pos = nx + i;
+    new_hist[i] = (pos < nh) ? old_hist[pos] : x[pos - nh];
+}
+
+// ---------------------------------------------------------------- handle
+struct mcrx_hip_s {
+    unsigned N = 0, K = 0, M = 0, cp = 0, taper = 0;
+    OfdmDesign od;
+    mcrx_hip_config cfg{};
+    std::vector<float> taps;
+    uint32_t dtheta = 0, slab_blocks = 64;
+    const float *d_taps = nullptr;
+    SyncConsts sc{};
+    std::vector<void *> owned;              // device allocations freed at destroy
+    // synchronizer bank
+    unsigned ch_first = 0, nch = 0;
+    uint32_t max_payload = 0, max_enc = 0, max_syms = 0, max_rec = 0;
+    uint64_t arena_cap = 0;
+    ChanState *d_st = nullptr; uint8_t *d_hbits = nullptr; float2 *d_R = nullptr;
+    uint8_t *d_soft = nullptr, *d_tmpa = nullptr, *d_tmpb = nullptr; float2 *d_syms = nullptr;
+    FrameRec *d_rec = nullptr; uint8_t *d_arena = nullptr; uint32_t *d_nrec = nullptr;
+    unsigned long long *d_arena_used = nullptr;
+    // streaming state
+    uint64_t total_samples = 0;             // wideband samples accepted since creation (NCO phase)
+    uint64_t stage_first = 0;               // absolute index of h_stage[0]
+    int64_t chan_samples = 0;               // channel-rate samples produced since creation
+    float2 *d_hist[2] = { nullptr, nullptr }; int hist_cur = 0;
+    float2 *d_in = nullptr;                 // device staging (stage_cap samples)
+    float2 *h_stage = nullptr; size_t stage_cap = 0, stage_fill = 0;   // pinned host staging (samples)
+    float2 *d_chan[2] = { nullptr, nullptr }; size_t chan_cap_tiles = 0; int chan_cur = 0;
+    unsigned hist_tiles = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+    bool ev_ch = false, ev_sy = false;
+    // harvested frames (host)
+    std::vector<FrameRec> recs; std::vector<uint8_t> arena_host; size_t next_frame = 0;
+    uint64_t dropped = 0;
+
+    template <class T> int upload(const T **dst, const T *src, size_t n)
+    {
+        T *p = nullptr;
+        RC(upload_raw(&p, src, n));
+        owned.push_back(p); *dst = p;
+        return MCRX_OK;
+    }
+    template <class T> int alloc(T **dst, size_t n)
+    {
+        HIPCHK(hipMalloc((void **)dst, std::max<size_t>(n, 1) * sizeof(T)));
+        HIPCHK(hipMemset(*dst, 0, std::max<size_t>(n, 1) * sizeof(T)));
+        owned.push_back(*dst);
+        return MCRX_OK;
+    }
+};
+
+static unsigned pow2ceil(unsigned v) { unsigned p = 1; while (p < v) p <<= 1; return p; }
+
+static int build_tables(mcrx_hip_t q)
+{
+    const OfdmDesign &od = q->od;
+    SyncConsts &c = q->sc;
+    c.M = (int)od.M; c.M2 = (int)od.M2; c.cp = (int)od.cp; c.L = (int)(od.M + od.cp); c.backoff = (int)od.backoff;
+    c.M_pilot = (int)od.M_pilot; c.M_data = (int)od.M_data; c.Nen = (int)od.Nen; c.M_S0 = (int)od.M_S0; c.M_S1 = (int)od.M_S1;
+    c.E = (int)pow2ceil((od.M + 63) / 64);
+    c.log2M = 0;
+    if ((od.M & (od.M - 1)) == 0) { unsigned l = 0; while ((1u << l) < od.M) l++; c.log2M = (int)l; }
+    c.detect_thresh = od.detect_thresh; c.sync_thresh = od.sync_thresh;
+    RC(q->upload(&c.sctype, od.p.data(), od.M));
+    RC(q->upload(&c.S0, od.S0.data(), od.M));
+    RC(q->upload(&c.S1, od.S1.data(), od.M));
+    RC(q->upload(&c.s0t, reinterpret_cast<const float2 *>(od.s0.data()), od.M));
+    RC(q->upload(&c.Ssm, od.Ssm.data(), od.Ssm.size()));
+    RC(q->upload(&c.Pfit, od.Pfit.data(), od.Pfit.size()));
+    std::vector<int16_t> dr(od.M), pr(od.M), er(od.M);
+    for (unsigned i = 0; i < od.M; i++) { dr[i] = (int16_t)od.data_rank[i]; pr[i] = (int16_t)od.pilot_rank[i]; er[i] = (int16_t)od.en_rank[i]; }
+    RC(q->upload(&c.data_rank, dr.data(), od.M));
+    RC(q->upload(&c.pilot_rank, pr.data(), od.M));
+    RC(q->upload(&c.en_rank, er.data(), od.M));
+    RC(q->upload(&c.pilot_seq, od.pilot_seq, 255));
+    std::vector<float2> tw(od.M);
+    for (unsigned k = 0; k < od.M; k++) {
+        double a = -2.0 * M_PI * (double)k / (double)od.M;
+        tw[k] = make_float2((float)cos(a), (float)sin(a));
+    }
+    RC(q->upload(&c.dft_tw, tw.data(), od.M));
+    RC(coding_tables(&c.cod));
+    c.max_payload_len = q->max_payload; c.max_enc_len = q->max_enc; c.max_syms = q->max_syms;
+    c.payload_soft = q->cfg.payload_soft ? 1 : 0;
+    return MCRX_OK;
+}
+
+// synchronizers back to SEEK, channelizer history cleared, undelivered device frames dropped
+static int restart_async(mcrx_hip_t q, hipStream_t st, bool from_zero)
+{
+    if (from_zero) { q->total_samples = 0; q->chan_samples = 0; }
+    q->stage_fill = 0; q->stage_first = q->total_samples;
+    HIPCHK(hipMemsetAsync(q->d_hist[0], 0, (size_t)HIST_BLOCKS * q->K * sizeof(float2), st));
+    HIPCHK(hipMemsetAsync(q->d_hist[1], 0, (size_t)HIST_BLOCKS * q->K * sizeof(float2), st));
+    q->hist_cur = 0;
+    HIPCHK(sync_reset_launch(q->d_st, q->nch, q->chan_samples, st));
+    HIPCHK(hipMemsetAsync(q->d_nrec, 0, 2 * sizeof(uint32_t), st));
+    HIPCHK(hipMemsetAsync(q->d_arena_used, 0, sizeof(unsigned long long), st));
+    return MCRX_OK;
+}
+
+extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned cp, unsigned taper,
+                               const unsigned char *p, const mcrx_hip_config *cfg)
+{
+    if (!out) return fail(MCRX_EINVAL, "null output handle");
+    *out = nullptr;
+    // argument checks of multichannelrx::multichannelrx (lib/multichannelrx.cc:54-66)
+    if (N < 1) return fail(MCRX_EINVAL, "error: multichannelrx, must have at least one channel");
+    if (M < 8) return fail(MCRX_EINVAL, "error: multichannelrx, number of subcarriers must be at least 8");
+    if (cp < 1) return fail(MCRX_EINVAL, "error: multichannelrx, cyclic prefix length must be at least 1");
+    if (taper > cp) return fail(MCRX_EINVAL, "error: multichannelrx, taper length cannot exceed cyclic prefix length");
+    if (!channelizer_supported(2 * N)) return fail(MCRX_EUNSUPP, "channelizer size 2N must be a power of two <= 1024");
+    if (M > 1024) return fail(MCRX_EUNSUPP, "at most 1024 subcarriers");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(MCRX_EHIP, "no HIP device: the MI355X kernels are the only implementation (no CPU fallback)");
+
+    mcrx_hip_t q = new mcrx_hip_s();
+    q->N = N; q->K = 2 * N; q->M = M; q->cp = cp; q->taper = taper;
+    if (q->od.init(M, cp, taper, p) != 0) { delete q; return fail(MCRX_EINVAL, "invalid subcarrier allocation"); }
+    if (cfg) memcpy(&q->cfg, cfg, std::min<size_t>(cfg->struct_size ? cfg->struct_size : sizeof(*cfg), sizeof(q->cfg)));
+    else q->cfg.payload_soft = 1;
+    q->max_payload = q->cfg.max_payload_len ? q->cfg.max_payload_len : 2048;
+    q->max_enc = 4 * (q->max_payload + 4) + 16;
+    if (q->max_enc < 64) q->max_enc = 64;
+    q->max_enc = (q->max_enc + 15) & ~15u;
+    q->max_syms = 8 * q->max_enc;
+    q->ch_first = q->cfg.channel_first;
+    q->nch = q->cfg.channel_count ? q->cfg.channel_count : N - q->ch_first;
+    if (q->ch_first + q->nch > N || q->nch == 0) { delete q; return fail(MCRX_EINVAL, "channel shard outside [0, N)"); }
+    q->max_rec = q->cfg.max_frames ? q->cfg.max_frames : 16 * q->nch + 64;
+    q->arena_cap = (uint64_t)q->max_rec * ((uint64_t)q->max_payload + 8ull * 4ull * (q->max_payload + 16));
+    if (q->arena_cap > (4ull << 30)) q->arena_cap = 4ull << 30;
+    q->slab_blocks = q->cfg.slab_blocks ? ((q->cfg.slab_blocks + 7) & ~7u) : 64;
+    q->taps = pfb_prototype(q->K, 7, 60.0f);
+    q->dtheta = channel_center_step(N);
+    q->hist_tiles = (M + cp + 8 + 7) / 8 + 1;
+
+    auto bail = [&](int rc) { mcrx_hip_destroy(q); return rc; };
+    int rc;
+    if ((rc = q->upload(&q->d_taps, q->taps.data(), q->taps.size()))) return bail(rc);
+    if ((rc = build_tables(q))) return bail(rc);
+    if ((rc = q->alloc(&q->d_st, q->nch))) return bail(rc);
+    if ((rc = q->alloc(&q->d_hbits, (size_t)q->nch * MCRX_HDR_SYMS))) return bail(rc);
+    if ((rc = q->alloc(&q->d_R, (size_t)q->nch * M))) return bail(rc);
+    if ((rc = q->alloc(&q->d_soft, (size_t)q->nch * 8 * q->max_enc))) return bail(rc);
+    if ((rc = q->alloc(&q->d_tmpa, (size_t)q->nch * (q->max_enc + 16)))) return bail(rc);
+    if ((rc = q->alloc(&q->d_tmpb, (size_t)q->nch * (q->max_enc + 16)))) return bail(rc);
+    if ((rc = q->alloc(&q->d_syms, (size_t)q->nch * q->max_syms))) return bail(rc);
+    if ((rc = q->alloc(&q->d_rec, q->max_rec))) return bail(rc);
+    if ((rc = q->alloc(&q->d_arena, q->arena_cap))) return bail(rc);
+    if ((rc = q->alloc(&q->d_nrec, 2))) return bail(rc);
+    if ((rc = q->alloc(&q->d_arena_used, 1))) return bail(rc);
+    if ((rc = q->alloc(&q->d_hist[0], (size_t)HIST_BLOCKS * q->K))) return bail(rc);
+    if ((rc = q->alloc(&q->d_hist[1], (size_t)HIST_BLOCKS * q->K))) return bail(rc);
+    // host staging for Execute(): whole tiles of 8 blocks
+    size_t tile_samples = (size_t)8 * q->K;
+    size_t want = q->cfg.batch_samples ? q->cfg.batch_samples : ((size_t)1 << 20);
+    q->stage_cap = std::max<size_t>(1, (want + tile_samples - 1) / tile_samples) * tile_samples;
+    if (hipHostMalloc((void **)&q->h_stage, q->stage_cap * sizeof(float2), hipHostMallocDefault) != hipSuccess)
+        return bail(fail(MCRX_ENOMEM, "pinned staging allocation failed"));
+    if ((rc = q->alloc(&q->d_in, q->stage_cap))) return bail(rc);
+    if (hipStreamCreate(&q->stream) != hipSuccess) return bail(fail(MCRX_EHIP, "hipStreamCreate failed"));
+    for (int i = 0; i < 4; i++) if (hipEventCreate(&q->ev[i]) != hipSuccess) return bail(fail(MCRX_EHIP, "hipEventCreate failed"));
+    if ((rc = restart_async(q, q->stream, true))) return bail(rc);
+    if (hipStreamSynchronize(q->stream) != hipSuccess) return bail(fail(MCRX_EHIP, "stream sync failed"));
+    *out = q;
+    return MCRX_OK;
+}
+
+extern "C" int mcrx_hip_destroy(mcrx_hip_t q)
+{
+    if (!q) return MCRX_OK;
+    hipDeviceSynchronize();
+    for (void *p : q->owned) hipFree(p);
+    for (int i = 0; i < 2; i++) if (q->d_chan[i]) hipFree(q->d_chan[i]);
+    if (q->h_stage) hipHostFree(q->h_stage);
+    for (int i = 0; i < 4; i++) if (q->ev[i]) hipEventDestroy(q->ev[i]);
+    if (q->stream) hipStreamDestroy(q->stream);
+    delete q;
+    return MCRX_OK;
+}
+
+extern "C" unsigned mcrx_hip_num_channels(mcrx_hip_t q) { return q ? q->N : 0; }
+extern "C" uint32_t mcrx_hip_nco_step(mcrx_hip_t q) { return q ? q->dtheta : 0; }
+extern "C" int mcrx_hip_get_taps(mcrx_hip_t q, float *h, size_t n)
+{
+    if (!q || !h || n < q->taps.size()) return fail(MCRX_EINVAL, "taps buffer too small");
+    memcpy(h, q->taps.data(), q->taps.size() * sizeof(float));
+    return MCRX_OK;
+}
+
+// ---------------------------------------------------------------- stage level
+static int launch_channelizer(mcrx_hip_t q, const float2 *x, size_t nblocks, uint64_t first_sample,
+                              const float2 *halo, float2 *out, unsigned groups, size_t ntiles_stride, hipStream_t st)
+{
+    if (nblocks == 0) return MCRX_OK;
+    if (nblocks % MCRX_TILE) return fail(MCRX_EINVAL, "nblocks must be a multiple of 8");
+    if (groups == 0 || q->N % groups) return fail(MCRX_EINVAL, "groups must divide the channel count");
+    ChanArgs a;
+    a.x = x; a.halo = halo; a.taps = q->d_taps; a.out = out;
+    a.nblocks = (uint32_t)nblocks; a.slab_blocks = q->slab_blocks;
+    a.first_sample_lo = (uint32_t)first_sample; a.dtheta = q->dtheta;
+    a.ntiles = (uint32_t)ntiles_stride; a.cg = q->N / groups;
+    HIPCHK(hipEventRecord(q->ev[0], st));
+    HIPCHK(channelizer_launch(q->K, a, st));
+    HIPCHK(hipEventRecord(q->ev[1], st));
+    q->ev_ch = true;
+    return MCRX_OK;
+}
+static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsigned off, int64_t buf_first, int64_t end, hipStream_t st)
+{
+    SyncArgs a;
+    a.c = q->sc; a.chan = chan; a.chan_stride = stride; a.chan_off = off;
+    a.buf_first = buf_first; a.end = end; a.nch = q->nch; a.ch_first = q->ch_first;
+    a.st = q->d_st; a.hbits = q->d_hbits; a.R = q->d_R; a.soft = q->d_soft; a.tmpa = q->d_tmpa; a.tmpb = q->d_tmpb;
+    a.syms = q->d_syms; a.rec = q->d_rec; a.arena = q->d_arena; a.nrec = q->d_nrec; a.arena_used = q->d_arena_used;
+    a.arena_cap = q->arena_cap; a.max_rec = q->max_rec;
+    HIPCHK(hipEventRecord(q->ev[2], st));
+    HIPCHK(sync_launch(a, st));
+    HIPCHK(hipEventRecord(q->ev[3], st));
+    q->ev_sy = true;
+    return MCRX_OK;
+}
+
+extern "C" int mcrx_hip_channelize(mcrx_hip_t q, const void *d_iq, size_t nblocks, uint64_t first_sample,
+                                   const void *d_halo, void *d_out, unsigned groups, void *stream)
+{
+    if (!q || !d_iq || !d_out) return fail(MCRX_EINVAL, "null argument");
+    hipStream_t st = stream ? (hipStream_t)stream : q->stream;
+    return launch_channelizer(q, (const float2 *)d_iq, nblocks, first_sample, (const float2 *)d_halo,
+                              (float2 *)d_out, groups, nblocks / MCRX_TILE, st);
+}
+extern "C" int mcrx_hip_sync(mcrx_hip_t q, const void *d_chan, uint64_t first_sample, size_t nsamples, void *stream)
+{
+    if (!q || !d_chan) return fail(MCRX_EINVAL, "null argument");
+    hipStream_t st = stream ? (hipStream_t)stream : q->stream;
+    return launch_sync(q, (const float2 *)d_chan, q->nch, 0, (int64_t)first_sample, (int64_t)(first_sample + nsamples), st);
+}
+extern "C" int mcrx_hip_restart(mcrx_hip_t q, void *stream)
+{
+    if (!q) return fail(MCRX_EINVAL, "null handle");
+    return restart_async(q, stream ? (hipStream_t)stream : q->stream, true);
+}
+extern "C" int mcrx_hip_kernel_time_ms(mcrx_hip_t q, float *ch_ms, float *sy_ms)
+{
+    if (!q) return fail(MCRX_EINVAL, "null handle");
+    if (ch_ms) { *ch_ms = 0; if (q->ev_ch) { HIPCHK(hipEventSynchronize(q->ev[1])); HIPCHK(hipEventElapsedTime(ch_ms, q->ev[0], q->ev[1])); } }
+    if (sy_ms) { *sy_ms = 0; if (q->ev_sy) { HIPCHK(hipEventSynchronize(q->ev[3])); HIPCHK(hipEventElapsedTime(sy_ms, q->ev[2], q->ev[3])); } }
+    return MCRX_OK;
+}
+
+// ---------------------------------------------------------------- streaming Execute()
+static int ensure_chan(mcrx_hip_t q, size_t tiles)
+{
+    if (tiles <= q->chan_cap_tiles) return MCRX_OK;
+    float2 *nb[2] = { nullptr, nullptr };
+    size_t n = tiles * (size_t)q->N * MCRX_TILE;
+    for (int i = 0; i < 2; i++) {
+        HIPCHK(hipMalloc((void **)&nb[i], n * sizeof(float2)));
+        HIPCHK(hipMemsetAsync(nb[i], 0, n * sizeof(float2), q->stream));
+    }
+    if (q->d_chan[q->chan_cur])         // keep the history tiles of the live buffer
+        HIPCHK(hipMemcpyAsync(nb[0], q->d_chan[q->chan_cur], (size_t)q->hist_tiles * q->N * MCRX_TILE * sizeof(float2),
+                              hipMemcpyDeviceToDevice, q->stream));
+    HIPCHK(hipStreamSynchronize(q->stream));
+    for (int i = 0; i < 2; i++) if (q->d_chan[i]) hipFree(q->d_chan[i]);
+    q->d_chan[0] = nb[0]; q->d_chan[1] = nb[1]; q->chan_cur = 0; q->chan_cap_tiles = tiles;
+    return MCRX_OK;
+}
+
+// channelize + synchronize `nblocks` (multiple of 8) blocks sitting in device memory
+static int run_blocks(mcrx_hip_t q, const float2 *x, size_t nblocks, uint64_t first_abs, hipStream_t st)
+{
+    if (nblocks == 0) return MCRX_OK;
+    const size_t ntiles = nblocks / MCRX_TILE;
+    RC(ensure_chan(q, q->hist_tiles + ntiles));
+    float2 *buf = q->d_chan[q->chan_cur];
+    const size_t tile_elems = (size_t)q->N * MCRX_TILE;
+    RC(launch_channelizer(q, x, nblocks, first_abs, q->d_hist[q->hist_cur], buf + q->hist_tiles * tile_elems, 1, ntiles, st));
+    const int64_t buf_first = q->chan_samples - (int64_t)q->hist_tiles * MCRX_TILE;
+    RC(launch_sync(q, buf, q->N, q->ch_first, buf_first, q->chan_samples + (int64_t)nblocks, st));
+    // FIR history: last 13 blocks of (history, x)
+    const uint64_t nh = (uint64_t)HIST_BLOCKS * q->K;
+    hipLaunchKernelGGL(hist_update_kernel, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, st,
+                       q->d_hist[q->hist_cur], x, (uint64_t)nblocks * q->K, q->d_hist[1 - q->hist_cur], nh);
+    HIPCHK(hipGetLastError());
+    q->hist_cur ^= 1;
+    // synchronizer history: last hist_tiles tiles move to the front of the other buffer
+    HIPCHK(hipMemcpyAsync(q->d_chan[1 - q->chan_cur], buf + ntiles * tile_elems,
+                          (size_t)q->hist_tiles * tile_elems * sizeof(float2), hipMemcpyDeviceToDevice, st));
+    q->chan_cur ^= 1;
+    q->chan_samples += (int64_t)nblocks;
+    return MCRX_OK;
+}
+
+static int process_staged(mcrx_hip_t q)
+{
+    const size_t tile_samples = (size_t)8 * q->K;
+    const size_t n = (q->stage_fill / tile_samples) * tile_samples;
+    if (n == 0) return MCRX_OK;
+    HIPCHK(hipMemcpyAsync(q->d_in, q->h_stage, n * sizeof(float2), hipMemcpyHostToDevice, q->stream));
+    RC(run_blocks(q, q->d_in, n / q->K, q->stage_first, q->stream));
+    HIPCHK(hipStreamSynchronize(q->stream));        // staging buffers are reused
+    const size_t rest = q->stage_fill - n;
+    if (rest) memmove(q->h_stage, q->h_stage + n, rest * sizeof(float2));
+    q->stage_fill = rest; q->stage_first += n;
+    return MCRX_OK;
+}
+
+extern "C" int mcrx_hip_execute_host(mcrx_hip_t q, const float *iq, size_t nsamples)
+{
+    if (!q || (!iq && nsamples)) return fail(MCRX_EINVAL, "null argument");
+    const float2 *src = reinterpret_cast<const float2 *>(iq);
+    while (nsamples) {
+        const size_t take = std::min(nsamples, q->stage_cap - q->stage_fill);
+        memcpy(q->h_stage + q->stage_fill, src, take * sizeof(float2));
+        q->stage_fill += take; q->total_samples += take; src += take; nsamples -= take;
+        if (q->stage_fill == q->stage_cap) RC(process_staged(q));
+    }
+    return MCRX_OK;
+}
+
+extern "C" int mcrx_hip_execute_device(mcrx_hip_t q, const void *d_iq, size_t nsamples, void *stream)
+{
+    if (!q || (!d_iq && nsamples)) return fail(MCRX_EINVAL, "null argument");
+    if (q->stage_fill) return fail(MCRX_EINVAL, "host samples are still staged: flush before pushing device buffers");
+    if (nsamples % ((size_t)8 * q->K)) return fail(MCRX_EINVAL, "device pushes must be whole tiles of 8 blocks (16*N samples)");
+    hipStream_t st = stream ? (hipStream_t)stream : q->stream;
+    RC(run_blocks(q, (const float2 *)d_iq, nsamples / q->K, q->total_samples, st));
+    q->total_samples += nsamples; q->stage_first = q->total_samples;
+    return MCRX_OK;
+}
+
+// ---------------------------------------------------------------- frames
+static int harvest(mcrx_hip_t q)
+{
+    HIPCHK(hipDeviceSynchronize());
+    uint32_t cnt[2] = { 0, 0 }; unsigned long long used = 0;
+    HIPCHK(hipMemcpy(cnt, q->d_nrec, sizeof(cnt), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&used, q->d_arena_used, sizeof(used), hipMemcpyDeviceToHost));
+    q->dropped += cnt[1];
+    const uint32_t n = std::min(cnt[0], q->max_rec);
+    if (used > q->arena_cap) used = q->arena_cap;
+    if (n) {
+        // drop frames already delivered, then append
+        if (q->next_frame == q->recs.size()) { q->recs.clear(); q->arena_host.clear(); q->next_frame = 0; }
+        const size_t base = q->arena_host.size(), r0 = q->recs.size();
+        q->recs.resize(r0 + n);
+        HIPCHK(hipMemcpy(q->recs.data() + r0, q->d_rec, (size_t)n * sizeof(FrameRec), hipMemcpyDeviceToHost));
+        q->arena_host.resize(base + (size_t)used);
+        if (used) HIPCHK(hipMemcpy(q->arena_host.data() + base, q->d_arena, (size_t)used, hipMemcpyDeviceToHost));
+        for (size_t i = r0; i < r0 + n; i++) { q->recs[i].payload_off += base; q->recs[i].syms_off += base; }
+        // reference order: by end time, then channel index (lib/multichannelrx.cc:193-194)
+        std::stable_sort(q->recs.begin() + r0, q->recs.end(), [](const FrameRec &a, const FrameRec &b) {
+            return a.end_sample != b.end_sample ? a.end_sample < b.end_sample : a.channel < b.channel; });
+    }
+    HIPCHK(hipMemset(q->d_nrec, 0, 2 * sizeof(uint32_t)));
+    HIPCHK(hipMemset(q->d_arena_used, 0, sizeof(unsigned long long)));
+    return cnt[1] ? MCRX_EOVERFLOW : MCRX_OK;
+}
+
+extern "C" int mcrx_hip_flush(mcrx_hip_t q)
+{
+    if (!q) return fail(MCRX_EINVAL, "null handle");
+    RC(process_staged(q));
+    return harvest(q);
+}
+extern "C" size_t mcrx_hip_frames_pending(mcrx_hip_t q) { return q ? q->recs.size() - q->next_frame : 0; }
+extern "C" uint64_t mcrx_hip_frames_dropped(mcrx_hip_t q) { return q ? q->dropped : 0; }
+extern "C" int mcrx_hip_next_frame(mcrx_hip_t q, mcrx_frame *out)
+{
+    if (!q || !out) return fail(MCRX_EINVAL, "null argument");
+    if (q->next_frame >= q->recs.size()) return 0;
+    const FrameRec &r = q->recs[q->next_frame++];
+    out->channel = r.channel; out->header_valid = r.header_valid; out->payload_valid = r.payload_valid;
+    out->payload_len = r.payload_len; memcpy(out->header, r.header, 8);
+    out->evm = r.evm; out->rssi = r.rssi; out->cfo = r.cfo;
+    out->mod_scheme = r.mod_scheme; out->mod_bps = r.mod_bps; out->check = r.check; out->fec0 = r.fec0; out->fec1 = r.fec1;
+    out->num_framesyms = r.num_framesyms; out->end_sample = (uint64_t)r.end_sample;
+    out->payload = r.payload_len ? q->arena_host.data() + r.payload_off : nullptr;
+    out->framesyms = r.num_framesyms ? reinterpret_cast<const float *>(q->arena_host.data() + r.syms_off) : nullptr;
+    return 1;
+}
+
+extern "C" int mcrx_hip_reset(mcrx_hip_t q)
+{
+    // multichannelrx::Reset (lib/multichannelrx.cc:135-153): synchronizers and channelizer windows
+    // reset, partial block dropped, NCO keeps running.  Frames decoded so far stay deliverable.
+    if (!q) return fail(MCRX_EINVAL, "null handle");
+    int rc = harvest(q);
+    if (rc != MCRX_OK && rc != MCRX_EOVERFLOW) return rc;
+    RC(restart_async(q, q->stream, false));
+    HIPCHK(hipStreamSynchronize(q->stream));
+    return MCRX_OK;
+}

@@ -1,0 +1,808 @@
+// ofdmsync.hip -- bank of OFDM flexible-frame synchronizers for gfx950, one wavefront
+// per channel.
+//
+// Replaces the reference's per-channel call
+//   ofdmflexframesync_execute(framesync[i], &X[i], 1)      (lib/multichannelrx.cc:193-194)
+// i.e. liquid's ofdmframesync state machine (seek S0 -> S0a -> S0b -> S1 -> symbols) plus
+// ofdmflexframesync's header / payload recovery (BPSK header, Golay(24,12) + CRC-32;
+// payload demodulated soft, de-interleaved, FEC decoded, CRC checked).
+//
+// The reference pushes one sample per call into a sample-serial state machine.  Here each
+// wavefront walks its channel's stream event by event: the sample index of the next
+// state-machine event is known in closed form from the timer, the (M+cp)-sample window is
+// read straight from the channelizer's (channel, tile) granules in HBM, the NCO phase of
+// every window sample is the exact 32-bit closed form theta_ref + (t - t_ref) * dtheta,
+// the M-point FFT runs across the 64 lanes (shuffle butterflies, bit-reversed subcarrier
+// per lane; direct DFT for M that are not powers of two), and the per-symbol pilot fit,
+// equalisation and soft demodulation are lane-parallel with wave reductions.  State lives
+// in HBM between launches so Execute() can be fed arbitrary pieces.
+#include "devmath.h"
+#include "kernels.h"
+
+namespace mcrx {
+
+#define WV 64
+#define TWO_PI_F 6.283185307179586f
+#define PI_F 3.14159265358979323846f
+
+// ------------------------------------------------------------------ small utilities
+__device__ __forceinline__ uint32_t wave_xor_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v ^= (uint32_t)__shfl_xor((int)v, o, WV);
+    return v;
+}
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+__device__ __forceinline__ unsigned fec_enc_len_d(unsigned fs, unsigned n)
+{
+    if (fs == 6) return (n / 2) * 3 + (n % 2) * 2;      // Hamming(12,8)
+    if (fs == 7) return (n / 3) * 6 + (n % 3) * 3;      // Golay(24,12)
+    return n;
+}
+__device__ __forceinline__ unsigned mod_bps_d(unsigned m)
+{ return m == 39 ? 1u : m == 40 ? 2u : m == 27 ? 4u : m == 29 ? 6u : 0u; }
+
+// ------------------------------------------------------------------ CRC-32, lane parallel
+__device__ uint32_t crc32_wave(const CodingDev &cod, const uint8_t *p, uint32_t n)
+{
+    const int l = lane_id();
+    const uint32_t Lc = (n + WV - 1) / WV;
+    uint32_t start = (uint32_t)l * Lc, stop = start + Lc;
+    if (start > n) start = n;
+    if (stop > n) stop = n;
+    uint32_t s = (l == 0) ? 0xFFFFFFFFu : 0u;
+    for (uint32_t i = start; i < stop; i++) s = (s >> 8) ^ cod.crc_byte[(s ^ p[i]) & 0xff];
+    uint32_t z = n - stop;                      // bytes that follow my chunk
+    for (int k = 0; z; k++, z >>= 1) {
+        if (z & 1) {
+            const uint32_t *A = cod.crc_zadv + (size_t)k * 1024;
+            s = A[s & 0xff] ^ A[256 + ((s >> 8) & 0xff)] ^ A[512 + ((s >> 16) & 0xff)] ^ A[768 + (s >> 24)];
+        }
+    }
+    return ~wave_xor_u32(s);
+}
+
+// ------------------------------------------------------------------ interleaver (inverse)
+__device__ __forceinline__ void il_dims(unsigned n, unsigned &Mi, unsigned &Ni)
+{
+    Mi = 1 + (unsigned)floorf(sqrtf((float)n));
+    Ni = n / Mi;
+    while (n >= Mi * Ni) Ni++;
+}
+// one pass: for the i-th valid cell j of the column walk swap masked bits of x[2i], x[2j+1].
+// SOFT: elements are groups of 8 soft bits (uint64), the mask selects whole bytes.
+template <bool SOFT>
+__device__ void il_pass(uint8_t *x, unsigned n, unsigned Mi, unsigned Ncol, unsigned mask)
+{
+    const int l = lane_id();
+    const unsigned n2 = n / 2, total = Mi * Ncol, c0 = n / 3;
+    unsigned long long m64 = 0;
+    if (SOFT) for (int k = 0; k < 8; k++) if ((mask >> (7 - k)) & 1) m64 |= 0xFFull << (8 * k);
+    unsigned base = 0;
+    for (unsigned q0 = 0; q0 < total && base < n2; q0 += WV) {
+        unsigned q = q0 + (unsigned)l;
+        unsigned m = q % Mi, c = (c0 + q / Mi) % Ncol;
+        unsigned j = m * Ncol + c;
+        bool valid = (q < total) && (j < n2);
+        unsigned long long bal = __ballot(valid);
+        unsigned i = base + (unsigned)__popcll(bal & ((1ull << l) - 1ull));
+        if (valid && i < n2) {
+            if (SOFT) {
+                unsigned long long *pa = reinterpret_cast<unsigned long long *>(x) + 2 * i;
+                unsigned long long *pb = reinterpret_cast<unsigned long long *>(x) + (2 * j + 1);
+                unsigned long long a = *pa, b = *pb;
+                *pa = (a & ~m64) | (b & m64);
+                *pb = (b & ~m64) | (a & m64);
+            } else {
+                unsigned a = x[2 * i], b = x[2 * j + 1];
+                x[2 * i]     = (uint8_t)((a & ~mask) | (b & mask));
+                x[2 * j + 1] = (uint8_t)((b & ~mask) | (a & mask));
+            }
+        }
+        base += (unsigned)__popcll(bal);
+    }
+    __syncthreads();
+}
+template <bool SOFT>
+__device__ void deinterleave(uint8_t *x, unsigned n, unsigned depth)
+{
+    unsigned Mi, Ni; il_dims(n, Mi, Ni);
+    if (depth > 3) il_pass<SOFT>(x, n, Mi, Ni + 8, 0x33);
+    if (depth > 2) il_pass<SOFT>(x, n, Mi, Ni + 4, 0x55);
+    if (depth > 1) il_pass<SOFT>(x, n, Mi, Ni + 2, 0x0f);
+    if (depth > 0) il_pass<SOFT>(x, n, Mi, Ni, 0xff);
+}
+
+// ------------------------------------------------------------------ block codes
+__device__ __forceinline__ unsigned par_d(unsigned v) { return (unsigned)__popc(v) & 1u; }
+__device__ __forceinline__ unsigned h128_dec_sym(unsigned c)
+{
+    unsigned z = (par_d(c & 0x01f) << 3) | (par_d(c & 0x1e1) << 2) | (par_d(c & 0x666) << 1) | par_d(c & 0xaaa);
+    if (z && z <= 12) c ^= 1u << (12 - z);
+    return (c & 0x00f) | ((c & 0x0e0) >> 1) | ((c & 0x200) >> 2);
+}
+__device__ unsigned h128_dec_soft_sym(const CodingDev &cod, const uint8_t *soft)
+{
+    unsigned sb[12], c = 0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) { sb[k] = soft[k]; c = (c << 1) | (sb[k] > 127 ? 1u : 0u); }
+    auto dist = [&](unsigned cw) {
+        unsigned d = 0;
+#pragma unroll
+        for (int k = 0; k < 12; k++) d += ((cw >> (11 - k)) & 1) ? 255u - sb[k] : sb[k];
+        return d;
+    };
+    unsigned s0 = h128_dec_sym(c), s_hat = s0;
+    unsigned dmin = dist(cod.h128_enc[s0]);
+    unsigned nnb = cod.h128_nnb[s0];
+    for (unsigned i = 0; i < nnb; i++) {
+        unsigned t = cod.h128_nb[s0 * MCRX_H128_NBD + i];
+        unsigned d = dist(cod.h128_enc[t]);
+        if (d < dmin) { dmin = d; s_hat = t; }
+    }
+    return s_hat;
+}
+__device__ __forceinline__ unsigned golay_mulP(unsigned v)
+{
+    const unsigned P[12] = { 0x08ed, 0x01db, 0x03b5, 0x0769, 0x0ed1, 0x0da3, 0x0b47, 0x068f, 0x0d1d, 0x0a3b, 0x0477, 0x0ffe };
+    unsigned y = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) if (v & (1u << (11 - i))) y ^= P[i];
+    return y;
+}
+__device__ unsigned golay_dec_sym(unsigned r)
+{
+    const unsigned P[12] = { 0x08ed, 0x01db, 0x03b5, 0x0769, 0x0ed1, 0x0da3, 0x0b47, 0x068f, 0x0d1d, 0x0a3b, 0x0477, 0x0ffe };
+    unsigned rp = (r >> 12) & 0xfff, rm = r & 0xfff;
+    unsigned s = rp ^ golay_mulP(rm), em = 0;
+    bool found = __popc(s) <= 3;
+    if (!found) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) if (!found && __popc(s ^ P[i]) <= 2) { em = 1u << (11 - i); found = true; }
+    }
+    if (!found) {
+        unsigned sP = golay_mulP(s);
+        if (__popc(sP) <= 3) { em = sP; found = true; }
+        else {
+#pragma unroll
+            for (int i = 0; i < 12; i++) if (!found && __popc(sP ^ P[i]) <= 2) { em = sP ^ P[i]; found = true; }
+        }
+    }
+    return (rm ^ em) & 0xfff;
+}
+
+// hard decode `enc` -> `dec` (dec_len bytes), lanes in parallel
+__device__ void fec_decode_hard(unsigned fs, unsigned n, const uint8_t *enc, uint8_t *dec)
+{
+    const int l = lane_id();
+    if (fs == 6) {
+        for (unsigned i = (unsigned)l; i < n; i += WV) {
+            unsigned o = 3 * (i / 2), m;
+            if ((i & 1) == 0) m = ((unsigned)enc[o] << 4) | ((unsigned)enc[o + 1] >> 4);
+            else              m = (((unsigned)enc[o + 1] & 0x0f) << 8) | (unsigned)enc[o + 2];
+            dec[i] = (uint8_t)h128_dec_sym(m);
+        }
+    } else if (fs == 7) {
+        const unsigned G = n / 3, r = n % 3;
+        for (unsigned g = (unsigned)l; g < G; g += WV) {
+            const uint8_t *e = enc + 6 * g;
+            unsigned s0 = golay_dec_sym(((unsigned)e[0] << 16) | ((unsigned)e[1] << 8) | e[2]);
+            unsigned s1 = golay_dec_sym(((unsigned)e[3] << 16) | ((unsigned)e[4] << 8) | e[5]);
+            dec[3 * g]     = (uint8_t)((s0 >> 4) & 0xff);
+            dec[3 * g + 1] = (uint8_t)(((s0 << 4) & 0xf0) | ((s1 >> 8) & 0x0f));
+            dec[3 * g + 2] = (uint8_t)(s1 & 0xff);
+        }
+        if ((unsigned)l < r) {
+            const uint8_t *e = enc + 6 * G + 3 * l;
+            dec[3 * G + l] = (uint8_t)(golay_dec_sym(((unsigned)e[0] << 16) | ((unsigned)e[1] << 8) | e[2]) & 0xff);
+        }
+    } else {
+        for (unsigned i = (unsigned)l; i < n; i += WV) dec[i] = enc[i];
+    }
+    __syncthreads();
+}
+// slice 8 soft bits per byte at 127 and pack MSB first
+__device__ void soft_pack(const uint8_t *soft, unsigned nbytes, uint8_t *out, bool unscramble)
+{
+    const int l = lane_id();
+    for (unsigned i = (unsigned)l; i < nbytes; i += WV) {
+        unsigned long long w = *reinterpret_cast<const unsigned long long *>(soft + 8 * (size_t)i);
+        unsigned b = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) b = (b << 1) | ((((unsigned)(w >> (8 * k)) & 0xff) > 127) ? 1u : 0u);
+        if (unscramble) { const unsigned msk[4] = { 0xb4, 0x6a, 0x8b, 0xc5 }; b ^= msk[i & 3]; }
+        out[i] = (uint8_t)b;
+    }
+    __syncthreads();
+}
+
+// CRC -> fec0 -> il -> fec1 -> il, inverted.  `soft` holds 8 soft bits per packet byte
+// (8-byte aligned).  Result message in tmpb[0..n_msg); returns validity.
+__device__ bool packet_decode(const CodingDev &cod, bool soft_mode, bool scrambled, unsigned n_msg,
+                              unsigned crc, unsigned fec0, unsigned fec1,
+                              uint8_t *soft, uint8_t *tmpa, uint8_t *tmpb)
+{
+    const int l = lane_id();
+    const unsigned crc_len = (crc == 6) ? 4u : 0u;
+    const unsigned n0 = n_msg + crc_len;
+    const unsigned e0 = fec_enc_len_d(fec0, n0), e1 = fec_enc_len_d(fec1, e0);
+    const unsigned d0 = (fec0 == 6 || fec0 == 7) ? 4u : 0u, d1 = (fec1 == 6 || fec1 == 7) ? 4u : 0u;
+    if (soft_mode && fec1 == 6) {
+        deinterleave<true>(soft, e1, d1);
+        for (unsigned i = (unsigned)l; i < e0; i += WV) tmpa[i] = (uint8_t)h128_dec_soft_sym(cod, soft + 12 * (size_t)i);
+        __syncthreads();
+    } else {
+        if (soft_mode) deinterleave<true>(soft, e1, d1);
+        soft_pack(soft, e1, tmpb, scrambled);
+        if (!soft_mode) deinterleave<false>(tmpb, e1, d1);
+        fec_decode_hard(fec1, e0, tmpb, tmpa);
+    }
+    deinterleave<false>(tmpa, e0, d0);
+    fec_decode_hard(fec0, n0, tmpa, tmpb);
+    if (crc_len == 0) return true;
+    uint32_t key = ((uint32_t)tmpb[n_msg] << 24) | ((uint32_t)tmpb[n_msg + 1] << 16) |
+                   ((uint32_t)tmpb[n_msg + 2] << 8) | (uint32_t)tmpb[n_msg + 3];
+    return crc32_wave(cod, tmpb, n_msg) == key;
+}
+
+// ------------------------------------------------------------------ modem
+__device__ __forceinline__ unsigned gray_dec_d(unsigned x) { unsigned y = x; while (x >>= 1) y ^= x; return y; }
+__device__ __forceinline__ cfd qam_point(unsigned sym, unsigned mq, float alpha)
+{
+    int L = 1 << mq;
+    int gi = 2 * (int)gray_dec_d(sym >> mq) - L + 1, gq = 2 * (int)gray_dec_d(sym & (unsigned)(L - 1)) - L + 1;
+    return make_float2((float)gi * alpha, (float)gq * alpha);
+}
+__device__ __forceinline__ unsigned qam_slice(float v, unsigned b, float alpha)
+{
+    unsigned s = 0;
+    for (unsigned k = b; k > 0; k--) {
+        float ref = (float)(1u << (k - 1)) * alpha;
+        s <<= 1;
+        if (v > 0) { s |= 1; v -= ref; } else v += ref;
+    }
+    return s;
+}
+__device__ __forceinline__ uint8_t soft_clamp(float v)
+{ int sb = (int)v; sb = sb > 255 ? 255 : sb; sb = sb < 0 ? 0 : sb; return (uint8_t)sb; }
+
+// soft demodulate r; writes bps soft bits (MSB first), returns hard symbol
+__device__ unsigned demod_soft(const CodingDev &cod, unsigned mod, cfd r, uint8_t *soft)
+{
+    if (mod == 39) {
+        soft[0] = soft_clamp((-2.0f * r.x * 4.0f) * 16.0f + 127.0f);
+        return r.x > 0 ? 0u : 1u;
+    }
+    if (mod == 40) {
+        soft[0] = soft_clamp((-2.0f * r.y * 5.8f) * 16.0f + 127.0f);
+        soft[1] = soft_clamp((-2.0f * r.x * 5.8f) * 16.0f + 127.0f);
+        return (r.x > 0 ? 0u : 1u) + (r.y > 0 ? 0u : 2u);
+    }
+    const unsigned bps = (mod == 27) ? 4u : 6u, mq = bps / 2;
+    const float alpha = (mod == 27) ? 0.31622776601683794f : 0.1543033499620919f;
+    const uint8_t *nbt = (mod == 27) ? cod.qam16_nb : cod.qam64_nb;
+    unsigned si = qam_slice(r.x, mq, alpha), sq = qam_slice(r.y, mq, alpha);
+    unsigned s = ((si ^ (si >> 1)) << mq) + (sq ^ (sq >> 1));
+    const float gamma = 1.2f * (float)(1u << bps);
+    float dmin0[6], dmin1[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) { dmin0[k] = 8.0f; dmin1[k] = 8.0f; }
+    cfd xh = qam_point(s, mq, alpha);
+    float dr = r.x - xh.x, di = r.y - xh.y, d = dr * dr + di * di;
+#pragma unroll
+    for (int k = 0; k < 6; k++) if ((unsigned)k < bps) { if ((s >> (bps - k - 1)) & 1) dmin1[k] = d; else dmin0[k] = d; }
+    for (int i = 0; i < 4; i++) {
+        unsigned nb = nbt[s * 4 + i];
+        xh = qam_point(nb, mq, alpha);
+        dr = r.x - xh.x; di = r.y - xh.y; d = dr * dr + di * di;
+#pragma unroll
+        for (int k = 0; k < 6; k++) if ((unsigned)k < bps) {
+            if ((nb >> (bps - k - 1)) & 1) { if (d < dmin1[k]) dmin1[k] = d; }
+            else                           { if (d < dmin0[k]) dmin0[k] = d; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) if ((unsigned)k < bps) soft[k] = soft_clamp(((dmin0[k] - dmin1[k]) * gamma) * 16.0f + 127.0f);
+    return s;
+}
+
+// ------------------------------------------------------------------ the walker
+template <int E>
+struct Walker {
+    const SyncArgs &a;
+    const SyncConsts &c;
+    const int l;                // lane
+    const uint32_t ch;          // channel within shard
+    float2 *ldsc;               // [M] complex scratch
+    float *ldsf;                // [2*M] float scratch
+    ChanState s;                // working copy of the channel state (wave uniform)
+    // per (lane, e) constants
+    int k[E];                   // subcarrier held after the FFT (-1: none)
+    uint8_t sct[E];
+    float S0v[E], S1v[E], fx[E];
+    int drank[E], prank[E], erank[E];
+    float2 R[E];
+    float2 twx[6];              // cross-lane stage twiddles, stage h = 32 >> s
+
+    __device__ Walker(const SyncArgs &a_, uint32_t ch_, float2 *lc, float *lf)
+        : a(a_), c(a_.c), l(lane_id()), ch(ch_), ldsc(lc), ldsf(lf) {}
+
+    __device__ __forceinline__ float2 sample(int64_t t) const
+    {
+        if (t < 0 || t < a.buf_first) return make_float2(0.f, 0.f);
+        const int64_t r = t - a.buf_first;
+        return a.chan[((size_t)(r >> 3) * a.chan_stride + a.chan_off + ch) * MCRX_TILE_S + (size_t)(r & 7)];
+    }
+    __device__ __forceinline__ float2 mixed(int64_t t) const
+    {
+        float2 v = sample(t);
+        if (t >= s.nco_t_ref) v = mix_down(v, s.nco_theta_ref + (uint32_t)(t - s.nco_t_ref) * s.nco_dtheta);
+        return v;
+    }
+    __device__ void init_consts()
+    {
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int i = l + WV * e;
+            int kk = -1;
+            if (i < c.M) kk = c.log2M ? (int)(__brev((unsigned)i) >> (32 - c.log2M)) : i;
+            k[e] = kk;
+            const int kq = kk < 0 ? 0 : kk;
+            sct[e] = kk < 0 ? (uint8_t)0 : c.sctype[kq];
+            S0v[e] = kk < 0 ? 0.f : c.S0[kq];
+            S1v[e] = kk < 0 ? 0.f : c.S1[kq];
+            drank[e] = kk < 0 ? -1 : c.data_rank[kq];
+            prank[e] = kk < 0 ? -1 : c.pilot_rank[kq];
+            erank[e] = kk < 0 ? -1 : c.en_rank[kq];
+            fx[e] = (kq > c.M2) ? (float)kq - (float)c.M : (float)kq;
+            R[e] = kk < 0 ? make_float2(0.f, 0.f) : a.R[(size_t)ch * c.M + kq];
+        }
+#pragma unroll
+        for (int st = 0; st < 6; st++) {
+            const int h = 32 >> st;
+            float sn, cs; sincos_u32((uint32_t)(l & (h - 1)) * (uint32_t)(0x80000000u / (unsigned)h), sn, cs);
+            twx[st] = make_float2(cs, -sn);
+        }
+    }
+    // forward DFT of x (time position i = l + 64 e) -> X[k[e]]
+    __device__ void fft(float2 (&x)[E])
+    {
+        if (c.log2M) {
+#pragma unroll
+            for (int j = E / 2; j >= 1; j >>= 1) {             // in-lane stages, h = 64 j
+#pragma unroll
+                for (int e = 0; e < E; e++) if ((e & j) == 0) {
+                    float2 u = x[e], v = x[e + j];
+                    const int h = WV * j;
+                    float sn, cs; sincos_u32((uint32_t)((l + WV * e) & (h - 1)) * (uint32_t)(0x80000000u / (unsigned)h), sn, cs);
+                    x[e] = cadd(u, v);
+                    x[e + j] = cmul(csub(u, v), make_float2(cs, -sn));
+                }
+            }
+#pragma unroll
+            for (int st = 0; st < 6; st++) {
+                const int h = 32 >> st;
+                if (h < c.M) {
+                    const bool up = (l & h) != 0;
+#pragma unroll
+                    for (int e = 0; e < E; e++) {
+                        float2 p = make_float2(__shfl_xor(x[e].x, h, WV), __shfl_xor(x[e].y, h, WV));
+                        x[e] = up ? cmul(csub(p, x[e]), twx[st]) : cadd(x[e], p);
+                    }
+                }
+            }
+        } else {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < E; e++) { const int i = l + WV * e; if (i < c.M) ldsc[i] = x[e]; }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                float2 acc = make_float2(0.f, 0.f);
+                if (k[e] >= 0) {
+                    int idx = 0;
+                    for (int n = 0; n < c.M; n++) {
+                        acc = cadd(acc, cmul(ldsc[n], c.dft_tw[idx]));
+                        idx += k[e]; if (idx >= c.M) idx -= c.M;
+                    }
+                }
+                x[e] = acc;
+            }
+            __syncthreads();
+        }
+    }
+    __device__ void load_window(int64_t t_start, bool mix, float2 (&x)[E])
+    {
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int i = l + WV * e;
+            x[e] = (i < c.M) ? (mix ? mixed(t_start + i) : sample(t_start + i)) : make_float2(0.f, 0.f);
+        }
+    }
+    // S0 gain estimate + metric on the newest M samples ending at t_ev; returns s_hat (not scaled by g)
+    __device__ float2 s0_metric(int64_t t_ev, bool mix, float &power)
+    {
+        float2 x[E];
+        load_window(t_ev - c.M + 1, mix, x);
+        float pw = 0.f;
+#pragma unroll
+        for (int e = 0; e < E; e++) pw += x[e].x * x[e].x + x[e].y * x[e].y;
+        power = wave_sum(pw);
+        fft(x);
+        const float gain = sqrtf((float)c.M_S0) / (float)c.M;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; e++) if (k[e] >= 0) { x[e] = cscale(x[e], S0v[e] * gain); ldsc[k[e]] = x[e]; }
+        __syncthreads();
+        float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int e = 0; e < E; e++) if (k[e] >= 0 && (k[e] & 1) == 0) {
+            int kn = k[e] + 2; if (kn >= c.M) kn -= c.M;
+            acc = cadd(acc, cmulc(ldsc[kn], x[e]));
+        }
+        acc = wave_csum(acc);
+        __syncthreads();
+        return cscale(acc, 1.0f / (float)c.M_S0);
+    }
+    __device__ __forceinline__ unsigned hbyte(int i) const { return (s.hw[i >> 2] >> (8 * (i & 3))) & 0xffu; }
+    __device__ void reset_framesync()
+    {
+        s.state = SY_SEEK; s.timer = 0; s.num_symbols = 0; s.pilot_count = 0;
+        s.nco_theta_ref = 0; s.nco_dtheta = 0; s.nco_t_ref = 0;
+        s.s_hat_0 = make_float2(0.f, 0.f); s.phi_prime = 0.f; s.p1_prime = 0.f;
+        s.fstate = FX_HEADER; s.header_symbol_index = 0; s.payload_symbol_index = 0; s.evm_hat = 0.f;
+    }
+
+    __device__ void emit(int64_t t_ev, bool with_payload, bool payload_valid, bool oversize = false)
+    {
+        const uint32_t nsym = (with_payload && !oversize) ? s.mod_len : 0u;
+        const uint32_t plen = (with_payload && !oversize) ? s.payload_len : 0u;
+        const unsigned long long pbytes = ((unsigned long long)plen + 15ull) & ~15ull;
+        const unsigned long long need = pbytes + 8ull * nsym;
+        uint32_t idx = 0xFFFFFFFFu; unsigned long long off = 0;
+        if (l == 0) {
+            off = atomicAdd(a.arena_used, need);
+            if (off + need <= a.arena_cap) idx = atomicAdd(a.nrec, 1u);
+            if (idx >= a.max_rec) { atomicAdd(a.nrec + 1, 1u); idx = 0xFFFFFFFFu; }
+        }
+        idx = (uint32_t)__shfl((int)idx, 0, WV);
+        off = (unsigned long long)__shfl((long long)off, 0, WV);
+        if (idx == 0xFFFFFFFFu) return;
+        if (l == 0) {
+            FrameRec r;
+            r.channel = a.ch_first + ch; r.header_valid = s.header_valid; r.payload_valid = payload_valid ? 1 : 0;
+            r.payload_len = plen;
+            for (int i = 0; i < 8; i++) r.header[i] = (uint8_t)hbyte(i);
+            r.evm = s.evm; r.rssi = -10.0f * log10f(s.g0);
+            r.cfo = u32rad(s.nco_dtheta) / TWO_PI_F;
+            r.mod_scheme = with_payload ? s.mod_scheme : 0u; r.mod_bps = with_payload ? s.bps : 0u;
+            r.check = with_payload ? s.check : 0u; r.fec0 = with_payload ? s.fec0 : 0u; r.fec1 = with_payload ? s.fec1 : 0u;
+            r.num_framesyms = nsym; r.end_sample = t_ev;
+            r.payload_off = off; r.syms_off = off + pbytes;
+            a.rec[idx] = r;
+        }
+        if (with_payload && !oversize) {
+            const uint8_t *src = a.tmpb + (size_t)ch * (c.max_enc_len + 16);
+            uint8_t *dst = a.arena + off;
+            for (uint32_t i = (uint32_t)l; i < plen; i += WV) dst[i] = src[i];
+            const float2 *ss = a.syms + (size_t)ch * c.max_syms;
+            float2 *ds = reinterpret_cast<float2 *>(a.arena + off + pbytes);
+            for (uint32_t i = (uint32_t)l; i < nsym; i += WV) ds[i] = ss[i];
+        }
+    }
+
+    // header complete: decode and configure the payload receiver
+    __device__ void decode_header()
+    {
+        uint8_t *soft = a.soft + (size_t)ch * 8 * c.max_enc_len;
+        uint8_t *ta = a.tmpa + (size_t)ch * (c.max_enc_len + 16), *tb = a.tmpb + (size_t)ch * (c.max_enc_len + 16);
+        const uint8_t *hb = a.hbits + (size_t)ch * MCRX_HDR_SYMS;
+        __syncthreads();
+        for (int i = l; i < MCRX_HDR_SYMS; i += WV) soft[i] = hb[i] ? 255 : 0;
+        __syncthreads();
+        bool ok = packet_decode(c.cod, false, true, MCRX_HDR_DEC, 6, 7, 1, soft, ta, tb);
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) if (4 * w + b < MCRX_HDR_DEC) v |= (uint32_t)tb[4 * w + b] << (8 * b);
+            s.hw[w] = v;
+        }
+        const unsigned proto = hbyte(8);
+        const unsigned plen = (hbyte(9) << 8) | hbyte(10);
+        const unsigned mod = hbyte(11);
+        const unsigned check = (hbyte(12) >> 5) & 7, fec0 = hbyte(12) & 0x1f, fec1 = hbyte(13) & 0x1f;
+        const unsigned bps = mod_bps_d(mod);
+        if (proto != 104 || bps == 0 || !(check == 1 || check == 6) ||
+            !(fec0 == 1 || fec0 == 6 || fec0 == 7) || !(fec1 == 1 || fec1 == 6 || fec1 == 7)) ok = false;
+        s.header_valid = ok ? 1 : 0;
+        if (ok) {
+            s.payload_len = plen; s.mod_scheme = mod; s.bps = bps; s.check = check; s.fec0 = fec0; s.fec1 = fec1;
+            const unsigned n0 = plen + (check == 6 ? 4u : 0u);
+            s.enc_len = fec_enc_len_d(fec1, fec_enc_len_d(fec0, n0));
+            const unsigned nb = 8 * s.enc_len;
+            s.mod_len = nb / bps + ((nb % bps) ? 1u : 0u);
+        }
+    }
+
+    // one received OFDM symbol X (equalised, de-rotated), flexible-frame level
+    __device__ bool flex_symbol(const float2 (&X)[E], int64_t t_ev)
+    {
+        uint8_t *hb = a.hbits + (size_t)ch * MCRX_HDR_SYMS;
+        if (s.fstate == FX_HEADER) {
+            float ev = 0.f;
+#pragma unroll
+            for (int e = 0; e < E; e++) if (drank[e] >= 0) {
+                const uint32_t idx = s.header_symbol_index + (uint32_t)drank[e];
+                if (idx < MCRX_HDR_SYMS) {
+                    const unsigned sym = X[e].x > 0 ? 0u : 1u;
+                    hb[idx] = (uint8_t)sym;
+                    const float xh = sym ? -1.0f : 1.0f;
+                    const float dr = xh - X[e].x, di = -X[e].y;
+                    const float evm = sqrtf(dr * dr + di * di);
+                    ev += evm * evm;
+                }
+            }
+            s.evm_hat += wave_sum(ev);
+            s.header_symbol_index += (uint32_t)c.M_data;
+            if (s.header_symbol_index >= MCRX_HDR_SYMS) {
+                decode_header();
+                s.evm = 10.0f * log10f(s.evm_hat / (float)MCRX_HDR_SYMS);
+                if (s.header_valid) { s.fstate = FX_PAYLOAD; s.payload_symbol_index = 0; }
+                else { emit(t_ev, false, false); return true; }
+            }
+            return false;
+        }
+        // payload
+        const bool oversize = s.enc_len > c.max_enc_len || s.mod_len > c.max_syms || s.payload_len > c.max_payload_len;
+        uint8_t *soft = a.soft + (size_t)ch * 8 * c.max_enc_len;
+        float2 *syms = a.syms + (size_t)ch * c.max_syms;
+        const uint32_t nbits = 8 * s.enc_len;
+        if (!oversize) {
+#pragma unroll
+            for (int e = 0; e < E; e++) if (drank[e] >= 0) {
+                const uint32_t idx = s.payload_symbol_index + (uint32_t)drank[e];
+                if (idx < s.mod_len) {
+                    syms[idx] = X[e];
+                    uint8_t sb[6];
+                    const unsigned hs = demod_soft(c.cod, s.mod_scheme, X[e], sb);
+                    for (unsigned kb = 0; kb < s.bps; kb++) {
+                        const uint32_t pos = idx * s.bps + kb;
+                        if (pos < nbits) soft[pos] = c.payload_soft ? sb[kb] : (uint8_t)(((hs >> (s.bps - 1 - kb)) & 1) ? 255 : 0);
+                    }
+                }
+            }
+        }
+        s.payload_symbol_index += (uint32_t)c.M_data;
+        if (s.payload_symbol_index >= s.mod_len) {
+            bool valid = false;
+            if (!oversize) {
+                __syncthreads();
+                valid = packet_decode(c.cod, c.payload_soft != 0, false, s.payload_len, s.check, s.fec0, s.fec1, soft,
+                                      a.tmpa + (size_t)ch * (c.max_enc_len + 16), a.tmpb + (size_t)ch * (c.max_enc_len + 16));
+            }
+            emit(t_ev, true, valid, oversize);
+            return true;
+        }
+        return false;
+    }
+
+    __device__ void run()
+    {
+        s = a.st[ch];
+        init_consts();
+        const int M = c.M, M2 = c.M2, L = c.L;
+        while (true) {
+            // sample index of the next state-machine event
+            int64_t t_ev;
+            if (s.state == SY_SEEK)       t_ev = s.cur + ((s.timer + 1 >= (uint32_t)M) ? 0 : (int64_t)(M - 1 - (int)s.timer));
+            else if (s.state == SY_S0A || s.state == SY_S0B)
+                                          t_ev = s.cur + ((s.timer + 1 >= (uint32_t)M2) ? 0 : (int64_t)(M2 - 1 - (int)s.timer));
+            else                          t_ev = s.cur + (int64_t)s.timer - 1;
+            if (t_ev >= a.end) {
+                // consume what is left of the buffer; keep counting the timer
+                const uint32_t adv = (uint32_t)(a.end - s.cur);
+                if (s.state == SY_S1 || s.state == SY_RX) s.timer -= adv; else s.timer += adv;
+                s.cur = a.end;
+                break;
+            }
+            s.cur = t_ev + 1;
+
+            if (s.state == SY_SEEK) {
+                float pw; float2 sh = s0_metric(t_ev, false, pw);
+                const float g = (float)M / pw;
+                sh = cscale(sh, g);
+                const float tau = atan2f(sh.y, sh.x) * (float)M2 / TWO_PI_F;
+                s.g0 = g; s.timer = 0;
+                if (sqrtf(sh.x * sh.x + sh.y * sh.y) > c.detect_thresh) {
+                    const int dt = (int)roundf(tau);
+                    s.timer = (uint32_t)(M + dt) % (uint32_t)M2 + (uint32_t)M;
+                    s.state = SY_S0A;
+                }
+            } else if (s.state == SY_S0A) {
+                float pw; float2 sh = s0_metric(t_ev, true, pw);
+                s.s_hat_0 = cscale(sh, s.g0);
+                s.timer = 0; s.state = SY_S0B;
+            } else if (s.state == SY_S0B) {
+                float pw; float2 sh = cscale(s0_metric(t_ev, true, pw), s.g0);
+                const float2 ssum = cadd(s.s_hat_0, sh);
+                const float tau = atan2f(ssum.y, ssum.x) * (float)M2 / TWO_PI_F;
+                s.timer = (uint32_t)(M + c.cp - c.backoff) - (uint32_t)(int)roundf(tau);
+                // CFO: time-domain ML estimate over the two halves of the oldest M window samples
+                float2 acc = make_float2(0.f, 0.f);
+                const int64_t w0 = t_ev - L + 1;
+                for (int i = l; i < M2; i += WV) {
+                    const float2 r0 = mixed(w0 + i), r1 = mixed(w0 + i + M2);
+                    const float2 sa = c.s0t[i], sb = c.s0t[i + M2];
+                    acc = cadd(acc, cmul(cmulc(sa, r0), cmulc(r1, sb)));
+                }
+                acc = wave_csum(acc);
+                const float nu = atan2f(acc.y, acc.x) / (float)M2;
+                s.nco_dtheta = rad2u32(nu); s.nco_theta_ref = 0; s.nco_t_ref = t_ev + 1;
+                s.state = SY_S1;
+            } else if (s.state == SY_S1) {
+                s.num_symbols++;
+                float2 x[E];
+                load_window(t_ev - M + 1, true, x);
+                fft(x);
+                const float gain = sqrtf((float)c.M_S1) / (float)M;
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < E; e++) if (k[e] >= 0) { x[e] = cscale(x[e], S1v[e] * gain); ldsc[k[e]] = x[e]; }
+                __syncthreads();
+                float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+                for (int e = 0; e < E; e++) if (k[e] >= 0) {
+                    int kn = k[e] + 1; if (kn >= M) kn -= M;
+                    acc = cadd(acc, cmulc(ldsc[kn], x[e]));
+                }
+                acc = wave_csum(acc);
+                float2 gh = cscale(acc, s.g0 / (float)c.M_S1);
+                { const double phi = (double)c.backoff * 6.283185307179586 / (double)M;
+                  gh = cmul(gh, make_float2((float)cos(phi), (float)sin(phi))); }
+                const float mag = sqrtf(gh.x * gh.x + gh.y * gh.y);
+                if (mag > c.sync_thresh && fabsf(atan2f(gh.y, gh.x)) < 0.1f * PI_F) {
+                    s.state = SY_RX; s.timer = (uint32_t)(M + c.cp + c.backoff); s.num_symbols = 0;
+                    // equaliser: order-4 LSQ smoothing of |G| and unwrapped arg G, R = 1/G
+                    const float g = (float)M / sqrtf((float)(c.M_pilot + c.M_data));
+                    float *yabs = ldsf, *yarg = ldsf + c.Nen;
+                    __syncthreads();
+#pragma unroll
+                    for (int e = 0; e < E; e++) if (erank[e] >= 0) {
+                        const float2 G = cscale(x[e], g);
+                        yabs[erank[e]] = sqrtf(G.x * G.x + G.y * G.y);
+                        yarg[erank[e]] = atan2f(G.y, G.x);
+                    }
+                    __syncthreads();
+                    if (l == 0) {
+                        for (int i = 1; i < c.Nen; i++) {
+                            float v = yarg[i];
+                            while ((v - yarg[i - 1]) >  PI_F) v -= 2.0f * PI_F;
+                            while ((v - yarg[i - 1]) < -PI_F) v += 2.0f * PI_F;
+                            yarg[i] = v;
+                        }
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int e = 0; e < E; e++) {
+                        float2 r = make_float2(0.f, 0.f);
+                        if (k[e] >= 0 && sct[e] != 0) {
+                            const float *row = c.Ssm + (size_t)k[e] * c.Nen;
+                            float A = 0.f, th = 0.f;
+                            for (int n = 0; n < c.Nen; n++) { A += row[n] * yabs[n]; th += row[n] * yarg[n]; }
+                            const float gr = A * cosf(th), gi = A * sinf(th);
+                            const float d = gr * gr + gi * gi;
+                            r = make_float2(gr / d, -gi / d);
+                        }
+                        R[e] = r;
+                        if (k[e] >= 0) a.R[(size_t)ch * M + k[e]] = r;
+                    }
+                    __syncthreads();
+                } else {
+                    if (s.num_symbols == 16) reset_framesync();
+                    s.timer = (uint32_t)M2;
+                }
+            } else {    // SY_RX
+                float2 X[E];
+                load_window(t_ev - L + 1 + c.cp - c.backoff, true, X);
+                fft(X);
+                // equalise, pilot phases
+                float *yph = ldsf;
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    X[e] = cmul(X[e], R[e]);
+                    if (prank[e] >= 0) {
+                        const float pil = c.pilot_seq[(s.pilot_count + (uint32_t)prank[e]) % 255u] ? 1.0f : -1.0f;
+                        yph[prank[e]] = atan2f(X[e].y * pil, X[e].x * pil);
+                    }
+                }
+                __syncthreads();
+                float p0 = 0.f, p1 = 0.f, prev = 0.f;
+                for (int n = 0; n < c.M_pilot; n++) {
+                    float v = yph[n];
+                    if (n > 0) {
+                        while ((v - prev) >  PI_F) v -= 2.0f * PI_F;
+                        while ((v - prev) < -PI_F) v += 2.0f * PI_F;
+                    }
+                    prev = v;
+                    p0 += c.Pfit[n] * v;
+                    p1 += c.Pfit[c.M_pilot + n] * v;
+                }
+                __syncthreads();
+                s.pilot_count = (s.pilot_count + (uint32_t)c.M_pilot) % 255u;
+                p1 = 0.3f * p1 + (1.0f - 0.3f) * s.p1_prime;
+                s.p1_prime = p1;
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    if (k[e] < 0 || sct[e] == 0) { X[e] = make_float2(0.f, 0.f); continue; }
+                    const float theta = p0 + p1 * fx[e];
+                    X[e] = mix_down(X[e], rad2u32(theta));
+                }
+                uint32_t new_dtheta = s.nco_dtheta;
+                if (s.num_symbols > 0) {
+                    float dphi = p0 - s.phi_prime;
+                    while (dphi >  PI_F) dphi -= 2.0f * PI_F;
+                    while (dphi < -PI_F) dphi += 2.0f * PI_F;
+                    new_dtheta += rad2u32(1e-3f * dphi);
+                }
+                // the frequency change applies to samples after this event
+                s.nco_theta_ref = s.nco_theta_ref + (uint32_t)(t_ev + 1 - s.nco_t_ref) * s.nco_dtheta;
+                s.nco_t_ref = t_ev + 1;
+                s.nco_dtheta = new_dtheta;
+                s.phi_prime = p0;
+                s.num_symbols++;
+                s.timer = (uint32_t)L;
+                if (flex_symbol(X, t_ev)) { reset_framesync(); s.timer = (uint32_t)L; }
+            }
+        }
+        if (l == 0) a.st[ch] = s;
+    }
+};
+
+template <int E>
+__global__ __launch_bounds__(WV) void sync_kernel(SyncArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    const uint32_t ch = blockIdx.x;
+    if (ch >= a.nch) return;
+    float2 *lc = lds;
+    float *lf = reinterpret_cast<float *>(lds + a.c.M);
+    Walker<E> w(a, ch, lc, lf);
+    w.run();
+}
+
+__global__ void sync_reset_kernel(ChanState *st, uint32_t nch, int64_t cur)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nch) return;
+    ChanState z;
+    memset(&z, 0, sizeof(z));
+    z.state = SY_SEEK; z.cur = cur; z.g0 = 1.0f; z.fstate = FX_HEADER;
+    st[i] = z;
+}
+
+hipError_t sync_reset_launch(ChanState *st, uint32_t nch, int64_t cur, hipStream_t stream)
+{
+    hipLaunchKernelGGL(sync_reset_kernel, dim3((nch + 255) / 256), dim3(256), 0, stream, st, nch, cur);
+    return hipGetLastError();
+}
+
+hipError_t sync_launch(const SyncArgs &a, hipStream_t st)
+{
+    if (a.nch == 0) return hipSuccess;
+    const size_t lds = (size_t)a.c.M * sizeof(float2) + (size_t)2 * a.c.M * sizeof(float);
+    const int E = a.c.E;
+    switch (E) {
+    case 1:  hipLaunchKernelGGL((sync_kernel<1>),  dim3(a.nch), dim3(WV), lds, st, a); break;
+    case 2:  hipLaunchKernelGGL((sync_kernel<2>),  dim3(a.nch), dim3(WV), lds, st, a); break;
+    case 4:  hipLaunchKernelGGL((sync_kernel<4>),  dim3(a.nch), dim3(WV), lds, st, a); break;
+    case 8:  hipLaunchKernelGGL((sync_kernel<8>),  dim3(a.nch), dim3(WV), lds, st, a); break;
+    case 16: hipLaunchKernelGGL((sync_kernel<16>), dim3(a.nch), dim3(WV), lds, st, a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace mcrx
