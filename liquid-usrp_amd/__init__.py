@@ -86,6 +86,12 @@ def lib():
         if not os.path.exists(_LIBPATH):
             raise RuntimeError("libmcrx_hip.so is not built (run __graft_entry__.build()); "
                                "liquid_usrp_amd has no CPU fallback")
+        try:
+            # PyTorch-ROCm bundles its own HIP runtime; load it first so this process holds a
+            # single libamdhip64 (device buffers and streams are shared with torch tensors).
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(_LIBPATH)
         for name, (res, args) in _EXPORTS.items():
             fn = getattr(L, name)

@@ -106,6 +106,7 @@ struct SyncArgs {
     unsigned long long *arena_used;
     uint64_t arena_cap;
     uint32_t max_rec;
+    int debug;                  // MCRX_DEBUG=1: trace state-machine events of channel 0
 };
 hipError_t sync_launch(const SyncArgs &a, hipStream_t st);
 hipError_t sync_reset_launch(ChanState *st, uint32_t nch, int64_t cur, hipStream_t stream);

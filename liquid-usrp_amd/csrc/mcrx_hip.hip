@@ -291,6 +291,7 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     a.st = q->d_st; a.hbits = q->d_hbits; a.R = q->d_R; a.soft = q->d_soft; a.tmpa = q->d_tmpa; a.tmpb = q->d_tmpb;
     a.syms = q->d_syms; a.rec = q->d_rec; a.arena = q->d_arena; a.nrec = q->d_nrec; a.arena_used = q->d_arena_used;
     a.arena_cap = q->arena_cap; a.max_rec = q->max_rec;
+    a.debug = getenv("MCRX_DEBUG") ? atoi(getenv("MCRX_DEBUG")) : 0;
     HIPCHK(hipEventRecord(q->ev[2], st));
     HIPCHK(sync_launch(a, st));
     HIPCHK(hipEventRecord(q->ev[3], st));

@@ -76,13 +76,17 @@ template <bool SOFT>
 __device__ void il_pass(uint8_t *x, unsigned n, unsigned Mi, unsigned Ncol, unsigned mask)
 {
     const int l = lane_id();
-    const unsigned n2 = n / 2, total = Mi * Ncol, c0 = n / 3;
+    // liquid's walk starts in column n/3 WITHOUT reducing it modulo Ncol (so the first column is
+    // usually a row-shifted alias of column (n/3) % Ncol), then steps (c+1) % Ncol; it stops
+    // after n/2 valid cells, which is always before an aliased cell would repeat.
+    const unsigned n2 = n / 2, total = Mi * (Ncol + 1), c0 = n / 3;
     unsigned long long m64 = 0;
     if (SOFT) for (int k = 0; k < 8; k++) if ((mask >> (7 - k)) & 1) m64 |= 0xFFull << (8 * k);
     unsigned base = 0;
     for (unsigned q0 = 0; q0 < total && base < n2; q0 += WV) {
         unsigned q = q0 + (unsigned)l;
-        unsigned m = q % Mi, c = (c0 + q / Mi) % Ncol;
+        unsigned m = q % Mi, tcol = q / Mi;
+        unsigned c = tcol ? (c0 + tcol) % Ncol : c0;
         unsigned j = m * Ncol + c;
         bool valid = (q < total) && (j < n2);
         unsigned long long bal = __ballot(valid);
@@ -308,14 +312,17 @@ __device__ unsigned demod_soft(const CodingDev &cod, unsigned mod, cfd r, uint8_
 }
 
 // ------------------------------------------------------------------ the walker
+// Wave-private LDS scratch, referenced by name so every access is a ds_* instruction.
+#define SY_MAXM 1024
+__shared__ __attribute__((aligned(16))) float2 ldsc[SY_MAXM];     // complex scratch [M]
+__shared__ __attribute__((aligned(16))) float ldsf[2 * SY_MAXM];   // float scratch [2*M]
+
 template <int E>
 struct Walker {
     const SyncArgs &a;
     const SyncConsts &c;
     const int l;                // lane
     const uint32_t ch;          // channel within shard
-    float2 *ldsc;               // [M] complex scratch
-    float *ldsf;                // [2*M] float scratch
     ChanState s;                // working copy of the channel state (wave uniform)
     // per (lane, e) constants
     int k[E];                   // subcarrier held after the FFT (-1: none)
@@ -325,8 +332,8 @@ struct Walker {
     float2 R[E];
     float2 twx[6];              // cross-lane stage twiddles, stage h = 32 >> s
 
-    __device__ Walker(const SyncArgs &a_, uint32_t ch_, float2 *lc, float *lf)
-        : a(a_), c(a_.c), l(lane_id()), ch(ch_), ldsc(lc), ldsf(lf) {}
+    __device__ Walker(const SyncArgs &a_, uint32_t ch_)
+        : a(a_), c(a_.c), l(lane_id()), ch(ch_) {}
 
     __device__ __forceinline__ float2 sample(int64_t t) const
     {
@@ -365,21 +372,31 @@ struct Walker {
             twx[st] = make_float2(cs, -sn);
         }
     }
+    template <int J>
+    __device__ __forceinline__ void inlane_stage(float2 (&x)[E])
+    {
+        constexpr int h = WV * J;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            if constexpr (true) {
+                if ((e & J) == 0 && e + J < E) {
+                    const float2 u = x[e], v = x[e + J];
+                    float sn, cs;
+                    sincos_u32((uint32_t)((l + WV * e) & (h - 1)) * (uint32_t)(0x80000000u / (unsigned)h), sn, cs);
+                    x[e] = cadd(u, v);
+                    x[e + J] = cmul(csub(u, v), make_float2(cs, -sn));
+                }
+            }
+        }
+    }
     // forward DFT of x (time position i = l + 64 e) -> X[k[e]]
     __device__ void fft(float2 (&x)[E])
     {
         if (c.log2M) {
-#pragma unroll
-            for (int j = E / 2; j >= 1; j >>= 1) {             // in-lane stages, h = 64 j
-#pragma unroll
-                for (int e = 0; e < E; e++) if ((e & j) == 0) {
-                    float2 u = x[e], v = x[e + j];
-                    const int h = WV * j;
-                    float sn, cs; sincos_u32((uint32_t)((l + WV * e) & (h - 1)) * (uint32_t)(0x80000000u / (unsigned)h), sn, cs);
-                    x[e] = cadd(u, v);
-                    x[e + j] = cmul(csub(u, v), make_float2(cs, -sn));
-                }
-            }
+            if constexpr (E >= 16) inlane_stage<8>(x);         // in-lane stages, h = 64 j
+            if constexpr (E >= 8) inlane_stage<4>(x);
+            if constexpr (E >= 4) inlane_stage<2>(x);
+            if constexpr (E >= 2) inlane_stage<1>(x);
 #pragma unroll
             for (int st = 0; st < 6; st++) {
                 const int h = 32 >> st;
@@ -591,7 +608,24 @@ struct Walker {
     __device__ void run()
     {
         s = a.st[ch];
+        if (a.debug == 2) return;
         init_consts();
+        if (a.debug == 3) return;
+        if (a.debug == 4) { float pw; float2 sh = s0_metric(c.M - 1, false, pw); if (l == 0 && sh.x == 12345.f) a.st[ch].g0 = pw; return; }
+        if (a.debug == 5) { float2 x[E]; load_window(0, false, x); if (x[0].x == 12345.f) a.st[ch].g0 = 1; return; }
+        if (a.debug >= 7 && a.debug <= 11) {
+            float2 x[E]; load_window(0, false, x); fft(x);
+            __syncthreads();
+            if (a.debug == 7) { if (k[0] >= 0) ldsc[k[0]] = x[0]; }
+            if (a.debug == 8) { if (k[E - 1] >= 0) ldsc[k[E - 1]] = x[E - 1]; }
+            if (a.debug == 9) { ldsc[l] = x[0]; }
+            if (a.debug == 10) { int bad = 0; for (int e = 0; e < E; e++) if (k[e] >= c.M || k[e] < -1) bad = 1; if (bad) a.st[ch].g0 = -777.f; }
+            if (a.debug == 11) { ldsc[l + WV * (E - 1)] = x[0]; }
+            __syncthreads();
+            if (ldsc[0].x == 12345.f) a.st[ch].g0 = 1;
+            return;
+        }
+        if (a.debug == 6) { float2 x[E]; load_window(0, false, x); fft(x); if (x[0].x == 12345.f) a.st[ch].g0 = 1; return; }
         const int M = c.M, M2 = c.M2, L = c.L;
         while (true) {
             // sample index of the next state-machine event
@@ -608,6 +642,7 @@ struct Walker {
                 break;
             }
             s.cur = t_ev + 1;
+            if (a.debug && l == 0 && ch == 0) printf("[sync] ch0 t=%lld state=%d fstate=%d timer=%u hsi=%u psi=%u\n", (long long)t_ev, s.state, s.fstate, s.timer, s.header_symbol_index, s.payload_symbol_index);
 
             if (s.state == SY_SEEK) {
                 float pw; float2 sh = s0_metric(t_ev, false, pw);
@@ -764,12 +799,9 @@ struct Walker {
 template <int E>
 __global__ __launch_bounds__(WV) void sync_kernel(SyncArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const uint32_t ch = blockIdx.x;
     if (ch >= a.nch) return;
-    float2 *lc = lds;
-    float *lf = reinterpret_cast<float *>(lds + a.c.M);
-    Walker<E> w(a, ch, lc, lf);
+    Walker<E> w(a, ch);
     w.run();
 }
 
@@ -792,7 +824,8 @@ hipError_t sync_reset_launch(ChanState *st, uint32_t nch, int64_t cur, hipStream
 hipError_t sync_launch(const SyncArgs &a, hipStream_t st)
 {
     if (a.nch == 0) return hipSuccess;
-    const size_t lds = (size_t)a.c.M * sizeof(float2) + (size_t)2 * a.c.M * sizeof(float);
+    const size_t lds = 0;
+    if (a.c.M > SY_MAXM) return hipErrorInvalidValue;
     const int E = a.c.E;
     switch (E) {
     case 1:  hipLaunchKernelGGL((sync_kernel<1>),  dim3(a.nch), dim3(WV), lds, st, a); break;
