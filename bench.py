@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- complex Msamples/s through a 512-channel multichannelrx on synthetic IQ.
+
+One step = one pass of the hot path (NCO + polyphase analysis channelizer -> per-channel
+OFDM frame synchronizer incl. header/payload decode) over one batch of wideband cf32 samples
+that is already resident in HBM.  Workload = BASELINE.json config "512-ch multichannelrx":
+N=512 channels (K=1024), M=64 subcarriers, cp=8, taper=4, QPSK, CRC-32 + Hamming(12,8),
+1200-byte payloads, frames back to back on every channel (reference traffic recipe,
+src/multichannel_tx.cc:163-213).
+
+--gpus N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling.  Rank r
+channelizes time slab r of the wideband stream, one RCCL all-to-all turns the time-sharded
+channelizer output into channel shards (64 channels per GPU at N=8), rank r synchronizes
+channels [r*512/N, (r+1)*512/N) over all slabs.  value = samples all ranks accepted / time.
+
+The CPU oracle (oracle/) appears in two places only: it synthesises the transmit waveform
+that is fed to the GPU (test-signal generation, outside every timed region) and it is the
+`cpu_baseline` leg, timed on a bounded sample of the same IQ.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+B_CHANNELIZER = 12.0           # algorithmic bytes / wideband sample: 8 read + 4 written (N of 2N bins)
+B_SYNC = 4.0                   # algorithmic bytes / wideband sample: the kept bins read once
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--channels", type=int, default=512)
+    ap.add_argument("--frames", type=int, default=8, help="frames per channel per GPU slab")
+    ap.add_argument("--payload", type=int, default=1200)
+    ap.add_argument("--cpu-reps", type=int, default=8, help="copies of the frame period timed on the CPU oracle")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--slab-blocks", type=int, default=0)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    from __graft_entry__ import load_product, load_oracle
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP kernels are the only implementation"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)      # RCCL over xGMI
+
+    prod, ora = load_product(), load_oracle()
+    N, M, cp, taper = args.channels, 64, 8, 4
+    K = 2 * N
+    assert N % world == 0
+    cg = N // world
+
+    # ---- synthetic IQ: one frame period of all channels from the oracle transmitter (untimed),
+    # tiled `frames` times in HBM.  Each copy ends in >= 64 idle blocks, so the cold-start
+    # transient of the next copy falls between frames.
+    t0 = time.time()
+    base, sent = ora.synth_traffic(N, M, cp, taper, 1, payload_len=args.payload, extra_blocks=64)
+    nb_base = (len(base) // K + 7) // 8 * 8
+    base = np.concatenate([base, np.zeros(nb_base * K - len(base), np.complex64)])
+    gen_s = time.time() - t0
+    reps = args.frames
+    T = nb_base * reps                                   # blocks per rank slab
+    d_base = torch.from_numpy(base).to(dev)
+    d_iq = d_base.repeat(reps)                           # slab of this rank, resident in HBM
+    d_halo = d_base[(nb_base - 13) * K:].clone() if rank > 0 else None
+    first_sample = rank * T * K
+    ntiles = T // 8
+
+    cfg = dict(max_payload_len=max(args.payload, 64), channel_first=rank * cg, channel_count=cg,
+               max_frames=cg * reps * world + 64)
+    if args.slab_blocks:
+        cfg["slab_blocks"] = args.slab_blocks
+    rx = prod.multichannelrx(N, M, cp, taper, **cfg)
+    d_out = torch.empty(world * ntiles * cg * 8, dtype=torch.complex64, device=dev)     # [dest][tile][c][8]
+    d_chan = torch.empty_like(d_out) if world > 1 else d_out                           # [src][tile][c][8]
+    stream = torch.cuda.current_stream()
+
+    def step():
+        rx.restart(stream)
+        rx.channelize(d_iq, T, first_sample, d_out, groups=world, d_halo=d_halo, stream=stream)
+        if world > 1:
+            dist.all_to_all_single(d_chan, d_out)        # time shards -> channel shards
+        rx.sync(d_chan, 0, world * T, stream=stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    rx.kernel_stats(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    stats = rx.kernel_stats()
+
+    # ---- verification of the last step (untimed): every frame of the shard decoded and valid
+    rx.Flush()
+    frames = rx.frames
+    expect = cg * reps * world
+    n_ok = sum(1 for f in frames if f.header_valid and f.payload_valid
+               and sent[f.channel][0] == (f.header, f.payload))
+    verified = (len(frames) == expect and n_ok == expect)
+
+    samples_per_step = world * T * K
+    value = samples_per_step * args.steps / elapsed / 1e6
+    out = None
+    if rank == 0:
+        ch_ms = stats["channelizer"][0] / max(stats["channelizer"][1], 1)
+        sy_ms = stats["sync"][0] / max(stats["sync"][1], 1)
+        if ch_ms >= sy_ms:
+            kname, kms, kbytes = "channelizer_kernel", ch_ms, B_CHANNELIZER * T * K
+        else:
+            kname, kms, kbytes = "sync_kernel", sy_ms, B_SYNC * world * T * K
+        achieved = kbytes / (kms * 1e-3) / 1e9
+        out = {
+            "metric": "complex Msamples/s through multichannelrx",
+            "value": round(value, 3), "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "512-ch multichannelrx (firpfbch K=2N m=7 + N x ofdmflexframesync), "
+                                   "M=64 cp=8 taper=4 QPSK CRC32+Hamming128 %dB payloads, %d frames/ch/GPU"
+                                   % (args.payload, reps),
+                       "channels": N, "subcarriers": M, "samples_per_step": samples_per_step,
+                       "parallelism": "time-sharded channelizer -> all-to-all -> %d channels/GPU" % cg
+                                      if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "ms_per_launch": round(kms, 4),
+                         "channelizer_ms": round(ch_ms, 4), "sync_ms": round(sy_ms, 4),
+                         "pipeline_frac_of_16B_roofline": round(value * 1e6 * 16.0 / (world * HBM_PEAK_GBS * 1e9), 5)},
+            "verified": {"frames": len(frames), "expected": expect, "bit_exact_payloads": n_ok, "ok": verified},
+            "setup_s": {"iq_generation": round(gen_s, 2)},
+        }
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(ora, base, N, M, cp, taper, args.cpu_reps)
+    rx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+    if not verified:
+        sys.exit("rank %d: verification failed (%d/%d frames, %d ok)" % (rank, len(frames), expect, n_ok))
+
+
+def cpu_baseline(ora, base, N, M, cp, taper, reps):
+    """The CPU oracle (a port: liquid-dsp itself is unavailable) on the same IQ, one thread
+    (the reference's multichannelrx is single threaded: lib/multichannelrx.cc:184)."""
+    rx = ora.MultiChannelRx(N, M, cp, taper)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        rx.execute(base)
+    dt = time.perf_counter() - t0
+    n = len(base) * reps
+    ok = sum(1 for f in rx.frames if f.payload_valid)
+    return {"value": round(n / dt / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": "%d copies of the benchmark's frame period (%d samples, %d frames decoded), oracle "
+                      "multichannelrx, single thread" % (reps, n, ok),
+            "host_cores": os.cpu_count(), "seconds": round(dt, 2)}
+
+
+if __name__ == "__main__":
+    main()

@@ -69,6 +69,8 @@ _EXPORTS = {
     "mcrx_hip_get_taps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "mcrx_hip_nco_step": (C.c_uint32, [C.c_void_p]),
     "mcrx_hip_kernel_time_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "mcrx_hip_kernel_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
+                                        C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
     "mcrx_hip_last_error": (C.c_char_p, []),
 }
 
@@ -245,6 +247,12 @@ class multichannelrx(object):
         a, b = C.c_float(0), C.c_float(0)
         _check(lib().mcrx_hip_kernel_time_ms(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def kernel_stats(self, reset=False):
+        """{'channelizer': (total_ms, launches), 'sync': (total_ms, launches)} from HIP events."""
+        a, b, na, nb = C.c_double(0), C.c_double(0), C.c_uint64(0), C.c_uint64(0)
+        _check(lib().mcrx_hip_kernel_stats(self._h, C.byref(a), C.byref(na), C.byref(b), C.byref(nb), 1 if reset else 0))
+        return {"channelizer": (a.value, na.value), "sync": (b.value, nb.value)}
 
     def frames_dropped(self):
         return int(lib().mcrx_hip_frames_dropped(self._h))

@@ -102,8 +102,35 @@ struct mcrx_hip_s {
     float2 *d_chan[2] = { nullptr, nullptr }; size_t chan_cap_tiles = 0; int chan_cur = 0;
     unsigned hist_tiles = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
-    bool ev_ch = false, ev_sy = false;
+    // per-kernel HIP event ring: [0] channelizer, [1] synchronizer; pairs (start, stop)
+    std::vector<hipEvent_t> evring[2];
+    size_t ev_used[2] = { 0, 0 };
+    double ev_ms_total[2] = { 0, 0 }; uint64_t ev_count[2] = { 0, 0 };
+    float ev_last[2] = { 0, 0 };
+
+    int ev_begin(int which, hipStream_t st)
+    {
+        if (ev_used[which] + 2 > evring[which].size()) RC(ev_resolve(which));
+        HIPCHK(hipEventRecord(evring[which][ev_used[which]], st));
+        return MCRX_OK;
+    }
+    int ev_end(int which, hipStream_t st)
+    {
+        HIPCHK(hipEventRecord(evring[which][ev_used[which] + 1], st));
+        ev_used[which] += 2;
+        return MCRX_OK;
+    }
+    int ev_resolve(int which)          // fold finished launches into the totals
+    {
+        for (size_t i = 0; i < ev_used[which]; i += 2) {
+            float ms = 0;
+            HIPCHK(hipEventSynchronize(evring[which][i + 1]));
+            HIPCHK(hipEventElapsedTime(&ms, evring[which][i], evring[which][i + 1]));
+            ev_ms_total[which] += ms; ev_count[which]++; ev_last[which] = ms;
+        }
+        ev_used[which] = 0;
+        return MCRX_OK;
+    }
     // harvested frames (host)
     std::vector<FrameRec> recs; std::vector<uint8_t> arena_host; size_t next_frame = 0;
     uint64_t dropped = 0;
@@ -204,8 +231,10 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     q->nch = q->cfg.channel_count ? q->cfg.channel_count : N - q->ch_first;
     if (q->ch_first + q->nch > N || q->nch == 0) { delete q; return fail(MCRX_EINVAL, "channel shard outside [0, N)"); }
     q->max_rec = q->cfg.max_frames ? q->cfg.max_frames : 16 * q->nch + 64;
-    q->arena_cap = (uint64_t)q->max_rec * ((uint64_t)q->max_payload + 8ull * 4ull * (q->max_payload + 16));
-    if (q->arena_cap > (4ull << 30)) q->arena_cap = 4ull << 30;
+    // frame arena: payload + equalised symbols; reserve for BPSK behind one rate-1/2 code
+    // (longer frames still fit while the total stays below the cap; overflow is counted)
+    q->arena_cap = (uint64_t)q->max_rec * ((((uint64_t)q->max_payload + 15) & ~15ull) + 8ull * 8ull * (2ull * (q->max_payload + 4) + 8));
+    if (q->arena_cap > (8ull << 30)) q->arena_cap = 8ull << 30;
     q->slab_blocks = q->cfg.slab_blocks ? ((q->cfg.slab_blocks + 7) & ~7u) : 64;
     q->taps = pfb_prototype(q->K, 7, 60.0f);
     q->dtheta = channel_center_step(N);
@@ -236,7 +265,10 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
         return bail(fail(MCRX_ENOMEM, "pinned staging allocation failed"));
     if ((rc = q->alloc(&q->d_in, q->stage_cap))) return bail(rc);
     if (hipStreamCreate(&q->stream) != hipSuccess) return bail(fail(MCRX_EHIP, "hipStreamCreate failed"));
-    for (int i = 0; i < 4; i++) if (hipEventCreate(&q->ev[i]) != hipSuccess) return bail(fail(MCRX_EHIP, "hipEventCreate failed"));
+    for (int w = 0; w < 2; w++) {
+        q->evring[w].resize(512, nullptr);
+        for (auto &e : q->evring[w]) if (hipEventCreate(&e) != hipSuccess) return bail(fail(MCRX_EHIP, "hipEventCreate failed"));
+    }
     if ((rc = restart_async(q, q->stream, true))) return bail(rc);
     if (hipStreamSynchronize(q->stream) != hipSuccess) return bail(fail(MCRX_EHIP, "stream sync failed"));
     *out = q;
@@ -250,7 +282,7 @@ extern "C" int mcrx_hip_destroy(mcrx_hip_t q)
     for (void *p : q->owned) hipFree(p);
     for (int i = 0; i < 2; i++) if (q->d_chan[i]) hipFree(q->d_chan[i]);
     if (q->h_stage) hipHostFree(q->h_stage);
-    for (int i = 0; i < 4; i++) if (q->ev[i]) hipEventDestroy(q->ev[i]);
+    for (int w = 0; w < 2; w++) for (auto e : q->evring[w]) if (e) hipEventDestroy(e);
     if (q->stream) hipStreamDestroy(q->stream);
     delete q;
     return MCRX_OK;
@@ -277,10 +309,9 @@ static int launch_channelizer(mcrx_hip_t q, const float2 *x, size_t nblocks, uin
     a.nblocks = (uint32_t)nblocks; a.slab_blocks = q->slab_blocks;
     a.first_sample_lo = (uint32_t)first_sample; a.dtheta = q->dtheta;
     a.ntiles = (uint32_t)ntiles_stride; a.cg = q->N / groups;
-    HIPCHK(hipEventRecord(q->ev[0], st));
+    RC(q->ev_begin(0, st));
     HIPCHK(channelizer_launch(q->K, a, st));
-    HIPCHK(hipEventRecord(q->ev[1], st));
-    q->ev_ch = true;
+    RC(q->ev_end(0, st));
     return MCRX_OK;
 }
 static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsigned off, int64_t buf_first, int64_t end, hipStream_t st)
@@ -292,10 +323,9 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     a.syms = q->d_syms; a.rec = q->d_rec; a.arena = q->d_arena; a.nrec = q->d_nrec; a.arena_used = q->d_arena_used;
     a.arena_cap = q->arena_cap; a.max_rec = q->max_rec;
     a.debug = getenv("MCRX_DEBUG") ? atoi(getenv("MCRX_DEBUG")) : 0;
-    HIPCHK(hipEventRecord(q->ev[2], st));
+    RC(q->ev_begin(1, st));
     HIPCHK(sync_launch(a, st));
-    HIPCHK(hipEventRecord(q->ev[3], st));
-    q->ev_sy = true;
+    RC(q->ev_end(1, st));
     return MCRX_OK;
 }
 
@@ -321,8 +351,23 @@ extern "C" int mcrx_hip_restart(mcrx_hip_t q, void *stream)
 extern "C" int mcrx_hip_kernel_time_ms(mcrx_hip_t q, float *ch_ms, float *sy_ms)
 {
     if (!q) return fail(MCRX_EINVAL, "null handle");
-    if (ch_ms) { *ch_ms = 0; if (q->ev_ch) { HIPCHK(hipEventSynchronize(q->ev[1])); HIPCHK(hipEventElapsedTime(ch_ms, q->ev[0], q->ev[1])); } }
-    if (sy_ms) { *sy_ms = 0; if (q->ev_sy) { HIPCHK(hipEventSynchronize(q->ev[3])); HIPCHK(hipEventElapsedTime(sy_ms, q->ev[2], q->ev[3])); } }
+    RC(q->ev_resolve(0)); RC(q->ev_resolve(1));
+    if (ch_ms) *ch_ms = q->ev_last[0];
+    if (sy_ms) *sy_ms = q->ev_last[1];
+    return MCRX_OK;
+}
+extern "C" int mcrx_hip_kernel_stats(mcrx_hip_t q, double *ch_ms_total, uint64_t *ch_launches,
+                                     double *sy_ms_total, uint64_t *sy_launches, int reset)
+{
+    // HIP-event durations of every channelizer / synchronizer launch since the last reset,
+    // recorded on the stream the kernels were launched on
+    if (!q) return fail(MCRX_EINVAL, "null handle");
+    RC(q->ev_resolve(0)); RC(q->ev_resolve(1));
+    if (ch_ms_total) *ch_ms_total = q->ev_ms_total[0];
+    if (ch_launches) *ch_launches = q->ev_count[0];
+    if (sy_ms_total) *sy_ms_total = q->ev_ms_total[1];
+    if (sy_launches) *sy_launches = q->ev_count[1];
+    if (reset) { q->ev_ms_total[0] = q->ev_ms_total[1] = 0; q->ev_count[0] = q->ev_count[1] = 0; }
     return MCRX_OK;
 }
 
