@@ -86,6 +86,14 @@ struct FrameRec {
     uint64_t payload_off, syms_off;     // byte offsets into the frame arena
 };
 
+// payload of one frame handed from the per-channel scout to a payload worker wave
+struct PayloadJob {
+    ChanState s;                // synchronizer state right after the last header symbol
+    uint32_t ch;                // channel within the shard
+    uint32_t pad;
+    uint64_t arena_off;         // pre-allocated record space: payload bytes, then framesyms
+};
+
 struct SyncArgs {
     SyncConsts c;
     const float2 *chan;         // [tile][chan_stride][8]; my channel c sits at chan_off + c
@@ -106,9 +114,15 @@ struct SyncArgs {
     unsigned long long *arena_used;
     uint64_t arena_cap;
     uint32_t max_rec;
-    int debug;                  // MCRX_DEBUG=1: trace state-machine events of channel 0
+    // scout -> payload worker hand-off (frame-parallel payload processing)
+    int scout;                  // 1: scouts hand complete in-buffer frames to payload workers
+    PayloadJob *jobs; uint32_t *njobs; uint32_t max_jobs;
+    float2 *jR;                 // [max_jobs][M]
+    uint8_t *jsoft;             // [max_jobs][8*max_enc_len]
+    uint8_t *jtmp;              // [max_jobs][2*(max_enc_len+16)]
+    int debug;                 // MCRX_DEBUG=1: trace state-machine events of channel 0
 };
-hipError_t sync_launch(const SyncArgs &a, hipStream_t st);
+hipError_t sync_launch(const SyncArgs &a, hipStream_t st);       // scout kernel (+ payload workers if a.scout)
 hipError_t sync_reset_launch(ChanState *st, uint32_t nch, int64_t cur, hipStream_t stream);
 
 }  // namespace mcrx

@@ -92,6 +92,9 @@ struct mcrx_hip_s {
     uint8_t *d_soft = nullptr, *d_tmpa = nullptr, *d_tmpb = nullptr; float2 *d_syms = nullptr;
     FrameRec *d_rec = nullptr; uint8_t *d_arena = nullptr; uint32_t *d_nrec = nullptr;
     unsigned long long *d_arena_used = nullptr;
+    PayloadJob *d_jobs = nullptr; uint32_t *d_njobs = nullptr; float2 *d_jR = nullptr;
+    uint8_t *d_jsoft = nullptr, *d_jtmp = nullptr;
+    bool scout = true;
     // streaming state
     uint64_t total_samples = 0;             // wideband samples accepted since creation (NCO phase)
     uint64_t stage_first = 0;               // absolute index of h_stage[0]
@@ -255,6 +258,14 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     if ((rc = q->alloc(&q->d_arena, q->arena_cap))) return bail(rc);
     if ((rc = q->alloc(&q->d_nrec, 2))) return bail(rc);
     if ((rc = q->alloc(&q->d_arena_used, 1))) return bail(rc);
+    q->scout = getenv("MCRX_NO_SCOUT") == nullptr;
+    if ((rc = q->alloc(&q->d_njobs, 1))) return bail(rc);
+    if (q->scout) {
+        if ((rc = q->alloc(&q->d_jobs, q->max_rec))) return bail(rc);
+        if ((rc = q->alloc(&q->d_jR, (size_t)q->max_rec * M))) return bail(rc);
+        if ((rc = q->alloc(&q->d_jsoft, (size_t)q->max_rec * 8 * q->max_enc))) return bail(rc);
+        if ((rc = q->alloc(&q->d_jtmp, (size_t)q->max_rec * 2 * (q->max_enc + 16)))) return bail(rc);
+    }
     if ((rc = q->alloc(&q->d_hist[0], (size_t)HIST_BLOCKS * q->K))) return bail(rc);
     if ((rc = q->alloc(&q->d_hist[1], (size_t)HIST_BLOCKS * q->K))) return bail(rc);
     // host staging for Execute(): whole tiles of 8 blocks
@@ -323,6 +334,10 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     a.syms = q->d_syms; a.rec = q->d_rec; a.arena = q->d_arena; a.nrec = q->d_nrec; a.arena_used = q->d_arena_used;
     a.arena_cap = q->arena_cap; a.max_rec = q->max_rec;
     a.debug = getenv("MCRX_DEBUG") ? atoi(getenv("MCRX_DEBUG")) : 0;
+    a.scout = q->scout ? 1 : 0;
+    a.jobs = q->d_jobs; a.njobs = q->d_njobs; a.max_jobs = q->max_rec;
+    a.jR = q->d_jR; a.jsoft = q->d_jsoft; a.jtmp = q->d_jtmp;
+    HIPCHK(hipMemsetAsync(q->d_njobs, 0, sizeof(uint32_t), st));
     RC(q->ev_begin(1, st));
     HIPCHK(sync_launch(a, st));
     RC(q->ev_end(1, st));

@@ -331,9 +331,34 @@ struct Walker {
     int drank[E], prank[E], erank[E];
     float2 R[E];
     float2 twx[6];              // cross-lane stage twiddles, stage h = 32 >> s
+    // working buffers: per channel (scout / serial walk) or per job (payload worker)
+    uint8_t *bsoft, *btmpa, *btmpb, *bhbits;
+    float2 *bsyms, *bR;
+    long long pre_off;          // >= 0: record space already reserved in the arena (payload worker)
+    int64_t handoff_last;       // scout: last event index of the frame just handed off
 
     __device__ Walker(const SyncArgs &a_, uint32_t ch_)
-        : a(a_), c(a_.c), l(lane_id()), ch(ch_) {}
+        : a(a_), c(a_.c), l(lane_id()), ch(ch_)
+    {
+        const size_t tstride = (size_t)c.max_enc_len + 16;
+        bsoft = a.soft + (size_t)ch * 8 * c.max_enc_len;
+        btmpa = a.tmpa + (size_t)ch * tstride; btmpb = a.tmpb + (size_t)ch * tstride;
+        bhbits = a.hbits + (size_t)ch * MCRX_HDR_SYMS;
+        bsyms = a.syms + (size_t)ch * c.max_syms;
+        bR = a.R + (size_t)ch * c.M;
+        pre_off = -1; handoff_last = 0;
+    }
+    __device__ void bind_job(uint32_t j, const PayloadJob &job)
+    {
+        const size_t tstride = (size_t)c.max_enc_len + 16;
+        bsoft = a.jsoft + (size_t)j * 8 * c.max_enc_len;
+        btmpa = a.jtmp + (size_t)j * 2 * tstride; btmpb = btmpa + tstride;
+        bR = a.jR + (size_t)j * c.M;
+        pre_off = (long long)job.arena_off;
+        const unsigned long long pbytes = ((unsigned long long)job.s.payload_len + 15ull) & ~15ull;
+        bsyms = reinterpret_cast<float2 *>(a.arena + job.arena_off + pbytes);
+        s = job.s;
+    }
 
     __device__ __forceinline__ float2 sample(int64_t t) const
     {
@@ -363,7 +388,7 @@ struct Walker {
             prank[e] = kk < 0 ? -1 : c.pilot_rank[kq];
             erank[e] = kk < 0 ? -1 : c.en_rank[kq];
             fx[e] = (kq > c.M2) ? (float)kq - (float)c.M : (float)kq;
-            R[e] = kk < 0 ? make_float2(0.f, 0.f) : a.R[(size_t)ch * c.M + kq];
+            R[e] = kk < 0 ? make_float2(0.f, 0.f) : bR[kq];
         }
 #pragma unroll
         for (int st = 0; st < 6; st++) {
@@ -479,8 +504,11 @@ struct Walker {
         const unsigned long long need = pbytes + 8ull * nsym;
         uint32_t idx = 0xFFFFFFFFu; unsigned long long off = 0;
         if (l == 0) {
-            off = atomicAdd(a.arena_used, need);
-            if (off + need <= a.arena_cap) idx = atomicAdd(a.nrec, 1u);
+            if (pre_off >= 0) { off = (unsigned long long)pre_off; idx = atomicAdd(a.nrec, 1u); }
+            else {
+                off = atomicAdd(a.arena_used, need);
+                if (off + need <= a.arena_cap) idx = atomicAdd(a.nrec, 1u);
+            }
             if (idx >= a.max_rec) { atomicAdd(a.nrec + 1, 1u); idx = 0xFFFFFFFFu; }
         }
         idx = (uint32_t)__shfl((int)idx, 0, WV);
@@ -500,21 +528,56 @@ struct Walker {
             a.rec[idx] = r;
         }
         if (with_payload && !oversize) {
-            const uint8_t *src = a.tmpb + (size_t)ch * (c.max_enc_len + 16);
+            const uint8_t *src = btmpb;
             uint8_t *dst = a.arena + off;
             for (uint32_t i = (uint32_t)l; i < plen; i += WV) dst[i] = src[i];
-            const float2 *ss = a.syms + (size_t)ch * c.max_syms;
-            float2 *ds = reinterpret_cast<float2 *>(a.arena + off + pbytes);
-            for (uint32_t i = (uint32_t)l; i < nsym; i += WV) ds[i] = ss[i];
+            if (pre_off < 0) {          // payload workers write framesyms straight into the record
+                const float2 *ss = bsyms;
+                float2 *ds = reinterpret_cast<float2 *>(a.arena + off + pbytes);
+                for (uint32_t i = (uint32_t)l; i < nsym; i += WV) ds[i] = ss[i];
+            }
         }
+    }
+
+    // scout: hand the payload of the frame whose header was just decoded to a worker wave
+    // if every payload symbol is already in the buffer.  Returns false to keep walking serially.
+    __device__ bool try_handoff(int64_t t_ev)
+    {
+        if (!a.scout) return false;
+        if (s.enc_len > c.max_enc_len || s.mod_len > c.max_syms || s.payload_len > c.max_payload_len) return false;
+        const int64_t nsym = (int64_t)((s.mod_len + (uint32_t)c.M_data - 1) / (uint32_t)c.M_data);
+        const int64_t t_last = t_ev + nsym * (int64_t)c.L;
+        if (t_last >= a.end) return false;
+        const unsigned long long pbytes = ((unsigned long long)s.payload_len + 15ull) & ~15ull;
+        const unsigned long long need = pbytes + 8ull * s.mod_len;
+        uint32_t j = 0xFFFFFFFFu; unsigned long long off = 0;
+        if (l == 0) {
+            j = atomicAdd(a.njobs, 1u);
+            if (j < a.max_jobs) {
+                off = atomicAdd(a.arena_used, need);
+                if (off + need > a.arena_cap) { a.jobs[j].ch = 0xFFFFFFFFu; j = 0xFFFFFFFEu; }  // void the slot
+            }
+        }
+        j = (uint32_t)__shfl((int)j, 0, WV);
+        off = (unsigned long long)__shfl((long long)off, 0, WV);
+        if (j >= a.max_jobs) return false;
+#pragma unroll
+        for (int e = 0; e < E; e++) if (k[e] >= 0) a.jR[(size_t)j * c.M + k[e]] = R[e];
+        if (l == 0) {
+            PayloadJob jb;
+            jb.s = s; jb.ch = ch; jb.pad = 0; jb.arena_off = off;
+            a.jobs[j] = jb;
+        }
+        handoff_last = t_last;
+        return true;
     }
 
     // header complete: decode and configure the payload receiver
     __device__ void decode_header()
     {
-        uint8_t *soft = a.soft + (size_t)ch * 8 * c.max_enc_len;
-        uint8_t *ta = a.tmpa + (size_t)ch * (c.max_enc_len + 16), *tb = a.tmpb + (size_t)ch * (c.max_enc_len + 16);
-        const uint8_t *hb = a.hbits + (size_t)ch * MCRX_HDR_SYMS;
+        uint8_t *soft = bsoft;
+        uint8_t *ta = btmpa, *tb = btmpb;
+        const uint8_t *hb = bhbits;
         __syncthreads();
         for (int i = l; i < MCRX_HDR_SYMS; i += WV) soft[i] = hb[i] ? 255 : 0;
         __syncthreads();
@@ -544,9 +607,10 @@ struct Walker {
     }
 
     // one received OFDM symbol X (equalised, de-rotated), flexible-frame level
-    __device__ bool flex_symbol(const float2 (&X)[E], int64_t t_ev)
+    // returns 0: frame continues, 1: frame finished (synchronizer resets), 2: payload handed off
+    __device__ int flex_symbol(const float2 (&X)[E], int64_t t_ev)
     {
-        uint8_t *hb = a.hbits + (size_t)ch * MCRX_HDR_SYMS;
+        uint8_t *hb = bhbits;
         if (s.fstate == FX_HEADER) {
             float ev = 0.f;
 #pragma unroll
@@ -566,15 +630,18 @@ struct Walker {
             if (s.header_symbol_index >= MCRX_HDR_SYMS) {
                 decode_header();
                 s.evm = 10.0f * log10f(s.evm_hat / (float)MCRX_HDR_SYMS);
-                if (s.header_valid) { s.fstate = FX_PAYLOAD; s.payload_symbol_index = 0; }
-                else { emit(t_ev, false, false); return true; }
+                if (s.header_valid) {
+                    s.fstate = FX_PAYLOAD; s.payload_symbol_index = 0;
+                    if (try_handoff(t_ev)) return 2;
+                }
+                else { emit(t_ev, false, false); return 1; }
             }
-            return false;
+            return 0;
         }
         // payload
         const bool oversize = s.enc_len > c.max_enc_len || s.mod_len > c.max_syms || s.payload_len > c.max_payload_len;
-        uint8_t *soft = a.soft + (size_t)ch * 8 * c.max_enc_len;
-        float2 *syms = a.syms + (size_t)ch * c.max_syms;
+        uint8_t *soft = bsoft;
+        float2 *syms = bsyms;
         const uint32_t nbits = 8 * s.enc_len;
         if (!oversize) {
 #pragma unroll
@@ -597,35 +664,89 @@ struct Walker {
             if (!oversize) {
                 __syncthreads();
                 valid = packet_decode(c.cod, c.payload_soft != 0, false, s.payload_len, s.check, s.fec0, s.fec1, soft,
-                                      a.tmpa + (size_t)ch * (c.max_enc_len + 16), a.tmpb + (size_t)ch * (c.max_enc_len + 16));
+                                      btmpa, btmpb);
             }
             emit(t_ev, true, valid, oversize);
-            return true;
+            return 1;
         }
-        return false;
+        return 0;
+    }
+
+    // one RXSYMBOLS event: FFT, equalise, pilot phase fit, de-rotate, NCO trim, frame level
+    __device__ int rx_event(int64_t t_ev)
+    {
+        const int L = c.L;
+        float2 X[E];
+        load_window(t_ev - L + 1 + c.cp - c.backoff, true, X);
+        fft(X);
+        // equalise, pilot phases
+        float *yph = ldsf;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            X[e] = cmul(X[e], R[e]);
+            if (prank[e] >= 0) {
+                const float pil = c.pilot_seq[(s.pilot_count + (uint32_t)prank[e]) % 255u] ? 1.0f : -1.0f;
+                yph[prank[e]] = atan2f(X[e].y * pil, X[e].x * pil);
+            }
+        }
+        __syncthreads();
+        float p0 = 0.f, p1 = 0.f, prev = 0.f;
+        for (int n = 0; n < c.M_pilot; n++) {
+            float v = yph[n];
+            if (n > 0) {
+                while ((v - prev) >  PI_F) v -= 2.0f * PI_F;
+                while ((v - prev) < -PI_F) v += 2.0f * PI_F;
+            }
+            prev = v;
+            p0 += c.Pfit[n] * v;
+            p1 += c.Pfit[c.M_pilot + n] * v;
+        }
+        __syncthreads();
+        s.pilot_count = (s.pilot_count + (uint32_t)c.M_pilot) % 255u;
+        p1 = 0.3f * p1 + (1.0f - 0.3f) * s.p1_prime;
+        s.p1_prime = p1;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            if (k[e] < 0 || sct[e] == 0) { X[e] = make_float2(0.f, 0.f); continue; }
+            const float theta = p0 + p1 * fx[e];
+            X[e] = mix_down(X[e], rad2u32(theta));
+        }
+        uint32_t new_dtheta = s.nco_dtheta;
+        if (s.num_symbols > 0) {
+            float dphi = p0 - s.phi_prime;
+            while (dphi >  PI_F) dphi -= 2.0f * PI_F;
+            while (dphi < -PI_F) dphi += 2.0f * PI_F;
+            new_dtheta += rad2u32(1e-3f * dphi);
+        }
+        // the frequency change applies to samples after this event
+        s.nco_theta_ref = s.nco_theta_ref + (uint32_t)(t_ev + 1 - s.nco_t_ref) * s.nco_dtheta;
+        s.nco_t_ref = t_ev + 1;
+        s.nco_dtheta = new_dtheta;
+        s.phi_prime = p0;
+        s.num_symbols++;
+        s.timer = (uint32_t)L;
+        return flex_symbol(X, t_ev);
+    }
+
+    // payload worker: run the symbols of one handed-off frame to its end
+    __device__ void run_job(uint32_t j)
+    {
+        const PayloadJob job = a.jobs[j];
+        bind_job(j, job);
+        init_consts();
+        while (true) {
+            const int64_t t_ev = s.cur + (int64_t)s.timer - 1;
+            if (t_ev >= a.end) break;               // cannot happen: the scout checked the frame fits
+            s.cur = t_ev + 1;
+            if (rx_event(t_ev) != 0) break;
+        }
     }
 
     __device__ void run()
     {
         s = a.st[ch];
-        if (a.debug == 2) return;
         init_consts();
-        if (a.debug == 3) return;
-        if (a.debug == 4) { float pw; float2 sh = s0_metric(c.M - 1, false, pw); if (l == 0 && sh.x == 12345.f) a.st[ch].g0 = pw; return; }
-        if (a.debug == 5) { float2 x[E]; load_window(0, false, x); if (x[0].x == 12345.f) a.st[ch].g0 = 1; return; }
-        if (a.debug >= 7 && a.debug <= 11) {
-            float2 x[E]; load_window(0, false, x); fft(x);
-            __syncthreads();
-            if (a.debug == 7) { if (k[0] >= 0) ldsc[k[0]] = x[0]; }
-            if (a.debug == 8) { if (k[E - 1] >= 0) ldsc[k[E - 1]] = x[E - 1]; }
-            if (a.debug == 9) { ldsc[l] = x[0]; }
-            if (a.debug == 10) { int bad = 0; for (int e = 0; e < E; e++) if (k[e] >= c.M || k[e] < -1) bad = 1; if (bad) a.st[ch].g0 = -777.f; }
-            if (a.debug == 11) { ldsc[l + WV * (E - 1)] = x[0]; }
-            __syncthreads();
-            if (ldsc[0].x == 12345.f) a.st[ch].g0 = 1;
-            return;
-        }
-        if (a.debug == 6) { float2 x[E]; load_window(0, false, x); fft(x); if (x[0].x == 12345.f) a.st[ch].g0 = 1; return; }
         const int M = c.M, M2 = c.M2, L = c.L;
         while (true) {
             // sample index of the next state-machine event
@@ -731,7 +852,7 @@ struct Walker {
                             r = make_float2(gr / d, -gi / d);
                         }
                         R[e] = r;
-                        if (k[e] >= 0) a.R[(size_t)ch * M + k[e]] = r;
+                        if (k[e] >= 0) bR[k[e]] = r;
                     }
                     __syncthreads();
                 } else {
@@ -739,57 +860,13 @@ struct Walker {
                     s.timer = (uint32_t)M2;
                 }
             } else {    // SY_RX
-                float2 X[E];
-                load_window(t_ev - L + 1 + c.cp - c.backoff, true, X);
-                fft(X);
-                // equalise, pilot phases
-                float *yph = ldsf;
-                __syncthreads();
-#pragma unroll
-                for (int e = 0; e < E; e++) {
-                    X[e] = cmul(X[e], R[e]);
-                    if (prank[e] >= 0) {
-                        const float pil = c.pilot_seq[(s.pilot_count + (uint32_t)prank[e]) % 255u] ? 1.0f : -1.0f;
-                        yph[prank[e]] = atan2f(X[e].y * pil, X[e].x * pil);
-                    }
+                const int fr = rx_event(t_ev);
+                if (fr == 1) { reset_framesync(); s.timer = (uint32_t)L; }
+                else if (fr == 2) {
+                    // payload handed to a worker: jump over it; liquid leaves the synchronizer in
+                    // SEEK with timer = M+cp after the frame's last symbol
+                    reset_framesync(); s.timer = (uint32_t)L; s.cur = handoff_last + 1;
                 }
-                __syncthreads();
-                float p0 = 0.f, p1 = 0.f, prev = 0.f;
-                for (int n = 0; n < c.M_pilot; n++) {
-                    float v = yph[n];
-                    if (n > 0) {
-                        while ((v - prev) >  PI_F) v -= 2.0f * PI_F;
-                        while ((v - prev) < -PI_F) v += 2.0f * PI_F;
-                    }
-                    prev = v;
-                    p0 += c.Pfit[n] * v;
-                    p1 += c.Pfit[c.M_pilot + n] * v;
-                }
-                __syncthreads();
-                s.pilot_count = (s.pilot_count + (uint32_t)c.M_pilot) % 255u;
-                p1 = 0.3f * p1 + (1.0f - 0.3f) * s.p1_prime;
-                s.p1_prime = p1;
-#pragma unroll
-                for (int e = 0; e < E; e++) {
-                    if (k[e] < 0 || sct[e] == 0) { X[e] = make_float2(0.f, 0.f); continue; }
-                    const float theta = p0 + p1 * fx[e];
-                    X[e] = mix_down(X[e], rad2u32(theta));
-                }
-                uint32_t new_dtheta = s.nco_dtheta;
-                if (s.num_symbols > 0) {
-                    float dphi = p0 - s.phi_prime;
-                    while (dphi >  PI_F) dphi -= 2.0f * PI_F;
-                    while (dphi < -PI_F) dphi += 2.0f * PI_F;
-                    new_dtheta += rad2u32(1e-3f * dphi);
-                }
-                // the frequency change applies to samples after this event
-                s.nco_theta_ref = s.nco_theta_ref + (uint32_t)(t_ev + 1 - s.nco_t_ref) * s.nco_dtheta;
-                s.nco_t_ref = t_ev + 1;
-                s.nco_dtheta = new_dtheta;
-                s.phi_prime = p0;
-                s.num_symbols++;
-                s.timer = (uint32_t)L;
-                if (flex_symbol(X, t_ev)) { reset_framesync(); s.timer = (uint32_t)L; }
             }
         }
         if (l == 0) a.st[ch] = s;
@@ -803,6 +880,20 @@ __global__ __launch_bounds__(WV) void sync_kernel(SyncArgs a)
     if (ch >= a.nch) return;
     Walker<E> w(a, ch);
     w.run();
+}
+
+// one wave per handed-off frame
+template <int E>
+__global__ __launch_bounds__(WV) void payload_kernel(SyncArgs a)
+{
+    const uint32_t j = blockIdx.x;
+    uint32_t nj = *a.njobs;
+    if (nj > a.max_jobs) nj = a.max_jobs;
+    if (j >= nj) return;
+    const uint32_t ch = a.jobs[j].ch;
+    if (ch >= a.nch) return;
+    Walker<E> w(a, ch);
+    w.run_job(j);
 }
 
 __global__ void sync_reset_kernel(ChanState *st, uint32_t nch, int64_t cur)
@@ -827,14 +918,19 @@ hipError_t sync_launch(const SyncArgs &a, hipStream_t st)
     const size_t lds = 0;
     if (a.c.M > SY_MAXM) return hipErrorInvalidValue;
     const int E = a.c.E;
+    const unsigned nj = a.scout ? a.max_jobs : 0;
+#define SY_LAUNCH(EE) \
+    hipLaunchKernelGGL((sync_kernel<EE>), dim3(a.nch), dim3(WV), lds, st, a); \
+    if (nj) hipLaunchKernelGGL((payload_kernel<EE>), dim3(nj), dim3(WV), lds, st, a);
     switch (E) {
-    case 1:  hipLaunchKernelGGL((sync_kernel<1>),  dim3(a.nch), dim3(WV), lds, st, a); break;
-    case 2:  hipLaunchKernelGGL((sync_kernel<2>),  dim3(a.nch), dim3(WV), lds, st, a); break;
-    case 4:  hipLaunchKernelGGL((sync_kernel<4>),  dim3(a.nch), dim3(WV), lds, st, a); break;
-    case 8:  hipLaunchKernelGGL((sync_kernel<8>),  dim3(a.nch), dim3(WV), lds, st, a); break;
-    case 16: hipLaunchKernelGGL((sync_kernel<16>), dim3(a.nch), dim3(WV), lds, st, a); break;
+    case 1:  SY_LAUNCH(1) break;
+    case 2:  SY_LAUNCH(2) break;
+    case 4:  SY_LAUNCH(4) break;
+    case 8:  SY_LAUNCH(8) break;
+    case 16: SY_LAUNCH(16) break;
     default: return hipErrorInvalidValue;
     }
+#undef SY_LAUNCH
     return hipGetLastError();
 }
 
