@@ -44,7 +44,7 @@ __device__ __forceinline__ unsigned mod_bps_d(unsigned m)
 { return m == 39 ? 1u : m == 40 ? 2u : m == 27 ? 4u : m == 29 ? 6u : 0u; }
 
 // ------------------------------------------------------------------ CRC-32, lane parallel
-__device__ uint32_t crc32_wave(const CodingDev &cod, const uint8_t *p, uint32_t n)
+__device__ uint32_t crc32_wave(const CodingDev cod, const uint8_t *p, uint32_t n)
 {
     const int l = lane_id();
     const uint32_t Lc = (n + WV - 1) / WV;
@@ -126,7 +126,7 @@ __device__ __forceinline__ unsigned h128_dec_sym(unsigned c)
     if (z && z <= 12) c ^= 1u << (12 - z);
     return (c & 0x00f) | ((c & 0x0e0) >> 1) | ((c & 0x200) >> 2);
 }
-__device__ unsigned h128_dec_soft_sym(const CodingDev &cod, const uint8_t *soft)
+__device__ unsigned h128_dec_soft_sym(const CodingDev cod, const uint8_t *soft)
 {
     unsigned sb[12], c = 0;
 #pragma unroll
@@ -223,7 +223,7 @@ __device__ void soft_pack(const uint8_t *soft, unsigned nbytes, uint8_t *out, bo
 
 // CRC -> fec0 -> il -> fec1 -> il, inverted.  `soft` holds 8 soft bits per packet byte
 // (8-byte aligned).  Result message in tmpb[0..n_msg); returns validity.
-__device__ bool packet_decode(const CodingDev &cod, bool soft_mode, bool scrambled, unsigned n_msg,
+__device__ bool packet_decode(const CodingDev cod, bool soft_mode, bool scrambled, unsigned n_msg,
                               unsigned crc, unsigned fec0, unsigned fec1,
                               uint8_t *soft, uint8_t *tmpa, uint8_t *tmpb)
 {
@@ -272,7 +272,7 @@ __device__ __forceinline__ uint8_t soft_clamp(float v)
 { int sb = (int)v; sb = sb > 255 ? 255 : sb; sb = sb < 0 ? 0 : sb; return (uint8_t)sb; }
 
 // soft demodulate r; writes bps soft bits (MSB first), returns hard symbol
-__device__ unsigned demod_soft(const CodingDev &cod, unsigned mod, cfd r, uint8_t *soft)
+__device__ __forceinline__ unsigned demod_soft(const CodingDev cod, unsigned mod, cfd r, uint8_t *soft)
 {
     if (mod == 39) {
         soft[0] = soft_clamp((-2.0f * r.x * 4.0f) * 16.0f + 127.0f);
@@ -337,7 +337,7 @@ struct Walker {
     long long pre_off;          // >= 0: record space already reserved in the arena (payload worker)
     int64_t handoff_last;       // scout: last event index of the frame just handed off
 
-    __device__ Walker(const SyncArgs &a_, uint32_t ch_)
+    __device__ __forceinline__ Walker(const SyncArgs &a_, uint32_t ch_)
         : a(a_), c(a_.c), l(lane_id()), ch(ch_)
     {
         const size_t tstride = (size_t)c.max_enc_len + 16;
@@ -348,7 +348,7 @@ struct Walker {
         bR = a.R + (size_t)ch * c.M;
         pre_off = -1; handoff_last = 0;
     }
-    __device__ void bind_job(uint32_t j, const PayloadJob &job)
+    __device__ __forceinline__ void bind_job(uint32_t j, const PayloadJob &job)
     {
         const size_t tstride = (size_t)c.max_enc_len + 16;
         bsoft = a.jsoft + (size_t)j * 8 * c.max_enc_len;
@@ -372,7 +372,7 @@ struct Walker {
         if (t >= s.nco_t_ref) v = mix_down(v, s.nco_theta_ref + (uint32_t)(t - s.nco_t_ref) * s.nco_dtheta);
         return v;
     }
-    __device__ void init_consts()
+    __device__ __forceinline__ void init_consts()
     {
 #pragma unroll
         for (int e = 0; e < E; e++) {
@@ -415,7 +415,7 @@ struct Walker {
         }
     }
     // forward DFT of x (time position i = l + 64 e) -> X[k[e]]
-    __device__ void fft(float2 (&x)[E])
+    __device__ __forceinline__ void fft(float2 (&x)[E])
     {
         if (c.log2M) {
             if constexpr (E >= 16) inlane_stage<8>(x);         // in-lane stages, h = 64 j
@@ -454,7 +454,7 @@ struct Walker {
             __syncthreads();
         }
     }
-    __device__ void load_window(int64_t t_start, bool mix, float2 (&x)[E])
+    __device__ __forceinline__ void load_window(int64_t t_start, bool mix, float2 (&x)[E])
     {
 #pragma unroll
         for (int e = 0; e < E; e++) {
@@ -463,7 +463,7 @@ struct Walker {
         }
     }
     // S0 gain estimate + metric on the newest M samples ending at t_ev; returns s_hat (not scaled by g)
-    __device__ float2 s0_metric(int64_t t_ev, bool mix, float &power)
+    __device__ __forceinline__ float2 s0_metric(int64_t t_ev, bool mix, float &power)
     {
         float2 x[E];
         load_window(t_ev - c.M + 1, mix, x);
@@ -488,7 +488,7 @@ struct Walker {
         return cscale(acc, 1.0f / (float)c.M_S0);
     }
     __device__ __forceinline__ unsigned hbyte(int i) const { return (s.hw[i >> 2] >> (8 * (i & 3))) & 0xffu; }
-    __device__ void reset_framesync()
+    __device__ __forceinline__ void reset_framesync()
     {
         s.state = SY_SEEK; s.timer = 0; s.num_symbols = 0; s.pilot_count = 0;
         s.nco_theta_ref = 0; s.nco_dtheta = 0; s.nco_t_ref = 0;
@@ -496,7 +496,7 @@ struct Walker {
         s.fstate = FX_HEADER; s.header_symbol_index = 0; s.payload_symbol_index = 0; s.evm_hat = 0.f;
     }
 
-    __device__ void emit(int64_t t_ev, bool with_payload, bool payload_valid, bool oversize = false)
+    __device__ __forceinline__ void emit(int64_t t_ev, bool with_payload, bool payload_valid, bool oversize = false)
     {
         const uint32_t nsym = (with_payload && !oversize) ? s.mod_len : 0u;
         const uint32_t plen = (with_payload && !oversize) ? s.payload_len : 0u;
@@ -541,7 +541,7 @@ struct Walker {
 
     // scout: hand the payload of the frame whose header was just decoded to a worker wave
     // if every payload symbol is already in the buffer.  Returns false to keep walking serially.
-    __device__ bool try_handoff(int64_t t_ev)
+    __device__ __forceinline__ bool try_handoff(int64_t t_ev)
     {
         if (!a.scout) return false;
         if (s.enc_len > c.max_enc_len || s.mod_len > c.max_syms || s.payload_len > c.max_payload_len) return false;
@@ -573,7 +573,7 @@ struct Walker {
     }
 
     // header complete: decode and configure the payload receiver
-    __device__ void decode_header()
+    __device__ __forceinline__ void decode_header()
     {
         uint8_t *soft = bsoft;
         uint8_t *ta = btmpa, *tb = btmpb;
@@ -608,7 +608,7 @@ struct Walker {
 
     // one received OFDM symbol X (equalised, de-rotated), flexible-frame level
     // returns 0: frame continues, 1: frame finished (synchronizer resets), 2: payload handed off
-    __device__ int flex_symbol(const float2 (&X)[E], int64_t t_ev)
+    __device__ __forceinline__ int flex_symbol(const float2 (&X)[E], int64_t t_ev)
     {
         uint8_t *hb = bhbits;
         if (s.fstate == FX_HEADER) {
@@ -673,7 +673,7 @@ struct Walker {
     }
 
     // one RXSYMBOLS event: FFT, equalise, pilot phase fit, de-rotate, NCO trim, frame level
-    __device__ int rx_event(int64_t t_ev)
+    __device__ __forceinline__ int rx_event(int64_t t_ev)
     {
         const int L = c.L;
         float2 X[E];
@@ -730,7 +730,7 @@ struct Walker {
     }
 
     // payload worker: run the symbols of one handed-off frame to its end
-    __device__ void run_job(uint32_t j)
+    __device__ __forceinline__ void run_job(uint32_t j)
     {
         const PayloadJob job = a.jobs[j];
         bind_job(j, job);
@@ -743,7 +743,7 @@ struct Walker {
         }
     }
 
-    __device__ void run()
+    __device__ __forceinline__ void run()
     {
         s = a.st[ch];
         init_consts();
@@ -873,9 +873,31 @@ struct Walker {
     }
 };
 
+// Pointers that arrive inside a by-value struct are generic ("flat") to the compiler: every
+// access becomes flat_load/flat_store, which also ties up the LDS/scalar wait counter.  Casting
+// through the global address space lets InferAddressSpaces turn them into global_* / s_load.
+template <class T> __device__ __forceinline__ T *as_global(T *p)
+{
+    typedef __attribute__((address_space(1))) T GT;
+    return (T *)(GT *)p;
+}
+#define LAUNDER(f) a.f = as_global(a.f)
+__device__ __forceinline__ void launder(SyncArgs &a)
+{
+    LAUNDER(c.sctype); LAUNDER(c.S0); LAUNDER(c.S1); LAUNDER(c.s0t); LAUNDER(c.Ssm); LAUNDER(c.Pfit);
+    LAUNDER(c.data_rank); LAUNDER(c.pilot_rank); LAUNDER(c.en_rank); LAUNDER(c.pilot_seq); LAUNDER(c.dft_tw);
+    LAUNDER(c.cod.h128_enc); LAUNDER(c.cod.h128_nb); LAUNDER(c.cod.h128_nnb); LAUNDER(c.cod.crc_byte);
+    LAUNDER(c.cod.crc_zadv); LAUNDER(c.cod.qam16_nb); LAUNDER(c.cod.qam64_nb);
+    LAUNDER(chan); LAUNDER(st); LAUNDER(hbits); LAUNDER(R); LAUNDER(soft); LAUNDER(tmpa); LAUNDER(tmpb);
+    LAUNDER(syms); LAUNDER(rec); LAUNDER(arena); LAUNDER(nrec); LAUNDER(arena_used);
+    LAUNDER(jobs); LAUNDER(njobs); LAUNDER(jR); LAUNDER(jsoft); LAUNDER(jtmp);
+}
+#undef LAUNDER
+
 template <int E>
 __global__ __launch_bounds__(WV) void sync_kernel(SyncArgs a)
 {
+    launder(a);
     const uint32_t ch = blockIdx.x;
     if (ch >= a.nch) return;
     Walker<E> w(a, ch);
@@ -886,6 +908,7 @@ __global__ __launch_bounds__(WV) void sync_kernel(SyncArgs a)
 template <int E>
 __global__ __launch_bounds__(WV) void payload_kernel(SyncArgs a)
 {
+    launder(a);
     const uint32_t j = blockIdx.x;
     uint32_t nj = *a.njobs;
     if (nj > a.max_jobs) nj = a.max_jobs;
