@@ -314,8 +314,22 @@ __device__ __forceinline__ unsigned demod_soft(const CodingDev cod, unsigned mod
 // ------------------------------------------------------------------ the walker
 // Wave-private LDS scratch, referenced by name so every access is a ds_* instruction.
 #define SY_MAXM 1024
-__shared__ __attribute__((aligned(16))) float2 ldsc[SY_MAXM];     // complex scratch [M]
-__shared__ __attribute__((aligned(16))) float ldsf[2 * SY_MAXM];   // float scratch [2*M]
+extern __shared__ __attribute__((aligned(16))) float2 sy_lds[];
+#define ldsc  sy_lds                                                          /* complex scratch [M]   */
+#define ldsf  (reinterpret_cast<float *>(sy_lds + c.M))                       /* float scratch  [2*M]  */
+#define ldspf (reinterpret_cast<float *>(sy_lds + c.M) + 2 * c.M)             /* pilot fit rows [M]    */
+#define ldsps (reinterpret_cast<uint8_t *>(reinterpret_cast<float *>(sy_lds + c.M) + 3 * c.M))  /* pilot bits [256] */
+#define SY_LDS_BYTES(M) ((size_t)(M) * 8 + (size_t)(M) * 12 + 256)
+
+// One wavefront per workgroup: LDS traffic of a wave is processed in order, so a compiler-level
+// fence is all the hand-off between lanes needs (no s_barrier, and no vmcnt(0) drain of the
+// outstanding global stores that __syncthreads() would add).
+__device__ __forceinline__ void wave_sync_lds()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 template <int E>
 struct Walker {
@@ -396,6 +410,10 @@ struct Walker {
             float sn, cs; sincos_u32((uint32_t)(l & (h - 1)) * (uint32_t)(0x80000000u / (unsigned)h), sn, cs);
             twx[st] = make_float2(cs, -sn);
         }
+        // per-symbol tables into LDS (they sit on the symbol loop's dependency chain)
+        for (int i = l; i < 255; i += WV) ldsps[i] = c.pilot_seq[i];
+        for (int i = l; i < 2 * c.M_pilot; i += WV) ldspf[i] = c.Pfit[i];
+        wave_sync_lds();
     }
     template <int J>
     __device__ __forceinline__ void inlane_stage(float2 (&x)[E])
@@ -435,10 +453,10 @@ struct Walker {
                 }
             }
         } else {
-            __syncthreads();
+            wave_sync_lds();
 #pragma unroll
             for (int e = 0; e < E; e++) { const int i = l + WV * e; if (i < c.M) ldsc[i] = x[e]; }
-            __syncthreads();
+            wave_sync_lds();
 #pragma unroll
             for (int e = 0; e < E; e++) {
                 float2 acc = make_float2(0.f, 0.f);
@@ -451,7 +469,23 @@ struct Walker {
                 }
                 x[e] = acc;
             }
-            __syncthreads();
+            wave_sync_lds();
+        }
+    }
+    __device__ __forceinline__ void load_raw(int64_t t_start, float2 (&x)[E])
+    {
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int i = l + WV * e;
+            x[e] = (i < c.M) ? sample(t_start + i) : make_float2(0.f, 0.f);
+        }
+    }
+    __device__ __forceinline__ void mix_window(int64_t t_start, float2 (&x)[E])
+    {
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int64_t t = t_start + l + WV * e;
+            if (t >= s.nco_t_ref) x[e] = mix_down(x[e], s.nco_theta_ref + (uint32_t)(t - s.nco_t_ref) * s.nco_dtheta);
         }
     }
     __device__ __forceinline__ void load_window(int64_t t_start, bool mix, float2 (&x)[E])
@@ -473,10 +507,10 @@ struct Walker {
         power = wave_sum(pw);
         fft(x);
         const float gain = sqrtf((float)c.M_S0) / (float)c.M;
-        __syncthreads();
+        wave_sync_lds();
 #pragma unroll
         for (int e = 0; e < E; e++) if (k[e] >= 0) { x[e] = cscale(x[e], S0v[e] * gain); ldsc[k[e]] = x[e]; }
-        __syncthreads();
+        wave_sync_lds();
         float2 acc = make_float2(0.f, 0.f);
 #pragma unroll
         for (int e = 0; e < E; e++) if (k[e] >= 0 && (k[e] & 1) == 0) {
@@ -484,7 +518,7 @@ struct Walker {
             acc = cadd(acc, cmulc(ldsc[kn], x[e]));
         }
         acc = wave_csum(acc);
-        __syncthreads();
+        wave_sync_lds();
         return cscale(acc, 1.0f / (float)c.M_S0);
     }
     __device__ __forceinline__ unsigned hbyte(int i) const { return (s.hw[i >> 2] >> (8 * (i & 3))) & 0xffu; }
@@ -675,22 +709,28 @@ struct Walker {
     // one RXSYMBOLS event: FFT, equalise, pilot phase fit, de-rotate, NCO trim, frame level
     __device__ __forceinline__ int rx_event(int64_t t_ev)
     {
-        const int L = c.L;
         float2 X[E];
-        load_window(t_ev - L + 1 + c.cp - c.backoff, true, X);
+        load_raw(t_ev - c.L + 1 + c.cp - c.backoff, X);
+        return rx_core(t_ev, X);
+    }
+    // X: raw (unmixed) window samples of the symbol
+    __device__ __forceinline__ int rx_core(int64_t t_ev, float2 (&X)[E])
+    {
+        const int L = c.L;
+        mix_window(t_ev - L + 1 + c.cp - c.backoff, X);
         fft(X);
         // equalise, pilot phases
         float *yph = ldsf;
-        __syncthreads();
+        wave_sync_lds();
 #pragma unroll
         for (int e = 0; e < E; e++) {
             X[e] = cmul(X[e], R[e]);
             if (prank[e] >= 0) {
-                const float pil = c.pilot_seq[(s.pilot_count + (uint32_t)prank[e]) % 255u] ? 1.0f : -1.0f;
+                const float pil = ldsps[(s.pilot_count + (uint32_t)prank[e]) % 255u] ? 1.0f : -1.0f;
                 yph[prank[e]] = atan2f(X[e].y * pil, X[e].x * pil);
             }
         }
-        __syncthreads();
+        wave_sync_lds();
         float p0 = 0.f, p1 = 0.f, prev = 0.f;
         for (int n = 0; n < c.M_pilot; n++) {
             float v = yph[n];
@@ -699,10 +739,10 @@ struct Walker {
                 while ((v - prev) < -PI_F) v += 2.0f * PI_F;
             }
             prev = v;
-            p0 += c.Pfit[n] * v;
-            p1 += c.Pfit[c.M_pilot + n] * v;
+            p0 += ldspf[n] * v;
+            p1 += ldspf[c.M_pilot + n] * v;
         }
-        __syncthreads();
+        wave_sync_lds();
         s.pilot_count = (s.pilot_count + (uint32_t)c.M_pilot) % 255u;
         p1 = 0.3f * p1 + (1.0f - 0.3f) * s.p1_prime;
         s.p1_prime = p1;
@@ -735,11 +775,24 @@ struct Walker {
         const PayloadJob job = a.jobs[j];
         bind_job(j, job);
         init_consts();
+        const int64_t woff = (int64_t)(c.cp - c.backoff) - (int64_t)c.L + 1;
+        float2 cur[E];
+        load_raw(s.cur + (int64_t)s.timer - 1 + woff, cur);
         while (true) {
             const int64_t t_ev = s.cur + (int64_t)s.timer - 1;
             if (t_ev >= a.end) break;               // cannot happen: the scout checked the frame fits
             s.cur = t_ev + 1;
-            if (rx_event(t_ev) != 0) break;
+            // the next symbol's window address is known now: fetch it under this symbol's work
+            float2 nxt[E];
+            const int64_t t_nx = t_ev + (int64_t)c.L;
+            if (t_nx < a.end) load_raw(t_nx + woff, nxt);
+            else {
+#pragma unroll
+                for (int e = 0; e < E; e++) nxt[e] = make_float2(0.f, 0.f);
+            }
+            if (rx_core(t_ev, cur) != 0) break;
+#pragma unroll
+            for (int e = 0; e < E; e++) cur[e] = nxt[e];
         }
     }
 
@@ -803,10 +856,10 @@ struct Walker {
                 load_window(t_ev - M + 1, true, x);
                 fft(x);
                 const float gain = sqrtf((float)c.M_S1) / (float)M;
-                __syncthreads();
+                wave_sync_lds();
 #pragma unroll
                 for (int e = 0; e < E; e++) if (k[e] >= 0) { x[e] = cscale(x[e], S1v[e] * gain); ldsc[k[e]] = x[e]; }
-                __syncthreads();
+                wave_sync_lds();
                 float2 acc = make_float2(0.f, 0.f);
 #pragma unroll
                 for (int e = 0; e < E; e++) if (k[e] >= 0) {
@@ -823,14 +876,14 @@ struct Walker {
                     // equaliser: order-4 LSQ smoothing of |G| and unwrapped arg G, R = 1/G
                     const float g = (float)M / sqrtf((float)(c.M_pilot + c.M_data));
                     float *yabs = ldsf, *yarg = ldsf + c.Nen;
-                    __syncthreads();
+                    wave_sync_lds();
 #pragma unroll
                     for (int e = 0; e < E; e++) if (erank[e] >= 0) {
                         const float2 G = cscale(x[e], g);
                         yabs[erank[e]] = sqrtf(G.x * G.x + G.y * G.y);
                         yarg[erank[e]] = atan2f(G.y, G.x);
                     }
-                    __syncthreads();
+                    wave_sync_lds();
                     if (l == 0) {
                         for (int i = 1; i < c.Nen; i++) {
                             float v = yarg[i];
@@ -839,7 +892,7 @@ struct Walker {
                             yarg[i] = v;
                         }
                     }
-                    __syncthreads();
+                    wave_sync_lds();
 #pragma unroll
                     for (int e = 0; e < E; e++) {
                         float2 r = make_float2(0.f, 0.f);
@@ -854,7 +907,7 @@ struct Walker {
                         R[e] = r;
                         if (k[e] >= 0) bR[k[e]] = r;
                     }
-                    __syncthreads();
+                    wave_sync_lds();
                 } else {
                     if (s.num_symbols == 16) reset_framesync();
                     s.timer = (uint32_t)M2;
@@ -906,7 +959,7 @@ __global__ __launch_bounds__(WV) void sync_kernel(SyncArgs a)
 
 // one wave per handed-off frame
 template <int E>
-__global__ __launch_bounds__(WV) void payload_kernel(SyncArgs a)
+__global__ __launch_bounds__(WV, 4) void payload_kernel(SyncArgs a)
 {
     launder(a);
     const uint32_t j = blockIdx.x;
@@ -938,7 +991,7 @@ hipError_t sync_reset_launch(ChanState *st, uint32_t nch, int64_t cur, hipStream
 hipError_t sync_launch(const SyncArgs &a, hipStream_t st)
 {
     if (a.nch == 0) return hipSuccess;
-    const size_t lds = 0;
+    const size_t lds = SY_LDS_BYTES(a.c.M);
     if (a.c.M > SY_MAXM) return hipErrorInvalidValue;
     const int E = a.c.E;
     const unsigned nj = a.scout ? a.max_jobs : 0;
