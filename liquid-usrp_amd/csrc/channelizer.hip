@@ -13,11 +13,16 @@
 // Mapping: a workgroup owns NS time slabs; a thread owns C adjacent columns n of one slab
 // and walks down the time axis with a register sliding window (13 history + 8 new blocks),
 // so every IQ sample is loaded from HBM exactly once (plus a 13-block halo per slab).
-// Rounds of 8 blocks land in an LDS tile, are transformed in place (radix-4 DIF, twiddles
-// staged in LDS), and the kept bins leave as 64-byte (channel, tile) granules:
-//   out[g][tile][c][8],  channel = g*Cg + c  -- the layout the synchronizer streams and
-// the per-destination chunking an xGMI all-to-all needs.
-// HBM-bound by design: 8 B read + 4 B written per wideband sample.
+// Rounds of 8 blocks land in an LDS tile and are transformed in place:
+//   * radix-4 DIF stages through LDS while the sub-transform is larger than 16 points
+//     (twiddles are loop invariant per thread and live in registers);
+//   * the remaining F-point (F = 2..16) transforms entirely in registers, one group per
+//     thread; the tile is padded by one element per F so that this stage, whose lanes are
+//     F elements apart, is LDS bank-conflict free.
+// The kept bins leave as 64-byte (channel, tile) granules
+//   out[g][tile][c][8],  channel = g*Cg + c
+// -- the layout the synchronizer streams and the per-destination chunking an xGMI
+// all-to-all needs.  HBM-bound by design: 8 B read + 4 B written per wideband sample.
 #include "devmath.h"
 #include "kernels.h"
 
@@ -30,15 +35,57 @@ namespace mcrx {
 template <int K> struct Log2 { enum { v = 1 + Log2<K / 2>::v }; };
 template <> struct Log2<1> { enum { v = 0 }; };
 
-// position of bin k after the in-place mixed radix-(4,...,4[,2]) DIF
+// transform plan: S radix-4 LDS stages, then F-point register transforms
+template <int K> struct Plan {
+    static constexpr int stages() { int L = K, s = 0; while (L > 16) { L /= 4; s++; } return s; }
+    static constexpr int final_size() { int L = K; while (L > 16) L /= 4; return L; }
+    enum { S = stages(), F = final_size(), RL = K + K / F, ROWP = RL + 1 };
+};
+// element index -> padded LDS index within a row
+template <int K> __device__ __forceinline__ int pad(int e) { return e + e / Plan<K>::F; }
+// position of bin k after the S DIF stages followed by natural-order F-point transforms
 template <int K>
 __device__ __forceinline__ int dif_pos(int k)
 {
     int L = K, pos = 0;
 #pragma unroll
-    for (int s = 0; s < Log2<K>::v / 2; s++) { pos += (k & 3) * (L >> 2); k >>= 2; L >>= 2; }
-    if (Log2<K>::v & 1) pos += (k & 1);
-    return pos;
+    for (int s = 0; s < Plan<K>::S; s++) { pos += (k & 3) * (L >> 2); k >>= 2; L >>= 2; }
+    return pos + k;
+}
+
+// exp(-j 2 pi k / 16), k = 0..7
+__device__ __forceinline__ float2 w16(int k)
+{
+    const float c[8] = { 1.0f, 0.92387953251f, 0.70710678119f, 0.38268343236f, 0.0f, -0.38268343236f, -0.70710678119f, -0.92387953251f };
+    const float s[8] = { 0.0f, -0.38268343236f, -0.70710678119f, -0.92387953251f, -1.0f, -0.92387953251f, -0.70710678119f, -0.38268343236f };
+    return make_float2(c[k], s[k]);
+}
+constexpr int bitrev_c(int i, int bits) { int r = 0; for (int b = 0; b < bits; b++) if (i & (1 << b)) r |= 1 << (bits - 1 - b); return r; }
+
+// F-point forward DFT in registers, natural order in and out
+template <int F>
+__device__ __forceinline__ void fft_reg(float2 (&v)[F])
+{
+#pragma unroll
+    for (int h = F / 2; h >= 1; h >>= 1) {
+#pragma unroll
+        for (int i = 0; i < F; i++) {
+            if ((i & h) == 0) {
+                const float2 u = v[i], w = v[i + h];
+                v[i] = cadd(u, w);
+                const float2 d = csub(u, w);
+                const int tk = (i & (h - 1)) * (8 / h);       // W_{2h}^{i mod h} as a power of W_16
+                if (tk == 0) v[i + h] = d;
+                else if (tk == 4) v[i + h] = cmulnj(d);
+                else v[i + h] = cmul(d, w16(tk));
+            }
+        }
+    }
+    float2 t[F];
+#pragma unroll
+    for (int i = 0; i < F; i++) t[bitrev_c(i, Log2<F>::v)] = v[i];
+#pragma unroll
+    for (int i = 0; i < F; i++) v[i] = t[i];
 }
 
 template <int K, int C, int T>
@@ -46,13 +93,11 @@ __global__ __launch_bounds__(T) void channelizer_kernel(ChanArgs a)
 {
     constexpr int TPS = K / C;              // threads per slab
     constexpr int NS = T / TPS;             // slabs per workgroup
-    constexpr int ROW = K + 1;              // padded row (complex elements)
     constexpr int N = K / 2;
+    constexpr int S = Plan<K>::S, F = Plan<K>::F, ROWP = Plan<K>::ROWP;
     static_assert(TPS * C == K && NS * TPS == T && NS >= 1, "bad channelizer geometry");
 
-    extern __shared__ __attribute__((aligned(16))) float2 lds[];
-    float2 *tile = lds;                                 // [NS][CH_R][ROW]
-    float2 *twid = lds + NS * CH_R * ROW;               // [K]  W_K^k
+    extern __shared__ __attribute__((aligned(16))) float2 tile[];     // [NS][CH_R][ROWP]
 
     const int tid = threadIdx.x;
     const int sl = tid / TPS, cg = tid % TPS;
@@ -61,17 +106,26 @@ __global__ __launch_bounds__(T) void channelizer_kernel(ChanArgs a)
     const long long bs = slab * (long long)a.slab_blocks;        // first block of my slab
     const bool active = bs < (long long)a.nblocks;
 
-    for (int k = tid; k < K; k += T) {
-        float s, c; sincos_u32((uint32_t)k * (uint32_t)(4294967296.0 / K), s, c);
-        twid[k] = make_float2(c, -s);
-    }
-
     // taps: tap[j][c] = h[K-1-n + j*K]
     float tap[CH_P][C];
 #pragma unroll
     for (int j = 0; j < CH_P; j++)
 #pragma unroll
         for (int c = 0; c < C; c++) tap[j][c] = a.taps[(K - 1 - (n0 + c)) + j * K];
+
+    // radix-4 stage twiddles W_L^{r*pos}, r = 1..3: pos = q % (L/4) does not depend on the
+    // loop trip because L/4 divides the workgroup size
+    float2 tw[S > 0 ? S : 1][3];
+#pragma unroll
+    for (int st = 0; st < S; st++) {
+        const int L = K >> (2 * st), q4 = L >> 2;
+        const int pos = tid % q4;
+#pragma unroll
+        for (int r = 1; r <= 3; r++) {
+            float sn, cs; sincos_u32((uint32_t)(r * pos) * (uint32_t)(4294967296.0 / L), sn, cs);
+            tw[st][r - 1] = make_float2(cs, -sn);
+        }
+    }
 
     const uint32_t dth = a.dtheta;
     const uint32_t t0 = a.first_sample_lo;
@@ -121,7 +175,7 @@ __global__ __launch_bounds__(T) void channelizer_kernel(ChanArgs a)
                         v[c].y += tap[j][c] * s[CH_H + r - j][c].y;
                     }
                 }
-                float2 *row = tile + (sl * CH_R + r) * ROW + n0;
+                float2 *row = tile + (sl * CH_R + r) * ROWP + pad<K>(n0);    // n0, n0+1 share a pad group
 #pragma unroll
                 for (int c = 0; c < C; c++) row[c] = v[c];
             }
@@ -132,40 +186,39 @@ __global__ __launch_bounds__(T) void channelizer_kernel(ChanArgs a)
         }
         __syncthreads();
 
-        // ---- NS*CH_R independent K-point FFTs in LDS, in place, radix-4 DIF
-        constexpr int NBF4 = NS * CH_R * (K / 4);       // radix-4 butterflies per stage
-        constexpr int LOG2K = Log2<K>::v;
-        int L = K;
-        if constexpr (LOG2K >= 2) {
+        // ---- NS*CH_R independent K-point FFTs, in place
+        if constexpr (S > 0) {
+            constexpr int NBF4 = NS * CH_R * (K / 4);       // radix-4 butterflies per stage
 #pragma unroll
-        for (int st = 0; st < LOG2K / 2; st++) {
-            const int q4 = L >> 2;
-            for (int q = tid; q < NBF4; q += T) {
-                const int f = q / (K / 4), j = q % (K / 4);
-                const int grp = j / q4, pos = j % q4;
-                float2 *base = tile + f * ROW + grp * L + pos;
-                float2 x0 = base[0], x1 = base[q4], x2 = base[2 * q4], x3 = base[3 * q4];
-                float2 a0 = cadd(x0, x2), a1 = csub(x0, x2), a2 = cadd(x1, x3), a3 = cmulnj(csub(x1, x3));
-                float2 y0 = cadd(a0, a2), y1 = cadd(a1, a3), y2 = csub(a0, a2), y3 = csub(a1, a3);
-                if (q4 > 1) {
-                    const int ts = K / L;               // twiddle stride
-                    y1 = cmul(y1, twid[pos * ts]);
-                    y2 = cmul(y2, twid[2 * pos * ts]);
-                    y3 = cmul(y3, twid[3 * pos * ts]);
+            for (int st = 0; st < S; st++) {
+                const int L = K >> (2 * st), q4 = L >> 2;
+                for (int q = tid; q < NBF4; q += T) {
+                    const int f = q / (K / 4), j = q % (K / 4);
+                    const int grp = j / q4, pos = j % q4;
+                    float2 *row = tile + f * ROWP;
+                    const int e0 = grp * L + pos;
+                    const int i0 = pad<K>(e0), i1 = pad<K>(e0 + q4), i2 = pad<K>(e0 + 2 * q4), i3 = pad<K>(e0 + 3 * q4);
+                    const float2 x0 = row[i0], x1 = row[i1], x2 = row[i2], x3 = row[i3];
+                    const float2 a0 = cadd(x0, x2), a1 = csub(x0, x2), a2 = cadd(x1, x3), a3 = cmulnj(csub(x1, x3));
+                    row[i0] = cadd(a0, a2);
+                    row[i1] = cmul(cadd(a1, a3), tw[st][0]);
+                    row[i2] = cmul(csub(a0, a2), tw[st][1]);
+                    row[i3] = cmul(csub(a1, a3), tw[st][2]);
                 }
-                base[0] = y0; base[q4] = y1; base[2 * q4] = y2; base[3 * q4] = y3;
+                __syncthreads();
             }
-            __syncthreads();
-            L >>= 2;
         }
-        }
-        if (LOG2K & 1) {                                 // final radix-2 stage (L == 2)
-            constexpr int NBF2 = NS * CH_R * (K / 2);
-            for (int q = tid; q < NBF2; q += T) {
-                const int f = q / (K / 2), j = q % (K / 2);
-                float2 *base = tile + f * ROW + 2 * j;
-                float2 x0 = base[0], x1 = base[1];
-                base[0] = cadd(x0, x1); base[1] = csub(x0, x1);
+        {
+            constexpr int NG = NS * CH_R * (K / F);         // F-point groups
+            for (int g = tid; g < NG; g += T) {
+                const int f = g / (K / F), gi = g % (K / F);
+                float2 *p = tile + f * ROWP + gi * (F + 1);  // == pad(gi * F)
+                float2 v[F];
+#pragma unroll
+                for (int m = 0; m < F; m++) v[m] = p[m];
+                fft_reg<F>(v);
+#pragma unroll
+                for (int m = 0; m < F; m++) p[m] = v[m];
             }
             __syncthreads();
         }
@@ -178,9 +231,9 @@ __global__ __launch_bounds__(T) void channelizer_kernel(ChanArgs a)
             const long long oslab = (long long)blockIdx.x * NS + osl;
             const long long ob0 = oslab * (long long)a.slab_blocks + (long long)rd * CH_R;
             if (ob0 < (long long)a.nblocks) {
-                const int pos = dif_pos<K>(ch);
-                const float2 *src = tile + (osl * CH_R + 2 * rp) * ROW + pos;
-                float2 v0 = src[0], v1 = src[ROW];
+                const int pos = pad<K>(dif_pos<K>(ch));
+                const float2 *src = tile + (osl * CH_R + 2 * rp) * ROWP + pos;
+                float2 v0 = src[0], v1 = src[ROWP];
                 const long long tl = ob0 / CH_R;
                 const int g = ch / a.cg, c = ch % a.cg;
                 float4 *dst = reinterpret_cast<float4 *>(
@@ -196,7 +249,7 @@ template <int K, int C, int T>
 static hipError_t launch_one(const ChanArgs &a, hipStream_t st)
 {
     constexpr int NS = T / (K / C);
-    size_t lds = (size_t)(NS * CH_R * (K + 1) + K) * sizeof(float2);
+    size_t lds = (size_t)(NS * CH_R * Plan<K>::ROWP) * sizeof(float2);
     long long nslabs = ((long long)a.nblocks + a.slab_blocks - 1) / a.slab_blocks;
     unsigned grid = (unsigned)((nslabs + NS - 1) / NS);
     if (grid == 0) return hipSuccess;
