@@ -32,6 +32,13 @@ namespace mcrx {
 #define CH_P 14         // taps per branch (m = 7)
 #define CH_H (CH_P - 1) // history blocks
 
+// Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain
+// vmcnt, so the prefetched IQ loads and the granule stores stay in flight across it.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int K> struct Log2 { enum { v = 1 + Log2<K / 2>::v }; };
 template <> struct Log2<1> { enum { v = 0 }; };
 
@@ -62,7 +69,7 @@ __device__ __forceinline__ float2 w16(int k)
 }
 constexpr int bitrev_c(int i, int bits) { int r = 0; for (int b = 0; b < bits; b++) if (i & (1 << b)) r |= 1 << (bits - 1 - b); return r; }
 
-// F-point forward DFT in registers, natural order in and out
+// F-point forward DFT in registers: natural order in, bit-reversed order out
 template <int F>
 __device__ __forceinline__ void fft_reg(float2 (&v)[F])
 {
@@ -81,12 +88,7 @@ __device__ __forceinline__ void fft_reg(float2 (&v)[F])
             }
         }
     }
-    float2 t[F];
-#pragma unroll
-    for (int i = 0; i < F; i++) t[bitrev_c(i, Log2<F>::v)] = v[i];
-#pragma unroll
-    for (int i = 0; i < F; i++) v[i] = t[i];
-}
+}   // result: v[i] holds X[bitrev(i)]; callers store v[i] at index bitrev_c(i, log2 F)
 
 template <int K, int C, int T>
 __global__ __launch_bounds__(T) void channelizer_kernel(ChanArgs a)
@@ -184,10 +186,10 @@ __global__ __launch_bounds__(T) void channelizer_kernel(ChanArgs a)
 #pragma unroll
                 for (int c = 0; c < C; c++) s[i][c] = s[i + CH_R][c];
         }
-        __syncthreads();
+        lds_barrier();
 
         // ---- NS*CH_R independent K-point FFTs, in place
-        if constexpr (S > 0) {
+        if constexpr (S > 0) if (!(a.ablate & 2)) {
             constexpr int NBF4 = NS * CH_R * (K / 4);       // radix-4 butterflies per stage
 #pragma unroll
             for (int st = 0; st < S; st++) {
@@ -205,10 +207,10 @@ __global__ __launch_bounds__(T) void channelizer_kernel(ChanArgs a)
                     row[i2] = cmul(csub(a0, a2), tw[st][1]);
                     row[i3] = cmul(csub(a1, a3), tw[st][2]);
                 }
-                __syncthreads();
+                lds_barrier();
             }
         }
-        {
+        if (!(a.ablate & 4)) {
             constexpr int NG = NS * CH_R * (K / F);         // F-point groups
             for (int g = tid; g < NG; g += T) {
                 const int f = g / (K / F), gi = g % (K / F);
@@ -218,9 +220,9 @@ __global__ __launch_bounds__(T) void channelizer_kernel(ChanArgs a)
                 for (int m = 0; m < F; m++) v[m] = p[m];
                 fft_reg<F>(v);
 #pragma unroll
-                for (int m = 0; m < F; m++) p[m] = v[m];
+                for (int m = 0; m < F; m++) p[bitrev_c(m, Log2<F>::v)] = v[m];
             }
-            __syncthreads();
+            lds_barrier();
         }
 
         // ---- store bins 0..N-1 as (channel, tile) granules of 8 time samples (64 B)
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(T) void channelizer_kernel(ChanArgs a)
             const int ch = rem / (CH_R / 2), rp = rem % (CH_R / 2);
             const long long oslab = (long long)blockIdx.x * NS + osl;
             const long long ob0 = oslab * (long long)a.slab_blocks + (long long)rd * CH_R;
-            if (ob0 < (long long)a.nblocks) {
+            if (ob0 < (long long)a.nblocks && !(a.ablate & 8)) {
                 const int pos = pad<K>(dif_pos<K>(ch));
                 const float2 *src = tile + (osl * CH_R + 2 * rp) * ROWP + pos;
                 float2 v0 = src[0], v1 = src[ROWP];
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(T) void channelizer_kernel(ChanArgs a)
                 *dst = make_float4(v0.x, v0.y, v1.x, v1.y);
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 

@@ -320,6 +320,7 @@ static int launch_channelizer(mcrx_hip_t q, const float2 *x, size_t nblocks, uin
     a.nblocks = (uint32_t)nblocks; a.slab_blocks = q->slab_blocks;
     a.first_sample_lo = (uint32_t)first_sample; a.dtheta = q->dtheta;
     a.ntiles = (uint32_t)ntiles_stride; a.cg = q->N / groups;
+    a.ablate = getenv("MCRX_ABLATE") ? (uint32_t)atoi(getenv("MCRX_ABLATE")) : 0u;
     RC(q->ev_begin(0, st));
     HIPCHK(channelizer_launch(q->K, a, st));
     RC(q->ev_end(0, st));
