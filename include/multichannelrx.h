@@ -1,0 +1,46 @@
+// multichannelrx.h -- MI355X-native multichannel OFDM receiver, source compatible with
+// liquid-usrp's class of the same name (reference: include/multichannelrx.h:29-58 for the
+// public interface; lib/multichannelrx.cc for the behaviour).
+//
+// Differences visible to callers, all forced by batching on the GPU:
+//   * callbacks fire on the calling thread at flush points -- when the internal staging buffer
+//     fills inside Execute(), in Reset(), in Flush() and in the destructor -- in the reference's
+//     order (frame end time, then channel index), not synchronously per sample;
+//   * samples are consumed in whole tiles of 8 channelizer blocks (16*N samples); a shorter
+//     tail waits for more input;
+//   * the reference's BST_DEBUG file dump at destruction (lib/multichannelrx.cc:118-122) is gone.
+#ifndef LIQUID_USRP_AMD_MULTICHANNELRX_H
+#define LIQUID_USRP_AMD_MULTICHANNELRX_H
+
+#include <complex>
+#include <liquid/liquid.h>
+
+class multichannelrx {
+public:
+    // num_channels >= 1 (2*num_channels a power of two <= 1024), M >= 8 subcarriers, cp_len >= 1,
+    // taper_len <= cp_len, p = subcarrier allocation or NULL, per-channel userdata / callbacks
+    // (both arrays are copied).  Invalid arguments: message on stderr and `throw 0`, like the
+    // reference (lib/multichannelrx.cc:54-66).
+    multichannelrx(unsigned int _num_channels, unsigned int _M, unsigned int _cp_len,
+                   unsigned int _taper_len, unsigned char *_p, void **_userdata,
+                   framesync_callback *_callback);
+    ~multichannelrx();
+
+    void Reset();
+    unsigned int GetNumChannels() { return num_channels; }
+    void Execute(std::complex<float> *_x, unsigned int _num_samples);
+
+    // additions
+    void Flush();                               // process what is buffered, deliver callbacks
+    void ExecuteDevice(const void *_d_x, unsigned int _num_samples);   // samples already in HBM
+
+private:
+    multichannelrx(const multichannelrx &);
+    multichannelrx &operator=(const multichannelrx &);
+    void Deliver();
+    unsigned int num_channels;
+    struct impl;
+    impl *pimpl;
+};
+
+#endif

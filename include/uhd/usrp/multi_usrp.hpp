@@ -1,0 +1,84 @@
+// uhd/usrp/multi_usrp.hpp -- synthetic-IQ stand-in for the slice of the UHD API that
+// liquid-usrp's src/multichannel_rx.cc uses (:121-141,161-162,176,186-199,220).  No radio:
+// recv() replays a raw cf32 file named by $MCRX_IQ_FILE in a loop (zeros if unset), one
+// "packet" of $MCRX_IQ_PACKET (default 4096) samples per call.  Own code, header only.
+#ifndef LIQUID_USRP_AMD_UHD_SHIM_HPP
+#define LIQUID_USRP_AMD_UHD_SHIM_HPP
+
+#include <complex>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace uhd {
+
+struct stream_cmd_t {
+    enum stream_mode_t { STREAM_MODE_START_CONTINUOUS = 'a', STREAM_MODE_STOP_CONTINUOUS = 'o' };
+    stream_mode_t stream_mode;
+    bool stream_now;
+    stream_cmd_t(stream_mode_t m) : stream_mode(m), stream_now(true) {}
+};
+
+struct device_addr_t { std::string args; };
+
+struct rx_metadata_t {
+    enum error_code_t { ERROR_CODE_NONE = 0x0, ERROR_CODE_TIMEOUT = 0x1, ERROR_CODE_OVERFLOW = 0x8 };
+    error_code_t error_code;
+    rx_metadata_t() : error_code(ERROR_CODE_NONE) {}
+};
+
+struct io_type_t { enum tid_t { COMPLEX_FLOAT32 = 'f' }; };
+
+class device {
+public:
+    enum recv_mode_t { RECV_MODE_FULL_BUFF = 0, RECV_MODE_ONE_PACKET = 1 };
+    typedef std::shared_ptr<device> sptr;
+    device() : pos(0), packet(4096)
+    {
+        if (const char *e = getenv("MCRX_IQ_PACKET")) packet = (size_t)atol(e);
+        if (const char *f = getenv("MCRX_IQ_FILE")) {
+            if (FILE *fp = fopen(f, "rb")) {
+                fseek(fp, 0, SEEK_END); long n = ftell(fp); fseek(fp, 0, SEEK_SET);
+                iq.resize((size_t)n / sizeof(std::complex<float>));
+                if (fread(iq.data(), sizeof(std::complex<float>), iq.size(), fp) != iq.size()) iq.clear();
+                fclose(fp);
+            } else fprintf(stderr, "uhd shim: cannot open %s\n", f);
+        }
+    }
+    size_t get_max_recv_samps_per_packet() const { return packet; }
+    size_t recv(void *buff, size_t n, rx_metadata_t &md, io_type_t::tid_t, recv_mode_t)
+    {
+        std::complex<float> *out = static_cast<std::complex<float> *>(buff);
+        if (n > packet) n = packet;
+        md.error_code = rx_metadata_t::ERROR_CODE_NONE;
+        if (iq.empty()) { memset((void *)out, 0, n * sizeof(*out)); return n; }
+        for (size_t i = 0; i < n; i++) { out[i] = iq[pos]; if (++pos == iq.size()) pos = 0; }
+        return n;
+    }
+private:
+    std::vector<std::complex<float> > iq;
+    size_t pos, packet;
+};
+
+namespace usrp {
+class multi_usrp {
+public:
+    typedef std::shared_ptr<multi_usrp> sptr;
+    static sptr make(const device_addr_t &) { return sptr(new multi_usrp()); }
+    multi_usrp() : dev(new device()), rate(0) {}
+    void set_rx_rate(double r) { rate = r; }
+    double get_rx_rate() const { return rate; }
+    void set_rx_freq(double) {}
+    void set_rx_gain(double) {}
+    device::sptr get_device() { return dev; }
+    void issue_stream_cmd(const stream_cmd_t &) {}
+private:
+    device::sptr dev;
+    double rate;
+};
+}  // namespace usrp
+}  // namespace uhd
+#endif

@@ -445,6 +445,8 @@ static int process_staged(mcrx_hip_t q)
     return MCRX_OK;
 }
 
+static int harvest(mcrx_hip_t q);
+
 extern "C" int mcrx_hip_execute_host(mcrx_hip_t q, const float *iq, size_t nsamples)
 {
     if (!q || (!iq && nsamples)) return fail(MCRX_EINVAL, "null argument");
@@ -453,7 +455,11 @@ extern "C" int mcrx_hip_execute_host(mcrx_hip_t q, const float *iq, size_t nsamp
         const size_t take = std::min(nsamples, q->stage_cap - q->stage_fill);
         memcpy(q->h_stage + q->stage_fill, src, take * sizeof(float2));
         q->stage_fill += take; q->total_samples += take; src += take; nsamples -= take;
-        if (q->stage_fill == q->stage_cap) RC(process_staged(q));
+        if (q->stage_fill == q->stage_cap) {
+            RC(process_staged(q));
+            int rc = harvest(q);                // frames become deliverable as soon as a batch is done
+            if (rc != MCRX_OK && rc != MCRX_EOVERFLOW) return rc;
+        }
     }
     return MCRX_OK;
 }

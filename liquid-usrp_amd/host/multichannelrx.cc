@@ -1,0 +1,91 @@
+// multichannelrx.cc -- host class over the C-ABI of libmcrx_hip.so (include/mcrx_hip.h).
+// Mirrors liquid-usrp's lib/multichannelrx.cc: ctor :45-104, dtor :107-132, Reset :135-153,
+// Execute :155-182; the DSP itself runs in the gfx950 kernels.
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "multichannelrx.h"
+#include "mcrx_hip.h"
+
+struct multichannelrx::impl {
+    mcrx_hip_t h;
+    std::vector<void *> userdata;
+    std::vector<framesync_callback> callback;
+    std::vector<unsigned char> payload;     // callbacks get mutable buffers, like liquid's
+};
+
+multichannelrx::multichannelrx(unsigned int _num_channels, unsigned int _M, unsigned int _cp_len,
+                               unsigned int _taper_len, unsigned char *_p, void **_userdata,
+                               framesync_callback *_callback)
+    : num_channels(_num_channels), pimpl(new impl)
+{
+    pimpl->h = NULL;
+    mcrx_hip_config cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.struct_size = sizeof(cfg);
+    cfg.payload_soft = 1;
+    int rc = mcrx_hip_create(&pimpl->h, _num_channels, _M, _cp_len, _taper_len, _p, &cfg);
+    if (rc != MCRX_OK) {
+        fprintf(stderr, "%s\n", mcrx_hip_last_error());
+        delete pimpl;
+        throw 0;
+    }
+    for (unsigned int i = 0; i < _num_channels; i++) {
+        pimpl->userdata.push_back(_userdata ? _userdata[i] : NULL);
+        pimpl->callback.push_back(_callback ? _callback[i] : NULL);
+    }
+}
+
+multichannelrx::~multichannelrx()
+{
+    if (pimpl->h) {
+        mcrx_hip_flush(pimpl->h);
+        Deliver();
+        mcrx_hip_destroy(pimpl->h);
+    }
+    delete pimpl;
+}
+
+void multichannelrx::Deliver()
+{
+    mcrx_frame f;
+    while (mcrx_hip_next_frame(pimpl->h, &f) == 1) {
+        if (f.channel >= num_channels || !pimpl->callback[f.channel]) continue;
+        framesyncstats_s st;
+        st.evm = f.evm; st.rssi = f.rssi; st.cfo = f.cfo;
+        st.framesyms = reinterpret_cast<liquid_float_complex *>(const_cast<float *>(f.framesyms));
+        st.num_framesyms = f.num_framesyms;
+        st.mod_scheme = f.mod_scheme; st.mod_bps = f.mod_bps; st.check = f.check; st.fec0 = f.fec0; st.fec1 = f.fec1;
+        unsigned char header[8];
+        memcpy(header, f.header, 8);
+        pimpl->payload.assign(f.payload, f.payload + f.payload_len);
+        pimpl->callback[f.channel](header, f.header_valid, f.payload_len ? pimpl->payload.data() : NULL,
+                                   f.payload_len, f.payload_valid, st, pimpl->userdata[f.channel]);
+    }
+}
+
+void multichannelrx::Reset()
+{
+    mcrx_hip_reset(pimpl->h);
+    Deliver();
+}
+
+void multichannelrx::Execute(std::complex<float> *_x, unsigned int _num_samples)
+{
+    int rc = mcrx_hip_execute_host(pimpl->h, reinterpret_cast<const float *>(_x), _num_samples);
+    if (rc != MCRX_OK && rc != MCRX_EOVERFLOW) { fprintf(stderr, "error: multichannelrx::Execute(), %s\n", mcrx_hip_last_error()); throw 0; }
+    if (mcrx_hip_frames_pending(pimpl->h)) Deliver();
+}
+
+void multichannelrx::ExecuteDevice(const void *_d_x, unsigned int _num_samples)
+{
+    int rc = mcrx_hip_execute_device(pimpl->h, _d_x, _num_samples, NULL);
+    if (rc != MCRX_OK) { fprintf(stderr, "error: multichannelrx::ExecuteDevice(), %s\n", mcrx_hip_last_error()); throw 0; }
+}
+
+void multichannelrx::Flush()
+{
+    mcrx_hip_flush(pimpl->h);
+    Deliver();
+}

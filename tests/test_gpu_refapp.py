@@ -1,0 +1,29 @@
+"""The reference's unchanged src/multichannel_rx.cc (binary built in the build container from
+/root/reference, see liquid-usrp_amd/host/Makefile `refapp`) running on the GPU library with
+the synthetic-IQ UHD shim."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "liquid-usrp_amd", "lib", "multichannel_rx_ref")
+
+
+@pytest.mark.skipif(not os.path.exists(EXE), reason="reference app binary not built")
+def test_unchanged_reference_app_decodes_synthetic_traffic(oracle, tmp_path):
+    N, M, cp, tp = 4, 64, 8, 4
+    iq, sent = oracle.synth_traffic(N, M, cp, tp, 3, payload_len=120)
+    f = tmp_path / "iq.bin"
+    iq.astype(np.complex64).tofile(f)
+    env = dict(os.environ, MCRX_IQ_FILE=str(f), MCRX_IQ_PACKET="4096")
+    out = subprocess.run([EXE, "-n", str(N), "-M", str(M), "-C", str(cp), "-T", str(tp), "-t", "0.5", "-v"],
+                         env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = re.findall(r"channel: (\d+) rx packet id:\s+(\d+)\n", out.stdout)
+    assert len(lines) >= 3 * N, out.stdout[-2000:]
+    assert {int(c) for c, _ in lines} == set(range(N))
+    assert "PAYLOAD INVALID" not in out.stdout.split("usrp data transfer started")[1][:2000]
