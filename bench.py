@@ -94,12 +94,12 @@ def main():
     d_chan = torch.empty_like(d_out) if world > 1 else d_out                           # [src][tile][c][8]
     stream = torch.cuda.current_stream()
 
+    from liquid_usrp_amd import sharding
+    assert sharding.slab_first_sample(rank, T, N) == first_sample
+
     def step():
-        rx.restart(stream)
-        rx.channelize(d_iq, T, first_sample, d_out, groups=world, d_halo=d_halo, stream=stream)
-        if world > 1:
-            dist.all_to_all_single(d_chan, d_out)        # time shards -> channel shards
-        rx.sync(d_chan, 0, world * T, stream=stream)
+        # restart -> channelize slab -> all-to-all (time shards -> channel shards) -> synchronize
+        sharding.step(rx, d_iq, T, rank, world, dist, d_out, d_chan, halo=d_halo, stream=stream)
 
     def fence():
         torch.cuda.synchronize()
