@@ -134,13 +134,18 @@ def main():
     value = samples_per_step * args.steps / elapsed / 1e6
     out = None
     if rank == 0:
-        ch_ms = stats["channelizer"][0] / max(stats["channelizer"][1], 1)
-        sy_ms = stats["sync"][0] / max(stats["sync"][1], 1)
-        if ch_ms >= sy_ms:
-            kname, kms, kbytes = "channelizer_kernel", ch_ms, B_CHANNELIZER * T * K
-        else:
-            kname, kms, kbytes = "sync_kernel", sy_ms, B_SYNC * world * T * K
-        achieved = kbytes / (kms * 1e-3) / 1e9
+        per = {k: v[0] / max(v[1], 1) for k, v in stats.items()}          # mean ms per launch
+        ch_ms, sc_ms, pw_ms = per["channelizer_kernel"], per["sync_kernel"], per["payload_kernel"]
+        sy_ms = sc_ms + pw_ms
+        # algorithmic bytes per launch: the channelizer moves 12 B per wideband
+        # sample of its slab; the payload workers read each channel sample of their frames once
+        # (8 B per channel sample = 4 B per wideband sample); the scout reads the rest.
+        kbytes = {"channelizer_kernel": B_CHANNELIZER * T * K,
+                  "payload_kernel": B_SYNC * world * T * K,
+                  "sync_kernel": B_SYNC * world * T * K * (10.0 / 176.0)}
+        kname = max(per, key=per.get)                                      # dominant kernel by time
+        kms = per[kname]
+        achieved = kbytes[kname] / (kms * 1e-3) / 1e9
         out = {
             "metric": "complex Msamples/s through multichannelrx",
             "value": round(value, 3), "unit": "Msamples/s",
@@ -158,6 +163,8 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "ms_per_launch": round(kms, 4),
                          "channelizer_ms": round(ch_ms, 4), "sync_ms": round(sy_ms, 4),
+                         "scout_ms": round(sc_ms, 4), "payload_ms": round(pw_ms, 4),
+                         "channelizer_gbs": round(B_CHANNELIZER * T * K / (ch_ms * 1e-3) / 1e9, 1),
                          "pipeline_frac_of_16B_roofline": round(value * 1e6 * 16.0 / (world * HBM_PEAK_GBS * 1e9), 5)},
             "verified": {"frames": len(frames), "expected": expect, "bit_exact_payloads": n_ok, "ok": verified},
             "setup_s": {"iq_generation": round(gen_s, 2)},

@@ -110,10 +110,10 @@ int  mcrx_hip_restart(mcrx_hip_t q, void *stream);
 int  mcrx_hip_get_taps(mcrx_hip_t q, float *h, size_t n);             /* p*K prototype taps */
 uint32_t mcrx_hip_nco_step(mcrx_hip_t q);                             /* 32-bit phase increment */
 int  mcrx_hip_kernel_time_ms(mcrx_hip_t q, float *channelizer_ms, float *sync_ms); /* last launches */
-/* summed HIP-event durations [ms] and launch counts of both kernels since the last reset of
- * the statistics (events are recorded on the launch stream; no host sync per launch) */
-int  mcrx_hip_kernel_stats(mcrx_hip_t q, double *channelizer_ms_total, uint64_t *channelizer_launches,
-                           double *sync_ms_total, uint64_t *sync_launches, int reset);
+/* summed HIP-event durations [ms] and launch counts since the last reset of the statistics,
+ * per kernel: [0] channelizer_kernel, [1] sync_kernel (per-channel scout), [2] payload_kernel
+ * (events are recorded on the launch stream; no host sync per launch) */
+int  mcrx_hip_kernel_stats(mcrx_hip_t q, double ms_total[3], uint64_t launches[3], int reset);
 
 const char *mcrx_hip_last_error(void);
 

@@ -69,8 +69,7 @@ _EXPORTS = {
     "mcrx_hip_get_taps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "mcrx_hip_nco_step": (C.c_uint32, [C.c_void_p]),
     "mcrx_hip_kernel_time_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
-    "mcrx_hip_kernel_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
-                                        C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
+    "mcrx_hip_kernel_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
     "mcrx_hip_last_error": (C.c_char_p, []),
 }
 
@@ -249,10 +248,11 @@ class multichannelrx(object):
         return a.value, b.value
 
     def kernel_stats(self, reset=False):
-        """{'channelizer': (total_ms, launches), 'sync': (total_ms, launches)} from HIP events."""
-        a, b, na, nb = C.c_double(0), C.c_double(0), C.c_uint64(0), C.c_uint64(0)
-        _check(lib().mcrx_hip_kernel_stats(self._h, C.byref(a), C.byref(na), C.byref(b), C.byref(nb), 1 if reset else 0))
-        return {"channelizer": (a.value, na.value), "sync": (b.value, nb.value)}
+        """{kernel: (total_ms, launches)} from HIP events recorded on the launch stream."""
+        ms, cnt = (C.c_double * 3)(), (C.c_uint64 * 3)()
+        _check(lib().mcrx_hip_kernel_stats(self._h, ms, cnt, 1 if reset else 0))
+        names = ("channelizer_kernel", "sync_kernel", "payload_kernel")
+        return {n: (ms[i], cnt[i]) for i, n in enumerate(names)}
 
     def frames_dropped(self):
         return int(lib().mcrx_hip_frames_dropped(self._h))

@@ -123,7 +123,8 @@ struct SyncArgs {
     uint8_t *jtmp;              // [max_jobs][2*(max_enc_len+16)]
     int debug;                 // MCRX_DEBUG=1: trace state-machine events of channel 0
 };
-hipError_t sync_launch(const SyncArgs &a, hipStream_t st);       // scout kernel (+ payload workers if a.scout)
+hipError_t sync_launch(const SyncArgs &a, hipStream_t st);           // scout kernel: one wave per channel
+hipError_t sync_launch_payload(const SyncArgs &a, hipStream_t st);   // payload workers: one wave per handed-off frame
 hipError_t sync_reset_launch(ChanState *st, uint32_t nch, int64_t cur, hipStream_t stream);
 
 }  // namespace mcrx

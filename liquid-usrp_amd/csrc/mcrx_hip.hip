@@ -105,11 +105,11 @@ struct mcrx_hip_s {
     float2 *d_chan[2] = { nullptr, nullptr }; size_t chan_cap_tiles = 0; int chan_cur = 0;
     unsigned hist_tiles = 0;
     hipStream_t stream = nullptr;
-    // per-kernel HIP event ring: [0] channelizer, [1] synchronizer; pairs (start, stop)
-    std::vector<hipEvent_t> evring[2];
-    size_t ev_used[2] = { 0, 0 };
-    double ev_ms_total[2] = { 0, 0 }; uint64_t ev_count[2] = { 0, 0 };
-    float ev_last[2] = { 0, 0 };
+    // per-kernel HIP event ring: [0] channelizer, [1] sync scout, [2] payload workers; pairs (start, stop)
+    std::vector<hipEvent_t> evring[3];
+    size_t ev_used[3] = { 0, 0, 0 };
+    double ev_ms_total[3] = { 0, 0, 0 }; uint64_t ev_count[3] = { 0, 0, 0 };
+    float ev_last[3] = { 0, 0, 0 };
 
     int ev_begin(int which, hipStream_t st)
     {
@@ -276,7 +276,7 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
         return bail(fail(MCRX_ENOMEM, "pinned staging allocation failed"));
     if ((rc = q->alloc(&q->d_in, q->stage_cap))) return bail(rc);
     if (hipStreamCreate(&q->stream) != hipSuccess) return bail(fail(MCRX_EHIP, "hipStreamCreate failed"));
-    for (int w = 0; w < 2; w++) {
+    for (int w = 0; w < 3; w++) {
         q->evring[w].resize(512, nullptr);
         for (auto &e : q->evring[w]) if (hipEventCreate(&e) != hipSuccess) return bail(fail(MCRX_EHIP, "hipEventCreate failed"));
     }
@@ -293,7 +293,7 @@ extern "C" int mcrx_hip_destroy(mcrx_hip_t q)
     for (void *p : q->owned) hipFree(p);
     for (int i = 0; i < 2; i++) if (q->d_chan[i]) hipFree(q->d_chan[i]);
     if (q->h_stage) hipHostFree(q->h_stage);
-    for (int w = 0; w < 2; w++) for (auto e : q->evring[w]) if (e) hipEventDestroy(e);
+    for (int w = 0; w < 3; w++) for (auto e : q->evring[w]) if (e) hipEventDestroy(e);
     if (q->stream) hipStreamDestroy(q->stream);
     delete q;
     return MCRX_OK;
@@ -342,6 +342,11 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     RC(q->ev_begin(1, st));
     HIPCHK(sync_launch(a, st));
     RC(q->ev_end(1, st));
+    if (q->scout) {
+        RC(q->ev_begin(2, st));
+        HIPCHK(sync_launch_payload(a, st));
+        RC(q->ev_end(2, st));
+    }
     return MCRX_OK;
 }
 
@@ -367,23 +372,22 @@ extern "C" int mcrx_hip_restart(mcrx_hip_t q, void *stream)
 extern "C" int mcrx_hip_kernel_time_ms(mcrx_hip_t q, float *ch_ms, float *sy_ms)
 {
     if (!q) return fail(MCRX_EINVAL, "null handle");
-    RC(q->ev_resolve(0)); RC(q->ev_resolve(1));
+    RC(q->ev_resolve(0)); RC(q->ev_resolve(1)); RC(q->ev_resolve(2));
     if (ch_ms) *ch_ms = q->ev_last[0];
-    if (sy_ms) *sy_ms = q->ev_last[1];
+    if (sy_ms) *sy_ms = q->ev_last[1] + q->ev_last[2];      // scout + payload workers
     return MCRX_OK;
 }
-extern "C" int mcrx_hip_kernel_stats(mcrx_hip_t q, double *ch_ms_total, uint64_t *ch_launches,
-                                     double *sy_ms_total, uint64_t *sy_launches, int reset)
+extern "C" int mcrx_hip_kernel_stats(mcrx_hip_t q, double ms_total[3], uint64_t launches[3], int reset)
 {
-    // HIP-event durations of every channelizer / synchronizer launch since the last reset,
-    // recorded on the stream the kernels were launched on
+    // HIP-event durations of every launch since the last reset, recorded on the stream the
+    // kernels were launched on: [0] channelizer_kernel, [1] sync_kernel (scout), [2] payload_kernel
     if (!q) return fail(MCRX_EINVAL, "null handle");
-    RC(q->ev_resolve(0)); RC(q->ev_resolve(1));
-    if (ch_ms_total) *ch_ms_total = q->ev_ms_total[0];
-    if (ch_launches) *ch_launches = q->ev_count[0];
-    if (sy_ms_total) *sy_ms_total = q->ev_ms_total[1];
-    if (sy_launches) *sy_launches = q->ev_count[1];
-    if (reset) { q->ev_ms_total[0] = q->ev_ms_total[1] = 0; q->ev_count[0] = q->ev_count[1] = 0; }
+    for (int w = 0; w < 3; w++) {
+        RC(q->ev_resolve(w));
+        if (ms_total) ms_total[w] = q->ev_ms_total[w];
+        if (launches) launches[w] = q->ev_count[w];
+        if (reset) { q->ev_ms_total[w] = 0; q->ev_count[w] = 0; }
+    }
     return MCRX_OK;
 }
 

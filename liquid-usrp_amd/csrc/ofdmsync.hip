@@ -994,11 +994,26 @@ hipError_t sync_launch(const SyncArgs &a, hipStream_t st)
     const size_t lds = SY_LDS_BYTES(a.c.M);
     if (a.c.M > SY_MAXM) return hipErrorInvalidValue;
     const int E = a.c.E;
-    const unsigned nj = a.scout ? a.max_jobs : 0;
-#define SY_LAUNCH(EE) \
-    hipLaunchKernelGGL((sync_kernel<EE>), dim3(a.nch), dim3(WV), lds, st, a); \
-    if (nj) hipLaunchKernelGGL((payload_kernel<EE>), dim3(nj), dim3(WV), lds, st, a);
+#define SY_LAUNCH(EE) hipLaunchKernelGGL((sync_kernel<EE>), dim3(a.nch), dim3(WV), lds, st, a);
     switch (E) {
+    case 1:  SY_LAUNCH(1) break;
+    case 2:  SY_LAUNCH(2) break;
+    case 4:  SY_LAUNCH(4) break;
+    case 8:  SY_LAUNCH(8) break;
+    case 16: SY_LAUNCH(16) break;
+    default: return hipErrorInvalidValue;
+    }
+#undef SY_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t sync_launch_payload(const SyncArgs &a, hipStream_t st)
+{
+    if (a.nch == 0 || !a.scout || a.max_jobs == 0) return hipSuccess;
+    const size_t lds = SY_LDS_BYTES(a.c.M);
+    const unsigned nj = a.max_jobs;
+#define SY_LAUNCH(EE) hipLaunchKernelGGL((payload_kernel<EE>), dim3(nj), dim3(WV), lds, st, a);
+    switch (a.c.E) {
     case 1:  SY_LAUNCH(1) break;
     case 2:  SY_LAUNCH(2) break;
     case 4:  SY_LAUNCH(4) break;
