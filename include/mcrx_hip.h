@@ -117,6 +117,20 @@ int  mcrx_hip_kernel_stats(mcrx_hip_t q, double ms_total[3], uint64_t launches[3
 
 const char *mcrx_hip_last_error(void);
 
+/* ---- front-end multi-stage resampler (decimating, 0 < rate <= 1) ----------------------
+ * Replaces msresamp_crcf_create(rate, As) / _execute / _destroy as the reference applications
+ * call it in front of a synchronizer (src/flexframe_rx.cc:179,240,275; rate computed as in
+ * src/multichannel_rx.cc:129-138).  Buffers are device pointers (cf32). */
+typedef struct msresamp_hip_s *msresamp_hip_t;
+int    msresamp_hip_create(msresamp_hip_t *out, float rate, float As);
+int    msresamp_hip_destroy(msresamp_hip_t q);
+int    msresamp_hip_reset(msresamp_hip_t q);
+float  msresamp_hip_get_delay(msresamp_hip_t q);
+size_t msresamp_hip_max_output(msresamp_hip_t q, size_t nin);
+int    msresamp_hip_execute_device(msresamp_hip_t q, const void *d_in, size_t nin, void *d_out,
+                                   size_t out_cap, size_t *nout, void *stream);
+const char *msresamp_hip_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,6 +71,14 @@ _EXPORTS = {
     "mcrx_hip_kernel_time_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "mcrx_hip_kernel_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
     "mcrx_hip_last_error": (C.c_char_p, []),
+    "msresamp_hip_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_float, C.c_float]),
+    "msresamp_hip_destroy": (C.c_int, [C.c_void_p]),
+    "msresamp_hip_reset": (C.c_int, [C.c_void_p]),
+    "msresamp_hip_get_delay": (C.c_float, [C.c_void_p]),
+    "msresamp_hip_max_output": (C.c_size_t, [C.c_void_p, C.c_size_t]),
+    "msresamp_hip_execute_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                              C.POINTER(C.c_size_t), C.c_void_p]),
+    "msresamp_hip_last_error": (C.c_char_p, []),
 }
 
 _lib = None
@@ -270,6 +278,51 @@ class multichannelrx(object):
             if getattr(self, "_h", None):
                 lib().mcrx_hip_destroy(self._h)
                 self._h = C.c_void_p()
+        except Exception:
+            pass
+
+
+class msresamp(object):
+    """GPU mirror of liquid's msresamp_crcf as the reference front ends use it
+    (src/flexframe_rx.cc:179,240): msresamp(rate, As); execute(x) -> y, with x / y torch
+    complex64 CUDA tensors (IQ stays in HBM).  Decimating rates only (0 < rate <= 1)."""
+
+    def __init__(self, rate, As=60.0):
+        self._h = C.c_void_p()
+        rc = lib().msresamp_hip_create(C.byref(self._h), rate, As)
+        if rc != MCRX_OK:
+            self._h = C.c_void_p()
+            msg = lib().msresamp_hip_last_error().decode()
+            if rc == MCRX_EINVAL:
+                raise ValueError(msg)
+            raise McrxError("msresamp_hip_create failed (%d): %s" % (rc, msg))
+        self.rate = rate
+
+    def get_delay(self):
+        return float(lib().msresamp_hip_get_delay(self._h))
+
+    def reset(self):
+        lib().msresamp_hip_reset(self._h)
+
+    def execute(self, x, stream=None):
+        import torch
+        n = int(x.numel())
+        cap = int(lib().msresamp_hip_max_output(self._h, n)) + 8
+        y = torch.empty(cap, dtype=torch.complex64, device=x.device)
+        nout = C.c_size_t(0)
+        rc = lib().msresamp_hip_execute_device(self._h, _dptr(x), n, _dptr(y), cap, C.byref(nout), _stream_ptr(stream))
+        if rc != MCRX_OK:
+            raise McrxError("msresamp_hip_execute_device failed (%d): %s" % (rc, lib().msresamp_hip_last_error().decode()))
+        return y[:nout.value]
+
+    def close(self):
+        if self._h:
+            lib().msresamp_hip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
         except Exception:
             pass
 

@@ -735,8 +735,12 @@ struct Walker {
         for (int n = 0; n < c.M_pilot; n++) {
             float v = yph[n];
             if (n > 0) {
-                while ((v - prev) >  PI_F) v -= 2.0f * PI_F;
-                while ((v - prev) < -PI_F) v += 2.0f * PI_F;
+                // liquid's `while (d > pi) v -= 2 pi; while (d < -pi) v += 2 pi`, branch free:
+                // |v| <= pi and the running reference drifts slowly, so three steps cover it
+#pragma unroll
+                for (int it = 0; it < 3; it++) v -= ((v - prev) > PI_F) ? 2.0f * PI_F : 0.0f;
+#pragma unroll
+                for (int it = 0; it < 3; it++) v += ((v - prev) < -PI_F) ? 2.0f * PI_F : 0.0f;
             }
             prev = v;
             p0 += ldspf[n] * v;
@@ -755,8 +759,10 @@ struct Walker {
         uint32_t new_dtheta = s.nco_dtheta;
         if (s.num_symbols > 0) {
             float dphi = p0 - s.phi_prime;
-            while (dphi >  PI_F) dphi -= 2.0f * PI_F;
-            while (dphi < -PI_F) dphi += 2.0f * PI_F;
+#pragma unroll
+            for (int it = 0; it < 3; it++) dphi -= (dphi > PI_F) ? 2.0f * PI_F : 0.0f;
+#pragma unroll
+            for (int it = 0; it < 3; it++) dphi += (dphi < -PI_F) ? 2.0f * PI_F : 0.0f;
             new_dtheta += rad2u32(1e-3f * dphi);
         }
         // the frequency change applies to samples after this event

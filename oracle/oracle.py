@@ -215,6 +215,28 @@ class Modem:
             self.q = None
 
 
+class MsResamp:
+    """Oracle msresamp_crcf (decimating)."""
+
+    def __init__(self, rate, As=60.0):
+        self.rate = rate
+        self.q = lib().ll_msresamp_create(rate, As)
+        if not self.q:
+            raise ValueError("rate must be in (0, 1]")
+
+    def execute(self, x):
+        x = np.ascontiguousarray(x, np.complex64)
+        y = np.zeros(int(len(x) * self.rate) + 64, np.complex64)
+        ny = C.c_uint(0)
+        lib().ll_msresamp_execute(self.q, _ptr(x), len(x), _ptr(y), C.byref(ny))
+        return y[:ny.value].copy()
+
+    def __del__(self):
+        if getattr(self, "q", None):
+            lib().ll_msresamp_destroy(self.q)
+            self.q = None
+
+
 class Channelizer:
     def __init__(self, kind, K, m, As=60.0):
         self.K = K
