@@ -131,6 +131,25 @@ int    msresamp_hip_execute_device(msresamp_hip_t q, const void *d_in, size_t ni
                                    size_t out_cap, size_t *nout, void *stream);
 const char *msresamp_hip_last_error(void);
 
+/* ---- synthetic IQ source: multichanneltx on the GPU ------------------------------------
+ * Replaces multichanneltx (lib/multichanneltx.cc:41-242: N x ofdmflexframegen -> 2N-channel
+ * synthesis bank, m = 13 -> NCO mix-up) driven by the traffic loop of src/multichannel_tx.cc:
+ * 163-213: frames back to back on every channel, header = [pid_hi, pid_lo, channel, 5 seeded
+ * bytes], seeded payloads, soft gain.  The stream is written to device memory. */
+typedef struct mctx_hip_s *mctx_hip_t;
+int    mctx_hip_create(mctx_hip_t *out, unsigned num_channels, unsigned M, unsigned cp_len,
+                       unsigned taper_len, const unsigned char *p);
+int    mctx_hip_destroy(mctx_hip_t q);
+/* blocks of 2N samples needed for `frames_per_channel` frames plus the filter tail (multiple of 8) */
+size_t mctx_hip_blocks_for(mctx_hip_t q, unsigned frames_per_channel, unsigned payload_len,
+                           int mod, int fec0, int fec1);
+/* writes nblocks*2N cf32 samples to d_iq; the headers / payloads that were sent are returned in
+ * hdr[ch][frame][8] and pay[ch][frame][payload_len] (host buffers, may be NULL) */
+int    mctx_hip_generate(mctx_hip_t q, void *d_iq, size_t nblocks, unsigned frames_per_channel,
+                         unsigned payload_len, int mod, int fec0, int fec1, float gain, uint32_t seed,
+                         uint8_t *hdr, uint8_t *pay, void *stream);
+const char *mctx_hip_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -79,6 +79,12 @@ _EXPORTS = {
     "msresamp_hip_execute_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                               C.POINTER(C.c_size_t), C.c_void_p]),
     "msresamp_hip_last_error": (C.c_char_p, []),
+    "mctx_hip_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_void_p]),
+    "mctx_hip_destroy": (C.c_int, [C.c_void_p]),
+    "mctx_hip_blocks_for": (C.c_size_t, [C.c_void_p, C.c_uint, C.c_uint, C.c_int, C.c_int, C.c_int]),
+    "mctx_hip_generate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint, C.c_uint, C.c_int, C.c_int, C.c_int,
+                                    C.c_float, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mctx_hip_last_error": (C.c_char_p, []),
 }
 
 _lib = None
@@ -318,6 +324,60 @@ class msresamp(object):
     def close(self):
         if self._h:
             lib().msresamp_hip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class multichanneltx(object):
+    """GPU multichannel OFDM transmitter used as the synthetic IQ source
+    (reference: lib/multichanneltx.cc + the traffic loop of src/multichannel_tx.cc:163-213).
+
+    generate(frames_per_channel, payload_len, ...) -> (iq, sent): iq is a torch complex64 CUDA
+    tensor with the wideband stream, sent[ch] = [(header, payload), ...]."""
+
+    def __init__(self, num_channels, M, cp_len, taper_len, p=None):
+        self._h = C.c_void_p()
+        self.N, self.K = num_channels, 2 * num_channels
+        parr = None if p is None else np.ascontiguousarray(np.frombuffer(bytes(bytearray(p)), np.uint8))
+        rc = lib().mctx_hip_create(C.byref(self._h), num_channels, M, cp_len, taper_len,
+                                   None if parr is None else parr.ctypes.data)
+        if rc != MCRX_OK:
+            self._h = C.c_void_p()
+            msg = lib().mctx_hip_last_error().decode()
+            if rc == MCRX_EINVAL:
+                raise ValueError(msg)
+            raise McrxError("mctx_hip_create failed (%d): %s" % (rc, msg))
+
+    def GetNumChannels(self):
+        return self.N
+
+    def generate(self, frames_per_channel, payload_len, mod=LIQUID_MODEM_QPSK, fec0=LIQUID_FEC_NONE,
+                 fec1=LIQUID_FEC_HAMMING128, gain=None, seed=0xC0FFEE, nblocks=None, device=None):
+        import torch
+        nb = int(lib().mctx_hip_blocks_for(self._h, frames_per_channel, payload_len, mod, fec0, fec1))
+        if nblocks is not None:
+            nb = max(nb, (int(nblocks) + 7) // 8 * 8)
+        iq = torch.empty(nb * self.K, dtype=torch.complex64, device=device or "cuda")
+        hdr = np.zeros((self.N, frames_per_channel, 8), np.uint8)
+        pay = np.zeros((self.N, frames_per_channel, max(payload_len, 1)), np.uint8)
+        g = (1.0 / self.N) if gain is None else gain
+        stream = torch.cuda.current_stream(iq.device)
+        rc = lib().mctx_hip_generate(self._h, _dptr(iq), nb, frames_per_channel, payload_len, mod, fec0, fec1, g,
+                                     seed & 0xFFFFFFFF, hdr.ctypes.data, pay.ctypes.data, _stream_ptr(stream))
+        if rc != MCRX_OK:
+            raise McrxError("mctx_hip_generate failed (%d): %s" % (rc, lib().mctx_hip_last_error().decode()))
+        sent = [[(bytes(hdr[c, f]), bytes(pay[c, f, :payload_len])) for f in range(frames_per_channel)]
+                for c in range(self.N)]
+        return iq, sent
+
+    def close(self):
+        if self._h:
+            lib().mctx_hip_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -1,0 +1,372 @@
+// txgen.hip -- multichanneltx on the GPU: the synthetic IQ source of the receive path.
+//
+// Replaces liquid-usrp's multichanneltx (lib/multichanneltx.cc: ctor :41-100, UpdateData
+// :165-189, GenerateSamples :192-227, GenerateFrameSamples :230-242) driven by the traffic
+// recipe of src/multichannel_tx.cc:163-213 (header = [pid_hi, pid_lo, channel, 5 random bytes],
+// random payloads, frames back to back on every channel, soft gain), writing the wideband cf32
+// stream straight into HBM:
+//   1. txsym_kernel   one wave per (channel, OFDM symbol): subcarrier mapping (data symbols
+//                     from the host-assembled frame bits, pilots from the order-8 m-sequence,
+//                     gain 1/sqrt(M_pilot+M_data)) and the M-point inverse FFT across the lanes;
+//   2. txifft_kernel  per block b: X[k<N] = frame sample b of channel k (cyclic prefix and
+//                     raised-cosine overlap applied on the fly), 2N-point inverse FFT in LDS;
+//   3. txfir_kernel   polyphase synthesis FIR (2N channels, m = 13 -> 26 taps per branch)
+//                     y_b[i] = sum_j h[i + jK] v_{b-j}[i], NCO mix-up by the exact 32-bit phase
+//                     (bK+i)*dtheta, soft gain.
+// Bit-level frame assembly (CRC/FEC/interleaver/scrambler) is host code: txcode.hpp.
+#include "../../include/mcrx_hip.h"
+#include "devmath.h"
+#include "txcode.hpp"
+#include <random>
+#include <string>
+#include <vector>
+
+namespace mcrx {
+
+#define TXW 64
+#define TX_P 26                 // synthesis taps per branch (m = 13)
+
+struct TxSymArgs {
+    int M, log2M, cp, taper, L, M_pilot, M_data, S, S_hdr, S_pay, frames, bps, mod;
+    float g_data;
+    const uint8_t *sctype; const int16_t *data_rank, *pilot_rank; const uint8_t *pilot_seq;
+    const float2 *s0t, *s1t;
+    const uint8_t *hdr;         // [ch][frame][S_hdr*M_data]
+    const uint8_t *pay;         // [ch][frame][S_pay*M_data]
+    float2 *xsym;               // [ch][frames*S][M]
+    uint32_t nch;
+};
+
+__device__ __forceinline__ unsigned gray_dec_t(unsigned x) { unsigned y = x; while (x >>= 1) y ^= x; return y; }
+__device__ __forceinline__ float2 modulate(int mod, unsigned sym)
+{
+    if (mod == 39) return make_float2(sym ? -1.0f : 1.0f, 0.f);
+    if (mod == 40) { const float a = 0.70710678118654752f; return make_float2((sym & 1) ? -a : a, (sym & 2) ? -a : a); }
+    const unsigned bps = (mod == 27) ? 4u : 6u, mq = bps / 2;
+    const float alpha = (mod == 27) ? 0.31622776601683794f : 0.1543033499620919f;
+    const int Lq = 1 << mq;
+    const int gi = 2 * (int)gray_dec_t(sym >> mq) - Lq + 1, gq = 2 * (int)gray_dec_t(sym & (unsigned)(Lq - 1)) - Lq + 1;
+    return make_float2((float)gi * alpha, (float)gq * alpha);
+}
+
+// one wave per (channel, global symbol index): time-domain symbol body x[M] (no prefix yet)
+template <int E>
+__global__ __launch_bounds__(TXW) void txsym_kernel(TxSymArgs a)
+{
+    const int l = threadIdx.x & 63;
+    const uint32_t gs = blockIdx.x, ch = blockIdx.y;
+    const int f = gs / a.S, s = gs % a.S;
+    float2 *dst = a.xsym + ((size_t)ch * a.frames * a.S + gs) * a.M;
+    if (s < 3 || s == a.S - 1) {                    // S0a, S0b, S1 bodies come from the tables; tail has none
+        const float2 *src = (s == 2) ? a.s1t : a.s0t;
+        for (int i = l; i < a.M; i += TXW) dst[i] = (s == a.S - 1) ? make_float2(0.f, 0.f) : src[i];
+        return;
+    }
+    const bool is_hdr = s < 3 + a.S_hdr;
+    const uint8_t *bits = is_hdr ? a.hdr + ((size_t)ch * a.frames + f) * a.S_hdr * a.M_data + (size_t)(s - 3) * a.M_data
+                                 : a.pay + ((size_t)ch * a.frames + f) * a.S_pay * a.M_data + (size_t)(s - 3 - a.S_hdr) * a.M_data;
+    const uint32_t pcount = (uint32_t)(s - 3) * (uint32_t)a.M_pilot;      // pilot generator resets per frame
+    float2 x[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int k = l + TXW * e;
+        float2 v = make_float2(0.f, 0.f);
+        if (k < a.M) {
+            const int t = a.sctype[k];
+            if (t == 1) v = make_float2(a.pilot_seq[(pcount + (uint32_t)a.pilot_rank[k]) % 255u] ? a.g_data : -a.g_data, 0.f);
+            else if (t == 2) { v = modulate(is_hdr ? 39 : a.mod, bits[a.data_rank[k]]); v.x *= a.g_data; v.y *= a.g_data; }
+        }
+        x[e] = make_float2(v.x, -v.y);              // inverse FFT = conj(FFT(conj(X)))
+    }
+    // forward DIF across position i = l + 64 e (natural subcarrier order in), bit-reversed out
+#pragma unroll
+    for (int j = E / 2; j >= 1; j >>= 1) {
+#pragma unroll
+        for (int e = 0; e < E; e++) if ((e & j) == 0 && e + j < E) {
+            const int h = TXW * j;
+            const float2 u = x[e], w = x[e + j];
+            float sn, cs; sincos_u32((uint32_t)((l + TXW * e) & (h - 1)) * (uint32_t)(0x80000000u / (unsigned)h), sn, cs);
+            x[e] = cadd(u, w);
+            x[e + j] = cmul(csub(u, w), make_float2(cs, -sn));
+        }
+    }
+#pragma unroll
+    for (int st = 0; st < 6; st++) {
+        const int h = 32 >> st;
+        if (h < a.M) {
+            float sn, cs; sincos_u32((uint32_t)(l & (h - 1)) * (uint32_t)(0x80000000u / (unsigned)h), sn, cs);
+            const float2 tw = make_float2(cs, -sn);
+            const bool up = (l & h) != 0;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const float2 p = make_float2(__shfl_xor(x[e].x, h, TXW), __shfl_xor(x[e].y, h, TXW));
+                x[e] = up ? cmul(csub(p, x[e]), tw) : cadd(x[e], p);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int i = l + TXW * e;
+        if (i < a.M) {
+            const int n = (int)(__brev((unsigned)i) >> (32 - a.log2M));
+            dst[n] = make_float2(x[e].x, -x[e].y);
+        }
+    }
+}
+
+struct TxSynthArgs {
+    int M, cp, taper, L, S, frames;
+    const float *taperwin;      // [taper]
+    const float2 *xsym;         // [ch][frames*S][M]
+    const float *taps;          // 26*K synthesis prototype
+    float2 *v;                  // [nblocks][K] inverse-FFT outputs
+    float2 *out;                // [nblocks][K] wideband samples
+    uint32_t nblocks, N;
+    uint32_t dtheta, first_sample_lo;
+    float gain;
+};
+
+// frame sample t of channel ch: cyclic prefix + raised-cosine overlap of consecutive symbols
+// (liquid ofdmframegen_gensymbol / write_S0a / write_S0b / writetail)
+__device__ __forceinline__ float2 frame_sample(const TxSynthArgs &a, uint32_t ch, uint32_t t)
+{
+    const uint32_t gs = t / (uint32_t)a.L, i = t % (uint32_t)a.L;
+    if (gs >= (uint32_t)(a.frames * a.S)) return make_float2(0.f, 0.f);
+    const int s = (int)(gs % (uint32_t)a.S);
+    const float2 *x = a.xsym + ((size_t)ch * a.frames * a.S + gs) * a.M;
+    const int M = a.M, cp = a.cp;
+    if (s == 0) {                                   // S0a: shifted copy, ramp up only
+        float2 v = x[(i + M - 2 * cp) % M];
+        if ((int)i < a.taper) { v.x *= a.taperwin[i]; v.y *= a.taperwin[i]; }
+        return v;
+    }
+    if (s == 1) return x[(i + M - cp) % M];         // S0b: plain cyclic extension
+    if (s == a.S - 1) {                             // tail: previous symbol's postfix ramping down
+        if ((int)i >= a.taper) return make_float2(0.f, 0.f);
+        const float2 p = (x - M)[i]; const float b = a.taperwin[a.taper - 1 - i];
+        return make_float2(p.x * b, p.y * b);
+    }
+    float2 v = x[(i + M - cp) % M];
+    if ((int)i < a.taper) {
+        const float2 p = (x - M)[i];                // first samples of the previous symbol body (S0b: s0)
+        const float wa = a.taperwin[i], wb = a.taperwin[a.taper - 1 - i];
+        v = make_float2(v.x * wa + p.x * wb, v.y * wa + p.y * wb);
+    }
+    return v;
+}
+
+// K-point inverse FFT of one block in LDS (radix-2 Stockham), bins >= N are zero
+template <int K>
+__global__ void txifft_kernel(TxSynthArgs a)
+{
+    constexpr int T = (K / 2 < 64) ? 64 : K / 2;
+    __shared__ float2 buf[2][K];
+    const uint32_t b = blockIdx.x;
+    const int tid = threadIdx.x;
+    for (int k = tid; k < K; k += T) buf[0][k] = (k < (int)a.N) ? frame_sample(a, (uint32_t)k, b) : make_float2(0.f, 0.f);
+    __syncthreads();
+    int cur = 0;
+    // Stockham autosort, decimation in frequency: stage with n = current sub-length, s = stride
+    for (int n = K, s = 1; n > 1; n >>= 1, s <<= 1) {
+        const int m = n >> 1;
+        for (int q = tid; q < K / 2; q += T) {
+            const int p = q / s, r = q % s;         // butterfly p of sub-length n, interleave slot r
+            float sn, cs; sincos_u32((uint32_t)p * (uint32_t)(4294967296.0 / n), sn, cs);
+            const float2 w = make_float2(cs, sn);   // e^{+j 2 pi p / n}: inverse transform
+            const float2 u = buf[cur][r + s * p], v = buf[cur][r + s * (p + m)];
+            buf[cur ^ 1][r + s * 2 * p] = cadd(u, v);
+            buf[cur ^ 1][r + s * (2 * p + 1)] = cmul(csub(u, v), w);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    float2 *dst = a.v + (size_t)b * K;
+    for (int k = tid; k < K; k += T) dst[k] = buf[cur][k];
+}
+
+// synthesis FIR down the time axis + NCO mix-up + gain; a thread owns one column for 8 blocks
+__global__ void txfir_kernel(TxSynthArgs a, uint32_t K)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K) return;
+    const long long b0 = (long long)blockIdx.y * 8;
+    float h[TX_P];
+#pragma unroll
+    for (int j = 0; j < TX_P; j++) h[j] = a.taps[i + (uint32_t)j * K];
+    float2 w[TX_P + 7];                             // w[q] = v[b0 - 25 + q][i]
+#pragma unroll
+    for (int q = 0; q < TX_P + 7; q++) {
+        const long long b = b0 - (TX_P - 1) + q;
+        w[q] = (b >= 0 && b < (long long)a.nblocks) ? a.v[(size_t)b * K + i] : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const long long b = b0 + r;
+        if (b >= (long long)a.nblocks) break;
+        float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int j = TX_P - 1; j >= 0; j--) {       // oldest first, like the window dot product
+            acc.x += h[j] * w[TX_P - 1 + r - j].x;
+            acc.y += h[j] * w[TX_P - 1 + r - j].y;
+        }
+        const uint32_t t = a.first_sample_lo + (uint32_t)((unsigned long long)b * K + i);
+        float2 y = mix_up(acc, t * a.dtheta);
+        a.out[(size_t)b * K + i] = make_float2(y.x * a.gain, y.y * a.gain);
+    }
+}
+
+}  // namespace mcrx
+
+using namespace mcrx;
+
+static thread_local std::string g_tx_err;
+#define TXCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_tx_err = std::string(#x) + ": " + hipGetErrorString(e_); return MCRX_EHIP; } } while (0)
+
+struct mctx_hip_s {
+    unsigned N, K, M, cp, taper;
+    OfdmDesign od;
+    std::vector<float> taps;
+    uint32_t dtheta;
+    std::vector<void *> owned;
+    const uint8_t *d_sctype, *d_pseq; const int16_t *d_drank, *d_prank; const float2 *d_s0t, *d_s1t;
+    const float *d_taper, *d_taps;
+    template <class T> int up(const T **dst, const T *src, size_t n)
+    {
+        T *p = nullptr;
+        TXCHK(hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T)));
+        if (n) TXCHK(hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice));
+        owned.push_back(p); *dst = p;
+        return MCRX_OK;
+    }
+};
+
+extern "C" const char *mctx_hip_last_error(void) { return g_tx_err.c_str(); }
+
+extern "C" int mctx_hip_create(mctx_hip_t *out, unsigned N, unsigned M, unsigned cp, unsigned taper, const unsigned char *p)
+{
+    if (!out) return MCRX_EINVAL;
+    *out = nullptr;
+    // argument checks of multichanneltx::multichanneltx (lib/multichanneltx.cc:48-60)
+    if (N < 1) { g_tx_err = "error: multichanneltx, must have at least one channel"; return MCRX_EINVAL; }
+    if (M < 8) { g_tx_err = "error: multichanneltx, number of subcarriers must be at least 8"; return MCRX_EINVAL; }
+    if (cp < 1) { g_tx_err = "error: multichanneltx, cyclic prefix length must be at least 1"; return MCRX_EINVAL; }
+    if (taper > cp) { g_tx_err = "error: multichanneltx, taper length cannot exceed cyclic prefix length"; return MCRX_EINVAL; }
+    const unsigned K = 2 * N;
+    if ((K & (K - 1)) || K > 1024) { g_tx_err = "2N must be a power of two <= 1024"; return MCRX_EUNSUPP; }
+    if ((M & (M - 1)) || M > 1024) { g_tx_err = "GPU transmitter needs a power-of-two subcarrier count <= 1024"; return MCRX_EUNSUPP; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_tx_err = "no HIP device (no CPU fallback)"; return MCRX_EHIP; }
+    mctx_hip_t q = new mctx_hip_s();
+    q->N = N; q->K = K; q->M = M; q->cp = cp; q->taper = taper;
+    if (q->od.init(M, cp, taper, p) != 0) { delete q; g_tx_err = "invalid subcarrier allocation"; return MCRX_EINVAL; }
+    q->taps = pfb_prototype(K, 13, 60.0f);
+    q->dtheta = channel_center_step(N);
+    std::vector<int16_t> dr(M), pr(M);
+    for (unsigned i = 0; i < M; i++) { dr[i] = (int16_t)q->od.data_rank[i]; pr[i] = (int16_t)q->od.pilot_rank[i]; }
+    int rc;
+    if ((rc = q->up(&q->d_sctype, q->od.p.data(), M)) || (rc = q->up(&q->d_pseq, q->od.pilot_seq, 255)) ||
+        (rc = q->up(&q->d_drank, dr.data(), M)) || (rc = q->up(&q->d_prank, pr.data(), M)) ||
+        (rc = q->up(&q->d_s0t, reinterpret_cast<const float2 *>(q->od.s0.data()), M)) ||
+        (rc = q->up(&q->d_s1t, reinterpret_cast<const float2 *>(q->od.s1.data()), M)) ||
+        (rc = q->up(&q->d_taper, q->od.taperwin.data(), q->od.taperwin.size())) ||
+        (rc = q->up(&q->d_taps, q->taps.data(), q->taps.size()))) { mctx_hip_destroy(q); return rc; }
+    *out = q;
+    return MCRX_OK;
+}
+
+extern "C" int mctx_hip_destroy(mctx_hip_t q)
+{
+    if (!q) return MCRX_OK;
+    hipDeviceSynchronize();
+    for (void *p : q->owned) hipFree(p);
+    delete q;
+    return MCRX_OK;
+}
+
+static void frame_geometry(mctx_hip_t q, unsigned payload_len, int mod, int fec0, int fec1,
+                           unsigned &S_hdr, unsigned &S_pay, unsigned &S)
+{
+    const unsigned Md = q->od.M_data, bps = mod_bps(mod);
+    const unsigned nb = 8 * packet_enc_len(payload_len, CRC_32, fec0, fec1);
+    const unsigned mod_len = nb / bps + ((nb % bps) ? 1 : 0);
+    S_hdr = (288 + Md - 1) / Md; S_pay = (mod_len + Md - 1) / Md; S = 3 + S_hdr + S_pay + 1;
+}
+
+extern "C" size_t mctx_hip_blocks_for(mctx_hip_t q, unsigned frames_per_channel, unsigned payload_len, int mod, int fec0, int fec1)
+{
+    if (!q || !mod_bps(mod)) return 0;
+    unsigned Sh, Sp, S; frame_geometry(q, payload_len, mod, fec0, fec1, Sh, Sp, S);
+    size_t nb = (size_t)frames_per_channel * S * (q->M + q->cp) + 64;     // + idle tail for the filter to ring out
+    return (nb + 7) / 8 * 8;
+}
+
+extern "C" int mctx_hip_generate(mctx_hip_t q, void *d_iq, size_t nblocks, unsigned frames, unsigned payload_len,
+                                 int mod, int fec0, int fec1, float gain, uint32_t seed,
+                                 uint8_t *hdr_out, uint8_t *pay_out, void *stream)
+{
+    if (!q || !d_iq || !mod_bps(mod)) { g_tx_err = "bad argument"; return MCRX_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    unsigned Sh, Sp, S; frame_geometry(q, payload_len, mod, fec0, fec1, Sh, Sp, S);
+    const unsigned Md = q->od.M_data, N = q->N, M = q->M, K = q->K;
+    // ---- host: traffic + bit-level assembly (src/multichannel_tx.cc:166-190 with a seeded generator)
+    std::vector<uint8_t> hdr((size_t)N * frames * Sh * Md), pay((size_t)N * frames * Sp * Md);
+    FrameSymbols fsym;
+    for (unsigned ch = 0; ch < N; ch++) {
+        std::mt19937 rng(seed + ch);
+        for (unsigned f = 0; f < frames; f++) {
+            uint8_t h8[8] = { (uint8_t)(f >> 8), (uint8_t)f, (uint8_t)ch, 0, 0, 0, 0, 0 };
+            for (int i = 3; i < 8; i++) h8[i] = (uint8_t)(rng() & 0xff);
+            std::vector<uint8_t> pl(payload_len);
+            for (auto &b : pl) b = (uint8_t)(rng() & 0xff);
+            assemble_frame(h8, pl, mod, fec0, fec1, Md, Sh, Sp, fsym);
+            memcpy(&hdr[((size_t)ch * frames + f) * Sh * Md], fsym.hdr.data(), fsym.hdr.size());
+            memcpy(&pay[((size_t)ch * frames + f) * Sp * Md], fsym.pay.data(), fsym.pay.size());
+            if (hdr_out) memcpy(hdr_out + ((size_t)ch * frames + f) * 8, h8, 8);
+            if (pay_out && payload_len) memcpy(pay_out + ((size_t)ch * frames + f) * payload_len, pl.data(), payload_len);
+        }
+    }
+    uint8_t *d_hdr = nullptr, *d_pay = nullptr; float2 *d_xsym = nullptr, *d_v = nullptr;
+    const size_t nsym = (size_t)frames * S;
+    TXCHK(hipMalloc((void **)&d_hdr, hdr.size())); TXCHK(hipMalloc((void **)&d_pay, std::max<size_t>(pay.size(), 1)));
+    TXCHK(hipMalloc((void **)&d_xsym, (size_t)N * nsym * M * sizeof(float2)));
+    TXCHK(hipMalloc((void **)&d_v, nblocks * K * sizeof(float2)));
+    TXCHK(hipMemcpyAsync(d_hdr, hdr.data(), hdr.size(), hipMemcpyHostToDevice, st));
+    TXCHK(hipMemcpyAsync(d_pay, pay.data(), pay.size(), hipMemcpyHostToDevice, st));
+    TxSymArgs sa;
+    sa.M = (int)M; sa.log2M = 0; while ((1u << sa.log2M) < M) sa.log2M++;
+    sa.cp = (int)q->cp; sa.taper = (int)q->taper; sa.L = (int)(M + q->cp); sa.M_pilot = (int)q->od.M_pilot; sa.M_data = (int)Md;
+    sa.S = (int)S; sa.S_hdr = (int)Sh; sa.S_pay = (int)Sp; sa.frames = (int)frames; sa.bps = (int)mod_bps(mod); sa.mod = mod;
+    sa.g_data = 1.0f / sqrtf((float)(q->od.M_pilot + q->od.M_data));
+    sa.sctype = q->d_sctype; sa.data_rank = q->d_drank; sa.pilot_rank = q->d_prank; sa.pilot_seq = q->d_pseq;
+    sa.s0t = q->d_s0t; sa.s1t = q->d_s1t; sa.hdr = d_hdr; sa.pay = d_pay; sa.xsym = d_xsym; sa.nch = N;
+    const dim3 gsym((unsigned)nsym, N);
+    const unsigned E = std::max(1u, M / 64);
+    switch (E) {
+    case 1:  hipLaunchKernelGGL((txsym_kernel<1>),  gsym, dim3(TXW), 0, st, sa); break;
+    case 2:  hipLaunchKernelGGL((txsym_kernel<2>),  gsym, dim3(TXW), 0, st, sa); break;
+    case 4:  hipLaunchKernelGGL((txsym_kernel<4>),  gsym, dim3(TXW), 0, st, sa); break;
+    case 8:  hipLaunchKernelGGL((txsym_kernel<8>),  gsym, dim3(TXW), 0, st, sa); break;
+    case 16: hipLaunchKernelGGL((txsym_kernel<16>), gsym, dim3(TXW), 0, st, sa); break;
+    default: g_tx_err = "unsupported subcarrier count"; return MCRX_EUNSUPP;
+    }
+    TXCHK(hipGetLastError());
+    TxSynthArgs ya;
+    ya.M = (int)M; ya.cp = (int)q->cp; ya.taper = (int)q->taper; ya.L = (int)(M + q->cp); ya.S = (int)S; ya.frames = (int)frames;
+    ya.taperwin = q->d_taper; ya.xsym = d_xsym; ya.taps = q->d_taps; ya.v = d_v; ya.out = (float2 *)d_iq;
+    ya.nblocks = (uint32_t)nblocks; ya.N = N; ya.dtheta = q->dtheta; ya.first_sample_lo = 0; ya.gain = gain;
+#define TX_IFFT(KK) hipLaunchKernelGGL((txifft_kernel<KK>), dim3((unsigned)nblocks), dim3((KK) / 2 < 64 ? 64 : (KK) / 2), 0, st, ya)
+    switch (K) {
+    case 2: TX_IFFT(2); break;       case 4: TX_IFFT(4); break;     case 8: TX_IFFT(8); break;     case 16: TX_IFFT(16); break;
+    case 32: TX_IFFT(32); break;     case 64: TX_IFFT(64); break;   case 128: TX_IFFT(128); break; case 256: TX_IFFT(256); break;
+    case 512: TX_IFFT(512); break;   case 1024: TX_IFFT(1024); break;
+    default: g_tx_err = "unsupported channel count"; return MCRX_EUNSUPP;
+    }
+#undef TX_IFFT
+    TXCHK(hipGetLastError());
+    const unsigned tb = K < 256 ? 64 : 256;
+    hipLaunchKernelGGL(txfir_kernel, dim3((K + tb - 1) / tb, (unsigned)((nblocks + 7) / 8)), dim3(tb), 0, st, ya, K);
+    TXCHK(hipGetLastError());
+    TXCHK(hipStreamSynchronize(st));
+    hipFree(d_hdr); hipFree(d_pay); hipFree(d_xsym); hipFree(d_v);
+    return MCRX_OK;
+}

@@ -17,7 +17,7 @@ REF = "/root/reference"
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "mcrx_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b((?:mcrx|msresamp)_hip_[a-z_0-9]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b((?:mcrx|msresamp|mctx)_hip_[a-z_0-9]+)\s*\(", text)))
 
 
 def test_header_and_python_binding_agree(product):
@@ -27,7 +27,7 @@ def test_header_and_python_binding_agree(product):
 def test_library_exports_every_declared_symbol(product):
     path = product.build()
     out = subprocess.check_output(["nm", "-D", "--defined-only", path]).decode()
-    exported = set(re.findall(r" T ((?:mcrx|msresamp)_hip_[a-z_0-9]+)", out))
+    exported = set(re.findall(r" T ((?:mcrx|msresamp|mctx)_hip_[a-z_0-9]+)", out))
     missing = [s for s in declared_symbols() if s not in exported]
     assert not missing, missing
     L = ctypes.CDLL(path)                       # loads without a GPU
