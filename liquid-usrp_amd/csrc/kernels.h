@@ -122,6 +122,7 @@ struct SyncArgs {
     uint8_t *jsoft;             // [max_jobs][8*max_enc_len]
     uint8_t *jtmp;              // [max_jobs][2*(max_enc_len+16)]
     int debug;                 // MCRX_DEBUG=1: trace state-machine events of channel 0
+    int no_fast;               // MCRX_NO_FAST=1: payload workers use the general symbol path (A/B experiments)
 };
 hipError_t sync_launch(const SyncArgs &a, hipStream_t st);           // scout kernel: one wave per channel
 hipError_t sync_launch_payload(const SyncArgs &a, hipStream_t st);   // payload workers: one wave per handed-off frame

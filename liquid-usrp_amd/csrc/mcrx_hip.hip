@@ -335,6 +335,7 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     a.syms = q->d_syms; a.rec = q->d_rec; a.arena = q->d_arena; a.nrec = q->d_nrec; a.arena_used = q->d_arena_used;
     a.arena_cap = q->arena_cap; a.max_rec = q->max_rec;
     a.debug = getenv("MCRX_DEBUG") ? atoi(getenv("MCRX_DEBUG")) : 0;
+    a.no_fast = getenv("MCRX_NO_FAST") ? atoi(getenv("MCRX_NO_FAST")) : 0;
     a.scout = q->scout ? 1 : 0;
     a.jobs = q->d_jobs; a.njobs = q->d_njobs; a.max_jobs = q->max_rec;
     a.jR = q->d_jR; a.jsoft = q->d_jsoft; a.jtmp = q->d_jtmp;

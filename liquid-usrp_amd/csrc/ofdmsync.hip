@@ -18,6 +18,7 @@
 // in HBM between launches so Execute() can be fed arbitrary pieces.
 #include "devmath.h"
 #include "kernels.h"
+#include <utility>
 
 namespace mcrx {
 
@@ -82,29 +83,56 @@ __device__ void il_pass(uint8_t *x, unsigned n, unsigned Mi, unsigned Ncol, unsi
     const unsigned n2 = n / 2, total = Mi * (Ncol + 1), c0 = n / 3;
     unsigned long long m64 = 0;
     if (SOFT) for (int k = 0; k < 8; k++) if ((mask >> (7 - k)) & 1) m64 |= 0xFFull << (8 * k);
+    // Lane l visits cells q = l, l + 64, ...: (row, column) advance incrementally (no division in
+    // the loop), and UN cells per lane are in flight at once -- the pairs of one pass are disjoint,
+    // so all loads of a group may precede its stores.
+    constexpr int UN = 4;
+    unsigned m = (unsigned)l % Mi, tcol = (unsigned)l / Mi, cm = (c0 + tcol) % Ncol;
+    const unsigned dm = WV % Mi, dt = WV / Mi;
+    const bool incremental = dt + 1 < Ncol;
     unsigned base = 0;
-    for (unsigned q0 = 0; q0 < total && base < n2; q0 += WV) {
-        unsigned q = q0 + (unsigned)l;
-        unsigned m = q % Mi, tcol = q / Mi;
-        unsigned c = tcol ? (c0 + tcol) % Ncol : c0;
-        unsigned j = m * Ncol + c;
-        bool valid = (q < total) && (j < n2);
-        unsigned long long bal = __ballot(valid);
-        unsigned i = base + (unsigned)__popcll(bal & ((1ull << l) - 1ull));
-        if (valid && i < n2) {
-            if (SOFT) {
-                unsigned long long *pa = reinterpret_cast<unsigned long long *>(x) + 2 * i;
-                unsigned long long *pb = reinterpret_cast<unsigned long long *>(x) + (2 * j + 1);
-                unsigned long long a = *pa, b = *pb;
-                *pa = (a & ~m64) | (b & m64);
-                *pb = (b & ~m64) | (a & m64);
+    for (unsigned q0 = 0; q0 < total && base < n2; q0 += UN * WV) {
+        unsigned ia[UN], jb[UN]; bool ok[UN];
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const unsigned q = q0 + (unsigned)(u * WV + l);
+            const unsigned c = tcol ? cm : c0;
+            const unsigned j = m * Ncol + c;
+            const bool valid = (q < total) && (j < n2);
+            const unsigned long long bal = __ballot(valid);
+            ia[u] = base + (unsigned)__popcll(bal & ((1ull << l) - 1ull));
+            jb[u] = j;
+            ok[u] = valid && ia[u] < n2;
+            base += (unsigned)__popcll(bal);
+            if (incremental) {
+                m += dm; const unsigned carry = m >= Mi ? 1u : 0u; m -= carry ? Mi : 0u;
+                const unsigned inc = dt + carry;
+                tcol += inc; cm += inc; cm -= cm >= Ncol ? Ncol : 0u;
             } else {
-                unsigned a = x[2 * i], b = x[2 * j + 1];
-                x[2 * i]     = (uint8_t)((a & ~mask) | (b & mask));
-                x[2 * j + 1] = (uint8_t)((b & ~mask) | (a & mask));
+                const unsigned qn = q + WV;
+                m = qn % Mi; tcol = qn / Mi; cm = (c0 + tcol) % Ncol;
             }
         }
-        base += (unsigned)__popcll(bal);
+        if (SOFT) {
+            unsigned long long va[UN], vb[UN];
+            unsigned long long *x64 = reinterpret_cast<unsigned long long *>(x);
+#pragma unroll
+            for (int u = 0; u < UN; u++) if (ok[u]) { va[u] = x64[2 * ia[u]]; vb[u] = x64[2 * jb[u] + 1]; }
+#pragma unroll
+            for (int u = 0; u < UN; u++) if (ok[u]) {
+                x64[2 * ia[u]]     = (va[u] & ~m64) | (vb[u] & m64);
+                x64[2 * jb[u] + 1] = (vb[u] & ~m64) | (va[u] & m64);
+            }
+        } else {
+            unsigned va[UN], vb[UN];
+#pragma unroll
+            for (int u = 0; u < UN; u++) if (ok[u]) { va[u] = x[2 * ia[u]]; vb[u] = x[2 * jb[u] + 1]; }
+#pragma unroll
+            for (int u = 0; u < UN; u++) if (ok[u]) {
+                x[2 * ia[u]]     = (uint8_t)((va[u] & ~mask) | (vb[u] & mask));
+                x[2 * jb[u] + 1] = (uint8_t)((vb[u] & ~mask) | (va[u] & mask));
+            }
+        }
     }
     __syncthreads();
 }
@@ -146,6 +174,55 @@ __device__ unsigned h128_dec_soft_sym(const CodingDev cod, const uint8_t *soft)
         if (d < dmin) { dmin = d; s_hat = t; }
     }
     return s_hat;
+}
+// The same decision without table walks.  Hamming(12,8) is linear, so the distance-3 neighbours
+// of codeword enc(s0) are enc(s0 ^ u) for the fixed set {u : weight(enc(u)) == 3}, and
+//   dist(enc(s0 ^ u)) - dist(enc(s0)) = sum over the three bits of enc(u) of the cost of flipping them.
+// The patterns are enumerated at compile time; the reference order (estimate first, then neighbours
+// by ascending symbol, strict `<`) becomes a lexicographic minimum over (distance, symbol).
+constexpr unsigned h128c_par(unsigned v) { v ^= v >> 4; v ^= v >> 2; v ^= v >> 1; return v & 1u; }
+constexpr unsigned h128c_enc(unsigned s)
+{
+    return (s & 0x0f) | ((s & 0x70) << 1) | ((s & 0x80) << 2) | (h128c_par(s & 0xda) << 11) | (h128c_par(s & 0xb6) << 10) |
+           (h128c_par(s & 0x71) << 8) | (h128c_par(s & 0x0f) << 4);
+}
+constexpr int h128c_weight(unsigned v) { int n = 0; while (v) { n += (int)(v & 1u); v >>= 1; } return n; }
+template <unsigned U>
+__device__ __forceinline__ void h128_try(const int (&flip)[12], unsigned s0, int &best)
+{
+    constexpr unsigned cw = h128c_enc(U);
+    if constexpr (h128c_weight(cw) == 3) {
+        int d = 4096;
+#pragma unroll
+        for (int k = 0; k < 12; k++) if ((cw >> (11 - k)) & 1u) d += flip[k];
+        const int key = (d << 9) | (int)((s0 ^ U) + 1u);
+        best = key < best ? key : best;
+    }
+}
+template <unsigned... U>
+__device__ __forceinline__ void h128_try_all(const int (&flip)[12], unsigned s0, int &best, std::integer_sequence<unsigned, U...>)
+{ (h128_try<U + 1u>(flip, s0, best), ...); }
+__device__ __forceinline__ unsigned h128_dec_soft_fast(const uint8_t *soft)
+{
+    const uint32_t *w32 = reinterpret_cast<const uint32_t *>(soft);           // 12-byte groups are 4-byte aligned
+    const uint32_t w[3] = { w32[0], w32[1], w32[2] };
+    int cost[12]; unsigned c = 0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        const int sb = (int)((w[k >> 2] >> (8 * (k & 3))) & 0xffu);
+        cost[k] = 255 - 2 * sb;                     // cost of deciding 1 minus cost of deciding 0
+        c = (c << 1) | (sb > 127 ? 1u : 0u);
+    }
+    const unsigned s0 = h128_dec_sym(c);
+    const unsigned cw0 = (s0 & 0x0f) | ((s0 & 0x70) << 1) | ((s0 & 0x80) << 2) | (par_d(s0 & 0xda) << 11) | (par_d(s0 & 0xb6) << 10) |
+                         (par_d(s0 & 0x71) << 8) | (par_d(s0 & 0x0f) << 4);
+    int flip[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) flip[k] = ((cw0 >> (11 - k)) & 1u) ? -cost[k] : cost[k];
+    int best = 4096 << 9;
+    h128_try_all(flip, s0, best, std::make_integer_sequence<unsigned, 255>{});
+    const unsigned r = (unsigned)best & 0x1ffu;
+    return r ? r - 1u : s0;
 }
 __device__ __forceinline__ unsigned golay_mulP(unsigned v)
 {
@@ -225,7 +302,7 @@ __device__ void soft_pack(const uint8_t *soft, unsigned nbytes, uint8_t *out, bo
 // (8-byte aligned).  Result message in tmpb[0..n_msg); returns validity.
 __device__ bool packet_decode(const CodingDev cod, bool soft_mode, bool scrambled, unsigned n_msg,
                               unsigned crc, unsigned fec0, unsigned fec1,
-                              uint8_t *soft, uint8_t *tmpa, uint8_t *tmpb)
+                              uint8_t *soft, uint8_t *tmpa, uint8_t *tmpb, unsigned ablate = 0)
 {
     const int l = lane_id();
     const unsigned crc_len = (crc == 6) ? 4u : 0u;
@@ -233,8 +310,8 @@ __device__ bool packet_decode(const CodingDev cod, bool soft_mode, bool scramble
     const unsigned e0 = fec_enc_len_d(fec0, n0), e1 = fec_enc_len_d(fec1, e0);
     const unsigned d0 = (fec0 == 6 || fec0 == 7) ? 4u : 0u, d1 = (fec1 == 6 || fec1 == 7) ? 4u : 0u;
     if (soft_mode && fec1 == 6) {
-        deinterleave<true>(soft, e1, d1);
-        for (unsigned i = (unsigned)l; i < e0; i += WV) tmpa[i] = (uint8_t)h128_dec_soft_sym(cod, soft + 12 * (size_t)i);
+        if (!(ablate & 8)) deinterleave<true>(soft, e1, d1);
+        if (!(ablate & 16)) for (unsigned i = (unsigned)l; i < e0; i += WV) tmpa[i] = (uint8_t)h128_dec_soft_fast(soft + 12 * (size_t)i);
         __syncthreads();
     } else {
         if (soft_mode) deinterleave<true>(soft, e1, d1);
@@ -244,7 +321,7 @@ __device__ bool packet_decode(const CodingDev cod, bool soft_mode, bool scramble
     }
     deinterleave<false>(tmpa, e0, d0);
     fec_decode_hard(fec0, n0, tmpa, tmpb);
-    if (crc_len == 0) return true;
+    if (crc_len == 0 || (ablate & 32)) return true;
     uint32_t key = ((uint32_t)tmpb[n_msg] << 24) | ((uint32_t)tmpb[n_msg + 1] << 16) |
                    ((uint32_t)tmpb[n_msg + 2] << 8) | (uint32_t)tmpb[n_msg + 3];
     return crc32_wave(cod, tmpb, n_msg) == key;
@@ -330,6 +407,52 @@ __device__ __forceinline__ void wave_sync_lds()
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+
+// ---- cross-lane primitives of the lean symbol loop.  The loop is VALU-issue bound, so lane
+// exchanges use DPP modifiers where the pattern exists (xor 1, 2, 8) and the otherwise idle LDS
+// crossbar (ds_swizzle / ds_bpermute: no LDS memory is touched) for xor 4, 16, 32.
+template <int CTRL, bool ZERO_OOB = true>
+__device__ __forceinline__ float dpp_mov(float v, float old = 0.f)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                                 CTRL, 0xf, 0xf, ZERO_OOB));
+}
+template <int H>
+__device__ __forceinline__ float xor_lane(float v, int bperm32)
+{
+    if constexpr (H == 1)       return dpp_mov<0xB1>(v);           // quad_perm [1,0,3,2]
+    else if constexpr (H == 2)  return dpp_mov<0x4E>(v);           // quad_perm [2,3,0,1]
+    else if constexpr (H == 8)  return dpp_mov<0x128>(v);          // row_ror:8
+    else if constexpr (H == 4)  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x101F));
+    else if constexpr (H == 16) return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
+    else                        return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bperm32, __builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ float wave_sum_fast(float v, int bperm32)
+{
+    v += xor_lane<1>(v, bperm32);  v += xor_lane<2>(v, bperm32);  v += xor_lane<4>(v, bperm32);
+    v += xor_lane<8>(v, bperm32);  v += xor_lane<16>(v, bperm32); v += xor_lane<32>(v, bperm32);
+    return v;
+}
+// inclusive prefix sum over the 64 lanes (DPP Kogge-Stone inside rows, row broadcasts across)
+__device__ __forceinline__ float wave_scan_fast(float v)
+{
+    v += dpp_mov<0x111>(v);                      // row_shr:1, out-of-row lanes add 0
+    v += dpp_mov<0x112>(v);
+    v += dpp_mov<0x114>(v);
+    v += dpp_mov<0x118>(v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));  // row_bcast:15
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false));  // row_bcast:31
+    return v;
+}
+// e^{-j 2 pi rev} on the transcendental unit (v_sin/v_cos take revolutions; measured max abs
+// error 1.24e-7 on gfx950, the same as the polynomial in devmath.h)
+__device__ __forceinline__ cfd rot_down(cfd x, float rev)
+{
+    const float s = __builtin_amdgcn_sinf(rev), c = __builtin_amdgcn_cosf(rev);
+    return make_float2(x.x * c + x.y * s, x.y * c - x.x * s);
+}
+__device__ __forceinline__ float u32rev(uint32_t th) { return (float)(int32_t)th * 2.3283064365386963e-10f; }   // 2^-32
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 template <int E>
 struct Walker {
@@ -802,6 +925,175 @@ struct Walker {
         }
     }
 
+    // ------------------------------------------------------------------------------------
+    // Lean payload symbol loop (M = 64 E a power of two, at most 64 pilots): the same arithmetic
+    // as rx_core + flex_symbol's payload branch, restructured for VALU issue: wave-uniform state
+    // in scalars, window addresses relative to the buffer, twiddles and butterfly signs in
+    // registers, DPP / LDS-crossbar lane exchanges, the pilot phase unwrap as a prefix sum of
+    // 2 pi jumps (liquid's sequential `while` unwrap only ever adds -rint(d / 2 pi) turns per
+    // step), and v_sin / v_cos for the two rotations per sample.
+    __device__ __forceinline__ bool fast_ok() const { return c.log2M >= 6 && c.M == WV * E && c.M_pilot <= WV; }
+
+    __device__ __forceinline__ void fast_fft(float2 (&x)[E], const float2 (&tw)[6], const float (&sg)[6], int bp32)
+    {
+        // in-lane stages (span 64 J), twiddle W_{128 J}^{i mod 64 J}
+#pragma unroll
+        for (int J = E / 2; J >= 1; J >>= 1) {
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                if ((e & J) == 0) {
+                    const float2 u = x[e], v = x[e + J];
+                    const float rev = (float)((l + WV * e) & (WV * J - 1)) * (0.5f / (float)(WV * J));
+                    x[e] = cadd(u, v);
+                    x[e + J] = rot_down(csub(u, v), rev);
+                }
+            }
+        }
+#define SY_XSTAGE(ST, H)                                                                       \
+        _Pragma("unroll") for (int e = 0; e < E; e++) {                                        \
+            const float px = xor_lane<H>(x[e].x, bp32), py = xor_lane<H>(x[e].y, bp32);        \
+            const float sx = fmaf(sg[ST], x[e].x, px), sy = fmaf(sg[ST], x[e].y, py);          \
+            if (H == 1) x[e] = make_float2(sx, sy);                                            \
+            else x[e] = make_float2(sx * tw[ST].x - sy * tw[ST].y, sx * tw[ST].y + sy * tw[ST].x); \
+        }
+        SY_XSTAGE(0, 32) SY_XSTAGE(1, 16) SY_XSTAGE(2, 8) SY_XSTAGE(3, 4) SY_XSTAGE(4, 2) SY_XSTAGE(5, 1)
+#undef SY_XSTAGE
+    }
+
+    __device__ __forceinline__ void run_job_fast(uint32_t j)
+    {
+        const PayloadJob job = a.jobs[j];
+        bind_job(j, job);
+        // ---- per-lane constants
+        float2 tw[6]; float sg[6];
+#pragma unroll
+        for (int st = 0; st < 6; st++) {
+            const int h = 32 >> st;
+            const bool up = (l & h) != 0;
+            const float rev = (float)(l & (h - 1)) * (0.5f / (float)h);
+            tw[st] = up ? make_float2(__builtin_amdgcn_cosf(rev), -__builtin_amdgcn_sinf(rev)) : make_float2(1.f, 0.f);
+            sg[st] = up ? -1.f : 1.f;
+        }
+        const int bp32 = (l ^ 32) << 2;
+        const int lg = c.log2M;
+        int dr[E], pr[E]; float fxr[E];
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int kk = (int)(__brev((unsigned)(l + WV * e)) >> (32 - lg));
+            k[e] = kk;
+            const int ty = c.sctype[kk];
+            dr[e] = c.data_rank[kk]; pr[e] = c.pilot_rank[kk];
+            fxr[e] = ((kk > c.M2) ? (float)kk - (float)c.M : (float)kk) * 0.15915494309189535f;   // revolutions per rad of slope
+            R[e] = ty ? bR[kk] : make_float2(0.f, 0.f);
+        }
+        const int Mp = c.M_pilot;
+        const float pf0 = (l < Mp) ? c.Pfit[l] : 0.f, pf1 = (l < Mp) ? c.Pfit[Mp + l] : 0.f;
+        for (int i = l; i < 255; i += WV) ldsps[i] = c.pilot_seq[i];
+        wave_sync_lds();
+
+        // ---- wave-uniform state in scalars
+        const int L = c.L, cb = c.cp - c.backoff, Md = c.M_data;
+        const uint32_t mod = rfl(s.mod_scheme), bps = rfl(s.bps), mod_len = rfl(s.mod_len), nbits = 8u * rfl(s.enc_len);
+        const uint32_t nsym = (mod_len + (uint32_t)Md - 1u) / (uint32_t)Md;
+        const int64_t t_ev0 = s.cur + (int64_t)s.timer - 1;                 // event of the first payload symbol
+        const int64_t ws0 = t_ev0 - L + 1 + cb;
+        uint32_t dth = rfl(s.nco_dtheta);
+        uint32_t th_ws = rfl(s.nco_theta_ref + (uint32_t)(ws0 - s.nco_t_ref) * s.nco_dtheta);    // NCO phase at the window start
+        uint32_t pc = rfl(s.pilot_count);
+        float phi_prime = s.phi_prime, p1_prime = s.p1_prime;
+        int32_t r_ws = (int32_t)rfl((uint32_t)(ws0 - a.buf_first));         // window start relative to the buffer
+        const float2 *chb = a.chan + ((size_t)a.chan_off + ch) * MCRX_TILE_S;
+        const size_t tstride = (size_t)a.chan_stride * MCRX_TILE_S;
+        uint8_t *soft = bsoft;
+        float2 *syms = bsyms;
+        const bool soft_mode = c.payload_soft != 0;
+
+        float2 cur[E], nxt[E];
+#pragma unroll
+        for (int e = 0; e < E; e++) nxt[e] = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int e = 0; e < E; e++) { const int r = r_ws + l + WV * e; cur[e] = chb[(size_t)(r >> 3) * tstride + (size_t)(r & 7)]; }
+        uint32_t psi = 0;
+        for (uint32_t n = 0; n < ((a.no_fast & 4) ? 1u : nsym); n++) {
+            if (n + 1 < nsym) {
+#pragma unroll
+                for (int e = 0; e < E; e++) { const int r = r_ws + L + l + WV * e; nxt[e] = chb[(size_t)(r >> 3) * tstride + (size_t)(r & 7)]; }
+            }
+            // NCO, FFT, equaliser
+            float2 X[E];
+#pragma unroll
+            for (int e = 0; e < E; e++) X[e] = rot_down(cur[e], u32rev(th_ws + (uint32_t)(l + WV * e) * dth));
+            fast_fft(X, tw, sg, bp32);
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                X[e] = cmul(X[e], R[e]);
+                if (pr[e] >= 0) ldsc[pr[e]] = X[e];
+            }
+            wave_sync_lds();
+            // pilots: lane n < Mp takes pilot n (subcarrier order), phase, unwrap, linear fit
+            float2 P = ldsc[l < Mp ? l : 0];
+            uint32_t pi_ = pc + (uint32_t)l; pi_ = pi_ >= 255u ? pi_ - 255u : pi_;
+            const bool pneg = ldsps[pi_ < 255u ? pi_ : 0u] == 0;
+            wave_sync_lds();
+            if (pneg) { P.x = -P.x; P.y = -P.y; }
+            const float v = atan2f(P.y, P.x);
+            const float prev = dpp_mov<0x138, false>(v, v);                  // wave_shr:1, lane 0 keeps its own
+            const float turns = rintf((v - prev) * 0.15915494309189535f);
+            const float y = fmaf(-TWO_PI_F, wave_scan_fast(turns), v);
+            const float p0 = wave_sum_fast(pf0 * y, bp32);
+            float p1 = wave_sum_fast(pf1 * y, bp32);
+            pc += (uint32_t)Mp; pc = pc >= 255u ? pc - 255u : pc;
+            p1 = 0.3f * p1 + (1.0f - 0.3f) * p1_prime;
+            p1_prime = p1;
+            // de-rotate, soft bits
+            const float p0r = p0 * 0.15915494309189535f;
+            const bool full = (psi + (uint32_t)Md) * bps <= nbits;           // no tail guard needed
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                if (dr[e] < 0) continue;
+                const uint32_t idx = psi + (uint32_t)dr[e];
+                if (idx >= mod_len) continue;
+                const float2 Z = rot_down(X[e], fmaf(p1, fxr[e], p0r));
+                syms[idx] = Z;
+                uint8_t sb[6];
+                const unsigned hs = demod_soft(c.cod, mod, Z, sb);
+                if (!soft_mode) {
+#pragma unroll
+                    for (int kb = 0; kb < 6; kb++) sb[kb] = (uint8_t)(((hs >> ((bps - 1 - kb) & 7)) & 1) ? 255 : 0);
+                }
+                uint8_t *dst = soft + (size_t)idx * bps;
+                if (full) {
+                    if (bps == 2)      *reinterpret_cast<uint16_t *>(dst) = (uint16_t)(sb[0] | (sb[1] << 8));
+                    else if (bps == 1) dst[0] = sb[0];
+                    else {
+                        *reinterpret_cast<uint16_t *>(dst) = (uint16_t)(sb[0] | (sb[1] << 8));
+                        *reinterpret_cast<uint16_t *>(dst + 2) = (uint16_t)(sb[2] | (sb[3] << 8));
+                        if (bps == 6) *reinterpret_cast<uint16_t *>(dst + 4) = (uint16_t)(sb[4] | (sb[5] << 8));
+                    }
+                } else {
+                    for (unsigned kb = 0; kb < bps; kb++) if (idx * bps + kb < nbits) dst[kb] = sb[kb];
+                }
+            }
+            psi += (uint32_t)Md;
+            // NCO trim: phase at the next window start uses the old step up to this event, the new one after
+            float dphi = p0 - phi_prime;
+            dphi -= TWO_PI_F * rintf(dphi * 0.15915494309189535f);
+            phi_prime = p0;
+            const uint32_t dnew = dth + rfl(rad2u32(1e-3f * dphi));
+            th_ws += (uint32_t)(L - cb) * dth + (uint32_t)cb * dnew;
+            dth = dnew;
+            r_ws += L;
+#pragma unroll
+            for (int e = 0; e < E; e++) cur[e] = nxt[e];
+        }
+        // ---- frame complete: decode and emit (same tail as flex_symbol)
+        s.nco_dtheta = dth;
+        __syncthreads();
+        const bool valid = (a.no_fast & 2) ? false :
+            packet_decode(c.cod, soft_mode, false, s.payload_len, s.check, s.fec0, s.fec1, soft, btmpa, btmpb, (unsigned)a.no_fast);
+        emit(t_ev0 + (int64_t)(nsym - 1) * L, true, valid, false);
+    }
+
     __device__ __forceinline__ void run()
     {
         s = a.st[ch];
@@ -975,7 +1267,8 @@ __global__ __launch_bounds__(WV, 4) void payload_kernel(SyncArgs a)
     const uint32_t ch = a.jobs[j].ch;
     if (ch >= a.nch) return;
     Walker<E> w(a, ch);
-    w.run_job(j);
+    if (w.fast_ok() && !(a.no_fast & 1)) w.run_job_fast(j);
+    else w.run_job(j);
 }
 
 __global__ void sync_reset_kernel(ChanState *st, uint32_t nch, int64_t cur)
