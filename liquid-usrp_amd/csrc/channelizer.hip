@@ -106,15 +106,21 @@ __global__ __launch_bounds__(T) void channelizer_kernel(ChanArgs a)
     const int n0 = cg * C;
     const long long slab = (long long)blockIdx.x * NS + sl;
     const long long bs = slab * (long long)a.slab_blocks;        // first block of my slab
-    const bool active = bs < (long long)a.nblocks;
 
-    // taps: tap[j][c] = h[K-1-n + j*K]
-    float tap[CH_P][C];
+    // taps: tap[j][c] = h[K-1-n + j*K].  They live in LDS (p*K floats behind the tile) and are
+    // fetched into registers for the FIR of each round only: across the FFT stages the registers
+    // hold the sliding window plus the next round's blocks that are already in flight.
+    float *ltap = reinterpret_cast<float *>(tile + NS * CH_R * ROWP);
+    {
+        constexpr int NT = CH_P * K;                 // all requests first, then the LDS writes: one round trip
+        constexpr int PER = (NT + T - 1) / T;
+        float tv[PER];
 #pragma unroll
-    for (int j = 0; j < CH_P; j++)
+        for (int i = 0; i < PER; i++) { const int idx = tid + i * T; tv[i] = a.taps[idx < NT ? idx : 0]; }
 #pragma unroll
-        for (int c = 0; c < C; c++) tap[j][c] = a.taps[(K - 1 - (n0 + c)) + j * K];
-
+        for (int i = 0; i < PER; i++) { const int idx = tid + i * T; if (idx < NT) ltap[idx] = tv[i]; }
+    }
+    __syncthreads();
     // radix-4 stage twiddles W_L^{r*pos}, r = 1..3: pos = q % (L/4) does not depend on the
     // loop trip because L/4 divides the workgroup size
     float2 tw[S > 0 ? S : 1][3];
@@ -132,60 +138,77 @@ __global__ __launch_bounds__(T) void channelizer_kernel(ChanArgs a)
     const uint32_t dth = a.dtheta;
     const uint32_t t0 = a.first_sample_lo;
 
-    auto load_block = [&](long long b, float2 (&dst)[C]) {
-        // samples of block b (relative to a.x), columns n0..n0+C-1, NCO applied
-        const float2 *src = nullptr;
-        if (b >= 0) { if (b < (long long)a.nblocks) src = a.x + (size_t)b * K + n0; }
-        else if (a.halo) src = a.halo + (size_t)(b + CH_H) * K + n0;
-        if (src) {
-            if constexpr (C == 2) {
-                float4 v = *reinterpret_cast<const float4 *>(src);
-                dst[0] = make_float2(v.x, v.y); dst[1] = make_float2(v.z, v.w);
-            } else dst[0] = src[0];
-            const uint32_t tt = t0 + (uint32_t)((long long)b * K + n0);
+    // raw samples of block b (relative to a.x), columns n0..n0+C-1; zeros outside the stream
+    // Branch free on purpose: a load inside a divergent `if` gets an s_waitcnt vmcnt(0) at the
+    // join, which would serialise the round's loads into one HBM round trip each.
+    auto load_raw = [&](long long b, float2 (&dst)[C]) {
+        const bool inx = b >= 0 && b < (long long)a.nblocks;
+        const bool inh = b < 0 && a.halo != nullptr;
+        const float2 *src = a.x + n0;                                   // always mapped
+        if (inx) src = a.x + (size_t)b * K + n0;
+        if (inh) src = a.halo + (size_t)(b + CH_H) * K + n0;
+        // the value is not touched here (that would wait for it): mix_block() zeroes blocks outside the stream
+        if constexpr (C == 2) {
+            const float4 v = *reinterpret_cast<const float4 *>(src);
+            dst[0] = make_float2(v.x, v.y); dst[1] = make_float2(v.z, v.w);
+        } else dst[0] = src[0];
+    };
+    // NCO in place; blocks outside the stream (before a cold start, past the end) become zeros
+    auto mix_block = [&](long long b, float2 (&dst)[C]) {
+        const bool valid = (b >= 0 && b < (long long)a.nblocks) || (b < 0 && a.halo != nullptr);
+        const uint32_t ph = (t0 + (uint32_t)((long long)b * K + n0)) * dth;
 #pragma unroll
-            for (int c = 0; c < C; c++) dst[c] = mix_down(dst[c], (tt + (uint32_t)c) * dth);
-        } else {
-#pragma unroll
-            for (int c = 0; c < C; c++) dst[c] = make_float2(0.f, 0.f);
+        for (int c = 0; c < C; c++) {
+            const float2 m = mix_down_hw(dst[c], ph + (uint32_t)c * dth);
+            dst[c] = valid ? m : make_float2(0.f, 0.f);
         }
     };
 
-    // s[0..12] history (oldest first), s[13..20] the round's new blocks
+    // s[0..12] history (oldest first), s[13..20] the round's new blocks.  The new blocks of
+    // round r+1 are requested into s[13..20] right after round r's FIR has consumed them, so
+    // the HBM latency hides under the FFT stages; they are mixed in place when the round starts.
     float2 s[CH_H + CH_R][C];
-    if (active) {
+    // (slabs past the end of the stream run on clamped addresses and zeros; their stores are masked.
+    //  Keeping this straight-line matters: a load under a branch is waited for at the join.)
 #pragma unroll
-        for (int i = 0; i < CH_H; i++) load_block(bs - CH_H + i, s[i]);
-    }
+    for (int i = 0; i < CH_H + CH_R; i++) load_raw(bs - CH_H + i, s[i]);
+#pragma unroll
+    for (int i = 0; i < CH_H; i++) mix_block(bs - CH_H + i, s[i]);
 
     const int rounds = a.slab_blocks / CH_R;
     for (int rd = 0; rd < rounds; rd++) {
         const long long b0 = bs + (long long)rd * CH_R;
-        if (active) {
+        float tap[CH_P][C];
 #pragma unroll
-            for (int r = 0; r < CH_R; r++) load_block(b0 + r, s[CH_H + r]);
+        for (int j = 0; j < CH_P; j++)
 #pragma unroll
-            for (int r = 0; r < CH_R; r++) {
-                float2 v[C];
+            for (int c = 0; c < C; c++) tap[j][c] = ltap[(K - 1 - (n0 + c)) + j * K];
 #pragma unroll
-                for (int c = 0; c < C; c++) v[c] = make_float2(0.f, 0.f);
+        for (int r = 0; r < CH_R; r++) mix_block(b0 + r, s[CH_H + r]);
 #pragma unroll
-                for (int j = CH_P - 1; j >= 0; j--) {           // oldest tap first, like a window dot product
+        for (int r = 0; r < CH_R; r++) {
+            float2 v[C];
 #pragma unroll
-                    for (int c = 0; c < C; c++) {
-                        v[c].x += tap[j][c] * s[CH_H + r - j][c].x;
-                        v[c].y += tap[j][c] * s[CH_H + r - j][c].y;
-                    }
+            for (int c = 0; c < C; c++) v[c] = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int j = CH_P - 1; j >= 0; j--) {           // oldest tap first, like a window dot product
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    v[c].x += tap[j][c] * s[CH_H + r - j][c].x;
+                    v[c].y += tap[j][c] * s[CH_H + r - j][c].y;
                 }
-                float2 *row = tile + (sl * CH_R + r) * ROWP + pad<K>(n0);    // n0, n0+1 share a pad group
-#pragma unroll
-                for (int c = 0; c < C; c++) row[c] = v[c];
             }
+            float2 *row = tile + (sl * CH_R + r) * ROWP + pad<K>(n0);    // n0, n0+1 share a pad group
 #pragma unroll
-            for (int i = 0; i < CH_H; i++)
-#pragma unroll
-                for (int c = 0; c < C; c++) s[i][c] = s[i + CH_R][c];
+            for (int c = 0; c < C; c++) row[c] = v[c];
         }
+#pragma unroll
+        for (int i = 0; i < CH_H; i++)
+#pragma unroll
+            for (int c = 0; c < C; c++) s[i][c] = s[i + CH_R][c];
+        // next round's blocks (past the slab's last round: clamped, never used)
+#pragma unroll
+        for (int r = 0; r < CH_R; r++) load_raw(b0 + CH_R + r, s[CH_H + r]);
         lds_barrier();
 
         // ---- NS*CH_R independent K-point FFTs, in place
@@ -251,7 +274,7 @@ template <int K, int C, int T>
 static hipError_t launch_one(const ChanArgs &a, hipStream_t st)
 {
     constexpr int NS = T / (K / C);
-    size_t lds = (size_t)(NS * CH_R * Plan<K>::ROWP) * sizeof(float2);
+    size_t lds = (size_t)(NS * CH_R * Plan<K>::ROWP) * sizeof(float2) + (size_t)CH_P * K * sizeof(float);
     long long nslabs = ((long long)a.nblocks + a.slab_blocks - 1) / a.slab_blocks;
     unsigned grid = (unsigned)((nslabs + NS - 1) / NS);
     if (grid == 0) return hipSuccess;
