@@ -292,6 +292,22 @@ static hipError_t launch_one(const ChanArgs &a, hipStream_t st)
 int channelizer_supported(unsigned K)
 { return (K >= 2 && K <= 1024 && (K & (K - 1)) == 0) ? 1 : 0; }
 
+// Slab sizing.  A slab costs a 13-block halo re-read, and a grid that is not a whole number of
+// waves over the CUs idles part of the chip in its last wave (K = 1024: one 512-thread workgroup
+// per CU).  Pick the largest slab <= 512 blocks for which the grid is k * capacity workgroups.
+// The result does not depend on the slab size (each output block sums the same terms in the same order).
+uint32_t channelizer_auto_slab(unsigned K, size_t nblocks, unsigned ncu)
+{
+    const unsigned threads = K >= 1024 ? 512u : 256u, C = K >= 4 ? 2u : 1u;
+    const unsigned ns = threads / (K / C > 0 ? K / C : 1u) ? threads / (K / C) : 1u;   // slabs per workgroup
+    const size_t capacity = (size_t)ncu * (K >= 1024 ? 1u : 2u) * ns;                   // slabs in one wave of workgroups
+    const size_t k = (nblocks + capacity * 512 - 1) / (capacity * 512);
+    size_t slab = (nblocks + capacity * k - 1) / (capacity * k);
+    slab = (slab + 7) & ~(size_t)7;
+    if (slab < 32) slab = 32;
+    return (uint32_t)slab;
+}
+
 hipError_t channelizer_launch(unsigned K, const ChanArgs &a, hipStream_t st)
 {
     switch (K) {

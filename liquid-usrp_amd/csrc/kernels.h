@@ -26,6 +26,8 @@ struct ChanArgs {
     uint32_t ablate;            // MCRX_ABLATE bit mask: skip phases (profiling experiments only)
 };
 int channelizer_supported(unsigned K);
+// blocks per workgroup slab such that the grid is a whole number of waves over `ncu` compute units
+uint32_t channelizer_auto_slab(unsigned K, size_t nblocks, unsigned ncu);
 hipError_t channelizer_launch(unsigned K, const ChanArgs &a, hipStream_t st);
 
 // ---------------------------------------------------------------- ofdmsync.hip

@@ -80,7 +80,7 @@ struct mcrx_hip_s {
     OfdmDesign od;
     mcrx_hip_config cfg{};
     std::vector<float> taps;
-    uint32_t dtheta = 0, slab_blocks = 64;
+    uint32_t dtheta = 0, slab_blocks = 0, ncu = 256;
     const float *d_taps = nullptr;
     SyncConsts sc{};
     std::vector<void *> owned;              // device allocations freed at destroy
@@ -238,7 +238,10 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     // (longer frames still fit while the total stays below the cap; overflow is counted)
     q->arena_cap = (uint64_t)q->max_rec * ((((uint64_t)q->max_payload + 15) & ~15ull) + 8ull * 8ull * (2ull * (q->max_payload + 4) + 8));
     if (q->arena_cap > (8ull << 30)) q->arena_cap = 8ull << 30;
-    q->slab_blocks = q->cfg.slab_blocks ? ((q->cfg.slab_blocks + 7) & ~7u) : 64;
+    q->slab_blocks = q->cfg.slab_blocks ? ((q->cfg.slab_blocks + 7) & ~7u) : 0;      // 0: sized per launch
+    { int dev = 0, n = 0;
+      if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+          q->ncu = (uint32_t)n; }
     q->taps = pfb_prototype(q->K, 7, 60.0f);
     q->dtheta = channel_center_step(N);
     q->hist_tiles = (M + cp + 8 + 7) / 8 + 1;
@@ -317,7 +320,8 @@ static int launch_channelizer(mcrx_hip_t q, const float2 *x, size_t nblocks, uin
     if (groups == 0 || q->N % groups) return fail(MCRX_EINVAL, "groups must divide the channel count");
     ChanArgs a;
     a.x = x; a.halo = halo; a.taps = q->d_taps; a.out = out;
-    a.nblocks = (uint32_t)nblocks; a.slab_blocks = q->slab_blocks;
+    a.nblocks = (uint32_t)nblocks;
+    a.slab_blocks = q->slab_blocks ? q->slab_blocks : channelizer_auto_slab(q->K, nblocks, q->ncu);
     a.first_sample_lo = (uint32_t)first_sample; a.dtheta = q->dtheta;
     a.ntiles = (uint32_t)ntiles_stride; a.cg = q->N / groups;
     a.ablate = getenv("MCRX_ABLATE") ? (uint32_t)atoi(getenv("MCRX_ABLATE")) : 0u;
