@@ -70,19 +70,118 @@ __device__ __forceinline__ uint32_t rad2u32(float rad)
 __device__ __forceinline__ float u32rad(uint32_t u)
 { return (float)((double)(int32_t)u * 1.4629180792671596e-09); }   // 2 pi / 2^32
 
-// wave64 all-reduce sums
-__device__ __forceinline__ float wave_sum(float v)
+// ---- cross-lane primitives.  Lane exchanges use DPP modifiers where the pattern exists
+// (xor 1, 2, 8: folded into the consuming VALU instruction) and the LDS crossbar
+// (ds_swizzle / ds_bpermute: no LDS memory is touched) for xor 4, 16, 32.
+template <int CTRL, bool ZERO_OOB = true>
+__device__ __forceinline__ float dpp_mov(float v, float old = 0.f)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                                 CTRL, 0xf, 0xf, ZERO_OOB));
+}
+__device__ __forceinline__ int lane_bperm32() { return (int)((__lane_id() ^ 32u) << 2); }   // ds_bpermute address of lane ^ 32
+template <int H>
+__device__ __forceinline__ float xor_lane(float v, int bperm32)
+{
+    if constexpr (H == 1)       return dpp_mov<0xB1>(v);           // quad_perm [1,0,3,2]
+    else if constexpr (H == 2)  return dpp_mov<0x4E>(v);           // quad_perm [2,3,0,1]
+    else if constexpr (H == 8)  return dpp_mov<0x128>(v);          // row_ror:8
+    else if constexpr (H == 4)  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x101F));
+    else if constexpr (H == 16) return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
+    else                        return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bperm32, __builtin_bit_cast(int, v)));
+}
+// x[l ^ 4] without the LDS crossbar: two bank-masked row shifts
+__device__ __forceinline__ float xor4_dpp(float v)
+{
+    const int b = __builtin_bit_cast(int, v);
+    const int t = __builtin_amdgcn_update_dpp(b, b, 0x104, 0xf, 0x5, false);      // row_shl:4 into banks 0, 2
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(t, b, 0x114, 0xf, 0xa, false));   // row_shr:4 into banks 1, 3
+}
+// One radix-2 DIF butterfly leg across lanes H apart, all on the VALU (the symbol loops are one
+// long dependent chain, so an LDS-crossbar round trip per stage is what they wait on):
+//   lanes with (l & H) == 0 (sg = +1): x + x[l ^ H];  lanes with (l & H) != 0 (sg = -1): x[l ^ H] - x.
+// H = 32 / 16 use gfx950's v_permlane32_swap / v_permlane16_swap on two copies of x: afterwards
+// the first copy holds the lower partner and the second the upper one in every lane.
+template <int H>
+__device__ __forceinline__ float bfly_leg(float x, float sg)
+{
+    if constexpr (H == 32) {
+        // (inline asm: with the builtin, hipcc 7.2 forwards the pre-swap copy into the use of the
+        //  second result.  s_nop covers the VALU-write -> permlane-read wait states.)
+        float lo = x, hi = x;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+        return fmaf(sg, hi, lo);
+    } else if constexpr (H == 16) {
+        float lo = x, hi = x;
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+        return fmaf(sg, hi, lo);
+    } else if constexpr (H == 8) return fmaf(sg, x, dpp_mov<0x128>(x));
+    else if constexpr (H == 4)   return fmaf(sg, x, xor4_dpp(x));
+    else if constexpr (H == 2)   return fmaf(sg, x, dpp_mov<0x4E>(x));
+    else                         return fmaf(sg, x, dpp_mov<0xB1>(x));
+}
+// wave64 all-reduce sums (butterfly: every lane ends with the total)
+__device__ __forceinline__ float wave_sum_fast(float v, int bperm32)
+{
+    v += xor_lane<1>(v, bperm32);  v += xor_lane<2>(v, bperm32);  v += xor_lane<4>(v, bperm32);
+    v += xor_lane<8>(v, bperm32);  v += xor_lane<16>(v, bperm32); v += xor_lane<32>(v, bperm32);
     return v;
 }
+__device__ __forceinline__ float wave_sum(float v) { return wave_sum_fast(v, lane_bperm32()); }
 __device__ __forceinline__ cfd wave_csum(cfd v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { v.x += __shfl_xor(v.x, o, 64); v.y += __shfl_xor(v.y, o, 64); }
+    const int bp = lane_bperm32();
+    return make_float2(wave_sum_fast(v.x, bp), wave_sum_fast(v.y, bp));
+}
+__device__ __forceinline__ uint32_t wave_xor_u32(uint32_t v)
+{
+    const int bp = lane_bperm32();
+#define MCRX_XSTEP(H) v ^= __builtin_bit_cast(uint32_t, xor_lane<H>(__builtin_bit_cast(float, v), bp));
+    MCRX_XSTEP(1) MCRX_XSTEP(2) MCRX_XSTEP(4) MCRX_XSTEP(8) MCRX_XSTEP(16) MCRX_XSTEP(32)
+#undef MCRX_XSTEP
     return v;
 }
+// inclusive prefix sum over the 64 lanes (DPP Kogge-Stone inside rows, row broadcasts across)
+__device__ __forceinline__ float wave_scan_fast(float v)
+{
+    v += dpp_mov<0x111>(v);                      // row_shr:1, lanes without a source add 0
+    v += dpp_mov<0x112>(v);
+    v += dpp_mov<0x114>(v);
+    v += dpp_mov<0x118>(v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));  // row_bcast:15
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false));  // row_bcast:31
+    return v;
+}
+// wave total through the DPP scan and one v_readlane (no LDS crossbar): wave-uniform result
+__device__ __forceinline__ float wave_total_dpp(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_scan_fast(v)), 63));
+}
+// atan2 for finite arguments: degree-7 minimax in t^2 on [0, 1] (max error 1.2e-7 evaluated in
+// float), octant folding, no special-case handling (0, 0 -> 0)
+__device__ __forceinline__ float atan2_fast(float y, float x)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float t = mn * __builtin_amdgcn_rcpf(fmaxf(mx, 1e-37f));
+    const float s = t * t;
+    float p = -4.0545611898e-03f;
+    p = fmaf(p, s, 2.1862935605e-02f); p = fmaf(p, s, -5.5912294062e-02f); p = fmaf(p, s, 9.6421949108e-02f);
+    p = fmaf(p, s, -1.3908628615e-01f); p = fmaf(p, s, 1.9946565475e-01f); p = fmaf(p, s, -3.3329860772e-01f);
+    p = fmaf(p, s, 9.9999933558e-01f);
+    float r = t * p;
+    r = ay > ax ? 1.5707963267948966f - r : r;
+    r = x < 0.f ? 3.14159265358979323846f - r : r;
+    return copysignf(r, y);
+}
+// e^{-j 2 pi rev} on the transcendental unit (see sincos_u32_hw)
+__device__ __forceinline__ cfd rot_down(cfd x, float rev)
+{
+    const float s = __builtin_amdgcn_sinf(rev), c = __builtin_amdgcn_cosf(rev);
+    return make_float2(fmaf(x.x, c, x.y * s), fmaf(x.y, c, -(x.x * s)));
+}
+__device__ __forceinline__ float u32rev(uint32_t th) { return (float)(int32_t)th * 2.3283064365386963e-10f; }   // 2^-32
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ cfd shfl_c(cfd v, int src) { return make_float2(__shfl(v.x, src, 64), __shfl(v.y, src, 64)); }
 
 }  // namespace mcrx

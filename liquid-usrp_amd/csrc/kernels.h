@@ -58,6 +58,7 @@ struct SyncConsts {
     const float *Pfit;          // [2][M_pilot]
     const int16_t *data_rank, *pilot_rank, *en_rank;    // [M]
     const uint8_t *pilot_seq;   // [255]
+    const uint16_t *hdr_map;    // [288] received header bit -> de-interleaved position | scrambler bit << 15
     const float2 *dft_tw;       // [M]  W_M^k
     CodingDev cod;
     uint32_t max_payload_len, max_enc_len, max_syms;

@@ -4,6 +4,7 @@
 #include "../../include/mcrx_hip.h"
 #include "design.hpp"
 #include "kernels.h"
+#include "txcode.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -178,6 +179,21 @@ static int build_tables(mcrx_hip_t q)
     RC(q->upload(&c.pilot_rank, pr.data(), od.M));
     RC(q->upload(&c.en_rank, er.data(), od.M));
     RC(q->upload(&c.pilot_seq, od.pilot_seq, 255));
+    {   // Header bit map.  The header packet is always 36 bytes (14 + CRC-32 behind Golay(24,12),
+        // ofdmflexframe header), so its 4-pass interleaver is one fixed permutation of 288 bits:
+        // map[p] = position in the de-interleaved stream of received bit p (MSB first), bit 15 = the
+        // scrambler's bit at p.  Found by pushing single bits through the transmit interleaver.
+        std::vector<uint16_t> map(MCRX_HDR_SYMS, 0);
+        static const uint8_t smask[4] = { 0xb4, 0x6a, 0x8b, 0xc5 };
+        for (unsigned d = 0; d < MCRX_HDR_SYMS; d++) {
+            std::vector<uint8_t> x(MCRX_HDR_ENC, 0);
+            x[d >> 3] = (uint8_t)(0x80u >> (d & 7));
+            interleave(x, 4);
+            for (unsigned p = 0; p < MCRX_HDR_SYMS; p++)
+                if ((x[p >> 3] >> (7 - (p & 7))) & 1) map[p] = (uint16_t)(d | (((smask[(p >> 3) & 3] >> (7 - (p & 7))) & 1) << 15));
+        }
+        RC(q->upload(&c.hdr_map, map.data(), map.size()));
+    }
     std::vector<float2> tw(od.M);
     for (unsigned k = 0; k < od.M; k++) {
         double a = -2.0 * M_PI * (double)k / (double)od.M;

@@ -27,12 +27,6 @@ namespace mcrx {
 #define PI_F 3.14159265358979323846f
 
 // ------------------------------------------------------------------ small utilities
-__device__ __forceinline__ uint32_t wave_xor_u32(uint32_t v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v ^= (uint32_t)__shfl_xor((int)v, o, WV);
-    return v;
-}
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 __device__ __forceinline__ unsigned fec_enc_len_d(unsigned fs, unsigned n)
@@ -396,7 +390,10 @@ extern __shared__ __attribute__((aligned(16))) float2 sy_lds[];
 #define ldsf  (reinterpret_cast<float *>(sy_lds + c.M))                       /* float scratch  [2*M]  */
 #define ldspf (reinterpret_cast<float *>(sy_lds + c.M) + 2 * c.M)             /* pilot fit rows [M]    */
 #define ldsps (reinterpret_cast<uint8_t *>(reinterpret_cast<float *>(sy_lds + c.M) + 3 * c.M))  /* pilot bits [256] */
-#define SY_LDS_BYTES(M) ((size_t)(M) * 8 + (size_t)(M) * 12 + 256)
+#define ldshm (reinterpret_cast<uint16_t *>(ldsps + 256))                      /* header bit map [288]  */
+#define ldshb (ldsps + 256 + 2 * MCRX_HDR_SYMS)                                /* header bits, decoded order [288] */
+#define ldshd (reinterpret_cast<uint16_t *>(ldsps + 256 + 3 * MCRX_HDR_SYMS))   /* Golay-decoded 12-bit words [12] */
+#define SY_LDS_BYTES(M) ((size_t)(M) * 8 + (size_t)(M) * 12 + 256 + 3 * MCRX_HDR_SYMS + 32)
 
 // One wavefront per workgroup: LDS traffic of a wave is processed in order, so a compiler-level
 // fence is all the hand-off between lanes needs (no s_barrier, and no vmcnt(0) drain of the
@@ -407,52 +404,6 @@ __device__ __forceinline__ void wave_sync_lds()
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-
-// ---- cross-lane primitives of the lean symbol loop.  The loop is VALU-issue bound, so lane
-// exchanges use DPP modifiers where the pattern exists (xor 1, 2, 8) and the otherwise idle LDS
-// crossbar (ds_swizzle / ds_bpermute: no LDS memory is touched) for xor 4, 16, 32.
-template <int CTRL, bool ZERO_OOB = true>
-__device__ __forceinline__ float dpp_mov(float v, float old = 0.f)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
-                                                                 CTRL, 0xf, 0xf, ZERO_OOB));
-}
-template <int H>
-__device__ __forceinline__ float xor_lane(float v, int bperm32)
-{
-    if constexpr (H == 1)       return dpp_mov<0xB1>(v);           // quad_perm [1,0,3,2]
-    else if constexpr (H == 2)  return dpp_mov<0x4E>(v);           // quad_perm [2,3,0,1]
-    else if constexpr (H == 8)  return dpp_mov<0x128>(v);          // row_ror:8
-    else if constexpr (H == 4)  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x101F));
-    else if constexpr (H == 16) return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
-    else                        return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bperm32, __builtin_bit_cast(int, v)));
-}
-__device__ __forceinline__ float wave_sum_fast(float v, int bperm32)
-{
-    v += xor_lane<1>(v, bperm32);  v += xor_lane<2>(v, bperm32);  v += xor_lane<4>(v, bperm32);
-    v += xor_lane<8>(v, bperm32);  v += xor_lane<16>(v, bperm32); v += xor_lane<32>(v, bperm32);
-    return v;
-}
-// inclusive prefix sum over the 64 lanes (DPP Kogge-Stone inside rows, row broadcasts across)
-__device__ __forceinline__ float wave_scan_fast(float v)
-{
-    v += dpp_mov<0x111>(v);                      // row_shr:1, out-of-row lanes add 0
-    v += dpp_mov<0x112>(v);
-    v += dpp_mov<0x114>(v);
-    v += dpp_mov<0x118>(v);
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));  // row_bcast:15
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false));  // row_bcast:31
-    return v;
-}
-// e^{-j 2 pi rev} on the transcendental unit (v_sin/v_cos take revolutions; measured max abs
-// error 1.24e-7 on gfx950, the same as the polynomial in devmath.h)
-__device__ __forceinline__ cfd rot_down(cfd x, float rev)
-{
-    const float s = __builtin_amdgcn_sinf(rev), c = __builtin_amdgcn_cosf(rev);
-    return make_float2(x.x * c + x.y * s, x.y * c - x.x * s);
-}
-__device__ __forceinline__ float u32rev(uint32_t th) { return (float)(int32_t)th * 2.3283064365386963e-10f; }   // 2^-32
-__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 template <int E>
 struct Walker {
@@ -472,7 +423,16 @@ struct Walker {
     uint8_t *bsoft, *btmpa, *btmpb, *bhbits;
     float2 *bsyms, *bR;
     long long pre_off;          // >= 0: record space already reserved in the arena (payload worker)
+    uint32_t pre_idx;           // ... and its record slot
     int64_t handoff_last;       // scout: last event index of the frame just handed off
+    uint32_t jres;              // scout: job slot reserved at frame detection (0xFFFFFFFF: none)
+    int64_t pf_t; float2 pf_x[E];   // scout: lookahead window (first sample, raw samples)
+    long long ph[6];                // MCRX_DEBUG=2: cycles per phase of the symbol events
+    // lean path (power-of-two M >= 64, <= 64 pilots): butterfly twiddles / signs, ranks, fit rows
+    bool fastp;
+    float2 tw[6]; float sg[6]; int bp32;
+    int dr[E], pr[E]; float fxr[E];
+    float pf0, pf1;
 
     __device__ __forceinline__ Walker(const SyncArgs &a_, uint32_t ch_)
         : a(a_), c(a_.c), l(lane_id()), ch(ch_)
@@ -483,18 +443,23 @@ struct Walker {
         bhbits = a.hbits + (size_t)ch * MCRX_HDR_SYMS;
         bsyms = a.syms + (size_t)ch * c.max_syms;
         bR = a.R + (size_t)ch * c.M;
-        pre_off = -1; handoff_last = 0;
+        pre_off = -1; handoff_last = 0; jres = 0xFFFFFFFFu; fastp = false; pf_t = INT64_MIN; for (int i = 0; i < 6; i++) ph[i] = 0;
     }
-    __device__ __forceinline__ void bind_job(uint32_t j, const PayloadJob &job)
+    // payload worker: take over the synchronizer state of the job and reserve the record space
+    // (payload bytes, then framesyms) in the frame arena; false if the arena is exhausted
+    __device__ __forceinline__ bool bind_job(uint32_t j, const PayloadJob &job)
     {
         const size_t tstride = (size_t)c.max_enc_len + 16;
         bsoft = a.jsoft + (size_t)j * 8 * c.max_enc_len;
         btmpa = a.jtmp + (size_t)j * 2 * tstride; btmpb = btmpa + tstride;
         bR = a.jR + (size_t)j * c.M;
-        pre_off = (long long)job.arena_off;
-        const unsigned long long pbytes = ((unsigned long long)job.s.payload_len + 15ull) & ~15ull;
-        bsyms = reinterpret_cast<float2 *>(a.arena + job.arena_off + pbytes);
         s = job.s;
+        const unsigned long long pbytes = ((unsigned long long)s.payload_len + 15ull) & ~15ull;
+        const unsigned long long off = job.arena_off;             // set by place_jobs_kernel
+        if (off == ~0ull) return false;
+        pre_off = (long long)off; pre_idx = job.pad;
+        bsyms = reinterpret_cast<float2 *>(a.arena + off + pbytes);
+        return true;
     }
 
     __device__ __forceinline__ float2 sample(int64_t t) const
@@ -506,7 +471,7 @@ struct Walker {
     __device__ __forceinline__ float2 mixed(int64_t t) const
     {
         float2 v = sample(t);
-        if (t >= s.nco_t_ref) v = mix_down(v, s.nco_theta_ref + (uint32_t)(t - s.nco_t_ref) * s.nco_dtheta);
+        if (t >= s.nco_t_ref) v = mix_down_hw(v, s.nco_theta_ref + (uint32_t)(t - s.nco_t_ref) * s.nco_dtheta);
         return v;
     }
     __device__ __forceinline__ void init_consts()
@@ -536,7 +501,34 @@ struct Walker {
         // per-symbol tables into LDS (they sit on the symbol loop's dependency chain)
         for (int i = l; i < 255; i += WV) ldsps[i] = c.pilot_seq[i];
         for (int i = l; i < 2 * c.M_pilot; i += WV) ldspf[i] = c.Pfit[i];
+        for (int i = l; i < MCRX_HDR_SYMS; i += WV) ldshm[i] = c.hdr_map[i];
+        if (fast_ok()) init_fast();
         wave_sync_lds();
+    }
+    // constants of the lean path (also the whole setup of a payload worker)
+    __device__ __forceinline__ void init_fast()
+    {
+        fastp = true;
+#pragma unroll
+        for (int st = 0; st < 6; st++) {
+            const int h = 32 >> st;
+            const bool up = (l & h) != 0;
+            const float rev = (float)(l & (h - 1)) * (0.5f / (float)h);
+            tw[st] = up ? make_float2(__builtin_amdgcn_cosf(rev), -__builtin_amdgcn_sinf(rev)) : make_float2(1.f, 0.f);
+            sg[st] = up ? -1.f : 1.f;
+        }
+        bp32 = (l ^ 32) << 2;
+        const int lg = c.log2M;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int kk = (int)(__brev((unsigned)(l + WV * e)) >> (32 - lg));
+            k[e] = kk;
+            sct[e] = c.sctype[kk];
+            dr[e] = c.data_rank[kk]; pr[e] = c.pilot_rank[kk];
+            fxr[e] = ((kk > c.M2) ? (float)kk - (float)c.M : (float)kk) * 0.15915494309189535f;   // revolutions per rad of slope
+        }
+        const int Mp = c.M_pilot;
+        pf0 = (l < Mp) ? c.Pfit[l] : 0.f; pf1 = (l < Mp) ? c.Pfit[Mp + l] : 0.f;
     }
     template <int J>
     __device__ __forceinline__ void inlane_stage(float2 (&x)[E])
@@ -558,6 +550,7 @@ struct Walker {
     // forward DFT of x (time position i = l + 64 e) -> X[k[e]]
     __device__ __forceinline__ void fft(float2 (&x)[E])
     {
+        if (fastp) { fast_fft(x); return; }
         if (c.log2M) {
             if constexpr (E >= 16) inlane_stage<8>(x);         // in-lane stages, h = 64 j
             if constexpr (E >= 8) inlane_stage<4>(x);
@@ -595,7 +588,7 @@ struct Walker {
             wave_sync_lds();
         }
     }
-    __device__ __forceinline__ void load_raw(int64_t t_start, float2 (&x)[E])
+    __device__ __forceinline__ void load_raw_direct(int64_t t_start, float2 (&x)[E])
     {
 #pragma unroll
         for (int e = 0; e < E; e++) {
@@ -603,21 +596,41 @@ struct Walker {
             x[e] = (i < c.M) ? sample(t_start + i) : make_float2(0.f, 0.f);
         }
     }
+    // Scout window fetch with a one-window lookahead.  The state machine is a serial chain of
+    // HBM round trips; where the next event is usually one stride on (seek: +M, S0a -> S0b: +M/2,
+    // symbols: +M+cp) its window is requested now and picked up from registers by the next event.
+    // The lookahead load is branch free (clamped addresses): a load under a branch is waited for at the join.
+    __device__ __forceinline__ void load_raw(int64_t t_start, float2 (&x)[E])
+    {
+        if (t_start == pf_t) {
+#pragma unroll
+            for (int e = 0; e < E; e++) x[e] = (l + WV * e < c.M) ? pf_x[e] : make_float2(0.f, 0.f);
+        } else load_raw_direct(t_start, x);
+        const int stride = s.state == SY_RX ? c.L : (s.state == SY_SEEK ? c.M : c.M2);
+        const int64_t tn = t_start + stride;
+        const int64_t rn = tn - a.buf_first, len = a.end - a.buf_first;
+        const bool ok = a.scout != 0 && rn >= 0 && rn + c.M <= len;
+        const int64_t rc = ok ? rn : 0;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            int64_t r = rc + l + WV * e;
+            r = r < len ? r : len - 1;
+            pf_x[e] = a.chan[((size_t)(r >> 3) * a.chan_stride + a.chan_off + ch) * MCRX_TILE_S + (size_t)(r & 7)];
+        }
+        pf_t = ok ? tn : INT64_MIN;
+    }
     __device__ __forceinline__ void mix_window(int64_t t_start, float2 (&x)[E])
     {
 #pragma unroll
         for (int e = 0; e < E; e++) {
             const int64_t t = t_start + l + WV * e;
-            if (t >= s.nco_t_ref) x[e] = mix_down(x[e], s.nco_theta_ref + (uint32_t)(t - s.nco_t_ref) * s.nco_dtheta);
+            if (t >= s.nco_t_ref) x[e] = mix_down_hw(x[e], s.nco_theta_ref + (uint32_t)(t - s.nco_t_ref) * s.nco_dtheta);
         }
     }
     __device__ __forceinline__ void load_window(int64_t t_start, bool mix, float2 (&x)[E])
     {
-#pragma unroll
-        for (int e = 0; e < E; e++) {
-            const int i = l + WV * e;
-            x[e] = (i < c.M) ? (mix ? mixed(t_start + i) : sample(t_start + i)) : make_float2(0.f, 0.f);
-        }
+        load_raw(t_start, x);
+        if (mix) mix_window(t_start, x);
     }
     // S0 gain estimate + metric on the newest M samples ending at t_ev; returns s_hat (not scaled by g)
     __device__ __forceinline__ float2 s0_metric(int64_t t_ev, bool mix, float &power)
@@ -661,7 +674,7 @@ struct Walker {
         const unsigned long long need = pbytes + 8ull * nsym;
         uint32_t idx = 0xFFFFFFFFu; unsigned long long off = 0;
         if (l == 0) {
-            if (pre_off >= 0) { off = (unsigned long long)pre_off; idx = atomicAdd(a.nrec, 1u); }
+            if (pre_off >= 0) { off = (unsigned long long)pre_off; idx = pre_idx; }      // both placed by place_jobs_kernel
             else {
                 off = atomicAdd(a.arena_used, need);
                 if (off + need <= a.arena_cap) idx = atomicAdd(a.nrec, 1u);
@@ -701,32 +714,42 @@ struct Walker {
     __device__ __forceinline__ bool try_handoff(int64_t t_ev)
     {
         if (!a.scout) return false;
-        if (s.enc_len > c.max_enc_len || s.mod_len > c.max_syms || s.payload_len > c.max_payload_len) return false;
         const int64_t nsym = (int64_t)((s.mod_len + (uint32_t)c.M_data - 1) / (uint32_t)c.M_data);
         const int64_t t_last = t_ev + nsym * (int64_t)c.L;
-        if (t_last >= a.end) return false;
-        const unsigned long long pbytes = ((unsigned long long)s.payload_len + 15ull) & ~15ull;
-        const unsigned long long need = pbytes + 8ull * s.mod_len;
-        uint32_t j = 0xFFFFFFFFu; unsigned long long off = 0;
-        if (l == 0) {
-            j = atomicAdd(a.njobs, 1u);
-            if (j < a.max_jobs) {
-                off = atomicAdd(a.arena_used, need);
-                if (off + need > a.arena_cap) { a.jobs[j].ch = 0xFFFFFFFFu; j = 0xFFFFFFFEu; }  // void the slot
-            }
+        if (s.enc_len > c.max_enc_len || s.mod_len > c.max_syms || s.payload_len > c.max_payload_len || t_last >= a.end) {
+            void_reservation();
+            return false;
         }
-        j = (uint32_t)__shfl((int)j, 0, WV);
-        off = (unsigned long long)__shfl((long long)off, 0, WV);
+        uint32_t j = jres;
+        if (j == 0xFFFFFFFFu) {             // frame detected in an earlier launch: no slot reserved yet
+            if (l == 0) j = atomicAdd(a.njobs, 1u);
+            j = (uint32_t)__shfl((int)j, 0, WV);
+        }
+        jres = 0xFFFFFFFFu;
         if (j >= a.max_jobs) return false;
 #pragma unroll
         for (int e = 0; e < E; e++) if (k[e] >= 0) a.jR[(size_t)j * c.M + k[e]] = R[e];
         if (l == 0) {
             PayloadJob jb;
-            jb.s = s; jb.ch = ch; jb.pad = 0; jb.arena_off = off;
+            jb.s = s; jb.ch = ch; jb.pad = 0; jb.arena_off = 0;
             a.jobs[j] = jb;
         }
         handoff_last = t_last;
         return true;
+    }
+    // The job slot is requested when the frame is detected (S1), so the atomic's round trip hides
+    // under the header symbols; a frame that ends up not handed off gives the slot back as void.
+    __device__ __forceinline__ void reserve_job()
+    {
+        if (!a.scout || jres != 0xFFFFFFFFu) return;
+        uint32_t j = 0;
+        if (l == 0) j = atomicAdd(a.njobs, 1u);
+        jres = (uint32_t)__shfl((int)j, 0, WV);
+    }
+    __device__ __forceinline__ void void_reservation()
+    {
+        if (jres != 0xFFFFFFFFu && jres < a.max_jobs && l == 0) a.jobs[jres].ch = 0xFFFFFFFFu;
+        jres = 0xFFFFFFFFu;
     }
 
     // header complete: decode and configure the payload receiver
@@ -746,6 +769,11 @@ struct Walker {
             for (int b = 0; b < 4; b++) if (4 * w + b < MCRX_HDR_DEC) v |= (uint32_t)tb[4 * w + b] << (8 * b);
             s.hw[w] = v;
         }
+        header_fields(ok);
+    }
+    // decoded header bytes (s.hw) -> payload configuration
+    __device__ __forceinline__ void header_fields(bool ok)
+    {
         const unsigned proto = hbyte(8);
         const unsigned plen = (hbyte(9) << 8) | hbyte(10);
         const unsigned mod = hbyte(11);
@@ -902,11 +930,11 @@ struct Walker {
     __device__ __forceinline__ void run_job(uint32_t j)
     {
         const PayloadJob job = a.jobs[j];
-        bind_job(j, job);
+        if (!bind_job(j, job)) return;
         init_consts();
         const int64_t woff = (int64_t)(c.cp - c.backoff) - (int64_t)c.L + 1;
         float2 cur[E];
-        load_raw(s.cur + (int64_t)s.timer - 1 + woff, cur);
+        load_raw_direct(s.cur + (int64_t)s.timer - 1 + woff, cur);
         while (true) {
             const int64_t t_ev = s.cur + (int64_t)s.timer - 1;
             if (t_ev >= a.end) break;               // cannot happen: the scout checked the frame fits
@@ -914,7 +942,7 @@ struct Walker {
             // the next symbol's window address is known now: fetch it under this symbol's work
             float2 nxt[E];
             const int64_t t_nx = t_ev + (int64_t)c.L;
-            if (t_nx < a.end) load_raw(t_nx + woff, nxt);
+            if (t_nx < a.end) load_raw_direct(t_nx + woff, nxt);
             else {
 #pragma unroll
                 for (int e = 0; e < E; e++) nxt[e] = make_float2(0.f, 0.f);
@@ -934,7 +962,7 @@ struct Walker {
     // step), and v_sin / v_cos for the two rotations per sample.
     __device__ __forceinline__ bool fast_ok() const { return c.log2M >= 6 && c.M == WV * E && c.M_pilot <= WV; }
 
-    __device__ __forceinline__ void fast_fft(float2 (&x)[E], const float2 (&tw)[6], const float (&sg)[6], int bp32)
+    __device__ __forceinline__ void fast_fft(float2 (&x)[E])
     {
         // in-lane stages (span 64 J), twiddle W_{128 J}^{i mod 64 J}
 #pragma unroll
@@ -951,8 +979,7 @@ struct Walker {
         }
 #define SY_XSTAGE(ST, H)                                                                       \
         _Pragma("unroll") for (int e = 0; e < E; e++) {                                        \
-            const float px = xor_lane<H>(x[e].x, bp32), py = xor_lane<H>(x[e].y, bp32);        \
-            const float sx = fmaf(sg[ST], x[e].x, px), sy = fmaf(sg[ST], x[e].y, py);          \
+            const float sx = bfly_leg<H>(x[e].x, sg[ST]), sy = bfly_leg<H>(x[e].y, sg[ST]);    \
             if (H == 1) x[e] = make_float2(sx, sy);                                            \
             else x[e] = make_float2(sx * tw[ST].x - sy * tw[ST].y, sx * tw[ST].y + sy * tw[ST].x); \
         }
@@ -960,34 +987,47 @@ struct Walker {
 #undef SY_XSTAGE
     }
 
+    // One received symbol up to the pilot fit: NCO on the raw window (phase th_ws at its first
+    // sample, step dth), FFT, equaliser, then the pilots -- lane n < M_pilot takes pilot n
+    // (subcarrier order): phase, unwrap, linear fit p0 + p1 k, slope smoothing.
+    __device__ __forceinline__ void fast_core(float2 (&X)[E], uint32_t th_ws, uint32_t dth, uint32_t &pc, float &p1_prime,
+                                              float &p0, float &p1)
+    {
+        const int Mp = c.M_pilot;
+#pragma unroll
+        for (int e = 0; e < E; e++) X[e] = rot_down(X[e], u32rev(th_ws + (uint32_t)(l + WV * e) * dth));
+        fast_fft(X);
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            X[e] = cmul(X[e], R[e]);
+            if (pr[e] >= 0) ldsc[pr[e]] = X[e];
+        }
+        wave_sync_lds();
+        float2 P = ldsc[l < Mp ? l : 0];
+        uint32_t pi_ = pc + (uint32_t)l; pi_ = pi_ >= 255u ? pi_ - 255u : pi_;
+        const bool pneg = ldsps[pi_ < 255u ? pi_ : 0u] == 0;
+        wave_sync_lds();
+        if (pneg) { P.x = -P.x; P.y = -P.y; }
+        const float v = atan2_fast(P.y, P.x);
+        const float prev = dpp_mov<0x138, false>(v, v);                  // wave_shr:1, lane 0 keeps its own
+        const float turns = rintf((v - prev) * 0.15915494309189535f);
+        const float y = fmaf(-TWO_PI_F, wave_scan_fast(turns), v);
+        p0 = wave_total_dpp(pf0 * y);
+        p1 = wave_total_dpp(pf1 * y);
+        pc += (uint32_t)Mp; pc = pc >= 255u ? pc - 255u : pc;
+        p1 = 0.3f * p1 + (1.0f - 0.3f) * p1_prime;
+        p1_prime = p1;
+    }
+
+    // payload worker, lean symbol loop: the same arithmetic as rx_core + flex_symbol's payload
+    // branch with the wave-uniform state in scalars and buffer-relative window addresses
     __device__ __forceinline__ void run_job_fast(uint32_t j)
     {
         const PayloadJob job = a.jobs[j];
-        bind_job(j, job);
-        // ---- per-lane constants
-        float2 tw[6]; float sg[6];
+        if (!bind_job(j, job)) return;
+        init_fast();
 #pragma unroll
-        for (int st = 0; st < 6; st++) {
-            const int h = 32 >> st;
-            const bool up = (l & h) != 0;
-            const float rev = (float)(l & (h - 1)) * (0.5f / (float)h);
-            tw[st] = up ? make_float2(__builtin_amdgcn_cosf(rev), -__builtin_amdgcn_sinf(rev)) : make_float2(1.f, 0.f);
-            sg[st] = up ? -1.f : 1.f;
-        }
-        const int bp32 = (l ^ 32) << 2;
-        const int lg = c.log2M;
-        int dr[E], pr[E]; float fxr[E];
-#pragma unroll
-        for (int e = 0; e < E; e++) {
-            const int kk = (int)(__brev((unsigned)(l + WV * e)) >> (32 - lg));
-            k[e] = kk;
-            const int ty = c.sctype[kk];
-            dr[e] = c.data_rank[kk]; pr[e] = c.pilot_rank[kk];
-            fxr[e] = ((kk > c.M2) ? (float)kk - (float)c.M : (float)kk) * 0.15915494309189535f;   // revolutions per rad of slope
-            R[e] = ty ? bR[kk] : make_float2(0.f, 0.f);
-        }
-        const int Mp = c.M_pilot;
-        const float pf0 = (l < Mp) ? c.Pfit[l] : 0.f, pf1 = (l < Mp) ? c.Pfit[Mp + l] : 0.f;
+        for (int e = 0; e < E; e++) R[e] = sct[e] ? bR[k[e]] : make_float2(0.f, 0.f);
         for (int i = l; i < 255; i += WV) ldsps[i] = c.pilot_seq[i];
         wave_sync_lds();
 
@@ -1019,32 +1059,8 @@ struct Walker {
 #pragma unroll
                 for (int e = 0; e < E; e++) { const int r = r_ws + L + l + WV * e; nxt[e] = chb[(size_t)(r >> 3) * tstride + (size_t)(r & 7)]; }
             }
-            // NCO, FFT, equaliser
-            float2 X[E];
-#pragma unroll
-            for (int e = 0; e < E; e++) X[e] = rot_down(cur[e], u32rev(th_ws + (uint32_t)(l + WV * e) * dth));
-            fast_fft(X, tw, sg, bp32);
-#pragma unroll
-            for (int e = 0; e < E; e++) {
-                X[e] = cmul(X[e], R[e]);
-                if (pr[e] >= 0) ldsc[pr[e]] = X[e];
-            }
-            wave_sync_lds();
-            // pilots: lane n < Mp takes pilot n (subcarrier order), phase, unwrap, linear fit
-            float2 P = ldsc[l < Mp ? l : 0];
-            uint32_t pi_ = pc + (uint32_t)l; pi_ = pi_ >= 255u ? pi_ - 255u : pi_;
-            const bool pneg = ldsps[pi_ < 255u ? pi_ : 0u] == 0;
-            wave_sync_lds();
-            if (pneg) { P.x = -P.x; P.y = -P.y; }
-            const float v = atan2f(P.y, P.x);
-            const float prev = dpp_mov<0x138, false>(v, v);                  // wave_shr:1, lane 0 keeps its own
-            const float turns = rintf((v - prev) * 0.15915494309189535f);
-            const float y = fmaf(-TWO_PI_F, wave_scan_fast(turns), v);
-            const float p0 = wave_sum_fast(pf0 * y, bp32);
-            float p1 = wave_sum_fast(pf1 * y, bp32);
-            pc += (uint32_t)Mp; pc = pc >= 255u ? pc - 255u : pc;
-            p1 = 0.3f * p1 + (1.0f - 0.3f) * p1_prime;
-            p1_prime = p1;
+            float p0, p1;
+            fast_core(cur, th_ws, dth, pc, p1_prime, p0, p1);
             // de-rotate, soft bits
             const float p0r = p0 * 0.15915494309189535f;
             const bool full = (psi + (uint32_t)Md) * bps <= nbits;           // no tail guard needed
@@ -1053,7 +1069,7 @@ struct Walker {
                 if (dr[e] < 0) continue;
                 const uint32_t idx = psi + (uint32_t)dr[e];
                 if (idx >= mod_len) continue;
-                const float2 Z = rot_down(X[e], fmaf(p1, fxr[e], p0r));
+                const float2 Z = rot_down(cur[e], fmaf(p1, fxr[e], p0r));
                 syms[idx] = Z;
                 uint8_t sb[6];
                 const unsigned hs = demod_soft(c.cod, mod, Z, sb);
@@ -1094,11 +1110,127 @@ struct Walker {
         emit(t_ev0 + (int64_t)(nsym - 1) * L, true, valid, false);
     }
 
+    // scout, lean RXSYMBOLS event: the counterpart of rx_core on the Walker's state
+    __device__ __forceinline__ int rx_event_fast(int64_t t_ev)
+    {
+        const int L = c.L, cb = c.cp - c.backoff;
+        const int64_t ws = t_ev - L + 1 + cb;
+        const bool prof = (a.debug & 2) != 0;
+        long long k0 = prof ? (long long)__builtin_readcyclecounter() : 0ll, k1;
+#define SY_TICK(i) if (prof) { k1 = (long long)__builtin_readcyclecounter(); ph[i] += k1 - k0; k0 = k1; }
+        float2 X[E];
+        load_raw(ws, X);
+        if (prof) { float z = 0.f; for (int e = 0; e < E; e++) z += X[e].x; if (z == 1.2345e-30f) ph[5]++; }   // wait for the window
+        SY_TICK(0)
+        const uint32_t dth = s.nco_dtheta;
+        const uint32_t th_ws = s.nco_theta_ref + (uint32_t)(ws - s.nco_t_ref) * dth;
+        float p0, p1;
+        fast_core(X, th_ws, dth, s.pilot_count, s.p1_prime, p0, p1);
+        if (prof && p0 == 1.2345e-30f) ph[5]++;
+        SY_TICK(1)
+        const float p0r = p0 * 0.15915494309189535f;
+#pragma unroll
+        for (int e = 0; e < E; e++) X[e] = sct[e] ? rot_down(X[e], fmaf(p1, fxr[e], p0r)) : make_float2(0.f, 0.f);
+        uint32_t new_dtheta = dth;
+        if (s.num_symbols > 0) {
+            float dphi = p0 - s.phi_prime;
+            dphi -= TWO_PI_F * rintf(dphi * 0.15915494309189535f);
+            new_dtheta += rad2u32(1e-3f * dphi);
+        }
+        s.nco_theta_ref = s.nco_theta_ref + (uint32_t)(t_ev + 1 - s.nco_t_ref) * dth;
+        s.nco_t_ref = t_ev + 1;
+        s.nco_dtheta = new_dtheta;
+        s.phi_prime = p0;
+        s.num_symbols++;
+        s.timer = (uint32_t)L;
+        if (prof && new_dtheta == 0x12345u && X[0].x == 1.2345e-30f) ph[5]++;
+        SY_TICK(2)
+        int r;
+        if (s.fstate == FX_HEADER) r = flex_header_fast(X, t_ev);
+        else r = flex_symbol(X, t_ev);
+        SY_TICK(3)
+#undef SY_TICK
+        return r;
+    }
+
+    // header symbols: hard BPSK bits go straight to their de-interleaved, de-scrambled place in LDS
+    // (the header packet is always 36 bytes, so its interleaver is one fixed bit permutation)
+    __device__ __forceinline__ int flex_header_fast(const float2 (&X)[E], int64_t t_ev)
+    {
+        float ev = 0.f;
+#pragma unroll
+        for (int e = 0; e < E; e++) if (dr[e] >= 0) {
+            const uint32_t idx = s.header_symbol_index + (uint32_t)dr[e];
+            if (idx < MCRX_HDR_SYMS) {
+                const unsigned sym = X[e].x > 0 ? 0u : 1u;
+                const unsigned m = ldshm[idx];
+                ldshb[m & 0x1ffu] = (uint8_t)(sym ^ (m >> 15));
+                const float xh = sym ? -1.0f : 1.0f;
+                const float drr = xh - X[e].x, dii = -X[e].y;
+                const float evm = sqrtf(drr * drr + dii * dii);
+                ev += evm * evm;
+            }
+        }
+        s.evm_hat += wave_sum_fast(ev, bp32);
+        s.header_symbol_index += (uint32_t)c.M_data;
+        if (s.header_symbol_index >= MCRX_HDR_SYMS) {
+            decode_header_fast();
+            s.evm = 10.0f * log10f(s.evm_hat / (float)MCRX_HDR_SYMS);
+            if (s.header_valid) {
+                s.fstate = FX_PAYLOAD; s.payload_symbol_index = 0;
+                if (try_handoff(t_ev)) return 2;
+            }
+            else { emit(t_ev, false, false); return 1; }
+        }
+        return 0;
+    }
+    // 12 Golay(24,12) words -> 18 bytes, CRC-32 over the first 14: registers and LDS only
+    __device__ __forceinline__ void decode_header_fast()
+    {
+        wave_sync_lds();
+        if (l < 12) {
+            unsigned r = 0;
+#pragma unroll
+            for (int q = 0; q < 24; q++) r = (r << 1) | (unsigned)ldshb[24 * l + q];
+            ldshd[l] = (uint16_t)golay_dec_sym(r);
+        }
+        wave_sync_lds();
+        unsigned by[18];
+#pragma unroll
+        for (int g = 0; g < 6; g++) {
+            const unsigned s0 = ldshd[2 * g], s1 = ldshd[2 * g + 1];
+            by[3 * g] = (s0 >> 4) & 0xffu; by[3 * g + 1] = ((s0 << 4) & 0xf0u) | ((s1 >> 8) & 0x0fu); by[3 * g + 2] = s1 & 0xffu;
+        }
+        wave_sync_lds();
+        uint32_t crc = 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = 0; i < MCRX_HDR_DEC; i++) {
+            crc ^= by[i];
+#pragma unroll
+            for (int b = 0; b < 8; b++) crc = (crc >> 1) ^ (0xEDB88320u & (0u - (crc & 1u)));
+        }
+        crc = ~crc;
+        const uint32_t key = (by[14] << 24) | (by[15] << 16) | (by[16] << 8) | by[17];
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) if (4 * w + b < MCRX_HDR_DEC) v |= by[4 * w + b] << (8 * b);
+            s.hw[w] = v;
+        }
+        header_fields(crc == key);
+    }
+
     __device__ __forceinline__ void run()
     {
         s = a.st[ch];
         init_consts();
+        if (fastp && s.state == SY_RX && s.fstate == FX_HEADER && s.header_symbol_index > 0) {
+            for (int i = l; i < MCRX_HDR_SYMS; i += WV) ldshb[i] = bhbits[i];
+            wave_sync_lds();
+        }
         const int M = c.M, M2 = c.M2, L = c.L;
+        long long prof_cyc[5] = {0, 0, 0, 0, 0}; int prof_n[5] = {0, 0, 0, 0, 0};
         while (true) {
             // sample index of the next state-machine event
             int64_t t_ev;
@@ -1114,7 +1246,8 @@ struct Walker {
                 break;
             }
             s.cur = t_ev + 1;
-            if (a.debug && l == 0 && ch == 0) printf("[sync] ch0 t=%lld state=%d fstate=%d timer=%u hsi=%u psi=%u\n", (long long)t_ev, s.state, s.fstate, s.timer, s.header_symbol_index, s.payload_symbol_index);
+            const int st_in = s.state; const long long tk0 = (a.debug & 2) ? (long long)__builtin_readcyclecounter() : 0ll;
+            if ((a.debug & 1) && l == 0 && ch == 0) printf("[sync] ch0 t=%lld state=%d fstate=%d timer=%u hsi=%u psi=%u\n", (long long)t_ev, s.state, s.fstate, s.timer, s.header_symbol_index, s.payload_symbol_index);
 
             if (s.state == SY_SEEK) {
                 float pw; float2 sh = s0_metric(t_ev, false, pw);
@@ -1171,6 +1304,7 @@ struct Walker {
                 const float mag = sqrtf(gh.x * gh.x + gh.y * gh.y);
                 if (mag > c.sync_thresh && fabsf(atan2f(gh.y, gh.x)) < 0.1f * PI_F) {
                     s.state = SY_RX; s.timer = (uint32_t)(M + c.cp + c.backoff); s.num_symbols = 0;
+                    reserve_job();
                     // equaliser: order-4 LSQ smoothing of |G| and unwrapped arg G, R = 1/G
                     const float g = (float)M / sqrtf((float)(c.M_pilot + c.M_data));
                     float *yabs = ldsf, *yarg = ldsf + c.Nen;
@@ -1182,7 +1316,15 @@ struct Walker {
                         yarg[erank[e]] = atan2f(G.y, G.x);
                     }
                     wave_sync_lds();
-                    if (l == 0) {
+                    if (c.Nen <= WV) {
+                        // unwrap as a prefix sum of whole turns (each step of liquid's loop adds -rint(d / 2 pi))
+                        const float v = yarg[l < c.Nen ? l : 0];
+                        const float prev = dpp_mov<0x138, false>(v, v);
+                        const float turns = rintf((v - prev) * 0.15915494309189535f);
+                        const float y = fmaf(-TWO_PI_F, wave_scan_fast(turns), v);
+                        wave_sync_lds();
+                        if (l < c.Nen) yarg[l] = y;
+                    } else if (l == 0) {
                         for (int i = 1; i < c.Nen; i++) {
                             float v = yarg[i];
                             while ((v - yarg[i - 1]) >  PI_F) v -= 2.0f * PI_F;
@@ -1197,7 +1339,15 @@ struct Walker {
                         if (k[e] >= 0 && sct[e] != 0) {
                             const float *row = c.Ssm + (size_t)k[e] * c.Nen;
                             float A = 0.f, th = 0.f;
-                            for (int n = 0; n < c.Nen; n++) { A += row[n] * yabs[n]; th += row[n] * yarg[n]; }
+                            int n = 0;
+                            for (; n + 16 <= c.Nen; n += 16) {          // rows arrive 16 coefficients per round trip
+                                float rw[16];
+#pragma unroll
+                                for (int u = 0; u < 16; u++) rw[u] = row[n + u];
+#pragma unroll
+                                for (int u = 0; u < 16; u++) { A += rw[u] * yabs[n + u]; th += rw[u] * yarg[n + u]; }
+                            }
+                            for (; n < c.Nen; n++) { A += row[n] * yabs[n]; th += row[n] * yarg[n]; }
                             const float gr = A * cosf(th), gi = A * sinf(th);
                             const float d = gr * gr + gi * gi;
                             r = make_float2(gr / d, -gi / d);
@@ -1211,15 +1361,25 @@ struct Walker {
                     s.timer = (uint32_t)M2;
                 }
             } else {    // SY_RX
-                const int fr = rx_event(t_ev);
-                if (fr == 1) { reset_framesync(); s.timer = (uint32_t)L; }
+                const int fr = fastp ? rx_event_fast(t_ev) : rx_event(t_ev);
+                if (fr == 1) { void_reservation(); reset_framesync(); s.timer = (uint32_t)L; }
                 else if (fr == 2) {
                     // payload handed to a worker: jump over it; liquid leaves the synchronizer in
                     // SEEK with timer = M+cp after the frame's last symbol
                     reset_framesync(); s.timer = (uint32_t)L; s.cur = handoff_last + 1;
                 }
             }
+            if (a.debug & 2) { prof_cyc[st_in] += (long long)__builtin_readcyclecounter() - tk0; prof_n[st_in]++; }
         }
+        if ((a.debug & 2) && l == 0 && ch == 0)
+            printf("[prof] ch0 cycles/events  seek %lld/%d  s0a %lld/%d  s0b %lld/%d  s1 %lld/%d  rx %lld/%d\n",
+                   prof_cyc[0], prof_n[0], prof_cyc[1], prof_n[1], prof_cyc[2], prof_n[2], prof_cyc[3], prof_n[3], prof_cyc[4], prof_n[4]);
+        if ((a.debug & 2) && l == 0 && ch == 0)
+            printf("[prof] ch0 rx phases: load %lld  core %lld  derot+nco %lld  flex %lld\n", ph[0], ph[1], ph[2], ph[3]);
+        void_reservation();
+        // a header in progress continues in the next launch: its bits move from LDS to the channel's HBM slot
+        if (fastp && s.state == SY_RX && s.fstate == FX_HEADER && s.header_symbol_index > 0)
+            for (int i = l; i < MCRX_HDR_SYMS; i += WV) bhbits[i] = ldshb[i];
         if (l == 0) a.st[ch] = s;
     }
 };
@@ -1255,8 +1415,10 @@ __global__ __launch_bounds__(WV) void sync_kernel(SyncArgs a)
     w.run();
 }
 
-// one wave per handed-off frame
-template <int E>
+// one wave per handed-off frame.  Two builds: the lean symbol loop (power-of-two M >= 64, <= 64
+// pilots: every configuration the reference's applications use) and the general walker; the host
+// picks per design, so neither carries the other's registers.
+template <int E, bool FAST>
 __global__ __launch_bounds__(WV, 4) void payload_kernel(SyncArgs a)
 {
     launder(a);
@@ -1267,8 +1429,78 @@ __global__ __launch_bounds__(WV, 4) void payload_kernel(SyncArgs a)
     const uint32_t ch = a.jobs[j].ch;
     if (ch >= a.nch) return;
     Walker<E> w(a, ch);
-    if (w.fast_ok() && !(a.no_fast & 1)) w.run_job_fast(j);
+    if constexpr (FAST) w.run_job_fast(j);
     else w.run_job(j);
+}
+
+// Record space for the handed-off frames: an exclusive prefix sum of their sizes in job order
+// (one workgroup, between the scout and the worker launch), so no wave queues on an allocation
+// counter.  Frames that do not fit the arena are counted as dropped.
+#define PJ_T 1024
+__global__ __launch_bounds__(PJ_T) void place_jobs_kernel(SyncArgs a)
+{
+    __shared__ unsigned long long part[PJ_T];
+    launder(a);
+    uint32_t nj = *a.njobs;
+    if (nj > a.max_jobs) nj = a.max_jobs;
+    const uint32_t per = (nj + PJ_T - 1) / PJ_T;
+    const uint32_t j0 = threadIdx.x * per, j1 = (j0 + per < nj) ? j0 + per : nj;
+    auto need_of = [&](uint32_t j) -> unsigned long long {
+        if (a.jobs[j].ch >= a.nch) return 0ull;
+        const unsigned long long pb = ((unsigned long long)a.jobs[j].s.payload_len + 15ull) & ~15ull;
+        return pb + 8ull * a.jobs[j].s.mod_len;
+    };
+    unsigned long long sum = 0;
+    for (uint32_t j = j0; j < j1; j++) sum += need_of(j);
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int o = 1; o < PJ_T; o <<= 1) {
+        unsigned long long v = (int)threadIdx.x >= o ? part[threadIdx.x - o] : 0ull;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    const unsigned long long base = *a.arena_used;
+    unsigned long long off = base + part[threadIdx.x] - sum;
+    const unsigned long long grand = part[PJ_T - 1];
+    __syncthreads();
+    // second scan: record slots of the jobs that fit
+    uint32_t fit = 0;
+    {
+        unsigned long long o = off;
+        for (uint32_t j = j0; j < j1; j++) {
+            const unsigned long long nd = need_of(j);
+            if (a.jobs[j].ch < a.nch && o + nd <= a.arena_cap) fit++;
+            o += nd;
+        }
+    }
+    part[threadIdx.x] = fit;
+    __syncthreads();
+    for (int o = 1; o < PJ_T; o <<= 1) {
+        unsigned long long v = (int)threadIdx.x >= o ? part[threadIdx.x - o] : 0ull;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    const uint32_t rbase = a.nrec[0];
+    uint32_t ridx = rbase + (uint32_t)part[threadIdx.x] - fit;
+    uint32_t dropped = 0;
+    for (uint32_t j = j0; j < j1; j++) {
+        const unsigned long long nd = need_of(j);
+        if (a.jobs[j].ch < a.nch) {
+            if (off + nd <= a.arena_cap && ridx < a.max_rec) { a.jobs[j].arena_off = off; a.jobs[j].pad = ridx++; }
+            else { a.jobs[j].arena_off = ~0ull; dropped++; }
+        }
+        off += nd;
+    }
+    if (dropped) atomicAdd(a.nrec + 1, dropped);
+    __syncthreads();
+    if (threadIdx.x == PJ_T - 1) {
+        const unsigned long long total = base + grand;
+        *a.arena_used = total < a.arena_cap ? total : a.arena_cap;
+        const unsigned long long rtot = (unsigned long long)rbase + part[PJ_T - 1];
+        a.nrec[0] = rtot < a.max_rec ? (uint32_t)rtot : a.max_rec;
+    }
 }
 
 __global__ void sync_reset_kernel(ChanState *st, uint32_t nch, int64_t cur)
@@ -1311,7 +1543,10 @@ hipError_t sync_launch_payload(const SyncArgs &a, hipStream_t st)
     if (a.nch == 0 || !a.scout || a.max_jobs == 0) return hipSuccess;
     const size_t lds = SY_LDS_BYTES(a.c.M);
     const unsigned nj = a.max_jobs;
-#define SY_LAUNCH(EE) hipLaunchKernelGGL((payload_kernel<EE>), dim3(nj), dim3(WV), lds, st, a);
+    const bool fast = a.c.log2M >= 6 && a.c.M == WV * a.c.E && a.c.M_pilot <= WV && !(a.no_fast & 1);
+    hipLaunchKernelGGL(place_jobs_kernel, dim3(1), dim3(PJ_T), 0, st, a);
+#define SY_LAUNCH(EE) if (fast) hipLaunchKernelGGL((payload_kernel<EE, true>), dim3(nj), dim3(WV), lds, st, a); \
+                      else      hipLaunchKernelGGL((payload_kernel<EE, false>), dim3(nj), dim3(WV), lds, st, a);
     switch (a.c.E) {
     case 1:  SY_LAUNCH(1) break;
     case 2:  SY_LAUNCH(2) break;

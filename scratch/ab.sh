@@ -1,5 +1,5 @@
 #!/bin/bash
-for v in 0 8 16; do
+for v in 0 2 6 8; do
 MCRX_NO_FAST=$v python bench.py --no-cpu 2>/dev/null | tail -1 > gpurun_out/bq.json
 python - <<PY
 import json
