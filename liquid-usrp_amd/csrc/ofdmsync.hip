@@ -1437,69 +1437,59 @@ __global__ __launch_bounds__(WV, 4) void payload_kernel(SyncArgs a)
 // (one workgroup, between the scout and the worker launch), so no wave queues on an allocation
 // counter.  Frames that do not fit the arena are counted as dropped.
 #define PJ_T 1024
+#define PJ_CAP 8192
 __global__ __launch_bounds__(PJ_T) void place_jobs_kernel(SyncArgs a)
 {
-    __shared__ unsigned long long part[PJ_T];
+    __shared__ unsigned long long part[PJ_T];       // (valid count << 40) | bytes, scanned together
+    __shared__ uint32_t need_l[PJ_CAP];
     launder(a);
     uint32_t nj = *a.njobs;
     if (nj > a.max_jobs) nj = a.max_jobs;
-    const uint32_t per = (nj + PJ_T - 1) / PJ_T;
-    const uint32_t j0 = threadIdx.x * per, j1 = (j0 + per < nj) ? j0 + per : nj;
-    auto need_of = [&](uint32_t j) -> unsigned long long {
-        if (a.jobs[j].ch >= a.nch) return 0ull;
+    auto need_of = [&](uint32_t j) -> uint32_t {      // 0 = void slot (a live frame always has symbols)
+        if (a.jobs[j].ch >= a.nch) return 0u;
         const unsigned long long pb = ((unsigned long long)a.jobs[j].s.payload_len + 15ull) & ~15ull;
-        return pb + 8ull * a.jobs[j].s.mod_len;
+        return (uint32_t)(pb + 8ull * a.jobs[j].s.mod_len);
     };
-    unsigned long long sum = 0;
-    for (uint32_t j = j0; j < j1; j++) sum += need_of(j);
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    for (int o = 1; o < PJ_T; o <<= 1) {
-        unsigned long long v = (int)threadIdx.x >= o ? part[threadIdx.x - o] : 0ull;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
-    }
     const unsigned long long base = *a.arena_used;
-    unsigned long long off = base + part[threadIdx.x] - sum;
-    const unsigned long long grand = part[PJ_T - 1];
-    __syncthreads();
-    // second scan: record slots of the jobs that fit
-    uint32_t fit = 0;
-    {
-        unsigned long long o = off;
-        for (uint32_t j = j0; j < j1; j++) {
-            const unsigned long long nd = need_of(j);
-            if (a.jobs[j].ch < a.nch && o + nd <= a.arena_cap) fit++;
-            o += nd;
-        }
-    }
-    part[threadIdx.x] = fit;
-    __syncthreads();
-    for (int o = 1; o < PJ_T; o <<= 1) {
-        unsigned long long v = (int)threadIdx.x >= o ? part[threadIdx.x - o] : 0ull;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
-    }
     const uint32_t rbase = a.nrec[0];
-    uint32_t ridx = rbase + (uint32_t)part[threadIdx.x] - fit;
-    uint32_t dropped = 0;
-    for (uint32_t j = j0; j < j1; j++) {
-        const unsigned long long nd = need_of(j);
-        if (a.jobs[j].ch < a.nch) {
-            if (off + nd <= a.arena_cap && ridx < a.max_rec) { a.jobs[j].arena_off = off; a.jobs[j].pad = ridx++; }
+    if (nj <= PJ_CAP) {
+        for (uint32_t j = threadIdx.x; j < nj; j += PJ_T) need_l[j] = need_of(j);      // all requests in flight at once
+        __syncthreads();
+        const uint32_t per = (nj + PJ_T - 1) / PJ_T;
+        const uint32_t j0 = threadIdx.x * per, j1 = (j0 + per < nj) ? j0 + per : nj;
+        unsigned long long mine = 0;
+        for (uint32_t j = j0; j < j1; j++) if (need_l[j]) mine += (1ull << 40) | need_l[j];
+        part[threadIdx.x] = mine;
+        __syncthreads();
+        for (int o = 1; o < PJ_T; o <<= 1) {
+            const unsigned long long v = (int)threadIdx.x >= o ? part[threadIdx.x - o] : 0ull;
+            __syncthreads();
+            part[threadIdx.x] += v;
+            __syncthreads();
+        }
+        const unsigned long long tot = part[PJ_T - 1];
+        const unsigned long long tot_bytes = tot & ((1ull << 40) - 1), tot_cnt = tot >> 40;
+        if (base + tot_bytes <= a.arena_cap && rbase + tot_cnt <= a.max_rec) {
+            const unsigned long long excl = part[threadIdx.x] - mine;
+            unsigned long long off = base + (excl & ((1ull << 40) - 1));
+            uint32_t ridx = rbase + (uint32_t)(excl >> 40);
+            for (uint32_t j = j0; j < j1; j++) if (need_l[j]) { a.jobs[j].arena_off = off; a.jobs[j].pad = ridx++; off += need_l[j]; }
+            if (threadIdx.x == 0) { *a.arena_used = base + tot_bytes; a.nrec[0] = rbase + (uint32_t)tot_cnt; }
+            return;
+        }
+        __syncthreads();
+    }
+    // not everything fits (or more jobs than the staging holds): exact sequential placement
+    if (threadIdx.x == 0) {
+        unsigned long long off = base; uint32_t ridx = rbase, dropped = 0;
+        for (uint32_t j = 0; j < nj; j++) {
+            const uint32_t nd = need_of(j);
+            if (!nd) continue;
+            if (off + nd <= a.arena_cap && ridx < a.max_rec) { a.jobs[j].arena_off = off; a.jobs[j].pad = ridx++; off += nd; }
             else { a.jobs[j].arena_off = ~0ull; dropped++; }
         }
-        off += nd;
-    }
-    if (dropped) atomicAdd(a.nrec + 1, dropped);
-    __syncthreads();
-    if (threadIdx.x == PJ_T - 1) {
-        const unsigned long long total = base + grand;
-        *a.arena_used = total < a.arena_cap ? total : a.arena_cap;
-        const unsigned long long rtot = (unsigned long long)rbase + part[PJ_T - 1];
-        a.nrec[0] = rtot < a.max_rec ? (uint32_t)rtot : a.max_rec;
+        *a.arena_used = off; a.nrec[0] = ridx;
+        if (dropped) atomicAdd(a.nrec + 1, dropped);
     }
 }
 

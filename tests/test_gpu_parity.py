@@ -224,3 +224,38 @@ def test_resampled_front_end_feeds_the_receiver(oracle, product):
     rx.Flush()
     check_frames(rx.frames, ora.frames, rel=5e-5)
     rx.close(); rs.close()
+
+
+def test_record_pool_overflow_is_counted_not_fatal(product):
+    """More frames than `max_frames`: the placement kernel's sequential path delivers the ones that fit,
+    counts the rest in frames_dropped, and the handle keeps working."""
+    N, M, cp = 8, 64, 8
+    tx = product.multichanneltx(N, M, cp, 4)
+    iq, sent = tx.generate(3, 100, seed=5)
+    n = int(iq.numel()) // (16 * N) * (16 * N)
+    rx = product.multichannelrx(N, M, cp, 4, max_frames=10)
+    rx.Execute(iq[:n]); rx.Flush()
+    assert len(rx.frames) == 10 and rx.frames_dropped() == 3 * N - 10
+    for f in rx.frames:
+        assert f.payload_valid and sent[f.channel][(f.header[0] << 8) | f.header[1]] == (f.header, f.payload)
+    rx.Reset()
+    rx.Execute(iq[:n]); rx.Flush()
+    assert len([f for f in rx.frames if f.payload_valid]) >= 10
+    rx.close(); tx.close()
+
+
+@pytest.mark.parametrize("M,cp,mod,fec1", [(128, 16, 27, 7), (256, 32, 29, 6), (512, 64, 40, 1)])
+def test_wide_symbols_take_the_lean_path(oracle, product, M, cp, mod, fec1):
+    """E = M / 64 > 1 elements per lane (in-lane FFT stages) against the oracle, GPU transmitter as the source."""
+    N = 2
+    tx = product.multichanneltx(N, M, cp, 4)
+    iq, sent = tx.generate(2, 333, mod=mod, fec1=fec1, seed=9)
+    n = int(iq.numel()) // (16 * N) * (16 * N)
+    x = iq[:n].cpu().numpy()
+    ora = oracle.MultiChannelRx(N, M, cp, 4)
+    ora.execute(x)
+    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=400)
+    rx.Execute(iq[:n]); rx.Flush()
+    assert len(rx.frames) == 2 * N
+    check_frames(rx.frames, ora.frames)
+    rx.close(); tx.close()
