@@ -125,6 +125,8 @@ struct SyncArgs {
     uint8_t *jsoft;             // [max_jobs][8*max_enc_len]
     uint8_t *jtmp;              // [max_jobs][2*(max_enc_len+16)]
     int debug;                 // MCRX_DEBUG=1: trace state-machine events of channel 0
+    uint32_t *hint;             // host-mapped word: longest coded frame (bytes) among this launch's jobs
+    uint32_t enc_hint;          // the value the host last saw there (0: none yet)
     int no_fast;               // MCRX_NO_FAST=1: payload workers use the general symbol path (A/B experiments)
 };
 hipError_t sync_launch(const SyncArgs &a, hipStream_t st);           // scout kernel: one wave per channel

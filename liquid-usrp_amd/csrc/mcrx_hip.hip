@@ -94,6 +94,7 @@ struct mcrx_hip_s {
     FrameRec *d_rec = nullptr; uint8_t *d_arena = nullptr; uint32_t *d_nrec = nullptr;
     unsigned long long *d_arena_used = nullptr;
     PayloadJob *d_jobs = nullptr; uint32_t *d_njobs = nullptr; float2 *d_jR = nullptr;
+    uint32_t *h_hint = nullptr, *d_hint = nullptr;     // pinned, device-mapped: longest coded frame of the last launch
     uint8_t *d_jsoft = nullptr, *d_jtmp = nullptr;
     bool scout = true;
     // streaming state
@@ -279,6 +280,10 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     if ((rc = q->alloc(&q->d_arena_used, 1))) return bail(rc);
     q->scout = getenv("MCRX_NO_SCOUT") == nullptr;
     if ((rc = q->alloc(&q->d_njobs, 1))) return bail(rc);
+    if (hipHostMalloc((void **)&q->h_hint, sizeof(uint32_t), hipHostMallocMapped) == hipSuccess) {
+        *q->h_hint = 0;
+        if (hipHostGetDevicePointer((void **)&q->d_hint, q->h_hint, 0) != hipSuccess) q->d_hint = nullptr;
+    }
     if (q->scout) {
         if ((rc = q->alloc(&q->d_jobs, q->max_rec))) return bail(rc);
         if ((rc = q->alloc(&q->d_jR, (size_t)q->max_rec * M))) return bail(rc);
@@ -308,12 +313,13 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
 extern "C" int mcrx_hip_destroy(mcrx_hip_t q)
 {
     if (!q) return MCRX_OK;
-    hipDeviceSynchronize();
-    for (void *p : q->owned) hipFree(p);
-    for (int i = 0; i < 2; i++) if (q->d_chan[i]) hipFree(q->d_chan[i]);
-    if (q->h_stage) hipHostFree(q->h_stage);
-    for (int w = 0; w < 3; w++) for (auto e : q->evring[w]) if (e) hipEventDestroy(e);
-    if (q->stream) hipStreamDestroy(q->stream);
+    (void)hipDeviceSynchronize();
+    for (void *p : q->owned) (void)hipFree(p);
+    for (int i = 0; i < 2; i++) if (q->d_chan[i]) (void)hipFree(q->d_chan[i]);
+    if (q->h_stage) (void)hipHostFree(q->h_stage);
+    if (q->h_hint) (void)hipHostFree(q->h_hint);
+    for (int w = 0; w < 3; w++) for (auto e : q->evring[w]) if (e) (void)hipEventDestroy(e);
+    if (q->stream) (void)hipStreamDestroy(q->stream);
     delete q;
     return MCRX_OK;
 }
@@ -359,6 +365,7 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     a.scout = q->scout ? 1 : 0;
     a.jobs = q->d_jobs; a.njobs = q->d_njobs; a.max_jobs = q->max_rec;
     a.jR = q->d_jR; a.jsoft = q->d_jsoft; a.jtmp = q->d_jtmp;
+    a.hint = q->d_hint; a.enc_hint = (q->h_hint && q->d_hint) ? *(volatile uint32_t *)q->h_hint : 0u;
     HIPCHK(hipMemsetAsync(q->d_njobs, 0, sizeof(uint32_t), st));
     RC(q->ev_begin(1, st));
     HIPCHK(sync_launch(a, st));
@@ -426,7 +433,7 @@ static int ensure_chan(mcrx_hip_t q, size_t tiles)
         HIPCHK(hipMemcpyAsync(nb[0], q->d_chan[q->chan_cur], (size_t)q->hist_tiles * q->N * MCRX_TILE * sizeof(float2),
                               hipMemcpyDeviceToDevice, q->stream));
     HIPCHK(hipStreamSynchronize(q->stream));
-    for (int i = 0; i < 2; i++) if (q->d_chan[i]) hipFree(q->d_chan[i]);
+    for (int i = 0; i < 2; i++) if (q->d_chan[i]) (void)hipFree(q->d_chan[i]);
     q->d_chan[0] = nb[0]; q->d_chan[1] = nb[1]; q->chan_cur = 0; q->chan_cap_tiles = tiles;
     return MCRX_OK;
 }

@@ -196,10 +196,9 @@ __device__ __forceinline__ void h128_try(const int (&flip)[12], unsigned s0, int
 template <unsigned... U>
 __device__ __forceinline__ void h128_try_all(const int (&flip)[12], unsigned s0, int &best, std::integer_sequence<unsigned, U...>)
 { (h128_try<U + 1u>(flip, s0, best), ...); }
-__device__ __forceinline__ unsigned h128_dec_soft_fast(const uint8_t *soft)
+__device__ __forceinline__ unsigned h128_dec_soft_words(uint32_t w0, uint32_t w1, uint32_t w2)
 {
-    const uint32_t *w32 = reinterpret_cast<const uint32_t *>(soft);           // 12-byte groups are 4-byte aligned
-    const uint32_t w[3] = { w32[0], w32[1], w32[2] };
+    const uint32_t w[3] = { w0, w1, w2 };
     int cost[12]; unsigned c = 0;
 #pragma unroll
     for (int k = 0; k < 12; k++) {
@@ -217,6 +216,11 @@ __device__ __forceinline__ unsigned h128_dec_soft_fast(const uint8_t *soft)
     h128_try_all(flip, s0, best, std::make_integer_sequence<unsigned, 255>{});
     const unsigned r = (unsigned)best & 0x1ffu;
     return r ? r - 1u : s0;
+}
+__device__ __forceinline__ unsigned h128_dec_soft_fast(const uint8_t *soft)
+{
+    const uint32_t *w32 = reinterpret_cast<const uint32_t *>(soft);           // 12-byte groups are 4-byte aligned
+    return h128_dec_soft_words(w32[0], w32[1], w32[2]);
 }
 __device__ __forceinline__ unsigned golay_mulP(unsigned v)
 {
@@ -666,7 +670,7 @@ struct Walker {
         s.fstate = FX_HEADER; s.header_symbol_index = 0; s.payload_symbol_index = 0; s.evm_hat = 0.f;
     }
 
-    __device__ __forceinline__ void emit(int64_t t_ev, bool with_payload, bool payload_valid, bool oversize = false)
+    __device__ __forceinline__ void emit(int64_t t_ev, bool with_payload, bool payload_valid, bool oversize = false, bool copy_payload = true)
     {
         const uint32_t nsym = (with_payload && !oversize) ? s.mod_len : 0u;
         const uint32_t plen = (with_payload && !oversize) ? s.payload_len : 0u;
@@ -700,7 +704,7 @@ struct Walker {
         if (with_payload && !oversize) {
             const uint8_t *src = btmpb;
             uint8_t *dst = a.arena + off;
-            for (uint32_t i = (uint32_t)l; i < plen; i += WV) dst[i] = src[i];
+            if (copy_payload) for (uint32_t i = (uint32_t)l; i < plen; i += WV) dst[i] = src[i];
             if (pre_off < 0) {          // payload workers write framesyms straight into the record
                 const float2 *ss = bsyms;
                 float2 *ds = reinterpret_cast<float2 *>(a.arena + off + pbytes);
@@ -1103,11 +1107,8 @@ struct Walker {
             for (int e = 0; e < E; e++) cur[e] = nxt[e];
         }
         // ---- frame complete: decode and emit (same tail as flex_symbol)
-        s.nco_dtheta = dth;
-        __syncthreads();
-        const bool valid = (a.no_fast & 2) ? false :
-            packet_decode(c.cod, soft_mode, false, s.payload_len, s.check, s.fec0, s.fec1, soft, btmpa, btmpb, (unsigned)a.no_fast);
-        emit(t_ev0 + (int64_t)(nsym - 1) * L, true, valid, false);
+        // ---- symbols done: decode_kernel (a workgroup per frame) takes the packet from here
+        if (l == 0) a.jobs[j].s.nco_dtheta = dth;
     }
 
     // scout, lean RXSYMBOLS event: the counterpart of rx_core on the Walker's state
@@ -1433,6 +1434,184 @@ __global__ __launch_bounds__(WV, 4) void payload_kernel(SyncArgs a)
     else w.run_job(j);
 }
 
+// ------------------------------------------------------------------ packet decode, a workgroup per frame
+// The payload workers leave 8 soft bits per coded byte in HBM.  De-interleaving them there costs
+// four passes of scattered 8-byte read-modify-writes per frame (measured: 4.7x the algorithmic HBM
+// bytes of the whole payload stage).  Here the frame's soft bits are staged once into LDS
+// (coalesced), the four passes run in LDS across 256 threads, and the Hamming(12,8) soft decoder
+// reads LDS.  A cell's rank in liquid's column walk is a closed form (columns are valid from row 0
+// down to a per-column count), so the passes need no ballots or sequential ranking.
+#define DK_T 256
+extern __shared__ __attribute__((aligned(16))) unsigned long long dk_soft[];
+// The passes walk the 8-byte groups with strides of ~2 sqrt(n) (one side) and ~sqrt(n)/2 (the other):
+// in a linear layout either lands on 4 of the 32 bank pairs.  XOR-folding index bits 5..9 into bits
+// 0..4 (a permutation inside every 1024-group block) spreads any such stride over all banks.
+#define DKP(e) ((e) ^ (((e) >> 5) & 31u))
+// valid cells in the first `len` columns of the walk after the (aliased) first one
+__device__ __forceinline__ unsigned il_cols_below(unsigned s0, unsigned len, unsigned Ncol, unsigned rem)
+{
+    auto span = [&](unsigned a0, unsigned b0) { const unsigned lo = a0 < rem ? a0 : rem, hi = b0 < rem ? b0 : rem; return hi - lo; };
+    return (s0 + len <= Ncol) ? span(s0, s0 + len) : span(s0, Ncol) + span(0u, s0 + len - Ncol);
+}
+// a / b and a % b for a < 2^22, b >= 1 through the float reciprocal (a dozen instructions instead of
+// the ~40 of a 32-bit division; the walk geometry is all such small numbers)
+__device__ __forceinline__ void divmod_small(unsigned a, unsigned b, unsigned &q, unsigned &r)
+{
+    q = (unsigned)((float)a * __builtin_amdgcn_rcpf((float)b));
+    int rr = (int)a - (int)(q * b);
+    if (rr < 0) { q--; rr += (int)b; }
+    if (rr >= (int)b) { q++; rr -= (int)b; }
+    r = (unsigned)rr;
+}
+// One de-interleaver pass on the LDS-resident soft bits.  Straight-line per cell (no exec-mask
+// branches: cells outside the walk swap a dummy group with itself), three cells per thread in flight.
+__device__ void il_pass_lds(unsigned n, unsigned Mi, unsigned Ncol, unsigned mask, unsigned dummy)
+{
+    const unsigned n2 = n / 2, total = Mi * (Ncol + 1), c0 = n / 3;
+    unsigned long long m64 = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) if ((mask >> (7 - k)) & 1) m64 |= 0xFFull << (8 * k);
+    unsigned R, rem, cnt0 = 0, t0, s1, c0r;
+    divmod_small(n2, Ncol, R, rem);                                      // column c < Ncol holds R + (c < rem) valid cells
+    if (c0 < n2) divmod_small(n2 - c0 + Ncol - 1, Ncol, cnt0, t0);      // first column: c0 is not reduced modulo Ncol
+    divmod_small(c0, Ncol, t0, c0r);
+    s1 = c0r + 1; s1 -= s1 >= Ncol ? Ncol : 0u;
+    constexpr int UN = 3;
+    for (unsigned q0 = threadIdx.x; q0 < total; q0 += UN * DK_T) {
+        unsigned ea[UN], eb[UN];
+        unsigned long long va[UN], vb[UN];
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const unsigned q = q0 + u * DK_T;
+            unsigned m, tcol; divmod_small(q, Mi, tcol, m);
+            unsigned cm = c0r + tcol; cm -= cm >= Ncol ? Ncol : 0u;          // tcol <= Ncol
+            const unsigned c = tcol ? cm : c0;
+            const unsigned j = m * Ncol + c;
+            // valid cells of the walk columns 1 .. tcol-1: (tcol-1) R plus the residues below rem among
+            // s1, s1+1, ... (mod Ncol), which wrap at most once
+            const unsigned len = tcol ? tcol - 1 : 0u, e = s1 + len;
+            const unsigned hi1 = e < Ncol ? e : Ncol, wrap = (e > Ncol ? e : Ncol) - Ncol;
+            const unsigned below = ((hi1 < rem ? hi1 : rem) - (s1 < rem ? s1 : rem)) + (wrap < rem ? wrap : rem);
+            const unsigned i = tcol ? cnt0 + len * R + below + m : m;
+            const bool ok = q < total && j < n2 && i < n2;
+            ea[u] = ok ? DKP(2 * i) : dummy;
+            eb[u] = ok ? DKP(2 * j + 1) : dummy;
+            va[u] = dk_soft[ea[u]]; vb[u] = dk_soft[eb[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            dk_soft[ea[u]] = (va[u] & ~m64) | (vb[u] & m64);
+            dk_soft[eb[u]] = (vb[u] & ~m64) | (va[u] & m64);
+        }
+    }
+    __syncthreads();
+}
+// CRC-32 of p[0..n) by one wave without long dependent chains through HBM: power-of-two chunks
+// aligned to the END of the message (lane r holds the r-th chunk from the right, the leftmost
+// one may be short and carries the 0xFFFFFFFF preset), byte table in LDS, then a binary tree in
+// which the right block always spans 2^k whole chunks, so every combine is one of the
+// precomputed "advance through 2^m zero bytes" operators.
+__device__ uint32_t crc32_tree(const CodingDev cod, uint32_t tab_off, uint32_t msg_off, uint32_t n)
+{
+    const uint32_t *lds_tab = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(dk_soft) + tab_off);
+    const uint8_t *p = reinterpret_cast<const uint8_t *>(dk_soft) + msg_off;
+    const int r = lane_id();
+    uint32_t C = 1, lc = 0;
+    while (64u * C < n) { C <<= 1; lc++; }
+    const int64_t hi = (int64_t)n - (int64_t)r * C, lo0 = hi - (int64_t)C;
+    const int64_t lo = lo0 < 0 ? 0 : lo0;
+    const uint32_t rmax = n ? (n + C - 1) / C - 1 : 0;
+    uint32_t s = ((uint32_t)r == rmax) ? 0xFFFFFFFFu : 0u;
+    for (int64_t i = lo; i < hi; i++) s = (s >> 8) ^ lds_tab[(s ^ p[i]) & 0xff];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const uint32_t v = (uint32_t)__shfl_down((int)s, 1 << k, WV);
+        if ((r & ((2 << k) - 1)) == 0 && r + (1 << k) < WV) {
+            const uint32_t *A = cod.crc_zadv + (size_t)(lc + k) * 1024;
+            s ^= A[v & 0xff] ^ A[256 + ((v >> 8) & 0xff)] ^ A[512 + ((v >> 16) & 0xff)] ^ A[768 + (v >> 24)];
+        }
+    }
+    return ~(uint32_t)__shfl((int)s, 0, WV);
+}
+__global__ __launch_bounds__(DK_T) void decode_kernel(SyncArgs a, uint32_t lds_soft_bytes, uint32_t msg_bytes)
+{
+    launder(a);
+    const uint32_t j = blockIdx.x;
+    uint32_t nj = *a.njobs;
+    if (nj > a.max_jobs) nj = a.max_jobs;
+    if (j >= nj) return;
+    const uint32_t ch = a.jobs[j].ch;
+    if (ch >= a.nch || a.jobs[j].arena_off == ~0ull) return;
+    const SyncConsts &c = a.c;
+    const uint32_t n_msg = a.jobs[j].s.payload_len, crc = a.jobs[j].s.check, fec0 = a.jobs[j].s.fec0, fec1 = a.jobs[j].s.fec1;
+    const uint32_t e1 = a.jobs[j].s.enc_len;
+    const size_t tstride = (size_t)c.max_enc_len + 16;
+    uint8_t *soft = a.jsoft + (size_t)j * 8 * c.max_enc_len;
+    uint8_t *tmpa = a.jtmp + (size_t)j * 2 * tstride, *tmpb = tmpa + tstride;
+    const uint32_t crc_len = (crc == 6) ? 4u : 0u, n0 = n_msg + crc_len;
+    const bool prof = (a.debug & 2) && j == 7;
+    long long tk[8]; int ntk = 0;
+#define DK_TICK() if (prof) tk[ntk++] = (long long)__builtin_readcyclecounter();
+    DK_TICK()
+    const bool lds_path = c.payload_soft && fec1 == 6 && fec0 == 1 && 8u * e1 <= lds_soft_bytes && !(a.no_fast & 8);
+    if (lds_path) {
+        const unsigned long long *g64 = reinterpret_cast<const unsigned long long *>(soft);
+        for (uint32_t b0 = 0; b0 < e1; b0 += 8 * DK_T) {           // eight requests per thread in flight
+            unsigned long long v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const uint32_t i = b0 + u * DK_T + threadIdx.x; v[u] = g64[i < e1 ? i : 0]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const uint32_t i = b0 + u * DK_T + threadIdx.x; if (i < e1) dk_soft[DKP(i)] = v[u]; }
+        }
+        __syncthreads();
+        DK_TICK()
+        unsigned Mi, Ni; il_dims(e1, Mi, Ni);
+        const unsigned dummy = lds_soft_bytes / 8 + msg_bytes / 8;          // one spare group behind the message area
+        il_pass_lds(e1, Mi, Ni + 8, 0x33, dummy);
+        il_pass_lds(e1, Mi, Ni + 4, 0x55, dummy);
+        il_pass_lds(e1, Mi, Ni + 2, 0x0f, dummy);
+        il_pass_lds(e1, Mi, Ni, 0xff, dummy);
+        DK_TICK()
+        // decoded bytes (message + CRC key) go to LDS behind the soft bits; the payload leaves for the
+        // frame arena from there, coalesced, by the whole workgroup
+        const uint32_t *w32 = reinterpret_cast<const uint32_t *>(dk_soft);
+        uint8_t *msg = reinterpret_cast<uint8_t *>(dk_soft) + lds_soft_bytes;
+        auto word = [&](uint32_t w) { return w32[2u * DKP(w >> 1) + (w & 1u)]; };            // 12 soft bits = 3 words, group-swizzled
+        for (uint32_t i = threadIdx.x; i < n0; i += DK_T) msg[i] = (uint8_t)h128_dec_soft_words(word(3 * i), word(3 * i + 1), word(3 * i + 2));
+        __syncthreads();
+        DK_TICK()
+        {
+            uint32_t *dst = reinterpret_cast<uint32_t *>(a.arena + a.jobs[j].arena_off);     // 8-byte aligned by construction
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(msg);
+            for (uint32_t i = threadIdx.x; i < (n_msg + 3) / 4; i += DK_T) dst[i] = src[i];   // record space is padded to 16 bytes
+        }
+        reinterpret_cast<uint32_t *>(dk_soft)[threadIdx.x] = c.cod.crc_byte[threadIdx.x];     // soft bits are spent: byte table in their place
+        __syncthreads();
+        if (threadIdx.x >= WV) return;
+    } else {
+        if (threadIdx.x >= WV) return;          // general schemes: one wave, in place in HBM
+    }
+    bool valid;
+    if (lds_path) {
+        valid = true;
+        if (crc_len) {
+            const uint8_t *msg = reinterpret_cast<const uint8_t *>(dk_soft) + lds_soft_bytes;
+            const uint32_t key = ((uint32_t)msg[n_msg] << 24) | ((uint32_t)msg[n_msg + 1] << 16) |
+                                 ((uint32_t)msg[n_msg + 2] << 8) | (uint32_t)msg[n_msg + 3];
+            valid = crc32_tree(c.cod, 0u, lds_soft_bytes, n_msg) == key;
+        }
+    } else valid = packet_decode(c.cod, c.payload_soft != 0, false, n_msg, crc, fec0, fec1, soft, tmpa, tmpb);
+    DK_TICK()
+    Walker<1> w(a, ch);
+    const PayloadJob job = a.jobs[j];
+    if (!w.bind_job(j, job)) return;
+    const int64_t nsym = (int64_t)((w.s.mod_len + (uint32_t)c.M_data - 1) / (uint32_t)c.M_data);
+    w.emit(w.s.cur + (int64_t)w.s.timer - 1 + (nsym - 1) * (int64_t)c.L, true, valid, false, /*copy_payload=*/!lds_path);
+    DK_TICK()
+    if (prof && threadIdx.x == 0) printf("[prof] decode wg7 cycles: stage %lld  passes %lld  h128 %lld  crc %lld  emit %lld\n", tk[1]-tk[0], tk[2]-tk[1], tk[3]-tk[2], tk[4]-tk[3], tk[5]-tk[4]);
+#undef DK_TICK
+}
+
 // Record space for the handed-off frames: an exclusive prefix sum of their sizes in job order
 // (one workgroup, between the scout and the worker launch), so no wave queues on an allocation
 // counter.  Frames that do not fit the arena are counted as dropped.
@@ -1442,6 +1621,9 @@ __global__ __launch_bounds__(PJ_T) void place_jobs_kernel(SyncArgs a)
 {
     __shared__ unsigned long long part[PJ_T];       // (valid count << 40) | bytes, scanned together
     __shared__ uint32_t need_l[PJ_CAP];
+    __shared__ uint32_t maxenc;
+    if (threadIdx.x == 0) maxenc = 0;
+    __syncthreads();
     launder(a);
     uint32_t nj = *a.njobs;
     if (nj > a.max_jobs) nj = a.max_jobs;
@@ -1453,8 +1635,15 @@ __global__ __launch_bounds__(PJ_T) void place_jobs_kernel(SyncArgs a)
     const unsigned long long base = *a.arena_used;
     const uint32_t rbase = a.nrec[0];
     if (nj <= PJ_CAP) {
-        for (uint32_t j = threadIdx.x; j < nj; j += PJ_T) need_l[j] = need_of(j);      // all requests in flight at once
+        uint32_t me = 0;
+        for (uint32_t j = threadIdx.x; j < nj; j += PJ_T) {                             // all requests in flight at once
+            need_l[j] = need_of(j);
+            const uint32_t e = a.jobs[j].ch < a.nch ? a.jobs[j].s.enc_len : 0u;
+            me = e > me ? e : me;
+        }
+        if (me) atomicMax(&maxenc, me);
         __syncthreads();
+        if (threadIdx.x == 0 && a.hint && maxenc) *a.hint = maxenc;                     // host-mapped: sizes the next launch's LDS
         const uint32_t per = (nj + PJ_T - 1) / PJ_T;
         const uint32_t j0 = threadIdx.x * per, j1 = (j0 + per < nj) ? j0 + per : nj;
         unsigned long long mine = 0;
@@ -1537,6 +1726,13 @@ hipError_t sync_launch_payload(const SyncArgs &a, hipStream_t st)
     hipLaunchKernelGGL(place_jobs_kernel, dim3(1), dim3(PJ_T), 0, st, a);
 #define SY_LAUNCH(EE) if (fast) hipLaunchKernelGGL((payload_kernel<EE, true>), dim3(nj), dim3(WV), lds, st, a); \
                       else      hipLaunchKernelGGL((payload_kernel<EE, false>), dim3(nj), dim3(WV), lds, st, a);
+    // soft bits of one frame in LDS: 8 bytes per coded byte, at most 60 KiB (longer frames decode in HBM)
+    // (sized from the longest frame the previous launch saw -- a.enc_hint, read without a sync -- so
+    //  that more workgroups fit a CU; 0 = no history yet: size for the configured maximum)
+    const uint32_t enc_cap = a.enc_hint ? ((a.enc_hint + 127u) & ~127u) : a.c.max_enc_len;
+    size_t soft_lds = (size_t)8 * (enc_cap < a.c.max_enc_len ? enc_cap : a.c.max_enc_len);
+    if (soft_lds > 56 * 1024) soft_lds = 56 * 1024;
+    if (soft_lds < 4096) soft_lds = 4096;
     switch (a.c.E) {
     case 1:  SY_LAUNCH(1) break;
     case 2:  SY_LAUNCH(2) break;
@@ -1546,6 +1742,8 @@ hipError_t sync_launch_payload(const SyncArgs &a, hipStream_t st)
     default: return hipErrorInvalidValue;
     }
 #undef SY_LAUNCH
+    const size_t msg_lds = ((size_t)a.c.max_payload_len + 4 + 15) & ~(size_t)15;
+    if (fast) hipLaunchKernelGGL(decode_kernel, dim3(nj), dim3(DK_T), soft_lds + msg_lds + 16, st, a, (uint32_t)soft_lds, (uint32_t)msg_lds);
     return hipGetLastError();
 }
 

@@ -16,10 +16,13 @@ with open(os.path.join(dst, "r1_%s_kernel_stats.csv" % tag), "w") as f:
 acc = collections.defaultdict(lambda: [0.0, 0])
 for fn in sorted(os.listdir(src)):
     if not fn.endswith("_counter_collection.csv"): continue
+    per = collections.defaultdict(float)            # rocprofv3 emits one row per counter instance: sum them per dispatch
     for r in csv.DictReader(open(os.path.join(src, fn))):
         if not any(o in r["Kernel_Name"] for o in ours): continue
         name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        a = acc[(name, r["Counter_Name"])]; a[0] += float(r["Counter_Value"]); a[1] += 1
+        per[(name, r["Counter_Name"], r["Dispatch_Id"])] += float(r["Counter_Value"])
+    for (name, cn, _), v in per.items():
+        a = acc[(name, cn)]; a[0] += v; a[1] += 1
 with open(os.path.join(dst, "r1_%s_pmc.csv" % tag), "w") as f:
     f.write("kernel,counter,dispatches,mean_per_dispatch\n")
     for (k, c), (s, n) in sorted(acc.items()): f.write('"%s",%s,%d,%.1f\n' % (k, c, n, s / n))
