@@ -135,17 +135,24 @@ def main():
     out = None
     if rank == 0:
         per = {k: v[0] / max(v[1], 1) for k, v in stats.items()}          # mean ms per launch
-        ch_ms, sc_ms, pw_ms = per["channelizer_kernel"], per["sync_kernel"], per["payload_kernel"]
-        sy_ms = sc_ms + pw_ms
-        # algorithmic bytes per launch: the channelizer moves 12 B per wideband
-        # sample of its slab; the payload workers read each channel sample of their frames once
-        # (8 B per channel sample = 4 B per wideband sample); the scout reads the rest.
+        ch_ms, sc_ms = per["channelizer_kernel"], per["sync_kernel"]
+        pl_ms, pw_ms, dk_ms = per["place_jobs_kernel"], per["payload_kernel"], per["decode_kernel"]
+        sy_ms = sc_ms + pl_ms + pw_ms + dk_ms
+        # algorithmic HBM bytes per launch: the channelizer moves 12 B per wideband
+        # sample of its slab (8 read + 4 written); the payload workers read each channel sample of their
+        # frames once (4 B per wideband sample) and write 8 B per data symbol plus its soft bits; the
+        # scout reads the preamble/header windows only; the decoder reads the soft bits once.
+        nsym_frame = -(-8 * ((args.payload + 4) * 3 // 2) // 2)                      # QPSK symbols of one h128-coded frame
+        nframes = N * reps
         kbytes = {"channelizer_kernel": B_CHANNELIZER * T * K,
-                  "payload_kernel": B_SYNC * world * T * K,
-                  "sync_kernel": B_SYNC * world * T * K * (10.0 / 176.0)}
+                  "payload_kernel": B_SYNC * world * T * K + nframes * nsym_frame * (8 + 2),
+                  "sync_kernel": B_SYNC * world * T * K * (10.0 / 176.0),
+                  "decode_kernel": nframes * (nsym_frame * 2 + args.payload),
+                  "place_jobs_kernel": nframes * 16.0}
         kname = max(per, key=per.get)                                      # dominant kernel by time
         kms = per[kname]
         achieved = kbytes[kname] / (kms * 1e-3) / 1e9
+        traffic = measured_traffic(kname, N, reps, args.payload, world)
         out = {
             "metric": "complex Msamples/s through multichannelrx",
             "value": round(value, 3), "unit": "Msamples/s",
@@ -160,11 +167,10 @@ def main():
                        "parallelism": "time-sharded channelizer -> all-to-all -> %d channels/GPU" % cg
                                       if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "ms_per_launch": round(kms, 4),
+                         "kernels_ms": {k: round(v, 4) for k, v in per.items()},
                          "channelizer_ms": round(ch_ms, 4), "sync_ms": round(sy_ms, 4),
-                         "scout_ms": round(sc_ms, 4), "payload_ms": round(pw_ms, 4),
-                         "channelizer_gbs": round(B_CHANNELIZER * T * K / (ch_ms * 1e-3) / 1e9, 1),
                          "pipeline_frac_of_16B_roofline": round(value * 1e6 * 16.0 / (world * HBM_PEAK_GBS * 1e9), 5)},
             "verified": {"frames": len(frames), "expected": expect, "bit_exact_payloads": n_ok, "ok": verified},
             "setup_s": {"iq_generation": round(gen_s, 2)},
@@ -179,6 +185,23 @@ def main():
         print(json.dumps(out))
     if not verified:
         sys.exit("rank %d: verification failed (%d/%d frames, %d ok)" % (rank, len(frames), expect, n_ok))
+
+
+def measured_traffic(kernel, N, reps, payload, world):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r1_*_traffic.json:
+    2 x FETCH_SIZE + WRITE_SIZE, collected on this workload by scratch/prof.sh); None when the run's
+    configuration is not the profiled one.  Counters cannot be read from inside the timed run."""
+    import glob
+    if (N, reps, payload, world) != (512, 8, 1200, 1):
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r1_*_traffic.json")))
+    if not files:
+        return None
+    prof = json.load(open(files[-1]))
+    for name, t in prof.get("kernels", {}).items():
+        if kernel in name:
+            return round(t["hbm_bytes_per_launch"], 0)
+    return None
 
 
 def cpu_baseline(ora, base, N, M, cp, taper, reps):

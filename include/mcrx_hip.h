@@ -110,10 +110,12 @@ int  mcrx_hip_restart(mcrx_hip_t q, void *stream);
 int  mcrx_hip_get_taps(mcrx_hip_t q, float *h, size_t n);             /* p*K prototype taps */
 uint32_t mcrx_hip_nco_step(mcrx_hip_t q);                             /* 32-bit phase increment */
 int  mcrx_hip_kernel_time_ms(mcrx_hip_t q, float *channelizer_ms, float *sync_ms); /* last launches */
-/* summed HIP-event durations [ms] and launch counts since the last reset of the statistics,
- * per kernel: [0] channelizer_kernel, [1] sync_kernel (per-channel scout), [2] payload_kernel
- * (events are recorded on the launch stream; no host sync per launch) */
-int  mcrx_hip_kernel_stats(mcrx_hip_t q, double ms_total[3], uint64_t launches[3], int reset);
+/* summed HIP-event durations [ms] and launch counts since the last reset of the statistics, per
+ * kernel: [0] channelizer_kernel, [1] sync_kernel (per-channel scout), [2] place_jobs_kernel,
+ * [3] payload_kernel (per-frame symbol loop), [4] decode_kernel (per-frame packet decode).
+ * Events are recorded on the launch stream; no host sync per launch. */
+#define MCRX_NKERNELS 5
+int  mcrx_hip_kernel_stats(mcrx_hip_t q, double ms_total[MCRX_NKERNELS], uint64_t launches[MCRX_NKERNELS], int reset);
 
 const char *mcrx_hip_last_error(void);
 

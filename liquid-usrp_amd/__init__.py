@@ -263,9 +263,9 @@ class multichannelrx(object):
 
     def kernel_stats(self, reset=False):
         """{kernel: (total_ms, launches)} from HIP events recorded on the launch stream."""
-        ms, cnt = (C.c_double * 3)(), (C.c_uint64 * 3)()
+        names = ("channelizer_kernel", "sync_kernel", "place_jobs_kernel", "payload_kernel", "decode_kernel")
+        ms, cnt = (C.c_double * len(names))(), (C.c_uint64 * len(names))()
         _check(lib().mcrx_hip_kernel_stats(self._h, ms, cnt, 1 if reset else 0))
-        names = ("channelizer_kernel", "sync_kernel", "payload_kernel")
         return {n: (ms[i], cnt[i]) for i, n in enumerate(names)}
 
     def frames_dropped(self):

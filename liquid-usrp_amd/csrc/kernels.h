@@ -130,7 +130,9 @@ struct SyncArgs {
     int no_fast;               // MCRX_NO_FAST=1: payload workers use the general symbol path (A/B experiments)
 };
 hipError_t sync_launch(const SyncArgs &a, hipStream_t st);           // scout kernel: one wave per channel
-hipError_t sync_launch_payload(const SyncArgs &a, hipStream_t st);   // payload workers: one wave per handed-off frame
+// stage 0: record placement (one workgroup), 1: payload workers (one wave per handed-off frame),
+// 2: packet decode (one workgroup per frame; only after the lean workers -- the general ones decode in place)
+hipError_t sync_launch_payload(const SyncArgs &a, int stage, hipStream_t st);
 hipError_t sync_reset_launch(ChanState *st, uint32_t nch, int64_t cur, hipStream_t stream);
 
 }  // namespace mcrx

@@ -107,11 +107,11 @@ struct mcrx_hip_s {
     float2 *d_chan[2] = { nullptr, nullptr }; size_t chan_cap_tiles = 0; int chan_cur = 0;
     unsigned hist_tiles = 0;
     hipStream_t stream = nullptr;
-    // per-kernel HIP event ring: [0] channelizer, [1] sync scout, [2] payload workers; pairs (start, stop)
-    std::vector<hipEvent_t> evring[3];
-    size_t ev_used[3] = { 0, 0, 0 };
-    double ev_ms_total[3] = { 0, 0, 0 }; uint64_t ev_count[3] = { 0, 0, 0 };
-    float ev_last[3] = { 0, 0, 0 };
+    // per-kernel HIP event rings (MCRX_NKERNELS of them, see mcrx_hip.h); pairs (start, stop)
+    std::vector<hipEvent_t> evring[MCRX_NKERNELS];
+    size_t ev_used[MCRX_NKERNELS] = {};
+    double ev_ms_total[MCRX_NKERNELS] = {}; uint64_t ev_count[MCRX_NKERNELS] = {};
+    float ev_last[MCRX_NKERNELS] = {};
 
     int ev_begin(int which, hipStream_t st)
     {
@@ -300,7 +300,7 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
         return bail(fail(MCRX_ENOMEM, "pinned staging allocation failed"));
     if ((rc = q->alloc(&q->d_in, q->stage_cap))) return bail(rc);
     if (hipStreamCreate(&q->stream) != hipSuccess) return bail(fail(MCRX_EHIP, "hipStreamCreate failed"));
-    for (int w = 0; w < 3; w++) {
+    for (int w = 0; w < MCRX_NKERNELS; w++) {
         q->evring[w].resize(512, nullptr);
         for (auto &e : q->evring[w]) if (hipEventCreate(&e) != hipSuccess) return bail(fail(MCRX_EHIP, "hipEventCreate failed"));
     }
@@ -318,7 +318,7 @@ extern "C" int mcrx_hip_destroy(mcrx_hip_t q)
     for (int i = 0; i < 2; i++) if (q->d_chan[i]) (void)hipFree(q->d_chan[i]);
     if (q->h_stage) (void)hipHostFree(q->h_stage);
     if (q->h_hint) (void)hipHostFree(q->h_hint);
-    for (int w = 0; w < 3; w++) for (auto e : q->evring[w]) if (e) (void)hipEventDestroy(e);
+    for (int w = 0; w < MCRX_NKERNELS; w++) for (auto e : q->evring[w]) if (e) (void)hipEventDestroy(e);
     if (q->stream) (void)hipStreamDestroy(q->stream);
     delete q;
     return MCRX_OK;
@@ -371,9 +371,11 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     HIPCHK(sync_launch(a, st));
     RC(q->ev_end(1, st));
     if (q->scout) {
-        RC(q->ev_begin(2, st));
-        HIPCHK(sync_launch_payload(a, st));
-        RC(q->ev_end(2, st));
+        for (int stage = 0; stage < 3; stage++) {           // record placement, payload workers, packet decode
+            RC(q->ev_begin(2 + stage, st));
+            HIPCHK(sync_launch_payload(a, stage, st));
+            RC(q->ev_end(2 + stage, st));
+        }
     }
     return MCRX_OK;
 }
@@ -400,17 +402,17 @@ extern "C" int mcrx_hip_restart(mcrx_hip_t q, void *stream)
 extern "C" int mcrx_hip_kernel_time_ms(mcrx_hip_t q, float *ch_ms, float *sy_ms)
 {
     if (!q) return fail(MCRX_EINVAL, "null handle");
-    RC(q->ev_resolve(0)); RC(q->ev_resolve(1)); RC(q->ev_resolve(2));
+    for (int w = 0; w < MCRX_NKERNELS; w++) RC(q->ev_resolve(w));
     if (ch_ms) *ch_ms = q->ev_last[0];
-    if (sy_ms) *sy_ms = q->ev_last[1] + q->ev_last[2];      // scout + payload workers
+    if (sy_ms) *sy_ms = q->ev_last[1] + q->ev_last[2] + q->ev_last[3] + q->ev_last[4];      // scout .. decode
     return MCRX_OK;
 }
-extern "C" int mcrx_hip_kernel_stats(mcrx_hip_t q, double ms_total[3], uint64_t launches[3], int reset)
+extern "C" int mcrx_hip_kernel_stats(mcrx_hip_t q, double ms_total[MCRX_NKERNELS], uint64_t launches[MCRX_NKERNELS], int reset)
 {
     // HIP-event durations of every launch since the last reset, recorded on the stream the
-    // kernels were launched on: [0] channelizer_kernel, [1] sync_kernel (scout), [2] payload_kernel
+    // kernels were launched on (order: mcrx_hip.h)
     if (!q) return fail(MCRX_EINVAL, "null handle");
-    for (int w = 0; w < 3; w++) {
+    for (int w = 0; w < MCRX_NKERNELS; w++) {
         RC(q->ev_resolve(w));
         if (ms_total) ms_total[w] = q->ev_ms_total[w];
         if (launches) launches[w] = q->ev_count[w];

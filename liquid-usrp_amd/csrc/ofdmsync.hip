@@ -1717,22 +1717,31 @@ hipError_t sync_launch(const SyncArgs &a, hipStream_t st)
     return hipGetLastError();
 }
 
-hipError_t sync_launch_payload(const SyncArgs &a, hipStream_t st)
+hipError_t sync_launch_payload(const SyncArgs &a, int stage, hipStream_t st)
 {
     if (a.nch == 0 || !a.scout || a.max_jobs == 0) return hipSuccess;
     const size_t lds = SY_LDS_BYTES(a.c.M);
     const unsigned nj = a.max_jobs;
     const bool fast = a.c.log2M >= 6 && a.c.M == WV * a.c.E && a.c.M_pilot <= WV && !(a.no_fast & 1);
-    hipLaunchKernelGGL(place_jobs_kernel, dim3(1), dim3(PJ_T), 0, st, a);
+    if (stage == 0) {
+        hipLaunchKernelGGL(place_jobs_kernel, dim3(1), dim3(PJ_T), 0, st, a);
+        return hipGetLastError();
+    }
+    if (stage == 2) {
+        if (!fast) return hipSuccess;
+        // soft bits of one frame in LDS: 8 bytes per coded byte, at most 56 KiB (longer frames decode in HBM);
+        // sized from the longest frame the previous launch saw -- a.enc_hint, read without a sync -- so
+        // that more workgroups fit a CU; 0 = no history yet: size for the configured maximum
+        const uint32_t enc_cap = a.enc_hint ? ((a.enc_hint + 127u) & ~127u) : a.c.max_enc_len;
+        size_t soft_lds = (size_t)8 * (enc_cap < a.c.max_enc_len ? enc_cap : a.c.max_enc_len);
+        if (soft_lds > 56 * 1024) soft_lds = 56 * 1024;
+        if (soft_lds < 4096) soft_lds = 4096;
+        const size_t msg_lds = ((size_t)a.c.max_payload_len + 4 + 15) & ~(size_t)15;
+        hipLaunchKernelGGL(decode_kernel, dim3(nj), dim3(DK_T), soft_lds + msg_lds + 16, st, a, (uint32_t)soft_lds, (uint32_t)msg_lds);
+        return hipGetLastError();
+    }
 #define SY_LAUNCH(EE) if (fast) hipLaunchKernelGGL((payload_kernel<EE, true>), dim3(nj), dim3(WV), lds, st, a); \
                       else      hipLaunchKernelGGL((payload_kernel<EE, false>), dim3(nj), dim3(WV), lds, st, a);
-    // soft bits of one frame in LDS: 8 bytes per coded byte, at most 60 KiB (longer frames decode in HBM)
-    // (sized from the longest frame the previous launch saw -- a.enc_hint, read without a sync -- so
-    //  that more workgroups fit a CU; 0 = no history yet: size for the configured maximum)
-    const uint32_t enc_cap = a.enc_hint ? ((a.enc_hint + 127u) & ~127u) : a.c.max_enc_len;
-    size_t soft_lds = (size_t)8 * (enc_cap < a.c.max_enc_len ? enc_cap : a.c.max_enc_len);
-    if (soft_lds > 56 * 1024) soft_lds = 56 * 1024;
-    if (soft_lds < 4096) soft_lds = 4096;
     switch (a.c.E) {
     case 1:  SY_LAUNCH(1) break;
     case 2:  SY_LAUNCH(2) break;
@@ -1742,8 +1751,6 @@ hipError_t sync_launch_payload(const SyncArgs &a, hipStream_t st)
     default: return hipErrorInvalidValue;
     }
 #undef SY_LAUNCH
-    const size_t msg_lds = ((size_t)a.c.max_payload_len + 4 + 15) & ~(size_t)15;
-    if (fast) hipLaunchKernelGGL(decode_kernel, dim3(nj), dim3(DK_T), soft_lds + msg_lds + 16, st, a, (uint32_t)soft_lds, (uint32_t)msg_lds);
     return hipGetLastError();
 }
 

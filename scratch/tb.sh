@@ -6,5 +6,5 @@ python - <<'PY'
 import json
 d=json.load(open("gpurun_out/bq.json"))
 r=d["roofline"]
-print("value", d["value"], "ms/step", d["ms_per_step"], "chan", r["channelizer_ms"], "scout", r["scout_ms"], "payload", r["payload_ms"], d["verified"])
+print("value", d["value"], "ms/step", d["ms_per_step"], r["kernel"], r["frac"], r["traffic"], r["kernels_ms"], d["verified"]["ok"])
 PY
