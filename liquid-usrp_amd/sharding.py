@@ -34,7 +34,12 @@ def exchange(out, recv, world, dist):
     """Time shards -> channel shards.  `out`/`recv` are flat tensors of world equal chunks."""
     if world == 1:
         return out
-    dist.all_to_all_single(recv, out)
+    if out.is_complex():
+        # RCCL (like NCCL) has no complex element type: exchange the same bytes as float pairs
+        import torch
+        dist.all_to_all_single(torch.view_as_real(recv).reshape(-1), torch.view_as_real(out).reshape(-1))
+    else:
+        dist.all_to_all_single(recv, out)
     return recv
 
 

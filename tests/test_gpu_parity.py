@@ -259,3 +259,40 @@ def test_wide_symbols_take_the_lean_path(oracle, product, M, cp, mod, fec1):
     assert len(rx.frames) == 2 * N
     check_frames(rx.frames, ora.frames)
     rx.close(); tx.close()
+
+
+def test_two_rank_sharding_emulated_on_one_gpu(product):
+    """The multi-GPU data path (bench.py --gpus 2) with both ranks' HIP handles in one process: rank r
+    channelizes time slab r (halo from the slab before, absolute NCO phase) into per-destination groups,
+    the all-to-all is played by slicing, rank r synchronizes its channel shard over both slabs."""
+    import torch
+    from liquid_usrp_amd import sharding
+    N, M, cp, world, nf, plen = 16, 64, 8, 2, 2, 300
+    K, cg = 2 * N, N // world
+    tx = product.multichanneltx(N, M, cp, 4)
+    d_iq, sent = tx.generate(nf, plen, seed=21)
+    T = int(d_iq.numel()) // K
+    assert T % 8 == 0
+    halo = d_iq[(T - 13) * K:].clone()
+    rx, out = [], []
+    for r in range(world):
+        c0, cnt = sharding.shard_of(r, world, N)
+        h = product.multichannelrx(N, M, cp, 4, max_payload_len=plen, channel_first=c0, channel_count=cnt)
+        o = torch.empty(world * (T // 8) * cg * 8, dtype=torch.complex64, device="cuda")
+        h.restart()
+        h.channelize(d_iq, T, sharding.slab_first_sample(r, T, N), o, groups=world, d_halo=halo if r else None)
+        rx.append(h); out.append(o)
+    torch.cuda.synchronize()
+    chunk = (T // 8) * cg * 8
+    for r in range(world):
+        chan = torch.cat([out[s][r * chunk:(r + 1) * chunk] for s in range(world)])      # all_to_all_single
+        rx[r].sync(chan, 0, world * T)
+        rx[r].Flush()
+        c0, cnt = sharding.shard_of(r, world, N)
+        fr = rx[r].frames
+        assert len(fr) == cnt * nf * world
+        for f in fr:
+            assert c0 <= f.channel < c0 + cnt and f.payload_valid
+            assert sent[f.channel][(f.header[0] << 8) | f.header[1]] == (f.header, f.payload)
+        rx[r].close()
+    tx.close()

@@ -114,3 +114,33 @@ def test_layout_helpers_roundtrip(product):
             got = sharding.unpack_shard(g[r], 1, cg)
             assert np.array_equal(got, blocks[:, c0:c0 + cg].T)
     assert sharding.slab_first_sample(3, 1000, 512) == 3 * 1000 * 1024
+
+
+def _complex_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    from __graft_entry__ import load_product
+    load_product()
+    from liquid_usrp_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = (torch.arange(8, dtype=torch.float32) + 100 * rank).to(torch.complex64) * (1 + 2j)
+    recv = torch.zeros_like(out)
+    got = sharding.exchange(out, recv, world, dist)
+    q.put((rank, got.numpy().copy()))
+    dist.destroy_process_group()
+
+
+def test_exchange_moves_complex_tensors_as_float_pairs():
+    """bench.py hands complex64 granules to the exchange; RCCL has no complex type, so they travel as floats."""
+    world, port = 2, 29000 + os.getpid() % 1000 + 7
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_complex_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps: p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in ps: p.join(60)
+    base = lambda r: (np.arange(8, dtype=np.float32) + 100 * r).astype(np.complex64) * (1 + 2j)
+    for r in range(world):
+        want = np.concatenate([base(s)[r * 4:(r + 1) * 4] for s in range(world)])
+        assert np.array_equal(res[r], want)
