@@ -91,6 +91,10 @@ struct OfdmDesign {
     std::vector<float> S0, S1;         // +-1 / 0 per bin
     std::vector<cf> s0, s1;            // time-domain training symbols (unit power)
     std::vector<float> Ssm;            // [M][Nen] equaliser smoother (order-4 LSQ projection)
+    // the same projection factored through an orthonormal basis of the fit: Ssm = smk * smn^T
+    // (rank = order + 1 <= 5, unused columns zero), so the GPU needs 5 wave sums instead of Nen-term rows
+    std::vector<float> smk;            // [M][5]   basis evaluated at every bin
+    std::vector<float> smn;            // [Nen][5] orthonormal basis on the enabled bins
     std::vector<float> Pfit;           // [2][M_pilot] pilot phase line fit
     std::vector<int> data_rank;        // rank of bin among data bins (ascending bin), -1 otherwise
     std::vector<int> pilot_rank;       // rank of bin among pilots in fft-shifted order, -1 otherwise
@@ -199,6 +203,35 @@ struct OfdmDesign {
                 double s = 0;
                 for (unsigned a = 0; a <= order; a++) s += std::pow(f, (double)a) * C[(size_t)a * Nen + n];
                 Ssm[(size_t)i * Nen + n] = (float)s;
+            }
+        }
+        {   // thin QR (modified Gram-Schmidt, double) of the Vandermonde matrix on the enabled bins:
+            // V = Q R, projection = Phi R^-1 Q^T
+            const unsigned ks = order + 1;
+            std::vector<double> Q((size_t)Nen * ks), Rm((size_t)ks * ks, 0.0);
+            for (unsigned n = 0; n < Nen; n++) for (unsigned a = 0; a < ks; a++) Q[(size_t)n * ks + a] = std::pow(xe[n], (double)a);
+            for (unsigned a = 0; a < ks; a++) {
+                for (unsigned b = 0; b < a; b++) {
+                    double d = 0; for (unsigned n = 0; n < Nen; n++) d += Q[(size_t)n * ks + b] * Q[(size_t)n * ks + a];
+                    Rm[b * ks + a] = d;
+                    for (unsigned n = 0; n < Nen; n++) Q[(size_t)n * ks + a] -= d * Q[(size_t)n * ks + b];
+                }
+                double nr = 0; for (unsigned n = 0; n < Nen; n++) nr += Q[(size_t)n * ks + a] * Q[(size_t)n * ks + a];
+                nr = std::sqrt(nr); Rm[a * ks + a] = nr;
+                for (unsigned n = 0; n < Nen; n++) Q[(size_t)n * ks + a] /= nr;
+            }
+            smk.assign((size_t)M * 5, 0.0f); smn.assign((size_t)Nen * 5, 0.0f);
+            for (unsigned n = 0; n < Nen; n++) for (unsigned a = 0; a < ks; a++) smn[(size_t)n * 5 + a] = (float)Q[(size_t)n * ks + a];
+            for (unsigned i = 0; i < M; i++) {
+                if (p[i] == SC_NULL) continue;
+                const double f = ((i > M2) ? (double)i - (double)M : (double)i) / (double)M;
+                double row[5];
+                for (unsigned d = 0; d < ks; d++) {                 // row = phi R^-1 by forward substitution (R upper triangular)
+                    double v = std::pow(f, (double)d);
+                    for (unsigned b = 0; b < d; b++) v -= row[b] * Rm[b * ks + d];
+                    row[d] = v / Rm[d * ks + d];
+                }
+                for (unsigned d = 0; d < ks; d++) smk[(size_t)i * 5 + d] = (float)row[d];
             }
         }
         lsq(xp, 2, C);

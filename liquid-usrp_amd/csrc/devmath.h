@@ -127,12 +127,7 @@ __device__ __forceinline__ float wave_sum_fast(float v, int bperm32)
     v += xor_lane<8>(v, bperm32);  v += xor_lane<16>(v, bperm32); v += xor_lane<32>(v, bperm32);
     return v;
 }
-__device__ __forceinline__ float wave_sum(float v) { return wave_sum_fast(v, lane_bperm32()); }
-__device__ __forceinline__ cfd wave_csum(cfd v)
-{
-    const int bp = lane_bperm32();
-    return make_float2(wave_sum_fast(v.x, bp), wave_sum_fast(v.y, bp));
-}
+// (wave_sum / wave_csum: all-VALU, see wave_total_dpp below)
 __device__ __forceinline__ uint32_t wave_xor_u32(uint32_t v)
 {
     const int bp = lane_bperm32();
@@ -157,6 +152,8 @@ __device__ __forceinline__ float wave_total_dpp(float v)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_scan_fast(v)), 63));
 }
+__device__ __forceinline__ float wave_sum(float v) { return wave_total_dpp(v); }
+__device__ __forceinline__ cfd wave_csum(cfd v) { return make_float2(wave_total_dpp(v.x), wave_total_dpp(v.y)); }
 // atan2 for finite arguments: degree-7 minimax in t^2 on [0, 1] (max error 1.2e-7 evaluated in
 // float), octant folding, no special-case handling (0, 0 -> 0)
 __device__ __forceinline__ float atan2_fast(float y, float x)

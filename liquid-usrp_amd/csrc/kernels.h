@@ -55,6 +55,8 @@ struct SyncConsts {
     const float *S0, *S1;       // [M]  +-1 / 0
     const float2 *s0t;          // [M]  time-domain S0
     const float *Ssm;           // [M][Nen]
+    const float *smk, *smn;     // [M][5], [Nen][5]: Ssm = smk smn^T through an orthonormal basis
+    float2 backoff_rot;         // e^{+j 2 pi backoff / M}: S1 gain estimate de-rotation
     const float *Pfit;          // [2][M_pilot]
     const int16_t *data_rank, *pilot_rank, *en_rank;    // [M]
     const uint8_t *pilot_seq;   // [255]

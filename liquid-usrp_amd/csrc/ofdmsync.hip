@@ -437,6 +437,7 @@ struct Walker {
     float2 tw[6]; float sg[6]; int bp32;
     int dr[E], pr[E]; float fxr[E];
     float pf0, pf1;
+    float smn_l[5], smk_e[E][5];   // equaliser smoother factors: lane's basis row (rank = lane), element's evaluation row
 
     __device__ __forceinline__ Walker(const SyncArgs &a_, uint32_t ch_)
         : a(a_), c(a_.c), l(lane_id()), ch(ch_)
@@ -506,6 +507,12 @@ struct Walker {
         for (int i = l; i < 255; i += WV) ldsps[i] = c.pilot_seq[i];
         for (int i = l; i < 2 * c.M_pilot; i += WV) ldspf[i] = c.Pfit[i];
         for (int i = l; i < MCRX_HDR_SYMS; i += WV) ldshm[i] = c.hdr_map[i];
+#pragma unroll
+        for (int d = 0; d < 5; d++) {
+            smn_l[d] = (l < c.Nen) ? c.smn[l * 5 + d] : 0.f;
+#pragma unroll
+            for (int e = 0; e < E; e++) smk_e[e][d] = (k[e] >= 0) ? c.smk[k[e] * 5 + d] : 0.f;
+        }
         if (fast_ok()) init_fast();
         wave_sync_lds();
     }
@@ -1172,14 +1179,19 @@ struct Walker {
                 ev += evm * evm;
             }
         }
-        s.evm_hat += wave_sum_fast(ev, bp32);
+        s.evm_hat += wave_total_dpp(ev);
         s.header_symbol_index += (uint32_t)c.M_data;
         if (s.header_symbol_index >= MCRX_HDR_SYMS) {
+            const bool prof = (a.debug & 2) != 0;
+            long long k0 = prof ? (long long)__builtin_readcyclecounter() : 0ll;
             decode_header_fast();
+            if (prof) { if (s.hw[0] == 0x12345678u && s.hw[1] == 0x9abcdef0u) ph[5]++; const long long k1 = (long long)__builtin_readcyclecounter(); ph[4] += k1 - k0; k0 = k1; }
             s.evm = 10.0f * log10f(s.evm_hat / (float)MCRX_HDR_SYMS);
             if (s.header_valid) {
                 s.fstate = FX_PAYLOAD; s.payload_symbol_index = 0;
-                if (try_handoff(t_ev)) return 2;
+                const bool ho = try_handoff(t_ev);
+                if (prof) ph[5] += (long long)__builtin_readcyclecounter() - k0;
+                if (ho) return 2;
             }
             else { emit(t_ev, false, false); return 1; }
         }
@@ -1300,8 +1312,7 @@ struct Walker {
                 }
                 acc = wave_csum(acc);
                 float2 gh = cscale(acc, s.g0 / (float)c.M_S1);
-                { const double phi = (double)c.backoff * 6.283185307179586 / (double)M;
-                  gh = cmul(gh, make_float2((float)cos(phi), (float)sin(phi))); }
+                gh = cmul(gh, c.backoff_rot);
                 const float mag = sqrtf(gh.x * gh.x + gh.y * gh.y);
                 if (mag > c.sync_thresh && fabsf(atan2f(gh.y, gh.x)) < 0.1f * PI_F) {
                     s.state = SY_RX; s.timer = (uint32_t)(M + c.cp + c.backoff); s.num_symbols = 0;
@@ -1317,14 +1328,18 @@ struct Walker {
                         yarg[erank[e]] = atan2f(G.y, G.x);
                     }
                     wave_sync_lds();
-                    if (c.Nen <= WV) {
-                        // unwrap as a prefix sum of whole turns (each step of liquid's loop adds -rint(d / 2 pi))
+                    const bool lowrank = c.Nen <= WV;
+                    float ca[5], ct[5];
+                    if (lowrank) {
+                        // unwrap as a prefix sum of whole turns (each step of liquid's loop adds -rint(d / 2 pi)),
+                        // then the fit's coefficients in its orthonormal basis: 2 x 5 wave totals
+                        const float va = yabs[l < c.Nen ? l : 0];
                         const float v = yarg[l < c.Nen ? l : 0];
                         const float prev = dpp_mov<0x138, false>(v, v);
                         const float turns = rintf((v - prev) * 0.15915494309189535f);
                         const float y = fmaf(-TWO_PI_F, wave_scan_fast(turns), v);
-                        wave_sync_lds();
-                        if (l < c.Nen) yarg[l] = y;
+#pragma unroll
+                        for (int d = 0; d < 5; d++) { ca[d] = wave_total_dpp(smn_l[d] * va); ct[d] = wave_total_dpp(smn_l[d] * y); }
                     } else if (l == 0) {
                         for (int i = 1; i < c.Nen; i++) {
                             float v = yarg[i];
@@ -1338,18 +1353,27 @@ struct Walker {
                     for (int e = 0; e < E; e++) {
                         float2 r = make_float2(0.f, 0.f);
                         if (k[e] >= 0 && sct[e] != 0) {
-                            const float *row = c.Ssm + (size_t)k[e] * c.Nen;
                             float A = 0.f, th = 0.f;
-                            int n = 0;
-                            for (; n + 16 <= c.Nen; n += 16) {          // rows arrive 16 coefficients per round trip
-                                float rw[16];
+                            if (lowrank) {
 #pragma unroll
-                                for (int u = 0; u < 16; u++) rw[u] = row[n + u];
+                                for (int d = 0; d < 5; d++) { A = fmaf(smk_e[e][d], ca[d], A); th = fmaf(smk_e[e][d], ct[d], th); }
+                            } else {
+                                const float *row = c.Ssm + (size_t)k[e] * c.Nen;
+                                int n = 0;
+                                for (; n + 16 <= c.Nen; n += 16) {          // rows arrive 16 coefficients per round trip
+                                    float rw[16];
 #pragma unroll
-                                for (int u = 0; u < 16; u++) { A += rw[u] * yabs[n + u]; th += rw[u] * yarg[n + u]; }
+                                    for (int u = 0; u < 16; u++) rw[u] = row[n + u];
+#pragma unroll
+                                    for (int u = 0; u < 16; u++) { A += rw[u] * yabs[n + u]; th += rw[u] * yarg[n + u]; }
+                                }
+                                for (; n < c.Nen; n++) { A += row[n] * yabs[n]; th += row[n] * yarg[n]; }
                             }
-                            for (; n < c.Nen; n++) { A += row[n] * yabs[n]; th += row[n] * yarg[n]; }
-                            const float gr = A * cosf(th), gi = A * sinf(th);
+                            // A e^{j th}: two-constant reduction of th to [-pi, pi], then the transcendental unit
+                            const float kk = rintf(th * 0.15915494309189535f);
+                            float rr = fmaf(-kk, 6.28125f, th); rr = fmaf(-kk, 1.9353071795864769e-3f, rr);
+                            const float rev = rr * 0.15915494309189535f;
+                            const float gr = A * __builtin_amdgcn_cosf(rev), gi = A * __builtin_amdgcn_sinf(rev);
                             const float d = gr * gr + gi * gi;
                             r = make_float2(gr / d, -gi / d);
                         }
@@ -1376,7 +1400,7 @@ struct Walker {
             printf("[prof] ch0 cycles/events  seek %lld/%d  s0a %lld/%d  s0b %lld/%d  s1 %lld/%d  rx %lld/%d\n",
                    prof_cyc[0], prof_n[0], prof_cyc[1], prof_n[1], prof_cyc[2], prof_n[2], prof_cyc[3], prof_n[3], prof_cyc[4], prof_n[4]);
         if ((a.debug & 2) && l == 0 && ch == 0)
-            printf("[prof] ch0 rx phases: load %lld  core %lld  derot+nco %lld  flex %lld\n", ph[0], ph[1], ph[2], ph[3]);
+            printf("[prof] ch0 rx phases: load %lld  core %lld  derot+nco %lld  flex %lld (header decode %lld, hand-off %lld)\n", ph[0], ph[1], ph[2], ph[3], ph[4], ph[5]);
         void_reservation();
         // a header in progress continues in the next launch: its bits move from LDS to the channel's HBM slot
         if (fastp && s.state == SY_RX && s.fstate == FX_HEADER && s.header_symbol_index > 0)
