@@ -44,6 +44,11 @@ def parse():
     ap.add_argument("--cpu-reps", type=int, default=2, help="passes over the GPU slab timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--slab-blocks", type=int, default=0)
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="steps in flight (throughput mode): consecutive steps are independent (each restarts its "
+                         "receiver), so with D > 1 they run on D receiver handles / HIP streams round robin and the serial "
+                         "per-channel chains of one step hide under the other steps' kernels.  The default 1 keeps every "
+                         "kernel's HIP-event duration free of queueing behind other streams, which the roofline block needs")
     return ap.parse_args()
 
 
@@ -89,17 +94,21 @@ def main():
                max_frames=cg * reps * world + 64)
     if args.slab_blocks:
         cfg["slab_blocks"] = args.slab_blocks
-    rx = prod.multichannelrx(N, M, cp, taper, **cfg)
-    d_out = torch.empty(world * ntiles * cg * 8, dtype=torch.complex64, device=dev)     # [dest][tile][c][8]
-    d_chan = torch.empty_like(d_out) if world > 1 else d_out                           # [src][tile][c][8]
-    stream = torch.cuda.current_stream()
+    # D independent receivers, output buffers and streams: step k runs on slot k % D.  One step is still
+    # restart -> channelize slab -> all-to-all (time shards -> channel shards) -> synchronize.
+    D = max(1, min(args.inflight, args.steps))
+    rxs = [prod.multichannelrx(N, M, cp, taper, **cfg) for _ in range(D)]
+    d_outs = [torch.empty(world * ntiles * cg * 8, dtype=torch.complex64, device=dev) for _ in range(D)]    # [dest][tile][c][8]
+    d_chans = [torch.empty_like(o) if world > 1 else o for o in d_outs]                                   # [src][tile][c][8]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(D)] if D > 1 else [torch.cuda.current_stream()]
 
     from liquid_usrp_amd import sharding
     assert sharding.slab_first_sample(rank, T, N) == first_sample
 
-    def step():
-        # restart -> channelize slab -> all-to-all (time shards -> channel shards) -> synchronize
-        sharding.step(rx, d_iq, T, rank, world, dist, d_out, d_chan, halo=d_halo, stream=stream)
+    def step(k):
+        i = k % D
+        with torch.cuda.stream(streams[i]):
+            sharding.step(rxs[i], d_iq, T, rank, world, dist, d_outs[i], d_chans[i], halo=d_halo, stream=streams[i])
 
     def fence():
         torch.cuda.synchronize()
@@ -107,28 +116,35 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(max(args.warmup, D if D > 1 else 0)):        # with D > 1 every slot is warmed at least once
+        step(k)
     fence()
-    rx.kernel_stats(reset=True)
+    for rx in rxs:
+        rx.kernel_stats(reset=True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for k in range(args.steps):
+        step(k)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    stats = rx.kernel_stats()
+    stats = {}
+    for rx in rxs:
+        for kname_, (ms_, cnt_) in rx.kernel_stats().items():
+            a_, b_ = stats.get(kname_, (0.0, 0))
+            stats[kname_] = (a_ + ms_, b_ + cnt_)
 
-    # ---- verification of the last step (untimed): every frame of the shard decoded and valid
-    rx.Flush()
-    frames = rx.frames
+    # ---- verification (untimed): the last step of every slot -- all frames of the shard decoded and valid
     expect = cg * reps * world
-    n_ok = sum(1 for f in frames if f.header_valid and f.payload_valid
-               and sent[f.channel][(f.header[0] << 8) | f.header[1]] == (f.header, f.payload))
-    verified = (len(frames) == expect and n_ok == expect)
+    nfr, n_ok = 0, 0
+    for rx in rxs:
+        rx.Flush()
+        nfr += len(rx.frames)
+        n_ok += sum(1 for f in rx.frames if f.header_valid and f.payload_valid
+                    and sent[f.channel][(f.header[0] << 8) | f.header[1]] == (f.header, f.payload))
+    verified = (nfr == expect * D and n_ok == expect * D)
 
     samples_per_step = world * T * K
     value = samples_per_step * args.steps / elapsed / 1e6
@@ -163,7 +179,7 @@ def main():
             "config": {"workload": "512-ch multichannelrx (firpfbch K=2N m=7 + N x ofdmflexframesync), "
                                    "M=64 cp=8 taper=4 QPSK CRC32+Hamming128 %dB payloads, %d frames/ch/GPU"
                                    % (args.payload, reps),
-                       "channels": N, "subcarriers": M, "samples_per_step": samples_per_step,
+                       "channels": N, "subcarriers": M, "samples_per_step": samples_per_step, "steps_in_flight": D,
                        "parallelism": "time-sharded channelizer -> all-to-all -> %d channels/GPU" % cg
                                       if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
@@ -172,19 +188,21 @@ def main():
                          "kernels_ms": {k: round(v, 4) for k, v in per.items()},
                          "channelizer_ms": round(ch_ms, 4), "sync_ms": round(sy_ms, 4),
                          "pipeline_frac_of_16B_roofline": round(value * 1e6 * 16.0 / (world * HBM_PEAK_GBS * 1e9), 5)},
-            "verified": {"frames": len(frames), "expected": expect, "bit_exact_payloads": n_ok, "ok": verified},
+            "verified": {"frames": nfr, "expected": expect * D, "bit_exact_payloads": n_ok, "ok": verified,
+                         "note": "last step of each of the %d receiver slots" % D},
             "setup_s": {"iq_generation": round(gen_s, 2)},
         }
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(ora, d_iq.cpu().numpy(), N, M, cp, taper, args.cpu_reps)
-    rx.close()
+    for rx in rxs:
+        rx.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
     if not verified:
-        sys.exit("rank %d: verification failed (%d/%d frames, %d ok)" % (rank, len(frames), expect, n_ok))
+        sys.exit("rank %d: verification failed (%d/%d frames, %d ok)" % (rank, nfr, expect * D, n_ok))
 
 
 def measured_traffic(kernel, N, reps, payload, world):
