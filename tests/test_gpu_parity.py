@@ -296,3 +296,25 @@ def test_two_rank_sharding_emulated_on_one_gpu(product):
             assert sent[f.channel][(f.header[0] << 8) | f.header[1]] == (f.header, f.payload)
         rx[r].close()
     tx.close()
+
+
+@pytest.mark.parametrize("snr_db,mod,fec1", [(30.0, 40, 6), (18.0, 40, 6), (25.0, 27, 7)])
+def test_noisy_channel_same_decisions_as_oracle(oracle, product, snr_db, mod, fec1):
+    """Seeded AWGN (30 dB; plus a level where the soft decoder has work to do): every frame's
+    validity flags and bytes equal the oracle's, equalised symbols within tolerance.  A carrier offset and a
+    fractional gain make the pilot tracking and the equaliser do real work too."""
+    N, M, cp = 4, 64, 8
+    iq, _ = oracle.synth_traffic(N, M, cp, 4, 3, payload_len=257, mod=mod, fec1=fec1, seed=99)
+    rng = np.random.RandomState(1)
+    sig = np.sqrt(np.mean(np.abs(iq) ** 2))
+    nstd = sig * 10.0 ** (-snr_db / 20.0) / np.sqrt(2.0)
+    n = np.arange(len(iq))
+    x = (0.73 * iq * np.exp(1j * (2e-4 * n + 0.4)) + nstd * (rng.randn(len(iq)) + 1j * rng.randn(len(iq)))).astype(np.complex64)
+    x = x[:len(x) // (16 * N) * (16 * N)]
+    ora = oracle.MultiChannelRx(N, M, cp, 4)
+    ora.execute(x)
+    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=300)
+    rx.Execute(x); rx.Flush()
+    assert len(ora.frames) >= 3 * N - 1
+    check_frames(rx.frames, ora.frames, rel=2e-5)
+    rx.close()
