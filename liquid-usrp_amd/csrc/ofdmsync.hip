@@ -1234,6 +1234,136 @@ struct Walker {
         header_fields(crc == key);
     }
 
+    // one event of the acquisition states (SEEK, S0a, S0b, S1 incl. the equaliser fit)
+    __device__ __forceinline__ void sync_event(int64_t t_ev)
+    {
+        const int M = c.M, M2 = c.M2, L = c.L;
+        if (s.state == SY_SEEK) {
+            float pw; float2 sh = s0_metric(t_ev, false, pw);
+            const float g = (float)M / pw;
+            sh = cscale(sh, g);
+            const float tau = atan2f(sh.y, sh.x) * (float)M2 / TWO_PI_F;
+            s.g0 = g; s.timer = 0;
+            if (sqrtf(sh.x * sh.x + sh.y * sh.y) > c.detect_thresh) {
+                const int dt = (int)roundf(tau);
+                s.timer = (uint32_t)(M + dt) % (uint32_t)M2 + (uint32_t)M;
+                s.state = SY_S0A;
+            }
+        } else if (s.state == SY_S0A) {
+            float pw; float2 sh = s0_metric(t_ev, true, pw);
+            s.s_hat_0 = cscale(sh, s.g0);
+            s.timer = 0; s.state = SY_S0B;
+        } else if (s.state == SY_S0B) {
+            float pw; float2 sh = cscale(s0_metric(t_ev, true, pw), s.g0);
+            const float2 ssum = cadd(s.s_hat_0, sh);
+            const float tau = atan2f(ssum.y, ssum.x) * (float)M2 / TWO_PI_F;
+            s.timer = (uint32_t)(M + c.cp - c.backoff) - (uint32_t)(int)roundf(tau);
+            // CFO: time-domain ML estimate over the two halves of the oldest M window samples
+            float2 acc = make_float2(0.f, 0.f);
+            const int64_t w0 = t_ev - L + 1;
+            for (int i = l; i < M2; i += WV) {
+                const float2 r0 = mixed(w0 + i), r1 = mixed(w0 + i + M2);
+                const float2 sa = c.s0t[i], sb = c.s0t[i + M2];
+                acc = cadd(acc, cmul(cmulc(sa, r0), cmulc(r1, sb)));
+            }
+            acc = wave_csum(acc);
+            const float nu = atan2f(acc.y, acc.x) / (float)M2;
+            s.nco_dtheta = rad2u32(nu); s.nco_theta_ref = 0; s.nco_t_ref = t_ev + 1;
+            s.state = SY_S1;
+        } else if (s.state == SY_S1) {
+            s.num_symbols++;
+            float2 x[E];
+            load_window(t_ev - M + 1, true, x);
+            fft(x);
+            const float gain = sqrtf((float)c.M_S1) / (float)M;
+            wave_sync_lds();
+#pragma unroll
+            for (int e = 0; e < E; e++) if (k[e] >= 0) { x[e] = cscale(x[e], S1v[e] * gain); ldsc[k[e]] = x[e]; }
+            wave_sync_lds();
+            float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int e = 0; e < E; e++) if (k[e] >= 0) {
+                int kn = k[e] + 1; if (kn >= M) kn -= M;
+                acc = cadd(acc, cmulc(ldsc[kn], x[e]));
+            }
+            acc = wave_csum(acc);
+            float2 gh = cscale(acc, s.g0 / (float)c.M_S1);
+            gh = cmul(gh, c.backoff_rot);
+            const float mag = sqrtf(gh.x * gh.x + gh.y * gh.y);
+            if (mag > c.sync_thresh && fabsf(atan2f(gh.y, gh.x)) < 0.1f * PI_F) {
+                s.state = SY_RX; s.timer = (uint32_t)(M + c.cp + c.backoff); s.num_symbols = 0;
+                reserve_job();
+                // equaliser: order-4 LSQ smoothing of |G| and unwrapped arg G, R = 1/G
+                const float g = (float)M / sqrtf((float)(c.M_pilot + c.M_data));
+                float *yabs = ldsf, *yarg = ldsf + c.Nen;
+                wave_sync_lds();
+#pragma unroll
+                for (int e = 0; e < E; e++) if (erank[e] >= 0) {
+                    const float2 G = cscale(x[e], g);
+                    yabs[erank[e]] = sqrtf(G.x * G.x + G.y * G.y);
+                    yarg[erank[e]] = atan2f(G.y, G.x);
+                }
+                wave_sync_lds();
+                const bool lowrank = c.Nen <= WV;
+                float ca[5], ct[5];
+                if (lowrank) {
+                    // unwrap as a prefix sum of whole turns (each step of liquid's loop adds -rint(d / 2 pi)),
+                    // then the fit's coefficients in its orthonormal basis: 2 x 5 wave totals
+                    const float va = yabs[l < c.Nen ? l : 0];
+                    const float v = yarg[l < c.Nen ? l : 0];
+                    const float prev = dpp_mov<0x138, false>(v, v);
+                    const float turns = rintf((v - prev) * 0.15915494309189535f);
+                    const float y = fmaf(-TWO_PI_F, wave_scan_fast(turns), v);
+#pragma unroll
+                    for (int d = 0; d < 5; d++) { ca[d] = wave_total_dpp(smn_l[d] * va); ct[d] = wave_total_dpp(smn_l[d] * y); }
+                } else if (l == 0) {
+                    for (int i = 1; i < c.Nen; i++) {
+                        float v = yarg[i];
+                        while ((v - yarg[i - 1]) >  PI_F) v -= 2.0f * PI_F;
+                        while ((v - yarg[i - 1]) < -PI_F) v += 2.0f * PI_F;
+                        yarg[i] = v;
+                    }
+                }
+                wave_sync_lds();
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    float2 r = make_float2(0.f, 0.f);
+                    if (k[e] >= 0 && sct[e] != 0) {
+                        float A = 0.f, th = 0.f;
+                        if (lowrank) {
+#pragma unroll
+                            for (int d = 0; d < 5; d++) { A = fmaf(smk_e[e][d], ca[d], A); th = fmaf(smk_e[e][d], ct[d], th); }
+                        } else {
+                            const float *row = c.Ssm + (size_t)k[e] * c.Nen;
+                            int n = 0;
+                            for (; n + 16 <= c.Nen; n += 16) {          // rows arrive 16 coefficients per round trip
+                                float rw[16];
+#pragma unroll
+                                for (int u = 0; u < 16; u++) rw[u] = row[n + u];
+#pragma unroll
+                                for (int u = 0; u < 16; u++) { A += rw[u] * yabs[n + u]; th += rw[u] * yarg[n + u]; }
+                            }
+                            for (; n < c.Nen; n++) { A += row[n] * yabs[n]; th += row[n] * yarg[n]; }
+                        }
+                        // A e^{j th}: two-constant reduction of th to [-pi, pi], then the transcendental unit
+                        const float kk = rintf(th * 0.15915494309189535f);
+                        float rr = fmaf(-kk, 6.28125f, th); rr = fmaf(-kk, 1.9353071795864769e-3f, rr);
+                        const float rev = rr * 0.15915494309189535f;
+                        const float gr = A * __builtin_amdgcn_cosf(rev), gi = A * __builtin_amdgcn_sinf(rev);
+                        const float d = gr * gr + gi * gi;
+                        r = make_float2(gr / d, -gi / d);
+                    }
+                    R[e] = r;
+                    if (k[e] >= 0) bR[k[e]] = r;
+                }
+                wave_sync_lds();
+            } else {
+                if (s.num_symbols == 16) reset_framesync();
+                s.timer = (uint32_t)M2;
+            }
+        }
+    }
+
     __device__ __forceinline__ void run()
     {
         s = a.st[ch];
@@ -1262,130 +1392,8 @@ struct Walker {
             const int st_in = s.state; const long long tk0 = (a.debug & 2) ? (long long)__builtin_readcyclecounter() : 0ll;
             if ((a.debug & 1) && l == 0 && ch == 0) printf("[sync] ch0 t=%lld state=%d fstate=%d timer=%u hsi=%u psi=%u\n", (long long)t_ev, s.state, s.fstate, s.timer, s.header_symbol_index, s.payload_symbol_index);
 
-            if (s.state == SY_SEEK) {
-                float pw; float2 sh = s0_metric(t_ev, false, pw);
-                const float g = (float)M / pw;
-                sh = cscale(sh, g);
-                const float tau = atan2f(sh.y, sh.x) * (float)M2 / TWO_PI_F;
-                s.g0 = g; s.timer = 0;
-                if (sqrtf(sh.x * sh.x + sh.y * sh.y) > c.detect_thresh) {
-                    const int dt = (int)roundf(tau);
-                    s.timer = (uint32_t)(M + dt) % (uint32_t)M2 + (uint32_t)M;
-                    s.state = SY_S0A;
-                }
-            } else if (s.state == SY_S0A) {
-                float pw; float2 sh = s0_metric(t_ev, true, pw);
-                s.s_hat_0 = cscale(sh, s.g0);
-                s.timer = 0; s.state = SY_S0B;
-            } else if (s.state == SY_S0B) {
-                float pw; float2 sh = cscale(s0_metric(t_ev, true, pw), s.g0);
-                const float2 ssum = cadd(s.s_hat_0, sh);
-                const float tau = atan2f(ssum.y, ssum.x) * (float)M2 / TWO_PI_F;
-                s.timer = (uint32_t)(M + c.cp - c.backoff) - (uint32_t)(int)roundf(tau);
-                // CFO: time-domain ML estimate over the two halves of the oldest M window samples
-                float2 acc = make_float2(0.f, 0.f);
-                const int64_t w0 = t_ev - L + 1;
-                for (int i = l; i < M2; i += WV) {
-                    const float2 r0 = mixed(w0 + i), r1 = mixed(w0 + i + M2);
-                    const float2 sa = c.s0t[i], sb = c.s0t[i + M2];
-                    acc = cadd(acc, cmul(cmulc(sa, r0), cmulc(r1, sb)));
-                }
-                acc = wave_csum(acc);
-                const float nu = atan2f(acc.y, acc.x) / (float)M2;
-                s.nco_dtheta = rad2u32(nu); s.nco_theta_ref = 0; s.nco_t_ref = t_ev + 1;
-                s.state = SY_S1;
-            } else if (s.state == SY_S1) {
-                s.num_symbols++;
-                float2 x[E];
-                load_window(t_ev - M + 1, true, x);
-                fft(x);
-                const float gain = sqrtf((float)c.M_S1) / (float)M;
-                wave_sync_lds();
-#pragma unroll
-                for (int e = 0; e < E; e++) if (k[e] >= 0) { x[e] = cscale(x[e], S1v[e] * gain); ldsc[k[e]] = x[e]; }
-                wave_sync_lds();
-                float2 acc = make_float2(0.f, 0.f);
-#pragma unroll
-                for (int e = 0; e < E; e++) if (k[e] >= 0) {
-                    int kn = k[e] + 1; if (kn >= M) kn -= M;
-                    acc = cadd(acc, cmulc(ldsc[kn], x[e]));
-                }
-                acc = wave_csum(acc);
-                float2 gh = cscale(acc, s.g0 / (float)c.M_S1);
-                gh = cmul(gh, c.backoff_rot);
-                const float mag = sqrtf(gh.x * gh.x + gh.y * gh.y);
-                if (mag > c.sync_thresh && fabsf(atan2f(gh.y, gh.x)) < 0.1f * PI_F) {
-                    s.state = SY_RX; s.timer = (uint32_t)(M + c.cp + c.backoff); s.num_symbols = 0;
-                    reserve_job();
-                    // equaliser: order-4 LSQ smoothing of |G| and unwrapped arg G, R = 1/G
-                    const float g = (float)M / sqrtf((float)(c.M_pilot + c.M_data));
-                    float *yabs = ldsf, *yarg = ldsf + c.Nen;
-                    wave_sync_lds();
-#pragma unroll
-                    for (int e = 0; e < E; e++) if (erank[e] >= 0) {
-                        const float2 G = cscale(x[e], g);
-                        yabs[erank[e]] = sqrtf(G.x * G.x + G.y * G.y);
-                        yarg[erank[e]] = atan2f(G.y, G.x);
-                    }
-                    wave_sync_lds();
-                    const bool lowrank = c.Nen <= WV;
-                    float ca[5], ct[5];
-                    if (lowrank) {
-                        // unwrap as a prefix sum of whole turns (each step of liquid's loop adds -rint(d / 2 pi)),
-                        // then the fit's coefficients in its orthonormal basis: 2 x 5 wave totals
-                        const float va = yabs[l < c.Nen ? l : 0];
-                        const float v = yarg[l < c.Nen ? l : 0];
-                        const float prev = dpp_mov<0x138, false>(v, v);
-                        const float turns = rintf((v - prev) * 0.15915494309189535f);
-                        const float y = fmaf(-TWO_PI_F, wave_scan_fast(turns), v);
-#pragma unroll
-                        for (int d = 0; d < 5; d++) { ca[d] = wave_total_dpp(smn_l[d] * va); ct[d] = wave_total_dpp(smn_l[d] * y); }
-                    } else if (l == 0) {
-                        for (int i = 1; i < c.Nen; i++) {
-                            float v = yarg[i];
-                            while ((v - yarg[i - 1]) >  PI_F) v -= 2.0f * PI_F;
-                            while ((v - yarg[i - 1]) < -PI_F) v += 2.0f * PI_F;
-                            yarg[i] = v;
-                        }
-                    }
-                    wave_sync_lds();
-#pragma unroll
-                    for (int e = 0; e < E; e++) {
-                        float2 r = make_float2(0.f, 0.f);
-                        if (k[e] >= 0 && sct[e] != 0) {
-                            float A = 0.f, th = 0.f;
-                            if (lowrank) {
-#pragma unroll
-                                for (int d = 0; d < 5; d++) { A = fmaf(smk_e[e][d], ca[d], A); th = fmaf(smk_e[e][d], ct[d], th); }
-                            } else {
-                                const float *row = c.Ssm + (size_t)k[e] * c.Nen;
-                                int n = 0;
-                                for (; n + 16 <= c.Nen; n += 16) {          // rows arrive 16 coefficients per round trip
-                                    float rw[16];
-#pragma unroll
-                                    for (int u = 0; u < 16; u++) rw[u] = row[n + u];
-#pragma unroll
-                                    for (int u = 0; u < 16; u++) { A += rw[u] * yabs[n + u]; th += rw[u] * yarg[n + u]; }
-                                }
-                                for (; n < c.Nen; n++) { A += row[n] * yabs[n]; th += row[n] * yarg[n]; }
-                            }
-                            // A e^{j th}: two-constant reduction of th to [-pi, pi], then the transcendental unit
-                            const float kk = rintf(th * 0.15915494309189535f);
-                            float rr = fmaf(-kk, 6.28125f, th); rr = fmaf(-kk, 1.9353071795864769e-3f, rr);
-                            const float rev = rr * 0.15915494309189535f;
-                            const float gr = A * __builtin_amdgcn_cosf(rev), gi = A * __builtin_amdgcn_sinf(rev);
-                            const float d = gr * gr + gi * gi;
-                            r = make_float2(gr / d, -gi / d);
-                        }
-                        R[e] = r;
-                        if (k[e] >= 0) bR[k[e]] = r;
-                    }
-                    wave_sync_lds();
-                } else {
-                    if (s.num_symbols == 16) reset_framesync();
-                    s.timer = (uint32_t)M2;
-                }
-            } else {    // SY_RX
+            if (s.state != SY_RX) sync_event(t_ev);
+            else {    // SY_RX
                 const int fr = fastp ? rx_event_fast(t_ev) : rx_event(t_ev);
                 if (fr == 1) { void_reservation(); reset_framesync(); s.timer = (uint32_t)L; }
                 else if (fr == 2) {
