@@ -100,6 +100,21 @@ struct PayloadJob {
     uint64_t arena_off;         // pre-allocated record space: payload bytes, then framesyms
 };
 
+// Frame-level speculation in the scout.  After a frame's last symbol liquid leaves the synchronizer in one
+// fixed state (SEEK, timer = M+cp, everything else reset), so a frame that starts where another one ended can be
+// acquired by an independent wave -- if the position is known.  Positions are predicted from where frames
+// ended in the previous launch (plus the cadence continued past the buffer); a speculative wave per prediction
+// runs detection .. header decode from the fresh state and parks the hand-off in a SpecSlot; the per-channel
+// scout adopts a slot when it arrives at exactly that position in exactly that state, else walks on as before.
+#define MCRX_SPEC_MAX 128
+struct SpecSlot {
+    int64_t start;              // first sample consumed from the fresh state
+    int64_t t_last;             // event index of the frame's last payload symbol
+    int32_t status;             // 1: frame acquired and handed off (job valid), 0: nothing usable
+    uint32_t pad;
+    PayloadJob job;
+};
+
 struct SyncArgs {
     SyncConsts c;
     const float2 *chan;         // [tile][chan_stride][8]; my channel c sits at chan_off + c
@@ -127,11 +142,17 @@ struct SyncArgs {
     uint8_t *jsoft;             // [max_jobs][8*max_enc_len]
     uint8_t *jtmp;              // [max_jobs][2*(max_enc_len+16)]
     int debug;                 // MCRX_DEBUG=1: trace state-machine events of channel 0
+    // speculation (see SpecSlot)
+    SpecSlot *spec; float2 *spec_R;      // [nch][MCRX_SPEC_MAX], [nch][MCRX_SPEC_MAX][M]
+    int64_t *pred; uint32_t *pred_n;     // predicted fresh-state positions for the next launch: [nch][MCRX_SPEC_MAX], [nch]
+    uint32_t spec_cap;                   // slots per channel the speculative kernel fills in this launch (0: off)
+    uint32_t *spec_hint;                 // host-mapped word: largest prediction count, sizes the next launch's grid
     uint32_t *hint;             // host-mapped word: longest coded frame (bytes) among this launch's jobs
     uint32_t enc_hint;          // the value the host last saw there (0: none yet)
     int no_fast;               // MCRX_NO_FAST=1: payload workers use the general symbol path (A/B experiments)
 };
 hipError_t sync_launch(const SyncArgs &a, hipStream_t st);           // scout kernel: one wave per channel
+hipError_t sync_launch_spec(const SyncArgs &a, hipStream_t st);      // speculative acquisition: one wave per (channel, predicted position)
 // stage 0: record placement (one workgroup), 1: payload workers (one wave per handed-off frame),
 // 2: packet decode (one workgroup per frame; only after the lean workers -- the general ones decode in place)
 hipError_t sync_launch_payload(const SyncArgs &a, int stage, hipStream_t st);

@@ -94,6 +94,8 @@ struct mcrx_hip_s {
     FrameRec *d_rec = nullptr; uint8_t *d_arena = nullptr; uint32_t *d_nrec = nullptr;
     unsigned long long *d_arena_used = nullptr;
     PayloadJob *d_jobs = nullptr; uint32_t *d_njobs = nullptr; float2 *d_jR = nullptr;
+    SpecSlot *d_spec = nullptr; float2 *d_spec_R = nullptr; int64_t *d_pred = nullptr; uint32_t *d_pred_n = nullptr;
+    bool spec = false;
     uint32_t *h_hint = nullptr, *d_hint = nullptr;     // pinned, device-mapped: longest coded frame of the last launch
     uint8_t *d_jsoft = nullptr, *d_jtmp = nullptr;
     bool scout = true;
@@ -283,8 +285,8 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     if ((rc = q->alloc(&q->d_arena_used, 1))) return bail(rc);
     q->scout = getenv("MCRX_NO_SCOUT") == nullptr;
     if ((rc = q->alloc(&q->d_njobs, 1))) return bail(rc);
-    if (hipHostMalloc((void **)&q->h_hint, sizeof(uint32_t), hipHostMallocMapped) == hipSuccess) {
-        *q->h_hint = 0;
+    if (hipHostMalloc((void **)&q->h_hint, 2 * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess) {
+        q->h_hint[0] = 0; q->h_hint[1] = 0;
         if (hipHostGetDevicePointer((void **)&q->d_hint, q->h_hint, 0) != hipSuccess) q->d_hint = nullptr;
     }
     if (q->scout) {
@@ -292,6 +294,15 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
         if ((rc = q->alloc(&q->d_jR, (size_t)q->max_rec * M))) return bail(rc);
         if ((rc = q->alloc(&q->d_jsoft, (size_t)q->max_rec * 8 * q->max_enc))) return bail(rc);
         if ((rc = q->alloc(&q->d_jtmp, (size_t)q->max_rec * 2 * (q->max_enc + 16)))) return bail(rc);
+        // speculative acquisition (lean path only): slots, their equalisers, the prediction lists
+        const bool lean = q->sc.log2M >= 6 && q->sc.M == 64 * q->sc.E && q->sc.M_pilot <= 64;
+        q->spec = lean && q->d_hint && getenv("MCRX_NO_SPEC") == nullptr;
+        if (q->spec) {
+            if ((rc = q->alloc(&q->d_spec, (size_t)q->nch * MCRX_SPEC_MAX))) return bail(rc);
+            if ((rc = q->alloc(&q->d_spec_R, (size_t)q->nch * MCRX_SPEC_MAX * M))) return bail(rc);
+            if ((rc = q->alloc(&q->d_pred, (size_t)q->nch * MCRX_SPEC_MAX))) return bail(rc);
+            if ((rc = q->alloc(&q->d_pred_n, q->nch))) return bail(rc);
+        }
     }
     if ((rc = q->alloc(&q->d_hist[0], (size_t)HIST_BLOCKS * q->K))) return bail(rc);
     if ((rc = q->alloc(&q->d_hist[1], (size_t)HIST_BLOCKS * q->K))) return bail(rc);
@@ -369,8 +380,15 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     a.jobs = q->d_jobs; a.njobs = q->d_njobs; a.max_jobs = q->max_rec;
     a.jR = q->d_jR; a.jsoft = q->d_jsoft; a.jtmp = q->d_jtmp;
     a.hint = q->d_hint; a.enc_hint = (q->h_hint && q->d_hint) ? *(volatile uint32_t *)q->h_hint : 0u;
+    a.spec = q->d_spec; a.spec_R = q->d_spec_R; a.pred = nullptr; a.pred_n = nullptr; a.spec_cap = 0; a.spec_hint = nullptr;
+    if (q->spec) {
+        a.pred = q->d_pred; a.pred_n = q->d_pred_n; a.spec_hint = q->d_hint + 1;
+        const uint32_t seen = ((volatile uint32_t *)q->h_hint)[1];         // largest prediction list so far (read without a sync)
+        a.spec_cap = seen < MCRX_SPEC_MAX ? seen : MCRX_SPEC_MAX;
+    }
     HIPCHK(hipMemsetAsync(q->d_njobs, 0, sizeof(uint32_t), st));
     RC(q->ev_begin(1, st));
+    HIPCHK(sync_launch_spec(a, st));          // speculative waves first, then the per-channel scouts that adopt them
     HIPCHK(sync_launch(a, st));
     RC(q->ev_end(1, st));
     if (q->scout) {

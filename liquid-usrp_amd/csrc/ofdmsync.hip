@@ -397,7 +397,8 @@ extern __shared__ __attribute__((aligned(16))) float2 sy_lds[];
 #define ldshm (reinterpret_cast<uint16_t *>(ldsps + 256))                      /* header bit map [288]  */
 #define ldshb (ldsps + 256 + 2 * MCRX_HDR_SYMS)                                /* header bits, decoded order [288] */
 #define ldshd (reinterpret_cast<uint16_t *>(ldsps + 256 + 3 * MCRX_HDR_SYMS))   /* Golay-decoded 12-bit words [12] */
-#define SY_LDS_BYTES(M) ((size_t)(M) * 8 + (size_t)(M) * 12 + 256 + 3 * MCRX_HDR_SYMS + 32)
+#define ldsad (ldsps + 256 + 3 * MCRX_HDR_SYMS + 32)                            /* adopted speculative slots [MCRX_SPEC_MAX] */
+#define SY_LDS_BYTES(M) ((size_t)(M) * 8 + (size_t)(M) * 12 + 256 + 3 * MCRX_HDR_SYMS + 32 + MCRX_SPEC_MAX)
 
 // One wavefront per workgroup: LDS traffic of a wave is processed in order, so a compiler-level
 // fence is all the hand-off between lanes needs (no s_barrier, and no vmcnt(0) drain of the
@@ -430,6 +431,7 @@ struct Walker {
     uint32_t pre_idx;           // ... and its record slot
     int64_t handoff_last;       // scout: last event index of the frame just handed off
     uint32_t jres;              // scout: job slot reserved at frame detection (0xFFFFFFFF: none)
+    SpecSlot *slot;             // != nullptr: this wave acquires speculatively into this slot (no side effects elsewhere)
     int64_t pf_t; float2 pf_x[E];   // scout: lookahead window (first sample, raw samples)
     long long ph[6];                // MCRX_DEBUG=2: cycles per phase of the symbol events
     // lean path (power-of-two M >= 64, <= 64 pilots): butterfly twiddles / signs, ranks, fit rows
@@ -448,7 +450,7 @@ struct Walker {
         bhbits = a.hbits + (size_t)ch * MCRX_HDR_SYMS;
         bsyms = a.syms + (size_t)ch * c.max_syms;
         bR = a.R + (size_t)ch * c.M;
-        pre_off = -1; handoff_last = 0; jres = 0xFFFFFFFFu; fastp = false; pf_t = INT64_MIN; for (int i = 0; i < 6; i++) ph[i] = 0;
+        pre_off = -1; handoff_last = 0; jres = 0xFFFFFFFFu; slot = nullptr; nadopted = 0; fastp = false; pf_t = INT64_MIN; for (int i = 0; i < 6; i++) ph[i] = 0;
     }
     // payload worker: take over the synchronizer state of the job and reserve the record space
     // (payload bytes, then framesyms) in the frame arena; false if the arena is exhausted
@@ -679,6 +681,7 @@ struct Walker {
 
     __device__ __forceinline__ void emit(int64_t t_ev, bool with_payload, bool payload_valid, bool oversize = false, bool copy_payload = true)
     {
+        if (slot) return;
         const uint32_t nsym = (with_payload && !oversize) ? s.mod_len : 0u;
         const uint32_t plen = (with_payload && !oversize) ? s.payload_len : 0u;
         const unsigned long long pbytes = ((unsigned long long)plen + 15ull) & ~15ull;
@@ -722,11 +725,22 @@ struct Walker {
 
     // scout: hand the payload of the frame whose header was just decoded to a worker wave
     // if every payload symbol is already in the buffer.  Returns false to keep walking serially.
+    // speculative wave: park the hand-off in the slot (R already sits in the slot's bR); no atomics, no records
+    __device__ __forceinline__ bool try_handoff_spec(int64_t t_ev)
+    {
+        const int64_t nsym = (int64_t)((s.mod_len + (uint32_t)c.M_data - 1) / (uint32_t)c.M_data);
+        const int64_t t_last = t_ev + nsym * (int64_t)c.L;
+        if (s.enc_len > c.max_enc_len || s.mod_len > c.max_syms || s.payload_len > c.max_payload_len || t_last >= a.end) return false;
+        if (l == 0) { PayloadJob jb; jb.s = s; jb.ch = ch; jb.pad = 0; jb.arena_off = 0; slot->job = jb; }
+        handoff_last = t_last;
+        return true;
+    }
     __device__ __forceinline__ bool try_handoff(int64_t t_ev)
     {
         if (!a.scout) return false;
         const int64_t nsym = (int64_t)((s.mod_len + (uint32_t)c.M_data - 1) / (uint32_t)c.M_data);
         const int64_t t_last = t_ev + nsym * (int64_t)c.L;
+
         if (s.enc_len > c.max_enc_len || s.mod_len > c.max_syms || s.payload_len > c.max_payload_len || t_last >= a.end) {
             void_reservation();
             return false;
@@ -752,7 +766,7 @@ struct Walker {
     // under the header symbols; a frame that ends up not handed off gives the slot back as void.
     __device__ __forceinline__ void reserve_job()
     {
-        if (!a.scout || jres != 0xFFFFFFFFu) return;
+        if (!a.scout || slot || jres != 0xFFFFFFFFu) return;
         uint32_t j = 0;
         if (l == 0) j = atomicAdd(a.njobs, 1u);
         jres = (uint32_t)__shfl((int)j, 0, WV);
@@ -1119,6 +1133,7 @@ struct Walker {
     }
 
     // scout, lean RXSYMBOLS event: the counterpart of rx_core on the Walker's state
+    template <bool SPEC = false>
     __device__ __forceinline__ int rx_event_fast(int64_t t_ev)
     {
         const int L = c.L, cb = c.cp - c.backoff;
@@ -1154,7 +1169,8 @@ struct Walker {
         if (prof && new_dtheta == 0x12345u && X[0].x == 1.2345e-30f) ph[5]++;
         SY_TICK(2)
         int r;
-        if (s.fstate == FX_HEADER) r = flex_header_fast(X, t_ev);
+        if (s.fstate == FX_HEADER) r = flex_header_fast<SPEC>(X, t_ev);
+        else if constexpr (SPEC) r = 1;          // a speculative wave never walks a payload itself
         else r = flex_symbol(X, t_ev);
         SY_TICK(3)
 #undef SY_TICK
@@ -1163,6 +1179,7 @@ struct Walker {
 
     // header symbols: hard BPSK bits go straight to their de-interleaved, de-scrambled place in LDS
     // (the header packet is always 36 bytes, so its interleaver is one fixed bit permutation)
+    template <bool SPEC = false>
     __device__ __forceinline__ int flex_header_fast(const float2 (&X)[E], int64_t t_ev)
     {
         float ev = 0.f;
@@ -1189,11 +1206,12 @@ struct Walker {
             s.evm = 10.0f * log10f(s.evm_hat / (float)MCRX_HDR_SYMS);
             if (s.header_valid) {
                 s.fstate = FX_PAYLOAD; s.payload_symbol_index = 0;
+                if constexpr (SPEC) return try_handoff_spec(t_ev) ? 2 : 1;
                 const bool ho = try_handoff(t_ev);
                 if (prof) ph[5] += (long long)__builtin_readcyclecounter() - k0;
                 if (ho) return 2;
             }
-            else { emit(t_ev, false, false); return 1; }
+            else { if constexpr (!SPEC) emit(t_ev, false, false); return 1; }
         }
         return 0;
     }
@@ -1364,6 +1382,101 @@ struct Walker {
         }
     }
 
+    // Scout side of the speculation.  The slot headers of the channel (start, status, frame end) are read
+    // once into registers, two per lane, so finding the slot that started exactly at s.cur is a compare
+    // and a ballot; the adopted slots are only noted (LDS) during the walk, and their parked jobs and
+    // equalisers are copied into the job list in one pipelined pass after it.  Nothing on the scout's
+    // serial chain waits for memory because of an adoption.
+    int64_t sp_start[2], sp_tlast[2]; uint32_t nadopted;
+    __device__ __forceinline__ void load_spec_headers()
+    {
+        const SpecSlot *sl = a.spec + (size_t)ch * MCRX_SPEC_MAX;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t k = (uint32_t)l + WV * h;
+            const bool live = k < a.spec_cap;
+            const SpecSlot *q = sl + (live ? k : 0);
+            sp_start[h] = (live && q->status == 1) ? q->start : -1;
+            sp_tlast[h] = q->t_last;
+        }
+        nadopted = 0;
+    }
+    __device__ __forceinline__ bool adopt_speculative()
+    {
+        static_assert(MCRX_SPEC_MAX <= 2 * WV, "two slot headers per lane");
+        const unsigned long long b0 = __ballot(sp_start[0] == s.cur), b1 = __ballot(sp_start[1] == s.cur);
+        if (!(b0 | b1)) return false;
+        const int hl = b0 ? (int)__builtin_ctzll(b0) : (int)__builtin_ctzll(b1);
+        const int64_t t_last = __shfl(b0 ? sp_tlast[0] : sp_tlast[1], hl, WV);
+        if (l == 0) ldsad[nadopted] = (uint8_t)(b0 ? hl : hl + WV);
+        nadopted++;
+        reset_framesync(); s.timer = (uint32_t)c.L; s.cur = t_last + 1;
+        return true;
+    }
+    __device__ __forceinline__ void publish_adopted()
+    {
+        static_assert(sizeof(PayloadJob) / 4 <= WV, "one job word per lane");
+        if (!nadopted) return;
+        wave_sync_lds();
+        uint32_t j0 = 0;
+        if (l == 0) j0 = atomicAdd(a.njobs, nadopted);             // one block of job slots for all of them
+        j0 = (uint32_t)__shfl((int)j0, 0, WV);
+        const SpecSlot *sl = a.spec + (size_t)ch * MCRX_SPEC_MAX;
+        uint32_t lost = 0;
+        for (uint32_t i0 = 0; i0 < nadopted; i0 += 4) {            // four frames' loads in flight
+            uint32_t w[4]; float2 r[4][E]; uint32_t jj[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t i = i0 + u < nadopted ? i0 + u : nadopted - 1;
+                const uint32_t k = ldsad[i];
+                jj[u] = i0 + u < nadopted ? j0 + i : 0xFFFFFFFFu;
+                w[u] = ((uint32_t)l < sizeof(PayloadJob) / 4) ? reinterpret_cast<const uint32_t *>(&sl[k].job)[l] : 0u;
+                const float2 *rs = a.spec_R + ((size_t)ch * MCRX_SPEC_MAX + k) * c.M;
+#pragma unroll
+                for (int e = 0; e < E; e++) r[u][e] = (l + WV * e < c.M) ? rs[l + WV * e] : make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (jj[u] == 0xFFFFFFFFu) continue;
+                if (jj[u] >= a.max_jobs) { lost++; continue; }     // job list (= record pool) full: counted as dropped
+                if ((uint32_t)l < sizeof(PayloadJob) / 4) reinterpret_cast<uint32_t *>(&a.jobs[jj[u]])[l] = w[u];
+#pragma unroll
+                for (int e = 0; e < E; e++) if (l + WV * e < c.M) a.jR[(size_t)jj[u] * c.M + l + WV * e] = r[u][e];
+            }
+        }
+        if (lost && l == 0) atomicAdd(a.nrec + 1, lost);
+    }
+
+    // speculative wave: acquire one frame from the fresh post-frame state at a predicted position
+    __device__ __forceinline__ void run_spec(uint32_t kslot)
+    {
+        slot = a.spec + (size_t)ch * MCRX_SPEC_MAX + kslot;
+        bR = a.spec_R + ((size_t)ch * MCRX_SPEC_MAX + kslot) * c.M;
+        const int64_t start = (kslot < a.pred_n[ch]) ? a.pred[(size_t)ch * MCRX_SPEC_MAX + kslot] : -1;
+        bool ok = start >= a.buf_first && start >= 0 && start < a.end;
+        if (ok) {
+            s = a.st[ch];                               // (only to give every field a defined value)
+            reset_framesync(); s.timer = (uint32_t)c.L; s.cur = start;
+            init_consts();
+            ok = false;
+            for (int nev = 0; nev < 64; nev++) {
+                int64_t t_ev;
+                if (s.state == SY_SEEK)       t_ev = s.cur + ((s.timer + 1 >= (uint32_t)c.M) ? 0 : (int64_t)(c.M - 1 - (int)s.timer));
+                else if (s.state == SY_S0A || s.state == SY_S0B)
+                                              t_ev = s.cur + ((s.timer + 1 >= (uint32_t)c.M2) ? 0 : (int64_t)(c.M2 - 1 - (int)s.timer));
+                else                          t_ev = s.cur + (int64_t)s.timer - 1;
+                if (t_ev >= a.end) break;
+                s.cur = t_ev + 1;
+                if (s.state != SY_RX) { sync_event(t_ev); continue; }
+                const int fr = rx_event_fast<true>(t_ev);
+                if (fr == 0) continue;
+                ok = fr == 2;                           // anything but a clean hand-off is left to the scout
+                break;
+            }
+        }
+        if (l == 0) { slot->start = ok ? start : -1; slot->t_last = handoff_last; slot->status = ok ? 1 : 0; }
+    }
+
     __device__ __forceinline__ void run()
     {
         s = a.st[ch];
@@ -1374,7 +1487,17 @@ struct Walker {
         }
         const int M = c.M, M2 = c.M2, L = c.L;
         long long prof_cyc[5] = {0, 0, 0, 0, 0}; int prof_n[5] = {0, 0, 0, 0, 0};
+        uint32_t npred = 0; int64_t pred_prev = 0, pred_last = 0;
+        nadopted = 0;
+        if (a.spec_cap) load_spec_headers();
         while (true) {
+            if (a.pred && s.state == SY_SEEK && s.timer == (uint32_t)L) {
+                // the fresh post-frame state: remember the position (next launch's prediction), and take the
+                // frame from a speculative wave if one started from exactly here
+                if (npred < MCRX_SPEC_MAX) { if (l == 0) a.pred[(size_t)ch * MCRX_SPEC_MAX + npred] = s.cur; npred++; }
+                pred_prev = pred_last; pred_last = s.cur;
+                if (a.spec_cap && adopt_speculative()) continue;
+            }
             // sample index of the next state-machine event
             int64_t t_ev;
             if (s.state == SY_SEEK)       t_ev = s.cur + ((s.timer + 1 >= (uint32_t)M) ? 0 : (int64_t)(M - 1 - (int)s.timer));
@@ -1410,6 +1533,18 @@ struct Walker {
         if ((a.debug & 2) && l == 0 && ch == 0)
             printf("[prof] ch0 rx phases: load %lld  core %lld  derot+nco %lld  flex %lld (header decode %lld, hand-off %lld)\n", ph[0], ph[1], ph[2], ph[3], ph[4], ph[5]);
         void_reservation();
+        publish_adopted();
+        if (a.pred) {
+            // continue the frame cadence past this buffer (a stream that goes on), then publish the predictions
+            const int64_t period = pred_last - pred_prev;
+            if (npred >= 2 && period > 0)
+                for (int64_t p = pred_last + period; npred < MCRX_SPEC_MAX && p < a.end + (a.end - a.buf_first); p += period) {
+                    if (l == 0) a.pred[(size_t)ch * MCRX_SPEC_MAX + npred] = p;
+                    npred++;
+                }
+            if (l == 0) { a.pred_n[ch] = npred; if (a.spec_hint && npred > *a.spec_hint) *a.spec_hint = npred; }
+            if ((a.debug & 4) && l == 0 && ch == 0) printf("[spec] ch0 predictions %u adopted %u spec_cap %u\n", npred, nadopted, a.spec_cap);
+        }
         // a header in progress continues in the next launch: its bits move from LDS to the channel's HBM slot
         if (fastp && s.state == SY_RX && s.fstate == FX_HEADER && s.header_symbol_index > 0)
             for (int i = l; i < MCRX_HDR_SYMS; i += WV) bhbits[i] = ldshb[i];
@@ -1435,6 +1570,7 @@ __device__ __forceinline__ void launder(SyncArgs &a)
     LAUNDER(chan); LAUNDER(st); LAUNDER(hbits); LAUNDER(R); LAUNDER(soft); LAUNDER(tmpa); LAUNDER(tmpb);
     LAUNDER(syms); LAUNDER(rec); LAUNDER(arena); LAUNDER(nrec); LAUNDER(arena_used);
     LAUNDER(jobs); LAUNDER(njobs); LAUNDER(jR); LAUNDER(jsoft); LAUNDER(jtmp);
+    LAUNDER(spec); LAUNDER(spec_R); LAUNDER(pred); LAUNDER(pred_n);
 }
 #undef LAUNDER
 
@@ -1446,6 +1582,17 @@ __global__ __launch_bounds__(WV) void sync_kernel(SyncArgs a)
     if (ch >= a.nch) return;
     Walker<E> w(a, ch);
     w.run();
+}
+
+// speculative acquisition: one wave per (channel, predicted position); lean path only
+template <int E>
+__global__ __launch_bounds__(WV) void sync_spec_kernel(SyncArgs a)
+{
+    launder(a);
+    const uint32_t ch = blockIdx.x / a.spec_cap, k = blockIdx.x % a.spec_cap;
+    if (ch >= a.nch) return;
+    Walker<E> w(a, ch);
+    w.run_spec(k);
 }
 
 // one wave per handed-off frame.  Two builds: the lean symbol loop (power-of-two M >= 64, <= 64
@@ -1738,6 +1885,23 @@ hipError_t sync_launch(const SyncArgs &a, hipStream_t st)
     const int E = a.c.E;
 #define SY_LAUNCH(EE) hipLaunchKernelGGL((sync_kernel<EE>), dim3(a.nch), dim3(WV), lds, st, a);
     switch (E) {
+    case 1:  SY_LAUNCH(1) break;
+    case 2:  SY_LAUNCH(2) break;
+    case 4:  SY_LAUNCH(4) break;
+    case 8:  SY_LAUNCH(8) break;
+    case 16: SY_LAUNCH(16) break;
+    default: return hipErrorInvalidValue;
+    }
+#undef SY_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t sync_launch_spec(const SyncArgs &a, hipStream_t st)
+{
+    if (a.nch == 0 || a.spec_cap == 0) return hipSuccess;
+    const size_t lds = SY_LDS_BYTES(a.c.M);
+#define SY_LAUNCH(EE) hipLaunchKernelGGL((sync_spec_kernel<EE>), dim3(a.nch * a.spec_cap), dim3(WV), lds, st, a);
+    switch (a.c.E) {
     case 1:  SY_LAUNCH(1) break;
     case 2:  SY_LAUNCH(2) break;
     case 4:  SY_LAUNCH(4) break;
