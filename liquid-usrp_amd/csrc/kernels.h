@@ -108,7 +108,7 @@ struct PayloadJob {
 // scout adopts a slot when it arrives at exactly that position in exactly that state, else walks on as before.
 #define MCRX_SPEC_MAX 128
 struct SpecSlot {
-    int64_t start;              // first sample consumed from the fresh state
+    int64_t start;              // the SEEK state it started from: next sample | timer << 48 (spec_key)
     int64_t t_last;             // event index of the frame's last payload symbol
     int32_t status;             // 1: frame acquired and handed off (job valid), 0: nothing usable
     uint32_t pad;

@@ -410,6 +410,10 @@ __device__ __forceinline__ void wave_sync_lds()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// speculation key: a SEEK state is fully described by (next sample, timer) -- every path into SEEK resets the
+// rest -- so a slot is keyed by both, packed (timer in the top 16 bits; positions stay below 2^48)
+__device__ __forceinline__ int64_t spec_key(int64_t pos, uint32_t timer) { return (int64_t)(((uint64_t)timer << 48) | ((uint64_t)pos & 0xFFFFFFFFFFFFull)); }
+
 template <int E>
 struct Walker {
     const SyncArgs &a;
@@ -1138,7 +1142,7 @@ struct Walker {
     {
         const int L = c.L, cb = c.cp - c.backoff;
         const int64_t ws = t_ev - L + 1 + cb;
-        const bool prof = (a.debug & 2) != 0;
+        const bool prof = !SPEC && (a.debug & 2) != 0;
         long long k0 = prof ? (long long)__builtin_readcyclecounter() : 0ll, k1;
 #define SY_TICK(i) if (prof) { k1 = (long long)__builtin_readcyclecounter(); ph[i] += k1 - k0; k0 = k1; }
         float2 X[E];
@@ -1199,7 +1203,7 @@ struct Walker {
         s.evm_hat += wave_total_dpp(ev);
         s.header_symbol_index += (uint32_t)c.M_data;
         if (s.header_symbol_index >= MCRX_HDR_SYMS) {
-            const bool prof = (a.debug & 2) != 0;
+            const bool prof = !SPEC && (a.debug & 2) != 0;
             long long k0 = prof ? (long long)__builtin_readcyclecounter() : 0ll;
             decode_header_fast();
             if (prof) { if (s.hw[0] == 0x12345678u && s.hw[1] == 0x9abcdef0u) ph[5]++; const long long k1 = (long long)__builtin_readcyclecounter(); ph[4] += k1 - k0; k0 = k1; }
@@ -1401,10 +1405,10 @@ struct Walker {
         }
         nadopted = 0;
     }
-    __device__ __forceinline__ bool adopt_speculative()
+    __device__ __forceinline__ bool adopt_speculative(int64_t key)
     {
         static_assert(MCRX_SPEC_MAX <= 2 * WV, "two slot headers per lane");
-        const unsigned long long b0 = __ballot(sp_start[0] == s.cur), b1 = __ballot(sp_start[1] == s.cur);
+        const unsigned long long b0 = __ballot(sp_start[0] == key), b1 = __ballot(sp_start[1] == key);
         if (!(b0 | b1)) return false;
         const int hl = b0 ? (int)__builtin_ctzll(b0) : (int)__builtin_ctzll(b1);
         const int64_t t_last = __shfl(b0 ? sp_tlast[0] : sp_tlast[1], hl, WV);
@@ -1452,11 +1456,12 @@ struct Walker {
     {
         slot = a.spec + (size_t)ch * MCRX_SPEC_MAX + kslot;
         bR = a.spec_R + ((size_t)ch * MCRX_SPEC_MAX + kslot) * c.M;
-        const int64_t start = (kslot < a.pred_n[ch]) ? a.pred[(size_t)ch * MCRX_SPEC_MAX + kslot] : -1;
+        const int64_t key = (kslot < a.pred_n[ch]) ? a.pred[(size_t)ch * MCRX_SPEC_MAX + kslot] : -1;
+        const int64_t start = key < 0 ? -1 : (int64_t)((uint64_t)key & 0xFFFFFFFFFFFFull);
         bool ok = start >= a.buf_first && start >= 0 && start < a.end;
         if (ok) {
             s = a.st[ch];                               // (only to give every field a defined value)
-            reset_framesync(); s.timer = (uint32_t)c.L; s.cur = start;
+            reset_framesync(); s.timer = (uint32_t)((uint64_t)key >> 48); s.cur = start;
             init_consts();
             ok = false;
             for (int nev = 0; nev < 64; nev++) {
@@ -1474,7 +1479,7 @@ struct Walker {
                 break;
             }
         }
-        if (l == 0) { slot->start = ok ? start : -1; slot->t_last = handoff_last; slot->status = ok ? 1 : 0; }
+        if (l == 0) { slot->start = ok ? key : -1; slot->t_last = handoff_last; slot->status = ok ? 1 : 0; }
     }
 
     __device__ __forceinline__ void run()
@@ -1487,17 +1492,21 @@ struct Walker {
         }
         const int M = c.M, M2 = c.M2, L = c.L;
         long long prof_cyc[5] = {0, 0, 0, 0, 0}; int prof_n[5] = {0, 0, 0, 0, 0};
-        uint32_t npred = 0; int64_t pred_prev = 0, pred_last = 0;
+        uint32_t npred = 0, nfresh = 0; int64_t pred_prev = 0, pred_last = 0; bool entry = true;
         nadopted = 0;
         if (a.spec_cap) load_spec_headers();
         while (true) {
-            if (a.pred && s.state == SY_SEEK && s.timer == (uint32_t)L) {
-                // the fresh post-frame state: remember the position (next launch's prediction), and take the
-                // frame from a speculative wave if one started from exactly here
-                if (npred < MCRX_SPEC_MAX) { if (l == 0) a.pred[(size_t)ch * MCRX_SPEC_MAX + npred] = s.cur; npred++; }
-                pred_prev = pred_last; pred_last = s.cur;
-                if (a.spec_cap && adopt_speculative()) continue;
+            if (a.pred && s.state == SY_SEEK && (s.timer == (uint32_t)L || entry)) {
+                // a SEEK state worth predicting -- the one this launch starts in, and the fresh one after every
+                // frame: remember it (next launch's prediction), and take the frame from a speculative wave if
+                // one started from exactly this state
+                const int64_t key = spec_key(s.cur, s.timer);
+                if (npred < MCRX_SPEC_MAX) { if (l == 0) a.pred[(size_t)ch * MCRX_SPEC_MAX + npred] = key; npred++; }
+                if (s.timer == (uint32_t)L) { pred_prev = pred_last; pred_last = s.cur; nfresh++; }
+                entry = false;
+                if (a.spec_cap && adopt_speculative(key)) continue;
             }
+            entry = false;
             // sample index of the next state-machine event
             int64_t t_ev;
             if (s.state == SY_SEEK)       t_ev = s.cur + ((s.timer + 1 >= (uint32_t)M) ? 0 : (int64_t)(M - 1 - (int)s.timer));
@@ -1536,10 +1545,12 @@ struct Walker {
         publish_adopted();
         if (a.pred) {
             // continue the frame cadence past this buffer (a stream that goes on), then publish the predictions
+            // (the state the next launch of a continuing stream starts in is known exactly, if it is SEEK)
+            if (s.state == SY_SEEK && npred < MCRX_SPEC_MAX) { if (l == 0) a.pred[(size_t)ch * MCRX_SPEC_MAX + npred] = spec_key(s.cur, s.timer); npred++; }
             const int64_t period = pred_last - pred_prev;
-            if (npred >= 2 && period > 0)
+            if (nfresh >= 2 && period > 0)
                 for (int64_t p = pred_last + period; npred < MCRX_SPEC_MAX && p < a.end + (a.end - a.buf_first); p += period) {
-                    if (l == 0) a.pred[(size_t)ch * MCRX_SPEC_MAX + npred] = p;
+                    if (l == 0) a.pred[(size_t)ch * MCRX_SPEC_MAX + npred] = spec_key(p, (uint32_t)L);
                     npred++;
                 }
             if (l == 0) { a.pred_n[ch] = npred; if (a.spec_hint && npred > *a.spec_hint) *a.spec_hint = npred; }

@@ -318,3 +318,31 @@ def test_noisy_channel_same_decisions_as_oracle(oracle, product, snr_db, mod, fe
     assert len(ora.frames) >= 3 * N - 1
     check_frames(rx.frames, ora.frames, rel=2e-5)
     rx.close()
+
+
+def test_speculation_survives_wrong_predictions(oracle, product):
+    """The scout's frame-level speculation predicts where frames start from the previous launch.  Feed it a
+    stream whose frame length changes (predictions from the first half are wrong for the second), in pieces,
+    twice (the replay makes the predictions right): every pass must equal the oracle's frames."""
+    import torch
+    N, M, cp = 4, 64, 8
+    tx = product.multichanneltx(N, M, cp, 4)
+    a, _ = tx.generate(3, 120, seed=31)
+    b, _ = tx.generate(4, 431, seed=32)
+    iq = torch.cat([a, b, a])
+    n = int(iq.numel()) // (16 * N) * (16 * N)
+    x = iq[:n].cpu().numpy()
+    ora = oracle.MultiChannelRx(N, M, cp, 4)
+    ora.execute(x)
+    assert len(ora.frames) >= (3 + 4 + 3) * N - N
+    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=500, batch_samples=16 * N * 40)
+    seen = 0
+    for rep in range(3):
+        rx.Reset() if rep else None
+        step = 16 * N * 97                              # launches cut frames at arbitrary places
+        for i in range(0, n, step):
+            rx.Execute(iq[i:min(i + step, n)])
+        rx.Flush()
+        check_frames(rx.frames[seen:], ora.frames)      # (the Python mirror keeps every delivered frame)
+        seen = len(rx.frames)
+    rx.close(); tx.close()
