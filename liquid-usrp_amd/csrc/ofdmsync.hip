@@ -1657,7 +1657,7 @@ __device__ __forceinline__ void divmod_small(unsigned a, unsigned b, unsigned &q
 // branches: cells outside the walk swap a dummy group with itself), three cells per thread in flight.
 __device__ void il_pass_lds(unsigned n, unsigned Mi, unsigned Ncol, unsigned mask, unsigned dummy)
 {
-    const unsigned n2 = n / 2, total = Mi * (Ncol + 1), c0 = n / 3;
+    const unsigned n2 = n / 2, c0 = n / 3;
     unsigned long long m64 = 0;
 #pragma unroll
     for (int k = 0; k < 8; k++) if ((mask >> (7 - k)) & 1) m64 |= 0xFFull << (8 * k);
@@ -1666,24 +1666,30 @@ __device__ void il_pass_lds(unsigned n, unsigned Mi, unsigned Ncol, unsigned mas
     if (c0 < n2) divmod_small(n2 - c0 + Ncol - 1, Ncol, cnt0, t0);      // first column: c0 is not reduced modulo Ncol
     divmod_small(c0, Ncol, t0, c0r);
     s1 = c0r + 1; s1 -= s1 >= Ncol ? Ncol : 0u;
-    constexpr int UN = 3;
-    for (unsigned q0 = threadIdx.x; q0 < total; q0 += UN * DK_T) {
+    // The threads take the PAIRS i = 0 .. n/2-1 (not the cells of the walk, 60 % of which are invalid): the
+    // i-th valid cell is found by inverting the column counts.  After the first column the walk meets, in
+    // order, a columns of R+1 cells (residues s1 .. rem-1), b of R (.. Ncol-1), w of R+1 (0 .. min(rem, s1)-1), then R.
+    const unsigned sa = s1 < rem ? rem - s1 : 0u, sb = Ncol - (s1 > rem ? s1 : rem), sw = rem < s1 ? rem : s1;
+    const unsigned B1 = sa * (R + 1), B2 = B1 + sb * R, B3 = B2 + sw * (R + 1);
+    constexpr int UN = 4;
+    for (unsigned i0 = threadIdx.x; i0 < n2; i0 += UN * DK_T) {
         unsigned ea[UN], eb[UN];
         unsigned long long va[UN], vb[UN];
 #pragma unroll
         for (int u = 0; u < UN; u++) {
-            const unsigned q = q0 + u * DK_T;
-            unsigned m, tcol; divmod_small(q, Mi, tcol, m);
-            unsigned cm = c0r + tcol; cm -= cm >= Ncol ? Ncol : 0u;          // tcol <= Ncol
-            const unsigned c = tcol ? cm : c0;
-            const unsigned j = m * Ncol + c;
-            // valid cells of the walk columns 1 .. tcol-1: (tcol-1) R plus the residues below rem among
-            // s1, s1+1, ... (mod Ncol), which wrap at most once
-            const unsigned len = tcol ? tcol - 1 : 0u, e = s1 + len;
-            const unsigned hi1 = e < Ncol ? e : Ncol, wrap = (e > Ncol ? e : Ncol) - Ncol;
-            const unsigned below = ((hi1 < rem ? hi1 : rem) - (s1 < rem ? s1 : rem)) + (wrap < rem ? wrap : rem);
-            const unsigned i = tcol ? cnt0 + len * R + below + m : m;
-            const bool ok = q < total && j < n2 && i < n2;
+            const unsigned i = i0 + u * DK_T;
+            const unsigned ip = i - cnt0;                                   // (meaningless, and unused, while i < cnt0)
+            const bool g1 = ip < B1, g2 = ip < B2, g3 = ip < B3;
+            unsigned d = (g1 || (!g2 && g3)) ? R + 1 : R;
+            d = d ? d : 1u;
+            const unsigned off = g1 ? ip : g2 ? ip - B1 : g3 ? ip - B2 : ip - B3;
+            const unsigned lbase = g1 ? 0u : g2 ? sa : g3 ? sa + sb : sa + sb + sw;
+            unsigned q, m; divmod_small(off, d, q, m);
+            const unsigned len = lbase + q;                                 // whole columns walked after the first
+            unsigned cm = s1 + len; cm -= cm >= Ncol ? Ncol : 0u;
+            const bool first = i < cnt0;
+            const unsigned j = first ? i * Ncol + c0 : m * Ncol + cm;
+            const bool ok = i < n2 && j < n2 && (first || (len < Ncol && m < Mi));
             ea[u] = ok ? DKP(2 * i) : dummy;
             eb[u] = ok ? DKP(2 * j + 1) : dummy;
             va[u] = dk_soft[ea[u]]; vb[u] = dk_soft[eb[u]];
