@@ -147,6 +147,16 @@ __device__ __forceinline__ float wave_scan_fast(float v)
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false));  // row_bcast:31
     return v;
 }
+// the same inside the first row only (lanes 0..15 carry the data, the rest hold zeros or are ignored)
+__device__ __forceinline__ float row_scan_fast(float v)
+{
+    v += dpp_mov<0x111>(v); v += dpp_mov<0x112>(v); v += dpp_mov<0x114>(v); v += dpp_mov<0x118>(v);
+    return v;
+}
+__device__ __forceinline__ float row_total_dpp(float v)      // total of lanes 0..15
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, row_scan_fast(v)), 15));
+}
 // wave total through the DPP scan and one v_readlane (no LDS crossbar): wave-uniform result
 __device__ __forceinline__ float wave_total_dpp(float v)
 {

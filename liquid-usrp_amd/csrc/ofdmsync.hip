@@ -1040,9 +1040,16 @@ struct Walker {
         const float v = atan2_fast(P.y, P.x);
         const float prev = dpp_mov<0x138, false>(v, v);                  // wave_shr:1, lane 0 keeps its own
         const float turns = rintf((v - prev) * 0.15915494309189535f);
-        const float y = fmaf(-TWO_PI_F, wave_scan_fast(turns), v);
-        p0 = wave_total_dpp(pf0 * y);
-        p1 = wave_total_dpp(pf1 * y);
+        float y;
+        if (Mp <= 16) {                     // the usual case (6 pilots at M = 64): everything stays in the first DPP row
+            y = fmaf(-TWO_PI_F, row_scan_fast(turns), v);
+            p0 = row_total_dpp(pf0 * y);
+            p1 = row_total_dpp(pf1 * y);
+        } else {
+            y = fmaf(-TWO_PI_F, wave_scan_fast(turns), v);
+            p0 = wave_total_dpp(pf0 * y);
+            p1 = wave_total_dpp(pf1 * y);
+        }
         pc += (uint32_t)Mp; pc = pc >= 255u ? pc - 255u : pc;
         p1 = 0.3f * p1 + (1.0f - 0.3f) * p1_prime;
         p1_prime = p1;
@@ -1124,7 +1131,7 @@ struct Walker {
             float dphi = p0 - phi_prime;
             dphi -= TWO_PI_F * rintf(dphi * 0.15915494309189535f);
             phi_prime = p0;
-            const uint32_t dnew = dth + rfl(rad2u32(1e-3f * dphi));
+            const uint32_t dnew = dth + rfl((uint32_t)__float2int_rn(dphi * (1e-3f * 683565275.5764316f)));    // |.| < 2^22: exact to the rounding of one product
             th_ws += (uint32_t)(L - cb) * dth + (uint32_t)cb * dnew;
             dth = dnew;
             r_ws += L;
