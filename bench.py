@@ -192,7 +192,7 @@ def main():
                          "note": "last step of each of the %d receiver slots" % D},
             "setup_s": {"iq_generation": round(gen_s, 2)},
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:                     # the CPU leg is reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(ora, d_iq.cpu().numpy(), N, M, cp, taper, args.cpu_reps)
     for rx in rxs:
         rx.close()
