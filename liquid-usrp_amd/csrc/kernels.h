@@ -54,8 +54,7 @@ struct SyncConsts {
     const uint8_t *sctype;      // [M]
     const float *S0, *S1;       // [M]  +-1 / 0
     const float2 *s0t;          // [M]  time-domain S0
-    const float *Ssm;           // [M][Nen]
-    const float *smk, *smn;     // [M][5], [Nen][5]: Ssm = smk smn^T through an orthonormal basis
+    const float *smk, *smn;     // [M][5], [Nen][5]: equaliser smoother (order-4 LSQ projection) = smk smn^T, orthonormal basis
     float2 backoff_rot;         // e^{+j 2 pi backoff / M}: S1 gain estimate de-rotation
     const float *Pfit;          // [2][M_pilot]
     const int16_t *data_rank, *pilot_rank, *en_rank;    // [M]

@@ -174,7 +174,6 @@ static int build_tables(mcrx_hip_t q)
     RC(q->upload(&c.S0, od.S0.data(), od.M));
     RC(q->upload(&c.S1, od.S1.data(), od.M));
     RC(q->upload(&c.s0t, reinterpret_cast<const float2 *>(od.s0.data()), od.M));
-    RC(q->upload(&c.Ssm, od.Ssm.data(), od.Ssm.size()));
     RC(q->upload(&c.smk, od.smk.data(), od.smk.size()));
     RC(q->upload(&c.smn, od.smn.data(), od.smn.size()));
     { const double phi = (double)od.backoff * 6.283185307179586 / (double)od.M; c.backoff_rot = make_float2((float)cos(phi), (float)sin(phi)); }

@@ -443,7 +443,6 @@ struct Walker {
     float2 tw[6]; float sg[6]; int bp32;
     int dr[E], pr[E]; float fxr[E];
     float pf0, pf1;
-    float smn_l[5], smk_e[E][5];   // equaliser smoother factors: lane's basis row (rank = lane), element's evaluation row
 
     __device__ __forceinline__ Walker(const SyncArgs &a_, uint32_t ch_)
         : a(a_), c(a_.c), l(lane_id()), ch(ch_)
@@ -513,12 +512,6 @@ struct Walker {
         for (int i = l; i < 255; i += WV) ldsps[i] = c.pilot_seq[i];
         for (int i = l; i < 2 * c.M_pilot; i += WV) ldspf[i] = c.Pfit[i];
         for (int i = l; i < MCRX_HDR_SYMS; i += WV) ldshm[i] = c.hdr_map[i];
-#pragma unroll
-        for (int d = 0; d < 5; d++) {
-            smn_l[d] = (l < c.Nen) ? c.smn[l * 5 + d] : 0.f;
-#pragma unroll
-            for (int e = 0; e < E; e++) smk_e[e][d] = (k[e] >= 0) ? c.smk[k[e] * 5 + d] : 0.f;
-        }
         if (fast_ok()) init_fast();
         wave_sync_lds();
     }
@@ -1333,24 +1326,40 @@ struct Walker {
                     yarg[erank[e]] = atan2f(G.y, G.x);
                 }
                 wave_sync_lds();
-                const bool lowrank = c.Nen <= WV;
+                // Lane l takes the enabled bins of rank l*E .. l*E+E-1 (fft-shifted order).  Phase unwrap as a
+                // prefix sum of whole turns (each step of liquid's loop adds -rint(d / 2 pi)): in the lane, then
+                // across lanes; then the fit's coefficients in its orthonormal basis: 2 x 5 wave totals.
                 float ca[5], ct[5];
-                if (lowrank) {
-                    // unwrap as a prefix sum of whole turns (each step of liquid's loop adds -rint(d / 2 pi)),
-                    // then the fit's coefficients in its orthonormal basis: 2 x 5 wave totals
-                    const float va = yabs[l < c.Nen ? l : 0];
-                    const float v = yarg[l < c.Nen ? l : 0];
-                    const float prev = dpp_mov<0x138, false>(v, v);
-                    const float turns = rintf((v - prev) * 0.15915494309189535f);
-                    const float y = fmaf(-TWO_PI_F, wave_scan_fast(turns), v);
+                float smk_e[E][5];          // the smoother's factors are fetched here, once per frame (one round trip),
+                {                           // rather than held in 10 E registers for the whole walk
+                    float smn_l[E][5];
 #pragma unroll
-                    for (int d = 0; d < 5; d++) { ca[d] = wave_total_dpp(smn_l[d] * va); ct[d] = wave_total_dpp(smn_l[d] * y); }
-                } else if (l == 0) {
-                    for (int i = 1; i < c.Nen; i++) {
-                        float v = yarg[i];
-                        while ((v - yarg[i - 1]) >  PI_F) v -= 2.0f * PI_F;
-                        while ((v - yarg[i - 1]) < -PI_F) v += 2.0f * PI_F;
-                        yarg[i] = v;
+                    for (int e = 0; e < E; e++)
+#pragma unroll
+                        for (int d = 0; d < 5; d++) {
+                            smn_l[e][d] = (l * E + e < c.Nen) ? c.smn[(l * E + e) * 5 + d] : 0.f;
+                            smk_e[e][d] = (k[e] >= 0) ? c.smk[k[e] * 5 + d] : 0.f;
+                        }
+                    float va[E], vy[E], tn[E];
+#pragma unroll
+                    for (int e = 0; e < E; e++) {
+                        const int n = l * E + e;
+                        va[e] = n < c.Nen ? yabs[n] : 0.f;
+                        vy[e] = yarg[n < c.Nen ? n : c.Nen - 1];
+                    }
+                    float prev = dpp_mov<0x138, false>(vy[E - 1], vy[0]);     // last of the lane before; lane 0: its own first
+                    float run = 0.f;
+#pragma unroll
+                    for (int e = 0; e < E; e++) { run += rintf((vy[e] - prev) * 0.15915494309189535f); tn[e] = run; prev = vy[e]; }
+                    const float before = wave_scan_fast(run) - run;             // whole turns of all lower lanes
+#pragma unroll
+                    for (int e = 0; e < E; e++) vy[e] = fmaf(-TWO_PI_F, before + tn[e], vy[e]);
+#pragma unroll
+                    for (int d = 0; d < 5; d++) {
+                        float sa = 0.f, st = 0.f;
+#pragma unroll
+                        for (int e = 0; e < E; e++) { sa = fmaf(smn_l[e][d], va[e], sa); st = fmaf(smn_l[e][d], vy[e], st); }
+                        ca[d] = wave_total_dpp(sa); ct[d] = wave_total_dpp(st);
                     }
                 }
                 wave_sync_lds();
@@ -1359,21 +1368,8 @@ struct Walker {
                     float2 r = make_float2(0.f, 0.f);
                     if (k[e] >= 0 && sct[e] != 0) {
                         float A = 0.f, th = 0.f;
-                        if (lowrank) {
 #pragma unroll
-                            for (int d = 0; d < 5; d++) { A = fmaf(smk_e[e][d], ca[d], A); th = fmaf(smk_e[e][d], ct[d], th); }
-                        } else {
-                            const float *row = c.Ssm + (size_t)k[e] * c.Nen;
-                            int n = 0;
-                            for (; n + 16 <= c.Nen; n += 16) {          // rows arrive 16 coefficients per round trip
-                                float rw[16];
-#pragma unroll
-                                for (int u = 0; u < 16; u++) rw[u] = row[n + u];
-#pragma unroll
-                                for (int u = 0; u < 16; u++) { A += rw[u] * yabs[n + u]; th += rw[u] * yarg[n + u]; }
-                            }
-                            for (; n < c.Nen; n++) { A += row[n] * yabs[n]; th += row[n] * yarg[n]; }
-                        }
+                        for (int d = 0; d < 5; d++) { A = fmaf(smk_e[e][d], ca[d], A); th = fmaf(smk_e[e][d], ct[d], th); }
                         // A e^{j th}: two-constant reduction of th to [-pi, pi], then the transcendental unit
                         const float kk = rintf(th * 0.15915494309189535f);
                         float rr = fmaf(-kk, 6.28125f, th); rr = fmaf(-kk, 1.9353071795864769e-3f, rr);
@@ -1581,7 +1577,7 @@ template <class T> __device__ __forceinline__ T *as_global(T *p)
 #define LAUNDER(f) a.f = as_global(a.f)
 __device__ __forceinline__ void launder(SyncArgs &a)
 {
-    LAUNDER(c.sctype); LAUNDER(c.S0); LAUNDER(c.S1); LAUNDER(c.s0t); LAUNDER(c.Ssm); LAUNDER(c.Pfit);
+    LAUNDER(c.sctype); LAUNDER(c.S0); LAUNDER(c.S1); LAUNDER(c.s0t); LAUNDER(c.smk); LAUNDER(c.smn); LAUNDER(c.Pfit);
     LAUNDER(c.data_rank); LAUNDER(c.pilot_rank); LAUNDER(c.en_rank); LAUNDER(c.pilot_seq); LAUNDER(c.dft_tw);
     LAUNDER(c.cod.h128_enc); LAUNDER(c.cod.h128_nb); LAUNDER(c.cod.h128_nnb); LAUNDER(c.cod.crc_byte);
     LAUNDER(c.cod.crc_zadv); LAUNDER(c.cod.qam16_nb); LAUNDER(c.cod.qam64_nb);

@@ -19,6 +19,8 @@ def test_unchanged_reference_app_decodes_synthetic_traffic(oracle, tmp_path):
     iq, sent = oracle.synth_traffic(N, M, cp, tp, 3, payload_len=120)
     f = tmp_path / "iq.bin"
     iq.astype(np.complex64).tofile(f)
+    # the class library is plain g++ code over the C-ABI: (re)build it where the test runs
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "liquid-usrp_amd", "host"), "-s"])
     env = dict(os.environ, MCRX_IQ_FILE=str(f), MCRX_IQ_PACKET="4096")
     out = subprocess.run([EXE, "-n", str(N), "-M", str(M), "-C", str(cp), "-T", str(tp), "-t", "0.5", "-v"],
                          env=env, capture_output=True, text=True, timeout=120)
