@@ -1752,7 +1752,8 @@ __global__ __launch_bounds__(DK_T) void decode_kernel(SyncArgs a, uint32_t lds_s
     long long tk[8]; int ntk = 0;
 #define DK_TICK() if (prof) tk[ntk++] = (long long)__builtin_readcyclecounter();
     DK_TICK()
-    const bool lds_path = c.payload_soft && fec1 == 6 && fec0 == 1 && 8u * e1 <= lds_soft_bytes && !(a.no_fast & 8);
+    // LDS path: soft decisions, no inner code, outer code Hamming(12,8) (soft decoder), Golay(24,12) (sliced) or none
+    const bool lds_path = c.payload_soft && fec0 == 1 && (fec1 == 6 || fec1 == 7 || fec1 == 1) && 8u * e1 <= lds_soft_bytes && !(a.no_fast & 8);
     if (lds_path) {
         const unsigned long long *g64 = reinterpret_cast<const unsigned long long *>(soft);
         for (uint32_t b0 = 0; b0 < e1; b0 += 8 * DK_T) {           // eight requests per thread in flight
@@ -1764,19 +1765,46 @@ __global__ __launch_bounds__(DK_T) void decode_kernel(SyncArgs a, uint32_t lds_s
         }
         __syncthreads();
         DK_TICK()
-        unsigned Mi, Ni; il_dims(e1, Mi, Ni);
-        const unsigned dummy = lds_soft_bytes / 8 + msg_bytes / 8;          // one spare group behind the message area
-        il_pass_lds(e1, Mi, Ni + 8, 0x33, dummy);
-        il_pass_lds(e1, Mi, Ni + 4, 0x55, dummy);
-        il_pass_lds(e1, Mi, Ni + 2, 0x0f, dummy);
-        il_pass_lds(e1, Mi, Ni, 0xff, dummy);
+        if (fec1 != 1) {                                                    // coded packets are interleaved (depth 4)
+            unsigned Mi, Ni; il_dims(e1, Mi, Ni);
+            const unsigned dummy = lds_soft_bytes / 8 + msg_bytes / 8;      // one spare group behind the message area
+            il_pass_lds(e1, Mi, Ni + 8, 0x33, dummy);
+            il_pass_lds(e1, Mi, Ni + 4, 0x55, dummy);
+            il_pass_lds(e1, Mi, Ni + 2, 0x0f, dummy);
+            il_pass_lds(e1, Mi, Ni, 0xff, dummy);
+        }
         DK_TICK()
         // decoded bytes (message + CRC key) go to LDS behind the soft bits; the payload leaves for the
         // frame arena from there, coalesced, by the whole workgroup
         const uint32_t *w32 = reinterpret_cast<const uint32_t *>(dk_soft);
         uint8_t *msg = reinterpret_cast<uint8_t *>(dk_soft) + lds_soft_bytes;
         auto word = [&](uint32_t w) { return w32[2u * DKP(w >> 1) + (w & 1u)]; };            // 12 soft bits = 3 words, group-swizzled
-        for (uint32_t i = threadIdx.x; i < n0; i += DK_T) msg[i] = (uint8_t)h128_dec_soft_words(word(3 * i), word(3 * i + 1), word(3 * i + 2));
+        // one coded byte = 8 soft bits sliced at 127, MSB first
+        auto slice = [&](uint32_t g) -> unsigned {
+            const unsigned long long v = dk_soft[DKP(g)];
+            unsigned b = 0;
+#pragma unroll
+            for (int kb = 0; kb < 8; kb++) b = (b << 1) | ((((unsigned)(v >> (8 * kb)) & 0xffu) > 127u) ? 1u : 0u);
+            return b;
+        };
+        if (fec1 == 6) {
+            for (uint32_t i = threadIdx.x; i < n0; i += DK_T) msg[i] = (uint8_t)h128_dec_soft_words(word(3 * i), word(3 * i + 1), word(3 * i + 2));
+        } else if (fec1 == 7) {
+            const uint32_t G = n0 / 3, rr = n0 % 3;                         // 6 coded bytes -> 3 message bytes; tail: 3 -> 1
+            for (uint32_t g = threadIdx.x; g < G; g += DK_T) {
+                const unsigned s0 = golay_dec_sym((slice(6 * g) << 16) | (slice(6 * g + 1) << 8) | slice(6 * g + 2));
+                const unsigned s1 = golay_dec_sym((slice(6 * g + 3) << 16) | (slice(6 * g + 4) << 8) | slice(6 * g + 5));
+                msg[3 * g]     = (uint8_t)((s0 >> 4) & 0xff);
+                msg[3 * g + 1] = (uint8_t)(((s0 << 4) & 0xf0) | ((s1 >> 8) & 0x0f));
+                msg[3 * g + 2] = (uint8_t)(s1 & 0xff);
+            }
+            if (threadIdx.x < rr) {
+                const uint32_t b = 6 * G + 3 * threadIdx.x;
+                msg[3 * G + threadIdx.x] = (uint8_t)(golay_dec_sym((slice(b) << 16) | (slice(b + 1) << 8) | slice(b + 2)) & 0xff);
+            }
+        } else {
+            for (uint32_t i = threadIdx.x; i < n0; i += DK_T) msg[i] = (uint8_t)slice(i);
+        }
         __syncthreads();
         DK_TICK()
         {
