@@ -1612,8 +1612,9 @@ __global__ __launch_bounds__(WV) void sync_spec_kernel(SyncArgs a)
 // one wave per handed-off frame.  Two builds: the lean symbol loop (power-of-two M >= 64, <= 64
 // pilots: every configuration the reference's applications use) and the general walker; the host
 // picks per design, so neither carries the other's registers.
+// (four waves per SIMD up to M = 256; wider symbols hold 2 E window registers twice over and get a larger budget)
 template <int E, bool FAST>
-__global__ __launch_bounds__(WV, 4) void payload_kernel(SyncArgs a)
+__global__ __launch_bounds__(WV, (E <= 4 ? 4 : (E <= 8 ? 2 : 1))) void payload_kernel(SyncArgs a)
 {
     launder(a);
     const uint32_t j = blockIdx.x;
