@@ -259,12 +259,7 @@ inline unsigned hamming128_encode(unsigned s)
 static const unsigned golay_P[12] = { 0x08ed, 0x01db, 0x03b5, 0x0769, 0x0ed1, 0x0da3,
                                       0x0b47, 0x068f, 0x0d1d, 0x0a3b, 0x0477, 0x0ffe };
 
-#define MCRX_H128_NB 24        /* neighbour slots per Hamming(12,8) codeword (distance 3) */
-
 struct CodingTables {
-    uint16_t h128_enc[256];
-    uint8_t  h128_nb[256][MCRX_H128_NB];
-    uint8_t  h128_nnb[256];
     uint32_t crc_byte[256];            // reflected CRC-32 byte table
     uint32_t crc_zadv[16][4][256];     // advance the CRC state through 2^k zero bytes (k = 0..15), by state byte
     uint8_t  qam16_nb[16][4];          // soft-demod nearest neighbours
@@ -296,14 +291,6 @@ struct CodingTables {
     }
     CodingTables()
     {
-        for (unsigned s = 0; s < 256; s++) h128_enc[s] = (uint16_t)hamming128_encode(s);
-        for (unsigned s = 0; s < 256; s++) {
-            unsigned n = 0;
-            for (unsigned t = 0; t < 256; t++)
-                if (t != s && __builtin_popcount(h128_enc[s] ^ h128_enc[t]) == 3 && n < MCRX_H128_NB) h128_nb[s][n++] = (uint8_t)t;
-            h128_nnb[s] = (uint8_t)n;
-            for (; n < MCRX_H128_NB; n++) h128_nb[s][n] = (uint8_t)s;
-        }
         for (unsigned b = 0; b < 256; b++) {
             uint32_t c = b;
             for (int j = 0; j < 8; j++) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1)));

@@ -6,7 +6,6 @@
 namespace mcrx {
 
 #define MCRX_TILE_S 8            // channel-rate samples per (channel, tile) granule
-#define MCRX_H128_NBD 24         // Hamming(12,8) neighbour slots (matches design.hpp)
 #define MCRX_HDR_SYMS 288        // BPSK header symbols
 #define MCRX_HDR_ENC 36
 #define MCRX_HDR_DEC 14
@@ -36,9 +35,6 @@ enum { FX_HEADER = 0, FX_PAYLOAD };
 
 // coding tables in device memory (one copy per process)
 struct CodingDev {
-    const uint16_t *h128_enc;       // [256]
-    const uint8_t *h128_nb;         // [256][MCRX_H128_NBD]
-    const uint8_t *h128_nnb;        // [256]
     const uint32_t *crc_byte;       // [256]
     const uint32_t *crc_zadv;       // [16][4][256]
     const uint8_t *qam16_nb;        // [16][4]

@@ -35,7 +35,6 @@ extern "C" const char *mcrx_hip_last_error(void) { return g_err.c_str(); }
 static std::mutex g_cod_mu;
 static bool g_cod_ready = false;
 static CodingDev g_cod;
-static_assert(MCRX_H128_NB == MCRX_H128_NBD, "neighbour table width mismatch");
 
 template <class T> static int upload_raw(T **dst, const T *src, size_t n)
 {
@@ -48,15 +47,12 @@ static int coding_tables(CodingDev *out)
     std::lock_guard<std::mutex> lk(g_cod_mu);
     if (!g_cod_ready) {
         CodingTables *t = new CodingTables();
-        uint16_t *a; uint8_t *b, *c, *f, *g; uint32_t *d, *e;
-        RC(upload_raw(&a, t->h128_enc, 256));
-        RC(upload_raw(&b, &t->h128_nb[0][0], 256 * MCRX_H128_NB));
-        RC(upload_raw(&c, t->h128_nnb, 256));
+        uint8_t *f, *g; uint32_t *d, *e;
         RC(upload_raw(&d, t->crc_byte, 256));
         RC(upload_raw(&e, &t->crc_zadv[0][0][0], 16 * 4 * 256));
         RC(upload_raw(&f, &t->qam16_nb[0][0], 64));
         RC(upload_raw(&g, &t->qam64_nb[0][0], 256));
-        g_cod.h128_enc = a; g_cod.h128_nb = b; g_cod.h128_nnb = c; g_cod.crc_byte = d; g_cod.crc_zadv = e;
+        g_cod.crc_byte = d; g_cod.crc_zadv = e;
         g_cod.qam16_nb = f; g_cod.qam64_nb = g;
         delete t;
         g_cod_ready = true;

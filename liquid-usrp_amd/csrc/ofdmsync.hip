@@ -148,28 +148,8 @@ __device__ __forceinline__ unsigned h128_dec_sym(unsigned c)
     if (z && z <= 12) c ^= 1u << (12 - z);
     return (c & 0x00f) | ((c & 0x0e0) >> 1) | ((c & 0x200) >> 2);
 }
-__device__ unsigned h128_dec_soft_sym(const CodingDev cod, const uint8_t *soft)
-{
-    unsigned sb[12], c = 0;
-#pragma unroll
-    for (int k = 0; k < 12; k++) { sb[k] = soft[k]; c = (c << 1) | (sb[k] > 127 ? 1u : 0u); }
-    auto dist = [&](unsigned cw) {
-        unsigned d = 0;
-#pragma unroll
-        for (int k = 0; k < 12; k++) d += ((cw >> (11 - k)) & 1) ? 255u - sb[k] : sb[k];
-        return d;
-    };
-    unsigned s0 = h128_dec_sym(c), s_hat = s0;
-    unsigned dmin = dist(cod.h128_enc[s0]);
-    unsigned nnb = cod.h128_nnb[s0];
-    for (unsigned i = 0; i < nnb; i++) {
-        unsigned t = cod.h128_nb[s0 * MCRX_H128_NBD + i];
-        unsigned d = dist(cod.h128_enc[t]);
-        if (d < dmin) { dmin = d; s_hat = t; }
-    }
-    return s_hat;
-}
-// The same decision without table walks.  Hamming(12,8) is linear, so the distance-3 neighbours
+// Soft decision without table walks (liquid: re-encode the hard estimate, then compare the distance-3
+// neighbour codewords in ascending order).  Hamming(12,8) is linear, so the distance-3 neighbours
 // of codeword enc(s0) are enc(s0 ^ u) for the fixed set {u : weight(enc(u)) == 3}, and
 //   dist(enc(s0 ^ u)) - dist(enc(s0)) = sum over the three bits of enc(u) of the cost of flipping them.
 // The patterns are enumerated at compile time; the reference order (estimate first, then neighbours
@@ -1579,7 +1559,7 @@ __device__ __forceinline__ void launder(SyncArgs &a)
 {
     LAUNDER(c.sctype); LAUNDER(c.S0); LAUNDER(c.S1); LAUNDER(c.s0t); LAUNDER(c.smk); LAUNDER(c.smn); LAUNDER(c.Pfit);
     LAUNDER(c.data_rank); LAUNDER(c.pilot_rank); LAUNDER(c.en_rank); LAUNDER(c.pilot_seq); LAUNDER(c.dft_tw);
-    LAUNDER(c.cod.h128_enc); LAUNDER(c.cod.h128_nb); LAUNDER(c.cod.h128_nnb); LAUNDER(c.cod.crc_byte);
+    LAUNDER(c.cod.crc_byte);
     LAUNDER(c.cod.crc_zadv); LAUNDER(c.cod.qam16_nb); LAUNDER(c.cod.qam64_nb);
     LAUNDER(chan); LAUNDER(st); LAUNDER(hbits); LAUNDER(R); LAUNDER(soft); LAUNDER(tmpa); LAUNDER(tmpb);
     LAUNDER(syms); LAUNDER(rec); LAUNDER(arena); LAUNDER(nrec); LAUNDER(arena_used);
