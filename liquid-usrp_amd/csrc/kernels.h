@@ -151,6 +151,9 @@ hipError_t sync_launch_spec(const SyncArgs &a, hipStream_t st);      // speculat
 // stage 0: record placement (one workgroup), 1: payload workers (one wave per handed-off frame),
 // 2: packet decode (one workgroup per frame; only after the lean workers -- the general ones decode in place)
 hipError_t sync_launch_payload(const SyncArgs &a, int stage, hipStream_t st);
-hipError_t sync_reset_launch(ChanState *st, uint32_t nch, int64_t cur, hipStream_t stream);
+// synchronizers back to SEEK at sample `cur`; optionally also zero two history buffers of hist_n cf32 each (hist_n even)
+// and the result counters -- a whole restart in one launch
+hipError_t sync_reset_launch(ChanState *st, uint32_t nch, int64_t cur, float2 *hist0, float2 *hist1, size_t hist_n,
+                             uint32_t *nrec, unsigned long long *arena_used, hipStream_t stream);
 
 }  // namespace mcrx

@@ -212,12 +212,9 @@ static int restart_async(mcrx_hip_t q, hipStream_t st, bool from_zero)
 {
     if (from_zero) { q->total_samples = 0; q->chan_samples = 0; }
     q->stage_fill = 0; q->stage_first = q->total_samples;
-    HIPCHK(hipMemsetAsync(q->d_hist[0], 0, (size_t)HIST_BLOCKS * q->K * sizeof(float2), st));
-    HIPCHK(hipMemsetAsync(q->d_hist[1], 0, (size_t)HIST_BLOCKS * q->K * sizeof(float2), st));
     q->hist_cur = 0;
-    HIPCHK(sync_reset_launch(q->d_st, q->nch, q->chan_samples, st));
-    HIPCHK(hipMemsetAsync(q->d_nrec, 0, 2 * sizeof(uint32_t), st));
-    HIPCHK(hipMemsetAsync(q->d_arena_used, 0, sizeof(unsigned long long), st));
+    HIPCHK(sync_reset_launch(q->d_st, q->nch, q->chan_samples, q->d_hist[0], q->d_hist[1], (size_t)HIST_BLOCKS * q->K,
+                             q->d_nrec, q->d_arena_used, st));
     return MCRX_OK;
 }
 

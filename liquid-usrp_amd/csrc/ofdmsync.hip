@@ -1890,9 +1890,13 @@ __global__ __launch_bounds__(PJ_T) void place_jobs_kernel(SyncArgs a)
     }
 }
 
-__global__ void sync_reset_kernel(ChanState *st, uint32_t nch, int64_t cur)
+// restart in one launch: synchronizers back to SEEK, channelizer history cleared, result counters zeroed
+__global__ void sync_reset_kernel(ChanState *st, uint32_t nch, int64_t cur, float4 *z0, float4 *z1, size_t nz,
+                                  uint32_t *nrec, unsigned long long *arena_used)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nz) { const float4 z = make_float4(0.f, 0.f, 0.f, 0.f); if (z0) z0[i] = z; if (z1) z1[i] = z; }
+    if (i == 0) { if (nrec) { nrec[0] = 0; nrec[1] = 0; } if (arena_used) *arena_used = 0; }
     if (i >= nch) return;
     ChanState z;
     memset(&z, 0, sizeof(z));
@@ -1900,9 +1904,13 @@ __global__ void sync_reset_kernel(ChanState *st, uint32_t nch, int64_t cur)
     st[i] = z;
 }
 
-hipError_t sync_reset_launch(ChanState *st, uint32_t nch, int64_t cur, hipStream_t stream)
+hipError_t sync_reset_launch(ChanState *st, uint32_t nch, int64_t cur, float2 *hist0, float2 *hist1, size_t hist_n,
+                             uint32_t *nrec, unsigned long long *arena_used, hipStream_t stream)
 {
-    hipLaunchKernelGGL(sync_reset_kernel, dim3((nch + 255) / 256), dim3(256), 0, stream, st, nch, cur);
+    const size_t nz = hist_n / 2;                               // float4 = two cf32
+    const size_t n = nz > nch ? nz : nch;
+    hipLaunchKernelGGL(sync_reset_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, st, nch, cur,
+                       reinterpret_cast<float4 *>(hist0), reinterpret_cast<float4 *>(hist1), nz, nrec, arena_used);
     return hipGetLastError();
 }
 
