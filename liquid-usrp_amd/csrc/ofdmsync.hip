@@ -489,9 +489,24 @@ struct Walker {
             twx[st] = make_float2(cs, -sn);
         }
         // per-symbol tables into LDS (they sit on the symbol loop's dependency chain)
-        for (int i = l; i < 255; i += WV) ldsps[i] = c.pilot_seq[i];
-        for (int i = l; i < 2 * c.M_pilot; i += WV) ldspf[i] = c.Pfit[i];
-        for (int i = l; i < MCRX_HDR_SYMS; i += WV) ldshm[i] = c.hdr_map[i];
+        // (word-wise, every request issued before the first LDS store: one round trip instead of one per chunk;
+        //  the 255-byte pilot table sits in an allocation of at least 256)
+        {
+            const uint32_t wps = reinterpret_cast<const uint32_t *>(c.pilot_seq)[l];
+            uint32_t whm[3];
+#pragma unroll
+            for (int u = 0; u < 3; u++) { const int i = l + WV * u; whm[u] = reinterpret_cast<const uint32_t *>(c.hdr_map)[i < MCRX_HDR_SYMS / 2 ? i : 0]; }
+            const int npf = 2 * c.M_pilot;
+            float wpf[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) { const int i = l + WV * u; wpf[u] = c.Pfit[i < npf ? i : 0]; }
+            reinterpret_cast<uint32_t *>(ldsps)[l] = wps;
+#pragma unroll
+            for (int u = 0; u < 3; u++) { const int i = l + WV * u; if (i < MCRX_HDR_SYMS / 2) reinterpret_cast<uint32_t *>(ldshm)[i] = whm[u]; }
+#pragma unroll
+            for (int u = 0; u < 2; u++) { const int i = l + WV * u; if (i < npf) ldspf[i] = wpf[u]; }
+            for (int i = l + 2 * WV; i < npf; i += WV) ldspf[i] = c.Pfit[i];        // more than 64 pilots (M > 512)
+        }
         if (fast_ok()) init_fast();
         wave_sync_lds();
     }
@@ -1037,7 +1052,7 @@ struct Walker {
         init_fast();
 #pragma unroll
         for (int e = 0; e < E; e++) R[e] = sct[e] ? bR[k[e]] : make_float2(0.f, 0.f);
-        for (int i = l; i < 255; i += WV) ldsps[i] = c.pilot_seq[i];
+        reinterpret_cast<uint32_t *>(ldsps)[l] = reinterpret_cast<const uint32_t *>(c.pilot_seq)[l];     // 256 bytes, one word per lane
         wave_sync_lds();
 
         // ---- wave-uniform state in scalars
