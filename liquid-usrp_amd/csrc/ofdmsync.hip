@@ -327,7 +327,8 @@ __device__ __forceinline__ uint8_t soft_clamp(float v)
 { int sb = (int)v; sb = sb > 255 ? 255 : sb; sb = sb < 0 ? 0 : sb; return (uint8_t)sb; }
 
 // soft demodulate r; writes bps soft bits (MSB first), returns hard symbol
-__device__ __forceinline__ unsigned demod_soft(const CodingDev cod, unsigned mod, cfd r, uint8_t *soft)
+// `nbt`: the modem's nearest-neighbour table (cod.qam16_nb / cod.qam64_nb, or a copy of it in LDS)
+__device__ __forceinline__ unsigned demod_soft(const uint8_t *nbt, unsigned mod, cfd r, uint8_t *soft)
 {
     if (mod == 39) {
         soft[0] = soft_clamp((-2.0f * r.x * 4.0f) * 16.0f + 127.0f);
@@ -340,7 +341,6 @@ __device__ __forceinline__ unsigned demod_soft(const CodingDev cod, unsigned mod
     }
     const unsigned bps = (mod == 27) ? 4u : 6u, mq = bps / 2;
     const float alpha = (mod == 27) ? 0.31622776601683794f : 0.1543033499620919f;
-    const uint8_t *nbt = (mod == 27) ? cod.qam16_nb : cod.qam64_nb;
     unsigned si = qam_slice(r.x, mq, alpha), sq = qam_slice(r.y, mq, alpha);
     unsigned s = ((si ^ (si >> 1)) << mq) + (sq ^ (sq >> 1));
     const float gamma = 1.2f * (float)(1u << bps);
@@ -378,7 +378,8 @@ extern __shared__ __attribute__((aligned(16))) float2 sy_lds[];
 #define ldshb (ldsps + 256 + 2 * MCRX_HDR_SYMS)                                /* header bits, decoded order [288] */
 #define ldshd (reinterpret_cast<uint16_t *>(ldsps + 256 + 3 * MCRX_HDR_SYMS))   /* Golay-decoded 12-bit words [12] */
 #define ldsad (ldsps + 256 + 3 * MCRX_HDR_SYMS + 32)                            /* adopted speculative slots [MCRX_SPEC_MAX] */
-#define SY_LDS_BYTES(M) ((size_t)(M) * 8 + (size_t)(M) * 12 + 256 + 3 * MCRX_HDR_SYMS + 32 + MCRX_SPEC_MAX)
+#define ldsqn (ldsad + MCRX_SPEC_MAX)                                             /* QAM neighbour table of the frame's modem [256] */
+#define SY_LDS_BYTES(M) ((size_t)(M) * 8 + (size_t)(M) * 12 + 256 + 3 * MCRX_HDR_SYMS + 32 + MCRX_SPEC_MAX + 256)
 
 // One wavefront per workgroup: LDS traffic of a wave is processed in order, so a compiler-level
 // fence is all the hand-off between lanes needs (no s_barrier, and no vmcnt(0) drain of the
@@ -852,7 +853,7 @@ struct Walker {
                 if (idx < s.mod_len) {
                     syms[idx] = X[e];
                     uint8_t sb[6];
-                    const unsigned hs = demod_soft(c.cod, s.mod_scheme, X[e], sb);
+                    const unsigned hs = demod_soft(s.mod_scheme == 27 ? c.cod.qam16_nb : c.cod.qam64_nb, s.mod_scheme, X[e], sb);
                     for (unsigned kb = 0; kb < s.bps; kb++) {
                         const uint32_t pos = idx * s.bps + kb;
                         if (pos < nbits) soft[pos] = c.payload_soft ? sb[kb] : (uint8_t)(((hs >> (s.bps - 1 - kb)) & 1) ? 255 : 0);
@@ -1053,6 +1054,10 @@ struct Walker {
 #pragma unroll
         for (int e = 0; e < E; e++) R[e] = sct[e] ? bR[k[e]] : make_float2(0.f, 0.f);
         reinterpret_cast<uint32_t *>(ldsps)[l] = reinterpret_cast<const uint32_t *>(c.pilot_seq)[l];     // 256 bytes, one word per lane
+        // the soft demodulator walks the symbol's nearest neighbours: their table (64 or 256 bytes) goes to LDS,
+        // it sits on every symbol's dependency chain
+        if (s.mod_scheme == 27) { if (l < 16) reinterpret_cast<uint32_t *>(ldsqn)[l] = reinterpret_cast<const uint32_t *>(c.cod.qam16_nb)[l]; }
+        else if (s.mod_scheme == 29) reinterpret_cast<uint32_t *>(ldsqn)[l] = reinterpret_cast<const uint32_t *>(c.cod.qam64_nb)[l];
         wave_sync_lds();
 
         // ---- wave-uniform state in scalars
@@ -1096,7 +1101,7 @@ struct Walker {
                 const float2 Z = rot_down(cur[e], fmaf(p1, fxr[e], p0r));
                 syms[idx] = Z;
                 uint8_t sb[6];
-                const unsigned hs = demod_soft(c.cod, mod, Z, sb);
+                const unsigned hs = demod_soft(ldsqn, mod, Z, sb);
                 if (!soft_mode) {
 #pragma unroll
                     for (int kb = 0; kb < 6; kb++) sb[kb] = (uint8_t)(((hs >> ((bps - 1 - kb) & 7)) & 1) ? 255 : 0);
