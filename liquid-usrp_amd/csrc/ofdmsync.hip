@@ -347,18 +347,27 @@ __device__ __forceinline__ unsigned demod_soft(const uint8_t *nbt, unsigned mod,
     float dmin0[6], dmin1[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) { dmin0[k] = 8.0f; dmin1[k] = 8.0f; }
-    cfd xh = qam_point(s, mq, alpha);
+    // constellation point of a symbol: Gray decode of <= 3 bits per axis is two shifts and two xors
+    auto point = [&](unsigned sym) {
+        const unsigned hi = sym >> mq, lo = sym & ((1u << mq) - 1u);
+        const int gi = 2 * (int)(hi ^ (hi >> 1) ^ (hi >> 2)) - (1 << mq) + 1, gq = 2 * (int)(lo ^ (lo >> 1) ^ (lo >> 2)) - (1 << mq) + 1;
+        return make_float2((float)gi * alpha, (float)gq * alpha);
+    };
+    cfd xh = point(s);
     float dr = r.x - xh.x, di = r.y - xh.y, d = dr * dr + di * di;
 #pragma unroll
     for (int k = 0; k < 6; k++) if ((unsigned)k < bps) { if ((s >> (bps - k - 1)) & 1) dmin1[k] = d; else dmin0[k] = d; }
+    const uint32_t nb4 = reinterpret_cast<const uint32_t *>(nbt)[s];       // the four neighbours in one word
+#pragma unroll
     for (int i = 0; i < 4; i++) {
-        unsigned nb = nbt[s * 4 + i];
-        xh = qam_point(nb, mq, alpha);
+        const unsigned nb = (nb4 >> (8 * i)) & 0xffu;
+        xh = point(nb);
         dr = r.x - xh.x; di = r.y - xh.y; d = dr * dr + di * di;
 #pragma unroll
         for (int k = 0; k < 6; k++) if ((unsigned)k < bps) {
-            if ((nb >> (bps - k - 1)) & 1) { if (d < dmin1[k]) dmin1[k] = d; }
-            else                           { if (d < dmin0[k]) dmin0[k] = d; }
+            const bool one = ((nb >> (bps - k - 1)) & 1u) != 0;
+            dmin1[k] = (one && d < dmin1[k]) ? d : dmin1[k];
+            dmin0[k] = (!one && d < dmin0[k]) ? d : dmin0[k];
         }
     }
 #pragma unroll
