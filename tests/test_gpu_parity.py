@@ -253,7 +253,7 @@ def test_record_pool_overflow_is_counted_not_fatal(product):
     rx.close(); tx.close()
 
 
-@pytest.mark.parametrize("M,cp,mod,fec1", [(128, 16, 27, 7), (256, 32, 29, 6), (512, 64, 40, 1)])
+@pytest.mark.parametrize("M,cp,mod,fec1", [(128, 16, 27, 7), (256, 32, 29, 6), (512, 64, 40, 1), (1024, 128, 40, 6)])
 def test_wide_symbols_take_the_lean_path(oracle, product, M, cp, mod, fec1):
     """E = M / 64 > 1 elements per lane (in-lane FFT stages) against the oracle, GPU transmitter as the source."""
     N = 2
@@ -266,7 +266,10 @@ def test_wide_symbols_take_the_lean_path(oracle, product, M, cp, mod, fec1):
     rx = product.multichannelrx(N, M, cp, 4, max_payload_len=400)
     rx.Execute(iq[:n]); rx.Flush()
     assert len(rx.frames) == 2 * N
-    check_frames(rx.frames, ora.frames)
+    # Decisions are identical at every width.  The symbol error between the two float pipelines grows like
+    # sqrt(M) (2.6e-6 at M = 64 ... 5.9e-6 at 256, measured): M = 1024 -- four times the widest symbol of any
+    # BASELINE configuration -- lands at 1.04e-5, so that one case is held to 2e-5.
+    check_frames(rx.frames, ora.frames, rel=2e-5 if M >= 1024 else REL)
     rx.close(); tx.close()
 
 
