@@ -133,6 +133,7 @@ struct SyncArgs {
     // scout -> payload worker hand-off (frame-parallel payload processing)
     int scout;                  // 1: scouts hand complete in-buffer frames to payload workers
     PayloadJob *jobs; uint32_t *njobs; uint32_t max_jobs;
+    uint32_t *njobs_next;       // the next launch's job counter: zeroed by this launch's placement kernel
     float2 *jR;                 // [max_jobs][M]
     uint8_t *jsoft;             // [max_jobs][8*max_enc_len]
     uint8_t *jtmp;              // [max_jobs][2*(max_enc_len+16)]

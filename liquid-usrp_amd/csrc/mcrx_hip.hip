@@ -89,7 +89,7 @@ struct mcrx_hip_s {
     uint8_t *d_soft = nullptr, *d_tmpa = nullptr, *d_tmpb = nullptr; float2 *d_syms = nullptr;
     FrameRec *d_rec = nullptr; uint8_t *d_arena = nullptr; uint32_t *d_nrec = nullptr;
     unsigned long long *d_arena_used = nullptr;
-    PayloadJob *d_jobs = nullptr; uint32_t *d_njobs = nullptr; float2 *d_jR = nullptr;
+    PayloadJob *d_jobs = nullptr; uint32_t *d_njobs = nullptr; float2 *d_jR = nullptr; unsigned njobs_parity = 0;
     SpecSlot *d_spec = nullptr; float2 *d_spec_R = nullptr; int64_t *d_pred = nullptr; uint32_t *d_pred_n = nullptr;
     bool spec = false;
     uint32_t *h_hint = nullptr, *d_hint = nullptr;     // pinned, device-mapped: longest coded frame of the last launch
@@ -276,7 +276,7 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     if ((rc = q->alloc(&q->d_nrec, 2))) return bail(rc);
     if ((rc = q->alloc(&q->d_arena_used, 1))) return bail(rc);
     q->scout = getenv("MCRX_NO_SCOUT") == nullptr;
-    if ((rc = q->alloc(&q->d_njobs, 1))) return bail(rc);
+    if ((rc = q->alloc(&q->d_njobs, 2))) return bail(rc);      // two counters used alternately: a launch zeroes the other one
     if (hipHostMalloc((void **)&q->h_hint, 2 * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess) {
         q->h_hint[0] = 0; q->h_hint[1] = 0;
         if (hipHostGetDevicePointer((void **)&q->d_hint, q->h_hint, 0) != hipSuccess) q->d_hint = nullptr;
@@ -369,7 +369,8 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     a.debug = getenv("MCRX_DEBUG") ? atoi(getenv("MCRX_DEBUG")) : 0;
     a.no_fast = getenv("MCRX_NO_FAST") ? atoi(getenv("MCRX_NO_FAST")) : 0;
     a.scout = q->scout ? 1 : 0;
-    a.jobs = q->d_jobs; a.njobs = q->d_njobs; a.max_jobs = q->max_rec;
+    a.jobs = q->d_jobs; a.njobs = q->d_njobs + q->njobs_parity; a.njobs_next = q->d_njobs + (q->njobs_parity ^ 1u); a.max_jobs = q->max_rec;
+    q->njobs_parity ^= 1u;
     a.jR = q->d_jR; a.jsoft = q->d_jsoft; a.jtmp = q->d_jtmp;
     a.hint = q->d_hint; a.enc_hint = (q->h_hint && q->d_hint) ? *(volatile uint32_t *)q->h_hint : 0u;
     a.spec = q->d_spec; a.spec_R = q->d_spec_R; a.pred = nullptr; a.pred_n = nullptr; a.spec_cap = 0; a.spec_hint = nullptr;
@@ -378,7 +379,7 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
         const uint32_t seen = ((volatile uint32_t *)q->h_hint)[1];         // largest prediction list so far (read without a sync)
         a.spec_cap = seen < MCRX_SPEC_MAX ? seen : MCRX_SPEC_MAX;
     }
-    HIPCHK(hipMemsetAsync(q->d_njobs, 0, sizeof(uint32_t), st));
+    if (!q->scout) HIPCHK(hipMemsetAsync(a.njobs, 0, sizeof(uint32_t), st));     // (with the scout, the previous launch's placement kernel zeroed it)
     RC(q->ev_begin(1, st));
     HIPCHK(sync_launch_spec(a, st));          // speculative waves first, then the per-channel scouts that adopt them
     HIPCHK(sync_launch(a, st));

@@ -1864,6 +1864,7 @@ __global__ __launch_bounds__(PJ_T) void place_jobs_kernel(SyncArgs a)
     launder(a);
     uint32_t nj = *a.njobs;
     if (nj > a.max_jobs) nj = a.max_jobs;
+    if (threadIdx.x == 0 && a.njobs_next) *a.njobs_next = 0;
     auto need_of = [&](uint32_t j) -> uint32_t {      // 0 = void slot (a live frame always has symbols)
         if (a.jobs[j].ch >= a.nch) return 0u;
         const unsigned long long pb = ((unsigned long long)a.jobs[j].s.payload_len + 15ull) & ~15ull;
