@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Soak: random traffic (frame lengths, modems, codes, gains, carrier offsets, noise), random Execute() piece sizes,
+many launches on one handle -- every pass compared with the CPU oracle (flags and bytes equal, symbols <= 2e-5)."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+from __graft_entry__ import load_product, load_oracle
+prod, ora = load_product(), load_oracle()
+rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+worst, nframes, nbad = 0.0, 0, 0
+for it in range(iters):
+    N = int(rng.choice([1, 2, 4, 8])); M, cp = [(64, 8), (64, 16), (128, 16), (256, 32)][rng.randint(4)]
+    tx = prod.multichanneltx(N, M, cp, 4)
+    parts = []
+    for seg in range(rng.randint(1, 4)):
+        mod = int(rng.choice([39, 40, 27, 29])); fec1 = int(rng.choice([1, 6, 7]))
+        plen = int(rng.randint(0, 600)); nf = int(rng.randint(1, 5))
+        x, _ = tx.generate(nf, plen, mod=mod, fec1=fec1, seed=int(rng.randint(1 << 30)), gain=float(rng.uniform(0.2, 1.0)) / N)
+        parts.append(x)
+    tx.close()
+    iq = torch.cat(parts)
+    n = int(iq.numel()) // (16 * N) * (16 * N)
+    x = iq[:n].cpu().numpy()
+    t = np.arange(n)
+    snr = rng.uniform(22, 40)
+    sig = np.sqrt(np.mean(np.abs(x) ** 2))
+    x = (x * np.exp(1j * (rng.uniform(-3e-4, 3e-4) * t + rng.uniform(0, 6.28))) +
+         sig * 10 ** (-snr / 20) / np.sqrt(2) * (rng.randn(n) + 1j * rng.randn(n))).astype(np.complex64)
+    o = ora.MultiChannelRx(N, M, cp, 4); o.execute(x)
+    rx = prod.multichannelrx(N, M, cp, 4, max_payload_len=640, batch_samples=16 * N * int(rng.randint(8, 200)))
+    xd = torch.from_numpy(x).cuda()
+    seen = 0
+    for rep in range(3):
+        if rep: rx.Reset()
+        i = 0
+        while i < n:
+            step = 16 * N * int(rng.randint(1, 400))
+            rx.Execute(xd[i:min(i + step, n)]); i += step
+        rx.Flush()
+        got = rx.frames[seen:]; seen = len(rx.frames)
+        gk = sorted([(f.channel, f.end_sample) for f in got])
+        if len(got) != len(o.frames):
+            nbad += 1; print("iter", it, "rep", rep, "frame count", len(got), len(o.frames)); continue
+        by = {}
+        for f in o.frames: by.setdefault(f.channel, []).append(f)
+        gy = {}
+        for f in got: gy.setdefault(f.channel, []).append(f)
+        for ch in by:
+            for fg, fo in zip(gy.get(ch, []), by[ch]):
+                nframes += 1
+                if (fg.header_valid, fg.payload_valid, fg.header, fg.payload) != (fo.header_valid, fo.payload_valid, fo.header, fo.payload):
+                    nbad += 1; print("iter", it, "rep", rep, "ch", ch, "mismatch", fg, fo)
+                elif len(fo.framesyms):
+                    e = float(np.max(np.abs(fg.framesyms - fo.framesyms)) / np.max(np.abs(fo.framesyms)))
+                    worst = max(worst, e)
+    rx.close()
+print(json.dumps({"iterations": iters, "frames_compared": nframes, "mismatches": nbad, "worst_symbol_rel_err": worst}))
