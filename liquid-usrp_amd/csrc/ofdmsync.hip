@@ -23,6 +23,9 @@
 namespace mcrx {
 
 #define WV 64
+#ifndef SY_PART
+#define SY_PART -1          /* -1: the whole file in one translation unit; 0/1/2: see the launchers at the end */
+#endif
 #define TWO_PI_F 6.283185307179586f
 #define PI_F 3.14159265358979323846f
 
@@ -1637,6 +1640,7 @@ __global__ __launch_bounds__(WV, (E <= 4 ? 4 : (E <= 8 ? 2 : 1))) void payload_k
     else w.run_job(j);
 }
 
+#if SY_PART <= 0        // kernels that do not depend on the symbol width live in part 0 only
 // ------------------------------------------------------------------ packet decode, a workgroup per frame
 // The payload workers leave 8 soft bits per coded byte in HBM.  De-interleaving them there costs
 // four passes of scattered 8-byte read-modify-writes per frame (measured: 4.7x the algorithmic HBM
@@ -1944,46 +1948,69 @@ hipError_t sync_reset_launch(ChanState *st, uint32_t nch, int64_t cur, float2 *h
     return hipGetLastError();
 }
 
+#endif  // SY_PART <= 0
+
+// ---- launchers.  The file is compiled in three parts (-DSY_PART=0/1/2: symbol widths E = 1,2 / 4,8 / 16) so that
+// the template instantiations build in parallel; every part defines the per-width launchers of its widths.
+enum { SYK_SCOUT = 0, SYK_SPEC = 1, SYK_PAYLOAD_FAST = 2, SYK_PAYLOAD_GENERAL = 3 };
+template <int EE>
+static hipError_t sy_launch_width(int what, const SyncArgs &a, unsigned grid, size_t lds, hipStream_t st)
+{
+    switch (what) {
+    case SYK_SCOUT:           hipLaunchKernelGGL((sync_kernel<EE>), dim3(grid), dim3(WV), lds, st, a); break;
+    case SYK_SPEC:            hipLaunchKernelGGL((sync_spec_kernel<EE>), dim3(grid), dim3(WV), lds, st, a); break;
+    case SYK_PAYLOAD_FAST:    hipLaunchKernelGGL((payload_kernel<EE, true>), dim3(grid), dim3(WV), lds, st, a); break;
+    case SYK_PAYLOAD_GENERAL: hipLaunchKernelGGL((payload_kernel<EE, false>), dim3(grid), dim3(WV), lds, st, a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+hipError_t sy_launch_e1(int what, const SyncArgs &a, unsigned grid, size_t lds, hipStream_t st);
+hipError_t sy_launch_e2(int what, const SyncArgs &a, unsigned grid, size_t lds, hipStream_t st);
+hipError_t sy_launch_e4(int what, const SyncArgs &a, unsigned grid, size_t lds, hipStream_t st);
+hipError_t sy_launch_e8(int what, const SyncArgs &a, unsigned grid, size_t lds, hipStream_t st);
+hipError_t sy_launch_e16(int what, const SyncArgs &a, unsigned grid, size_t lds, hipStream_t st);
+#if SY_PART < 0 || SY_PART == 0
+hipError_t sy_launch_e1(int what, const SyncArgs &a, unsigned grid, size_t lds, hipStream_t st) { return sy_launch_width<1>(what, a, grid, lds, st); }
+hipError_t sy_launch_e2(int what, const SyncArgs &a, unsigned grid, size_t lds, hipStream_t st) { return sy_launch_width<2>(what, a, grid, lds, st); }
+#endif
+#if SY_PART < 0 || SY_PART == 1
+hipError_t sy_launch_e4(int what, const SyncArgs &a, unsigned grid, size_t lds, hipStream_t st) { return sy_launch_width<4>(what, a, grid, lds, st); }
+hipError_t sy_launch_e8(int what, const SyncArgs &a, unsigned grid, size_t lds, hipStream_t st) { return sy_launch_width<8>(what, a, grid, lds, st); }
+#endif
+#if SY_PART < 0 || SY_PART == 2
+hipError_t sy_launch_e16(int what, const SyncArgs &a, unsigned grid, size_t lds, hipStream_t st) { return sy_launch_width<16>(what, a, grid, lds, st); }
+#endif
+
+#if SY_PART <= 0
+static hipError_t sy_launch(int what, const SyncArgs &a, unsigned grid, size_t lds, hipStream_t st)
+{
+    switch (a.c.E) {
+    case 1:  return sy_launch_e1(what, a, grid, lds, st);
+    case 2:  return sy_launch_e2(what, a, grid, lds, st);
+    case 4:  return sy_launch_e4(what, a, grid, lds, st);
+    case 8:  return sy_launch_e8(what, a, grid, lds, st);
+    case 16: return sy_launch_e16(what, a, grid, lds, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
 hipError_t sync_launch(const SyncArgs &a, hipStream_t st)
 {
     if (a.nch == 0) return hipSuccess;
-    const size_t lds = SY_LDS_BYTES(a.c.M);
     if (a.c.M > SY_MAXM) return hipErrorInvalidValue;
-    const int E = a.c.E;
-#define SY_LAUNCH(EE) hipLaunchKernelGGL((sync_kernel<EE>), dim3(a.nch), dim3(WV), lds, st, a);
-    switch (E) {
-    case 1:  SY_LAUNCH(1) break;
-    case 2:  SY_LAUNCH(2) break;
-    case 4:  SY_LAUNCH(4) break;
-    case 8:  SY_LAUNCH(8) break;
-    case 16: SY_LAUNCH(16) break;
-    default: return hipErrorInvalidValue;
-    }
-#undef SY_LAUNCH
-    return hipGetLastError();
+    return sy_launch(SYK_SCOUT, a, a.nch, SY_LDS_BYTES(a.c.M), st);
 }
 
 hipError_t sync_launch_spec(const SyncArgs &a, hipStream_t st)
 {
     if (a.nch == 0 || a.spec_cap == 0) return hipSuccess;
-    const size_t lds = SY_LDS_BYTES(a.c.M);
-#define SY_LAUNCH(EE) hipLaunchKernelGGL((sync_spec_kernel<EE>), dim3(a.nch * a.spec_cap), dim3(WV), lds, st, a);
-    switch (a.c.E) {
-    case 1:  SY_LAUNCH(1) break;
-    case 2:  SY_LAUNCH(2) break;
-    case 4:  SY_LAUNCH(4) break;
-    case 8:  SY_LAUNCH(8) break;
-    case 16: SY_LAUNCH(16) break;
-    default: return hipErrorInvalidValue;
-    }
-#undef SY_LAUNCH
-    return hipGetLastError();
+    return sy_launch(SYK_SPEC, a, a.nch * a.spec_cap, SY_LDS_BYTES(a.c.M), st);
 }
 
 hipError_t sync_launch_payload(const SyncArgs &a, int stage, hipStream_t st)
 {
     if (a.nch == 0 || !a.scout || a.max_jobs == 0) return hipSuccess;
-    const size_t lds = SY_LDS_BYTES(a.c.M);
     const unsigned nj = a.max_jobs;
     const bool fast = a.c.log2M >= 6 && a.c.M == WV * a.c.E && a.c.M_pilot <= WV && !(a.no_fast & 1);
     if (stage == 0) {
@@ -2003,18 +2030,8 @@ hipError_t sync_launch_payload(const SyncArgs &a, int stage, hipStream_t st)
         hipLaunchKernelGGL(decode_kernel, dim3(nj), dim3(DK_T), soft_lds + msg_lds + 16, st, a, (uint32_t)soft_lds, (uint32_t)msg_lds);
         return hipGetLastError();
     }
-#define SY_LAUNCH(EE) if (fast) hipLaunchKernelGGL((payload_kernel<EE, true>), dim3(nj), dim3(WV), lds, st, a); \
-                      else      hipLaunchKernelGGL((payload_kernel<EE, false>), dim3(nj), dim3(WV), lds, st, a);
-    switch (a.c.E) {
-    case 1:  SY_LAUNCH(1) break;
-    case 2:  SY_LAUNCH(2) break;
-    case 4:  SY_LAUNCH(4) break;
-    case 8:  SY_LAUNCH(8) break;
-    case 16: SY_LAUNCH(16) break;
-    default: return hipErrorInvalidValue;
-    }
-#undef SY_LAUNCH
-    return hipGetLastError();
+    return sy_launch(fast ? SYK_PAYLOAD_FAST : SYK_PAYLOAD_GENERAL, a, nj, SY_LDS_BYTES(a.c.M), st);
 }
+#endif  // SY_PART <= 0
 
 }  // namespace mcrx
