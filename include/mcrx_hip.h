@@ -39,6 +39,7 @@ extern "C" {
 #define MCRX_EHIP       -3      /* HIP runtime error; see mcrx_hip_last_error() */
 #define MCRX_EUNSUPP    -4      /* configuration outside the kernels' supported set */
 #define MCRX_EOVERFLOW  -5      /* frame pool exhausted: frames were dropped */
+#define MCRX_EBUSY      -6      /* multichanneltx::UpdateData on a channel whose frame is still going out */
 
 #define MCRX_TILE 8             /* time samples per (channel, tile) granule = 64 bytes */
 
@@ -150,6 +151,20 @@ size_t mctx_hip_blocks_for(mctx_hip_t q, unsigned frames_per_channel, unsigned p
 int    mctx_hip_generate(mctx_hip_t q, void *d_iq, size_t nblocks, unsigned frames_per_channel,
                          unsigned payload_len, int mod, int fec0, int fec1, float gain, uint32_t seed,
                          uint8_t *hdr, uint8_t *pay, void *stream);
+/* Streaming form = the class interface of lib/multichanneltx.cc, one call per reference method:
+ *   stream_begin    sizes the per-channel frame slots (call once, before the first update)
+ *   stream_ready    IsChannelReadyForData (:147-162): 1 ready, 0 frame still going out, <0 error
+ *   stream_update   UpdateData (:165-189): assemble a frame for one channel (MCRX_EBUSY when not ready)
+ *   stream_generate GenerateSamples (:192-227): the next 2N wideband samples into a host buffer
+ *   stream_reset    Reset (:126-149): frames and filter state dropped, the oscillator keeps its phase
+ * The GPU works one OFDM symbol period (M + cp calls of stream_generate) ahead, which is the
+ * granularity at which the reference's own frame generators are stepped (:230-242). */
+int    mctx_hip_stream_begin(mctx_hip_t q, unsigned max_payload_len);
+int    mctx_hip_stream_ready(mctx_hip_t q, unsigned channel);
+int    mctx_hip_stream_update(mctx_hip_t q, unsigned channel, const uint8_t *header8, const uint8_t *payload,
+                              unsigned payload_len, int mod, int fec0, int fec1);
+int    mctx_hip_stream_generate(mctx_hip_t q, float *buffer);
+int    mctx_hip_stream_reset(mctx_hip_t q);
 const char *mctx_hip_last_error(void);
 
 #ifdef __cplusplus

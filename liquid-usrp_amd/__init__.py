@@ -18,7 +18,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBPATH = os.path.join(_HERE, "lib", "libmcrx_hip.so")
 
-MCRX_OK, MCRX_EINVAL, MCRX_ENOMEM, MCRX_EHIP, MCRX_EUNSUPP, MCRX_EOVERFLOW = 0, -1, -2, -3, -4, -5
+MCRX_OK, MCRX_EINVAL, MCRX_ENOMEM, MCRX_EHIP, MCRX_EUNSUPP, MCRX_EOVERFLOW, MCRX_EBUSY = 0, -1, -2, -3, -4, -5, -6
 TILE = 8
 
 LIQUID_CRC_NONE, LIQUID_CRC_32 = 1, 6
@@ -84,6 +84,11 @@ _EXPORTS = {
     "mctx_hip_blocks_for": (C.c_size_t, [C.c_void_p, C.c_uint, C.c_uint, C.c_int, C.c_int, C.c_int]),
     "mctx_hip_generate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint, C.c_uint, C.c_int, C.c_int, C.c_int,
                                     C.c_float, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mctx_hip_stream_begin": (C.c_int, [C.c_void_p, C.c_uint]),
+    "mctx_hip_stream_ready": (C.c_int, [C.c_void_p, C.c_uint]),
+    "mctx_hip_stream_update": (C.c_int, [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_uint, C.c_int, C.c_int, C.c_int]),
+    "mctx_hip_stream_generate": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mctx_hip_stream_reset": (C.c_int, [C.c_void_p]),
     "mctx_hip_last_error": (C.c_char_p, []),
 }
 
@@ -340,9 +345,10 @@ class multichanneltx(object):
     generate(frames_per_channel, payload_len, ...) -> (iq, sent): iq is a torch complex64 CUDA
     tensor with the wideband stream, sent[ch] = [(header, payload), ...]."""
 
-    def __init__(self, num_channels, M, cp_len, taper_len, p=None):
+    def __init__(self, num_channels, M, cp_len, taper_len, p=None, max_payload_len=2048):
         self._h = C.c_void_p()
         self.N, self.K = num_channels, 2 * num_channels
+        self.max_payload_len, self._stream_max = max_payload_len, -1
         parr = None if p is None else np.ascontiguousarray(np.frombuffer(bytes(bytearray(p)), np.uint8))
         rc = lib().mctx_hip_create(C.byref(self._h), num_channels, M, cp_len, taper_len,
                                    None if parr is None else parr.ctypes.data)
@@ -374,6 +380,53 @@ class multichanneltx(object):
         sent = [[(bytes(hdr[c, f]), bytes(pay[c, f, :payload_len])) for f in range(frames_per_channel)]
                 for c in range(self.N)]
         return iq, sent
+
+    # ---- class interface of the reference (lib/multichanneltx.cc:126-227), served by the GPU one symbol period at a time
+    def _begin(self, payload_len):
+        if payload_len > self._stream_max:
+            if self._stream_max >= 0:
+                raise McrxError("stream sized for payloads up to %d bytes; pass max_payload_len to the constructor" % self._stream_max)
+            self._stream_max = max(int(self.max_payload_len), int(payload_len))
+            self._chk(lib().mctx_hip_stream_begin(self._h, self._stream_max), "mctx_hip_stream_begin")
+
+    def _chk(self, rc, what):
+        if rc != MCRX_OK:
+            msg = lib().mctx_hip_last_error().decode()
+            if rc == MCRX_EINVAL:
+                raise ValueError(msg)
+            raise McrxError("%s failed (%d): %s" % (what, rc, msg))
+
+    def Reset(self):
+        if self._stream_max >= 0:
+            self._chk(lib().mctx_hip_stream_reset(self._h), "mctx_hip_stream_reset")
+
+    def IsChannelReadyForData(self, channel_id):
+        if not 0 <= channel_id < self.N:
+            raise ValueError("error: multichanneltx::IsChannelReadyForData(), invalid channel id")
+        if self._stream_max < 0:
+            return True
+        return lib().mctx_hip_stream_ready(self._h, channel_id) == 1
+
+    def UpdateData(self, channel_id, header, payload, mod=LIQUID_MODEM_QPSK, fec0=LIQUID_FEC_NONE, fec1=LIQUID_FEC_HAMMING128):
+        """Returns False (the reference prints a warning and returns) when the channel is busy."""
+        if not 0 <= channel_id < self.N:
+            raise ValueError("error: multichanneltx::UpdateData(), invalid channel id")
+        h = np.frombuffer(bytes(bytearray(header))[:8].ljust(8, b"\0"), np.uint8)
+        pl = np.frombuffer(bytes(bytearray(payload)), np.uint8)
+        self._begin(len(pl))
+        rc = lib().mctx_hip_stream_update(self._h, channel_id, h.ctypes.data, pl.ctypes.data if len(pl) else None, len(pl), mod, fec0, fec1)
+        if rc == MCRX_EBUSY:
+            return False
+        self._chk(rc, "mctx_hip_stream_update")
+        return True
+
+    def GenerateSamples(self, buffer=None):
+        """The next 2N wideband samples (host numpy complex64; written into `buffer` when given)."""
+        self._begin(0)
+        out = np.empty(self.K, np.complex64) if buffer is None else buffer
+        assert out.dtype == np.complex64 and out.size >= self.K and out.flags.c_contiguous
+        self._chk(lib().mctx_hip_stream_generate(self._h, out.ctypes.data), "mctx_hip_stream_generate")
+        return out
 
     def close(self):
         if self._h:

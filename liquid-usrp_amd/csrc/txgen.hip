@@ -124,16 +124,31 @@ struct TxSynthArgs {
     uint32_t nblocks, N;
     uint32_t dtheta, first_sample_lo;
     float gain;
+    // streaming (multichanneltx class semantics): one current frame per channel, anywhere on the block axis
+    const long long *ft0;       // [N] absolute block index of the channel's frame start (NULL: batch layout above)
+    const int *fS;              // [N] symbols of the channel's current frame (0: none yet)
+    uint32_t xstride;           // symbols per channel slot in xsym
+    long long b_first;          // absolute index of this launch's block 0
+    int hist;                   // blocks of inverse-FFT history stored in front of v (0: cold start)
 };
 
 // frame sample t of channel ch: cyclic prefix + raised-cosine overlap of consecutive symbols
 // (liquid ofdmframegen_gensymbol / write_S0a / write_S0b / writetail)
-__device__ __forceinline__ float2 frame_sample(const TxSynthArgs &a, uint32_t ch, uint32_t t)
+__device__ __forceinline__ float2 frame_sample(const TxSynthArgs &a, uint32_t ch, uint32_t b)
 {
+    uint32_t t = b; int S = a.S; uint32_t nsym = (uint32_t)(a.frames * a.S);
+    const float2 *xb = a.xsym + (size_t)ch * a.frames * a.S * a.M;
+    if (a.ft0) {                                    // streaming: position inside the channel's current frame
+        const long long rel = a.b_first + (long long)b - a.ft0[ch];
+        S = a.fS[ch]; nsym = (uint32_t)S;
+        if (rel < 0 || S == 0 || rel >= (long long)S * a.L) return make_float2(0.f, 0.f);
+        t = (uint32_t)rel;
+        xb = a.xsym + (size_t)ch * a.xstride * a.M;
+    }
     const uint32_t gs = t / (uint32_t)a.L, i = t % (uint32_t)a.L;
-    if (gs >= (uint32_t)(a.frames * a.S)) return make_float2(0.f, 0.f);
-    const int s = (int)(gs % (uint32_t)a.S);
-    const float2 *x = a.xsym + ((size_t)ch * a.frames * a.S + gs) * a.M;
+    if (gs >= nsym) return make_float2(0.f, 0.f);
+    const int s = (int)(gs % (uint32_t)S);
+    const float2 *x = xb + (size_t)gs * a.M;
     const int M = a.M, cp = a.cp;
     if (s == 0) {                                   // S0a: shifted copy, ramp up only
         float2 v = x[(i + M - 2 * cp) % M];
@@ -141,7 +156,7 @@ __device__ __forceinline__ float2 frame_sample(const TxSynthArgs &a, uint32_t ch
         return v;
     }
     if (s == 1) return x[(i + M - cp) % M];         // S0b: plain cyclic extension
-    if (s == a.S - 1) {                             // tail: previous symbol's postfix ramping down
+    if (s == S - 1) {                               // tail: previous symbol's postfix ramping down
         if ((int)i >= a.taper) return make_float2(0.f, 0.f);
         const float2 p = (x - M)[i]; const float b = a.taperwin[a.taper - 1 - i];
         return make_float2(p.x * b, p.y * b);
@@ -197,7 +212,7 @@ __global__ void txfir_kernel(TxSynthArgs a, uint32_t K)
 #pragma unroll
     for (int q = 0; q < TX_P + 7; q++) {
         const long long b = b0 - (TX_P - 1) + q;
-        w[q] = (b >= 0 && b < (long long)a.nblocks) ? a.v[(size_t)b * K + i] : make_float2(0.f, 0.f);
+        w[q] = (b >= -(long long)a.hist && b < (long long)a.nblocks) ? a.v[b * (long long)K + (long long)i] : make_float2(0.f, 0.f);
     }
 #pragma unroll
     for (int r = 0; r < 8; r++) {
@@ -230,6 +245,18 @@ struct mctx_hip_s {
     std::vector<void *> owned;
     const uint8_t *d_sctype, *d_pseq; const int16_t *d_drank, *d_prank; const float2 *d_s0t, *d_s1t;
     const float *d_taper, *d_taps;
+    // ---- streaming state (mctx_hip_stream_*): the multichanneltx class semantics, one symbol period per launch
+    bool st_on = false;
+    unsigned st_maxpay = 0, st_Sh = 0, st_Spmax = 0, st_Smax = 0;
+    uint8_t *d_shdr = nullptr, *d_spay = nullptr;       // [N][Sh*Md], [N][Spmax*Md] modem symbols of each channel's current frame
+    float2 *d_sxsym = nullptr;                          // [N][Smax][M] its time-domain symbol bodies
+    long long *d_ft0 = nullptr; int *d_fS = nullptr;    // [N] frame start block, symbols per frame
+    float2 *d_sv[2] = { nullptr, nullptr };             // [25 + L][K] inverse-FFT outputs: history, then the period
+    float2 *d_sout = nullptr, *h_sout = nullptr;        // [L][K] the period's wideband samples (device, pinned host)
+    int sv_cur = 0;
+    std::vector<long long> ft0; std::vector<int> fS, fS_new; std::vector<uint8_t> assembled, pending;
+    long long period = 0, blocks_out = 0; unsigned out_pos = 0;
+    hipStream_t sst = nullptr;
     template <class T> int up(const T **dst, const T *src, size_t n)
     {
         T *p = nullptr;
@@ -277,8 +304,12 @@ extern "C" int mctx_hip_create(mctx_hip_t *out, unsigned N, unsigned M, unsigned
 extern "C" int mctx_hip_destroy(mctx_hip_t q)
 {
     if (!q) return MCRX_OK;
-    hipDeviceSynchronize();
-    for (void *p : q->owned) hipFree(p);
+    (void)hipDeviceSynchronize();
+    for (void *p : q->owned) (void)hipFree(p);
+    for (void *p : { (void *)q->d_shdr, (void *)q->d_spay, (void *)q->d_sxsym, (void *)q->d_ft0, (void *)q->d_fS,
+                     (void *)q->d_sv[0], (void *)q->d_sv[1], (void *)q->d_sout }) if (p) (void)hipFree(p);
+    if (q->h_sout) (void)hipHostFree(q->h_sout);
+    if (q->sst) (void)hipStreamDestroy(q->sst);
     delete q;
     return MCRX_OK;
 }
@@ -354,6 +385,7 @@ extern "C" int mctx_hip_generate(mctx_hip_t q, void *d_iq, size_t nblocks, unsig
     ya.M = (int)M; ya.cp = (int)q->cp; ya.taper = (int)q->taper; ya.L = (int)(M + q->cp); ya.S = (int)S; ya.frames = (int)frames;
     ya.taperwin = q->d_taper; ya.xsym = d_xsym; ya.taps = q->d_taps; ya.v = d_v; ya.out = (float2 *)d_iq;
     ya.nblocks = (uint32_t)nblocks; ya.N = N; ya.dtheta = q->dtheta; ya.first_sample_lo = 0; ya.gain = gain;
+    ya.ft0 = nullptr; ya.fS = nullptr; ya.xstride = 0; ya.b_first = 0; ya.hist = 0;
 #define TX_IFFT(KK) hipLaunchKernelGGL((txifft_kernel<KK>), dim3((unsigned)nblocks), dim3((KK) / 2 < 64 ? 64 : (KK) / 2), 0, st, ya)
     switch (K) {
     case 2: TX_IFFT(2); break;       case 4: TX_IFFT(4); break;     case 8: TX_IFFT(8); break;     case 16: TX_IFFT(16); break;
@@ -368,5 +400,158 @@ extern "C" int mctx_hip_generate(mctx_hip_t q, void *d_iq, size_t nblocks, unsig
     TXCHK(hipGetLastError());
     TXCHK(hipStreamSynchronize(st));
     hipFree(d_hdr); hipFree(d_pay); hipFree(d_xsym); hipFree(d_v);
+    return MCRX_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Streaming interface: what the reference's multichanneltx class does per call
+//   IsChannelReadyForData (lib/multichanneltx.cc:147-162), UpdateData (:165-189), GenerateSamples (:192-227)
+// Frames start on OFDM symbol boundaries (the class steps all N frame generators together, one symbol of
+// M+cp samples per GenerateFrameSamples, :230-242), so one launch produces one symbol period = M+cp blocks of
+// 2N samples; a channel is ready again once the period with its frame's last (tail) symbol has been produced.
+static int tx_launch_sym(mctx_hip_t q, const TxSymArgs &sa, unsigned nsym, unsigned nch, hipStream_t st)
+{
+    const dim3 gsym(nsym, nch);
+    switch (std::max(1u, q->M / 64)) {
+    case 1:  hipLaunchKernelGGL((txsym_kernel<1>),  gsym, dim3(TXW), 0, st, sa); break;
+    case 2:  hipLaunchKernelGGL((txsym_kernel<2>),  gsym, dim3(TXW), 0, st, sa); break;
+    case 4:  hipLaunchKernelGGL((txsym_kernel<4>),  gsym, dim3(TXW), 0, st, sa); break;
+    case 8:  hipLaunchKernelGGL((txsym_kernel<8>),  gsym, dim3(TXW), 0, st, sa); break;
+    case 16: hipLaunchKernelGGL((txsym_kernel<16>), gsym, dim3(TXW), 0, st, sa); break;
+    default: g_tx_err = "unsupported subcarrier count"; return MCRX_EUNSUPP;
+    }
+    TXCHK(hipGetLastError());
+    return MCRX_OK;
+}
+static int tx_launch_ifft(mctx_hip_t q, const TxSynthArgs &ya, unsigned nblocks, hipStream_t st)
+{
+#define TX_IFFT(KK) hipLaunchKernelGGL((txifft_kernel<KK>), dim3(nblocks), dim3((KK) / 2 < 64 ? 64 : (KK) / 2), 0, st, ya)
+    switch (q->K) {
+    case 2: TX_IFFT(2); break;       case 4: TX_IFFT(4); break;     case 8: TX_IFFT(8); break;     case 16: TX_IFFT(16); break;
+    case 32: TX_IFFT(32); break;     case 64: TX_IFFT(64); break;   case 128: TX_IFFT(128); break; case 256: TX_IFFT(256); break;
+    case 512: TX_IFFT(512); break;   case 1024: TX_IFFT(1024); break;
+    default: g_tx_err = "unsupported channel count"; return MCRX_EUNSUPP;
+    }
+#undef TX_IFFT
+    TXCHK(hipGetLastError());
+    return MCRX_OK;
+}
+
+extern "C" int mctx_hip_stream_begin(mctx_hip_t q, unsigned max_payload_len)
+{
+    if (!q) { g_tx_err = "null handle"; return MCRX_EINVAL; }
+    if (q->st_on && max_payload_len <= q->st_maxpay) return MCRX_OK;
+    if (q->st_on) { g_tx_err = "stream already sized for shorter payloads"; return MCRX_EINVAL; }
+    const unsigned N = q->N, M = q->M, K = q->K, L = M + q->cp, Md = q->od.M_data;
+    // worst case: BPSK behind two rate-1/2 codes
+    unsigned Sh, Sp, S; frame_geometry(q, max_payload_len, 39, 7, 7, Sh, Sp, S);
+    q->st_maxpay = max_payload_len; q->st_Sh = Sh; q->st_Spmax = Sp; q->st_Smax = S;
+    TXCHK(hipMalloc((void **)&q->d_shdr, (size_t)N * Sh * Md));
+    TXCHK(hipMalloc((void **)&q->d_spay, (size_t)N * Sp * Md));
+    TXCHK(hipMalloc((void **)&q->d_sxsym, (size_t)N * S * M * sizeof(float2)));
+    TXCHK(hipMalloc((void **)&q->d_ft0, N * sizeof(long long)));
+    TXCHK(hipMalloc((void **)&q->d_fS, N * sizeof(int)));
+    for (int i = 0; i < 2; i++) {
+        TXCHK(hipMalloc((void **)&q->d_sv[i], (size_t)(TX_P - 1 + L) * K * sizeof(float2)));
+        TXCHK(hipMemset(q->d_sv[i], 0, (size_t)(TX_P - 1 + L) * K * sizeof(float2)));
+    }
+    TXCHK(hipMalloc((void **)&q->d_sout, (size_t)L * K * sizeof(float2)));
+    TXCHK(hipHostMalloc((void **)&q->h_sout, (size_t)L * K * sizeof(float2), hipHostMallocDefault));
+    TXCHK(hipStreamCreate(&q->sst));
+    q->ft0.assign(N, 0); q->fS.assign(N, 0); q->fS_new.assign(N, 0); q->assembled.assign(N, 0); q->pending.assign(N, 0);
+    q->period = 0; q->out_pos = L; q->sv_cur = 0;
+    q->st_on = true;
+    return MCRX_OK;
+}
+
+extern "C" int mctx_hip_stream_reset(mctx_hip_t q)
+{
+    if (!q || !q->st_on) { g_tx_err = "stream not started"; return MCRX_EINVAL; }
+    const unsigned L = q->M + q->cp;
+    TXCHK(hipStreamSynchronize(q->sst));
+    for (int i = 0; i < 2; i++) TXCHK(hipMemset(q->d_sv[i], 0, (size_t)(TX_P - 1 + L) * q->K * sizeof(float2)));
+    std::fill(q->fS.begin(), q->fS.end(), 0); std::fill(q->assembled.begin(), q->assembled.end(), 0);
+    std::fill(q->pending.begin(), q->pending.end(), 0);
+    q->out_pos = L;                         // (like the reference's Reset, the oscillator keeps its phase: blocks_out stays)
+    return MCRX_OK;
+}
+
+extern "C" int mctx_hip_stream_ready(mctx_hip_t q, unsigned ch)
+{
+    if (!q || !q->st_on || ch >= q->N) return MCRX_EINVAL;
+    return q->assembled[ch] ? 0 : 1;
+}
+
+extern "C" int mctx_hip_stream_update(mctx_hip_t q, unsigned ch, const uint8_t *header8, const uint8_t *payload, unsigned payload_len,
+                                      int mod, int fec0, int fec1)
+{
+    if (!q || !q->st_on || !header8 || (!payload && payload_len)) { g_tx_err = "bad argument"; return MCRX_EINVAL; }
+    if (ch >= q->N) { g_tx_err = "error: multichanneltx::UpdateData(), invalid channel id"; return MCRX_EINVAL; }
+    if (!mod_bps(mod)) { g_tx_err = "unsupported modulation scheme"; return MCRX_EUNSUPP; }
+    if (q->assembled[ch]) { g_tx_err = "warning: multichanneltx::UpdateData(), channel busy"; return MCRX_EBUSY; }
+    if (payload_len > q->st_maxpay) { g_tx_err = "payload longer than the stream was sized for"; return MCRX_EINVAL; }
+    const unsigned M = q->M, Md = q->od.M_data;
+    unsigned Sh, Sp, S; frame_geometry(q, payload_len, mod, fec0, fec1, Sh, Sp, S);
+    if (Sp > q->st_Spmax || S > q->st_Smax) { g_tx_err = "frame longer than the stream was sized for"; return MCRX_EINVAL; }
+    FrameSymbols fsym;
+    std::vector<uint8_t> pl(payload, payload + payload_len);
+    assemble_frame(header8, pl, mod, fec0, fec1, Md, Sh, Sp, fsym);
+    uint8_t *dh = q->d_shdr + (size_t)ch * q->st_Sh * Md, *dp = q->d_spay + (size_t)ch * q->st_Spmax * Md;
+    TXCHK(hipMemcpyAsync(dh, fsym.hdr.data(), fsym.hdr.size(), hipMemcpyHostToDevice, q->sst));
+    if (!fsym.pay.empty()) TXCHK(hipMemcpyAsync(dp, fsym.pay.data(), fsym.pay.size(), hipMemcpyHostToDevice, q->sst));
+    TXCHK(hipStreamSynchronize(q->sst));                // (the staging vectors go out of scope)
+    TxSymArgs sa;
+    sa.M = (int)M; sa.log2M = 0; while ((1u << sa.log2M) < M) sa.log2M++;
+    sa.cp = (int)q->cp; sa.taper = (int)q->taper; sa.L = (int)(M + q->cp); sa.M_pilot = (int)q->od.M_pilot; sa.M_data = (int)Md;
+    sa.S = (int)S; sa.S_hdr = (int)Sh; sa.S_pay = (int)Sp; sa.frames = 1; sa.bps = (int)mod_bps(mod); sa.mod = mod;
+    sa.g_data = 1.0f / sqrtf((float)(q->od.M_pilot + q->od.M_data));
+    sa.sctype = q->d_sctype; sa.data_rank = q->d_drank; sa.pilot_rank = q->d_prank; sa.pilot_seq = q->d_pseq;
+    sa.s0t = q->d_s0t; sa.s1t = q->d_s1t; sa.hdr = dh; sa.pay = dp; sa.nch = 1;
+    sa.xsym = q->d_sxsym + (size_t)ch * q->st_Smax * M;
+    int rc = tx_launch_sym(q, sa, S, 1, q->sst);
+    if (rc) return rc;
+    q->assembled[ch] = 1; q->pending[ch] = 1; q->fS_new[ch] = (int)S;
+    return MCRX_OK;
+}
+
+static int tx_stream_period(mctx_hip_t q)
+{
+    const unsigned N = q->N, M = q->M, K = q->K, L = M + q->cp;
+    const long long B0 = q->period * (long long)L;
+    for (unsigned ch = 0; ch < N; ch++) if (q->pending[ch]) { q->ft0[ch] = B0; q->fS[ch] = q->fS_new[ch]; q->pending[ch] = 0; }
+    TXCHK(hipMemcpyAsync(q->d_ft0, q->ft0.data(), N * sizeof(long long), hipMemcpyHostToDevice, q->sst));
+    TXCHK(hipMemcpyAsync(q->d_fS, q->fS.data(), N * sizeof(int), hipMemcpyHostToDevice, q->sst));
+    float2 *vbuf = q->d_sv[q->sv_cur];
+    TxSynthArgs ya;
+    ya.M = (int)M; ya.cp = (int)q->cp; ya.taper = (int)q->taper; ya.L = (int)L; ya.S = 0; ya.frames = 0;
+    ya.taperwin = q->d_taper; ya.xsym = q->d_sxsym; ya.taps = q->d_taps; ya.v = vbuf + (size_t)(TX_P - 1) * K; ya.out = q->d_sout;
+    ya.nblocks = L; ya.N = N; ya.dtheta = q->dtheta; ya.first_sample_lo = (uint32_t)((unsigned long long)q->blocks_out * K); ya.gain = 1.0f;
+    ya.ft0 = q->d_ft0; ya.fS = q->d_fS; ya.xstride = q->st_Smax; ya.b_first = B0; ya.hist = TX_P - 1;
+    int rc = tx_launch_ifft(q, ya, L, q->sst);
+    if (rc) return rc;
+    const unsigned tb = K < 256 ? 64 : 256;
+    hipLaunchKernelGGL(txfir_kernel, dim3((K + tb - 1) / tb, (L + 7) / 8), dim3(tb), 0, q->sst, ya, K);
+    TXCHK(hipGetLastError());
+    TXCHK(hipMemcpyAsync(q->h_sout, q->d_sout, (size_t)L * K * sizeof(float2), hipMemcpyDeviceToHost, q->sst));
+    // next period's history = the last 25 blocks of (history ++ this period), written into the other buffer
+    float2 *nbuf = q->d_sv[q->sv_cur ^ 1];
+    TXCHK(hipMemcpyAsync(nbuf, vbuf + (size_t)L * K, (size_t)(TX_P - 1) * K * sizeof(float2), hipMemcpyDeviceToDevice, q->sst));
+    q->sv_cur ^= 1;
+    TXCHK(hipStreamSynchronize(q->sst));
+    for (unsigned ch = 0; ch < N; ch++)
+        if (q->assembled[ch] && !q->pending[ch] && q->fS[ch] && B0 + (long long)L >= q->ft0[ch] + (long long)q->fS[ch] * L) q->assembled[ch] = 0;
+    q->period++;
+    q->out_pos = 0;
+    return MCRX_OK;
+}
+
+extern "C" int mctx_hip_stream_generate(mctx_hip_t q, float *out)
+{
+    if (!q || !q->st_on || !out) { g_tx_err = "bad argument"; return MCRX_EINVAL; }
+    const unsigned L = q->M + q->cp;
+    if (q->out_pos >= L) { int rc = tx_stream_period(q); if (rc) return rc; }
+    memcpy(out, q->h_sout + (size_t)q->out_pos * q->K, (size_t)q->K * sizeof(float2));
+    q->out_pos++; q->blocks_out++;
     return MCRX_OK;
 }

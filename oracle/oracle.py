@@ -132,6 +132,7 @@ def lib():
     sig("ll_mctx_is_channel_ready", i, vp, u)
     sig("ll_mctx_update_data", i, vp, u, vp, vp, u, i, i, i)
     sig("ll_mctx_generate_samples", None, vp, vp)
+    sig("ll_mctx_reset", None, vp)
     _lib = L
     return L
 
@@ -435,6 +436,9 @@ class MultiChannelTx:
     def update(self, ch, header, payload, mod=MODEM_QPSK, fec0=FEC_NONE, fec1=FEC_HAMMING128):
         h, pl = _bytes(header), _bytes(payload)
         return lib().ll_mctx_update_data(self.q, ch, _ptr(h), _ptr(pl), len(payload), mod, fec0, fec1)
+
+    def reset(self):
+        lib().ll_mctx_reset(self.q)
 
     def generate(self, nblocks):
         out = np.zeros((nblocks, self.K), np.complex64)

@@ -67,3 +67,107 @@ def test_gpu_tx_argument_errors(product):
     for args in [(0, 64, 8, 4), (2, 7, 8, 4), (2, 64, 0, 0), (2, 64, 4, 5)]:       # lib/multichanneltx.cc:48-60
         with pytest.raises(ValueError):
             product.multichanneltx(*args)
+
+
+# ---- streaming form: the reference class interface (IsChannelReadyForData / UpdateData / GenerateSamples / Reset)
+@pytest.mark.parametrize("N,M,cp,mods,plens", [
+    (2, 64, 8, [(40, 1, 6)], [60]),
+    (4, 64, 16, [(40, 1, 6), (27, 1, 7), (39, 7, 7), (29, 1, 1)], [0, 33, 150, 411]),      # mixed schemes, ragged lengths
+    (8, 128, 16, [(40, 1, 6), (27, 1, 7)], [200, 90]),
+])
+def test_gpu_tx_streaming_class_matches_oracle(oracle, product, N, M, cp, mods, plens):
+    """Same call sequence on both classes: poll readiness, update the channels that are ready (some channels
+    are left idle for a while so that frames start at different symbol periods), pull one block at a time."""
+    rng = np.random.RandomState(11)
+    ref = oracle.MultiChannelTx(N, M, cp, 4)
+    tx = product.multichanneltx(N, M, cp, 4, max_payload_len=512)
+    L = M + cp
+    nperiods = 70
+    got, want = [], []
+    nupd = 0
+    busy_seen = False
+    for per in range(nperiods):
+        for c in range(N):
+            r_ref, r_got = ref.ready(c), tx.IsChannelReadyForData(c)
+            assert r_ref == r_got, (per, c)
+            if not r_got:
+                if not busy_seen:                                   # UpdateData on a busy channel: refused, state unchanged
+                    assert tx.UpdateData(c, b"\0" * 8, b"x") is False
+                    busy_seen = True
+                continue
+            if rng.rand() < 0.35:                                   # leave the channel idle this period
+                continue
+            mod, f0, f1 = mods[rng.randint(len(mods))]
+            pl = bytes(rng.randint(0, 256, plens[rng.randint(len(plens))]).astype(np.uint8))
+            h = bytes(rng.randint(0, 256, 8).astype(np.uint8))
+            assert ref.update(c, h, pl, mod, f0, f1) == 0
+            assert tx.UpdateData(c, h, pl, mod, f0, f1) is True
+            nupd += 1
+        want.append(ref.generate(L))
+        got.append(np.concatenate([tx.GenerateSamples().copy() for _ in range(L)]))
+    got, want = np.concatenate(got), np.concatenate(want)
+    assert nupd >= 2 * N and busy_seen
+    err = np.max(np.abs(got - want)) / np.max(np.abs(want))
+    assert err <= 1e-5, err
+    tx.close()
+
+
+def test_gpu_tx_streaming_reset_mid_frame(oracle, product):
+    """Reset (lib/multichanneltx.cc:126-149) drops the frames and the filter state but not the oscillator phase."""
+    N, M, cp = 2, 64, 8
+    L = M + cp
+    ref = oracle.MultiChannelTx(N, M, cp, 4)
+    tx = product.multichanneltx(N, M, cp, 4, max_payload_len=256)
+    rng = np.random.RandomState(5)
+
+    def step(nblocks):
+        a = ref.generate(nblocks)
+        b = np.concatenate([tx.GenerateSamples().copy() for _ in range(nblocks)])
+        return a, b
+
+    def load():
+        for c in range(N):
+            if ref.ready(c):
+                h, pl = bytes(rng.randint(0, 256, 8).astype(np.uint8)), bytes(rng.randint(0, 256, 100).astype(np.uint8))
+                ref.update(c, h, pl); tx.UpdateData(c, h, pl)
+
+    load()
+    a0, b0 = step(3 * L + 17)                                       # stop in the middle of a symbol period
+    ref.reset(); tx.Reset()
+    assert all(ref.ready(c) and tx.IsChannelReadyForData(c) for c in range(N))
+    load()
+    a1, b1 = step(30 * L)
+    a, b = np.concatenate([a0, a1]), np.concatenate([b0, b1])
+    assert np.max(np.abs(a - b)) / np.max(np.abs(a)) <= 1e-5
+    tx.close()
+
+
+def test_gpu_tx_streaming_feeds_gpu_rx(oracle, product):
+    """Class-interface transmitter -> receiver round trip with ragged traffic."""
+    import torch
+    N, M, cp = 4, 64, 8
+    L = M + cp
+    tx = product.multichanneltx(N, M, cp, 4, max_payload_len=300)
+    rng = np.random.RandomState(3)
+    sent = {}
+    pid = [0] * N
+    blocks = []
+    idle = 0
+    while idle < 3:                                                 # until every frame has gone out, plus the filter tail
+        idle = idle + 1 if all(pid[c] == 4 and tx.IsChannelReadyForData(c) for c in range(N)) else 0
+        for c in range(N):
+            if pid[c] < 4 and tx.IsChannelReadyForData(c) and rng.rand() < 0.7:
+                pl = bytes(rng.randint(0, 256, int(rng.randint(1, 300))).astype(np.uint8))
+                h = bytes([0, pid[c], c]) + bytes(rng.randint(0, 256, 5).astype(np.uint8))
+                assert tx.UpdateData(c, h, pl)
+                sent[(c, pid[c])] = (h, pl); pid[c] += 1
+        blocks.extend(tx.GenerateSamples().copy() for _ in range(L))
+    iq = (np.concatenate(blocks) / np.float32(N)).astype(np.complex64)
+    rx = product.multichannelrx(N, M, cp, 4)
+    n = len(iq) // (16 * N) * (16 * N)
+    rx.Execute(torch.from_numpy(iq[:n]).cuda())
+    rx.Flush()
+    assert len(rx.frames) == len(sent) == 4 * N
+    for f in rx.frames:
+        assert f.payload_valid and sent[(f.channel, f.header[1])] == (f.header, f.payload)
+    rx.close(); tx.close()
