@@ -43,6 +43,12 @@ typedef int (*framesync_callback)(unsigned char *_header, int _header_valid,
                                   unsigned char *_payload, unsigned int _payload_len,
                                   int _payload_valid, framesyncstats_s _stats, void *_userdata);
 
+/* option parsing used by the applications (src/multichannel_tx.cc:49,52,93-95) */
+modulation_scheme liquid_getopt_str2mod(const char *_str);
+fec_scheme        liquid_getopt_str2fec(const char *_str);
+void              liquid_print_modulation_schemes(void);
+void              liquid_print_fec_schemes(void);
+
 /* frame generator properties (lib/multichanneltx.cc:70-75,184) */
 typedef struct { unsigned int check, fec0, fec1, mod_scheme; } ofdmflexframegenprops_s;
 

@@ -152,7 +152,7 @@ int    mctx_hip_generate(mctx_hip_t q, void *d_iq, size_t nblocks, unsigned fram
                          unsigned payload_len, int mod, int fec0, int fec1, float gain, uint32_t seed,
                          uint8_t *hdr, uint8_t *pay, void *stream);
 /* Streaming form = the class interface of lib/multichanneltx.cc, one call per reference method:
- *   stream_begin    sizes the per-channel frame slots (call once, before the first update)
+ *   stream_begin    starts streaming with frame slots for payloads up to max_payload_len (slots grow on demand)
  *   stream_ready    IsChannelReadyForData (:147-162): 1 ready, 0 frame still going out, <0 error
  *   stream_update   UpdateData (:165-189): assemble a frame for one channel (MCRX_EBUSY when not ready)
  *   stream_generate GenerateSamples (:192-227): the next 2N wideband samples into a host buffer

@@ -1,7 +1,11 @@
 // uhd/usrp/multi_usrp.hpp -- synthetic-IQ stand-in for the slice of the UHD API that
 // liquid-usrp's src/multichannel_rx.cc uses (:121-141,161-162,176,186-199,220).  No radio:
 // recv() replays a raw cf32 file named by $MCRX_IQ_FILE in a loop (zeros if unset), one
-// "packet" of $MCRX_IQ_PACKET (default 4096) samples per call.  Own code, header only.
+// "packet" of $MCRX_IQ_PACKET (default 4096) samples per call.  The transmit side used by
+// src/multichannel_tx.cc (:102-121,154-158,202-207,213-218) appends what send() is given to the raw
+// cf32 file named by $MCTX_IQ_FILE and ends the process (exit status 0) once $MCTX_IQ_SAMPLES
+// (default 2^20) samples have gone out -- the reference's transmit loop has no exit of its own.
+// Own code, header only.
 #ifndef LIQUID_USRP_AMD_UHD_SHIM_HPP
 #define LIQUID_USRP_AMD_UHD_SHIM_HPP
 
@@ -12,6 +16,7 @@
 #include <memory>
 #include <string>
 #include <vector>
+#include <unistd.h>
 
 namespace uhd {
 
@@ -30,14 +35,21 @@ struct rx_metadata_t {
     rx_metadata_t() : error_code(ERROR_CODE_NONE) {}
 };
 
+struct tx_metadata_t {
+    bool start_of_burst, end_of_burst, has_time_spec;
+    tx_metadata_t() : start_of_burst(false), end_of_burst(false), has_time_spec(false) {}
+};
+
 struct io_type_t { enum tid_t { COMPLEX_FLOAT32 = 'f' }; };
 
 class device {
 public:
     enum recv_mode_t { RECV_MODE_FULL_BUFF = 0, RECV_MODE_ONE_PACKET = 1 };
+    enum send_mode_t { SEND_MODE_FULL_BUFF = 0, SEND_MODE_ONE_PACKET = 1 };
     typedef std::shared_ptr<device> sptr;
-    device() : pos(0), packet(4096)
+    device() : pos(0), packet(4096), txfp(NULL), txsent(0), txlimit((size_t)1 << 20)
     {
+        if (const char *e = getenv("MCTX_IQ_SAMPLES")) txlimit = (size_t)atol(e);
         if (const char *e = getenv("MCRX_IQ_PACKET")) packet = (size_t)atol(e);
         if (const char *f = getenv("MCRX_IQ_FILE")) {
             if (FILE *fp = fopen(f, "rb")) {
@@ -58,9 +70,19 @@ public:
         for (size_t i = 0; i < n; i++) { out[i] = iq[pos]; if (++pos == iq.size()) pos = 0; }
         return n;
     }
+    size_t send(const void *buff, size_t n, const tx_metadata_t &, io_type_t::tid_t, send_mode_t)
+    {
+        if (!txfp) { const char *f = getenv("MCTX_IQ_FILE"); txfp = fopen(f ? f : "/dev/null", "wb"); }
+        if (n > txlimit - txsent) n = txlimit - txsent;
+        if (txfp && n) fwrite(buff, sizeof(std::complex<float>), n, txfp);
+        txsent += n;
+        if (txsent >= txlimit) { if (txfp) fclose(txfp); printf("uhd shim: %zu samples sent\n", txsent); exit(0); }
+        return n;
+    }
 private:
     std::vector<std::complex<float> > iq;
     size_t pos, packet;
+    FILE *txfp; size_t txsent, txlimit;
 };
 
 namespace usrp {
@@ -68,16 +90,20 @@ class multi_usrp {
 public:
     typedef std::shared_ptr<multi_usrp> sptr;
     static sptr make(const device_addr_t &) { return sptr(new multi_usrp()); }
-    multi_usrp() : dev(new device()), rate(0) {}
+    multi_usrp() : dev(new device()), rate(0), txrate(0) {}
     void set_rx_rate(double r) { rate = r; }
     double get_rx_rate() const { return rate; }
     void set_rx_freq(double) {}
     void set_rx_gain(double) {}
+    void set_tx_rate(double r) { txrate = r; }
+    double get_tx_rate() const { return txrate; }
+    void set_tx_freq(double) {}
+    void set_tx_gain(double) {}
     device::sptr get_device() { return dev; }
     void issue_stream_cmd(const stream_cmd_t &) {}
 private:
     device::sptr dev;
-    double rate;
+    double rate, txrate;
 };
 }  // namespace usrp
 }  // namespace uhd

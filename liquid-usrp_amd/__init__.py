@@ -383,9 +383,7 @@ class multichanneltx(object):
 
     # ---- class interface of the reference (lib/multichanneltx.cc:126-227), served by the GPU one symbol period at a time
     def _begin(self, payload_len):
-        if payload_len > self._stream_max:
-            if self._stream_max >= 0:
-                raise McrxError("stream sized for payloads up to %d bytes; pass max_payload_len to the constructor" % self._stream_max)
+        if self._stream_max < 0:
             self._stream_max = max(int(self.max_payload_len), int(payload_len))
             self._chk(lib().mctx_hip_stream_begin(self._h, self._stream_max), "mctx_hip_stream_begin")
 

@@ -438,18 +438,39 @@ static int tx_launch_ifft(mctx_hip_t q, const TxSynthArgs &ya, unsigned nblocks,
     return MCRX_OK;
 }
 
+// (re)size the per-channel frame slots to hold Sp payload symbols; frames in flight are carried over
+static int tx_stream_slots(mctx_hip_t q, unsigned Sp)
+{
+    const unsigned N = q->N, M = q->M, Md = q->od.M_data, Sh = q->st_Sh, S = 3 + Sh + Sp + 1;
+    uint8_t *npay = nullptr; float2 *nx = nullptr;
+    TXCHK(hipMalloc((void **)&npay, (size_t)N * Sp * Md));
+    TXCHK(hipMalloc((void **)&nx, (size_t)N * S * M * sizeof(float2)));
+    if (q->d_spay) {
+        TXCHK(hipStreamSynchronize(q->sst));
+        TXCHK(hipMemcpy2D(npay, (size_t)Sp * Md, q->d_spay, (size_t)q->st_Spmax * Md, (size_t)q->st_Spmax * Md, N, hipMemcpyDeviceToDevice));
+        TXCHK(hipMemcpy2D(nx, (size_t)S * M * sizeof(float2), q->d_sxsym, (size_t)q->st_Smax * M * sizeof(float2),
+                          (size_t)q->st_Smax * M * sizeof(float2), N, hipMemcpyDeviceToDevice));
+        TXCHK(hipFree(q->d_spay)); TXCHK(hipFree(q->d_sxsym));
+    }
+    q->d_spay = npay; q->d_sxsym = nx; q->st_Spmax = Sp; q->st_Smax = S;
+    return MCRX_OK;
+}
+
 extern "C" int mctx_hip_stream_begin(mctx_hip_t q, unsigned max_payload_len)
 {
     if (!q) { g_tx_err = "null handle"; return MCRX_EINVAL; }
-    if (q->st_on && max_payload_len <= q->st_maxpay) return MCRX_OK;
-    if (q->st_on) { g_tx_err = "stream already sized for shorter payloads"; return MCRX_EINVAL; }
     const unsigned N = q->N, M = q->M, K = q->K, L = M + q->cp, Md = q->od.M_data;
-    // worst case: BPSK behind two rate-1/2 codes
+    // slots for the longest frame a payload of this size can make: BPSK behind two rate-1/2 codes
     unsigned Sh, Sp, S; frame_geometry(q, max_payload_len, 39, 7, 7, Sh, Sp, S);
-    q->st_maxpay = max_payload_len; q->st_Sh = Sh; q->st_Spmax = Sp; q->st_Smax = S;
+    if (q->st_on) {                                 // called again: only ever grows (update also grows on demand)
+        if (Sp > q->st_Spmax) { int rc = tx_stream_slots(q, Sp); if (rc) return rc; }
+        q->st_maxpay = std::max(q->st_maxpay, max_payload_len);
+        return MCRX_OK;
+    }
+    TXCHK(hipStreamCreate(&q->sst));
+    q->st_maxpay = max_payload_len; q->st_Sh = Sh;
     TXCHK(hipMalloc((void **)&q->d_shdr, (size_t)N * Sh * Md));
-    TXCHK(hipMalloc((void **)&q->d_spay, (size_t)N * Sp * Md));
-    TXCHK(hipMalloc((void **)&q->d_sxsym, (size_t)N * S * M * sizeof(float2)));
+    { int rc = tx_stream_slots(q, Sp); if (rc) return rc; }
     TXCHK(hipMalloc((void **)&q->d_ft0, N * sizeof(long long)));
     TXCHK(hipMalloc((void **)&q->d_fS, N * sizeof(int)));
     for (int i = 0; i < 2; i++) {
@@ -458,7 +479,6 @@ extern "C" int mctx_hip_stream_begin(mctx_hip_t q, unsigned max_payload_len)
     }
     TXCHK(hipMalloc((void **)&q->d_sout, (size_t)L * K * sizeof(float2)));
     TXCHK(hipHostMalloc((void **)&q->h_sout, (size_t)L * K * sizeof(float2), hipHostMallocDefault));
-    TXCHK(hipStreamCreate(&q->sst));
     q->ft0.assign(N, 0); q->fS.assign(N, 0); q->fS_new.assign(N, 0); q->assembled.assign(N, 0); q->pending.assign(N, 0);
     q->period = 0; q->out_pos = L; q->sv_cur = 0;
     q->st_on = true;
@@ -490,10 +510,9 @@ extern "C" int mctx_hip_stream_update(mctx_hip_t q, unsigned ch, const uint8_t *
     if (ch >= q->N) { g_tx_err = "error: multichanneltx::UpdateData(), invalid channel id"; return MCRX_EINVAL; }
     if (!mod_bps(mod)) { g_tx_err = "unsupported modulation scheme"; return MCRX_EUNSUPP; }
     if (q->assembled[ch]) { g_tx_err = "warning: multichanneltx::UpdateData(), channel busy"; return MCRX_EBUSY; }
-    if (payload_len > q->st_maxpay) { g_tx_err = "payload longer than the stream was sized for"; return MCRX_EINVAL; }
     const unsigned M = q->M, Md = q->od.M_data;
     unsigned Sh, Sp, S; frame_geometry(q, payload_len, mod, fec0, fec1, Sh, Sp, S);
-    if (Sp > q->st_Spmax || S > q->st_Smax) { g_tx_err = "frame longer than the stream was sized for"; return MCRX_EINVAL; }
+    if (Sp > q->st_Spmax) { int rc = tx_stream_slots(q, Sp + Sp / 4); if (rc) return rc; }
     FrameSymbols fsym;
     std::vector<uint8_t> pl(payload, payload + payload_len);
     assemble_frame(header8, pl, mod, fec0, fec1, Md, Sh, Sp, fsym);

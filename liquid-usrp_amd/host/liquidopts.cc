@@ -1,0 +1,41 @@
+// liquidopts.cc -- the option-parsing helpers of liquid-dsp that liquid-usrp's applications call
+// (src/multichannel_tx.cc:49,52,93-95), for the schemes the GPU path carries.  Names as the liquid
+// command-line tools print them; unknown names give LIQUID_*_UNKNOWN like liquid's own parsers.
+#include <cstdio>
+#include <cstring>
+
+#include <liquid/liquid.h>
+
+static const struct { const char *name; modulation_scheme ms; } mods[] = {
+    { "bpsk", LIQUID_MODEM_BPSK }, { "qpsk", LIQUID_MODEM_QPSK }, { "qam16", LIQUID_MODEM_QAM16 }, { "qam64", LIQUID_MODEM_QAM64 } };
+static const struct { const char *name; fec_scheme fs; } fecs[] = {
+    { "none", LIQUID_FEC_NONE }, { "rep3", LIQUID_FEC_REP3 }, { "rep5", LIQUID_FEC_REP5 }, { "h74", LIQUID_FEC_HAMMING74 },
+    { "h84", LIQUID_FEC_HAMMING84 }, { "h128", LIQUID_FEC_HAMMING128 }, { "g2412", LIQUID_FEC_GOLAY2412 } };
+
+extern "C" modulation_scheme liquid_getopt_str2mod(const char *_str)
+{
+    for (const auto &m : mods) if (!strcmp(_str, m.name)) return m.ms;
+    fprintf(stderr, "warning: liquid_getopt_str2mod(), unknown/unsupported mod scheme : %s\n", _str);
+    return LIQUID_MODEM_UNKNOWN;
+}
+
+extern "C" fec_scheme liquid_getopt_str2fec(const char *_str)
+{
+    for (const auto &f : fecs) if (!strcmp(_str, f.name)) return f.fs;
+    fprintf(stderr, "warning: liquid_getopt_str2fec(), unknown/unsupported fec scheme : %s\n", _str);
+    return LIQUID_FEC_UNKNOWN;
+}
+
+extern "C" void liquid_print_modulation_schemes(void)
+{
+    printf("          ");
+    for (const auto &m : mods) printf("%s ", m.name);
+    printf("\n");
+}
+
+extern "C" void liquid_print_fec_schemes(void)
+{
+    printf("          ");
+    for (const auto &f : fecs) printf("%s ", f.name);
+    printf("\n");
+}

@@ -1,7 +1,7 @@
 """Drop-in boundary checks that need no GPU: the C-ABI library loads and exports every
 symbol include/mcrx_hip.h declares; the host C++ class library builds; and, when the
 reference tree is mounted (this container, not the GPU box), the reference's UNCHANGED
-src/multichannel_rx.cc compiles and links against the shims and the new library."""
+src/multichannel_rx.cc and src/multichannel_tx.cc compile and link against the shims and the new library."""
 import ctypes
 import os
 import re
@@ -55,7 +55,11 @@ def test_host_class_library_builds(product):
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "liquid-usrp_amd", "host"), "-s"])
     out = subprocess.check_output(["nm", "-DC", "--defined-only", os.path.join(LIB, "libliquidusrp_hip.so")]).decode()
     for sym in ["multichannelrx::multichannelrx(", "multichannelrx::Execute(std::complex<float>*, unsigned int)",
-                "multichannelrx::Reset()", "multichannelrx::~multichannelrx()", "timer_create()", "timer_toc("]:
+                "multichannelrx::Reset()", "multichannelrx::~multichannelrx()", "timer_create()", "timer_toc(",
+                "multichanneltx::multichanneltx(unsigned int, unsigned int, unsigned int, unsigned int, unsigned char*)",
+                "multichanneltx::IsChannelReadyForData(unsigned int)", "multichanneltx::GenerateSamples(std::complex<float>*)",
+                "multichanneltx::UpdateData(unsigned int, unsigned char*, unsigned char*, unsigned int, int, int, int)",
+                "multichanneltx::Reset()", "liquid_getopt_str2mod", "liquid_getopt_str2fec"]:
         assert sym in out, sym
 
 
@@ -63,10 +67,10 @@ def test_host_class_library_builds(product):
 def test_reference_app_compiles_and_links_unchanged(product):
     product.build()
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "liquid-usrp_amd", "host"), "-s", "refapp"])
-    exe = os.path.join(LIB, "multichannel_rx_ref")
-    assert os.path.exists(exe)
-    # the binary was produced from the file under /root/reference, not from a copy in the repo
+    for exe in ["multichannel_rx_ref", "multichannel_tx_ref"]:
+        assert os.path.exists(os.path.join(LIB, exe))
+    # the binaries were produced from the files under /root/reference, not from copies in the repo
     for dirpath, _, files in os.walk(ROOT):
         if ".git" in dirpath:
             continue
-        assert "multichannel_rx.cc" not in files, dirpath
+        assert "multichannel_rx.cc" not in files and "multichannel_tx.cc" not in files, dirpath

@@ -70,17 +70,18 @@ def test_gpu_tx_argument_errors(product):
 
 
 # ---- streaming form: the reference class interface (IsChannelReadyForData / UpdateData / GenerateSamples / Reset)
-@pytest.mark.parametrize("N,M,cp,mods,plens", [
-    (2, 64, 8, [(40, 1, 6)], [60]),
-    (4, 64, 16, [(40, 1, 6), (27, 1, 7), (39, 7, 7), (29, 1, 1)], [0, 33, 150, 411]),      # mixed schemes, ragged lengths
-    (8, 128, 16, [(40, 1, 6), (27, 1, 7)], [200, 90]),
+@pytest.mark.parametrize("N,M,cp,mods,plens,maxpl", [
+    (2, 64, 8, [(40, 1, 6)], [60], 512),
+    (4, 64, 16, [(40, 1, 6), (27, 1, 7), (39, 7, 7), (29, 1, 1)], [0, 33, 150, 411], 512),  # mixed schemes, ragged lengths
+    (8, 128, 16, [(40, 1, 6), (27, 1, 7)], [200, 90], 512),
+    (4, 64, 8, [(40, 1, 6), (39, 7, 7)], [5, 40, 90, 260], 4),                              # frame slots grow while frames are in flight
 ])
-def test_gpu_tx_streaming_class_matches_oracle(oracle, product, N, M, cp, mods, plens):
+def test_gpu_tx_streaming_class_matches_oracle(oracle, product, N, M, cp, mods, plens, maxpl):
     """Same call sequence on both classes: poll readiness, update the channels that are ready (some channels
     are left idle for a while so that frames start at different symbol periods), pull one block at a time."""
     rng = np.random.RandomState(11)
     ref = oracle.MultiChannelTx(N, M, cp, 4)
-    tx = product.multichanneltx(N, M, cp, 4, max_payload_len=512)
+    tx = product.multichanneltx(N, M, cp, 4, max_payload_len=maxpl)
     L = M + cp
     nperiods = 70
     got, want = [], []
