@@ -54,6 +54,9 @@ typedef struct {
     uint32_t channel_first;      /* synchronizer shard: first channel ...          */
     uint32_t channel_count;      /* ... and count handled by this handle; 0 -> all  */
     uint32_t batch_samples;      /* execute_host staging size [wideband samples]; 0 -> auto */
+    uint32_t single_channel;     /* 1 = no channelizer: num_channels must be 1 and the samples pushed are that
+                                    channel's own stream, i.e. one ofdmflexframesync (lib/ofdmtxrx.cc:91,620-626);
+                                    samples are consumed 8 at a time */
 } mcrx_hip_config;
 
 /* One decoded frame = the arguments of the reference's framesync_callback
@@ -159,6 +162,13 @@ int    mctx_hip_generate(mctx_hip_t q, void *d_iq, size_t nblocks, unsigned fram
  *   stream_reset    Reset (:126-149): frames and filter state dropped, the oscillator keeps its phase
  * The GPU works one OFDM symbol period (M + cp calls of stream_generate) ahead, which is the
  * granularity at which the reference's own frame generators are stepped (:230-242). */
+/* One frame of one frame generator at the channel rate = ofdmflexframegen_assemble + _writesymbol until the
+ * last symbol, as ofdmtxrx::transmit_packet / assemble_frame + write_symbol drive it (lib/ofdmtxrx.cc:297-342,
+ * 366-388): frame_len() samples (a whole number of M+cp symbols, tail symbol included), scaled by `gain`,
+ * into a host buffer.  Works on any mctx handle (the channel count does not matter). */
+size_t mctx_hip_frame_len(mctx_hip_t q, unsigned payload_len, int mod, int fec0, int fec1);
+int    mctx_hip_frame(mctx_hip_t q, const uint8_t *header8, const uint8_t *payload, unsigned payload_len,
+                      int mod, int fec0, int fec1, float gain, float *out, size_t out_cap_samples);
 int    mctx_hip_stream_begin(mctx_hip_t q, unsigned max_payload_len);
 int    mctx_hip_stream_ready(mctx_hip_t q, unsigned channel);
 int    mctx_hip_stream_update(mctx_hip_t q, unsigned channel, const uint8_t *header8, const uint8_t *payload,

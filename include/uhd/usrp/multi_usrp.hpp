@@ -60,6 +60,7 @@ public:
             } else fprintf(stderr, "uhd shim: cannot open %s\n", f);
         }
     }
+    ~device() { if (txfp) fclose(txfp); }
     size_t get_max_recv_samps_per_packet() const { return packet; }
     size_t recv(void *buff, size_t n, rx_metadata_t &md, io_type_t::tid_t, recv_mode_t)
     {
@@ -99,6 +100,8 @@ public:
     double get_tx_rate() const { return txrate; }
     void set_tx_freq(double) {}
     void set_tx_gain(double) {}
+    void set_tx_antenna(const std::string &) {}
+    void set_rx_antenna(const std::string &) {}
     device::sptr get_device() { return dev; }
     void issue_stream_cmd(const stream_cmd_t &) {}
 private:

@@ -40,7 +40,7 @@ def build(force=False):
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("max_payload_len", C.c_uint32), ("max_frames", C.c_uint32),
                 ("payload_soft", C.c_uint32), ("slab_blocks", C.c_uint32), ("channel_first", C.c_uint32),
-                ("channel_count", C.c_uint32), ("batch_samples", C.c_uint32)]
+                ("channel_count", C.c_uint32), ("batch_samples", C.c_uint32), ("single_channel", C.c_uint32)]
 
 
 class FrameC(C.Structure):
@@ -84,6 +84,9 @@ _EXPORTS = {
     "mctx_hip_blocks_for": (C.c_size_t, [C.c_void_p, C.c_uint, C.c_uint, C.c_int, C.c_int, C.c_int]),
     "mctx_hip_generate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint, C.c_uint, C.c_int, C.c_int, C.c_int,
                                     C.c_float, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mctx_hip_frame_len": (C.c_size_t, [C.c_void_p, C.c_uint, C.c_int, C.c_int, C.c_int]),
+    "mctx_hip_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_float,
+                                 C.c_void_p, C.c_size_t]),
     "mctx_hip_stream_begin": (C.c_int, [C.c_void_p, C.c_uint]),
     "mctx_hip_stream_ready": (C.c_int, [C.c_void_p, C.c_uint]),
     "mctx_hip_stream_update": (C.c_int, [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_uint, C.c_int, C.c_int, C.c_int]),
@@ -426,6 +429,19 @@ class multichanneltx(object):
         self._chk(lib().mctx_hip_stream_generate(self._h, out.ctypes.data), "mctx_hip_stream_generate")
         return out
 
+    def frame(self, header, payload, mod=LIQUID_MODEM_QPSK, fec0=LIQUID_FEC_NONE, fec1=LIQUID_FEC_HAMMING128, gain=1.0):
+        """All samples of one frame of one frame generator (ofdmflexframegen assemble + writesymbol to the last
+        symbol, lib/ofdmtxrx.cc:297-342), channel rate, host numpy complex64."""
+        h = np.frombuffer(bytes(bytearray(header))[:8].ljust(8, b"\0"), np.uint8)
+        pl = np.frombuffer(bytes(bytearray(payload)), np.uint8)
+        n = int(lib().mctx_hip_frame_len(self._h, len(pl), mod, fec0, fec1))
+        if n == 0:
+            raise ValueError("unsupported frame properties")
+        out = np.empty(n, np.complex64)
+        self._chk(lib().mctx_hip_frame(self._h, h.ctypes.data, pl.ctypes.data if len(pl) else None, len(pl), mod, fec0, fec1,
+                                       gain, out.ctypes.data, n), "mctx_hip_frame")
+        return out
+
     def close(self):
         if self._h:
             lib().mctx_hip_destroy(self._h)
@@ -436,6 +452,24 @@ class multichanneltx(object):
             self.close()
         except Exception:
             pass
+
+
+class ofdmflexframesync(multichannelrx):
+    """One frame synchronizer fed its channel's samples directly -- the receive half of the reference's
+    ofdmtxrx (lib/ofdmtxrx.cc:91,620-626) -- on the same kernels as the multichannel bank, without a channelizer.
+    callback(header, header_valid, payload, payload_len, payload_valid, stats, userdata)."""
+
+    def __init__(self, M, cp_len, taper_len, p=None, callback=None, userdata=None, **cfg):
+        multichannelrx.__init__(self, 1, M, cp_len, taper_len, p, [userdata], [callback], single_channel=1, **cfg)
+        self.K = 1
+
+    execute = multichannelrx.Execute
+    reset = multichannelrx.Reset
+
+
+def ofdmflexframegen(M, cp_len, taper_len, p=None):
+    """One frame generator (the transmit half of ofdmtxrx): .frame(header, payload, mod, fec0, fec1, gain)."""
+    return multichanneltx(1, M, cp_len, taper_len, p)
 
 
 def tiles_to_channels(chan, nch):

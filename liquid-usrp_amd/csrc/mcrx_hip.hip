@@ -74,6 +74,7 @@ __global__ void hist_update_kernel(const float2 *old_hist, const float2 *x, uint
 // ---------------------------------------------------------------- handle
 struct mcrx_hip_s {
     unsigned N = 0, K = 0, M = 0, cp = 0, taper = 0;
+    bool bypass = false;                    // one synchronizer fed channel-rate samples, no channelizer (ofdmtxrx)
     OfdmDesign od;
     mcrx_hip_config cfg{};
     std::vector<float> taps;
@@ -228,14 +229,16 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     if (M < 8) return fail(MCRX_EINVAL, "error: multichannelrx, number of subcarriers must be at least 8");
     if (cp < 1) return fail(MCRX_EINVAL, "error: multichannelrx, cyclic prefix length must be at least 1");
     if (taper > cp) return fail(MCRX_EINVAL, "error: multichannelrx, taper length cannot exceed cyclic prefix length");
-    if (!channelizer_supported(2 * N)) return fail(MCRX_EUNSUPP, "channelizer size 2N must be a power of two <= 1024");
+    const bool bypass = cfg && cfg->struct_size >= offsetof(mcrx_hip_config, single_channel) + sizeof(uint32_t) && cfg->single_channel;
+    if (bypass && N != 1) return fail(MCRX_EINVAL, "single_channel needs num_channels == 1");
+    if (!bypass && !channelizer_supported(2 * N)) return fail(MCRX_EUNSUPP, "channelizer size 2N must be a power of two <= 1024");
     if (M > 1024) return fail(MCRX_EUNSUPP, "at most 1024 subcarriers");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(MCRX_EHIP, "no HIP device: the MI355X kernels are the only implementation (no CPU fallback)");
 
     mcrx_hip_t q = new mcrx_hip_s();
-    q->N = N; q->K = 2 * N; q->M = M; q->cp = cp; q->taper = taper;
+    q->N = N; q->K = bypass ? 1 : 2 * N; q->M = M; q->cp = cp; q->taper = taper; q->bypass = bypass;
     if (q->od.init(M, cp, taper, p) != 0) { delete q; return fail(MCRX_EINVAL, "invalid subcarrier allocation"); }
     if (cfg) memcpy(&q->cfg, cfg, std::min<size_t>(cfg->struct_size ? cfg->struct_size : sizeof(*cfg), sizeof(q->cfg)));
     else q->cfg.payload_soft = 1;
@@ -256,8 +259,8 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     { int dev = 0, n = 0;
       if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
           q->ncu = (uint32_t)n; }
-    q->taps = pfb_prototype(q->K, 7, 60.0f);
-    q->dtheta = channel_center_step(N);
+    q->taps = bypass ? std::vector<float>(14, 0.f) : pfb_prototype(q->K, 7, 60.0f);
+    q->dtheta = bypass ? 0u : channel_center_step(N);
     q->hist_tiles = (M + cp + 8 + 7) / 8 + 1;
 
     auto bail = [&](int rc) { mcrx_hip_destroy(q); return rc; };
@@ -397,6 +400,7 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
 extern "C" int mcrx_hip_channelize(mcrx_hip_t q, const void *d_iq, size_t nblocks, uint64_t first_sample,
                                    const void *d_halo, void *d_out, unsigned groups, void *stream)
 {
+    if (q && q->bypass) return fail(MCRX_EUNSUPP, "single_channel handle has no channelizer");
     if (!q || !d_iq || !d_out) return fail(MCRX_EINVAL, "null argument");
     hipStream_t st = stream ? (hipStream_t)stream : q->stream;
     return launch_channelizer(q, (const float2 *)d_iq, nblocks, first_sample, (const float2 *)d_halo,
@@ -462,15 +466,20 @@ static int run_blocks(mcrx_hip_t q, const float2 *x, size_t nblocks, uint64_t fi
     RC(ensure_chan(q, q->hist_tiles + ntiles));
     float2 *buf = q->d_chan[q->chan_cur];
     const size_t tile_elems = (size_t)q->N * MCRX_TILE;
-    RC(launch_channelizer(q, x, nblocks, first_abs, q->d_hist[q->hist_cur], buf + q->hist_tiles * tile_elems, 1, ntiles, st));
+    if (q->bypass)      // the input already is the channel's sample stream (8 samples per tile, contiguous)
+        HIPCHK(hipMemcpyAsync(buf + q->hist_tiles * tile_elems, x, nblocks * sizeof(float2), hipMemcpyDeviceToDevice, st));
+    else
+        RC(launch_channelizer(q, x, nblocks, first_abs, q->d_hist[q->hist_cur], buf + q->hist_tiles * tile_elems, 1, ntiles, st));
     const int64_t buf_first = q->chan_samples - (int64_t)q->hist_tiles * MCRX_TILE;
     RC(launch_sync(q, buf, q->N, q->ch_first, buf_first, q->chan_samples + (int64_t)nblocks, st));
     // FIR history: last 13 blocks of (history, x)
-    const uint64_t nh = (uint64_t)HIST_BLOCKS * q->K;
-    hipLaunchKernelGGL(hist_update_kernel, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, st,
-                       q->d_hist[q->hist_cur], x, (uint64_t)nblocks * q->K, q->d_hist[1 - q->hist_cur], nh);
-    HIPCHK(hipGetLastError());
-    q->hist_cur ^= 1;
+    if (!q->bypass) {
+        const uint64_t nh = (uint64_t)HIST_BLOCKS * q->K;
+        hipLaunchKernelGGL(hist_update_kernel, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, st,
+                           q->d_hist[q->hist_cur], x, (uint64_t)nblocks * q->K, q->d_hist[1 - q->hist_cur], nh);
+        HIPCHK(hipGetLastError());
+        q->hist_cur ^= 1;
+    }
     // synchronizer history: last hist_tiles tiles move to the front of the other buffer
     HIPCHK(hipMemcpyAsync(q->d_chan[1 - q->chan_cur], buf + ntiles * tile_elems,
                           (size_t)q->hist_tiles * tile_elems * sizeof(float2), hipMemcpyDeviceToDevice, st));

@@ -114,6 +114,46 @@ __global__ __launch_bounds__(TXW) void txsym_kernel(TxSymArgs a)
     }
 }
 
+// the same for a subcarrier count that is not a power of two (the reference applications default to M = 48):
+// direct inverse DFT, X staged in LDS, exact integer phase (k n mod M) / M
+__global__ __launch_bounds__(TXW) void txsym_dft_kernel(TxSymArgs a)
+{
+    __shared__ float2 X[1024];
+    const int l = threadIdx.x & 63;
+    const uint32_t gs = blockIdx.x, ch = blockIdx.y;
+    const int f = gs / a.S, s = gs % a.S;
+    float2 *dst = a.xsym + ((size_t)ch * a.frames * a.S + gs) * a.M;
+    if (s < 3 || s == a.S - 1) {
+        const float2 *src = (s == 2) ? a.s1t : a.s0t;
+        for (int i = l; i < a.M; i += TXW) dst[i] = (s == a.S - 1) ? make_float2(0.f, 0.f) : src[i];
+        return;
+    }
+    const bool is_hdr = s < 3 + a.S_hdr;
+    const uint8_t *bits = is_hdr ? a.hdr + ((size_t)ch * a.frames + f) * a.S_hdr * a.M_data + (size_t)(s - 3) * a.M_data
+                                 : a.pay + ((size_t)ch * a.frames + f) * a.S_pay * a.M_data + (size_t)(s - 3 - a.S_hdr) * a.M_data;
+    const uint32_t pcount = (uint32_t)(s - 3) * (uint32_t)a.M_pilot;
+    for (int k = l; k < a.M; k += TXW) {
+        float2 v = make_float2(0.f, 0.f);
+        const int t = a.sctype[k];
+        if (t == 1) v = make_float2(a.pilot_seq[(pcount + (uint32_t)a.pilot_rank[k]) % 255u] ? a.g_data : -a.g_data, 0.f);
+        else if (t == 2) { v = modulate(is_hdr ? 39 : a.mod, bits[a.data_rank[k]]); v.x *= a.g_data; v.y *= a.g_data; }
+        X[k] = v;
+    }
+    __syncthreads();
+    const double stepd = 4294967296.0 / (double)a.M;                    // phase of (k n mod M) / M revolutions, to 2^-32
+    for (int n = l; n < a.M; n += TXW) {
+        float2 acc = make_float2(0.f, 0.f);
+        uint32_t kn = 0;                                                // k n mod M
+        for (int k = 0; k < a.M; k++) {
+            float sn, cs; sincos_u32((uint32_t)((double)kn * stepd), sn, cs);
+            acc.x += X[k].x * cs - X[k].y * sn;
+            acc.y += X[k].x * sn + X[k].y * cs;
+            kn += (uint32_t)n; if (kn >= (uint32_t)a.M) kn -= (uint32_t)a.M;
+        }
+        dst[n] = acc;
+    }
+}
+
 struct TxSynthArgs {
     int M, cp, taper, L, S, frames;
     const float *taperwin;      // [taper]
@@ -199,6 +239,15 @@ __global__ void txifft_kernel(TxSynthArgs a)
     for (int k = tid; k < K; k += T) dst[k] = buf[cur][k];
 }
 
+// one channel's frame as channel-rate samples (ofdmflexframegen_writesymbol output, symbol after symbol)
+__global__ void txframe_kernel(TxSynthArgs a, uint32_t nsamples)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nsamples) return;
+    const float2 v = frame_sample(a, 0, t);
+    a.out[t] = make_float2(v.x * a.gain, v.y * a.gain);
+}
+
 // synthesis FIR down the time axis + NCO mix-up + gain; a thread owns one column for 8 blocks
 __global__ void txfir_kernel(TxSynthArgs a, uint32_t K)
 {
@@ -280,7 +329,7 @@ extern "C" int mctx_hip_create(mctx_hip_t *out, unsigned N, unsigned M, unsigned
     if (taper > cp) { g_tx_err = "error: multichanneltx, taper length cannot exceed cyclic prefix length"; return MCRX_EINVAL; }
     const unsigned K = 2 * N;
     if ((K & (K - 1)) || K > 1024) { g_tx_err = "2N must be a power of two <= 1024"; return MCRX_EUNSUPP; }
-    if ((M & (M - 1)) || M > 1024) { g_tx_err = "GPU transmitter needs a power-of-two subcarrier count <= 1024"; return MCRX_EUNSUPP; }
+    if (M > 1024) { g_tx_err = "at most 1024 subcarriers"; return MCRX_EUNSUPP; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_tx_err = "no HIP device (no CPU fallback)"; return MCRX_EHIP; }
     mctx_hip_t q = new mctx_hip_s();
@@ -313,6 +362,8 @@ extern "C" int mctx_hip_destroy(mctx_hip_t q)
     delete q;
     return MCRX_OK;
 }
+
+static int tx_launch_sym(mctx_hip_t q, const TxSymArgs &sa, unsigned nsym, unsigned nch, hipStream_t st);
 
 static void frame_geometry(mctx_hip_t q, unsigned payload_len, int mod, int fec0, int fec1,
                            unsigned &S_hdr, unsigned &S_pay, unsigned &S)
@@ -370,17 +421,7 @@ extern "C" int mctx_hip_generate(mctx_hip_t q, void *d_iq, size_t nblocks, unsig
     sa.g_data = 1.0f / sqrtf((float)(q->od.M_pilot + q->od.M_data));
     sa.sctype = q->d_sctype; sa.data_rank = q->d_drank; sa.pilot_rank = q->d_prank; sa.pilot_seq = q->d_pseq;
     sa.s0t = q->d_s0t; sa.s1t = q->d_s1t; sa.hdr = d_hdr; sa.pay = d_pay; sa.xsym = d_xsym; sa.nch = N;
-    const dim3 gsym((unsigned)nsym, N);
-    const unsigned E = std::max(1u, M / 64);
-    switch (E) {
-    case 1:  hipLaunchKernelGGL((txsym_kernel<1>),  gsym, dim3(TXW), 0, st, sa); break;
-    case 2:  hipLaunchKernelGGL((txsym_kernel<2>),  gsym, dim3(TXW), 0, st, sa); break;
-    case 4:  hipLaunchKernelGGL((txsym_kernel<4>),  gsym, dim3(TXW), 0, st, sa); break;
-    case 8:  hipLaunchKernelGGL((txsym_kernel<8>),  gsym, dim3(TXW), 0, st, sa); break;
-    case 16: hipLaunchKernelGGL((txsym_kernel<16>), gsym, dim3(TXW), 0, st, sa); break;
-    default: g_tx_err = "unsupported subcarrier count"; return MCRX_EUNSUPP;
-    }
-    TXCHK(hipGetLastError());
+    { int rc = tx_launch_sym(q, sa, (unsigned)nsym, N, st); if (rc) return rc; }
     TxSynthArgs ya;
     ya.M = (int)M; ya.cp = (int)q->cp; ya.taper = (int)q->taper; ya.L = (int)(M + q->cp); ya.S = (int)S; ya.frames = (int)frames;
     ya.taperwin = q->d_taper; ya.xsym = d_xsym; ya.taps = q->d_taps; ya.v = d_v; ya.out = (float2 *)d_iq;
@@ -413,6 +454,11 @@ extern "C" int mctx_hip_generate(mctx_hip_t q, void *d_iq, size_t nblocks, unsig
 static int tx_launch_sym(mctx_hip_t q, const TxSymArgs &sa, unsigned nsym, unsigned nch, hipStream_t st)
 {
     const dim3 gsym(nsym, nch);
+    if (q->M & (q->M - 1)) {
+        hipLaunchKernelGGL(txsym_dft_kernel, gsym, dim3(TXW), 0, st, sa);
+        TXCHK(hipGetLastError());
+        return MCRX_OK;
+    }
     switch (std::max(1u, q->M / 64)) {
     case 1:  hipLaunchKernelGGL((txsym_kernel<1>),  gsym, dim3(TXW), 0, st, sa); break;
     case 2:  hipLaunchKernelGGL((txsym_kernel<2>),  gsym, dim3(TXW), 0, st, sa); break;
@@ -573,4 +619,56 @@ extern "C" int mctx_hip_stream_generate(mctx_hip_t q, float *out)
     memcpy(out, q->h_sout + (size_t)q->out_pos * q->K, (size_t)q->K * sizeof(float2));
     q->out_pos++; q->blocks_out++;
     return MCRX_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// One frame of one frame generator, at the channel rate: what ofdmflexframegen_assemble followed by
+// ofdmflexframegen_writesymbol until it reports the last symbol produces (lib/ofdmtxrx.cc:297-342,
+// 385-388): S0a, S0b, S1, header symbols, payload symbols and the tail symbol, M + cp samples each.
+extern "C" size_t mctx_hip_frame_len(mctx_hip_t q, unsigned payload_len, int mod, int fec0, int fec1)
+{
+    if (!q || !mod_bps(mod)) return 0;
+    unsigned Sh, Sp, S; frame_geometry(q, payload_len, mod, fec0, fec1, Sh, Sp, S);
+    return (size_t)S * (q->M + q->cp);
+}
+
+extern "C" int mctx_hip_frame(mctx_hip_t q, const uint8_t *header8, const uint8_t *payload, unsigned payload_len,
+                              int mod, int fec0, int fec1, float gain, float *out, size_t out_cap)
+{
+    if (!q || !header8 || (!payload && payload_len) || !out) { g_tx_err = "bad argument"; return MCRX_EINVAL; }
+    if (!mod_bps(mod)) { g_tx_err = "unsupported modulation scheme"; return MCRX_EUNSUPP; }
+    const unsigned M = q->M, Md = q->od.M_data, L = M + q->cp;
+    unsigned Sh, Sp, S; frame_geometry(q, payload_len, mod, fec0, fec1, Sh, Sp, S);
+    const size_t ns = (size_t)S * L;
+    if (out_cap < ns) { g_tx_err = "output buffer shorter than mctx_hip_frame_len()"; return MCRX_EINVAL; }
+    FrameSymbols fsym;
+    std::vector<uint8_t> pl(payload, payload + payload_len);
+    assemble_frame(header8, pl, mod, fec0, fec1, Md, Sh, Sp, fsym);
+    uint8_t *d_hdr = nullptr, *d_pay = nullptr; float2 *d_x = nullptr, *d_out = nullptr;
+    auto done = [&](int rc) { (void)hipFree(d_hdr); (void)hipFree(d_pay); (void)hipFree(d_x); (void)hipFree(d_out); return rc; };
+#define TXF(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_tx_err = std::string(#x) + ": " + hipGetErrorString(e_); return done(MCRX_EHIP); } } while (0)
+    TXF(hipMalloc((void **)&d_hdr, fsym.hdr.size())); TXF(hipMalloc((void **)&d_pay, std::max<size_t>(fsym.pay.size(), 1)));
+    TXF(hipMalloc((void **)&d_x, (size_t)S * M * sizeof(float2))); TXF(hipMalloc((void **)&d_out, ns * sizeof(float2)));
+    TXF(hipMemcpy(d_hdr, fsym.hdr.data(), fsym.hdr.size(), hipMemcpyHostToDevice));
+    if (!fsym.pay.empty()) TXF(hipMemcpy(d_pay, fsym.pay.data(), fsym.pay.size(), hipMemcpyHostToDevice));
+    TxSymArgs sa;
+    sa.M = (int)M; sa.log2M = 0; while ((1u << sa.log2M) < M) sa.log2M++;
+    sa.cp = (int)q->cp; sa.taper = (int)q->taper; sa.L = (int)L; sa.M_pilot = (int)q->od.M_pilot; sa.M_data = (int)Md;
+    sa.S = (int)S; sa.S_hdr = (int)Sh; sa.S_pay = (int)Sp; sa.frames = 1; sa.bps = (int)mod_bps(mod); sa.mod = mod;
+    sa.g_data = 1.0f / sqrtf((float)(q->od.M_pilot + q->od.M_data));
+    sa.sctype = q->d_sctype; sa.data_rank = q->d_drank; sa.pilot_rank = q->d_prank; sa.pilot_seq = q->d_pseq;
+    sa.s0t = q->d_s0t; sa.s1t = q->d_s1t; sa.hdr = d_hdr; sa.pay = d_pay; sa.xsym = d_x; sa.nch = 1;
+    int rc = tx_launch_sym(q, sa, S, 1, nullptr);
+    if (rc) return done(rc);
+    TxSynthArgs ya;
+    ya.M = (int)M; ya.cp = (int)q->cp; ya.taper = (int)q->taper; ya.L = (int)L; ya.S = (int)S; ya.frames = 1;
+    ya.taperwin = q->d_taper; ya.xsym = d_x; ya.taps = q->d_taps; ya.v = nullptr; ya.out = d_out;
+    ya.nblocks = (uint32_t)ns; ya.N = 1; ya.dtheta = 0; ya.first_sample_lo = 0; ya.gain = gain;
+    ya.ft0 = nullptr; ya.fS = nullptr; ya.xstride = 0; ya.b_first = 0; ya.hist = 0;
+    hipLaunchKernelGGL(txframe_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, nullptr, ya, (uint32_t)ns);
+    TXF(hipGetLastError());
+    TXF(hipMemcpy(out, d_out, ns * sizeof(float2), hipMemcpyDeviceToHost));
+#undef TXF
+    return done(MCRX_OK);
 }

@@ -61,3 +61,37 @@ def test_unchanged_reference_tx_app_feeds_both_receivers(oracle, product, tmp_pa
         assert len(per_ch[c]) >= 5 and per_ch[c] == list(range(1, len(per_ch[c]) + 1)), per_ch      # pid counts up from 1
     assert all(fr.payload_valid and fr.header[2] == fr.channel and len(fr.payload) == P for fr in rx.frames)
     rx.close()
+
+
+OTX = os.path.join(ROOT, "liquid-usrp_amd", "lib", "ofdmflexframe_tx_ref")
+ORX = os.path.join(ROOT, "liquid-usrp_amd", "lib", "ofdmflexframe_rx_ref")
+
+
+@pytest.mark.skipif(not (os.path.exists(OTX) and os.path.exists(ORX)), reason="reference app binaries not built")
+def test_unchanged_ofdmflexframe_tx_and_rx_apps_loop_back(oracle, product, tmp_path):
+    """BASELINE configs[0] as the reference runs it: src/ofdmflexframe_tx.cc -> (file instead of a radio) ->
+    src/ofdmflexframe_rx.cc, both unchanged, on the GPU ofdmtxrx class, at the applications' default
+    numerology (M=48, cp=6, taper=4, QPSK, crc32 + Golay(24,12)).  The capture is also decoded by the oracle."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "liquid-usrp_amd", "host"), "-s"])
+    f = tmp_path / "tx.bin"
+    nframes, P = 12, 300
+    env = dict(os.environ, MCTX_IQ_FILE=str(f), MCTX_IQ_SAMPLES=str(1 << 30))
+    out = subprocess.run([OTX, "-N", str(nframes), "-P", str(P)], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert len(re.findall(r"tx packet id:", out.stdout)) == nframes
+    iq = np.fromfile(f, np.complex64)
+    ora = oracle.FlexFrameSync(48, 6, 4)
+    ora.execute(np.concatenate([iq, np.zeros(200, np.complex64)]))
+    assert [((fr.header[0] << 8) | fr.header[1], fr.payload_valid, len(fr.payload)) for fr in ora.frames] == \
+        [(i, 1, P) for i in range(nframes)]
+    assert all((fr.mod_scheme, fr.fec0, fr.fec1) == (40, 1, 7) for fr in ora.frames)
+    # the receiver application replays the capture in a loop for one second
+    np.concatenate([iq, np.zeros(4096, np.complex64)]).tofile(f)
+    env = dict(os.environ, MCRX_IQ_FILE=str(f), MCRX_IQ_PACKET="4096")
+    out = subprocess.run([ORX, "-t", "1.0"], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    ids = [int(x) for x in re.findall(r"rx packet id:\s+(\d+)\n", out.stdout)]
+    assert len(ids) >= nframes and set(ids) == set(range(nframes)), out.stdout[-3000:]
+    assert "INVALID" not in out.stdout
+    m = re.search(r"frames detected\s+:\s+(\d+)\n\s+valid headers\s+:\s+(\d+).*\n\s+valid packets\s+:\s+(\d+)", out.stdout)
+    assert m and m.group(1) == m.group(2) == m.group(3) and int(m.group(1)) == len(ids)

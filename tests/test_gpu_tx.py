@@ -29,6 +29,7 @@ def oracle_waveform(oracle, N, M, cp, taper, sent, mod, fec0, fec1, gain, nblock
     (4, 256, 32, 27, 7, 200, 2),
     (2, 128, 16, 29, 1, 77, 1),
     (2, 64, 8, 39, 7, 0, 2),
+    (2, 48, 6, 40, 6, 100, 2),                  # src/multichannel_tx.cc defaults (M = 48: direct inverse DFT)
 ])
 def test_gpu_tx_waveform_matches_oracle(oracle, product, N, M, cp, mod, fec1, plen, nf):
     import torch
