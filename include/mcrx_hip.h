@@ -48,7 +48,8 @@ typedef struct mcrx_hip_s *mcrx_hip_t;
 typedef struct {
     uint32_t struct_size;        /* sizeof(mcrx_hip_config) */
     uint32_t max_payload_len;    /* largest decodable payload [bytes]; 0 -> 2048 */
-    uint32_t max_frames;         /* frame records kept between flushes; 0 -> auto */
+    uint32_t max_frames;         /* frame records kept between flushes; 0 -> auto (covers one host batch of
+                                    the shortest possible frames on every channel) */
     uint32_t payload_soft;       /* 1 = soft-decision payload decoding (default), 0 = hard */
     uint32_t slab_blocks;        /* channelizer blocks per workgroup slab; 0 -> auto */
     uint32_t channel_first;      /* synchronizer shard: first channel ...          */
@@ -82,7 +83,8 @@ int  mcrx_hip_destroy(mcrx_hip_t q);
 int  mcrx_hip_reset(mcrx_hip_t q);
 unsigned mcrx_hip_num_channels(mcrx_hip_t q);
 
-/* push wideband cf32 samples (interleaved re,im).  Any n; partial blocks are buffered. */
+/* push wideband cf32 samples (interleaved re,im).  Any n; partial blocks are buffered.  MCRX_EOVERFLOW: the
+ * samples were all processed but the frame pool filled up and frames were dropped (mcrx_hip_frames_dropped). */
 int  mcrx_hip_execute_host(mcrx_hip_t q, const float *iq, size_t nsamples);
 /* same with the samples already in device memory; `stream` is a hipStream_t (NULL = default).
  * nsamples must be a multiple of 2*num_channels. */

@@ -5,6 +5,9 @@
 // src/multichannel_tx.cc (:102-121,154-158,202-207,213-218) appends what send() is given to the raw
 // cf32 file named by $MCTX_IQ_FILE and ends the process (exit status 0) once $MCTX_IQ_SAMPLES
 // (default 2^20) samples have gone out -- the reference's transmit loop has no exit of its own.
+// With $MCTX_LOOPBACK=1 send() feeds an in-process FIFO instead and recv() drains it (idle: 1 ms nap, then a
+// short packet of zeros), so a transceiver object hears its own transmissions -- the stand-in for the second
+// radio of src/multichannel_txrx.cc ($MCTX_TEE_FILE additionally records what recv() handed out).
 // Own code, header only.
 #ifndef LIQUID_USRP_AMD_UHD_SHIM_HPP
 #define LIQUID_USRP_AMD_UHD_SHIM_HPP
@@ -14,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 #include <unistd.h>
@@ -42,6 +46,35 @@ struct tx_metadata_t {
 
 struct io_type_t { enum tid_t { COMPLEX_FLOAT32 = 'f' }; };
 
+// process-wide loopback FIFO ($MCTX_LOOPBACK=1)
+struct loop_fifo {
+    std::mutex mu; std::vector<std::complex<float> > q; size_t rd; FILE *tee; bool tee_checked;
+    loop_fifo() : rd(0), tee(NULL), tee_checked(false) {}
+    void push(const std::complex<float> *x, size_t n)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (q.size() - rd > ((size_t)1 << 27)) return;          // nobody is listening: drop
+        if (rd > ((size_t)1 << 22)) { q.erase(q.begin(), q.begin() + rd); rd = 0; }
+        q.insert(q.end(), x, x + n);
+    }
+    size_t pop(std::complex<float> *x, size_t n)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        size_t have = q.size() - rd; if (n > have) n = have;
+        if (n) memcpy((void *)x, &q[0] + rd, n * sizeof(*x));
+        rd += n;
+        return n;
+    }
+    void record(const std::complex<float> *x, size_t n)         // optional capture of what the receiver was handed
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!tee_checked) { tee_checked = true; if (const char *f = getenv("MCTX_TEE_FILE")) tee = fopen(f, "wb"); }
+        if (tee) { fwrite(x, sizeof(*x), n, tee); fflush(tee); }
+    }
+};
+inline loop_fifo &loopback() { static loop_fifo f; return f; }
+inline bool loopback_enabled() { const char *e = getenv("MCTX_LOOPBACK"); return e && *e && *e != '0'; }
+
 class device {
 public:
     enum recv_mode_t { RECV_MODE_FULL_BUFF = 0, RECV_MODE_ONE_PACKET = 1 };
@@ -67,12 +100,23 @@ public:
         std::complex<float> *out = static_cast<std::complex<float> *>(buff);
         if (n > packet) n = packet;
         md.error_code = rx_metadata_t::ERROR_CODE_NONE;
+        if (loopback_enabled()) {
+            size_t got = loopback().pop(out, n);
+            if (!got) {                                         // idle air: a short packet of silence per millisecond
+                usleep(1000);
+                got = n < 64 ? n : 64;
+                memset((void *)out, 0, got * sizeof(*out));
+            }
+            loopback().record(out, got);
+            return got;
+        }
         if (iq.empty()) { memset((void *)out, 0, n * sizeof(*out)); return n; }
         for (size_t i = 0; i < n; i++) { out[i] = iq[pos]; if (++pos == iq.size()) pos = 0; }
         return n;
     }
     size_t send(const void *buff, size_t n, const tx_metadata_t &, io_type_t::tid_t, send_mode_t)
     {
+        if (loopback_enabled()) { loopback().push(static_cast<const std::complex<float> *>(buff), n); return n; }
         if (!txfp) { const char *f = getenv("MCTX_IQ_FILE"); txfp = fopen(f ? f : "/dev/null", "wb"); }
         if (n > txlimit - txsent) n = txlimit - txsent;
         if (txfp && n) fwrite(buff, sizeof(std::complex<float>), n, txfp);

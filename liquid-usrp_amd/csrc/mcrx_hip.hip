@@ -251,6 +251,14 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     q->nch = q->cfg.channel_count ? q->cfg.channel_count : N - q->ch_first;
     if (q->ch_first + q->nch > N || q->nch == 0) { delete q; return fail(MCRX_EINVAL, "channel shard outside [0, N)"); }
     q->max_rec = q->cfg.max_frames ? q->cfg.max_frames : 16 * q->nch + 64;
+    if (!q->cfg.max_frames) {
+        // ... and never fewer than one host batch (Execute() harvests per batch) can hold: the shortest frame is
+        // S0a, S0b, S1, the header symbols, one payload symbol and the tail
+        const uint64_t batch = q->cfg.batch_samples ? q->cfg.batch_samples : ((uint64_t)1 << 20);
+        const uint64_t min_frame = (uint64_t)(3 + (288 + q->od.M_data - 1) / q->od.M_data + 2) * (M + cp);
+        const uint64_t per_ch = (batch / q->K + 8) / min_frame + 2;
+        q->max_rec = (uint32_t)std::max<uint64_t>(q->max_rec, std::min<uint64_t>(per_ch * q->nch, 1u << 22));
+    }
     // frame arena: payload + equalised symbols; reserve for BPSK behind one rate-1/2 code
     // (longer frames still fit while the total stays below the cap; overflow is counted)
     q->arena_cap = (uint64_t)q->max_rec * ((((uint64_t)q->max_payload + 15) & ~15ull) + 8ull * 8ull * (2ull * (q->max_payload + 4) + 8));
@@ -508,6 +516,7 @@ extern "C" int mcrx_hip_execute_host(mcrx_hip_t q, const float *iq, size_t nsamp
 {
     if (!q || (!iq && nsamples)) return fail(MCRX_EINVAL, "null argument");
     const float2 *src = reinterpret_cast<const float2 *>(iq);
+    bool overflow = false;
     while (nsamples) {
         const size_t take = std::min(nsamples, q->stage_cap - q->stage_fill);
         memcpy(q->h_stage + q->stage_fill, src, take * sizeof(float2));
@@ -516,9 +525,10 @@ extern "C" int mcrx_hip_execute_host(mcrx_hip_t q, const float *iq, size_t nsamp
             RC(process_staged(q));
             int rc = harvest(q);                // frames become deliverable as soon as a batch is done
             if (rc != MCRX_OK && rc != MCRX_EOVERFLOW) return rc;
+            overflow |= rc == MCRX_EOVERFLOW;
         }
     }
-    return MCRX_OK;
+    return overflow ? fail(MCRX_EOVERFLOW, "frame pool exhausted: frames were dropped (raise max_frames)") : MCRX_OK;
 }
 
 extern "C" int mcrx_hip_execute_device(mcrx_hip_t q, const void *d_iq, size_t nsamples, void *stream)

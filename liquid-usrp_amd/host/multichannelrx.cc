@@ -75,6 +75,9 @@ void multichannelrx::Execute(std::complex<float> *_x, unsigned int _num_samples)
 {
     int rc = mcrx_hip_execute_host(pimpl->h, reinterpret_cast<const float *>(_x), _num_samples);
     if (rc != MCRX_OK && rc != MCRX_EOVERFLOW) { fprintf(stderr, "error: multichannelrx::Execute(), %s\n", mcrx_hip_last_error()); throw 0; }
+    if (rc == MCRX_EOVERFLOW)
+        fprintf(stderr, "warning: multichannelrx::Execute(), frame pool exhausted, %llu frames dropped so far\n",
+                (unsigned long long)mcrx_hip_frames_dropped(pimpl->h));
     if (mcrx_hip_frames_pending(pimpl->h)) Deliver();
 }
 

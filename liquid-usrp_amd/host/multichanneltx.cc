@@ -2,11 +2,15 @@
 // mctx_hip_stream_*).  Mirrors liquid-usrp's lib/multichanneltx.cc: ctor :41-100, dtor :103-122,
 // Reset :126-149, IsChannelReadyForData :151-162, UpdateData :165-189, GenerateSamples :192-227.
 #include <cstdio>
+#include <mutex>
 
 #include "multichanneltx.h"
 #include "mcrx_hip.h"
 
-struct multichanneltx::impl { mctx_hip_t h; };
+// one lock around every call: multichanneltxrx polls / updates from the application thread while its
+// transmit worker pulls samples (lib/multichanneltxrx.cc:217-299,451-470)
+struct multichanneltx::impl { mctx_hip_t h; std::mutex mu; };
+#define TX_LOCK std::lock_guard<std::mutex> lk_(pimpl->mu)
 
 static void tx_fail(const char *what)
 {
@@ -36,6 +40,7 @@ multichanneltx::~multichanneltx()
 
 void multichanneltx::Reset()
 {
+    TX_LOCK;
     if (mctx_hip_stream_reset(pimpl->h) != MCRX_OK) tx_fail("multichanneltx::Reset");
 }
 
@@ -45,6 +50,7 @@ int multichanneltx::IsChannelReadyForData(unsigned int _channel)
         fprintf(stderr, "error: multichanneltx:IsChannelReadyForData(%u), invalid channel id\n", _channel);
         throw 0;
     }
+    TX_LOCK;
     return mctx_hip_stream_ready(pimpl->h, _channel);
 }
 
@@ -55,6 +61,7 @@ void multichanneltx::UpdateData(unsigned int _channel, unsigned char *_header, u
         fprintf(stderr, "error: multichanneltx:UpdateData(%u), invalid channel id\n", _channel);
         throw 0;
     }
+    TX_LOCK;
     int rc = mctx_hip_stream_update(pimpl->h, _channel, _header, _payload, _payload_len, _mod, _fec0, _fec1);
     if (rc == MCRX_EBUSY) {
         fprintf(stderr, "warning: multichanneltx:UpdateData(%u), channel not ready yet\n", _channel);
@@ -65,6 +72,7 @@ void multichanneltx::UpdateData(unsigned int _channel, unsigned char *_header, u
 
 void multichanneltx::GenerateSamples(std::complex<float> *_buffer)
 {
+    TX_LOCK;
     if (mctx_hip_stream_generate(pimpl->h, reinterpret_cast<float *>(_buffer)) != MCRX_OK)
         tx_fail("multichanneltx::GenerateSamples");
 }

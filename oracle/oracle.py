@@ -211,9 +211,12 @@ class Modem:
         return s, soft[:self.bps].copy()
 
     def __del__(self):
-        if getattr(self, "q", None):
-            lib().ll_modem_destroy(self.q)
-            self.q = None
+        try:
+            if getattr(self, "q", None):
+                lib().ll_modem_destroy(self.q)
+                self.q = None
+        except Exception:          # interpreter shutdown
+            pass
 
 
 class MsResamp:
@@ -233,9 +236,12 @@ class MsResamp:
         return y[:ny.value].copy()
 
     def __del__(self):
-        if getattr(self, "q", None):
-            lib().ll_msresamp_destroy(self.q)
-            self.q = None
+        try:
+            if getattr(self, "q", None):
+                lib().ll_msresamp_destroy(self.q)
+                self.q = None
+        except Exception:          # interpreter shutdown
+            pass
 
 
 class Channelizer:
@@ -264,9 +270,12 @@ class Channelizer:
         return y
 
     def __del__(self):
-        if getattr(self, "q", None):
-            lib().ll_firpfbch_destroy(self.q)
-            self.q = None
+        try:
+            if getattr(self, "q", None):
+                lib().ll_firpfbch_destroy(self.q)
+                self.q = None
+        except Exception:          # interpreter shutdown
+            pass
 
 
 class Packetizer:
@@ -295,9 +304,12 @@ class Packetizer:
         return bool(ok), out[:self.n]
 
     def __del__(self):
-        if getattr(self, "q", None):
-            lib().ll_packetizer_destroy(self.q)
-            self.q = None
+        try:
+            if getattr(self, "q", None):
+                lib().ll_packetizer_destroy(self.q)
+                self.q = None
+        except Exception:          # interpreter shutdown
+            pass
 
 
 class Frame:
@@ -357,9 +369,12 @@ class FlexFrameGen:
         return out
 
     def __del__(self):
-        if getattr(self, "q", None):
-            lib().ll_ofdmflexframegen_destroy(self.q)
-            self.q = None
+        try:
+            if getattr(self, "q", None):
+                lib().ll_ofdmflexframegen_destroy(self.q)
+                self.q = None
+        except Exception:          # interpreter shutdown
+            pass
 
 
 class FlexFrameSync:
@@ -379,9 +394,12 @@ class FlexFrameSync:
         lib().ll_ofdmflexframesync_reset(self.q)
 
     def __del__(self):
-        if getattr(self, "q", None):
-            lib().ll_ofdmflexframesync_destroy(self.q)
-            self.q = None
+        try:
+            if getattr(self, "q", None):
+                lib().ll_ofdmflexframesync_destroy(self.q)
+                self.q = None
+        except Exception:          # interpreter shutdown
+            pass
 
 
 class MultiChannelRx:
@@ -415,9 +433,12 @@ class MultiChannelRx:
         lib().ll_mcrx_reset(self.q)
 
     def __del__(self):
-        if getattr(self, "q", None):
-            lib().ll_mcrx_destroy(self.q)
-            self.q = None
+        try:
+            if getattr(self, "q", None):
+                lib().ll_mcrx_destroy(self.q)
+                self.q = None
+        except Exception:          # interpreter shutdown
+            pass
 
 
 class MultiChannelTx:
@@ -447,9 +468,12 @@ class MultiChannelTx:
         return out.reshape(-1)
 
     def __del__(self):
-        if getattr(self, "q", None):
-            lib().ll_mctx_destroy(self.q)
-            self.q = None
+        try:
+            if getattr(self, "q", None):
+                lib().ll_mctx_destroy(self.q)
+                self.q = None
+        except Exception:          # interpreter shutdown
+            pass
 
 
 def synth_traffic(N, M, cp, taper, nframes, payload_len=1200, seed=0xC0FFEE, mod=MODEM_QPSK,

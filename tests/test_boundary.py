@@ -62,7 +62,10 @@ def test_host_class_library_builds(product):
                 "multichanneltx::Reset()", "liquid_getopt_str2mod", "liquid_getopt_str2fec",
                 "ofdmtxrx::transmit_packet(unsigned char*, unsigned char*, unsigned int, int, int, int)",
                 "ofdmtxrx::assemble_frame(", "ofdmtxrx::write_symbol()", "ofdmtxrx::transmit_symbol()", "ofdmtxrx::end_transmit_frame()",
-                "ofdmtxrx::start_rx()", "ofdmtxrx::stop_rx()", "ofdmtxrx::reset_rx()", "ofdmtxrx::set_tx_gain_soft(float)"]:
+                "ofdmtxrx::start_rx()", "ofdmtxrx::stop_rx()", "ofdmtxrx::reset_rx()", "ofdmtxrx::set_tx_gain_soft(float)",
+                "multichanneltxrx::transmit_packet(unsigned int, unsigned char*, unsigned char*, unsigned int, int, int, int)",
+                "multichanneltxrx::get_available_channel()", "multichanneltxrx::wait_for_tx_to_complete()",
+                "multichanneltxrx::start_tx()", "multichanneltxrx::stop_tx()", "multichanneltxrx::start_rx()", "multichanneltxrx::stop_rx()"]:
         assert sym in out, sym
 
 
@@ -70,10 +73,10 @@ def test_host_class_library_builds(product):
 def test_reference_app_compiles_and_links_unchanged(product):
     product.build()
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "liquid-usrp_amd", "host"), "-s", "refapp"])
-    for exe in ["multichannel_rx_ref", "multichannel_tx_ref", "ofdmflexframe_tx_ref", "ofdmflexframe_rx_ref"]:
+    for exe in ["multichannel_rx_ref", "multichannel_tx_ref", "ofdmflexframe_tx_ref", "ofdmflexframe_rx_ref", "multichannel_txrx_ref"]:
         assert os.path.exists(os.path.join(LIB, exe))
     # the binaries were produced from the files under /root/reference, not from copies in the repo
     for dirpath, _, files in os.walk(ROOT):
         if ".git" in dirpath:
             continue
-        assert not {"multichannel_rx.cc", "multichannel_tx.cc", "ofdmflexframe_tx.cc", "ofdmflexframe_rx.cc"} & set(files), dirpath
+        assert not {"multichannel_rx.cc", "multichannel_tx.cc", "ofdmflexframe_tx.cc", "ofdmflexframe_rx.cc", "multichannel_txrx.cc"} & set(files), dirpath
