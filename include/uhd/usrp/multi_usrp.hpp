@@ -48,11 +48,14 @@ struct io_type_t { enum tid_t { COMPLEX_FLOAT32 = 'f' }; };
 
 // process-wide loopback FIFO ($MCTX_LOOPBACK=1)
 struct loop_fifo {
-    std::mutex mu; std::vector<std::complex<float> > q; size_t rd; FILE *tee; bool tee_checked;
-    loop_fifo() : rd(0), tee(NULL), tee_checked(false) {}
+    std::mutex mu; std::vector<std::complex<float> > q; size_t rd; FILE *tee; bool tee_checked, in_burst;
+    loop_fifo() : rd(0), tee(NULL), tee_checked(false), in_burst(false) {}
+    void end_burst() { std::lock_guard<std::mutex> lk(mu); in_burst = false; }
+    bool bursting() { std::lock_guard<std::mutex> lk(mu); return in_burst; }
     void push(const std::complex<float> *x, size_t n)
     {
         std::lock_guard<std::mutex> lk(mu);
+        if (n) in_burst = true;                                 // until a packet flagged end_of_burst
         if (q.size() - rd > ((size_t)1 << 27)) return;          // nobody is listening: drop
         if (rd > ((size_t)1 << 22)) { q.erase(q.begin(), q.begin() + rd); rd = 0; }
         q.insert(q.end(), x, x + n);
@@ -102,6 +105,8 @@ public:
         md.error_code = rx_metadata_t::ERROR_CODE_NONE;
         if (loopback_enabled()) {
             size_t got = loopback().pop(out, n);
+            // mid-burst the transmitter is merely a little behind: the air is continuous, wait for it (at most 0.1 s)
+            for (int tries = 0; !got && tries < 500 && loopback().bursting(); tries++) { usleep(200); got = loopback().pop(out, n); }
             if (!got) {                                         // idle air: a short packet of silence per millisecond
                 usleep(1000);
                 got = n < 64 ? n : 64;
@@ -114,9 +119,13 @@ public:
         for (size_t i = 0; i < n; i++) { out[i] = iq[pos]; if (++pos == iq.size()) pos = 0; }
         return n;
     }
-    size_t send(const void *buff, size_t n, const tx_metadata_t &, io_type_t::tid_t, send_mode_t)
+    size_t send(const void *buff, size_t n, const tx_metadata_t &md, io_type_t::tid_t, send_mode_t)
     {
-        if (loopback_enabled()) { loopback().push(static_cast<const std::complex<float> *>(buff), n); return n; }
+        if (loopback_enabled()) {
+            loopback().push(static_cast<const std::complex<float> *>(buff), n);
+            if (md.end_of_burst) loopback().end_burst();
+            return n;
+        }
         if (!txfp) { const char *f = getenv("MCTX_IQ_FILE"); txfp = fopen(f ? f : "/dev/null", "wb"); }
         if (n > txlimit - txsent) n = txlimit - txsent;
         if (txfp && n) fwrite(buff, sizeof(std::complex<float>), n, txfp);

@@ -73,10 +73,11 @@ def test_host_class_library_builds(product):
 def test_reference_app_compiles_and_links_unchanged(product):
     product.build()
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "liquid-usrp_amd", "host"), "-s", "refapp"])
-    for exe in ["multichannel_rx_ref", "multichannel_tx_ref", "ofdmflexframe_tx_ref", "ofdmflexframe_rx_ref", "multichannel_txrx_ref"]:
+    for exe in ["multichannel_rx_ref", "multichannel_tx_ref", "ofdmflexframe_tx_ref", "ofdmflexframe_rx_ref", "multichannel_txrx_ref", "halfduplex_txrx_ref",
+                "fullduplex_txrx_ref"]:
         assert os.path.exists(os.path.join(LIB, exe))
     # the binaries were produced from the files under /root/reference, not from copies in the repo
     for dirpath, _, files in os.walk(ROOT):
         if ".git" in dirpath:
             continue
-        assert not {"multichannel_rx.cc", "multichannel_tx.cc", "ofdmflexframe_tx.cc", "ofdmflexframe_rx.cc", "multichannel_txrx.cc"} & set(files), dirpath
+        assert not {"multichannel_rx.cc", "multichannel_tx.cc", "ofdmflexframe_tx.cc", "ofdmflexframe_rx.cc", "multichannel_txrx.cc", "halfduplex_txrx.cc", "fullduplex_txrx.cc"} & set(files), dirpath

@@ -131,3 +131,21 @@ def test_unchanged_multichannel_txrx_app_hears_its_own_bursts(oracle, tmp_path):
     assert sorted(got) == sorted(want)                                  # live callbacks == oracle on the recording
     assert nfail == sum(1 for f in orx.frames if not f.header_valid)
     assert len(got) >= 0.98 * len(sent) and set(got) <= set(sent)
+
+
+FDX = os.path.join(ROOT, "liquid-usrp_amd", "lib", "fullduplex_txrx_ref")
+
+
+@pytest.mark.skipif(not os.path.exists(FDX), reason="reference app binary not built")
+def test_unchanged_fullduplex_app_receives_while_transmitting():
+    """src/fullduplex_txrx.cc (unchanged): the receiver of one ofdmtxrx object runs while its transmitter sends
+    200 frames; with the stand-in looped back every frame must come out of the callback, valid and in order."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "liquid-usrp_amd", "host"), "-s"])
+    env = dict(os.environ, MCTX_LOOPBACK="1")
+    out = subprocess.run([FDX, "-N", "200", "-P", "500", "-m", "qam16", "-c", "h128", "-k", "none"], env=env,
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert len(re.findall(r"tx packet id:", out.stdout)) == 200
+    ids = [int(x) for x in re.findall(r"rx packet id:\s+(\d+)\n", out.stdout)]
+    assert ids == list(range(200)), (len(ids), out.stdout[-1500:])
+    assert "INVALID" not in out.stdout
