@@ -7,6 +7,7 @@
 #include "txcode.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -72,6 +73,25 @@ __global__ void hist_update_kernel(const float2 *old_hist, const float2 *x, uint
 }
 
 // ---------------------------------------------------------------- handle
+// harvested payloads / equalised symbols on the host: pinned and never value-initialised (hundreds of MB per
+// harvest at 512 channels), grown geometrically
+struct HostArena {
+    uint8_t *p = nullptr; size_t size = 0, cap = 0;
+    int grow_to(size_t n)
+    {
+        if (n <= cap) { size = n; return MCRX_OK; }
+        size_t ncap = std::max<size_t>(n, cap + cap / 2);
+        uint8_t *np = nullptr;
+        if (hipHostMalloc((void **)&np, ncap, hipHostMallocDefault) != hipSuccess) return MCRX_ENOMEM;
+        if (size) memcpy(np, p, size);
+        if (p) (void)hipHostFree(p);
+        p = np; cap = ncap; size = n;
+        return MCRX_OK;
+    }
+    void clear() { size = 0; }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; size = cap = 0; }
+};
+
 struct mcrx_hip_s {
     unsigned N = 0, K = 0, M = 0, cp = 0, taper = 0;
     bool bypass = false;                    // one synchronizer fed channel-rate samples, no channelizer (ofdmtxrx)
@@ -106,6 +126,12 @@ struct mcrx_hip_s {
     float2 *d_chan[2] = { nullptr, nullptr }; size_t chan_cap_tiles = 0; int chan_cur = 0;
     unsigned hist_tiles = 0;
     hipStream_t stream = nullptr;
+    // large host buffers skip the staging copy: chunks go from the caller's memory to one of two device buffers
+    float2 *d_direct[2] = { nullptr, nullptr }; size_t direct_cap = 0; int direct_idx = 0; bool direct_used[2] = { false, false };
+    hipStream_t copy_stream = nullptr; hipEvent_t ev_copy[2] = { nullptr, nullptr }, ev_done[2] = { nullptr, nullptr };
+    uint64_t min_frame = 1;                 // channel-rate samples of the shortest possible frame
+    uint64_t pending_bound = 0;             // upper bound of frame records produced since the last harvest
+    double t_copy = 0, t_harvest = 0, t_run = 0, t_wait = 0, t_d2h = 0, b_d2h = 0, t_grow = 0;   // MCRX_DEBUG=8: host seconds spent per phase of the bulk path
     // per-kernel HIP event rings (MCRX_NKERNELS of them, see mcrx_hip.h); pairs (start, stop)
     std::vector<hipEvent_t> evring[MCRX_NKERNELS];
     size_t ev_used[MCRX_NKERNELS] = {};
@@ -136,7 +162,7 @@ struct mcrx_hip_s {
         return MCRX_OK;
     }
     // harvested frames (host)
-    std::vector<FrameRec> recs; std::vector<uint8_t> arena_host; size_t next_frame = 0;
+    std::vector<FrameRec> recs; HostArena arena_host; size_t next_frame = 0;
     uint64_t dropped = 0;
 
     template <class T> int upload(const T **dst, const T *src, size_t n)
@@ -251,13 +277,20 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     q->nch = q->cfg.channel_count ? q->cfg.channel_count : N - q->ch_first;
     if (q->ch_first + q->nch > N || q->nch == 0) { delete q; return fail(MCRX_EINVAL, "channel shard outside [0, N)"); }
     q->max_rec = q->cfg.max_frames ? q->cfg.max_frames : 16 * q->nch + 64;
+    q->min_frame = (uint64_t)(3 + (288 + q->od.M_data - 1) / q->od.M_data + 2) * (M + cp);
     if (!q->cfg.max_frames) {
         // ... and never fewer than one host batch (Execute() harvests per batch) can hold: the shortest frame is
         // S0a, S0b, S1, the header symbols, one payload symbol and the tail
         const uint64_t batch = q->cfg.batch_samples ? q->cfg.batch_samples : ((uint64_t)1 << 20);
-        const uint64_t min_frame = (uint64_t)(3 + (288 + q->od.M_data - 1) / q->od.M_data + 2) * (M + cp);
+        const uint64_t min_frame = q->min_frame;
         const uint64_t per_ch = (batch / q->K + 8) / min_frame + 2;
         q->max_rec = (uint32_t)std::max<uint64_t>(q->max_rec, std::min<uint64_t>(per_ch * q->nch, 1u << 22));
+        // ... and enough for bulk Execute() calls to run in chunks of up to 16 Mi samples between harvests, within
+        // about 2 GB of per-record buffers (arena share, soft bits, scratch, equaliser)
+        const uint64_t per_rec = ((((uint64_t)q->max_payload + 15) & ~15ull) + 64ull * (2ull * (q->max_payload + 4) + 8)) +
+                                 10ull * q->max_enc + 32 + 8ull * M;
+        const uint64_t bulk = std::min<uint64_t>((((uint64_t)16 << 20) / q->K + 8) / min_frame + 3, ((uint64_t)2 << 30) / per_rec / q->nch);
+        q->max_rec = (uint32_t)std::max<uint64_t>(q->max_rec, bulk * q->nch);
     }
     // frame arena: payload + equalised symbols; reserve for BPSK behind one rate-1/2 code
     // (longer frames still fit while the total stays below the cap; overflow is counted)
@@ -331,9 +364,18 @@ extern "C" int mcrx_hip_destroy(mcrx_hip_t q)
 {
     if (!q) return MCRX_OK;
     (void)hipDeviceSynchronize();
+    if (getenv("MCRX_DEBUG") && (atoi(getenv("MCRX_DEBUG")) & 8))
+        fprintf(stderr, "mcrx bulk path: copy %.4f s, launch %.4f s, waiting for the GPU %.4f s, harvest (incl. that wait) %.4f s of which frame D2H %.4f s for %.1f MB, host arena growth %.4f s\n", q->t_copy, q->t_run, q->t_wait, q->t_harvest, q->t_d2h, q->b_d2h / 1e6, q->t_grow);
     for (void *p : q->owned) (void)hipFree(p);
     for (int i = 0; i < 2; i++) if (q->d_chan[i]) (void)hipFree(q->d_chan[i]);
     if (q->h_stage) (void)hipHostFree(q->h_stage);
+    q->arena_host.release();
+    for (int i = 0; i < 2; i++) {
+        if (q->d_direct[i]) (void)hipFree(q->d_direct[i]);
+        if (q->ev_copy[i]) (void)hipEventDestroy(q->ev_copy[i]);
+        if (q->ev_done[i]) (void)hipEventDestroy(q->ev_done[i]);
+    }
+    if (q->copy_stream) (void)hipStreamDestroy(q->copy_stream);
     if (q->h_hint) (void)hipHostFree(q->h_hint);
     for (int w = 0; w < MCRX_NKERNELS; w++) for (auto e : q->evring[w]) if (e) (void)hipEventDestroy(e);
     if (q->stream) (void)hipStreamDestroy(q->stream);
@@ -511,12 +553,82 @@ static int process_staged(mcrx_hip_t q)
 }
 
 static int harvest(mcrx_hip_t q);
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// frame records `blocks` channelizer blocks can produce at most (every channel sending shortest frames back to back)
+static uint64_t record_bound(mcrx_hip_t q, uint64_t blocks) { return ((blocks + 8) / q->min_frame + 2) * q->nch; }
+
+// Bulk Execute(buf, n): whole tiles go straight from the caller's (pageable) memory into one of two device
+// buffers on a copy stream while the previous chunk is still being processed; frames are harvested only when
+// the record pool could otherwise fill up.  What does not fill a tile is left for the staging path.
+static int execute_direct(mcrx_hip_t q, const float2 *&src, size_t &nsamples, bool &overflow)
+{
+    const size_t tile_samples = (size_t)8 * q->K;
+    if (q->stage_fill || nsamples < 64 * tile_samples) return MCRX_OK;
+    // largest chunk whose frames are sure to fit the record pool, at most 16 Mi samples
+    uint64_t blocks_cap = q->max_rec / q->nch > 3 ? (uint64_t)(q->max_rec / q->nch - 3) * q->min_frame : 0;
+    size_t chunk = (size_t)std::min<uint64_t>(blocks_cap * q->K, (uint64_t)16 << 20) / tile_samples * tile_samples;
+    if (chunk < 64 * tile_samples) return MCRX_OK;
+    if (!q->copy_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&q->copy_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) {
+            HIPCHK(hipEventCreateWithFlags(&q->ev_copy[i], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&q->ev_done[i], hipEventDisableTiming));
+        }
+    }
+    while (nsamples >= 64 * tile_samples) {
+        const size_t take = std::min(chunk, nsamples / tile_samples * tile_samples);
+        if (take > q->direct_cap) {
+            HIPCHK(hipDeviceSynchronize());
+            for (int i = 0; i < 2; i++) {
+                if (q->d_direct[i]) (void)hipFree(q->d_direct[i]);
+                q->d_direct[i] = nullptr; q->direct_used[i] = false;
+                HIPCHK(hipMalloc((void **)&q->d_direct[i], take * sizeof(float2)));
+            }
+            q->direct_cap = take;
+        }
+        const uint64_t bound = record_bound(q, take / q->K);
+        if (q->pending_bound && q->pending_bound + bound > q->max_rec) {
+            int rc = harvest(q);
+            if (rc != MCRX_OK && rc != MCRX_EOVERFLOW) return rc;
+            overflow |= rc == MCRX_EOVERFLOW;
+        }
+        const int b = q->direct_idx ^= 1;
+        double t0 = now_s();
+        if (q->direct_used[b]) HIPCHK(hipEventSynchronize(q->ev_done[b]));
+        q->t_wait += now_s() - t0; t0 = now_s();
+        HIPCHK(hipMemcpyAsync(q->d_direct[b], src, take * sizeof(float2), hipMemcpyHostToDevice, q->copy_stream));
+        HIPCHK(hipEventRecord(q->ev_copy[b], q->copy_stream));
+        HIPCHK(hipStreamWaitEvent(q->stream, q->ev_copy[b], 0));
+        q->t_copy += now_s() - t0; t0 = now_s();
+        RC(run_blocks(q, q->d_direct[b], take / q->K, q->total_samples, q->stream));
+        q->t_run += now_s() - t0; t0 = now_s();
+        HIPCHK(hipEventRecord(q->ev_done[b], q->stream));
+        q->direct_used[b] = true;
+        HIPCHK(hipStreamSynchronize(q->copy_stream));          // the caller's buffer has been read
+        q->t_copy += now_s() - t0;
+        q->pending_bound += bound;
+        q->total_samples += take; q->stage_first = q->total_samples;
+        src += take; nsamples -= take;
+    }
+    return MCRX_OK;
+}
 
 extern "C" int mcrx_hip_execute_host(mcrx_hip_t q, const float *iq, size_t nsamples)
 {
     if (!q || (!iq && nsamples)) return fail(MCRX_EINVAL, "null argument");
     const float2 *src = reinterpret_cast<const float2 *>(iq);
     bool overflow = false;
+    const size_t tile_samples = (size_t)8 * q->K;
+    if (q->stage_fill && nsamples >= 64 * tile_samples) {
+        // a partial tile is waiting: complete it from this buffer so that the bulk path can take over
+        const size_t need = std::min(nsamples, (tile_samples - q->stage_fill % tile_samples) % tile_samples);
+        memcpy(q->h_stage + q->stage_fill, src, need * sizeof(float2));
+        q->stage_fill += need; q->total_samples += need; src += need; nsamples -= need;
+        RC(process_staged(q));
+        q->pending_bound += record_bound(q, q->stage_cap / q->K);
+    }
+    RC(execute_direct(q, src, nsamples, overflow));
     while (nsamples) {
         const size_t take = std::min(nsamples, q->stage_cap - q->stage_fill);
         memcpy(q->h_stage + q->stage_fill, src, take * sizeof(float2));
@@ -543,9 +655,17 @@ extern "C" int mcrx_hip_execute_device(mcrx_hip_t q, const void *d_iq, size_t ns
 }
 
 // ---------------------------------------------------------------- frames
+static int harvest_impl(mcrx_hip_t q);
 static int harvest(mcrx_hip_t q)
 {
-    HIPCHK(hipDeviceSynchronize());
+    const double t0 = now_s();
+    int rc = harvest_impl(q);
+    q->t_harvest += now_s() - t0;
+    return rc;
+}
+static int harvest_impl(mcrx_hip_t q)
+{
+    { const double t0 = now_s(); HIPCHK(hipDeviceSynchronize()); q->t_wait += now_s() - t0; }
     uint32_t cnt[2] = { 0, 0 }; unsigned long long used = 0;
     HIPCHK(hipMemcpy(cnt, q->d_nrec, sizeof(cnt), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(&used, q->d_arena_used, sizeof(used), hipMemcpyDeviceToHost));
@@ -555,11 +675,15 @@ static int harvest(mcrx_hip_t q)
     if (n) {
         // drop frames already delivered, then append
         if (q->next_frame == q->recs.size()) { q->recs.clear(); q->arena_host.clear(); q->next_frame = 0; }
-        const size_t base = q->arena_host.size(), r0 = q->recs.size();
+        const size_t base = q->arena_host.size, r0 = q->recs.size();
         q->recs.resize(r0 + n);
         HIPCHK(hipMemcpy(q->recs.data() + r0, q->d_rec, (size_t)n * sizeof(FrameRec), hipMemcpyDeviceToHost));
-        q->arena_host.resize(base + (size_t)used);
-        if (used) HIPCHK(hipMemcpy(q->arena_host.data() + base, q->d_arena, (size_t)used, hipMemcpyDeviceToHost));
+        { const double t0 = now_s();
+          if (q->arena_host.grow_to(base + (size_t)used) != MCRX_OK) return fail(MCRX_ENOMEM, "host frame arena allocation failed");
+          q->t_grow += now_s() - t0; }
+        { const double t0 = now_s();
+          if (used) HIPCHK(hipMemcpy(q->arena_host.p + base, q->d_arena, (size_t)used, hipMemcpyDeviceToHost));
+          q->t_d2h += now_s() - t0; q->b_d2h += (double)used; }
         for (size_t i = r0; i < r0 + n; i++) { q->recs[i].payload_off += base; q->recs[i].syms_off += base; }
         // reference order: by end time, then channel index (lib/multichannelrx.cc:193-194)
         std::stable_sort(q->recs.begin() + r0, q->recs.end(), [](const FrameRec &a, const FrameRec &b) {
@@ -567,6 +691,7 @@ static int harvest(mcrx_hip_t q)
     }
     HIPCHK(hipMemset(q->d_nrec, 0, 2 * sizeof(uint32_t)));
     HIPCHK(hipMemset(q->d_arena_used, 0, sizeof(unsigned long long)));
+    q->pending_bound = 0;
     return cnt[1] ? MCRX_EOVERFLOW : MCRX_OK;
 }
 
@@ -588,8 +713,8 @@ extern "C" int mcrx_hip_next_frame(mcrx_hip_t q, mcrx_frame *out)
     out->evm = r.evm; out->rssi = r.rssi; out->cfo = r.cfo;
     out->mod_scheme = r.mod_scheme; out->mod_bps = r.mod_bps; out->check = r.check; out->fec0 = r.fec0; out->fec1 = r.fec1;
     out->num_framesyms = r.num_framesyms; out->end_sample = (uint64_t)r.end_sample;
-    out->payload = r.payload_len ? q->arena_host.data() + r.payload_off : nullptr;
-    out->framesyms = r.num_framesyms ? reinterpret_cast<const float *>(q->arena_host.data() + r.syms_off) : nullptr;
+    out->payload = r.payload_len ? q->arena_host.p + r.payload_off : nullptr;
+    out->framesyms = r.num_framesyms ? reinterpret_cast<const float *>(q->arena_host.p + r.syms_off) : nullptr;
     return 1;
 }
 

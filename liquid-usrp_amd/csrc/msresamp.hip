@@ -93,7 +93,7 @@ static int stage_reserve(msresamp_hip_t q, StageBuf &b, size_t extra, hipStream_
     RSCHK(hipMalloc((void **)&nd, ncap * sizeof(float2)));
     if (keep) RSCHK(hipMemcpyAsync(nd, b.d + (have - keep), keep * sizeof(float2), hipMemcpyDeviceToDevice, st));
     RSCHK(hipStreamSynchronize(st));
-    if (b.d) hipFree(b.d);
+    if (b.d) (void)hipFree(b.d);
     b.d = nd; b.cap = ncap; b.base = b.end - (long long)keep;
     (void)q;
     return MCRX_OK;
@@ -134,10 +134,10 @@ extern "C" int msresamp_hip_create(msresamp_hip_t *out, float rate, float As)
 extern "C" int msresamp_hip_destroy(msresamp_hip_t q)
 {
     if (!q) return MCRX_OK;
-    hipDeviceSynchronize();
-    for (auto &b : q->in) if (b.d) hipFree(b.d);
-    hipFree(q->d_h1); hipFree(q->d_hpfb);
-    if (q->stream) hipStreamDestroy(q->stream);
+    (void)hipDeviceSynchronize();
+    for (auto &b : q->in) if (b.d) (void)hipFree(b.d);
+    (void)hipFree(q->d_h1); (void)hipFree(q->d_hpfb);
+    if (q->stream) (void)hipStreamDestroy(q->stream);
     delete q;
     return MCRX_OK;
 }

@@ -440,7 +440,7 @@ extern "C" int mctx_hip_generate(mctx_hip_t q, void *d_iq, size_t nblocks, unsig
     hipLaunchKernelGGL(txfir_kernel, dim3((K + tb - 1) / tb, (unsigned)((nblocks + 7) / 8)), dim3(tb), 0, st, ya, K);
     TXCHK(hipGetLastError());
     TXCHK(hipStreamSynchronize(st));
-    hipFree(d_hdr); hipFree(d_pay); hipFree(d_xsym); hipFree(d_v);
+    (void)hipFree(d_hdr); (void)hipFree(d_pay); (void)hipFree(d_xsym); (void)hipFree(d_v);
     return MCRX_OK;
 }
 

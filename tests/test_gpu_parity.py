@@ -358,3 +358,33 @@ def test_speculation_survives_wrong_predictions(oracle, product):
         check_frames(rx.frames[seen:], ora.frames)      # (the Python mirror keeps every delivered frame)
         seen = len(rx.frames)
     rx.close(); tx.close()
+
+
+def test_bulk_host_execute_equals_device_path(product):
+    """Execute(host buffer) takes whole tiles straight from the caller's memory in large chunks and stages only
+    what does not fill a tile; however the buffer is cut, the frames must equal those of the device path."""
+    torch = _torch()
+    N, M, cp = 8, 64, 8
+    tx = product.multichanneltx(N, M, cp, 4)
+    iq, sent = tx.generate(12, 300, seed=21)
+    n = int(iq.numel()) // (16 * N) * (16 * N)
+    x = iq[:n].cpu().numpy()
+    ref = product.multichannelrx(N, M, cp, 4, max_payload_len=300)
+    ref.Execute(iq[:n]); ref.Flush()
+    assert len(ref.frames) == 12 * N
+    # (bytes and positions exactly; the floats to the parity tolerance: a frame that straddles two launches is
+    # walked by the serial path, whose arithmetic order differs from the per-frame workers')
+    key = lambda f: (f.channel, f.end_sample, f.header, f.payload, f.payload_valid)
+    want = sorted(map(key, ref.frames))
+    rng = np.random.RandomState(4)
+    for cuts in ([n], [16 * N * 64 * 3 + 5, 7, 16 * N * 200 + 1], None):
+        rx = product.multichannelrx(N, M, cp, 4, max_payload_len=300)
+        i = 0
+        while i < n:
+            step = int(rng.randint(1, 16 * N * 300)) if cuts is None else (cuts.pop(0) if cuts else n)
+            rx.Execute(x[i:i + step]); i += step
+        rx.Flush()
+        assert sorted(map(key, rx.frames)) == want
+        check_frames(rx.frames, ref.frames)
+        rx.close()
+    ref.close(); tx.close()
