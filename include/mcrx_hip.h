@@ -139,6 +139,21 @@ int    msresamp_hip_execute_device(msresamp_hip_t q, const void *d_in, size_t ni
                                    size_t out_cap, size_t *nout, void *stream);
 const char *msresamp_hip_last_error(void);
 
+/* ---- alternate front end: 2x-oversampled analysis bank --------------------------------
+ * Replaces firpfbch2_crcf_create_kaiser(LIQUID_ANALYZER, M, m, As) / _execute / _destroy (liquid-dsp; the
+ * channelizer BASELINE.json's north_star names -- liquid-usrp's own receiver uses the critically sampled bank,
+ * lib/multichannelrx.cc:89-91).  M channels (a power of two here), every step consumes M/2 samples and
+ * produces one sample on each of the M channels.  Stage-level operator on device buffers:
+ * d_x[0] is absolute sample first_step * M/2 of the stream and is preceded in memory by `lead_samples`
+ * valid samples of history (0 = cold start; 2*m*M covers the whole filter); d_out is [nsteps][M] cf32. */
+typedef struct mcrx_hip_pfb2_s *mcrx_hip_pfb2_t;
+int    mcrx_hip_pfb2_create(mcrx_hip_pfb2_t *out, unsigned num_channels, unsigned m, float As);
+int    mcrx_hip_pfb2_destroy(mcrx_hip_pfb2_t q);
+int    mcrx_hip_pfb2_get_taps(mcrx_hip_pfb2_t q, float *h, size_t n);        /* 2*m*M prototype taps */
+int    mcrx_hip_pfb2_analyze(mcrx_hip_pfb2_t q, const void *d_x, size_t lead_samples, size_t nsteps,
+                             uint64_t first_step, void *d_out, void *stream);
+const char *mcrx_hip_pfb2_last_error(void);
+
 /* ---- synthetic IQ source: multichanneltx on the GPU ------------------------------------
  * Replaces multichanneltx (lib/multichanneltx.cc:41-242: N x ofdmflexframegen -> 2N-channel
  * synthesis bank, m = 13 -> NCO mix-up) driven by the traffic loop of src/multichannel_tx.cc:

@@ -79,6 +79,11 @@ _EXPORTS = {
     "msresamp_hip_execute_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                               C.POINTER(C.c_size_t), C.c_void_p]),
     "msresamp_hip_last_error": (C.c_char_p, []),
+    "mcrx_hip_pfb2_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint, C.c_uint, C.c_float]),
+    "mcrx_hip_pfb2_destroy": (C.c_int, [C.c_void_p]),
+    "mcrx_hip_pfb2_get_taps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mcrx_hip_pfb2_analyze": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "mcrx_hip_pfb2_last_error": (C.c_char_p, []),
     "mctx_hip_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_void_p]),
     "mctx_hip_destroy": (C.c_int, [C.c_void_p]),
     "mctx_hip_blocks_for": (C.c_size_t, [C.c_void_p, C.c_uint, C.c_uint, C.c_int, C.c_int, C.c_int]),
@@ -445,6 +450,64 @@ class multichanneltx(object):
     def close(self):
         if self._h:
             lib().mctx_hip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class firpfbch2(object):
+    """2x-oversampled analysis bank on the GPU (liquid firpfbch2_crcf analyzer): M channels, M/2 samples per step.
+
+    analyze(x) takes a torch complex64 CUDA tensor holding a whole number of steps and returns [nsteps, M];
+    the filter state carries over between calls (the last 2*m*M samples are kept in HBM)."""
+
+    def __init__(self, num_channels, m, As=60.0):
+        self._h = C.c_void_p()
+        self.M, self.m = num_channels, m
+        rc = lib().mcrx_hip_pfb2_create(C.byref(self._h), num_channels, m, As)
+        if rc != MCRX_OK:
+            self._h = C.c_void_p()
+            msg = lib().mcrx_hip_pfb2_last_error().decode()
+            if rc == MCRX_EINVAL:
+                raise ValueError(msg)
+            raise McrxError("mcrx_hip_pfb2_create failed (%d): %s" % (rc, msg))
+        self._hist = None
+        self._step = 0
+
+    def taps(self):
+        h = np.zeros(2 * self.m * self.M, np.float32)
+        _check(lib().mcrx_hip_pfb2_get_taps(self._h, h.ctypes.data, h.size))
+        return h
+
+    def reset(self):
+        self._hist, self._step = None, 0
+
+    def analyze(self, x):
+        import torch
+        M2, depth = self.M // 2, 2 * self.m * self.M
+        n = int(x.numel())
+        if n % M2:
+            raise ValueError("input must be a whole number of M/2-sample steps")
+        ns = n // M2
+        lead = 0 if self._hist is None else int(self._hist.numel())
+        buf = x if lead == 0 else torch.cat([self._hist, x])
+        out = torch.empty((ns, self.M), dtype=torch.complex64, device=x.device)
+        stream = torch.cuda.current_stream(x.device)
+        rc = lib().mcrx_hip_pfb2_analyze(self._h, C.c_void_p(buf.data_ptr() + 8 * lead), lead, ns, self._step, _dptr(out),
+                                         _stream_ptr(stream))
+        if rc != MCRX_OK:
+            raise McrxError("mcrx_hip_pfb2_analyze failed (%d): %s" % (rc, lib().mcrx_hip_pfb2_last_error().decode()))
+        self._hist = buf[-depth:].clone() if buf.numel() > depth else buf.clone()
+        self._step += ns
+        return out
+
+    def close(self):
+        if self._h:
+            lib().mcrx_hip_pfb2_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -58,6 +58,18 @@ inline std::vector<float> pfb_prototype(unsigned K, unsigned m, float As)
     return h;
 }
 
+// prototype of firpfbch2_crcf_create_kaiser(LIQUID_ANALYZER, M, m, As): (2Mm+1)-tap Kaiser design at fc = 1/M,
+// scaled so that the taps sum to M (float accumulation in index order, like the oracle), first 2*m*M taps used
+inline std::vector<float> pfb2_prototype(unsigned M, unsigned m, float As)
+{
+    std::vector<float> h = firdes_kaiser(2 * M * m + 1, 1.0f / (float)M, As);
+    float sum = 0.0f;
+    for (float v : h) sum += v;
+    for (float &v : h) v = v * (float)M / sum;
+    h.resize((size_t)2 * m * M);
+    return h;
+}
+
 // ---------------------------------------------------------------- NCO
 inline uint32_t rad2u32(float rad)
 {

@@ -1,0 +1,146 @@
+// pfb2.hip -- 2x-oversampled polyphase analysis bank (liquid firpfbch2_crcf, analyzer) for gfx950.
+//
+// liquid-usrp's receiver uses the critically sampled bank (channelizer.hip); this is the alternate front end
+// BASELINE.json's north_star names, as a stage-level operator with its own parity
+// tests.  Closed form of the two-phase window shuffle of firpfbch2_crcf_execute_analyzer (verified against the
+// oracle's state machine and a float64 direct-form model, tests/test_oracle_dsp.py):
+//     Z_s[r] = sum_{k < 2m} h[r + k M] u[(s+1) M/2 - 1 - r - k M]          r = 0 .. M-1
+//     y_s[n] = (-1)^(n s) / M * sum_r Z_s[r] e^{+j 2 pi r n / M}
+// i.e. every step is a polyphase FIR over the last 2mM samples and an M-point inverse FFT, the odd steps with
+// alternating output signs.  One workgroup per step: thread r gathers its residue (coalesced across r, the
+// 2m-fold reuse of every sample is served by L2), the inverse FFT is radix-2 Stockham in LDS.
+// Algorithmic HBM bytes per input sample: 8 read + 2 x 8 written (M outputs per M/2 inputs) = 24 B.
+// Not tuned beyond that; the critically sampled bank is the measured hot path.
+#include "../../include/mcrx_hip.h"
+#include "design.hpp"
+#include "devmath.h"
+
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+
+namespace mcrx {
+
+struct Pfb2Args {
+    const float2 *x;            // x[0] = absolute sample first_step * M/2; `lead` valid samples precede it
+    const float *taps;          // 2m * M
+    float2 *out;                // [nsteps][M]
+    long long lead;
+    uint32_t nsteps, first_step, p;
+};
+
+template <int M>
+__global__ void pfb2_kernel(Pfb2Args a)
+{
+    constexpr int T = (M / 2 < 64) ? 64 : M / 2;
+    __shared__ float2 buf[2][M];
+    const uint32_t sl = blockIdx.x;                             // step within this call
+    const int tid = threadIdx.x;
+    const long long A = ((long long)sl + 1) * (M / 2) - 1;      // newest sample of the step, relative to x
+    for (int r = tid; r < M; r += T) {
+        float2 acc = make_float2(0.f, 0.f);
+        for (int k = (int)a.p - 1; k >= 0; k--) {               // oldest first, like the window dot product
+            const long long idx = A - r - (long long)k * M;
+            const float h = a.taps[r + k * M];
+            if (idx >= -a.lead) { const float2 u = a.x[idx]; acc.x += h * u.x; acc.y += h * u.y; }
+        }
+        buf[0][r] = acc;
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int n = M, s = 1; n > 1; n >>= 1, s <<= 1) {           // Stockham autosort, decimation in frequency
+        const int m2 = n >> 1;
+        for (int q = tid; q < M / 2; q += T) {
+            const int p = q / s, r = q % s;
+            float sn, cs; sincos_u32((uint32_t)p * (uint32_t)(4294967296.0 / n), sn, cs);
+            const float2 w = make_float2(cs, sn);               // e^{+j 2 pi p / n}: inverse transform
+            const float2 u = buf[cur][r + s * p], v = buf[cur][r + s * (p + m2)];
+            buf[cur ^ 1][r + s * 2 * p] = cadd(u, v);
+            buf[cur ^ 1][r + s * (2 * p + 1)] = cmul(csub(u, v), w);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    const bool odd_step = ((a.first_step + sl) & 1u) != 0;
+    const float g = 1.0f / (float)M;
+    float2 *dst = a.out + (size_t)sl * M;
+    for (int n = tid; n < M; n += T) {
+        const float sg = (odd_step && (n & 1)) ? -g : g;
+        dst[n] = make_float2(buf[cur][n].x * sg, buf[cur][n].y * sg);
+    }
+}
+
+}  // namespace mcrx
+
+using namespace mcrx;
+
+static thread_local std::string g_pfb2_err;
+#define P2CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_pfb2_err = std::string(#x) + ": " + hipGetErrorString(e_); return MCRX_EHIP; } } while (0)
+
+struct mcrx_hip_pfb2_s {
+    unsigned M, m;
+    std::vector<float> taps;
+    float *d_taps = nullptr;
+};
+
+extern "C" const char *mcrx_hip_pfb2_last_error(void) { return g_pfb2_err.c_str(); }
+
+extern "C" int mcrx_hip_pfb2_create(mcrx_hip_pfb2_t *out, unsigned M, unsigned m, float As)
+{
+    if (!out) return MCRX_EINVAL;
+    *out = nullptr;
+    // argument checks of firpfbch2_crcf_create: even channel count, filter semi-length at least 1
+    if (M < 2 || (M & 1)) { g_pfb2_err = "error: firpfbch2, number of channels must be even (and at least 2)"; return MCRX_EINVAL; }
+    if (m < 1) { g_pfb2_err = "error: firpfbch2, filter semi-length must be at least 1"; return MCRX_EINVAL; }
+    if ((M & (M - 1)) || M > 1024) { g_pfb2_err = "channel count must be a power of two <= 1024"; return MCRX_EUNSUPP; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_pfb2_err = "no HIP device (no CPU fallback)"; return MCRX_EHIP; }
+    mcrx_hip_pfb2_t q = new mcrx_hip_pfb2_s();
+    q->M = M; q->m = m;
+    q->taps = pfb2_prototype(M, m, As);
+    if (hipMalloc((void **)&q->d_taps, q->taps.size() * sizeof(float)) != hipSuccess ||
+        hipMemcpy(q->d_taps, q->taps.data(), q->taps.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        if (q->d_taps) (void)hipFree(q->d_taps);
+        delete q; g_pfb2_err = "device allocation failed"; return MCRX_ENOMEM;
+    }
+    *out = q;
+    return MCRX_OK;
+}
+
+extern "C" int mcrx_hip_pfb2_destroy(mcrx_hip_pfb2_t q)
+{
+    if (!q) return MCRX_OK;
+    (void)hipDeviceSynchronize();
+    (void)hipFree(q->d_taps);
+    delete q;
+    return MCRX_OK;
+}
+
+extern "C" int mcrx_hip_pfb2_get_taps(mcrx_hip_pfb2_t q, float *h, size_t n)
+{
+    if (!q || !h || n < q->taps.size()) { g_pfb2_err = "bad argument"; return MCRX_EINVAL; }
+    std::copy(q->taps.begin(), q->taps.end(), h);
+    return MCRX_OK;
+}
+
+extern "C" int mcrx_hip_pfb2_analyze(mcrx_hip_pfb2_t q, const void *d_x, size_t lead_samples, size_t nsteps,
+                                     uint64_t first_step, void *d_out, void *stream)
+{
+    if (!q || !d_x || !d_out) { g_pfb2_err = "bad argument"; return MCRX_EINVAL; }
+    if (nsteps == 0) return MCRX_OK;
+    if (nsteps > 0x7fffffffu) { g_pfb2_err = "too many steps in one call"; return MCRX_EINVAL; }
+    Pfb2Args a;
+    a.x = (const float2 *)d_x; a.taps = q->d_taps; a.out = (float2 *)d_out;
+    a.lead = (long long)lead_samples; a.nsteps = (uint32_t)nsteps; a.first_step = (uint32_t)first_step; a.p = 2 * q->m;
+    hipStream_t st = (hipStream_t)stream;
+#define P2(MM) hipLaunchKernelGGL((pfb2_kernel<MM>), dim3((unsigned)nsteps), dim3((MM) / 2 < 64 ? 64 : (MM) / 2), 0, st, a)
+    switch (q->M) {
+    case 2: P2(2); break;       case 4: P2(4); break;     case 8: P2(8); break;     case 16: P2(16); break;
+    case 32: P2(32); break;     case 64: P2(64); break;   case 128: P2(128); break; case 256: P2(256); break;
+    case 512: P2(512); break;   case 1024: P2(1024); break;
+    default: g_pfb2_err = "unsupported channel count"; return MCRX_EUNSUPP;
+    }
+#undef P2
+    P2CHK(hipGetLastError());
+    return MCRX_OK;
+}

@@ -74,6 +74,15 @@ void        ll_firpfbch_analyzer_execute(ll_firpfbch q, const ll_cf *x, ll_cf *y
 void        ll_firpfbch_synthesizer_execute(ll_firpfbch q, const ll_cf *X, ll_cf *y);
 unsigned    ll_firpfbch_get_taps(ll_firpfbch q, float *h);   /* returns p*K, copies prototype */
 
+/* 2x-oversampled analysis bank (liquid firpfbch2_crcf, analyzer): M channels, M/2 samples in, M out per call */
+typedef struct ll_firpfbch2_s *ll_firpfbch2;
+ll_firpfbch2 ll_firpfbch2_create_kaiser(unsigned M, unsigned m, float As);
+void         ll_firpfbch2_destroy(ll_firpfbch2 q);
+void         ll_firpfbch2_reset(ll_firpfbch2 q);
+void         ll_firpfbch2_analyzer_execute(ll_firpfbch2 q, const ll_cf *x, ll_cf *y);
+unsigned     ll_firpfbch2_get_taps(ll_firpfbch2 q, float *h);  /* returns 2m*M, copies prototype */
+void         ll_firpfbch2_analyze(ll_firpfbch2 q, const ll_cf *x, unsigned nsteps, ll_cf *y);
+
 /* ---- modem (liquid: src/modem/src/modem_{bpsk,qpsk,qam}.c, modem_common.c) - */
 typedef struct ll_modem_s *ll_modem;
 ll_modem ll_modem_create(int scheme);

@@ -133,6 +133,11 @@ def lib():
     sig("ll_mctx_update_data", i, vp, u, vp, vp, u, i, i, i)
     sig("ll_mctx_generate_samples", None, vp, vp)
     sig("ll_mctx_reset", None, vp)
+    sig("ll_firpfbch2_create_kaiser", vp, u, u, f)
+    sig("ll_firpfbch2_destroy", None, vp)
+    sig("ll_firpfbch2_reset", None, vp)
+    sig("ll_firpfbch2_get_taps", u, vp, vp)
+    sig("ll_firpfbch2_analyze", None, vp, vp, u, vp)
     _lib = L
     return L
 
@@ -239,6 +244,41 @@ class MsResamp:
         try:
             if getattr(self, "q", None):
                 lib().ll_msresamp_destroy(self.q)
+                self.q = None
+        except Exception:          # interpreter shutdown
+            pass
+
+
+class Channelizer2:
+    """2x-oversampled analysis bank (liquid firpfbch2_crcf analyzer): M channels, M/2 samples per step."""
+
+    def __init__(self, M, m, As=60.0):
+        self.M = M
+        self.q = lib().ll_firpfbch2_create_kaiser(M, m, As)
+        if not self.q:
+            raise ValueError("invalid firpfbch2 arguments")
+
+    def taps(self):
+        n = lib().ll_firpfbch2_get_taps(self.q, None)
+        h = np.zeros(n, np.float32)
+        lib().ll_firpfbch2_get_taps(self.q, _ptr(h))
+        return h
+
+    def analyze(self, x):
+        """x: whole number of M/2-sample steps -> [nsteps, M]; state carries over between calls."""
+        x = np.ascontiguousarray(x, np.complex64)
+        ns = len(x) // (self.M // 2)
+        y = np.zeros((ns, self.M), np.complex64)
+        lib().ll_firpfbch2_analyze(self.q, _ptr(x), ns, _ptr(y))
+        return y
+
+    def reset(self):
+        lib().ll_firpfbch2_reset(self.q)
+
+    def __del__(self):
+        try:
+            if getattr(self, "q", None):
+                lib().ll_firpfbch2_destroy(self.q)
                 self.q = None
         except Exception:          # interpreter shutdown
             pass

@@ -388,3 +388,34 @@ def test_bulk_host_execute_equals_device_path(product):
         check_frames(rx.frames, ref.frames)
         rx.close()
     ref.close(); tx.close()
+
+
+@pytest.mark.parametrize("M,m", [(2, 3), (8, 2), (16, 4), (128, 7), (1024, 7)])
+def test_oversampled_bank_matches_oracle(oracle, product, M, m):
+    """firpfbch2-style analysis bank (alternate front end): taps identical, outputs <= 1e-5 relative, fed in
+    pieces of uneven length (odd step counts flip the phase of the next call) with the filter state in HBM."""
+    torch = _torch()
+    ns = 96 if M >= 128 else 301
+    rng = np.random.RandomState(M + m)
+    x = (rng.randn(ns * M // 2) + 1j * rng.randn(ns * M // 2)).astype(np.complex64)
+    ora = oracle.Channelizer2(M, m)
+    want = ora.analyze(x)
+    pfb = product.firpfbch2(M, m)
+    assert np.array_equal(pfb.taps(), ora.taps())
+    d_x = torch.from_numpy(x).cuda()
+    got, s = [], 0
+    for steps in (1, 7, 20, ns):                                        # cold start, then warm continuations
+        steps = min(steps, ns - s)
+        got.append(pfb.analyze(d_x[s * (M // 2):(s + steps) * (M // 2)]).cpu().numpy()); s += steps
+    got = np.concatenate(got)
+    assert got.shape == want.shape
+    assert relerr(got, want) <= 1e-5
+    pfb.reset()
+    assert relerr(pfb.analyze(d_x).cpu().numpy(), want) <= 1e-5
+    pfb.close()
+
+
+def test_oversampled_bank_argument_errors(product):
+    for M, m in [(0, 4), (7, 4), (8, 0)]:                                # firpfbch2_crcf_create: even M, m >= 1
+        with pytest.raises(ValueError):
+            product.firpfbch2(M, m)

@@ -202,3 +202,52 @@ def test_msresamp_half_rate_and_arbitrary(oracle):
         assert abs(np.median(ph) / (2 * np.pi) - f_in / rate) < 1e-4
         assert abs(np.mean(np.abs(yy)) - 1.0) < 2e-2
         L.ll_msresamp_destroy(q)
+
+
+@pytest.mark.parametrize("M,m", [(8, 2), (16, 4), (64, 7)])
+def test_oversampled_bank_equals_float64_direct_form(oracle, M, m):
+    """firpfbch2 analyzer restatement (two-phase window shuffle) against an independent float64 model:
+    y_s[n] = (-1)^(n s) / M * sum_t h[t] e^{j 2 pi n t / M} u[(s+1) M/2 - 1 - t] -- a bank of band-pass filters
+    centred on n/M, sampled every M/2 inputs -- and against the float64 prototype (Kaiser, fc = 1/M, sum = M)."""
+    ch = oracle.Channelizer2(M, m)
+    h = ch.taps().astype(np.float64)
+    n_h = 2 * M * m + 1
+    beta = 0.1102 * (60.0 - 8.7)
+    t = np.arange(n_h) - (n_h - 1) / 2.0
+    proto = np.sinc(2.0 / M * t) * scipy.special.i0(beta * np.sqrt(np.maximum(0.0, 1.0 - (2.0 * t / n_h) ** 2))) / scipy.special.i0(beta)
+    proto = proto * M / proto.sum()
+    assert np.max(np.abs(h - proto[:2 * M * m])) < 2e-6 and abs(h.sum() - M) < 1e-3
+    rng = np.random.RandomState(M)
+    ns = 60
+    x = (rng.randn(ns * M // 2) + 1j * rng.randn(ns * M // 2)).astype(np.complex64)
+    y = ch.analyze(x[:len(x) // 2])
+    y = np.concatenate([y, ch.analyze(x[len(x) // 2:])])                # state carries over between calls
+    u = np.concatenate([np.zeros(len(h), np.complex128), x.astype(np.complex128)])
+    tt = np.arange(len(h))
+    E = np.exp(2j * np.pi * np.outer(np.arange(M), tt) / M)            # [n][t]
+    worst = 0.0
+    for s in range(ns):
+        seg = u[(s + 1) * (M // 2) - 1 + len(h) - tt]
+        d = (E * (h * seg)).sum(axis=1) / M * ((-1.0) ** (np.arange(M) * s))
+        worst = max(worst, np.max(np.abs(d - y[s])))
+    assert worst < 2e-6, worst
+    ch.reset()
+    assert np.array_equal(ch.analyze(x), y)                             # reset returns to the cold start
+
+
+def test_oversampled_bank_tone_and_oversampling(oracle):
+    """Prototype cut-off 1/M puts the -6 dB point on the neighbouring channel centres: a tone on channel k's
+    centre comes out of k at 0 dB, of k+-1 at -6 dB and of nothing else (< -75 dB); a tone half a spacing away is
+    passed at full level by both nearer channels -- what the 2x oversampling buys over the critically sampled bank."""
+    M, m, k = 32, 6, 5
+    ch = oracle.Channelizer2(M, m)
+    n = np.arange(400 * M // 2)
+    y = ch.analyze(np.exp(2j * np.pi * k * n / M).astype(np.complex64))[4 * m:]
+    p = 10 * np.log10(np.mean(np.abs(y) ** 2, axis=0) + 1e-30)
+    assert abs(p[k]) < 0.01 and abs(p[k - 1] + 6.02) < 0.05 and abs(p[k + 1] + 6.02) < 0.05
+    assert np.max(np.delete(p, [k - 1, k, k + 1])) < -75.0
+    assert np.max(np.abs(np.abs(y[:, k]) - 1.0)) < 1e-3                 # constant envelope: no step-to-step sign error
+    ch.reset()
+    y = ch.analyze(np.exp(2j * np.pi * (k + 0.5) * n / M).astype(np.complex64))[4 * m:]
+    p = 10 * np.log10(np.mean(np.abs(y) ** 2, axis=0) + 1e-30)
+    assert abs(p[k]) < 0.05 and abs(p[k + 1]) < 0.05 and np.max(np.delete(p, [k, k + 1])) < -70.0
