@@ -7,10 +7,11 @@
 //     Z_s[r] = sum_{k < 2m} h[r + k M] u[(s+1) M/2 - 1 - r - k M]          r = 0 .. M-1
 //     y_s[n] = (-1)^(n s) / M * sum_r Z_s[r] e^{+j 2 pi r n / M}
 // i.e. every step is a polyphase FIR over the last 2mM samples and an M-point inverse FFT, the odd steps with
-// alternating output signs.  One workgroup per step: thread r gathers its residue (coalesced across r, the
-// 2m-fold reuse of every sample is served by L2), the inverse FFT is radix-2 Stockham in LDS.
+// alternating output signs.  pfb2_kernel: one workgroup per step, thread r gathers its residue (coalesced across
+// r, the 2m-fold reuse of every sample is served by L2), radix-2 Stockham inverse FFT in LDS -- any m, any M.
+// pfb2_tile_kernel (m = 7, M >= 64): eight steps per workgroup on register sliding windows, see below.
 // Algorithmic HBM bytes per input sample: 8 read + 2 x 8 written (M outputs per M/2 inputs) = 24 B.
-// Not tuned beyond that; the critically sampled bank is the measured hot path.
+// The critically sampled bank (channelizer.hip) is the measured hot path; this one is tuned one level only.
 #include "../../include/mcrx_hip.h"
 #include "design.hpp"
 #include "devmath.h"
@@ -67,6 +68,93 @@ __global__ void pfb2_kernel(Pfb2Args a)
     for (int n = tid; n < M; n += T) {
         const float sg = (odd_step && (n & 1)) ? -g : g;
         dst[n] = make_float2(buf[cur][n].x * sg, buf[cur][n].y * sg);
+    }
+}
+
+// The same for the usual prototype length (m = 7, 14 taps per branch) and M >= 64: a workgroup owns TS = 8
+// consecutive steps and a thread one residue r.  Steps of equal parity slide one position along the thread's
+// polyphase stream, so the thread keeps two register windows (even / odd steps, 14 + 3 samples each) and every
+// sample is fetched 2 x 17 / 8 = 4.25 times per output instead of 14; the eight inverse FFTs advance together
+// through one ping-pong LDS tile (one barrier per stage for all of them).
+constexpr int PF_P = 14, PF_TS = 8;
+template <int M>
+__global__ __launch_bounds__(M) void pfb2_tile_kernel(Pfb2Args a)
+{
+    constexpr int W = PF_P + PF_TS / 2 - 1;
+    extern __shared__ float2 tile[];                            // [2][TS][M]
+    const int r = threadIdx.x;
+    const long long sl0 = (long long)blockIdx.x * PF_TS;
+    const long long total = (long long)a.nsteps * (M / 2);
+    float h[PF_P];
+#pragma unroll
+    for (int k = 0; k < PF_P; k++) h[k] = a.taps[r + k * M];
+    float2 we[W], wo[W];
+    const long long base = (sl0 + 1) * (M / 2) - 1 - r - (long long)(PF_P - 1) * M;
+#pragma unroll
+    for (int j = 0; j < W; j++) {                               // branch-free loads on clamped addresses
+        const long long ie = base + (long long)j * M, io = ie + M / 2;
+        const bool ve = ie >= -a.lead && ie < total, vo = io >= -a.lead && io < total;
+        const float2 e = a.x[ve ? ie : 0], o = a.x[vo ? io : 0];
+        we[j] = ve ? e : make_float2(0.f, 0.f);
+        wo[j] = vo ? o : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int sl = 0; sl < PF_TS; sl++) {
+        float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int k = PF_P - 1; k >= 0; k--) {                   // oldest first, like the window dot product
+            const float2 u = (sl & 1) ? wo[sl / 2 + PF_P - 1 - k] : we[sl / 2 + PF_P - 1 - k];
+            acc.x += h[k] * u.x; acc.y += h[k] * u.y;
+        }
+        tile[sl * M + r] = acc;
+    }
+    __syncthreads();
+    int cur = 0;
+    int n = M, s = 1;
+    for (; n >= 4; n >>= 2, s <<= 2) {                          // radix-4 Stockham stages, all TS transforms per stage
+        const int n1 = n >> 2;
+        float2 *src = tile + cur * (PF_TS * M), *dst = tile + (cur ^ 1) * (PF_TS * M);
+        for (int q = r; q < PF_TS * (M / 4); q += M) {
+            const int t = q / (M / 4), bq = q % (M / 4);
+            const int p = bq / s, rr = bq % s;
+            float sn, cs; sincos_u32((uint32_t)p * (uint32_t)(4294967296.0 / n), sn, cs);
+            const float2 w1 = make_float2(cs, sn), w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+            const float2 *x0 = src + t * M + rr + s * p;
+            const float2 xa = x0[0], xb = x0[s * n1], xc = x0[2 * s * n1], xd = x0[3 * s * n1];
+            const float2 apc = cadd(xa, xc), amc = csub(xa, xc), bpd = cadd(xb, xd), bmd = csub(xb, xd);
+            const float2 jbmd = make_float2(-bmd.y, bmd.x);     // +j (b - d): inverse transform
+            float2 *y0 = dst + t * M + rr + s * 4 * p;
+            y0[0] = cadd(apc, bpd);
+            y0[s] = cmul(cadd(amc, jbmd), w1);
+            y0[2 * s] = cmul(csub(apc, bpd), w2);
+            y0[3 * s] = cmul(csub(amc, jbmd), w3);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    for (; n > 1; n >>= 1, s <<= 1) {                           // (one radix-2 stage when log2 M is odd)
+        const int m2 = n >> 1;
+        float2 *src = tile + cur * (PF_TS * M), *dst = tile + (cur ^ 1) * (PF_TS * M);
+        for (int q = r; q < PF_TS * (M / 2); q += M) {
+            const int t = q / (M / 2), bq = q % (M / 2);
+            const int p = bq / s, rr = bq % s;
+            float sn, cs; sincos_u32((uint32_t)p * (uint32_t)(4294967296.0 / n), sn, cs);
+            const float2 w = make_float2(cs, sn);
+            const float2 u = src[t * M + rr + s * p], v = src[t * M + rr + s * (p + m2)];
+            dst[t * M + rr + s * 2 * p] = cadd(u, v);
+            dst[t * M + rr + s * (2 * p + 1)] = cmul(csub(u, v), w);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    const float g = 1.0f / (float)M;
+    const float2 *res = tile + cur * (PF_TS * M);
+#pragma unroll
+    for (int sl = 0; sl < PF_TS; sl++) {
+        if (sl0 + sl >= (long long)a.nsteps) break;
+        const bool odd_step = ((a.first_step + (uint32_t)(sl0 + sl)) & 1u) != 0;
+        const float sg = (odd_step && (r & 1)) ? -g : g;
+        a.out[(size_t)(sl0 + sl) * M + r] = make_float2(res[sl * M + r].x * sg, res[sl * M + r].y * sg);
     }
 }
 
@@ -133,6 +221,19 @@ extern "C" int mcrx_hip_pfb2_analyze(mcrx_hip_pfb2_t q, const void *d_x, size_t 
     a.x = (const float2 *)d_x; a.taps = q->d_taps; a.out = (float2 *)d_out;
     a.lead = (long long)lead_samples; a.nsteps = (uint32_t)nsteps; a.first_step = (uint32_t)first_step; a.p = 2 * q->m;
     hipStream_t st = (hipStream_t)stream;
+    if (a.p == PF_P && q->M >= 64) {
+        const unsigned nwg = (unsigned)((nsteps + PF_TS - 1) / PF_TS);
+        const size_t lds = (size_t)2 * PF_TS * q->M * sizeof(float2);
+#define P2T(MM) do { static bool attr_ = false; if (!attr_) { P2CHK(hipFuncSetAttribute((const void *)pfb2_tile_kernel<MM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_ = true; } \
+                     hipLaunchKernelGGL((pfb2_tile_kernel<MM>), dim3(nwg), dim3(MM), lds, st, a); } while (0)
+        switch (q->M) {
+        case 64: P2T(64); break;   case 128: P2T(128); break; case 256: P2T(256); break;
+        case 512: P2T(512); break; case 1024: P2T(1024); break;
+        }
+#undef P2T
+        P2CHK(hipGetLastError());
+        return MCRX_OK;
+    }
 #define P2(MM) hipLaunchKernelGGL((pfb2_kernel<MM>), dim3((unsigned)nsteps), dim3((MM) / 2 < 64 ? 64 : (MM) / 2), 0, st, a)
     switch (q->M) {
     case 2: P2(2); break;       case 4: P2(4); break;     case 8: P2(8); break;     case 16: P2(16); break;

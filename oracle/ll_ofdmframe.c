@@ -142,7 +142,7 @@ void ll_ofdmframe_eq_smoother(const unsigned char *p, unsigned M, unsigned order
     if (order > Nen - 1) order = Nen - 1;
     if (order > 10) order = 10;
     unsigned k = order + 1;
-    double *x = (double *)malloc(sizeof(double) * Nen);
+    double *x = (double *)calloc(Nen, sizeof(double));
     double *C = (double *)malloc(sizeof(double) * k * Nen);
     unsigned n = 0;
     for (unsigned i = 0; i < M; i++) {
@@ -170,7 +170,7 @@ void ll_ofdmframe_pilot_fit(const unsigned char *p, unsigned M, float *P)
 {
     unsigned M2 = M / 2, Np = 0;
     for (unsigned i = 0; i < M; i++) if (p[i] == LL_SCTYPE_PILOT) Np++;
-    double *x = (double *)malloc(sizeof(double) * Np);
+    double *x = (double *)calloc(Np, sizeof(double));
     double *C = (double *)malloc(sizeof(double) * 2 * Np);
     unsigned n = 0;
     for (unsigned i = 0; i < M; i++) {

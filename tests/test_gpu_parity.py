@@ -390,7 +390,7 @@ def test_bulk_host_execute_equals_device_path(product):
     ref.close(); tx.close()
 
 
-@pytest.mark.parametrize("M,m", [(2, 3), (8, 2), (16, 4), (128, 7), (1024, 7)])
+@pytest.mark.parametrize("M,m", [(2, 3), (8, 2), (16, 4), (64, 7), (128, 7), (256, 7), (512, 7), (1024, 7), (256, 5)])
 def test_oversampled_bank_matches_oracle(oracle, product, M, m):
     """firpfbch2-style analysis bank (alternate front end): taps identical, outputs <= 1e-5 relative, fed in
     pieces of uneven length (odd step counts flip the phase of the next call) with the filter state in HBM."""
