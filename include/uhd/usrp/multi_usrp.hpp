@@ -50,6 +50,7 @@ struct io_type_t { enum tid_t { COMPLEX_FLOAT32 = 'f' }; };
 struct loop_fifo {
     std::mutex mu; std::vector<std::complex<float> > q; size_t rd; FILE *tee; bool tee_checked, in_burst;
     loop_fifo() : rd(0), tee(NULL), tee_checked(false), in_burst(false) {}
+    ~loop_fifo() { if (tee) fclose(tee); }
     void end_burst() { std::lock_guard<std::mutex> lk(mu); in_burst = false; }
     bool bursting() { std::lock_guard<std::mutex> lk(mu); return in_burst; }
     void push(const std::complex<float> *x, size_t n)
@@ -72,7 +73,7 @@ struct loop_fifo {
     {
         std::lock_guard<std::mutex> lk(mu);
         if (!tee_checked) { tee_checked = true; if (const char *f = getenv("MCTX_TEE_FILE")) tee = fopen(f, "wb"); }
-        if (tee) { fwrite(x, sizeof(*x), n, tee); fflush(tee); }
+        if (tee) fwrite(x, sizeof(*x), n, tee);
     }
 };
 inline loop_fifo &loopback() { static loop_fifo f; return f; }
@@ -105,8 +106,8 @@ public:
         md.error_code = rx_metadata_t::ERROR_CODE_NONE;
         if (loopback_enabled()) {
             size_t got = loopback().pop(out, n);
-            // mid-burst the transmitter is merely a little behind: the air is continuous, wait for it (at most 0.1 s)
-            for (int tries = 0; !got && tries < 500 && loopback().bursting(); tries++) { usleep(200); got = loopback().pop(out, n); }
+            // mid-burst the transmitter is merely a little behind: the air is continuous, wait for it (at most 2 s)
+            for (int tries = 0; !got && tries < 10000 && loopback().bursting(); tries++) { usleep(200); got = loopback().pop(out, n); }
             if (!got) {                                         // idle air: a short packet of silence per millisecond
                 usleep(1000);
                 got = n < 64 ? n : 64;

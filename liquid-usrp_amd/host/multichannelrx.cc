@@ -3,6 +3,7 @@
 // Execute :155-182; the DSP itself runs in the gfx950 kernels.
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "multichannelrx.h"
@@ -10,6 +11,7 @@
 
 struct multichannelrx::impl {
     mcrx_hip_t h;
+    std::recursive_mutex mu;                // multichanneltxrx resets the receiver while its worker is in Execute()
     std::vector<void *> userdata;
     std::vector<framesync_callback> callback;
     std::vector<unsigned char> payload;     // callbacks get mutable buffers, like liquid's
@@ -67,12 +69,14 @@ void multichannelrx::Deliver()
 
 void multichannelrx::Reset()
 {
+    std::lock_guard<std::recursive_mutex> lk(pimpl->mu);
     mcrx_hip_reset(pimpl->h);
     Deliver();
 }
 
 void multichannelrx::Execute(std::complex<float> *_x, unsigned int _num_samples)
 {
+    std::lock_guard<std::recursive_mutex> lk(pimpl->mu);
     int rc = mcrx_hip_execute_host(pimpl->h, reinterpret_cast<const float *>(_x), _num_samples);
     if (rc != MCRX_OK && rc != MCRX_EOVERFLOW) { fprintf(stderr, "error: multichannelrx::Execute(), %s\n", mcrx_hip_last_error()); throw 0; }
     if (rc == MCRX_EOVERFLOW)
@@ -83,12 +87,14 @@ void multichannelrx::Execute(std::complex<float> *_x, unsigned int _num_samples)
 
 void multichannelrx::ExecuteDevice(const void *_d_x, unsigned int _num_samples)
 {
+    std::lock_guard<std::recursive_mutex> lk(pimpl->mu);
     int rc = mcrx_hip_execute_device(pimpl->h, _d_x, _num_samples, NULL);
     if (rc != MCRX_OK) { fprintf(stderr, "error: multichannelrx::ExecuteDevice(), %s\n", mcrx_hip_last_error()); throw 0; }
 }
 
 void multichannelrx::Flush()
 {
+    std::lock_guard<std::recursive_mutex> lk(pimpl->mu);
     mcrx_hip_flush(pimpl->h);
     Deliver();
 }
