@@ -73,6 +73,7 @@ void        ll_firpfbch_reset(ll_firpfbch q);
 void        ll_firpfbch_analyzer_execute(ll_firpfbch q, const ll_cf *x, ll_cf *y);
 void        ll_firpfbch_synthesizer_execute(ll_firpfbch q, const ll_cf *X, ll_cf *y);
 unsigned    ll_firpfbch_get_taps(ll_firpfbch q, float *h);   /* returns p*K, copies prototype */
+void        ll_firpfbch_copy_state(ll_firpfbch dst, const struct ll_firpfbch_s *src);
 
 /* 2x-oversampled analysis bank (liquid firpfbch2_crcf, analyzer): M channels, M/2 samples in, M out per call */
 typedef struct ll_firpfbch2_s *ll_firpfbch2;
@@ -163,6 +164,10 @@ typedef struct {
 typedef int (*ll_framesync_callback)(unsigned char *header, int header_valid,
                                      unsigned char *payload, unsigned payload_len, int payload_valid,
                                      ll_framesyncstats stats, void *userdata);
+/* benchmark helper: a callback that only counts, and its userdata */
+typedef struct { unsigned long long frames, headers_valid, payloads_valid, bytes; } ll_frame_counter;
+int ll_counting_callback(unsigned char *header, int header_valid, unsigned char *payload, unsigned payload_len,
+                         int payload_valid, ll_framesyncstats stats, void *userdata);
 typedef struct { unsigned check, fec0, fec1, mod_scheme; } ll_ofdmflexframegenprops;
 
 typedef struct ll_ofdmflexframegen_s *ll_ofdmflexframegen;
@@ -202,6 +207,7 @@ void     ll_mcrx_destroy(ll_mcrx q);
 void     ll_mcrx_reset(ll_mcrx q);
 void     ll_mcrx_set_soft(ll_mcrx q, int payload_soft);
 void     ll_mcrx_execute(ll_mcrx q, const ll_cf *x, unsigned n);
+void     ll_mcrx_execute_parallel(ll_mcrx q, const ll_cf *x, unsigned n, int nthreads);   /* OpenMP: banks over time, synchronizers over channels */
 /* stage tap for parity tests: NCO + analyzer only, keeps bins [0,N): out[nblocks][N] */
 void     ll_mcrx_channelize(ll_mcrx q, const ll_cf *x, unsigned nblocks, ll_cf *out);
 

@@ -93,3 +93,10 @@ void ll_firpfbch_synthesizer_execute(ll_firpfbch q, const ll_cf *X, ll_cf *y)
         y[i] = dot(q->hsub + i * p, q->win + i * p, p);
     }
 }
+
+/* test/benchmark helper: make dst continue exactly where src stands (same K, p) */
+void ll_firpfbch_copy_state(ll_firpfbch dst, const struct ll_firpfbch_s *src)
+{
+    memcpy(dst->win, src->win, sizeof(ll_cf) * src->p * src->K);
+    dst->filter_index = src->filter_index;
+}

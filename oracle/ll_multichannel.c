@@ -18,6 +18,8 @@
  *              Half-band stage design parameters are [UPSTREAM-UNVERIFIED] (m=7 each).
  */
 #include "liquidlite.h"
+#include <omp.h>
+#include <stdio.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -31,12 +33,26 @@ struct ll_mcrx_s {
     unsigned buffer_index;
     ll_ofdmflexframesync *fs;
     ll_nco nco;
+    ll_cf *par_buf; size_t par_cap;     /* ll_mcrx_execute_parallel: channel streams [N][nblocks] */
 };
 
 static float mc_offset(unsigned N)
 {
     float f = -0.5f * (float)(N - 1) / (float)N;
     return (float)((double)f * M_PI);
+}
+
+/* a callback that only counts (benchmark legs: no per-frame work outside the receiver itself); userdata -> ll_frame_counter */
+int ll_counting_callback(unsigned char *header, int header_valid, unsigned char *payload, unsigned payload_len,
+                         int payload_valid, ll_framesyncstats stats, void *userdata)
+{
+    (void)header; (void)payload; (void)stats;
+    ll_frame_counter *k = (ll_frame_counter *)userdata;
+    if (!k) return 0;
+    __atomic_add_fetch(&k->frames, 1, __ATOMIC_RELAXED);
+    if (header_valid) __atomic_add_fetch(&k->headers_valid, 1, __ATOMIC_RELAXED);
+    if (payload_valid) { __atomic_add_fetch(&k->payloads_valid, 1, __ATOMIC_RELAXED); __atomic_add_fetch(&k->bytes, payload_len, __ATOMIC_RELAXED); }
+    return 0;
 }
 
 ll_mcrx ll_mcrx_create(unsigned N, unsigned M, unsigned cp, unsigned taper, const unsigned char *p,
@@ -61,7 +77,7 @@ void ll_mcrx_destroy(ll_mcrx q)
     if (!q) return;
     for (unsigned i = 0; i < q->N; i++) ll_ofdmflexframesync_destroy(q->fs[i]);
     ll_firpfbch_destroy(q->ch);
-    free(q->fs); free(q->X); free(q->x); free(q);
+    free(q->fs); free(q->X); free(q->x); free(q->par_buf); free(q);
 }
 void ll_mcrx_reset(ll_mcrx q)
 {
@@ -87,6 +103,50 @@ void ll_mcrx_execute(ll_mcrx q, const ll_cf *xin, unsigned n)
         }
     }
 }
+/* The same result as ll_mcrx_execute on whole blocks, using every host core: the bench's "all cores" CPU leg.
+ * The reference's Execute() is single threaded (lib/multichannelrx.cc:155-195); this is what its loop allows:
+ * the analysis bank is independent across time given the 13 preceding blocks (each thread warms a private bank
+ * on them; the oscillator phase is theta0 + t * dtheta), the synchronizers are independent across channels.
+ * Callbacks arrive grouped by channel instead of by time.  Falls back to the serial loop for short inputs. */
+void ll_mcrx_execute_parallel(ll_mcrx q, const ll_cf *xin, unsigned n, int nthreads)
+{
+    unsigned K = 2 * q->N, N = q->N;
+    unsigned nblocks = n / K;
+    if (nthreads < 1) nthreads = 1;
+    if (q->buffer_index != 0 || nblocks < 64 * (unsigned)nthreads || nthreads == 1) { ll_mcrx_execute(q, xin, n); return; }
+    double t_start = omp_get_wtime();
+    if ((size_t)nblocks * N > q->par_cap) { free(q->par_buf); q->par_cap = (size_t)nblocks * N; q->par_buf = (ll_cf *)malloc(sizeof(ll_cf) * q->par_cap); }
+    ll_cf *chan = q->par_buf;                               /* kept between calls: first-touch page faults are paid once */
+    const uint32_t theta0 = q->nco.theta, dth = q->nco.d_theta;
+    const unsigned H = 13;                              /* 2m - 1 blocks of history */
+    ll_firpfbch *bank = (ll_firpfbch *)calloc((size_t)nthreads, sizeof(ll_firpfbch));
+    bank[0] = q->ch;
+#pragma omp parallel for num_threads(nthreads) schedule(static, 1)
+    for (int t = 0; t < nthreads; t++) {
+        unsigned b0 = (unsigned)((unsigned long long)nblocks * (unsigned)t / (unsigned)nthreads);
+        unsigned b1 = (unsigned)((unsigned long long)nblocks * (unsigned)(t + 1) / (unsigned)nthreads);
+        ll_cf *x = (ll_cf *)malloc(sizeof(ll_cf) * K), *X = (ll_cf *)malloc(sizeof(ll_cf) * K);
+        if (t) bank[t] = ll_firpfbch_create_kaiser(LL_ANALYZER, K, 7, 60.0f);       /* private bank, designed in parallel */
+        for (unsigned b = (t ? b0 - H : b0); b < b1; b++) {
+            ll_nco nco = { theta0 + (uint32_t)((unsigned long long)b * K) * dth, dth };
+            for (unsigned i = 0; i < K; i++) { x[i] = ll_nco_mix_down(&nco, xin[(size_t)b * K + i]); ll_nco_step(&nco); }
+            ll_firpfbch_analyzer_execute(bank[t], x, X);
+            if (b >= b0) for (unsigned c = 0; c < N; c++) chan[(size_t)c * nblocks + b] = X[c];   /* [channel][block] */
+        }
+        free(x); free(X);
+    }
+    double t_bank = omp_get_wtime();
+    if (nthreads > 1) ll_firpfbch_copy_state(q->ch, bank[nthreads - 1]);
+    for (int t = 1; t < nthreads; t++) ll_firpfbch_destroy(bank[t]);
+    free(bank);
+    q->nco.theta = theta0 + (uint32_t)((unsigned long long)nblocks * K) * dth;
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
+    for (unsigned c = 0; c < N; c++)
+        for (unsigned b = 0; b < nblocks; b++) ll_ofdmflexframesync_execute(q->fs[c], &chan[(size_t)c * nblocks + b], 1);
+    if (getenv("LL_ORACLE_TIMING")) fprintf(stderr, "ll_mcrx_execute_parallel: banks %.3f s, synchronizers %.3f s (%d threads)\n", t_bank - t_start, omp_get_wtime() - t_bank, nthreads);
+    if (n > nblocks * K) ll_mcrx_execute(q, xin + (size_t)nblocks * K, n - nblocks * K);
+}
+
 void ll_mcrx_channelize(ll_mcrx q, const ll_cf *xin, unsigned nblocks, ll_cf *out)
 {
     unsigned K = 2 * q->N;

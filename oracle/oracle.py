@@ -126,6 +126,7 @@ def lib():
     sig("ll_mcrx_reset", None, vp)
     sig("ll_mcrx_set_soft", None, vp, i)
     sig("ll_mcrx_execute", None, vp, vp, u)
+    sig("ll_mcrx_execute_parallel", None, vp, vp, u, i)
     sig("ll_mcrx_channelize", None, vp, vp, u, vp)
     sig("ll_mctx_create", vp, u, u, u, u, vp)
     sig("ll_mctx_destroy", None, vp)
@@ -445,12 +446,20 @@ class FlexFrameSync:
 class MultiChannelRx:
     """Oracle mirror of the reference class (lib/multichannelrx.cc)."""
 
-    def __init__(self, N, M, cp, taper, p=None, soft=True):
+    def __init__(self, N, M, cp, taper, p=None, soft=True, count_only=False):
+        """count_only: frames are only counted, in C (self.counts()), instead of being handed to Python --
+        for timing the receiver itself."""
         self.N, self.K = N, 2 * N
         self.frames = []
-        self._cbs = [_make_cb(self.frames, c) for c in range(N)]
-        arr = (FRAMESYNC_CB * N)(*self._cbs)
-        ud = (C.c_void_p * N)()
+        if count_only:
+            self._counter = (C.c_ulonglong * 4)()
+            fn = C.cast(lib().ll_counting_callback, C.c_void_p).value
+            arr = (C.c_void_p * N)(*([fn] * N))
+            ud = (C.c_void_p * N)(*([C.addressof(self._counter)] * N))
+        else:
+            self._cbs = [_make_cb(self.frames, c) for c in range(N)]
+            arr = (FRAMESYNC_CB * N)(*self._cbs)
+            ud = (C.c_void_p * N)()
         self._p = None if p is None else np.ascontiguousarray(p, np.uint8)
         self.q = lib().ll_mcrx_create(N, M, cp, taper, None if p is None else _ptr(self._p),
                                       C.cast(ud, C.c_void_p), C.cast(arr, C.c_void_p))
@@ -461,6 +470,15 @@ class MultiChannelRx:
     def execute(self, x):
         x = np.ascontiguousarray(x, np.complex64)
         lib().ll_mcrx_execute(self.q, _ptr(x), len(x))
+
+    def counts(self):
+        """(frames, valid headers, valid payloads, payload bytes) of a count_only receiver."""
+        return tuple(int(v) for v in self._counter)
+
+    def execute_parallel(self, x, nthreads):
+        """Same frames as execute() (grouped by channel instead of by time), on `nthreads` host threads."""
+        x = np.ascontiguousarray(x, np.complex64)
+        lib().ll_mcrx_execute_parallel(self.q, _ptr(x), len(x), int(nthreads))
 
     def channelize(self, x):
         x = np.ascontiguousarray(x, np.complex64)

@@ -251,3 +251,22 @@ def test_oversampled_bank_tone_and_oversampling(oracle):
     y = ch.analyze(np.exp(2j * np.pi * (k + 0.5) * n / M).astype(np.complex64))[4 * m:]
     p = 10 * np.log10(np.mean(np.abs(y) ** 2, axis=0) + 1e-30)
     assert abs(p[k]) < 0.05 and abs(p[k + 1]) < 0.05 and np.max(np.delete(p, [k, k + 1])) < -70.0
+
+
+def test_all_cores_receiver_equals_serial(oracle):
+    """The OpenMP form of the oracle receiver (bench.py's all-cores CPU leg) produces the serial loop's frames bit
+    for bit, also when the stream is split over calls with different thread counts and carries a ragged tail."""
+    N, M, cp = 8, 64, 8
+    iq, sent = oracle.synth_traffic(N, M, cp, 4, 5, payload_len=200)
+    a = oracle.MultiChannelRx(N, M, cp, 4)
+    a.execute(iq)
+    b = oracle.MultiChannelRx(N, M, cp, 4)
+    cut = (len(iq) // 2) // (2 * N) * (2 * N)
+    b.execute_parallel(iq[:cut], 4)
+    b.execute_parallel(iq[cut:-5], 3)
+    b.execute_parallel(iq[-5:], 8)                                  # too short for threads: serial fallback
+    key = lambda f: (f.channel, f.header, f.payload, f.header_valid, f.payload_valid, f.evm, f.rssi, f.cfo, f.framesyms.tobytes())
+    assert len(a.frames) == 5 * N and sorted(map(key, a.frames)) == sorted(map(key, b.frames))
+    c = oracle.MultiChannelRx(N, M, cp, 4, count_only=True)         # the bench's counting callback (no Python per frame)
+    c.execute_parallel(iq, 4)
+    assert c.counts() == (5 * N, 5 * N, 5 * N, 5 * N * 200)
