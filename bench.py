@@ -36,8 +36,9 @@ B_SYNC = 4.0                   # algorithmic bytes / wideband sample: the kept b
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    # a step is under a millisecond: 200 timed steps after 20 warm-up steps let the clocks settle (10 steps read ~10 % low)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--channels", type=int, default=512)
     ap.add_argument("--frames", type=int, default=8, help="frames per channel per GPU slab")
     ap.add_argument("--payload", type=int, default=1200)
