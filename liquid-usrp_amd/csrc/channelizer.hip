@@ -136,6 +136,8 @@ __global__ __launch_bounds__(T) void channelizer_kernel(ChanArgs a)
     }
 
     const uint32_t dth = a.dtheta;
+    float sd1, cd1; sincos_u32(dth, sd1, cd1);                  // e^{j dtheta}: column n+1 from column n
+    float sk8, ck8; sincos_u32((uint32_t)K * dth, sk8, ck8);    // e^{j K dtheta}: block b+1 from block b
     const uint32_t t0 = a.first_sample_lo;
 
     // raw samples of block b (relative to a.x), columns n0..n0+C-1; zeros outside the stream
@@ -147,19 +149,30 @@ __global__ __launch_bounds__(T) void channelizer_kernel(ChanArgs a)
         const float2 *src = a.x + n0;                                   // always mapped
         if (inx) src = a.x + (size_t)b * K + n0;
         if (inh) src = a.halo + (size_t)(b + CH_H) * K + n0;
-        // the value is not touched here (that would wait for it): mix_block() zeroes blocks outside the stream
+        // the value is not touched here (that would wait for it): the mixer zeroes blocks outside the stream
         if constexpr (C == 2) {
             const float4 v = *reinterpret_cast<const float4 *>(src);
             dst[0] = make_float2(v.x, v.y); dst[1] = make_float2(v.z, v.w);
         } else dst[0] = src[0];
     };
     // NCO in place; blocks outside the stream (before a cold start, past the end) become zeros
-    auto mix_block = [&](long long b, float2 (&dst)[C]) {
+    // Oscillator: one transcendental pair per thread and group of CH_R blocks.  Block g (a multiple of CH_R) gets
+    // sin/cos of the exact phase of its first column; the following blocks of the group are that value turned by
+    // the launch-constant per-block step K*dtheta, the neighbouring column by the per-sample step.  Every value is
+    // a fixed function of (group start, position in the group, column), so a stream cut into several calls on
+    // tile boundaries reproduces the single-call result bit for bit (explicit fma shapes, no reassociation).
+    auto osc_start = [&](long long g, float &sn, float &cs) {
+        sincos_u32_hw((t0 + (uint32_t)(g * K + n0)) * dth, sn, cs);
+    };
+    auto osc_next_block = [&](float &sn, float &cs) {
+        const float s2 = fmaf(sn, ck8, cs * sk8), c2 = fmaf(cs, ck8, -(sn * sk8)); sn = s2; cs = c2;
+    };
+    auto mix_with = [&](long long b, float sn, float cs, float2 (&dst)[C]) {
         const bool valid = (b >= 0 && b < (long long)a.nblocks) || (b < 0 && a.halo != nullptr);
-        const uint32_t ph = (t0 + (uint32_t)((long long)b * K + n0)) * dth;
 #pragma unroll
         for (int c = 0; c < C; c++) {
-            const float2 m = mix_down_hw(dst[c], ph + (uint32_t)c * dth);
+            if (c > 0) { const float s2 = fmaf(sn, cd1, cs * sd1), c2 = fmaf(cs, cd1, -(sn * sd1)); sn = s2; cs = c2; }
+            const float2 m = make_float2(fmaf(dst[c].x, cs, dst[c].y * sn), fmaf(dst[c].y, cs, -(dst[c].x * sn)));
             dst[c] = valid ? m : make_float2(0.f, 0.f);
         }
     };
@@ -172,8 +185,17 @@ __global__ __launch_bounds__(T) void channelizer_kernel(ChanArgs a)
     //  Keeping this straight-line matters: a load under a branch is waited for at the join.)
 #pragma unroll
     for (int i = 0; i < CH_H + CH_R; i++) load_raw(bs - CH_H + i, s[i]);
+    {   // the history blocks bs-13 .. bs-1 sit in the groups starting at bs-16 (positions 3..7) and bs-8 (0..7)
+        static_assert(CH_H == 13 && CH_R == 8, "history walk below assumes 13 history blocks and groups of 8");
+        float sn, cs;
+        osc_start(bs - 16, sn, cs);
+        osc_next_block(sn, cs); osc_next_block(sn, cs); osc_next_block(sn, cs);
 #pragma unroll
-    for (int i = 0; i < CH_H; i++) mix_block(bs - CH_H + i, s[i]);
+        for (int i = 0; i < 5; i++) { mix_with(bs - 13 + i, sn, cs, s[i]); osc_next_block(sn, cs); }
+        osc_start(bs - 8, sn, cs);
+#pragma unroll
+        for (int i = 5; i < 13; i++) { mix_with(bs - 13 + i, sn, cs, s[i]); osc_next_block(sn, cs); }
+    }
 
     const int rounds = a.slab_blocks / CH_R;
     for (int rd = 0; rd < rounds; rd++) {
@@ -183,8 +205,12 @@ __global__ __launch_bounds__(T) void channelizer_kernel(ChanArgs a)
         for (int j = 0; j < CH_P; j++)
 #pragma unroll
             for (int c = 0; c < C; c++) tap[j][c] = ltap[(K - 1 - (n0 + c)) + j * K];
+        {
+            float sn, cs;
+            osc_start(b0, sn, cs);
 #pragma unroll
-        for (int r = 0; r < CH_R; r++) mix_block(b0 + r, s[CH_H + r]);
+            for (int r = 0; r < CH_R; r++) { mix_with(b0 + r, sn, cs, s[CH_H + r]); osc_next_block(sn, cs); }
+        }
 #pragma unroll
         for (int r = 0; r < CH_R; r++) {
             float2 v[C];
