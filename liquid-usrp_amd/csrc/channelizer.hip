@@ -168,12 +168,14 @@ __global__ __launch_bounds__(T) void channelizer_kernel(ChanArgs a)
         const float s2 = fmaf(sn, ck8, cs * sk8), c2 = fmaf(cs, ck8, -(sn * sk8)); sn = s2; cs = c2;
     };
     auto mix_with = [&](long long b, float sn, float cs, float2 (&dst)[C]) {
+        // blocks outside the stream become zeros: a zeroed oscillator (by value; the caller's copy keeps turning)
+        // zeroes both columns, two selects per block instead of four.  (Clamped loads return finite samples.)
         const bool valid = (b >= 0 && b < (long long)a.nblocks) || (b < 0 && a.halo != nullptr);
+        sn = valid ? sn : 0.f; cs = valid ? cs : 0.f;
 #pragma unroll
         for (int c = 0; c < C; c++) {
             if (c > 0) { const float s2 = fmaf(sn, cd1, cs * sd1), c2 = fmaf(cs, cd1, -(sn * sd1)); sn = s2; cs = c2; }
-            const float2 m = make_float2(fmaf(dst[c].x, cs, dst[c].y * sn), fmaf(dst[c].y, cs, -(dst[c].x * sn)));
-            dst[c] = valid ? m : make_float2(0.f, 0.f);
+            dst[c] = make_float2(fmaf(dst[c].x, cs, dst[c].y * sn), fmaf(dst[c].y, cs, -(dst[c].x * sn)));
         }
     };
 
