@@ -4,7 +4,8 @@
 The reference holds no golden vectors and liquid-dsp is unavailable, so
 these fixtures pin the ORACLE's behaviour at commit time: design data (prototype taps, training
 symbols, allocation), one transmitted frame per PHY configuration with its decoded bytes and
-equalised symbols, and a short multichannel stream with the channelizer output.  They guard the
+equalised symbols, a short multichannel stream with the channelizer output, and the oversampled analysis bank's
+prototype and outputs for a seeded input.  They guard the
 oracle against drift and give the GPU path data-only test cases."""
 import os
 import sys
@@ -65,8 +66,20 @@ def multichannel():
                         channels=np.array([f.channel for f in rx.frames]))
 
 
+def oversampled_bank():
+    """firpfbch2-style analysis bank: prototype and the outputs for a seeded input (M = 16, m = 4 and M = 64, m = 7)."""
+    d = {}
+    for M, m in ((16, 4), (64, 7)):
+        rng = np.random.RandomState(100 + M)
+        x = (rng.randn(40 * M // 2) + 1j * rng.randn(40 * M // 2)).astype(np.complex64)
+        ch = O.Channelizer2(M, m)
+        d["taps_M%d" % M], d["x_M%d" % M], d["y_M%d" % M] = ch.taps(), x, ch.analyze(x)
+    np.savez_compressed(os.path.join(HERE, "pfb2.npz"), **d)
+
+
 if __name__ == "__main__":
     design()
+    oversampled_bank()
     frame("frame_m64_qpsk_h128", 64, 8, 4, O.MODEM_QPSK, O.FEC_HAMMING128, 64, 1)
     frame("frame_m256_qam16_g2412", 256, 32, 4, O.MODEM_QAM16, O.FEC_GOLAY2412, 100, 2)
     frame("frame_m48_bpsk_none", 48, 6, 4, O.MODEM_BPSK, O.FEC_NONE, 21, 3)

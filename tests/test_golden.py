@@ -44,6 +44,27 @@ def test_oracle_reproduces_golden_multichannel(oracle):
     assert np.max(np.abs(chan - g["chan"])) <= 2e-6 * np.max(np.abs(g["chan"]))
 
 
+def test_oracle_reproduces_golden_oversampled_bank(oracle):
+    g = np.load(os.path.join(G, "pfb2.npz"))
+    for M, m in ((16, 4), (64, 7)):
+        ch = oracle.Channelizer2(M, m)
+        assert np.array_equal(ch.taps(), g["taps_M%d" % M])
+        y = ch.analyze(g["x_M%d" % M])
+        assert np.max(np.abs(y - g["y_M%d" % M])) <= 2e-6 * np.max(np.abs(g["y_M%d" % M]))
+
+
+@pytest.mark.gpu
+def test_gpu_oversampled_bank_reproduces_golden(product):
+    import torch
+    g = np.load(os.path.join(G, "pfb2.npz"))
+    for M, m in ((16, 4), (64, 7)):
+        pfb = product.firpfbch2(M, m)
+        assert np.array_equal(pfb.taps(), g["taps_M%d" % M])
+        y = pfb.analyze(torch.from_numpy(g["x_M%d" % M]).cuda()).cpu().numpy()
+        assert np.max(np.abs(y - g["y_M%d" % M])) <= 1e-5 * np.max(np.abs(g["y_M%d" % M]))
+        pfb.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", FRAMES)
 def test_gpu_sync_decodes_golden_frame(product, name):
