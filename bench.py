@@ -1,21 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- complex Msamples/s through a 512-channel multichannelrx on synthetic IQ.
 
-One step = one pass of the hot path (NCO + polyphase analysis channelizer -> per-channel
-OFDM frame synchronizer incl. header/payload decode) over one batch of wideband cf32 samples
-that is already resident in HBM.  Workload = BASELINE.json config "512-ch multichannelrx":
-N=512 channels (K=1024), M=64 subcarriers, cp=8, taper=4, QPSK, CRC-32 + Hamming(12,8),
-1200-byte payloads, frames back to back on every channel (reference traffic recipe,
-src/multichannel_tx.cc:163-213).
+Workload = BASELINE.json config "512-ch multichannelrx": N=512 channels (K=1024), M=64 subcarriers, cp=8,
+taper=4, QPSK, CRC-32 + Hamming(12,8), 1200-byte payloads, frames back to back on every channel (reference
+traffic recipe, src/multichannel_tx.cc:163-213), 8 frames per channel and slab.
 
---gpus N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling.  Rank r
-channelizes time slab r of the wideband stream, one RCCL all-to-all turns the time-sharded
-channelizer output into channel shards (64 channels per GPU at N=8), rank r synchronizes
-channels [r*512/N, (r+1)*512/N) over all slabs.  value = samples all ranks accepted / time.
+One step = one pass of the hot path (NCO + polyphase analysis channelizer -> per-channel OFDM frame synchronizer
+incl. header/payload decode) over one batch of wideband cf32 samples already resident in HBM.  The batch is
+`--slabs` (3) DIFFERENT slabs -- different seeds, different idle gaps between them -- pushed one after the other
+through ONE streaming receiver that is never restarted: the stream is continuous across slabs and steps, so the
+scouts' frame-position speculation only hits where the traffic really is periodic (`spec_hit_rate`).
+`value` leaves the decoded frames in HBM (dropped per slab on the device); `value_with_harvest` is the same loop
+with every frame's record + payload copied to pinned host memory and walked through the C-ABI frame iterator
+(the reference's callbacks fire inside Execute, lib/multichannelrx.cc:193-194); `value_with_full_harvest` also
+moves the equalised symbols (59 KB per frame: host-link bound).
 
-The input is synthesised on the GPU by the product's own multichanneltx (txgen.hip; untimed,
-parity-tested against the oracle's transmitter in tests/test_gpu_tx.py).  The CPU oracle
-(oracle/) appears only as the `cpu_baseline` leg, timed on the same IQ on one host thread.
+--gpus N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling.  Sub-slabs of the stream go
+round robin to the ranks; per round every rank channelizes its sub-slab, one RCCL all-to-all turns the
+time-sharded output into channel shards (512/N channels per GPU), the rank synchronizes its shard; rounds are
+pipelined (channelize(c+1) || all_to_all(c) || synchronizers(c-1), liquid_usrp_amd/sharding.py).
+value = samples all ranks accepted / time.
+
+The input is synthesised on the GPU by the product's own multichanneltx (txgen.hip; untimed, parity-tested
+against the oracle's transmitter in tests/test_gpu_tx.py).  The CPU oracle (oracle/) appears only as the
+`cpu_baseline` leg: timed on the first slab on one host thread, and its decoded frames / equalised symbols are
+compared with the GPU's for that slab.
 """
 import argparse
 import json
@@ -28,7 +37,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec); 6.29 TB/s measured for a float4 copy
 B_CHANNELIZER = 12.0           # algorithmic bytes / wideband sample: 8 read + 4 written (N of 2N bins)
 B_SYNC = 4.0                   # algorithmic bytes / wideband sample: the kept bins read once
 
@@ -36,21 +45,27 @@ B_SYNC = 4.0                   # algorithmic bytes / wideband sample: the kept b
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # a step is under a millisecond: 200 timed steps after 20 warm-up steps let the clocks settle (10 steps read ~10 % low)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--channels", type=int, default=512)
-    ap.add_argument("--frames", type=int, default=8, help="frames per channel per GPU slab")
+    ap.add_argument("--frames", type=int, default=8, help="frames per channel per slab")
+    ap.add_argument("--slabs", type=int, default=3, help="different slabs per step and GPU")
     ap.add_argument("--payload", type=int, default=1200)
-    ap.add_argument("--cpu-reps", type=int, default=2, help="passes over the GPU slab timed on the CPU oracle")
+    ap.add_argument("--rounds", type=int, default=6, help="--gpus > 1: exchange rounds per step")
+    ap.add_argument("--serial-steps", type=int, default=8, help="steps of the unpipelined pass that times each kernel alone")
+    ap.add_argument("--harvest-steps", type=int, default=10)
+    ap.add_argument("--cpu-reps", type=int, default=1, help="passes over the first slab timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-harvest", action="store_true")
     ap.add_argument("--slab-blocks", type=int, default=0)
-    ap.add_argument("--inflight", type=int, default=1,
-                    help="steps in flight (throughput mode): consecutive steps are independent (each restarts its "
-                         "receiver), so with D > 1 they run on D receiver handles / HIP streams round robin and the serial "
-                         "per-channel chains of one step hide under the other steps' kernels.  The default 1 keeps every "
-                         "kernel's HIP-event duration free of queueing behind other streams, which the roofline block needs")
+    ap.add_argument("--chunk-blocks", type=int, default=0, help="split every push into sub-slabs of this many blocks")
+    ap.add_argument("--serial", action="store_true", help="time the unpipelined receiver (every kernel in order on one stream)")
     return ap.parse_args()
+
+
+def frame_index(sent):
+    """[(header, payload)] per channel -> dict for verification"""
+    return [{(h[0] << 8) | h[1]: (h, p) for (h, p) in ch} for ch in sent]
 
 
 def main():
@@ -70,46 +85,36 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)      # RCCL over xGMI
 
     prod, ora = load_product(), load_oracle()
+    from liquid_usrp_amd import sharding
     N, M, cp, taper = args.channels, 64, 8, 4
     K = 2 * N
     assert N % world == 0
-    cg = N // world
+    c0, cg = sharding.shard_of(rank, world, N)
 
-    # ---- synthetic IQ source (untimed): the GPU multichanneltx writes this rank's time slab
-    # straight into HBM -- `frames` frames back to back on every channel, reference traffic recipe.
-    # Every rank's slab carries the same frames (same seed); the slab ends in >= 64 idle blocks, so
-    # the next slab's cold-start transient falls between frames.
+    # ---- synthetic IQ (untimed): world * slabs different slabs = one period of the stream; every slab ends in
+    # >= 64 idle blocks, their number differs from slab to slab
     t0 = time.time()
-    reps = args.frames
     tx = prod.multichanneltx(N, M, cp, taper)
-    d_iq, sent = tx.generate(reps, args.payload, seed=0xC0FFEE, device=dev)
+    nslab = world * args.slabs
+    base_blocks = int(prod.lib().mctx_hip_blocks_for(tx._h, args.frames, args.payload, 40, 1, 6))
+    slabs, sents = [], []
+    for i in range(nslab):
+        pad = (0, 72, 24, 136, 48, 104)[i % 6]                       # different idle gaps (blocks)
+        d, s = tx.generate(args.frames, args.payload, seed=0xC0FFEE + 7919 * i, nblocks=base_blocks + pad, device=dev)
+        slabs.append(d); sents.append(frame_index(s))
     torch.cuda.synchronize()
     tx.close()
     gen_s = time.time() - t0
-    T = int(d_iq.numel()) // K                           # blocks per rank slab
-    d_halo = d_iq[(T - 13) * K:].clone() if rank > 0 else None
-    first_sample = rank * T * K
-    ntiles = T // 8
+    slab_blocks = [int(d.numel()) // K for d in slabs]
+    period_blocks = sum(slab_blocks)
+    slab_start = np.concatenate([[0], np.cumsum(slab_blocks)])          # channel-rate sample (= block) index of every slab in the period
 
-    cfg = dict(max_payload_len=max(args.payload, 64), channel_first=rank * cg, channel_count=cg,
-               max_frames=cg * reps * world + 64)
+    max_frames = N * args.frames + 64 if world == 1 else cg * args.frames * nslab + 64
+    cfg = dict(max_payload_len=max(args.payload, 64), max_frames=max_frames)
     if args.slab_blocks:
         cfg["slab_blocks"] = args.slab_blocks
-    # D independent receivers, output buffers and streams: step k runs on slot k % D.  One step is still
-    # restart -> channelize slab -> all-to-all (time shards -> channel shards) -> synchronize.
-    D = max(1, min(args.inflight, args.steps))
-    rxs = [prod.multichannelrx(N, M, cp, taper, **cfg) for _ in range(D)]
-    d_outs = [torch.empty(world * ntiles * cg * 8, dtype=torch.complex64, device=dev) for _ in range(D)]    # [dest][tile][c][8]
-    d_chans = [torch.empty_like(o) if world > 1 else o for o in d_outs]                                   # [src][tile][c][8]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(D)] if D > 1 else [torch.cuda.current_stream()]
-
-    from liquid_usrp_amd import sharding
-    assert sharding.slab_first_sample(rank, T, N) == first_sample
-
-    def step(k):
-        i = k % D
-        with torch.cuda.stream(streams[i]):
-            sharding.step(rxs[i], d_iq, T, rank, world, dist, d_outs[i], d_chans[i], halo=d_halo, stream=streams[i])
+    if args.chunk_blocks:
+        cfg["chunk_blocks"] = args.chunk_blocks
 
     def fence():
         torch.cuda.synchronize()
@@ -117,59 +122,125 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in range(max(args.warmup, D if D > 1 else 0)):        # with D > 1 every slot is warmed at least once
-        step(k)
+    # ---- every kernel alone (serial handle, HIP events on the launch stream): the roofline block's durations.
+    # Runs first, so it also brings the clocks up before the timed region.
+    ser = prod.multichannelrx(N, M, cp, taper, serial=1, channel_first=c0, channel_count=cg, **cfg)
+    for k in range(args.serial_steps + 2):
+        if k == 2:
+            torch.cuda.synchronize(); ser.kernel_stats(reset=True)
+        for d in slabs[:args.slabs]:
+            ser.Execute(d)
+            ser.Discard()
+    torch.cuda.synchronize()
+    ser_stats = ser.kernel_stats()
+    ser.close()
+
+    if world == 1:
+        rx = prod.multichannelrx(N, M, cp, taper, serial=1 if args.serial else 0, **cfg)
+
+        def step(harvest_rx=None):
+            h = harvest_rx or rx
+            for d in slabs:
+                h.Execute(d)
+                if harvest_rx is None:
+                    h.Discard()
+                else:
+                    h.Poll()                        # a result generation holds one slab's frames
+        samples_per_step = period_blocks * K
+        pipe = None
+    else:
+        # one period of the stream = nslab slabs; cut into rounds * world sub-slabs, sub-slab u -> rank u % world
+        rounds = args.rounds
+        stream = torch.cat(slabs)
+        unit = rounds * world * 8
+        tot = (period_blocks + unit - 1) // unit * unit
+        if tot > period_blocks:
+            stream = torch.cat([stream, torch.zeros((tot - period_blocks) * K, dtype=torch.complex64, device=dev)])
+        Tc = tot // (rounds * world)
+        v = stream.view(rounds, world, Tc * K)
+        mine = [v[c, rank].clone() for c in range(rounds)]
+        halos = []
+        for c in range(rounds):
+            u = c * world + rank
+            lo = (u * Tc - 13) * K
+            halos.append(stream[lo:lo + 13 * K].clone() if lo >= 0 else stream[lo:].clone())   # u = 0: the period's tail (wraps)
+        del stream, v
+        slabs_keep0 = slabs[0]
+        slabs = None
+        torch.cuda.empty_cache()
+        period_blocks = tot
+        rx = prod.multichannelrx(N, M, cp, taper, channel_first=c0, channel_count=cg, **cfg)
+        pipe = sharding.Pipeline(rx, rank, world, dist, N, Tc, rx.hist_tiles, device=dev)
+        first_push = [True]
+
+        def step(harvest_rx=None):
+            for c in range(rounds):
+                pipe.push(mine[c], None if first_push[0] else halos[c])
+                first_push[0] = False
+            if harvest_rx is None:
+                rx.Discard()
+        samples_per_step = world * rounds * Tc * K
+
+    for k in range(args.warmup):
+        step()
     fence()
-    for rx in rxs:
-        rx.kernel_stats(reset=True)
+    rx.kernel_stats(reset=True)
+    rx.spec_stats(reset=True)
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(k)
+        step()
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    stats = {}
-    for rx in rxs:
-        for kname_, (ms_, cnt_) in rx.kernel_stats().items():
-            a_, b_ = stats.get(kname_, (0.0, 0))
-            stats[kname_] = (a_ + ms_, b_ + cnt_)
+    walked, adopted = rx.spec_stats()
+    ovl_stats = rx.kernel_stats()
 
-    # ---- verification (untimed): the last step of every slot -- all frames of the shard decoded and valid
-    expect = cg * reps * world
-    nfr, n_ok = 0, 0
-    for rx in rxs:
-        rx.Flush()
-        nfr += len(rx.frames)
-        n_ok += sum(1 for f in rx.frames if f.header_valid and f.payload_valid
-                    and sent[f.channel][(f.header[0] << 8) | f.header[1]] == (f.header, f.payload))
-    verified = (nfr == expect * D and n_ok == expect * D)
+    # ---- verification (untimed): one more step of the continuing stream, harvested; every frame of the step
+    # decoded, valid and equal to what the transmitter sent
+    rx.Flush(); rx.frames.clear()
+    step_first = int(args.warmup + args.steps) * period_blocks           # channel-rate sample index where this step starts
+    step(harvest_rx=rx)
+    rx.Flush()
+    nfr, n_ok = len(rx.frames), 0
+    for f in rx.frames:
+        pos = (f.end_sample - step_first) % period_blocks
+        si = int(np.searchsorted(slab_start, pos, side="right") - 1)
+        want = sents[min(si, nslab - 1)][f.channel].get((f.header[0] << 8) | f.header[1])
+        n_ok += 1 if (f.header_valid and f.payload_valid and want == (f.header, f.payload)) else 0
+    expect = cg * args.frames * nslab
+    verified = (nfr == expect and n_ok == expect)
+    rx.frames.clear()
 
-    samples_per_step = world * T * K
     value = samples_per_step * args.steps / elapsed / 1e6
     out = None
+    harvest = None
+    if world == 1 and not args.no_harvest:
+        harvest = harvest_legs(prod, N, M, cp, taper, cfg, slabs, K, args, torch)
     if rank == 0:
-        per = {k: v[0] / max(v[1], 1) for k, v in stats.items()}          # mean ms per launch
-        ch_ms, sc_ms = per["channelizer_kernel"], per["sync_kernel"]
-        pl_ms, pw_ms, dk_ms = per["place_jobs_kernel"], per["payload_kernel"], per["decode_kernel"]
-        sy_ms = sc_ms + pl_ms + pw_ms + dk_ms
-        # algorithmic HBM bytes per launch: the channelizer moves 12 B per wideband
-        # sample of its slab (8 read + 4 written); the payload workers read each channel sample of their
-        # frames once (4 B per wideband sample) and write 8 B per data symbol plus its soft bits; the
-        # scout reads the preamble/header windows only; the decoder reads the soft bits once.
+        per = {k: v[0] / max(v[1], 1) for k, v in ser_stats.items()}          # mean ms per launch, kernel alone
+        ovl = {k: v[0] / max(v[1], 1) for k, v in ovl_stats.items()}
+        blocks0 = slab_blocks[0] if world == 1 else None
+        # algorithmic HBM bytes per launch, for one slab of the serial pass: the channelizer
+        # moves 12 B per wideband sample (8 read + 4 written); the payload workers read each channel sample of
+        # their frames once (4 B per wideband sample) and write 8 B per data symbol plus its soft bits; the scout
+        # reads the preamble/header windows only; the decoder reads the soft bits once.
+        mean_blocks = float(np.mean(slab_blocks[:args.slabs]))
         nsym_frame = -(-8 * ((args.payload + 4) * 3 // 2) // 2)                      # QPSK symbols of one h128-coded frame
-        nframes = N * reps
-        kbytes = {"channelizer_kernel": B_CHANNELIZER * T * K,
-                  "payload_kernel": B_SYNC * world * T * K + nframes * nsym_frame * (8 + 2),
-                  "sync_kernel": B_SYNC * world * T * K * (10.0 / 176.0),
+        nframes = cg * args.frames
+        share = cg / float(N)
+        kbytes = {"channelizer_kernel": B_CHANNELIZER * mean_blocks * K,
+                  "payload_kernel": B_SYNC * mean_blocks * K * share + nframes * nsym_frame * (8 + 2),
+                  "sync_kernel": B_SYNC * mean_blocks * K * share * (10.0 / 176.0),
                   "decode_kernel": nframes * (nsym_frame * 2 + args.payload),
                   "place_jobs_kernel": nframes * 16.0}
         kname = max(per, key=per.get)                                      # dominant kernel by time
         kms = per[kname]
         achieved = kbytes[kname] / (kms * 1e-3) / 1e9
-        traffic = measured_traffic(kname, N, reps, args.payload, world)
+        traffic = measured_traffic(kname, N, args.frames, args.payload)
+        total = walked + adopted
         out = {
             "metric": "complex Msamples/s through multichannelrx",
             "value": round(value, 3), "unit": "Msamples/s",
@@ -178,42 +249,78 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "512-ch multichannelrx (firpfbch K=2N m=7 + N x ofdmflexframesync), "
-                                   "M=64 cp=8 taper=4 QPSK CRC32+Hamming128 %dB payloads, %d frames/ch/GPU"
-                                   % (args.payload, reps),
-                       "channels": N, "subcarriers": M, "samples_per_step": samples_per_step, "steps_in_flight": D,
-                       "parallelism": "time-sharded channelizer -> all-to-all -> %d channels/GPU" % cg
-                                      if world > 1 else "single GPU"},
+                                   "M=64 cp=8 taper=4 QPSK CRC32+Hamming128 %dB payloads, %d frames/ch/slab, "
+                                   "%d different slabs per step and GPU, one continuous un-restarted stream"
+                                   % (args.payload, args.frames, args.slabs),
+                       "channels": N, "subcarriers": M, "samples_per_step": samples_per_step,
+                       "receiver": "serial (one stream)" if args.serial else "pipelined (3 internal streams, 3 buffer sets)",
+                       "parallelism": ("round-robin time-sharded channelizer -> all-to-all -> %d channels/GPU, %d rounds per step, "
+                                       "exchange overlapped" % (cg, args.rounds)) if world > 1 else "single GPU"},
+            "spec_hit_rate": round(adopted / total, 4) if total else None,
+            "frames_acquired": {"by_scout_walk": walked, "adopted_from_speculation": adopted},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "ms_per_launch": round(kms, 4),
+                         "measured": "kernel alone: serial receiver, %d steps, HIP events on the launch stream" % args.serial_steps,
                          "kernels_ms": {k: round(v, 4) for k, v in per.items()},
-                         "channelizer_ms": round(ch_ms, 4), "sync_ms": round(sy_ms, 4),
+                         "kernels_ms_overlapped": {k: round(v, 4) for k, v in ovl.items()},
+                         "serial_sum_ms_per_slab": round(sum(per.values()), 4),
                          "pipeline_frac_of_16B_roofline": round(value * 1e6 * 16.0 / (world * HBM_PEAK_GBS * 1e9), 5)},
-            "verified": {"frames": nfr, "expected": expect * D, "bit_exact_payloads": n_ok, "ok": verified,
-                         "note": "last step of each of the %d receiver slots" % D},
+            "verified": {"frames": nfr, "expected": expect, "bit_exact_payloads": n_ok, "ok": verified,
+                         "note": "the step after the timed region, same continuing stream"},
             "setup_s": {"iq_generation": round(gen_s, 2)},
         }
+        if harvest:
+            out.update(harvest)
         if not args.no_cpu and world == 1:                     # the CPU leg is reported at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(ora, d_iq.cpu().numpy(), N, M, cp, taper, args.cpu_reps)
-    for rx in rxs:
-        rx.close()
+            out["cpu_baseline"] = cpu_baseline(ora, prod, slabs[0], N, M, cp, taper, args.cpu_reps, cfg)
+    rx.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
     if not verified:
-        sys.exit("rank %d: verification failed (%d/%d frames, %d ok)" % (rank, nfr, expect * D, n_ok))
+        sys.exit("rank %d: verification failed (%d/%d frames, %d ok)" % (rank, nfr, expect, n_ok))
 
 
-def measured_traffic(kernel, N, reps, payload, world):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r1_*_traffic.json:
+def harvest_legs(prod, N, M, cp, taper, cfg, slabs, K, args, torch):
+    """The same continuous stream with the frames delivered: push slab k, poll (slab k-1's records + payloads come
+    over the host link while slab k is processed), walk them through mcrx_hip_next_frame."""
+    res = {}
+    samples = sum(int(d.numel()) for d in slabs)
+    for name, skip, steps in (("value_with_harvest", 1, args.harvest_steps), ("value_with_full_harvest", 0, max(2, args.harvest_steps // 3))):
+        rx = prod.multichannelrx(N, M, cp, taper, skip_framesyms=skip, **cfg)
+        for d in slabs:                                   # warm (buffers, pinned arena growth)
+            rx.Execute(d); rx.Poll(deliver=False); rx.drain_count()
+        rx.Flush(); rx.drain_count()
+        torch.cuda.synchronize()
+        nfr = nok = nbytes = 0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            for d in slabs:
+                rx.Execute(d)
+                rx.Poll(deliver=False)
+                a, b, c = rx.drain_count(); nfr += a; nok += b; nbytes += c
+        lib_rc = prod.lib().mcrx_hip_flush(rx._h)
+        a, b, c = rx.drain_count(); nfr += a; nok += b; nbytes += c
+        dt = time.perf_counter() - t0
+        res[name] = round(samples * steps / dt / 1e6, 3)
+        res[name + "_detail"] = {"steps": steps, "frames_delivered": nfr, "valid": nok, "payload_bytes": nbytes,
+                                 "expected_frames": N * args.frames * len(slabs) * steps, "dropped": rx.frames_dropped(),
+                                 "equalised_symbols_to_host": not skip, "flush_rc": int(lib_rc)}
+        rx.close()
+    return res
+
+
+def measured_traffic(kernel, N, frames, payload):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r*_traffic.json:
     2 x FETCH_SIZE + WRITE_SIZE, collected on this workload by scratch/prof.sh); None when the run's
     configuration is not the profiled one.  Counters cannot be read from inside the timed run."""
     import glob
-    if (N, reps, payload, world) != (512, 8, 1200, 1):
+    if (N, frames, payload) != (512, 8, 1200):
         return None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r1_*_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
     if not files:
         return None
     prof = json.load(open(files[-1]))
@@ -247,9 +354,10 @@ def usable_cores():
     return max(1, n), note
 
 
-def cpu_baseline(ora, base, N, M, cp, taper, reps):
-    """The CPU oracle (a port: liquid-dsp itself is unavailable) on the same IQ, one thread
-    (the reference's multichannelrx is single threaded: lib/multichannelrx.cc:184)."""
+def cpu_baseline(ora, prod, d_slab, N, M, cp, taper, reps, cfg):
+    """The CPU oracle (a port: liquid-dsp itself is unavailable) on the first slab, one thread (the reference's
+    multichannelrx is single threaded: lib/multichannelrx.cc:184); then its frames against the GPU's."""
+    base = d_slab.cpu().numpy()
     rx = ora.MultiChannelRx(N, M, cp, taper, count_only=True)      # frames are counted in C: only the receiver is timed
     chunk = 1 << 22
     t0 = time.perf_counter()
@@ -260,23 +368,47 @@ def cpu_baseline(ora, base, N, M, cp, taper, reps):
     n = len(base) * reps
     ok = rx.counts()[2]
     out = {"value": round(n / dt / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": "port",
-           "sample": "the benchmark's whole GPU slab x%d (%d samples, %d frames decoded), oracle "
+           "sample": "the benchmark's first slab x%d (%d samples, %d frames decoded), oracle "
                      "multichannelrx, single thread" % (reps, n, ok),
            "host_cores": os.cpu_count(), "seconds": round(dt, 2)}
     # the same oracle on every host core (analysis banks split over time, synchronizers over channels; same
     # frames bit for bit, tests/test_oracle_dsp.py) -- what the reference's loop would allow, not what it does
     try:
         nthr, quota_note = usable_cores()
-        rx2 = ora.MultiChannelRx(N, M, cp, taper, count_only=True)
+        rx3 = ora.MultiChannelRx(N, M, cp, taper, count_only=True)
         t0 = time.perf_counter()
-        for _ in range(reps):
-            rx2.execute_parallel(base, nthr)
+        rx3.execute_parallel(base, nthr)
         dt2 = time.perf_counter() - t0
-        ok2 = rx2.counts()[2]
-        out["all_cores"] = {"value": round(n / dt2 / 1e6, 3), "unit": "Msamples/s", "cores": nthr, "seconds": round(dt2, 2),
-                            "frames_decoded": ok2, "note": "OpenMP over time blocks (channelizer) and channels (synchronizers); " + quota_note}
+        out["all_cores"] = {"value": round(len(base) / dt2 / 1e6, 3), "unit": "Msamples/s", "cores": nthr, "seconds": round(dt2, 2),
+                            "frames_decoded": rx3.counts()[2],
+                            "note": "OpenMP over time blocks (channelizer) and channels (synchronizers); " + quota_note}
     except Exception as e:                                  # the single-thread figure above is the contract
-        out["all_cores"] = {"error": str(e)}
+        out["all_cores"] = {"error": repr(e)}
+    try:
+        # ---- parity on the benchmark's own slab (untimed): the oracle keeping its frames vs a fresh GPU receiver
+        # (cold start, like the oracle)
+        rx2 = ora.MultiChannelRx(N, M, cp, taper)
+        for i in range(0, len(base), chunk):
+            rx2.execute(base[i:i + chunk])
+        g = prod.multichannelrx(N, M, cp, taper, **cfg)
+        g.Execute(d_slab); g.Flush()
+        key = lambda f: (f.channel, f.header)
+        of = {key(f): f for f in rx2.frames}
+        worst, bad, cmpd = 0.0, 0, 0
+        for f in g.frames:
+            o = of.get(key(f))
+            if o is None or o.payload != f.payload or int(o.payload_valid) != int(f.payload_valid) or len(o.framesyms) != len(f.framesyms):
+                bad += 1
+                continue
+            cmpd += 1
+            worst = max(worst, float(np.max(np.abs(f.framesyms - o.framesyms)) / np.max(np.abs(o.framesyms))))
+        out["gpu_vs_oracle_on_this_slab"] = {"gpu_frames": len(g.frames), "oracle_frames": len(rx2.frames), "compared": cmpd,
+                                            "mismatched_or_missing": bad + abs(len(g.frames) - len(rx2.frames)),
+                                            "framesyms_max_rel_err": worst, "tolerance": 1e-5,
+                                            "ok": bad == 0 and len(g.frames) == len(rx2.frames) and worst <= 1e-5}
+        g.close()
+    except Exception as e:
+        out["gpu_vs_oracle_on_this_slab"] = {"error": repr(e), "ok": False}
     return out
 
 

@@ -58,6 +58,13 @@ typedef struct {
     uint32_t single_channel;     /* 1 = no channelizer: num_channels must be 1 and the samples pushed are that
                                     channel's own stream, i.e. one ofdmflexframesync (lib/ofdmtxrx.cc:91,620-626);
                                     samples are consumed 8 at a time */
+    uint32_t serial;             /* 1 = every kernel of a push runs in order on the caller's stream (profiling, debugging).
+                                    Default 0: the handle overlaps its own stages -- channelizer, acquisition and payload/decode
+                                    kernels of consecutive pushes run on three internal streams with three sets of buffers */
+    uint32_t chunk_blocks;       /* execute_device: split a push into sub-slabs of this many blocks (multiple of 8) so that
+                                    the stages of ONE call overlap too; 0 = one launch sequence per call */
+    uint32_t skip_framesyms;     /* 1 = harvests leave the equalised symbols in HBM (frames report num_framesyms = 0): 1.2 KB
+                                    instead of 59 KB per frame over the host link at the benchmark's frame size */
 } mcrx_hip_config;
 
 /* One decoded frame = the arguments of the reference's framesync_callback
@@ -92,6 +99,22 @@ int  mcrx_hip_execute_device(mcrx_hip_t q, const void *d_iq, size_t nsamples, vo
 
 /* wait for all pushed samples, gather decoded frames (ordered by end time, then channel). */
 int  mcrx_hip_flush(mcrx_hip_t q);
+/* Overlapped harvest for a stream that keeps coming (callbacks inside Execute, lib/multichannelrx.cc:193-194, at
+ * slab granularity): gathers the frames of everything pushed before the PREVIOUS poll -- waiting only for those
+ * launches -- and marks what was pushed since for the next poll.  With one push + one poll per slab, slab k-1's
+ * frames cross the host link while the GPU works on slab k. */
+int  mcrx_hip_poll(mcrx_hip_t q);
+/* as poll, but the frames are dropped on the device (no host wait, no copy): steady-state benchmarking */
+int  mcrx_hip_discard(mcrx_hip_t q);
+/* make `stream` wait (on the device) for everything pushed so far, e.g. before a stage-level buffer is reused */
+int  mcrx_hip_stream_wait(mcrx_hip_t q, void *stream);
+/* ... or only for synchronizer launch number `launch` (0-based; mcrx_hip_launches() - 1 right after a
+ * mcrx_hip_sync / execute_device call): what a rotating stage-level buffer needs before it is overwritten */
+uint64_t mcrx_hip_launches(mcrx_hip_t q);
+int  mcrx_hip_stream_wait_launch(mcrx_hip_t q, uint64_t launch, void *stream);
+/* frames the per-channel scouts acquired themselves / took over from speculative waves since the last reset of
+ * the statistics (synchronises the device) */
+int  mcrx_hip_spec_stats(mcrx_hip_t q, uint64_t *walked, uint64_t *adopted, int reset);
 size_t mcrx_hip_frames_pending(mcrx_hip_t q);
 int  mcrx_hip_next_frame(mcrx_hip_t q, mcrx_frame *out);      /* 1 = frame written, 0 = none */
 uint64_t mcrx_hip_frames_dropped(mcrx_hip_t q);

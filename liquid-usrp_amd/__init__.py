@@ -40,7 +40,8 @@ def build(force=False):
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("max_payload_len", C.c_uint32), ("max_frames", C.c_uint32),
                 ("payload_soft", C.c_uint32), ("slab_blocks", C.c_uint32), ("channel_first", C.c_uint32),
-                ("channel_count", C.c_uint32), ("batch_samples", C.c_uint32), ("single_channel", C.c_uint32)]
+                ("channel_count", C.c_uint32), ("batch_samples", C.c_uint32), ("single_channel", C.c_uint32),
+                ("serial", C.c_uint32), ("chunk_blocks", C.c_uint32), ("skip_framesyms", C.c_uint32)]
 
 
 class FrameC(C.Structure):
@@ -60,6 +61,12 @@ _EXPORTS = {
     "mcrx_hip_execute_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "mcrx_hip_execute_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "mcrx_hip_flush": (C.c_int, [C.c_void_p]),
+    "mcrx_hip_poll": (C.c_int, [C.c_void_p]),
+    "mcrx_hip_discard": (C.c_int, [C.c_void_p]),
+    "mcrx_hip_stream_wait": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mcrx_hip_launches": (C.c_uint64, [C.c_void_p]),
+    "mcrx_hip_stream_wait_launch": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
+    "mcrx_hip_spec_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]),
     "mcrx_hip_frames_pending": (C.c_size_t, [C.c_void_p]),
     "mcrx_hip_next_frame": (C.c_int, [C.c_void_p, C.POINTER(FrameC)]),
     "mcrx_hip_frames_dropped": (C.c_uint64, [C.c_void_p]),
@@ -204,11 +211,11 @@ class multichannelrx(object):
     def GetNumChannels(self):
         return self.N
 
-    def Execute(self, x, num_samples=None):
+    def Execute(self, x, num_samples=None, stream=None):
         """Push samples: a complex64 numpy array (host) or a torch complex64 CUDA tensor (HBM)."""
         if hasattr(x, "is_cuda") and x.is_cuda:
             n = int(x.numel()) if num_samples is None else int(num_samples)
-            _check(lib().mcrx_hip_execute_device(self._h, _dptr(x), n, None))
+            _check(lib().mcrx_hip_execute_device(self._h, _dptr(x), n, _stream_ptr(stream)))
             return
         a = np.ascontiguousarray(x, np.complex64)
         n = a.size if num_samples is None else int(num_samples)
@@ -226,6 +233,45 @@ class multichannelrx(object):
         _check(rc, allow=(MCRX_EOVERFLOW,))
         self._deliver(flush=False)
         return rc
+
+    def Poll(self, deliver=True):
+        """Overlapped harvest (mcrx_hip_poll): frames of everything pushed before the previous Poll."""
+        rc = lib().mcrx_hip_poll(self._h)
+        _check(rc, allow=(MCRX_EOVERFLOW,))
+        if deliver:
+            self._deliver(flush=False)
+        return rc
+
+    def Discard(self):
+        _check(lib().mcrx_hip_discard(self._h))
+
+    def frames_pending(self):
+        return int(lib().mcrx_hip_frames_pending(self._h))
+
+    def drain_count(self):
+        """Walk the harvested frames through the C-ABI (mcrx_hip_next_frame) without building Python objects;
+        returns (frames, valid payloads, payload bytes)."""
+        f = FrameC()
+        n = ok = nbytes = 0
+        nxt = lib().mcrx_hip_next_frame
+        ref = C.byref(f)
+        while nxt(self._h, ref) == 1:
+            n += 1
+            ok += 1 if (f.header_valid and f.payload_valid) else 0
+            nbytes += f.payload_len
+        return n, ok, nbytes
+
+    def stream_wait(self, stream=None, launch=None):
+        if launch is None:
+            _check(lib().mcrx_hip_stream_wait(self._h, _stream_ptr(stream)))
+        else:
+            _check(lib().mcrx_hip_stream_wait_launch(self._h, launch, _stream_ptr(stream)))
+
+    def spec_stats(self, reset=False):
+        """(frames acquired by the scouts' own walk, frames adopted from speculative waves)"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        _check(lib().mcrx_hip_spec_stats(self._h, C.byref(a), C.byref(b), 1 if reset else 0))
+        return int(a.value), int(b.value)
 
     def _deliver(self, flush):
         f = FrameC()
@@ -264,7 +310,14 @@ class multichannelrx(object):
                                          _dptr(d_out), groups, _stream_ptr(stream)))
 
     def sync(self, d_chan, first_sample, nsamples, stream=None):
-        _check(lib().mcrx_hip_sync(self._h, _dptr(d_chan), first_sample, nsamples, _stream_ptr(stream)))
+        """Returns the launch number (for stream_wait).  first_sample may be negative (history in front of sample 0)."""
+        _check(lib().mcrx_hip_sync(self._h, _dptr(d_chan), first_sample & 0xFFFFFFFFFFFFFFFF, nsamples, _stream_ptr(stream)))
+        return int(lib().mcrx_hip_launches(self._h)) - 1
+
+    @property
+    def hist_tiles(self):
+        """tiles of channel-rate history a stage-level sync needs in front of new samples"""
+        return (self.M + self.cp + 8 + 7) // 8 + 1
 
     def restart(self, stream=None):
         _check(lib().mcrx_hip_restart(self._h, _stream_ptr(stream)))

@@ -84,15 +84,16 @@ struct FrameRec {
     float evm, rssi, cfo;
     uint32_t mod_scheme, mod_bps, check, fec0, fec1, num_framesyms;
     int64_t end_sample;
-    uint64_t payload_off, syms_off;     // byte offsets into the frame arena
+    uint64_t payload_off, syms_off;     // byte offsets into the payload arena / the symbol arena
 };
 
 // payload of one frame handed from the per-channel scout to a payload worker wave
 struct PayloadJob {
     ChanState s;                // synchronizer state right after the last header symbol
     uint32_t ch;                // channel within the shard
-    uint32_t pad;
-    uint64_t arena_off;         // pre-allocated record space: payload bytes, then framesyms
+    uint32_t pad;               // record slot (set by place_jobs_kernel)
+    uint64_t arena_off;         // pre-allocated record space: payload bytes in the payload arena ...
+    uint64_t syms_off;          // ... and framesyms in the symbol arena (~0: no room, frame dropped)
 };
 
 // Frame-level speculation in the scout.  After a frame's last symbol liquid leaves the synchronizer in one
@@ -125,10 +126,12 @@ struct SyncArgs {
     uint8_t *tmpa, *tmpb;       // [nch][max_enc_len + 16]
     float2 *syms;               // [nch][max_syms]
     // output pool
-    FrameRec *rec; uint8_t *arena;
+    // (payloads and equalised symbols live in separate arenas: a harvest that only wants the decoded bytes
+    //  moves 1.2 KB per frame over the host link instead of 59 KB)
+    FrameRec *rec; uint8_t *arena; uint8_t *sarena;
     uint32_t *nrec;             // [0] allocated count, [1] dropped count
-    unsigned long long *arena_used;
-    uint64_t arena_cap;
+    unsigned long long *arena_used;     // [0] payload arena bytes, [1] symbol arena bytes
+    uint64_t arena_cap, sarena_cap;
     uint32_t max_rec;
     // scout -> payload worker hand-off (frame-parallel payload processing)
     int scout;                  // 1: scouts hand complete in-buffer frames to payload workers
@@ -145,6 +148,7 @@ struct SyncArgs {
     uint32_t *spec_hint;                 // host-mapped word: largest prediction count, sizes the next launch's grid
     uint32_t *hint;             // host-mapped word: longest coded frame (bytes) among this launch's jobs
     uint32_t enc_hint;          // the value the host last saw there (0: none yet)
+    uint32_t *stats;            // [0] frames the scouts acquired themselves, [1] frames adopted from speculative waves (NULL: not counted)
     int no_fast;               // MCRX_NO_FAST=1: payload workers use the general symbol path (A/B experiments)
 };
 hipError_t sync_launch(const SyncArgs &a, hipStream_t st);           // scout kernel: one wave per channel
@@ -155,6 +159,6 @@ hipError_t sync_launch_payload(const SyncArgs &a, int stage, hipStream_t st);
 // synchronizers back to SEEK at sample `cur`; optionally also zero two history buffers of hist_n cf32 each (hist_n even)
 // and the result counters -- a whole restart in one launch
 hipError_t sync_reset_launch(ChanState *st, uint32_t nch, int64_t cur, float2 *hist0, float2 *hist1, size_t hist_n,
-                             uint32_t *nrec, unsigned long long *arena_used, hipStream_t stream);
+                             uint32_t *nrec, unsigned long long *arena_used, uint32_t *pred_n, hipStream_t stream);
 
 }  // namespace mcrx

@@ -18,6 +18,8 @@
 using namespace mcrx;
 
 #define HIST_BLOCKS 13      /* 2m - 1 blocks of FIR history (m = 7) */
+#define MCRX_SLOTS 3        /* per-launch buffers (channel tiles, job list, per-job scratch): launch k uses slot k % 3 */
+#define MCRX_GENS 2         /* result generations (records + arenas): one fills while the other is harvested */
 
 static thread_local std::string g_err;
 static void set_err(const char *what, hipError_t e, const char *file, int line)
@@ -108,13 +110,28 @@ struct mcrx_hip_s {
     uint64_t arena_cap = 0;
     ChanState *d_st = nullptr; uint8_t *d_hbits = nullptr; float2 *d_R = nullptr;
     uint8_t *d_soft = nullptr, *d_tmpa = nullptr, *d_tmpb = nullptr; float2 *d_syms = nullptr;
-    FrameRec *d_rec = nullptr; uint8_t *d_arena = nullptr; uint32_t *d_nrec = nullptr;
-    unsigned long long *d_arena_used = nullptr;
-    PayloadJob *d_jobs = nullptr; uint32_t *d_njobs = nullptr; float2 *d_jR = nullptr; unsigned njobs_parity = 0;
+    // results: two generations.  Launches write into generation `gen`; a harvest closes it (new launches go to
+    // the other one) and copies it out once its last launch has finished -- the GPU keeps working meanwhile.
+    FrameRec *d_rec[MCRX_GENS] = {}; uint8_t *d_arena[MCRX_GENS] = {}, *d_sarena[MCRX_GENS] = {};
+    uint32_t *d_nrec[MCRX_GENS] = {}; unsigned long long *d_arena_used[MCRX_GENS] = {};
+    int gen = 0; bool gen_used[MCRX_GENS] = { false, false }, gen_closed[MCRX_GENS] = { false, false };
+    hipEvent_t ev_gen[MCRX_GENS] = {};       // recorded behind the last launch that wrote into the generation
+    uint64_t sarena_cap = 0;
+    // per-launch slots
+    PayloadJob *d_jobs[MCRX_SLOTS] = {}; uint32_t *d_njobs = nullptr; float2 *d_jR[MCRX_SLOTS] = {};
+    uint64_t seq = 0;                       // synchronizer launches so far (slot = seq % MCRX_SLOTS)
+    uint32_t *d_stats = nullptr;            // speculation statistics (SyncArgs::stats)
+    // internal streams: channelizer | acquisition (speculative waves, scouts, placement) | payload workers + decode.
+    // Launch k+1's acquisition -- a chain of dependent events per channel, a few waves per CU -- runs under launch
+    // k's payload/decode kernels, and launch k+1's channelizer as soon as CUs free up.
+    bool pipelined = true;
+    hipStream_t s_scout = nullptr, s_work = nullptr, s_copy = nullptr;
+    hipEvent_t ev_ready[MCRX_SLOTS] = {}, ev_scout[MCRX_SLOTS] = {}, ev_done[MCRX_SLOTS] = {}, ev_in = nullptr, ev_consumed = nullptr, ev_tmp[3] = {};
+    int last_slot = -1; size_t last_ntiles = 0;     // where the synchronizer history (tail of the previous launch) sits
     SpecSlot *d_spec = nullptr; float2 *d_spec_R = nullptr; int64_t *d_pred = nullptr; uint32_t *d_pred_n = nullptr;
     bool spec = false;
     uint32_t *h_hint = nullptr, *d_hint = nullptr;     // pinned, device-mapped: longest coded frame of the last launch
-    uint8_t *d_jsoft = nullptr, *d_jtmp = nullptr;
+    uint8_t *d_jsoft[MCRX_SLOTS] = {}, *d_jtmp[MCRX_SLOTS] = {};
     bool scout = true;
     // streaming state
     uint64_t total_samples = 0;             // wideband samples accepted since creation (NCO phase)
@@ -123,12 +140,12 @@ struct mcrx_hip_s {
     float2 *d_hist[2] = { nullptr, nullptr }; int hist_cur = 0;
     float2 *d_in = nullptr;                 // device staging (stage_cap samples)
     float2 *h_stage = nullptr; size_t stage_cap = 0, stage_fill = 0;   // pinned host staging (samples)
-    float2 *d_chan[2] = { nullptr, nullptr }; size_t chan_cap_tiles = 0; int chan_cur = 0;
+    float2 *d_chan[MCRX_SLOTS] = {}; size_t chan_cap_tiles = 0;
     unsigned hist_tiles = 0;
     hipStream_t stream = nullptr;
     // large host buffers skip the staging copy: chunks go from the caller's memory to one of two device buffers
     float2 *d_direct[2] = { nullptr, nullptr }; size_t direct_cap = 0; int direct_idx = 0; bool direct_used[2] = { false, false };
-    hipStream_t copy_stream = nullptr; hipEvent_t ev_copy[2] = { nullptr, nullptr }, ev_done[2] = { nullptr, nullptr };
+    hipStream_t copy_stream = nullptr; hipEvent_t ev_dcopy[2] = { nullptr, nullptr }, ev_ddone[2] = { nullptr, nullptr };
     uint64_t min_frame = 1;                 // channel-rate samples of the shortest possible frame
     uint64_t pending_bound = 0;             // upper bound of frame records produced since the last harvest
     double t_copy = 0, t_harvest = 0, t_run = 0, t_wait = 0, t_d2h = 0, b_d2h = 0, t_grow = 0;   // MCRX_DEBUG=8: host seconds spent per phase of the bulk path
@@ -140,7 +157,8 @@ struct mcrx_hip_s {
 
     int ev_begin(int which, hipStream_t st)
     {
-        if (ev_used[which] + 2 > evring[which].size()) RC(ev_resolve(which));
+        // ring full: fold the older half (long finished in a running stream, so the host does not stall on it)
+        if (ev_used[which] + 2 > evring[which].size()) RC(ev_resolve(which, evring[which].size() / 2));
         HIPCHK(hipEventRecord(evring[which][ev_used[which]], st));
         return MCRX_OK;
     }
@@ -150,19 +168,21 @@ struct mcrx_hip_s {
         ev_used[which] += 2;
         return MCRX_OK;
     }
-    int ev_resolve(int which)          // fold finished launches into the totals
+    int ev_resolve(int which, size_t upto = ~(size_t)0)          // fold finished launches into the totals
     {
-        for (size_t i = 0; i < ev_used[which]; i += 2) {
+        const size_t n = std::min(upto & ~(size_t)1, ev_used[which]);
+        for (size_t i = 0; i < n; i += 2) {
             float ms = 0;
             HIPCHK(hipEventSynchronize(evring[which][i + 1]));
             HIPCHK(hipEventElapsedTime(&ms, evring[which][i], evring[which][i + 1]));
             ev_ms_total[which] += ms; ev_count[which]++; ev_last[which] = ms;
         }
-        ev_used[which] = 0;
+        std::rotate(evring[which].begin(), evring[which].begin() + n, evring[which].end());
+        ev_used[which] -= n;
         return MCRX_OK;
     }
     // harvested frames (host)
-    std::vector<FrameRec> recs; HostArena arena_host; size_t next_frame = 0;
+    std::vector<FrameRec> recs; HostArena arena_host, sarena_host; size_t next_frame = 0;
     uint64_t dropped = 0;
 
     template <class T> int upload(const T **dst, const T *src, size_t n)
@@ -234,14 +254,45 @@ static int build_tables(mcrx_hip_t q)
     return MCRX_OK;
 }
 
+// every internal stream has finished what was enqueued so far before `st` goes on (no host wait)
+static int join_into(mcrx_hip_t q, hipStream_t st)
+{
+    if (!q->pipelined) return MCRX_OK;
+    hipStream_t in[3] = { q->stream, q->s_scout, q->s_work };
+    for (int i = 0; i < 3; i++) {
+        if (in[i] == st) continue;
+        HIPCHK(hipEventRecord(q->ev_tmp[i], in[i]));
+        HIPCHK(hipStreamWaitEvent(st, q->ev_tmp[i], 0));
+    }
+    return MCRX_OK;
+}
+// ... and the reverse: nothing enqueued on the internal streams from here on starts before `st` got here
+static int fork_from(mcrx_hip_t q, hipStream_t st)
+{
+    if (!q->pipelined) return MCRX_OK;
+    HIPCHK(hipEventRecord(q->ev_tmp[0], st));
+    hipStream_t out[3] = { q->stream, q->s_scout, q->s_work };
+    for (int i = 0; i < 3; i++) if (out[i] != st) HIPCHK(hipStreamWaitEvent(out[i], q->ev_tmp[0], 0));
+    return MCRX_OK;
+}
+
 // synchronizers back to SEEK, channelizer history cleared, undelivered device frames dropped
 static int restart_async(mcrx_hip_t q, hipStream_t st, bool from_zero)
 {
     if (from_zero) { q->total_samples = 0; q->chan_samples = 0; }
     q->stage_fill = 0; q->stage_first = q->total_samples;
     q->hist_cur = 0;
-    HIPCHK(sync_reset_launch(q->d_st, q->nch, q->chan_samples, q->d_hist[0], q->d_hist[1], (size_t)HIST_BLOCKS * q->K,
-                             q->d_nrec, q->d_arena_used, st));
+    q->last_slot = -1; q->last_ntiles = 0;
+    RC(join_into(q, st));
+    // (both result generations: counters zeroed; the prediction lists only survive a Reset(), not a restart from zero)
+    for (int g = 0; g < MCRX_GENS; g++) {
+        HIPCHK(sync_reset_launch(q->d_st, q->nch, q->chan_samples, g == 0 ? q->d_hist[0] : nullptr, g == 0 ? q->d_hist[1] : nullptr,
+                                 (size_t)HIST_BLOCKS * q->K, q->d_nrec[g], q->d_arena_used[g],
+                                 (from_zero && g == 0) ? q->d_pred_n : nullptr, st));
+        q->gen_used[g] = false; q->gen_closed[g] = false;
+    }
+    q->gen = 0;
+    RC(fork_from(q, st));
     return MCRX_OK;
 }
 
@@ -274,8 +325,8 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     q->max_enc = (q->max_enc + 15) & ~15u;
     q->max_syms = 8 * q->max_enc;
     q->ch_first = q->cfg.channel_first;
+    if (q->ch_first >= N || (uint64_t)q->ch_first + q->cfg.channel_count > N) { delete q; return fail(MCRX_EINVAL, "channel shard outside [0, N)"); }
     q->nch = q->cfg.channel_count ? q->cfg.channel_count : N - q->ch_first;
-    if (q->ch_first + q->nch > N || q->nch == 0) { delete q; return fail(MCRX_EINVAL, "channel shard outside [0, N)"); }
     q->max_rec = q->cfg.max_frames ? q->cfg.max_frames : 16 * q->nch + 64;
     q->min_frame = (uint64_t)(3 + (288 + q->od.M_data - 1) / q->od.M_data + 2) * (M + cp);
     if (!q->cfg.max_frames) {
@@ -292,10 +343,12 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
         const uint64_t bulk = std::min<uint64_t>((((uint64_t)16 << 20) / q->K + 8) / min_frame + 3, ((uint64_t)2 << 30) / per_rec / q->nch);
         q->max_rec = (uint32_t)std::max<uint64_t>(q->max_rec, bulk * q->nch);
     }
-    // frame arena: payload + equalised symbols; reserve for BPSK behind one rate-1/2 code
-    // (longer frames still fit while the total stays below the cap; overflow is counted)
-    q->arena_cap = (uint64_t)q->max_rec * ((((uint64_t)q->max_payload + 15) & ~15ull) + 8ull * 8ull * (2ull * (q->max_payload + 4) + 8));
-    if (q->arena_cap > (8ull << 30)) q->arena_cap = 8ull << 30;
+    // frame arenas (per result generation): payload bytes | equalised symbols, the latter reserved for BPSK
+    // behind one rate-1/2 code (longer frames still fit while the total stays below the cap; overflow is counted)
+    q->arena_cap = (uint64_t)q->max_rec * (((uint64_t)q->max_payload + 15) & ~15ull);
+    q->sarena_cap = (uint64_t)q->max_rec * (8ull * 8ull * (2ull * (q->max_payload + 4) + 8));
+    if (q->sarena_cap > (8ull << 30)) q->sarena_cap = 8ull << 30;
+    q->pipelined = !(q->cfg.struct_size >= offsetof(mcrx_hip_config, serial) + sizeof(uint32_t) && q->cfg.serial) && getenv("MCRX_SERIAL") == nullptr;
     q->slab_blocks = q->cfg.slab_blocks ? ((q->cfg.slab_blocks + 7) & ~7u) : 0;      // 0: sized per launch
     { int dev = 0, n = 0;
       if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
@@ -315,21 +368,28 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     if ((rc = q->alloc(&q->d_tmpa, (size_t)q->nch * (q->max_enc + 16)))) return bail(rc);
     if ((rc = q->alloc(&q->d_tmpb, (size_t)q->nch * (q->max_enc + 16)))) return bail(rc);
     if ((rc = q->alloc(&q->d_syms, (size_t)q->nch * q->max_syms))) return bail(rc);
-    if ((rc = q->alloc(&q->d_rec, q->max_rec))) return bail(rc);
-    if ((rc = q->alloc(&q->d_arena, q->arena_cap))) return bail(rc);
-    if ((rc = q->alloc(&q->d_nrec, 2))) return bail(rc);
-    if ((rc = q->alloc(&q->d_arena_used, 1))) return bail(rc);
+    for (int g = 0; g < MCRX_GENS; g++) {
+        if ((rc = q->alloc(&q->d_rec[g], q->max_rec))) return bail(rc);
+        if ((rc = q->alloc(&q->d_arena[g], q->arena_cap))) return bail(rc);
+        if ((rc = q->alloc(&q->d_sarena[g], q->sarena_cap))) return bail(rc);
+        if ((rc = q->alloc(&q->d_nrec[g], 2))) return bail(rc);
+        if ((rc = q->alloc(&q->d_arena_used[g], 2))) return bail(rc);
+        if (hipEventCreateWithFlags(&q->ev_gen[g], hipEventDisableTiming) != hipSuccess) return bail(fail(MCRX_EHIP, "hipEventCreate failed"));
+    }
     q->scout = getenv("MCRX_NO_SCOUT") == nullptr;
-    if ((rc = q->alloc(&q->d_njobs, 2))) return bail(rc);      // two counters used alternately: a launch zeroes the other one
+    if ((rc = q->alloc(&q->d_njobs, MCRX_SLOTS))) return bail(rc);      // one counter per slot: a launch's placement kernel zeroes the next slot's
+    if ((rc = q->alloc(&q->d_stats, 4))) return bail(rc);
     if (hipHostMalloc((void **)&q->h_hint, 2 * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess) {
         q->h_hint[0] = 0; q->h_hint[1] = 0;
         if (hipHostGetDevicePointer((void **)&q->d_hint, q->h_hint, 0) != hipSuccess) q->d_hint = nullptr;
     }
     if (q->scout) {
-        if ((rc = q->alloc(&q->d_jobs, q->max_rec))) return bail(rc);
-        if ((rc = q->alloc(&q->d_jR, (size_t)q->max_rec * M))) return bail(rc);
-        if ((rc = q->alloc(&q->d_jsoft, (size_t)q->max_rec * 8 * q->max_enc))) return bail(rc);
-        if ((rc = q->alloc(&q->d_jtmp, (size_t)q->max_rec * 2 * (q->max_enc + 16)))) return bail(rc);
+        for (int sl = 0; sl < MCRX_SLOTS; sl++) {
+            if ((rc = q->alloc(&q->d_jobs[sl], q->max_rec))) return bail(rc);
+            if ((rc = q->alloc(&q->d_jR[sl], (size_t)q->max_rec * M))) return bail(rc);
+            if ((rc = q->alloc(&q->d_jsoft[sl], (size_t)q->max_rec * 8 * q->max_enc))) return bail(rc);
+            if ((rc = q->alloc(&q->d_jtmp[sl], (size_t)q->max_rec * 2 * (q->max_enc + 16)))) return bail(rc);
+        }
         // speculative acquisition (lean path only): slots, their equalisers, the prediction lists
         const bool lean = q->sc.log2M >= 6 && q->sc.M == 64 * q->sc.E && q->sc.M_pilot <= 64;
         q->spec = lean && q->d_hint && getenv("MCRX_NO_SPEC") == nullptr;
@@ -349,9 +409,22 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     if (hipHostMalloc((void **)&q->h_stage, q->stage_cap * sizeof(float2), hipHostMallocDefault) != hipSuccess)
         return bail(fail(MCRX_ENOMEM, "pinned staging allocation failed"));
     if ((rc = q->alloc(&q->d_in, q->stage_cap))) return bail(rc);
+    // (blocking streams: work a caller puts on the legacy default stream -- e.g. a torch copy of a result buffer --
+    //  still orders against them, as it did when everything ran on one stream)
     if (hipStreamCreate(&q->stream) != hipSuccess) return bail(fail(MCRX_EHIP, "hipStreamCreate failed"));
+    if (hipStreamCreate(&q->s_scout) != hipSuccess) return bail(fail(MCRX_EHIP, "hipStreamCreate failed"));
+    if (hipStreamCreate(&q->s_work) != hipSuccess) return bail(fail(MCRX_EHIP, "hipStreamCreate failed"));
+    if (hipStreamCreateWithFlags(&q->s_copy, hipStreamNonBlocking) != hipSuccess) return bail(fail(MCRX_EHIP, "hipStreamCreate failed"));
+    {
+        hipEvent_t *evs[] = { &q->ev_in, &q->ev_consumed, &q->ev_tmp[0], &q->ev_tmp[1], &q->ev_tmp[2] };
+        for (hipEvent_t *e : evs) if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return bail(fail(MCRX_EHIP, "hipEventCreate failed"));
+        for (int sl = 0; sl < MCRX_SLOTS; sl++) {
+            hipEvent_t *ev3[] = { &q->ev_ready[sl], &q->ev_scout[sl], &q->ev_done[sl] };
+            for (hipEvent_t *e : ev3) if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return bail(fail(MCRX_EHIP, "hipEventCreate failed"));
+        }
+    }
     for (int w = 0; w < MCRX_NKERNELS; w++) {
-        q->evring[w].resize(512, nullptr);
+        q->evring[w].resize(2048, nullptr);
         for (auto &e : q->evring[w]) if (hipEventCreate(&e) != hipSuccess) return bail(fail(MCRX_EHIP, "hipEventCreate failed"));
     }
     if ((rc = restart_async(q, q->stream, true))) return bail(rc);
@@ -367,13 +440,24 @@ extern "C" int mcrx_hip_destroy(mcrx_hip_t q)
     if (getenv("MCRX_DEBUG") && (atoi(getenv("MCRX_DEBUG")) & 8))
         fprintf(stderr, "mcrx bulk path: copy %.4f s, launch %.4f s, waiting for the GPU %.4f s, harvest (incl. that wait) %.4f s of which frame D2H %.4f s for %.1f MB, host arena growth %.4f s\n", q->t_copy, q->t_run, q->t_wait, q->t_harvest, q->t_d2h, q->b_d2h / 1e6, q->t_grow);
     for (void *p : q->owned) (void)hipFree(p);
-    for (int i = 0; i < 2; i++) if (q->d_chan[i]) (void)hipFree(q->d_chan[i]);
+    for (int i = 0; i < MCRX_SLOTS; i++) if (q->d_chan[i]) (void)hipFree(q->d_chan[i]);
     if (q->h_stage) (void)hipHostFree(q->h_stage);
-    q->arena_host.release();
+    q->arena_host.release(); q->sarena_host.release();
+    {
+        hipEvent_t evs[] = { q->ev_in, q->ev_consumed, q->ev_tmp[0], q->ev_tmp[1], q->ev_tmp[2], q->ev_gen[0], q->ev_gen[1] };
+        for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+        for (int sl = 0; sl < MCRX_SLOTS; sl++) {
+            if (q->ev_ready[sl]) (void)hipEventDestroy(q->ev_ready[sl]);
+            if (q->ev_scout[sl]) (void)hipEventDestroy(q->ev_scout[sl]);
+            if (q->ev_done[sl]) (void)hipEventDestroy(q->ev_done[sl]);
+        }
+        hipStream_t sts[] = { q->s_scout, q->s_work, q->s_copy };
+        for (hipStream_t t : sts) if (t) (void)hipStreamDestroy(t);
+    }
     for (int i = 0; i < 2; i++) {
         if (q->d_direct[i]) (void)hipFree(q->d_direct[i]);
-        if (q->ev_copy[i]) (void)hipEventDestroy(q->ev_copy[i]);
-        if (q->ev_done[i]) (void)hipEventDestroy(q->ev_done[i]);
+        if (q->ev_dcopy[i]) (void)hipEventDestroy(q->ev_dcopy[i]);
+        if (q->ev_ddone[i]) (void)hipEventDestroy(q->ev_ddone[i]);
     }
     if (q->copy_stream) (void)hipStreamDestroy(q->copy_stream);
     if (q->h_hint) (void)hipHostFree(q->h_hint);
@@ -411,20 +495,27 @@ static int launch_channelizer(mcrx_hip_t q, const float2 *x, size_t nblocks, uin
     RC(q->ev_end(0, st));
     return MCRX_OK;
 }
+// One pass of the synchronizer bank over a channel-tile buffer that is ready in `st`'s order.
+// Pipelined: the acquisition kernels go to s_scout, the payload workers and the decoder to s_work; `st` itself
+// does not wait for them (mcrx_hip_stream_wait / flush / poll do).  Slot reuse: launch k waits for launch k-2's
+// decode, which frees the job counter its placement kernel zeroes and (in order on s_work) its own slot.
 static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsigned off, int64_t buf_first, int64_t end, hipStream_t st)
 {
+    const unsigned slot = (unsigned)(q->seq % MCRX_SLOTS), next = (unsigned)((q->seq + 1) % MCRX_SLOTS);
+    const int g = q->gen;
     SyncArgs a;
     a.c = q->sc; a.chan = chan; a.chan_stride = stride; a.chan_off = off;
     a.buf_first = buf_first; a.end = end; a.nch = q->nch; a.ch_first = q->ch_first;
     a.st = q->d_st; a.hbits = q->d_hbits; a.R = q->d_R; a.soft = q->d_soft; a.tmpa = q->d_tmpa; a.tmpb = q->d_tmpb;
-    a.syms = q->d_syms; a.rec = q->d_rec; a.arena = q->d_arena; a.nrec = q->d_nrec; a.arena_used = q->d_arena_used;
-    a.arena_cap = q->arena_cap; a.max_rec = q->max_rec;
+    a.syms = q->d_syms; a.rec = q->d_rec[g]; a.arena = q->d_arena[g]; a.sarena = q->d_sarena[g];
+    a.nrec = q->d_nrec[g]; a.arena_used = q->d_arena_used[g];
+    a.arena_cap = q->arena_cap; a.sarena_cap = q->sarena_cap; a.max_rec = q->max_rec;
     a.debug = getenv("MCRX_DEBUG") ? atoi(getenv("MCRX_DEBUG")) : 0;
     a.no_fast = getenv("MCRX_NO_FAST") ? atoi(getenv("MCRX_NO_FAST")) : 0;
     a.scout = q->scout ? 1 : 0;
-    a.jobs = q->d_jobs; a.njobs = q->d_njobs + q->njobs_parity; a.njobs_next = q->d_njobs + (q->njobs_parity ^ 1u); a.max_jobs = q->max_rec;
-    q->njobs_parity ^= 1u;
-    a.jR = q->d_jR; a.jsoft = q->d_jsoft; a.jtmp = q->d_jtmp;
+    a.jobs = q->d_jobs[slot]; a.njobs = q->d_njobs + slot; a.njobs_next = q->d_njobs + next; a.max_jobs = q->max_rec;
+    a.jR = q->d_jR[slot]; a.jsoft = q->d_jsoft[slot]; a.jtmp = q->d_jtmp[slot];
+    a.stats = q->d_stats;
     a.hint = q->d_hint; a.enc_hint = (q->h_hint && q->d_hint) ? *(volatile uint32_t *)q->h_hint : 0u;
     a.spec = q->d_spec; a.spec_R = q->d_spec_R; a.pred = nullptr; a.pred_n = nullptr; a.spec_cap = 0; a.spec_hint = nullptr;
     if (q->spec) {
@@ -432,18 +523,36 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
         const uint32_t seen = ((volatile uint32_t *)q->h_hint)[1];         // largest prediction list so far (read without a sync)
         a.spec_cap = seen < MCRX_SPEC_MAX ? seen : MCRX_SPEC_MAX;
     }
-    if (!q->scout) HIPCHK(hipMemsetAsync(a.njobs, 0, sizeof(uint32_t), st));     // (with the scout, the previous launch's placement kernel zeroed it)
-    RC(q->ev_begin(1, st));
-    HIPCHK(sync_launch_spec(a, st));          // speculative waves first, then the per-channel scouts that adopt them
-    HIPCHK(sync_launch(a, st));
-    RC(q->ev_end(1, st));
+    hipStream_t sa = st, sw = st;
+    if (q->pipelined && q->scout) {
+        sa = q->s_scout; sw = q->s_work;
+        HIPCHK(hipEventRecord(q->ev_ready[slot], st));
+        HIPCHK(hipStreamWaitEvent(sa, q->ev_ready[slot], 0));
+        if (q->seq + 1 >= MCRX_SLOTS) HIPCHK(hipStreamWaitEvent(sa, q->ev_done[next], 0));     // launch seq-2
+    }
+    if (!q->scout) HIPCHK(hipMemsetAsync(a.njobs, 0, sizeof(uint32_t), sa));     // (with the scout, the previous launch's placement kernel zeroed it)
+    RC(q->ev_begin(1, sa));
+    HIPCHK(sync_launch_spec(a, sa));          // speculative waves first, then the per-channel scouts that adopt them
+    HIPCHK(sync_launch(a, sa));
+    RC(q->ev_end(1, sa));
     if (q->scout) {
-        for (int stage = 0; stage < 3; stage++) {           // record placement, payload workers, packet decode
-            RC(q->ev_begin(2 + stage, st));
-            HIPCHK(sync_launch_payload(a, stage, st));
-            RC(q->ev_end(2 + stage, st));
+        RC(q->ev_begin(2, sa));               // record placement
+        HIPCHK(sync_launch_payload(a, 0, sa));
+        RC(q->ev_end(2, sa));
+        if (sw != sa) {
+            HIPCHK(hipEventRecord(q->ev_scout[slot], sa));
+            HIPCHK(hipStreamWaitEvent(sw, q->ev_scout[slot], 0));
+        }
+        for (int stage = 1; stage < 3; stage++) {           // payload workers, packet decode
+            RC(q->ev_begin(2 + stage, sw));
+            HIPCHK(sync_launch_payload(a, stage, sw));
+            RC(q->ev_end(2 + stage, sw));
         }
     }
+    HIPCHK(hipEventRecord(q->ev_done[slot], sw));
+    HIPCHK(hipEventRecord(q->ev_gen[g], sw));
+    q->gen_used[g] = true;
+    q->seq++;
     return MCRX_OK;
 }
 
@@ -493,47 +602,61 @@ extern "C" int mcrx_hip_kernel_stats(mcrx_hip_t q, double ms_total[MCRX_NKERNELS
 static int ensure_chan(mcrx_hip_t q, size_t tiles)
 {
     if (tiles <= q->chan_cap_tiles) return MCRX_OK;
-    float2 *nb[2] = { nullptr, nullptr };
-    size_t n = tiles * (size_t)q->N * MCRX_TILE;
-    for (int i = 0; i < 2; i++) {
+    HIPCHK(hipDeviceSynchronize());             // every stream that may still read the old buffers
+    float2 *nb[MCRX_SLOTS] = {};
+    const size_t n = tiles * (size_t)q->N * MCRX_TILE, tile_elems = (size_t)q->N * MCRX_TILE;
+    for (int i = 0; i < MCRX_SLOTS; i++) {
         HIPCHK(hipMalloc((void **)&nb[i], n * sizeof(float2)));
-        HIPCHK(hipMemsetAsync(nb[i], 0, n * sizeof(float2), q->stream));
+        HIPCHK(hipMemset(nb[i], 0, n * sizeof(float2)));
     }
-    if (q->d_chan[q->chan_cur])         // keep the history tiles of the live buffer
-        HIPCHK(hipMemcpyAsync(nb[0], q->d_chan[q->chan_cur], (size_t)q->hist_tiles * q->N * MCRX_TILE * sizeof(float2),
-                              hipMemcpyDeviceToDevice, q->stream));
-    HIPCHK(hipStreamSynchronize(q->stream));
-    for (int i = 0; i < 2; i++) if (q->d_chan[i]) (void)hipFree(q->d_chan[i]);
-    q->d_chan[0] = nb[0]; q->d_chan[1] = nb[1]; q->chan_cur = 0; q->chan_cap_tiles = tiles;
+    if (q->last_slot >= 0)                       // keep the synchronizer history: the tail of the last launch's tiles
+        HIPCHK(hipMemcpy(nb[q->last_slot] + q->last_ntiles * tile_elems, q->d_chan[q->last_slot] + q->last_ntiles * tile_elems,
+                         (size_t)q->hist_tiles * tile_elems * sizeof(float2), hipMemcpyDeviceToDevice));
+    for (int i = 0; i < MCRX_SLOTS; i++) { if (q->d_chan[i]) (void)hipFree(q->d_chan[i]); q->d_chan[i] = nb[i]; }
+    q->chan_cap_tiles = tiles;
     return MCRX_OK;
 }
 
-// channelize + synchronize `nblocks` (multiple of 8) blocks sitting in device memory
+// channelize + synchronize `nblocks` (multiple of 8) blocks sitting in device memory, readable in `st`'s order.
+// Launch k writes the channel tiles of slot k % 3: [history: the last hist_tiles tiles of launch k-1][ntiles new].
 static int run_blocks(mcrx_hip_t q, const float2 *x, size_t nblocks, uint64_t first_abs, hipStream_t st)
 {
     if (nblocks == 0) return MCRX_OK;
     const size_t ntiles = nblocks / MCRX_TILE;
     RC(ensure_chan(q, q->hist_tiles + ntiles));
-    float2 *buf = q->d_chan[q->chan_cur];
+    const int slot = (int)(q->seq % MCRX_SLOTS);
+    float2 *buf = q->d_chan[slot];
     const size_t tile_elems = (size_t)q->N * MCRX_TILE;
+    hipStream_t sc = st;
+    if (q->pipelined) {
+        // the channelizer runs on the handle's own stream once the input is there and launch k-3's workers have
+        // finished with this slot's tiles
+        sc = q->stream;
+        if (st != sc) { HIPCHK(hipEventRecord(q->ev_in, st)); HIPCHK(hipStreamWaitEvent(sc, q->ev_in, 0)); }
+        if (q->seq >= MCRX_SLOTS) HIPCHK(hipStreamWaitEvent(sc, q->ev_done[slot], 0));
+    }
+    if (q->last_slot >= 0)
+        HIPCHK(hipMemcpyAsync(buf, q->d_chan[q->last_slot] + q->last_ntiles * tile_elems,
+                              (size_t)q->hist_tiles * tile_elems * sizeof(float2), hipMemcpyDeviceToDevice, sc));
     if (q->bypass)      // the input already is the channel's sample stream (8 samples per tile, contiguous)
-        HIPCHK(hipMemcpyAsync(buf + q->hist_tiles * tile_elems, x, nblocks * sizeof(float2), hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(buf + q->hist_tiles * tile_elems, x, nblocks * sizeof(float2), hipMemcpyDeviceToDevice, sc));
     else
-        RC(launch_channelizer(q, x, nblocks, first_abs, q->d_hist[q->hist_cur], buf + q->hist_tiles * tile_elems, 1, ntiles, st));
-    const int64_t buf_first = q->chan_samples - (int64_t)q->hist_tiles * MCRX_TILE;
-    RC(launch_sync(q, buf, q->N, q->ch_first, buf_first, q->chan_samples + (int64_t)nblocks, st));
+        RC(launch_channelizer(q, x, nblocks, first_abs, q->d_hist[q->hist_cur], buf + q->hist_tiles * tile_elems, 1, ntiles, sc));
     // FIR history: last 13 blocks of (history, x)
     if (!q->bypass) {
         const uint64_t nh = (uint64_t)HIST_BLOCKS * q->K;
-        hipLaunchKernelGGL(hist_update_kernel, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, st,
+        hipLaunchKernelGGL(hist_update_kernel, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, sc,
                            q->d_hist[q->hist_cur], x, (uint64_t)nblocks * q->K, q->d_hist[1 - q->hist_cur], nh);
         HIPCHK(hipGetLastError());
         q->hist_cur ^= 1;
     }
-    // synchronizer history: last hist_tiles tiles move to the front of the other buffer
-    HIPCHK(hipMemcpyAsync(q->d_chan[1 - q->chan_cur], buf + ntiles * tile_elems,
-                          (size_t)q->hist_tiles * tile_elems * sizeof(float2), hipMemcpyDeviceToDevice, st));
-    q->chan_cur ^= 1;
+    if (sc != st) {     // the caller's stream may reuse x once the channelizer has read it -- not once the frames are decoded
+        HIPCHK(hipEventRecord(q->ev_consumed, sc));
+        HIPCHK(hipStreamWaitEvent(st, q->ev_consumed, 0));
+    }
+    const int64_t buf_first = q->chan_samples - (int64_t)q->hist_tiles * MCRX_TILE;
+    q->last_slot = slot; q->last_ntiles = ntiles;
+    RC(launch_sync(q, buf, q->N, q->ch_first, buf_first, q->chan_samples + (int64_t)nblocks, sc));
     q->chan_samples += (int64_t)nblocks;
     return MCRX_OK;
 }
@@ -545,7 +668,7 @@ static int process_staged(mcrx_hip_t q)
     if (n == 0) return MCRX_OK;
     HIPCHK(hipMemcpyAsync(q->d_in, q->h_stage, n * sizeof(float2), hipMemcpyHostToDevice, q->stream));
     RC(run_blocks(q, q->d_in, n / q->K, q->stage_first, q->stream));
-    HIPCHK(hipStreamSynchronize(q->stream));        // staging buffers are reused
+    HIPCHK(hipStreamSynchronize(q->stream));        // staging buffers are reused (the channelizer has read them; decoding goes on)
     const size_t rest = q->stage_fill - n;
     if (rest) memmove(q->h_stage, q->h_stage + n, rest * sizeof(float2));
     q->stage_fill = rest; q->stage_first += n;
@@ -572,8 +695,8 @@ static int execute_direct(mcrx_hip_t q, const float2 *&src, size_t &nsamples, bo
     if (!q->copy_stream) {
         HIPCHK(hipStreamCreateWithFlags(&q->copy_stream, hipStreamNonBlocking));
         for (int i = 0; i < 2; i++) {
-            HIPCHK(hipEventCreateWithFlags(&q->ev_copy[i], hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&q->ev_done[i], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&q->ev_dcopy[i], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&q->ev_ddone[i], hipEventDisableTiming));
         }
     }
     while (nsamples >= 64 * tile_samples) {
@@ -595,15 +718,15 @@ static int execute_direct(mcrx_hip_t q, const float2 *&src, size_t &nsamples, bo
         }
         const int b = q->direct_idx ^= 1;
         double t0 = now_s();
-        if (q->direct_used[b]) HIPCHK(hipEventSynchronize(q->ev_done[b]));
+        if (q->direct_used[b]) HIPCHK(hipEventSynchronize(q->ev_ddone[b]));
         q->t_wait += now_s() - t0; t0 = now_s();
         HIPCHK(hipMemcpyAsync(q->d_direct[b], src, take * sizeof(float2), hipMemcpyHostToDevice, q->copy_stream));
-        HIPCHK(hipEventRecord(q->ev_copy[b], q->copy_stream));
-        HIPCHK(hipStreamWaitEvent(q->stream, q->ev_copy[b], 0));
+        HIPCHK(hipEventRecord(q->ev_dcopy[b], q->copy_stream));
+        HIPCHK(hipStreamWaitEvent(q->stream, q->ev_dcopy[b], 0));
         q->t_copy += now_s() - t0; t0 = now_s();
         RC(run_blocks(q, q->d_direct[b], take / q->K, q->total_samples, q->stream));
         q->t_run += now_s() - t0; t0 = now_s();
-        HIPCHK(hipEventRecord(q->ev_done[b], q->stream));
+        HIPCHK(hipEventRecord(q->ev_ddone[b], q->stream));
         q->direct_used[b] = true;
         HIPCHK(hipStreamSynchronize(q->copy_stream));          // the caller's buffer has been read
         q->t_copy += now_s() - t0;
@@ -649,50 +772,154 @@ extern "C" int mcrx_hip_execute_device(mcrx_hip_t q, const void *d_iq, size_t ns
     if (q->stage_fill) return fail(MCRX_EINVAL, "host samples are still staged: flush before pushing device buffers");
     if (nsamples % ((size_t)8 * q->K)) return fail(MCRX_EINVAL, "device pushes must be whole tiles of 8 blocks (16*N samples)");
     hipStream_t st = stream ? (hipStream_t)stream : q->stream;
-    RC(run_blocks(q, (const float2 *)d_iq, nsamples / q->K, q->total_samples, st));
-    q->total_samples += nsamples; q->stage_first = q->total_samples;
+    // optional split into sub-slabs: within one call, sub-slab i+1's channelizer and acquisition overlap sub-slab i's
+    // payload workers (consecutive calls overlap in the same way without it)
+    const size_t nblocks = nsamples / q->K;
+    size_t chunk = q->cfg.struct_size >= offsetof(mcrx_hip_config, chunk_blocks) + sizeof(uint32_t) && q->cfg.chunk_blocks
+                       ? ((size_t)q->cfg.chunk_blocks + 7) / 8 * 8 : nblocks;
+    const float2 *x = (const float2 *)d_iq;
+    for (size_t b = 0; b < nblocks; b += chunk) {
+        const size_t nb = std::min(chunk, nblocks - b);
+        RC(run_blocks(q, x + b * q->K, nb, q->total_samples, st));
+        q->total_samples += nb * q->K;
+    }
+    q->stage_first = q->total_samples;
+    q->pending_bound += record_bound(q, nblocks);
+    return MCRX_OK;
+}
+
+extern "C" int mcrx_hip_stream_wait(mcrx_hip_t q, void *stream)
+{
+    if (!q) return fail(MCRX_EINVAL, "null handle");
+    return join_into(q, stream ? (hipStream_t)stream : q->stream);
+}
+extern "C" uint64_t mcrx_hip_launches(mcrx_hip_t q) { return q ? q->seq : 0; }
+extern "C" int mcrx_hip_stream_wait_launch(mcrx_hip_t q, uint64_t launch, void *stream)
+{
+    // the event ring holds the last MCRX_SLOTS launches; an older launch shares its slot with a later one that
+    // finishes after it (payload workers and decoders run in launch order), so waiting for the slot is enough
+    if (!q) return fail(MCRX_EINVAL, "null handle");
+    if (launch >= q->seq) return fail(MCRX_EINVAL, "no such launch");
+    HIPCHK(hipStreamWaitEvent(stream ? (hipStream_t)stream : q->stream, q->ev_done[launch % MCRX_SLOTS], 0));
     return MCRX_OK;
 }
 
 // ---------------------------------------------------------------- frames
-static int harvest_impl(mcrx_hip_t q);
-static int harvest(mcrx_hip_t q)
+// Copy one closed result generation to the host once its last launch has finished (only that is waited for:
+// launches enqueued later write the other generation and keep the GPU busy during the copy).
+static int collect(mcrx_hip_t q, int g)
 {
+    if (!q->gen_closed[g]) return MCRX_OK;
     const double t0 = now_s();
-    int rc = harvest_impl(q);
-    q->t_harvest += now_s() - t0;
-    return rc;
-}
-static int harvest_impl(mcrx_hip_t q)
-{
-    { const double t0 = now_s(); HIPCHK(hipDeviceSynchronize()); q->t_wait += now_s() - t0; }
-    uint32_t cnt[2] = { 0, 0 }; unsigned long long used = 0;
-    HIPCHK(hipMemcpy(cnt, q->d_nrec, sizeof(cnt), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&used, q->d_arena_used, sizeof(used), hipMemcpyDeviceToHost));
+    HIPCHK(hipEventSynchronize(q->ev_gen[g]));
+    q->t_wait += now_s() - t0;
+    uint32_t cnt[2] = { 0, 0 }; unsigned long long used[2] = { 0, 0 };
+    HIPCHK(hipMemcpyAsync(cnt, q->d_nrec[g], sizeof(cnt), hipMemcpyDeviceToHost, q->s_copy));
+    HIPCHK(hipMemcpyAsync(used, q->d_arena_used[g], sizeof(used), hipMemcpyDeviceToHost, q->s_copy));
+    HIPCHK(hipStreamSynchronize(q->s_copy));
     q->dropped += cnt[1];
     const uint32_t n = std::min(cnt[0], q->max_rec);
-    if (used > q->arena_cap) used = q->arena_cap;
+    if (used[0] > q->arena_cap) used[0] = q->arena_cap;
+    if (used[1] > q->sarena_cap) used[1] = q->sarena_cap;
+    const bool want_syms = !(q->cfg.struct_size >= offsetof(mcrx_hip_config, skip_framesyms) + sizeof(uint32_t) && q->cfg.skip_framesyms);
     if (n) {
         // drop frames already delivered, then append
-        if (q->next_frame == q->recs.size()) { q->recs.clear(); q->arena_host.clear(); q->next_frame = 0; }
-        const size_t base = q->arena_host.size, r0 = q->recs.size();
+        if (q->next_frame == q->recs.size()) { q->recs.clear(); q->arena_host.clear(); q->sarena_host.clear(); q->next_frame = 0; }
+        const size_t base = q->arena_host.size, sbase = q->sarena_host.size, r0 = q->recs.size();
         q->recs.resize(r0 + n);
-        HIPCHK(hipMemcpy(q->recs.data() + r0, q->d_rec, (size_t)n * sizeof(FrameRec), hipMemcpyDeviceToHost));
-        { const double t0 = now_s();
-          if (q->arena_host.grow_to(base + (size_t)used) != MCRX_OK) return fail(MCRX_ENOMEM, "host frame arena allocation failed");
-          q->t_grow += now_s() - t0; }
-        { const double t0 = now_s();
-          if (used) HIPCHK(hipMemcpy(q->arena_host.p + base, q->d_arena, (size_t)used, hipMemcpyDeviceToHost));
-          q->t_d2h += now_s() - t0; q->b_d2h += (double)used; }
-        for (size_t i = r0; i < r0 + n; i++) { q->recs[i].payload_off += base; q->recs[i].syms_off += base; }
+        { const double t1 = now_s();
+          if (q->arena_host.grow_to(base + (size_t)used[0]) != MCRX_OK) return fail(MCRX_ENOMEM, "host frame arena allocation failed");
+          if (want_syms && q->sarena_host.grow_to(sbase + (size_t)used[1]) != MCRX_OK) return fail(MCRX_ENOMEM, "host frame arena allocation failed");
+          q->t_grow += now_s() - t1; }
+        { const double t1 = now_s();
+          HIPCHK(hipMemcpyAsync(q->recs.data() + r0, q->d_rec[g], (size_t)n * sizeof(FrameRec), hipMemcpyDeviceToHost, q->s_copy));
+          if (used[0]) HIPCHK(hipMemcpyAsync(q->arena_host.p + base, q->d_arena[g], (size_t)used[0], hipMemcpyDeviceToHost, q->s_copy));
+          if (want_syms && used[1]) HIPCHK(hipMemcpyAsync(q->sarena_host.p + sbase, q->d_sarena[g], (size_t)used[1], hipMemcpyDeviceToHost, q->s_copy));
+          HIPCHK(hipStreamSynchronize(q->s_copy));
+          q->t_d2h += now_s() - t1; q->b_d2h += (double)used[0] + (want_syms ? (double)used[1] : 0.0); }
+        for (size_t i = r0; i < r0 + n; i++) {
+            q->recs[i].payload_off += base;
+            if (want_syms) q->recs[i].syms_off += sbase; else q->recs[i].num_framesyms = 0;
+        }
         // reference order: by end time, then channel index (lib/multichannelrx.cc:193-194)
         std::stable_sort(q->recs.begin() + r0, q->recs.end(), [](const FrameRec &a, const FrameRec &b) {
             return a.end_sample != b.end_sample ? a.end_sample < b.end_sample : a.channel < b.channel; });
     }
-    HIPCHK(hipMemset(q->d_nrec, 0, 2 * sizeof(uint32_t)));
-    HIPCHK(hipMemset(q->d_arena_used, 0, sizeof(unsigned long long)));
-    q->pending_bound = 0;
+    HIPCHK(hipMemsetAsync(q->d_nrec[g], 0, 2 * sizeof(uint32_t), q->s_copy));
+    HIPCHK(hipMemsetAsync(q->d_arena_used[g], 0, 2 * sizeof(unsigned long long), q->s_copy));
+    HIPCHK(hipStreamSynchronize(q->s_copy));
+    q->gen_closed[g] = false; q->gen_used[g] = false;
     return cnt[1] ? MCRX_EOVERFLOW : MCRX_OK;
+}
+// close the generation launches are writing into; later launches write the other one (which must be collected)
+static void close_generation(mcrx_hip_t q)
+{
+    const int g = q->gen;
+    if (!q->gen_used[g] || q->gen_closed[g ^ 1]) return;
+    q->gen_closed[g] = true;
+    q->gen = g ^ 1;
+}
+
+// Everything decoded so far becomes deliverable: both generations, blocking.
+static int harvest(mcrx_hip_t q)
+{
+    const double t0 = now_s();
+    int rc = collect(q, q->gen ^ 1);
+    if (rc == MCRX_OK || rc == MCRX_EOVERFLOW) {
+        close_generation(q);
+        const int rc2 = collect(q, q->gen ^ 1);
+        rc = (rc2 == MCRX_OK) ? rc : rc2;
+    }
+    q->pending_bound = 0;
+    q->t_harvest += now_s() - t0;
+    return rc;
+}
+
+// Overlapped harvest for a stream that keeps coming: deliver the frames of the launches enqueued before the
+// PREVIOUS poll (waiting only for those), and close the current generation for the next poll.  With one
+// execute_device + one poll per slab, slab k-1's frames cross the host link while slab k is being processed.
+extern "C" int mcrx_hip_poll(mcrx_hip_t q)
+{
+    if (!q) return fail(MCRX_EINVAL, "null handle");
+    const double t0 = now_s();
+    const int rc = collect(q, q->gen ^ 1);
+    if (rc == MCRX_OK || rc == MCRX_EOVERFLOW) close_generation(q);
+    q->pending_bound = record_bound(q, 0);
+    q->t_harvest += now_s() - t0;
+    return rc;
+}
+
+// Benchmark helper: as mcrx_hip_poll, but the closed generation's frames stay in HBM and are dropped (its
+// counters are zeroed on the device once its launches have finished; nothing is waited for on the host).
+extern "C" int mcrx_hip_discard(mcrx_hip_t q)
+{
+    if (!q) return fail(MCRX_EINVAL, "null handle");
+    const int c = q->gen ^ 1;
+    if (q->gen_closed[c]) {
+        HIPCHK(hipStreamWaitEvent(q->s_copy, q->ev_gen[c], 0));
+        HIPCHK(hipMemsetAsync(q->d_nrec[c], 0, 2 * sizeof(uint32_t), q->s_copy));
+        HIPCHK(hipMemsetAsync(q->d_arena_used[c], 0, 2 * sizeof(unsigned long long), q->s_copy));
+        HIPCHK(hipEventRecord(q->ev_gen[c], q->s_copy));
+        // the next launches into generation c start behind the zeroing
+        hipStream_t sa = (q->pipelined && q->scout) ? q->s_scout : q->stream;
+        HIPCHK(hipStreamWaitEvent(sa, q->ev_gen[c], 0));
+        q->gen_closed[c] = false; q->gen_used[c] = false;
+    }
+    close_generation(q);
+    q->pending_bound = 0;
+    return MCRX_OK;
+}
+
+extern "C" int mcrx_hip_spec_stats(mcrx_hip_t q, uint64_t *walked, uint64_t *adopted, int reset)
+{
+    if (!q) return fail(MCRX_EINVAL, "null handle");
+    HIPCHK(hipDeviceSynchronize());
+    uint32_t v[4] = { 0, 0, 0, 0 };
+    HIPCHK(hipMemcpy(v, q->d_stats, sizeof(v), hipMemcpyDeviceToHost));
+    if (walked) *walked = v[0];
+    if (adopted) *adopted = v[1];
+    if (reset) HIPCHK(hipMemset(q->d_stats, 0, sizeof(v)));
+    return MCRX_OK;
 }
 
 extern "C" int mcrx_hip_flush(mcrx_hip_t q)
@@ -714,18 +941,22 @@ extern "C" int mcrx_hip_next_frame(mcrx_hip_t q, mcrx_frame *out)
     out->mod_scheme = r.mod_scheme; out->mod_bps = r.mod_bps; out->check = r.check; out->fec0 = r.fec0; out->fec1 = r.fec1;
     out->num_framesyms = r.num_framesyms; out->end_sample = (uint64_t)r.end_sample;
     out->payload = r.payload_len ? q->arena_host.p + r.payload_off : nullptr;
-    out->framesyms = r.num_framesyms ? reinterpret_cast<const float *>(q->arena_host.p + r.syms_off) : nullptr;
+    out->framesyms = r.num_framesyms ? reinterpret_cast<const float *>(q->sarena_host.p + r.syms_off) : nullptr;
     return 1;
 }
 
 extern "C" int mcrx_hip_reset(mcrx_hip_t q)
 {
     // multichannelrx::Reset (lib/multichannelrx.cc:135-153): synchronizers and channelizer windows
-    // reset, partial block dropped, NCO keeps running.  Frames decoded so far stay deliverable.
+    // reset, partial block dropped, NCO keeps running.  Everything pushed before the Reset has been
+    // synchronized by the reference at this point, so the whole tiles still in the staging buffer are processed
+    // first and only the sub-tile tail (< 16 N samples; the reference drops < 2 N) is discarded.  Frames decoded
+    // so far stay deliverable.
     if (!q) return fail(MCRX_EINVAL, "null handle");
+    RC(process_staged(q));
     int rc = harvest(q);
     if (rc != MCRX_OK && rc != MCRX_EOVERFLOW) return rc;
     RC(restart_async(q, q->stream, false));
-    HIPCHK(hipStreamSynchronize(q->stream));
+    HIPCHK(hipDeviceSynchronize());
     return MCRX_OK;
 }

@@ -424,7 +424,8 @@ struct Walker {
     // working buffers: per channel (scout / serial walk) or per job (payload worker)
     uint8_t *bsoft, *btmpa, *btmpb, *bhbits;
     float2 *bsyms, *bR;
-    long long pre_off;          // >= 0: record space already reserved in the arena (payload worker)
+    long long pre_off;          // >= 0: record space already reserved in the payload arena (payload worker)
+    unsigned long long pre_soff;    // ... its framesyms in the symbol arena
     uint32_t pre_idx;           // ... and its record slot
     int64_t handoff_last;       // scout: last event index of the frame just handed off
     uint32_t jres;              // scout: job slot reserved at frame detection (0xFFFFFFFF: none)
@@ -457,11 +458,10 @@ struct Walker {
         btmpa = a.jtmp + (size_t)j * 2 * tstride; btmpb = btmpa + tstride;
         bR = a.jR + (size_t)j * c.M;
         s = job.s;
-        const unsigned long long pbytes = ((unsigned long long)s.payload_len + 15ull) & ~15ull;
         const unsigned long long off = job.arena_off;             // set by place_jobs_kernel
         if (off == ~0ull) return false;
-        pre_off = (long long)off; pre_idx = job.pad;
-        bsyms = reinterpret_cast<float2 *>(a.arena + off + pbytes);
+        pre_off = (long long)off; pre_soff = job.syms_off; pre_idx = job.pad;
+        bsyms = reinterpret_cast<float2 *>(a.sarena + job.syms_off);
         return true;
     }
 
@@ -690,18 +690,24 @@ struct Walker {
         const uint32_t nsym = (with_payload && !oversize) ? s.mod_len : 0u;
         const uint32_t plen = (with_payload && !oversize) ? s.payload_len : 0u;
         const unsigned long long pbytes = ((unsigned long long)plen + 15ull) & ~15ull;
-        const unsigned long long need = pbytes + 8ull * nsym;
-        uint32_t idx = 0xFFFFFFFFu; unsigned long long off = 0;
+        const unsigned long long sbytes = 8ull * nsym;
+        uint32_t idx = 0xFFFFFFFFu; unsigned long long off = 0, soff = 0;
         if (l == 0) {
-            if (pre_off >= 0) { off = (unsigned long long)pre_off; idx = pre_idx; }      // both placed by place_jobs_kernel
+            if (pre_off >= 0) { off = (unsigned long long)pre_off; soff = pre_soff; idx = pre_idx; }      // all placed by place_jobs_kernel
             else {
-                off = atomicAdd(a.arena_used, need);
-                if (off + need <= a.arena_cap) idx = atomicAdd(a.nrec, 1u);
+                off = atomicAdd(a.arena_used, pbytes);
+                soff = atomicAdd(a.arena_used + 1, sbytes);
+                if (off + pbytes <= a.arena_cap && soff + sbytes <= a.sarena_cap) idx = atomicAdd(a.nrec, 1u);
+                else {      // no room: give the space back, so that later, smaller frames of this interval still fit
+                    atomicAdd(a.arena_used, 0ull - pbytes);
+                    atomicAdd(a.arena_used + 1, 0ull - sbytes);
+                }
             }
             if (idx >= a.max_rec) { atomicAdd(a.nrec + 1, 1u); idx = 0xFFFFFFFFu; }
         }
         idx = (uint32_t)__shfl((int)idx, 0, WV);
         off = (unsigned long long)__shfl((long long)off, 0, WV);
+        soff = (unsigned long long)__shfl((long long)soff, 0, WV);
         if (idx == 0xFFFFFFFFu) return;
         if (l == 0) {
             FrameRec r;
@@ -713,7 +719,7 @@ struct Walker {
             r.mod_scheme = with_payload ? s.mod_scheme : 0u; r.mod_bps = with_payload ? s.bps : 0u;
             r.check = with_payload ? s.check : 0u; r.fec0 = with_payload ? s.fec0 : 0u; r.fec1 = with_payload ? s.fec1 : 0u;
             r.num_framesyms = nsym; r.end_sample = t_ev;
-            r.payload_off = off; r.syms_off = off + pbytes;
+            r.payload_off = off; r.syms_off = soff;
             a.rec[idx] = r;
         }
         if (with_payload && !oversize) {
@@ -722,7 +728,7 @@ struct Walker {
             if (copy_payload) for (uint32_t i = (uint32_t)l; i < plen; i += WV) dst[i] = src[i];
             if (pre_off < 0) {          // payload workers write framesyms straight into the record
                 const float2 *ss = bsyms;
-                float2 *ds = reinterpret_cast<float2 *>(a.arena + off + pbytes);
+                float2 *ds = reinterpret_cast<float2 *>(a.sarena + soff);
                 for (uint32_t i = (uint32_t)l; i < nsym; i += WV) ds[i] = ss[i];
             }
         }
@@ -736,7 +742,7 @@ struct Walker {
         const int64_t nsym = (int64_t)((s.mod_len + (uint32_t)c.M_data - 1) / (uint32_t)c.M_data);
         const int64_t t_last = t_ev + nsym * (int64_t)c.L;
         if (s.enc_len > c.max_enc_len || s.mod_len > c.max_syms || s.payload_len > c.max_payload_len || t_last >= a.end) return false;
-        if (l == 0) { PayloadJob jb; jb.s = s; jb.ch = ch; jb.pad = 0; jb.arena_off = 0; slot->job = jb; }
+        if (l == 0) { PayloadJob jb; jb.s = s; jb.ch = ch; jb.pad = 0; jb.arena_off = 0; jb.syms_off = 0; slot->job = jb; }
         handoff_last = t_last;
         return true;
     }
@@ -761,7 +767,7 @@ struct Walker {
         for (int e = 0; e < E; e++) if (k[e] >= 0) a.jR[(size_t)j * c.M + k[e]] = R[e];
         if (l == 0) {
             PayloadJob jb;
-            jb.s = s; jb.ch = ch; jb.pad = 0; jb.arena_off = 0;
+            jb.s = s; jb.ch = ch; jb.pad = 0; jb.arena_off = 0; jb.syms_off = 0;
             a.jobs[j] = jb;
         }
         handoff_last = t_last;
@@ -1406,7 +1412,7 @@ struct Walker {
     // and a ballot; the adopted slots are only noted (LDS) during the walk, and their parked jobs and
     // equalisers are copied into the job list in one pipelined pass after it.  Nothing on the scout's
     // serial chain waits for memory because of an adoption.
-    int64_t sp_start[2], sp_tlast[2]; uint32_t nadopted;
+    int64_t sp_start[2], sp_tlast[2]; uint32_t nadopted; uint32_t nwalked = 0;
     __device__ __forceinline__ void load_spec_headers()
     {
         const SpecSlot *sl = a.spec + (size_t)ch * MCRX_SPEC_MAX;
@@ -1542,8 +1548,9 @@ struct Walker {
             if (s.state != SY_RX) sync_event(t_ev);
             else {    // SY_RX
                 const int fr = fastp ? rx_event_fast(t_ev) : rx_event(t_ev);
-                if (fr == 1) { void_reservation(); reset_framesync(); s.timer = (uint32_t)L; }
+                if (fr == 1) { void_reservation(); reset_framesync(); s.timer = (uint32_t)L; nwalked++; }
                 else if (fr == 2) {
+                    nwalked++;
                     // payload handed to a worker: jump over it; liquid leaves the synchronizer in
                     // SEEK with timer = M+cp after the frame's last symbol
                     reset_framesync(); s.timer = (uint32_t)L; s.cur = handoff_last + 1;
@@ -1558,6 +1565,7 @@ struct Walker {
             printf("[prof] ch0 rx phases: load %lld  core %lld  derot+nco %lld  flex %lld (header decode %lld, hand-off %lld)\n", ph[0], ph[1], ph[2], ph[3], ph[4], ph[5]);
         void_reservation();
         publish_adopted();
+        if (a.stats && l == 0) { if (nwalked) atomicAdd(a.stats, nwalked); if (nadopted) atomicAdd(a.stats + 1, nadopted); }
         if (a.pred) {
             // continue the frame cadence past this buffer (a stream that goes on), then publish the predictions
             // (the state the next launch of a continuing stream starts in is known exactly, if it is SEEK)
@@ -1594,9 +1602,9 @@ __device__ __forceinline__ void launder(SyncArgs &a)
     LAUNDER(c.cod.crc_byte);
     LAUNDER(c.cod.crc_zadv); LAUNDER(c.cod.qam16_nb); LAUNDER(c.cod.qam64_nb);
     LAUNDER(chan); LAUNDER(st); LAUNDER(hbits); LAUNDER(R); LAUNDER(soft); LAUNDER(tmpa); LAUNDER(tmpb);
-    LAUNDER(syms); LAUNDER(rec); LAUNDER(arena); LAUNDER(nrec); LAUNDER(arena_used);
+    LAUNDER(syms); LAUNDER(rec); LAUNDER(arena); LAUNDER(sarena); LAUNDER(nrec); LAUNDER(arena_used);
     LAUNDER(jobs); LAUNDER(njobs); LAUNDER(jR); LAUNDER(jsoft); LAUNDER(jtmp);
-    LAUNDER(spec); LAUNDER(spec_R); LAUNDER(pred); LAUNDER(pred_n);
+    LAUNDER(spec); LAUNDER(spec_R); LAUNDER(pred); LAUNDER(pred_n); LAUNDER(stats);
 }
 #undef LAUNDER
 
@@ -1860,8 +1868,10 @@ __global__ __launch_bounds__(DK_T) void decode_kernel(SyncArgs a, uint32_t lds_s
 #define PJ_CAP 8192
 __global__ __launch_bounds__(PJ_T) void place_jobs_kernel(SyncArgs a)
 {
-    __shared__ unsigned long long part[PJ_T];       // (valid count << 40) | bytes, scanned together
-    __shared__ uint32_t need_l[PJ_CAP];
+    __shared__ unsigned long long part[PJ_T];       // (valid count << 40) | symbol bytes, scanned together
+    __shared__ uint32_t part2[PJ_T];                // payload bytes in 16-byte units
+    __shared__ uint32_t need_l[PJ_CAP];             // symbol-arena bytes of job j (0 = void slot: a live frame always has symbols)
+    __shared__ uint16_t pay_l[PJ_CAP];              // payload-arena bytes of job j in 16-byte units
     __shared__ uint32_t maxenc;
     if (threadIdx.x == 0) maxenc = 0;
     __syncthreads();
@@ -1869,17 +1879,18 @@ __global__ __launch_bounds__(PJ_T) void place_jobs_kernel(SyncArgs a)
     uint32_t nj = *a.njobs;
     if (nj > a.max_jobs) nj = a.max_jobs;
     if (threadIdx.x == 0 && a.njobs_next) *a.njobs_next = 0;
-    auto need_of = [&](uint32_t j) -> uint32_t {      // 0 = void slot (a live frame always has symbols)
+    auto need_of = [&](uint32_t j, uint32_t &pay16) -> uint32_t {
+        pay16 = 0;
         if (a.jobs[j].ch >= a.nch) return 0u;
-        const unsigned long long pb = ((unsigned long long)a.jobs[j].s.payload_len + 15ull) & ~15ull;
-        return (uint32_t)(pb + 8ull * a.jobs[j].s.mod_len);
+        pay16 = (a.jobs[j].s.payload_len + 15u) >> 4;
+        return 8u * a.jobs[j].s.mod_len;
     };
-    const unsigned long long base = *a.arena_used;
+    const unsigned long long base = a.arena_used[0], sbase = a.arena_used[1];
     const uint32_t rbase = a.nrec[0];
     if (nj <= PJ_CAP) {
         uint32_t me = 0;
         for (uint32_t j = threadIdx.x; j < nj; j += PJ_T) {                             // all requests in flight at once
-            need_l[j] = need_of(j);
+            uint32_t p16; need_l[j] = need_of(j, p16); pay_l[j] = (uint16_t)p16;
             const uint32_t e = a.jobs[j].ch < a.nch ? a.jobs[j].s.enc_len : 0u;
             me = e > me ? e : me;
         }
@@ -1888,50 +1899,58 @@ __global__ __launch_bounds__(PJ_T) void place_jobs_kernel(SyncArgs a)
         if (threadIdx.x == 0 && a.hint && maxenc) *a.hint = maxenc;                     // host-mapped: sizes the next launch's LDS
         const uint32_t per = (nj + PJ_T - 1) / PJ_T;
         const uint32_t j0 = threadIdx.x * per, j1 = (j0 + per < nj) ? j0 + per : nj;
-        unsigned long long mine = 0;
-        for (uint32_t j = j0; j < j1; j++) if (need_l[j]) mine += (1ull << 40) | need_l[j];
-        part[threadIdx.x] = mine;
+        unsigned long long mine = 0; uint32_t mine2 = 0;
+        for (uint32_t j = j0; j < j1; j++) if (need_l[j]) { mine += (1ull << 40) | need_l[j]; mine2 += pay_l[j]; }
+        part[threadIdx.x] = mine; part2[threadIdx.x] = mine2;
         __syncthreads();
         for (int o = 1; o < PJ_T; o <<= 1) {
             const unsigned long long v = (int)threadIdx.x >= o ? part[threadIdx.x - o] : 0ull;
+            const uint32_t v2 = (int)threadIdx.x >= o ? part2[threadIdx.x - o] : 0u;
             __syncthreads();
-            part[threadIdx.x] += v;
+            part[threadIdx.x] += v; part2[threadIdx.x] += v2;
             __syncthreads();
         }
         const unsigned long long tot = part[PJ_T - 1];
-        const unsigned long long tot_bytes = tot & ((1ull << 40) - 1), tot_cnt = tot >> 40;
-        if (base + tot_bytes <= a.arena_cap && rbase + tot_cnt <= a.max_rec) {
+        const unsigned long long tot_sym = tot & ((1ull << 40) - 1), tot_cnt = tot >> 40, tot_pay = 16ull * part2[PJ_T - 1];
+        if (base + tot_pay <= a.arena_cap && sbase + tot_sym <= a.sarena_cap && rbase + tot_cnt <= a.max_rec) {
             const unsigned long long excl = part[threadIdx.x] - mine;
-            unsigned long long off = base + (excl & ((1ull << 40) - 1));
+            unsigned long long soff = sbase + (excl & ((1ull << 40) - 1));
+            unsigned long long off = base + 16ull * (part2[threadIdx.x] - mine2);
             uint32_t ridx = rbase + (uint32_t)(excl >> 40);
-            for (uint32_t j = j0; j < j1; j++) if (need_l[j]) { a.jobs[j].arena_off = off; a.jobs[j].pad = ridx++; off += need_l[j]; }
-            if (threadIdx.x == 0) { *a.arena_used = base + tot_bytes; a.nrec[0] = rbase + (uint32_t)tot_cnt; }
+            for (uint32_t j = j0; j < j1; j++) if (need_l[j]) {
+                a.jobs[j].arena_off = off; a.jobs[j].syms_off = soff; a.jobs[j].pad = ridx++;
+                off += 16ull * pay_l[j]; soff += need_l[j];
+            }
+            if (threadIdx.x == 0) { a.arena_used[0] = base + tot_pay; a.arena_used[1] = sbase + tot_sym; a.nrec[0] = rbase + (uint32_t)tot_cnt; }
             return;
         }
         __syncthreads();
     }
     // not everything fits (or more jobs than the staging holds): exact sequential placement
     if (threadIdx.x == 0) {
-        unsigned long long off = base; uint32_t ridx = rbase, dropped = 0;
+        unsigned long long off = base, soff = sbase; uint32_t ridx = rbase, dropped = 0;
         for (uint32_t j = 0; j < nj; j++) {
-            const uint32_t nd = need_of(j);
+            uint32_t p16; const uint32_t nd = need_of(j, p16);
             if (!nd) continue;
-            if (off + nd <= a.arena_cap && ridx < a.max_rec) { a.jobs[j].arena_off = off; a.jobs[j].pad = ridx++; off += nd; }
-            else { a.jobs[j].arena_off = ~0ull; dropped++; }
+            if (off + 16ull * p16 <= a.arena_cap && soff + nd <= a.sarena_cap && ridx < a.max_rec) {
+                a.jobs[j].arena_off = off; a.jobs[j].syms_off = soff; a.jobs[j].pad = ridx++; off += 16ull * p16; soff += nd;
+            }
+            else { a.jobs[j].arena_off = ~0ull; a.jobs[j].syms_off = ~0ull; dropped++; }
         }
-        *a.arena_used = off; a.nrec[0] = ridx;
+        a.arena_used[0] = off; a.arena_used[1] = soff; a.nrec[0] = ridx;
         if (dropped) atomicAdd(a.nrec + 1, dropped);
     }
 }
 
 // restart in one launch: synchronizers back to SEEK, channelizer history cleared, result counters zeroed
 __global__ void sync_reset_kernel(ChanState *st, uint32_t nch, int64_t cur, float4 *z0, float4 *z1, size_t nz,
-                                  uint32_t *nrec, unsigned long long *arena_used)
+                                  uint32_t *nrec, unsigned long long *arena_used, uint32_t *pred_n)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nz) { const float4 z = make_float4(0.f, 0.f, 0.f, 0.f); if (z0) z0[i] = z; if (z1) z1[i] = z; }
-    if (i == 0) { if (nrec) { nrec[0] = 0; nrec[1] = 0; } if (arena_used) *arena_used = 0; }
+    if (i == 0) { if (nrec) { nrec[0] = 0; nrec[1] = 0; } if (arena_used) { arena_used[0] = 0; arena_used[1] = 0; } }
     if (i >= nch) return;
+    if (pred_n) pred_n[i] = 0;          // a restarted stream has no history to predict frame positions from
     ChanState z;
     memset(&z, 0, sizeof(z));
     z.state = SY_SEEK; z.cur = cur; z.g0 = 1.0f; z.fstate = FX_HEADER;
@@ -1939,12 +1958,12 @@ __global__ void sync_reset_kernel(ChanState *st, uint32_t nch, int64_t cur, floa
 }
 
 hipError_t sync_reset_launch(ChanState *st, uint32_t nch, int64_t cur, float2 *hist0, float2 *hist1, size_t hist_n,
-                             uint32_t *nrec, unsigned long long *arena_used, hipStream_t stream)
+                             uint32_t *nrec, unsigned long long *arena_used, uint32_t *pred_n, hipStream_t stream)
 {
     const size_t nz = hist_n / 2;                               // float4 = two cf32
     const size_t n = nz > nch ? nz : nch;
     hipLaunchKernelGGL(sync_reset_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, st, nch, cur,
-                       reinterpret_cast<float4 *>(hist0), reinterpret_cast<float4 *>(hist1), nz, nrec, arena_used);
+                       reinterpret_cast<float4 *>(hist0), reinterpret_cast<float4 *>(hist1), nz, nrec, arena_used, pred_n);
     return hipGetLastError();
 }
 

@@ -35,6 +35,7 @@ struct worker {
     void start()
     {
         std::unique_lock<std::mutex> lk(mu);
+        if (running) { cv.notify_all(); return; }   // already started: the reference only re-signals its condition (:320-333)
         cv.wait(lk, [this] { return idle; });
         running = true;
         cv.notify_all();

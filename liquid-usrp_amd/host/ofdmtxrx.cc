@@ -16,6 +16,7 @@ struct ofdmtxrx::impl {
     unsigned int M, cp_len, taper_len;
     mctx_hip_t fg;                                  // frame generator
     mcrx_hip_t fs;                                  // frame synchronizer (single_channel handle)
+    std::recursive_mutex fs_mu;                               // the C-ABI allows one caller per handle: worker (execute/deliver/flush) vs reset_rx()
     framesync_callback callback; void *userdata;
     int mod, fec0, fec1;
     float tx_gain;
@@ -62,10 +63,12 @@ struct ofdmtxrx::impl {
                 size_t n = usrp_rx->get_device()->recv(&buffer.front(), buffer.size(), md,
                                                        uhd::io_type_t::COMPLEX_FLOAT32, uhd::device::RECV_MODE_ONE_PACKET);
                 // the synchronizer sees every sample in order (lib/ofdmtxrx.cc:620-626); frames surface per batch
+                std::lock_guard<std::recursive_mutex> fl(fs_mu);
                 int rc = mcrx_hip_execute_host(fs, reinterpret_cast<const float *>(&buffer.front()), n);
                 if (rc != MCRX_OK && rc != MCRX_EOVERFLOW) { fprintf(stderr, "ofdmtxrx rx worker: %s\n", mcrx_hip_last_error()); rx_running = false; }
                 deliver();
             }
+            std::lock_guard<std::recursive_mutex> fl(fs_mu);
             mcrx_hip_flush(fs);
             deliver();
         }
@@ -214,6 +217,9 @@ void ofdmtxrx::set_rx_antenna(char *_rx_antenna) { pimpl->usrp_rx->set_rx_antenn
 
 void ofdmtxrx::reset_rx()
 {
+    // the worker may be inside execute/deliver on the same handle (the reference's race only resets state; here
+    // a harvest reallocates host buffers): serialise the two
+    std::lock_guard<std::recursive_mutex> fl(pimpl->fs_mu);
     if (mcrx_hip_reset(pimpl->fs) != MCRX_OK) { fprintf(stderr, "ofdmtxrx::reset_rx: %s\n", mcrx_hip_last_error()); throw 0; }
 }
 

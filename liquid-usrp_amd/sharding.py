@@ -2,13 +2,19 @@
 
 The polyphase analysis bank couples all channels inside one K-point FFT but is independent
 across time blocks (13 blocks of FIR halo); the synchronizers are independent per channel but
-serial in time.  So rank r channelizes time slab r, and one all-to-all turns the time-sharded
-channelizer output into channel shards:
+serial in time.  So the stream is cut into sub-slabs of `sub_blocks` blocks that go round robin
+to the ranks -- sub-slab u to rank u % G -- and every round of G sub-slabs ends in one all-to-all
+that turns the time-sharded channelizer output into channel shards:
 
-    channelize:  out[g][tile][c][8]   g = destination rank, channel = g*Cg + c   (rank r, slab r)
+    channelize:  out[g][tile][c][8]   g = destination rank, channel = g*Cg + c   (rank r, sub-slab c*G + r)
     all-to-all:  chunk g of rank r  ->  chunk r of rank g
-    sync:        chan[s][tile][c][8]  s = source rank = time slab  ==  [global tile][c][8]
+    sync:        chan[s][tile][c][8]  s = source rank  ==  [tile of the round][c][8], contiguous in time
 
+Rounds are pipelined on three streams with rotating buffers:
+
+    channelize(c+1)  ||  all_to_all(c)  ||  synchronizers(c-1)
+
+(the synchronizer stage itself overlaps its acquisition and payload kernels inside the handle).
 No collective other than this exchange is on the data path.
 The backend object supplies the two compute stages (the HIP library in production; tests
 inject a CPU stand-in so the orchestration runs under gloo without a GPU).
@@ -44,13 +50,98 @@ def exchange(out, recv, world, dist):
 
 
 def step(backend, iq, slab_blocks, rank, world, dist, out, recv, halo=None, stream=None):
-    """One pass over this rank's slab: restart, channelize, exchange, synchronize."""
+    """Unpipelined form, one slab per rank: restart, channelize, exchange, synchronize (each stage after the
+    other on `stream`; kept for the stage-level tests -- bench.py uses Pipeline)."""
     backend.restart(stream)
     first = slab_first_sample(rank, slab_blocks, backend.N)
     backend.channelize(iq, slab_blocks, first, out, groups=world, d_halo=halo, stream=stream)
     chan = exchange(out, recv, world, dist)
     backend.sync(chan, 0, world * slab_blocks, stream=stream)
     return chan
+
+
+class Pipeline(object):
+    """Round-robin time sharding with the exchange overlapped (see the module docstring).
+
+    push(iq_sub, halo) runs one round: this rank's sub-slab of the round (`sub_blocks` blocks, the 13 blocks that
+    precede it in the stream as `halo`, None = zeros), the all-to-all, and the synchronizers of the rank's channel
+    shard over the round's G*sub_blocks blocks.  Buffers rotate over `nbuf` rounds; nothing waits on the host.
+    Tensors are complex64 on the backend's device (CUDA: three torch streams; CPU/gloo: everything in order).
+    """
+
+    def __init__(self, backend, rank, world, dist, num_channels, sub_blocks, hist_tiles, device=None, nbuf=3):
+        import torch
+        assert sub_blocks % TILE == 0 and num_channels % world == 0
+        self.be, self.rank, self.world, self.dist = backend, rank, world, dist
+        self.N, self.K, self.Tc, self.hist, self.nbuf = num_channels, 2 * num_channels, sub_blocks, hist_tiles, nbuf
+        self.cg = num_channels // world
+        self.tiles = sub_blocks // TILE
+        self.cuda = device is not None and torch.device(device).type == "cuda"
+        per = self.tiles * self.cg * TILE
+        self.out = [torch.zeros(world * per, dtype=torch.complex64, device=device) for _ in range(nbuf)]
+        self.recv = [torch.zeros((hist_tiles * self.cg * TILE) + world * per, dtype=torch.complex64, device=device)
+                     for _ in range(nbuf)]
+        self.hist_elems = hist_tiles * self.cg * TILE
+        self.rounds = 0
+        self.tickets = [None] * nbuf
+        if self.cuda:
+            self.sA, self.sB, self.sC = (torch.cuda.Stream(device=device) for _ in range(3))
+            self.evA = [torch.cuda.Event() for _ in range(nbuf)]
+            self.evB = [torch.cuda.Event() for _ in range(nbuf)]
+            self.evC = [torch.cuda.Event() for _ in range(nbuf)]
+        else:
+            self.sA = self.sB = self.sC = None
+
+    def first_sample(self, rnd=None):
+        rnd = self.rounds if rnd is None else rnd
+        return (rnd * self.world + self.rank) * self.Tc * self.K
+
+    def push(self, iq_sub, halo=None):
+        import torch
+        c, i, nb = self.rounds, self.rounds % self.nbuf, self.nbuf
+        out, recv = self.out[i], self.recv[i]
+        new = recv[self.hist_elems:]
+        # ---- A: channelize this rank's sub-slab into per-destination groups
+        if self.cuda:
+            if c >= nb:
+                self.sA.wait_event(self.evB[i])                 # the exchange that last read out[i]
+            with torch.cuda.stream(self.sA):
+                self.be.channelize(iq_sub, self.Tc, self.first_sample(c), out, groups=self.world, d_halo=halo, stream=self.sA)
+                self.evA[i].record(self.sA)
+        else:
+            self.be.channelize(iq_sub, self.Tc, self.first_sample(c), out, groups=self.world, d_halo=halo, stream=None)
+        # ---- B: time shards -> channel shards
+        if self.cuda:
+            self.sB.wait_event(self.evA[i])
+            if c >= nb:
+                self.be.stream_wait(self.sB, launch=self.tickets[i])   # the synchronizers that last read recv[i]
+                self.sB.wait_event(self.evC[(i + 1) % nb])             # ... and the history copy that read its tail
+            with torch.cuda.stream(self.sB):
+                if self.world == 1:
+                    new.copy_(out, non_blocking=True)
+                else:
+                    exchange(out, new, self.world, self.dist)
+                self.evB[i].record(self.sB)
+        else:
+            if self.world == 1:
+                new.copy_(out)
+            else:
+                exchange(out, new, self.world, self.dist)
+        # ---- C: synchronizer history in front (tail of the previous round), then the bank over the round
+        first_chan = c * self.world * self.Tc - self.hist * TILE
+        nsamp = self.hist * TILE + self.world * self.Tc
+        if self.cuda:
+            self.sC.wait_event(self.evB[i])
+            with torch.cuda.stream(self.sC):
+                if c > 0:
+                    recv[:self.hist_elems].copy_(self.recv[(c - 1) % nb][-self.hist_elems:], non_blocking=True)
+                self.evC[i].record(self.sC)
+                self.tickets[i] = self.be.sync(recv, first_chan, nsamp, stream=self.sC)
+        else:
+            if c > 0:
+                recv[:self.hist_elems].copy_(self.recv[(c - 1) % nb][-self.hist_elems:])
+            self.tickets[i] = self.be.sync(recv, first_chan, nsamp, stream=None)
+        self.rounds += 1
 
 
 def pack_groups(blocks, world):
