@@ -148,7 +148,8 @@ int  mcrx_hip_kernel_stats(mcrx_hip_t q, double ms_total[MCRX_NKERNELS], uint64_
 
 const char *mcrx_hip_last_error(void);
 
-/* ---- front-end multi-stage resampler (decimating, 0 < rate <= 1) ----------------------
+/* ---- multi-stage resampler: decimating front end (0 < rate <= 1) and the transmit side's interpolator
+ *      (rate > 1: msresamp_crcf_create(2.0, 60), src/flexframe_tx.cc:170) -------------
  * Replaces msresamp_crcf_create(rate, As) / _execute / _destroy as the reference applications
  * call it in front of a synchronizer (src/flexframe_rx.cc:179,240,275; rate computed as in
  * src/multichannel_rx.cc:129-138).  Buffers are device pointers (cf32). */

@@ -16,7 +16,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIBPATH = os.path.join(_HERE, "lib", "libmcrx_hip.so")
+_LIBPATH = os.environ.get("MCRX_LIB") or os.path.join(_HERE, "lib", "libmcrx_hip.so")      # (MCRX_LIB: A/B builds)
 
 MCRX_OK, MCRX_EINVAL, MCRX_ENOMEM, MCRX_EHIP, MCRX_EUNSUPP, MCRX_EOVERFLOW, MCRX_EBUSY = 0, -1, -2, -3, -4, -5, -6
 TILE = 8
@@ -357,7 +357,8 @@ class multichannelrx(object):
 class msresamp(object):
     """GPU mirror of liquid's msresamp_crcf as the reference front ends use it
     (src/flexframe_rx.cc:179,240): msresamp(rate, As); execute(x) -> y, with x / y torch
-    complex64 CUDA tensors (IQ stays in HBM).  Decimating rates only (0 < rate <= 1)."""
+    complex64 CUDA tensors (IQ stays in HBM).  rate <= 1 decimates (receive front ends), rate > 1 interpolates
+    (the transmit applications' msresamp_crcf_create(2.0, 60), src/flexframe_tx.cc:170)."""
 
     def __init__(self, rate, As=60.0):
         self._h = C.c_void_p()

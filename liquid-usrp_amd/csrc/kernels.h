@@ -75,6 +75,9 @@ struct ChanState {
     uint32_t payload_len, mod_scheme, bps, check, fec0, fec1, enc_len, mod_len;
     int32_t header_valid;
     uint32_t hw[4];             // decoded header bytes 0..13, little-endian words
+    // frame cadence seen so far (speculation only; never part of the synchronizer's decisions)
+    uint32_t period_hint;       // distance between the last two consecutive post-frame states (0: none yet)
+    int64_t last_fresh;         // the most recent post-frame state's position
 };
 
 // one decoded frame (device side); host copies payload / framesyms from the slot arrays
@@ -98,8 +101,11 @@ struct PayloadJob {
 
 // Frame-level speculation in the scout.  After a frame's last symbol liquid leaves the synchronizer in one
 // fixed state (SEEK, timer = M+cp, everything else reset), so a frame that starts where another one ended can be
-// acquired by an independent wave -- if the position is known.  Positions are predicted from where frames
-// ended in the previous launch (plus the cadence continued past the buffer); a speculative wave per prediction
+// acquired by an independent wave -- if the position is known.  Positions are predicted from the frame cadence:
+// the state the previous launch ended in and its cadence continued into this buffer, and -- because an idle gap
+// or a new burst breaks that cadence -- re-anchored inside the launch: the acquisition runs in rounds
+// (speculative waves, then scouts), and in all but the last round a scout that had to acquire a frame itself
+// stops right behind it and predicts the following frames from there.  A speculative wave per prediction
 // runs detection .. header decode from the fresh state and parks the hand-off in a SpecSlot; the per-channel
 // scout adopts a slot when it arrives at exactly that position in exactly that state, else walks on as before.
 #define MCRX_SPEC_MAX 128
@@ -148,6 +154,8 @@ struct SyncArgs {
     uint32_t *spec_hint;                 // host-mapped word: largest prediction count, sizes the next launch's grid
     uint32_t *hint;             // host-mapped word: longest coded frame (bytes) among this launch's jobs
     uint32_t enc_hint;          // the value the host last saw there (0: none yet)
+    int stop_after_walk;        // 1: a scout that had to acquire a frame itself stops behind it and predicts the frames that
+                                //    follow from there (cadence re-anchored inside the launch); the next round continues
     uint32_t *stats;            // [0] frames the scouts acquired themselves, [1] frames adopted from speculative waves (NULL: not counted)
     int no_fast;               // MCRX_NO_FAST=1: payload workers use the general symbol path (A/B experiments)
 };

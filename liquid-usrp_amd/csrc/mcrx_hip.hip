@@ -132,7 +132,7 @@ struct mcrx_hip_s {
     bool spec = false;
     uint32_t *h_hint = nullptr, *d_hint = nullptr;     // pinned, device-mapped: longest coded frame of the last launch
     uint8_t *d_jsoft[MCRX_SLOTS] = {}, *d_jtmp[MCRX_SLOTS] = {};
-    bool scout = true;
+    bool scout = true; int scout_rounds = 2;
     // streaming state
     uint64_t total_samples = 0;             // wideband samples accepted since creation (NCO phase)
     uint64_t stage_first = 0;               // absolute index of h_stage[0]
@@ -393,6 +393,7 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
         // speculative acquisition (lean path only): slots, their equalisers, the prediction lists
         const bool lean = q->sc.log2M >= 6 && q->sc.M == 64 * q->sc.E && q->sc.M_pilot <= 64;
         q->spec = lean && q->d_hint && getenv("MCRX_NO_SPEC") == nullptr;
+        if (getenv("MCRX_SCOUT_ROUNDS")) q->scout_rounds = std::max(1, std::min(8, atoi(getenv("MCRX_SCOUT_ROUNDS"))));
         if (q->spec) {
             if ((rc = q->alloc(&q->d_spec, (size_t)q->nch * MCRX_SPEC_MAX))) return bail(rc);
             if ((rc = q->alloc(&q->d_spec_R, (size_t)q->nch * MCRX_SPEC_MAX * M))) return bail(rc);
@@ -412,7 +413,12 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     // (blocking streams: work a caller puts on the legacy default stream -- e.g. a torch copy of a result buffer --
     //  still orders against them, as it did when everything ran on one stream)
     if (hipStreamCreate(&q->stream) != hipSuccess) return bail(fail(MCRX_EHIP, "hipStreamCreate failed"));
-    if (hipStreamCreate(&q->s_scout) != hipSuccess) return bail(fail(MCRX_EHIP, "hipStreamCreate failed"));
+    {   // the acquisition stream carries the serial per-channel chains every payload launch waits for: highest priority
+        int least = 0, greatest = 0;
+        const bool prio = getenv("MCRX_NO_PRIO") == nullptr && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least;
+        if ((prio ? hipStreamCreateWithPriority(&q->s_scout, hipStreamDefault, greatest) : hipStreamCreate(&q->s_scout)) != hipSuccess)
+            return bail(fail(MCRX_EHIP, "hipStreamCreate failed"));
+    }
     if (hipStreamCreate(&q->s_work) != hipSuccess) return bail(fail(MCRX_EHIP, "hipStreamCreate failed"));
     if (hipStreamCreateWithFlags(&q->s_copy, hipStreamNonBlocking) != hipSuccess) return bail(fail(MCRX_EHIP, "hipStreamCreate failed"));
     {
@@ -439,6 +445,11 @@ extern "C" int mcrx_hip_destroy(mcrx_hip_t q)
     (void)hipDeviceSynchronize();
     if (getenv("MCRX_DEBUG") && (atoi(getenv("MCRX_DEBUG")) & 8))
         fprintf(stderr, "mcrx bulk path: copy %.4f s, launch %.4f s, waiting for the GPU %.4f s, harvest (incl. that wait) %.4f s of which frame D2H %.4f s for %.1f MB, host arena growth %.4f s\n", q->t_copy, q->t_run, q->t_wait, q->t_harvest, q->t_d2h, q->b_d2h / 1e6, q->t_grow);
+    if (getenv("MCRX_DEBUG") && (atoi(getenv("MCRX_DEBUG")) & 32) && q->d_stats) {
+        uint32_t v[4] = {};
+        (void)hipMemcpy(v, q->d_stats, sizeof(v), hipMemcpyDeviceToHost);
+        fprintf(stderr, "mcrx stats: walked %u adopted %u last failed crc: key %08x computed %08x\n", v[0], v[1], v[2], v[3]);
+    }
     for (void *p : q->owned) (void)hipFree(p);
     for (int i = 0; i < MCRX_SLOTS; i++) if (q->d_chan[i]) (void)hipFree(q->d_chan[i]);
     if (q->h_stage) (void)hipHostFree(q->h_stage);
@@ -532,8 +543,14 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     }
     if (!q->scout) HIPCHK(hipMemsetAsync(a.njobs, 0, sizeof(uint32_t), sa));     // (with the scout, the previous launch's placement kernel zeroed it)
     RC(q->ev_begin(1, sa));
-    HIPCHK(sync_launch_spec(a, sa));          // speculative waves first, then the per-channel scouts that adopt them
-    HIPCHK(sync_launch(a, sa));
+    // acquisition rounds: speculative waves first, then the per-channel scouts that adopt them; in all but the last
+    // round a scout that had to acquire a frame itself stops behind it and re-anchors the predictions there
+    const int rounds = q->spec ? q->scout_rounds : 1;
+    for (int r = 0; r < rounds; r++) {
+        a.stop_after_walk = (r + 1 < rounds) ? 1 : 0;
+        HIPCHK(sync_launch_spec(a, sa));
+        HIPCHK(sync_launch(a, sa));
+    }
     RC(q->ev_end(1, sa));
     if (q->scout) {
         RC(q->ev_begin(2, sa));               // record placement

@@ -308,6 +308,17 @@ __device__ bool packet_decode(const CodingDev cod, bool soft_mode, bool scramble
     return crc32_wave(cod, tmpb, n_msg) == key;
 }
 
+// The same behind a call boundary, for the per-channel scout: it decodes a packet itself only when a frame straddles
+// pushes, and its kernel is already at the register file's limit (256 VGPRs + AGPR and scratch spills) -- inlined
+// there, the decoder's live ranges land in the middle of that pressure (and a build of it came out
+// mis-scheduled: right bytes, wrong CRC verdict, depending on unrelated edits).
+__device__ __attribute__((noinline)) bool packet_decode_call(const CodingDev *cod, bool soft_mode, bool scrambled, unsigned n_msg,
+                                                             unsigned crc, unsigned fec0, unsigned fec1,
+                                                             uint8_t *soft, uint8_t *tmpa, uint8_t *tmpb)
+{
+    return packet_decode(*cod, soft_mode, scrambled, n_msg, crc, fec0, fec1, soft, tmpa, tmpb);
+}
+
 // ------------------------------------------------------------------ modem
 __device__ __forceinline__ unsigned gray_dec_d(unsigned x) { unsigned y = x; while (x >>= 1) y ^= x; return y; }
 __device__ __forceinline__ cfd qam_point(unsigned sym, unsigned mq, float alpha)
@@ -708,6 +719,7 @@ struct Walker {
         idx = (uint32_t)__shfl((int)idx, 0, WV);
         off = (unsigned long long)__shfl((long long)off, 0, WV);
         soff = (unsigned long long)__shfl((long long)soff, 0, WV);
+        if ((a.debug & 16) && l == 0) printf("[emit] ch %u t_ev %lld payload %d valid %d placed %d idx %u off %llu len %u\n", ch, (long long)t_ev, (int)with_payload, (int)payload_valid, (int)(pre_off >= 0), idx, off, plen);
         if (idx == 0xFFFFFFFFu) return;
         if (l == 0) {
             FrameRec r;
@@ -797,7 +809,7 @@ struct Walker {
         __syncthreads();
         for (int i = l; i < MCRX_HDR_SYMS; i += WV) soft[i] = hb[i] ? 255 : 0;
         __syncthreads();
-        bool ok = packet_decode(c.cod, false, true, MCRX_HDR_DEC, 6, 7, 1, soft, ta, tb);
+        bool ok = packet_decode_call(&c.cod, false, true, MCRX_HDR_DEC, 6, 7, 1, soft, ta, tb);
 #pragma unroll
         for (int w = 0; w < 4; w++) {
             uint32_t v = 0;
@@ -884,8 +896,8 @@ struct Walker {
             bool valid = false;
             if (!oversize) {
                 __syncthreads();
-                valid = packet_decode(c.cod, c.payload_soft != 0, false, s.payload_len, s.check, s.fec0, s.fec1, soft,
-                                      btmpa, btmpb);
+                valid = packet_decode_call(&c.cod, c.payload_soft != 0, false, s.payload_len, s.check, s.fec0, s.fec1, soft,
+                                           btmpa, btmpb);
             }
             emit(t_ev, true, valid, oversize);
             return 1;
@@ -1514,6 +1526,7 @@ struct Walker {
         const int M = c.M, M2 = c.M2, L = c.L;
         long long prof_cyc[5] = {0, 0, 0, 0, 0}; int prof_n[5] = {0, 0, 0, 0, 0};
         uint32_t npred = 0, nfresh = 0; int64_t pred_prev = 0, pred_last = 0; bool entry = true;
+        bool walked_now = false, stopped = false;
         nadopted = 0;
         if (a.spec_cap) load_spec_headers();
         while (true) {
@@ -1548,15 +1561,16 @@ struct Walker {
             if (s.state != SY_RX) sync_event(t_ev);
             else {    // SY_RX
                 const int fr = fastp ? rx_event_fast(t_ev) : rx_event(t_ev);
-                if (fr == 1) { void_reservation(); reset_framesync(); s.timer = (uint32_t)L; nwalked++; }
+                if (fr == 1) { void_reservation(); reset_framesync(); s.timer = (uint32_t)L; nwalked++; walked_now = true; }
                 else if (fr == 2) {
-                    nwalked++;
+                    nwalked++; walked_now = true;
                     // payload handed to a worker: jump over it; liquid leaves the synchronizer in
                     // SEEK with timer = M+cp after the frame's last symbol
                     reset_framesync(); s.timer = (uint32_t)L; s.cur = handoff_last + 1;
                 }
             }
             if (a.debug & 2) { prof_cyc[st_in] += (long long)__builtin_readcyclecounter() - tk0; prof_n[st_in]++; }
+            if (walked_now && a.stop_after_walk && a.pred) { stopped = true; break; }
         }
         if ((a.debug & 2) && l == 0 && ch == 0)
             printf("[prof] ch0 cycles/events  seek %lld/%d  s0a %lld/%d  s0b %lld/%d  s1 %lld/%d  rx %lld/%d\n",
@@ -1567,17 +1581,36 @@ struct Walker {
         publish_adopted();
         if (a.stats && l == 0) { if (nwalked) atomicAdd(a.stats, nwalked); if (nadopted) atomicAdd(a.stats + 1, nadopted); }
         if (a.pred) {
-            // continue the frame cadence past this buffer (a stream that goes on), then publish the predictions
-            // (the state the next launch of a continuing stream starts in is known exactly, if it is SEEK)
-            if (s.state == SY_SEEK && npred < MCRX_SPEC_MAX) { if (l == 0) a.pred[(size_t)ch * MCRX_SPEC_MAX + npred] = spec_key(s.cur, s.timer); npred++; }
-            const int64_t period = pred_last - pred_prev;
-            if (nfresh >= 2 && period > 0)
-                for (int64_t p = pred_last + period; npred < MCRX_SPEC_MAX && p < a.end + (a.end - a.buf_first); p += period) {
-                    if (l == 0) a.pred[(size_t)ch * MCRX_SPEC_MAX + npred] = spec_key(p, (uint32_t)L);
-                    npred++;
+            const int64_t period_seen = pred_last - pred_prev;
+            if (nfresh >= 2 && period_seen > 0 && period_seen < (int64_t)0x7fffffff) s.period_hint = (uint32_t)period_seen;
+            if (nfresh >= 1) s.last_fresh = pred_last;
+            const int64_t P = (int64_t)s.period_hint;
+            if (stopped) {
+                // this round ends behind a frame the scout acquired itself: the next round's speculative waves get the
+                // exact state it stands in, and the cadence continued from here to the end of the buffer
+                s.last_fresh = s.cur;
+                if (l == 0) a.pred[(size_t)ch * MCRX_SPEC_MAX] = spec_key(s.cur, s.timer);
+                npred = 1;
+                if (P > 0)
+                    for (int64_t p = s.cur + P; npred < MCRX_SPEC_MAX && p < a.end; p += P) {
+                        if (l == 0) a.pred[(size_t)ch * MCRX_SPEC_MAX + npred] = spec_key(p, (uint32_t)L);
+                        npred++;
+                    }
+            } else {
+                // the state the next launch of a continuing stream starts in is known exactly, if it is SEEK; then the
+                // cadence continued past this buffer
+                if (s.state == SY_SEEK && npred < MCRX_SPEC_MAX) { if (l == 0) a.pred[(size_t)ch * MCRX_SPEC_MAX + npred] = spec_key(s.cur, s.timer); npred++; }
+                if (P > 0 && s.last_fresh > 0) {
+                    int64_t p = s.last_fresh + P;
+                    if (p < s.cur) p += (s.cur - p + P - 1) / P * P;
+                    for (; npred < MCRX_SPEC_MAX && p < a.end + (a.end - a.buf_first); p += P) {
+                        if (l == 0) a.pred[(size_t)ch * MCRX_SPEC_MAX + npred] = spec_key(p, (uint32_t)L);
+                        npred++;
+                    }
                 }
+            }
             if (l == 0) { a.pred_n[ch] = npred; if (a.spec_hint && npred > *a.spec_hint) *a.spec_hint = npred; }
-            if ((a.debug & 4) && l == 0 && ch == 0) printf("[spec] ch0 predictions %u adopted %u spec_cap %u\n", npred, nadopted, a.spec_cap);
+            if ((a.debug & 4) && l == 0 && ch == 0) printf("[spec] ch0 predictions %u adopted %u walked %u stopped %d spec_cap %u\n", npred, nadopted, nwalked, (int)stopped, a.spec_cap);
         }
         // a header in progress continues in the next launch: its bits move from LDS to the channel's HBM slot
         if (fastp && s.state == SY_RX && s.fstate == FX_HEADER && s.header_symbol_index > 0)

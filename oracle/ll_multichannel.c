@@ -248,7 +248,8 @@ typedef struct { unsigned m; float *h1; ll_cf *w0, *w1; } ll_resamp2;   /* half-
 
 struct ll_msresamp_s {
     float rate, As;
-    unsigned num_stages;         /* half-band decimation stages (rate < 0.5) */
+    int interp;                  /* rate > 1: arbitrary stage first, then half-band interpolators */
+    unsigned num_stages;         /* half-band stages: decimators (rate < 0.5) or interpolators (rate > 2) */
     ll_resamp2 *hb;
     ll_cf *hb_buf; unsigned hb_count;
     /* arbitrary stage */
@@ -285,16 +286,32 @@ static ll_cf resamp2_decim(ll_resamp2 *r, ll_cf x0, ll_cf x1)
     return y;
 }
 
+/* half-band interpolator (liquid resamp2_crcf_interp_execute): delay branch first, filter branch second */
+static void resamp2_interp(ll_resamp2 *r, ll_cf x, ll_cf *y)
+{
+    unsigned n = 2 * r->m;
+    memmove(r->w0, r->w0 + 1, sizeof(ll_cf) * (n - 1)); r->w0[n - 1] = x;
+    y[0] = r->w0[r->m - 1];
+    memmove(r->w1, r->w1 + 1, sizeof(ll_cf) * (n - 1)); r->w1[n - 1] = x;
+    ll_cf y1 = { 0, 0 };
+    for (unsigned i = 0; i < n; i++) { y1.re += r->h1[i] * r->w1[i].re; y1.im += r->h1[i] * r->w1[i].im; }
+    y[1] = y1;
+}
+
 ll_msresamp ll_msresamp_create(float rate, float As)
 {
-    if (rate <= 0.0f || rate > 1.0f) return NULL;       /* decimating front end only */
+    if (!(rate > 0.0f) || rate > 1024.0f) return NULL;
     ll_msresamp q = (ll_msresamp)calloc(1, sizeof(*q));
     q->rate = rate; q->As = As;
     q->rate_arb = (double)rate;
-    while (q->rate_arb < 0.5) { q->num_stages++; q->rate_arb *= 2.0; }
+    q->interp = rate > 1.0f;
+    /* liquid msresamp_crcf_create: the arbitrary stage works in [0.5, 1] (decimating) or (1, 2] (interpolating,
+     * as the transmit applications use it: src/flexframe_tx.cc:170 msresamp_crcf_create(2.0, 60)) */
+    if (q->interp) while (q->rate_arb > 2.0) { q->num_stages++; q->rate_arb *= 0.5; }
+    else           while (q->rate_arb < 0.5) { q->num_stages++; q->rate_arb *= 2.0; }
     q->hb = (ll_resamp2 *)calloc(q->num_stages ? q->num_stages : 1, sizeof(ll_resamp2));
     for (unsigned i = 0; i < q->num_stages; i++) resamp2_init(&q->hb[i], 7, As);
-    q->hb_buf = (ll_cf *)calloc(1u << q->num_stages, sizeof(ll_cf));
+    q->hb_buf = (ll_cf *)calloc(2u << q->num_stages, sizeof(ll_cf));
     q->npfb = 256; q->nbits = 8; q->m = 7;
     float fc = 0.515f * (float)q->rate_arb; if (fc > 0.49f) fc = 0.49f;
     unsigned n = 2 * q->m * q->npfb + 1;
@@ -352,6 +369,26 @@ static unsigned resamp_arb(ll_msresamp q, ll_cf x, ll_cf *y)
 void ll_msresamp_execute(ll_msresamp q, const ll_cf *x, unsigned nx, ll_cf *y, unsigned *ny)
 {
     unsigned n = 0, D = 1u << q->num_stages;
+    if (q->interp) {
+        /* msresamp_crcf_interp_execute: arbitrary stage, then every sample through the half-band interpolators */
+        ll_cf arb[4];
+        ll_cf *a = q->hb_buf, *b = q->hb_buf + D;
+        for (unsigned i = 0; i < nx; i++) {
+            unsigned na = resamp_arb(q, x[i], arb);
+            for (unsigned j = 0; j < na; j++) {
+                a[0] = arb[j];
+                unsigned cnt = 1;
+                for (unsigned s = 0; s < q->num_stages; s++) {
+                    for (unsigned k = 0; k < cnt; k++) resamp2_interp(&q->hb[s], a[k], b + 2 * k);
+                    cnt *= 2;
+                    ll_cf *t = a; a = b; b = t;
+                }
+                for (unsigned k = 0; k < cnt; k++) y[n++] = a[k];
+            }
+        }
+        *ny = n;
+        return;
+    }
     for (unsigned i = 0; i < nx; i++) {
         ll_cf v = x[i];
         if (q->num_stages) {

@@ -226,17 +226,17 @@ class Modem:
 
 
 class MsResamp:
-    """Oracle msresamp_crcf (decimating)."""
+    """Oracle msresamp_crcf (decimating for rate < 1, interpolating for rate > 1)."""
 
     def __init__(self, rate, As=60.0):
         self.rate = rate
         self.q = lib().ll_msresamp_create(rate, As)
         if not self.q:
-            raise ValueError("rate must be in (0, 1]")
+            raise ValueError("rate must be positive")
 
     def execute(self, x):
         x = np.ascontiguousarray(x, np.complex64)
-        y = np.zeros(int(len(x) * self.rate) + 64, np.complex64)
+        y = np.zeros(int(len(x) * self.rate * 1.001) + 64, np.complex64)
         ny = C.c_uint(0)
         lib().ll_msresamp_execute(self.q, _ptr(x), len(x), _ptr(y), C.byref(ny))
         return y[:ny.value].copy()

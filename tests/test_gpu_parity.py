@@ -181,10 +181,10 @@ def test_corrupted_frames_are_flagged_not_dropped(oracle, product):
     rx.close()
 
 
-@pytest.mark.parametrize("rate", [0.5, 0.37, 0.8, 0.2, 0.11])
+@pytest.mark.parametrize("rate", [0.5, 0.37, 0.8, 0.2, 0.11, 2.0, 1.5, 4.0, 6.3])
 def test_msresamp_front_end_matches_oracle(oracle, product, rate):
-    """Front-end resampler (BASELINE config 3 uses r = 0.5): GPU output == oracle within 1e-5,
-    including when the input arrives in uneven pieces."""
+    """Front-end resampler (BASELINE config 3 uses r = 0.5; its input is made with the transmit side's r = 2.0,
+    src/flexframe_tx.cc:170): GPU output == oracle within 1e-5, including when the input arrives in uneven pieces."""
     torch = _torch()
     rng = np.random.RandomState(int(rate * 1000))
     n = 64 * 1024
@@ -194,7 +194,7 @@ def test_msresamp_front_end_matches_oracle(oracle, product, rate):
     d_x = torch.from_numpy(x).cuda()
     got = q.execute(d_x).cpu().numpy()
     m = min(len(ref), len(got))
-    assert abs(len(ref) - len(got)) <= 1 and m > 0.9 * rate * n
+    assert abs(len(ref) - len(got)) <= (1 if rate <= 1 else 8) and m > 0.9 * rate * n
     assert relerr(got[:m], ref[:m]) <= REL
     assert q.get_delay() >= 7.0
     q.reset()
@@ -208,7 +208,7 @@ def test_msresamp_front_end_matches_oracle(oracle, product, rate):
     assert np.array_equal(got2[:m], got[:m])
     q.close()
     with pytest.raises(ValueError):
-        product.msresamp(1.5)
+        product.msresamp(0.0)
 
 
 def test_resampled_front_end_feeds_the_receiver(oracle, product):

@@ -1,0 +1,153 @@
+"""GPU tests of the streaming engine: a handle that overlaps its own stages (three internal streams, three
+buffer sets, two result generations), overlapped harvests, Reset() semantics, in-launch re-anchored speculation.
+Everything is compared with the CPU oracle or with what the transmitter sent."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+def _key(f):
+    return (f.channel, f.header, f.payload, int(f.header_valid), int(f.payload_valid))
+
+
+def _slabs(product, N, M, cp, nslab, nf, plen, pads):
+    """`nslab` different slabs (seeds, idle tails) from the GPU transmitter + what was sent."""
+    tx = product.multichanneltx(N, M, cp, 4)
+    base = int(product.lib().mctx_hip_blocks_for(tx._h, nf, plen, 40, 1, 6))
+    out = []
+    for i in range(nslab):
+        iq, sent = tx.generate(nf, plen, seed=1000 + 17 * i, nblocks=base + pads[i % len(pads)])
+        out.append((iq, sent))
+    tx.close()
+    return out
+
+
+@pytest.mark.parametrize("serial", [0, 1])
+def test_continuous_stream_poll_equals_oracle(oracle, product, serial):
+    """Three different slabs pushed back to back through one un-restarted receiver, frames collected with the
+    overlapped harvest (Poll after every push): same frames, same order per channel, as the oracle over the
+    concatenated stream -- pipelined and serial receiver alike."""
+    torch = _torch()
+    N, M, cp, nf, plen = 8, 64, 8, 3, 200
+    slabs = _slabs(product, N, M, cp, 3, nf, plen, (0, 40, 16))
+    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=plen, serial=serial)
+    for rep in range(2):
+        for iq, _ in slabs:
+            rx.Execute(iq)
+            rx.Poll()
+    rx.Flush()
+    x = np.concatenate([iq.cpu().numpy() for iq, _ in slabs] * 2)
+    ora = oracle.MultiChannelRx(N, M, cp, 4)
+    ora.execute(x)
+    assert len(ora.frames) == 2 * 3 * nf * N
+    by = lambda fr: {c: [_key(f) for f in fr if f.channel == c] for c in range(N)}
+    assert by(rx.frames) == by(ora.frames)
+    worst = 0.0
+    oi = {}
+    for f in ora.frames:
+        oi.setdefault(f.channel, []).append(f)
+    gi = {}
+    for f in rx.frames:
+        gi.setdefault(f.channel, []).append(f)
+    for c in range(N):
+        for a, b in zip(gi[c], oi[c]):
+            worst = max(worst, float(np.max(np.abs(a.framesyms - b.framesyms)) / np.max(np.abs(b.framesyms))))
+    assert worst <= 1e-5, worst
+    keys = [(f.end_sample, f.channel) for f in rx.frames]
+    assert keys == sorted(keys)                       # reference callback order survives the generations
+    rx.close()
+
+
+def test_reanchored_speculation_hits_after_a_gap(product):
+    """A gap between bursts breaks the frame cadence the previous launch predicted; the first acquisition round
+    stops behind the first frame of the new burst and re-anchors the predictions, so the frames that follow are
+    still taken from speculative waves.  Decisions do not depend on any of it."""
+    torch = _torch()
+    N, M, cp, nf, plen = 16, 64, 8, 6, 300
+    slabs = _slabs(product, N, M, cp, 3, nf, plen, (0, 72, 24))
+    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=plen)
+    for rep in range(3):
+        for iq, _ in slabs:
+            rx.Execute(iq)
+            rx.Poll()
+    rx.Flush()
+    assert len(rx.frames) == 3 * 3 * nf * N
+    k = 0
+    per_ch = {}
+    for f in rx.frames:
+        per_ch.setdefault(f.channel, []).append(f)
+    for c, fr in per_ch.items():
+        assert len(fr) == 9 * nf
+        for i, f in enumerate(fr):
+            sent = slabs[(i // nf) % 3][1]
+            assert f.payload_valid and sent[c][(f.header[0] << 8) | f.header[1]] == (f.header, f.payload)
+    walked, adopted = rx.spec_stats()
+    assert walked + adopted == 9 * nf * N
+    # after the first pass (no history yet) at most the first frame of a burst is walked by the scout itself
+    assert adopted >= 2 * 3 * (nf - 1) * N * 0.9, (walked, adopted)
+    rx.close()
+
+
+def test_reset_delivers_frames_that_were_still_staged(oracle, product):
+    """multichannelrx::Reset (lib/multichannelrx.cc:135-153): everything pushed before the Reset has been
+    synchronized -- also what this implementation still holds in its host staging buffer."""
+    N, M, cp = 2, 64, 8
+    iq, sent = oracle.synth_traffic(N, M, cp, 4, 2, payload_len=60, seed=5)
+    got = []
+    rx = product.multichannelrx(N, M, cp, 4, callback=[lambda *a: got.append(a) or 0] * N, userdata=list(range(N)))
+    assert len(iq) < (1 << 20)                    # fits the default staging buffer: nothing has run on the GPU yet
+    for i in range(0, len(iq), 4096):
+        rx.Execute(iq[i:i + 4096])
+    assert not got
+    rx.Reset()
+    assert len(got) == 2 * N and all(a[4] for a in got)           # payload_valid
+    ora = oracle.MultiChannelRx(N, M, cp, 4)
+    ora.execute(iq)
+    assert sorted(_key(f) for f in rx.frames) == sorted(_key(f) for f in ora.frames)
+    # the receiver keeps working after the Reset
+    rx.Execute(iq); rx.Flush()
+    assert len(rx.frames) == 4 * N
+    rx.close()
+
+
+def test_chunked_push_is_the_same_stream(product):
+    """chunk_blocks splits one push into sub-slabs whose stages overlap; the frames are those of the unsplit push."""
+    torch = _torch()
+    N, M, cp, nf, plen = 8, 64, 8, 4, 150
+    (iq, sent), = _slabs(product, N, M, cp, 1, nf, plen, (0,))
+    res = []
+    for chunk in (0, 64, 1000):
+        rx = product.multichannelrx(N, M, cp, 4, max_payload_len=plen, chunk_blocks=chunk)
+        rx.Execute(iq); rx.Flush()
+        res.append(sorted(_key(f) for f in rx.frames))
+        assert len(rx.frames) == nf * N
+        rx.close()
+    assert res[0] == res[1] == res[2]
+
+
+def test_discard_keeps_the_stream_going(product):
+    """Discard() drops a slab's frames on the device without a host wait; the stream, and the frames of later
+    slabs, are unaffected (what bench.py's timed loop does)."""
+    N, M, cp, nf, plen = 8, 64, 8, 2, 100
+    slabs = _slabs(product, N, M, cp, 2, nf, plen, (0, 32))
+    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=plen, max_frames=nf * N + 8)
+    for rep in range(5):
+        for iq, _ in slabs:
+            rx.Execute(iq)
+            rx.Discard()
+    rx.Flush()
+    rx.frames.clear()
+    for iq, _ in slabs:
+        rx.Execute(iq)
+        rx.Poll()
+    rx.Flush()
+    assert rx.frames_dropped() == 0
+    assert len(rx.frames) == 2 * nf * N and all(f.payload_valid for f in rx.frames)
+    rx.close()

@@ -204,6 +204,30 @@ def test_msresamp_half_rate_and_arbitrary(oracle):
         L.ll_msresamp_destroy(q)
 
 
+@pytest.mark.parametrize("rate", [2.0, 1.5, 4.0, 6.3])
+def test_msresamp_interpolating(oracle, rate):
+    """rate > 1 (the transmit side's msresamp_crcf_create(2.0, 60), src/flexframe_tx.cc:170): a tone comes out as a
+    unit tone at f / rate with rate * n samples, images suppressed; and interpolating then decimating by the same
+    factor gives the input back (delayed)."""
+    n, f_in = 4000, 0.11
+    x = np.exp(2j * np.pi * f_in * np.arange(n)).astype(np.complex64)
+    y = oracle.MsResamp(rate).execute(x)
+    assert abs(len(y) - rate * n) <= 8
+    yy = y[int(200 * rate):]
+    ph = np.angle(yy[1:] * np.conj(yy[:-1]))
+    assert abs(np.median(ph) / (2 * np.pi) - f_in / rate) < 1e-4
+    assert abs(np.mean(np.abs(yy)) - 1.0) < 2e-2
+    spec = np.abs(np.fft.fft(yy[:2048] * np.hanning(2048)))
+    k0 = int(round(f_in / rate * 2048))
+    img = np.delete(spec, np.arange(k0 - 6, k0 + 7) % 2048)
+    assert 20 * np.log10(img.max() / spec.max()) < -50            # images of the zero-order hold are gone
+    back = oracle.MsResamp(1.0 / rate).execute(y)
+    d = int(np.argmax(np.abs(np.correlate(back[300:900], x[250:800], "valid")))) + 50
+    seg = back[300:900][:]
+    ref = x[300 - d:900 - d]
+    assert np.max(np.abs(seg - ref * (seg @ np.conj(ref)) / (ref @ np.conj(ref)))) < 2e-2
+
+
 @pytest.mark.parametrize("M,m", [(8, 2), (16, 4), (64, 7)])
 def test_oversampled_bank_equals_float64_direct_form(oracle, M, m):
     """firpfbch2 analyzer restatement (two-phase window shuffle) against an independent float64 model:
