@@ -154,12 +154,17 @@ struct SyncArgs {
     uint32_t *spec_hint;                 // host-mapped word: largest prediction count, sizes the next launch's grid
     uint32_t *hint;             // host-mapped word: longest coded frame (bytes) among this launch's jobs
     uint32_t enc_hint;          // the value the host last saw there (0: none yet)
-    int stop_after_walk;        // 1: a scout that had to acquire a frame itself stops behind it and predicts the frames that
-                                //    follow from there (cadence re-anchored inside the launch); the next round continues
+    int stop_after_walk;        // 1: a scout standing in a post-frame (or the entry) state nobody predicted stops there and predicts
+                                //    the frames that follow from it (cadence re-anchored inside the launch); the next round continues
+    int tail_only;              // sync_kernel as the lean configurations' tail kernel: only channels with a payload in progress.
+                                //    1 (before the acquisition rounds): the frame a previous push left unfinished, to its end;
+                                //    2 (after them): a frame the lean scout could not hand off -- it straddles the end of the buffer,
+                                //    is oversize, or the job list is full -- and then on to the end of the buffer
     uint32_t *stats;            // [0] frames the scouts acquired themselves, [1] frames adopted from speculative waves (NULL: not counted)
     int no_fast;               // MCRX_NO_FAST=1: payload workers use the general symbol path (A/B experiments)
 };
-hipError_t sync_launch(const SyncArgs &a, hipStream_t st);           // scout kernel: one wave per channel
+hipError_t sync_launch(const SyncArgs &a, hipStream_t st);           // full state machine, one wave per channel (general configurations; tail kernel)
+hipError_t sync_launch_lean(const SyncArgs &a, hipStream_t st);      // lean scout: acquisition + header + hand-off, one wave per channel
 hipError_t sync_launch_spec(const SyncArgs &a, hipStream_t st);      // speculative acquisition: one wave per (channel, predicted position)
 // stage 0: record placement (one workgroup), 1: payload workers (one wave per handed-off frame),
 // 2: packet decode (one workgroup per frame; only after the lean workers -- the general ones decode in place)

@@ -18,8 +18,8 @@
 using namespace mcrx;
 
 #define HIST_BLOCKS 13      /* 2m - 1 blocks of FIR history (m = 7) */
-#define MCRX_SLOTS 3        /* per-launch buffers (channel tiles, job list, per-job scratch): launch k uses slot k % 3 */
-#define MCRX_GENS 2         /* result generations (records + arenas): one fills while the other is harvested */
+#define MCRX_SLOTS 8        /* most per-launch buffer sets (channel tiles, job list, per-job scratch); launch k uses slot k % nslots */
+#define MCRX_GENS 4         /* result generations (records + arenas), a ring: one fills while older ones are harvested or dropped */
 
 static thread_local std::string g_err;
 static void set_err(const char *what, hipError_t e, const char *file, int line)
@@ -114,12 +114,14 @@ struct mcrx_hip_s {
     // the other one) and copies it out once its last launch has finished -- the GPU keeps working meanwhile.
     FrameRec *d_rec[MCRX_GENS] = {}; uint8_t *d_arena[MCRX_GENS] = {}, *d_sarena[MCRX_GENS] = {};
     uint32_t *d_nrec[MCRX_GENS] = {}; unsigned long long *d_arena_used[MCRX_GENS] = {};
-    int gen = 0; bool gen_used[MCRX_GENS] = { false, false }, gen_closed[MCRX_GENS] = { false, false };
+    int gen = 0; bool gen_used[MCRX_GENS] = {}, gen_closed[MCRX_GENS] = {};
+    uint64_t gen_close_seq[MCRX_GENS] = {}, close_counter = 0;      // order in which generations were closed (= delivery order)
     hipEvent_t ev_gen[MCRX_GENS] = {};       // recorded behind the last launch that wrote into the generation
     uint64_t sarena_cap = 0;
     // per-launch slots
     PayloadJob *d_jobs[MCRX_SLOTS] = {}; uint32_t *d_njobs = nullptr; float2 *d_jR[MCRX_SLOTS] = {};
-    uint64_t seq = 0;                       // synchronizer launches so far (slot = seq % MCRX_SLOTS)
+    uint64_t seq = 0;                       // synchronizer launches so far (slot = seq % nslots)
+    unsigned nslots = 5;                    // buffer sets in use: the channelizer and the acquisition chain of up to nslots - 1 pushes run ahead of the payload workers
     uint32_t *d_stats = nullptr;            // speculation statistics (SyncArgs::stats)
     // internal streams: channelizer | acquisition (speculative waves, scouts, placement) | payload workers + decode.
     // Launch k+1's acquisition -- a chain of dependent events per channel, a few waves per CU -- runs under launch
@@ -377,6 +379,8 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
         if (hipEventCreateWithFlags(&q->ev_gen[g], hipEventDisableTiming) != hipSuccess) return bail(fail(MCRX_EHIP, "hipEventCreate failed"));
     }
     q->scout = getenv("MCRX_NO_SCOUT") == nullptr;
+    if (getenv("MCRX_SLOTS")) q->nslots = (unsigned)std::max(2, std::min(MCRX_SLOTS, atoi(getenv("MCRX_SLOTS"))));
+    if (!q->pipelined) q->nslots = 2;
     if ((rc = q->alloc(&q->d_njobs, MCRX_SLOTS))) return bail(rc);      // one counter per slot: a launch's placement kernel zeroes the next slot's
     if ((rc = q->alloc(&q->d_stats, 4))) return bail(rc);
     if (hipHostMalloc((void **)&q->h_hint, 2 * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess) {
@@ -384,7 +388,7 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
         if (hipHostGetDevicePointer((void **)&q->d_hint, q->h_hint, 0) != hipSuccess) q->d_hint = nullptr;
     }
     if (q->scout) {
-        for (int sl = 0; sl < MCRX_SLOTS; sl++) {
+        for (unsigned sl = 0; sl < q->nslots; sl++) {
             if ((rc = q->alloc(&q->d_jobs[sl], q->max_rec))) return bail(rc);
             if ((rc = q->alloc(&q->d_jR[sl], (size_t)q->max_rec * M))) return bail(rc);
             if ((rc = q->alloc(&q->d_jsoft[sl], (size_t)q->max_rec * 8 * q->max_enc))) return bail(rc);
@@ -455,8 +459,9 @@ extern "C" int mcrx_hip_destroy(mcrx_hip_t q)
     if (q->h_stage) (void)hipHostFree(q->h_stage);
     q->arena_host.release(); q->sarena_host.release();
     {
-        hipEvent_t evs[] = { q->ev_in, q->ev_consumed, q->ev_tmp[0], q->ev_tmp[1], q->ev_tmp[2], q->ev_gen[0], q->ev_gen[1] };
+        hipEvent_t evs[] = { q->ev_in, q->ev_consumed, q->ev_tmp[0], q->ev_tmp[1], q->ev_tmp[2] };
         for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+        for (int g = 0; g < MCRX_GENS; g++) if (q->ev_gen[g]) (void)hipEventDestroy(q->ev_gen[g]);
         for (int sl = 0; sl < MCRX_SLOTS; sl++) {
             if (q->ev_ready[sl]) (void)hipEventDestroy(q->ev_ready[sl]);
             if (q->ev_scout[sl]) (void)hipEventDestroy(q->ev_scout[sl]);
@@ -512,7 +517,7 @@ static int launch_channelizer(mcrx_hip_t q, const float2 *x, size_t nblocks, uin
 // decode, which frees the job counter its placement kernel zeroes and (in order on s_work) its own slot.
 static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsigned off, int64_t buf_first, int64_t end, hipStream_t st)
 {
-    const unsigned slot = (unsigned)(q->seq % MCRX_SLOTS), next = (unsigned)((q->seq + 1) % MCRX_SLOTS);
+    const unsigned slot = (unsigned)(q->seq % q->nslots), next = (unsigned)((q->seq + 1) % q->nslots);
     const int g = q->gen;
     SyncArgs a;
     a.c = q->sc; a.chan = chan; a.chan_stride = stride; a.chan_off = off;
@@ -539,17 +544,28 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
         sa = q->s_scout; sw = q->s_work;
         HIPCHK(hipEventRecord(q->ev_ready[slot], st));
         HIPCHK(hipStreamWaitEvent(sa, q->ev_ready[slot], 0));
-        if (q->seq + 1 >= MCRX_SLOTS) HIPCHK(hipStreamWaitEvent(sa, q->ev_done[next], 0));     // launch seq-2
+        if (q->seq + 1 >= q->nslots) HIPCHK(hipStreamWaitEvent(sa, q->ev_done[next], 0));     // launch seq + 1 - nslots
     }
     if (!q->scout) HIPCHK(hipMemsetAsync(a.njobs, 0, sizeof(uint32_t), sa));     // (with the scout, the previous launch's placement kernel zeroed it)
     RC(q->ev_begin(1, sa));
-    // acquisition rounds: speculative waves first, then the per-channel scouts that adopt them; in all but the last
-    // round a scout that had to acquire a frame itself stops behind it and re-anchors the predictions there
-    const int rounds = q->spec ? q->scout_rounds : 1;
-    for (int r = 0; r < rounds; r++) {
-        a.stop_after_walk = (r + 1 < rounds) ? 1 : 0;
-        HIPCHK(sync_launch_spec(a, sa));
-        HIPCHK(sync_launch(a, sa));
+    a.stop_after_walk = 0; a.tail_only = 0;
+    if (q->spec) {
+        // lean configurations: a payload that straddles two pushes is walked by the tail kernel (before the rounds:
+        // the frame the previous push left in progress; after them: the one this push ends in), everything else by
+        // acquisition rounds -- speculative waves, then the lean per-channel scouts that adopt them; in all but the
+        // last round a scout stops at a state nobody predicted and re-anchors the predictions there
+        SyncArgs t = a;
+        t.tail_only = 1; t.pred = nullptr; t.pred_n = nullptr; t.spec_cap = 0; t.spec_hint = nullptr; t.stats = nullptr;
+        HIPCHK(sync_launch(t, sa));
+        for (int r = 0; r < q->scout_rounds; r++) {
+            a.stop_after_walk = (r + 1 < q->scout_rounds) ? 1 : 0;
+            HIPCHK(sync_launch_spec(a, sa));
+            HIPCHK(sync_launch_lean(a, sa));
+        }
+        t.tail_only = 2;
+        HIPCHK(sync_launch(t, sa));
+    } else {
+        HIPCHK(sync_launch(a, sa));           // general configurations: one wave per channel walks everything
     }
     RC(q->ev_end(1, sa));
     if (q->scout) {
@@ -622,7 +638,7 @@ static int ensure_chan(mcrx_hip_t q, size_t tiles)
     HIPCHK(hipDeviceSynchronize());             // every stream that may still read the old buffers
     float2 *nb[MCRX_SLOTS] = {};
     const size_t n = tiles * (size_t)q->N * MCRX_TILE, tile_elems = (size_t)q->N * MCRX_TILE;
-    for (int i = 0; i < MCRX_SLOTS; i++) {
+    for (unsigned i = 0; i < q->nslots; i++) {
         HIPCHK(hipMalloc((void **)&nb[i], n * sizeof(float2)));
         HIPCHK(hipMemset(nb[i], 0, n * sizeof(float2)));
     }
@@ -641,7 +657,7 @@ static int run_blocks(mcrx_hip_t q, const float2 *x, size_t nblocks, uint64_t fi
     if (nblocks == 0) return MCRX_OK;
     const size_t ntiles = nblocks / MCRX_TILE;
     RC(ensure_chan(q, q->hist_tiles + ntiles));
-    const int slot = (int)(q->seq % MCRX_SLOTS);
+    const int slot = (int)(q->seq % q->nslots);
     float2 *buf = q->d_chan[slot];
     const size_t tile_elems = (size_t)q->N * MCRX_TILE;
     hipStream_t sc = st;
@@ -650,7 +666,7 @@ static int run_blocks(mcrx_hip_t q, const float2 *x, size_t nblocks, uint64_t fi
         // finished with this slot's tiles
         sc = q->stream;
         if (st != sc) { HIPCHK(hipEventRecord(q->ev_in, st)); HIPCHK(hipStreamWaitEvent(sc, q->ev_in, 0)); }
-        if (q->seq >= MCRX_SLOTS) HIPCHK(hipStreamWaitEvent(sc, q->ev_done[slot], 0));
+        if (q->seq >= q->nslots) HIPCHK(hipStreamWaitEvent(sc, q->ev_done[slot], 0));
     }
     if (q->last_slot >= 0)
         HIPCHK(hipMemcpyAsync(buf, q->d_chan[q->last_slot] + q->last_ntiles * tile_elems,
@@ -817,7 +833,7 @@ extern "C" int mcrx_hip_stream_wait_launch(mcrx_hip_t q, uint64_t launch, void *
     // finishes after it (payload workers and decoders run in launch order), so waiting for the slot is enough
     if (!q) return fail(MCRX_EINVAL, "null handle");
     if (launch >= q->seq) return fail(MCRX_EINVAL, "no such launch");
-    HIPCHK(hipStreamWaitEvent(stream ? (hipStream_t)stream : q->stream, q->ev_done[launch % MCRX_SLOTS], 0));
+    HIPCHK(hipStreamWaitEvent(stream ? (hipStream_t)stream : q->stream, q->ev_done[launch % q->nslots], 0));
     return MCRX_OK;
 }
 
@@ -868,23 +884,38 @@ static int collect(mcrx_hip_t q, int g)
     q->gen_closed[g] = false; q->gen_used[g] = false;
     return cnt[1] ? MCRX_EOVERFLOW : MCRX_OK;
 }
-// close the generation launches are writing into; later launches write the other one (which must be collected)
+// close the generation launches are writing into; later launches write the next one of the ring (which must be clean)
 static void close_generation(mcrx_hip_t q)
 {
-    const int g = q->gen;
-    if (!q->gen_used[g] || q->gen_closed[g ^ 1]) return;
-    q->gen_closed[g] = true;
-    q->gen = g ^ 1;
+    const int g = q->gen, next = (g + 1) % MCRX_GENS;
+    if (!q->gen_used[g] || q->gen_used[next] || q->gen_closed[next]) return;
+    q->gen_closed[g] = true; q->gen_close_seq[g] = ++q->close_counter;
+    q->gen = next;
+}
+// collect every closed generation, oldest first
+static int collect_closed(mcrx_hip_t q)
+{
+    int rc = MCRX_OK;
+    while (true) {
+        int best = -1;
+        for (int g = 0; g < MCRX_GENS; g++)
+            if (q->gen_closed[g] && (best < 0 || q->gen_close_seq[g] < q->gen_close_seq[best])) best = g;
+        if (best < 0) break;
+        const int r = collect(q, best);
+        if (r != MCRX_OK && r != MCRX_EOVERFLOW) return r;
+        if (r == MCRX_EOVERFLOW) rc = r;
+    }
+    return rc;
 }
 
-// Everything decoded so far becomes deliverable: both generations, blocking.
+// Everything decoded so far becomes deliverable: all generations, blocking.
 static int harvest(mcrx_hip_t q)
 {
     const double t0 = now_s();
-    int rc = collect(q, q->gen ^ 1);
+    int rc = collect_closed(q);
     if (rc == MCRX_OK || rc == MCRX_EOVERFLOW) {
         close_generation(q);
-        const int rc2 = collect(q, q->gen ^ 1);
+        const int rc2 = collect_closed(q);
         rc = (rc2 == MCRX_OK) ? rc : rc2;
     }
     q->pending_bound = 0;
@@ -899,30 +930,33 @@ extern "C" int mcrx_hip_poll(mcrx_hip_t q)
 {
     if (!q) return fail(MCRX_EINVAL, "null handle");
     const double t0 = now_s();
-    const int rc = collect(q, q->gen ^ 1);
+    const int rc = collect_closed(q);
     if (rc == MCRX_OK || rc == MCRX_EOVERFLOW) close_generation(q);
     q->pending_bound = record_bound(q, 0);
     q->t_harvest += now_s() - t0;
     return rc;
 }
 
-// Benchmark helper: as mcrx_hip_poll, but the closed generation's frames stay in HBM and are dropped (its
-// counters are zeroed on the device once its launches have finished; nothing is waited for on the host).
+// Benchmark helper: the frames decoded since the last poll/discard stay in HBM and are dropped.  Launches move on
+// to the next generation of the ring; if that one still holds (abandoned) frames, its counters are zeroed on the
+// device once its launches -- MCRX_GENS - 1 discards ago -- have finished.  Nothing is waited for on the host.
 extern "C" int mcrx_hip_discard(mcrx_hip_t q)
 {
     if (!q) return fail(MCRX_EINVAL, "null handle");
-    const int c = q->gen ^ 1;
-    if (q->gen_closed[c]) {
-        HIPCHK(hipStreamWaitEvent(q->s_copy, q->ev_gen[c], 0));
-        HIPCHK(hipMemsetAsync(q->d_nrec[c], 0, 2 * sizeof(uint32_t), q->s_copy));
-        HIPCHK(hipMemsetAsync(q->d_arena_used[c], 0, 2 * sizeof(unsigned long long), q->s_copy));
-        HIPCHK(hipEventRecord(q->ev_gen[c], q->s_copy));
-        // the next launches into generation c start behind the zeroing
+    const int g = q->gen, next = (g + 1) % MCRX_GENS;
+    if (!q->gen_used[g]) return MCRX_OK;
+    if (q->gen_used[next] || q->gen_closed[next]) {
+        HIPCHK(hipStreamWaitEvent(q->s_copy, q->ev_gen[next], 0));
+        HIPCHK(hipMemsetAsync(q->d_nrec[next], 0, 2 * sizeof(uint32_t), q->s_copy));
+        HIPCHK(hipMemsetAsync(q->d_arena_used[next], 0, 2 * sizeof(unsigned long long), q->s_copy));
+        HIPCHK(hipEventRecord(q->ev_gen[next], q->s_copy));
+        // the next launches into that generation start behind the zeroing
         hipStream_t sa = (q->pipelined && q->scout) ? q->s_scout : q->stream;
-        HIPCHK(hipStreamWaitEvent(sa, q->ev_gen[c], 0));
-        q->gen_closed[c] = false; q->gen_used[c] = false;
+        HIPCHK(hipStreamWaitEvent(sa, q->ev_gen[next], 0));
+        q->gen_closed[next] = false; q->gen_used[next] = false;
     }
-    close_generation(q);
+    q->gen_closed[g] = true; q->gen_close_seq[g] = ++q->close_counter;      // abandoned (a later flush would still deliver it)
+    q->gen = next;
     q->pending_bound = 0;
     return MCRX_OK;
 }

@@ -24,8 +24,12 @@ namespace mcrx {
 
 #define WV 64
 #ifndef SY_PART
-#define SY_PART -1          /* -1: the whole file in one translation unit; 0/1/2: see the launchers at the end */
+#define SY_PART -1          /* -1: the whole file in one translation unit; 0/1/2/3: see the launchers at the end */
 #endif
+#ifndef SY_PROFILE
+#define SY_PROFILE 0        /* 1: MCRX_DEBUG=2 cycle counters per event / phase (they cost ~40 registers in the scout) */
+#endif
+#define SY_PROF(a) (SY_PROFILE && ((a).debug & 2) != 0)
 #define TWO_PI_F 6.283185307179586f
 #define PI_F 3.14159265358979323846f
 
@@ -417,6 +421,11 @@ __device__ __forceinline__ void wave_sync_lds()
 // speculation key: a SEEK state is fully described by (next sample, timer) -- every path into SEEK resets the
 // rest -- so a slot is keyed by both, packed (timer in the top 16 bits; positions stay below 2^48)
 __device__ __forceinline__ int64_t spec_key(int64_t pos, uint32_t timer) { return (int64_t)(((uint64_t)timer << 48) | ((uint64_t)pos & 0xFFFFFFFFFFFFull)); }
+
+// what a Walker instance is compiled for: everything (general configurations, and the tail kernel that walks the
+// payload of a frame straddling two pushes), a speculative acquisition wave, or the lean per-channel scout
+// (acquisition + header only: a frame whose payload does not fit the buffer is left to the tail kernel)
+enum { SYM_FULL = 0, SYM_SPEC = 1, SYM_LEAN = 2 };
 
 template <int E>
 struct Walker {
@@ -1167,12 +1176,12 @@ struct Walker {
     }
 
     // scout, lean RXSYMBOLS event: the counterpart of rx_core on the Walker's state
-    template <bool SPEC = false>
+    template <int MODE = SYM_FULL>
     __device__ __forceinline__ int rx_event_fast(int64_t t_ev)
     {
         const int L = c.L, cb = c.cp - c.backoff;
         const int64_t ws = t_ev - L + 1 + cb;
-        const bool prof = !SPEC && (a.debug & 2) != 0;
+        const bool prof = MODE != SYM_SPEC && SY_PROF(a);
         long long k0 = prof ? (long long)__builtin_readcyclecounter() : 0ll, k1;
 #define SY_TICK(i) if (prof) { k1 = (long long)__builtin_readcyclecounter(); ph[i] += k1 - k0; k0 = k1; }
         float2 X[E];
@@ -1203,8 +1212,9 @@ struct Walker {
         if (prof && new_dtheta == 0x12345u && X[0].x == 1.2345e-30f) ph[5]++;
         SY_TICK(2)
         int r;
-        if (s.fstate == FX_HEADER) r = flex_header_fast<SPEC>(X, t_ev);
-        else if constexpr (SPEC) r = 1;          // a speculative wave never walks a payload itself
+        if (s.fstate == FX_HEADER) r = flex_header_fast<MODE>(X, t_ev);
+        else if constexpr (MODE == SYM_SPEC) r = 1;          // a speculative wave never walks a payload itself
+        else if constexpr (MODE == SYM_LEAN) r = 3;          // (the lean scout never gets here: payloads belong to the tail kernel)
         else r = flex_symbol(X, t_ev);
         SY_TICK(3)
 #undef SY_TICK
@@ -1213,7 +1223,9 @@ struct Walker {
 
     // header symbols: hard BPSK bits go straight to their de-interleaved, de-scrambled place in LDS
     // (the header packet is always 36 bytes, so its interleaver is one fixed bit permutation)
-    template <bool SPEC = false>
+    // returns 0: header continues, 1: frame over (invalid header), 2: payload handed off, 3 (lean scout only): valid
+    // header, but the payload is not entirely in the buffer (or is oversize): the tail kernel walks it
+    template <int MODE = SYM_FULL>
     __device__ __forceinline__ int flex_header_fast(const float2 (&X)[E], int64_t t_ev)
     {
         float ev = 0.f;
@@ -1233,19 +1245,20 @@ struct Walker {
         s.evm_hat += wave_total_dpp(ev);
         s.header_symbol_index += (uint32_t)c.M_data;
         if (s.header_symbol_index >= MCRX_HDR_SYMS) {
-            const bool prof = !SPEC && (a.debug & 2) != 0;
+            const bool prof = MODE != SYM_SPEC && SY_PROF(a);
             long long k0 = prof ? (long long)__builtin_readcyclecounter() : 0ll;
             decode_header_fast();
             if (prof) { if (s.hw[0] == 0x12345678u && s.hw[1] == 0x9abcdef0u) ph[5]++; const long long k1 = (long long)__builtin_readcyclecounter(); ph[4] += k1 - k0; k0 = k1; }
             s.evm = 10.0f * log10f(s.evm_hat / (float)MCRX_HDR_SYMS);
             if (s.header_valid) {
                 s.fstate = FX_PAYLOAD; s.payload_symbol_index = 0;
-                if constexpr (SPEC) return try_handoff_spec(t_ev) ? 2 : 1;
+                if constexpr (MODE == SYM_SPEC) return try_handoff_spec(t_ev) ? 2 : 1;
                 const bool ho = try_handoff(t_ev);
                 if (prof) ph[5] += (long long)__builtin_readcyclecounter() - k0;
                 if (ho) return 2;
+                if constexpr (MODE == SYM_LEAN) return 3;
             }
-            else { if constexpr (!SPEC) emit(t_ev, false, false); return 1; }
+            else { if constexpr (MODE != SYM_SPEC) emit(t_ev, false, false); return 1; }
         }
         return 0;
     }
@@ -1506,7 +1519,7 @@ struct Walker {
                 if (t_ev >= a.end) break;
                 s.cur = t_ev + 1;
                 if (s.state != SY_RX) { sync_event(t_ev); continue; }
-                const int fr = rx_event_fast<true>(t_ev);
+                const int fr = rx_event_fast<SYM_SPEC>(t_ev);
                 if (fr == 0) continue;
                 ok = fr == 2;                           // anything but a clean hand-off is left to the scout
                 break;
@@ -1515,9 +1528,16 @@ struct Walker {
         if (l == 0) { slot->start = ok ? key : -1; slot->t_last = handoff_last; slot->status = ok ? 1 : 0; }
     }
 
+    // MODE SYM_FULL: the whole state machine (general configurations; with a.tail_only the tail kernel of the lean
+    // configurations: only channels with a payload in progress, and only to that frame's end).
+    // MODE SYM_LEAN: the lean scout -- acquisition, header, hand-off; a payload in progress is not its business.
+    template <int MODE = SYM_FULL>
     __device__ __forceinline__ void run()
     {
         s = a.st[ch];
+        const bool mid_payload = s.state == SY_RX && s.fstate == FX_PAYLOAD;
+        if constexpr (MODE == SYM_LEAN) { if (mid_payload) return; }
+        else if (a.tail_only && !mid_payload) return;
         init_consts();
         if (fastp && s.state == SY_RX && s.fstate == FX_HEADER && s.header_symbol_index > 0) {
             for (int i = l; i < MCRX_HDR_SYMS; i += WV) ldshb[i] = bhbits[i];
@@ -1526,19 +1546,21 @@ struct Walker {
         const int M = c.M, M2 = c.M2, L = c.L;
         long long prof_cyc[5] = {0, 0, 0, 0, 0}; int prof_n[5] = {0, 0, 0, 0, 0};
         uint32_t npred = 0, nfresh = 0; int64_t pred_prev = 0, pred_last = 0; bool entry = true;
-        bool walked_now = false, stopped = false;
+        bool stopped = false;
         nadopted = 0;
         if (a.spec_cap) load_spec_headers();
         while (true) {
             if (a.pred && s.state == SY_SEEK && (s.timer == (uint32_t)L || entry)) {
-                // a SEEK state worth predicting -- the one this launch starts in, and the fresh one after every
-                // frame: remember it (next launch's prediction), and take the frame from a speculative wave if
-                // one started from exactly this state
+                // a SEEK state a speculative wave may have started from -- the one this launch starts in, and the fresh
+                // one after every frame: take the frame from that wave if it started from exactly this state
                 const int64_t key = spec_key(s.cur, s.timer);
-                if (npred < MCRX_SPEC_MAX) { if (l == 0) a.pred[(size_t)ch * MCRX_SPEC_MAX + npred] = key; npred++; }
                 if (s.timer == (uint32_t)L) { pred_prev = pred_last; pred_last = s.cur; nfresh++; }
                 entry = false;
                 if (a.spec_cap && adopt_speculative(key)) continue;
+                // nobody predicted this state.  In all but the last acquisition round the scout stops here instead of
+                // acquiring the frame itself: the next round's speculative waves start from this exact state and from
+                // the cadence continued from it, all in parallel
+                if (a.stop_after_walk) { stopped = true; break; }
             }
             entry = false;
             // sample index of the next state-machine event
@@ -1555,27 +1577,33 @@ struct Walker {
                 break;
             }
             s.cur = t_ev + 1;
-            const int st_in = s.state; const long long tk0 = (a.debug & 2) ? (long long)__builtin_readcyclecounter() : 0ll;
+            const int st_in = s.state; const long long tk0 = SY_PROF(a) ? (long long)__builtin_readcyclecounter() : 0ll;
             if ((a.debug & 1) && l == 0 && ch == 0) printf("[sync] ch0 t=%lld state=%d fstate=%d timer=%u hsi=%u psi=%u\n", (long long)t_ev, s.state, s.fstate, s.timer, s.header_symbol_index, s.payload_symbol_index);
 
             if (s.state != SY_RX) sync_event(t_ev);
             else {    // SY_RX
-                const int fr = fastp ? rx_event_fast(t_ev) : rx_event(t_ev);
-                if (fr == 1) { void_reservation(); reset_framesync(); s.timer = (uint32_t)L; nwalked++; walked_now = true; }
+                int fr;
+                if constexpr (MODE == SYM_LEAN) fr = rx_event_fast<SYM_LEAN>(t_ev);
+                else fr = fastp ? rx_event_fast<SYM_FULL>(t_ev) : rx_event(t_ev);
+                if (fr == 3) break;                 // lean scout: valid header, payload for the tail kernel (state saved below)
+                if (fr == 1) {
+                    void_reservation(); reset_framesync(); s.timer = (uint32_t)L; nwalked++;
+                    if (MODE == SYM_FULL && a.tail_only == 1) break;    // tail kernel before the rounds: the frame in progress is done,
+                                                                        // the lean scouts go on from here (after the rounds it walks on to the end)
+                }
                 else if (fr == 2) {
-                    nwalked++; walked_now = true;
+                    nwalked++;
                     // payload handed to a worker: jump over it; liquid leaves the synchronizer in
                     // SEEK with timer = M+cp after the frame's last symbol
                     reset_framesync(); s.timer = (uint32_t)L; s.cur = handoff_last + 1;
                 }
             }
-            if (a.debug & 2) { prof_cyc[st_in] += (long long)__builtin_readcyclecounter() - tk0; prof_n[st_in]++; }
-            if (walked_now && a.stop_after_walk && a.pred) { stopped = true; break; }
+            if (SY_PROF(a)) { prof_cyc[st_in] += (long long)__builtin_readcyclecounter() - tk0; prof_n[st_in]++; }
         }
-        if ((a.debug & 2) && l == 0 && ch == 0)
+        if (SY_PROF(a) && l == 0 && ch == 0)
             printf("[prof] ch0 cycles/events  seek %lld/%d  s0a %lld/%d  s0b %lld/%d  s1 %lld/%d  rx %lld/%d\n",
                    prof_cyc[0], prof_n[0], prof_cyc[1], prof_n[1], prof_cyc[2], prof_n[2], prof_cyc[3], prof_n[3], prof_cyc[4], prof_n[4]);
-        if ((a.debug & 2) && l == 0 && ch == 0)
+        if (SY_PROF(a) && l == 0 && ch == 0)
             printf("[prof] ch0 rx phases: load %lld  core %lld  derot+nco %lld  flex %lld (header decode %lld, hand-off %lld)\n", ph[0], ph[1], ph[2], ph[3], ph[4], ph[5]);
         void_reservation();
         publish_adopted();
@@ -1585,28 +1613,19 @@ struct Walker {
             if (nfresh >= 2 && period_seen > 0 && period_seen < (int64_t)0x7fffffff) s.period_hint = (uint32_t)period_seen;
             if (nfresh >= 1) s.last_fresh = pred_last;
             const int64_t P = (int64_t)s.period_hint;
-            if (stopped) {
-                // this round ends behind a frame the scout acquired itself: the next round's speculative waves get the
-                // exact state it stands in, and the cadence continued from here to the end of the buffer
-                s.last_fresh = s.cur;
-                if (l == 0) a.pred[(size_t)ch * MCRX_SPEC_MAX] = spec_key(s.cur, s.timer);
-                npred = 1;
-                if (P > 0)
-                    for (int64_t p = s.cur + P; npred < MCRX_SPEC_MAX && p < a.end; p += P) {
-                        if (l == 0) a.pred[(size_t)ch * MCRX_SPEC_MAX + npred] = spec_key(p, (uint32_t)L);
-                        npred++;
-                    }
-            } else {
-                // the state the next launch of a continuing stream starts in is known exactly, if it is SEEK; then the
-                // cadence continued past this buffer
-                if (s.state == SY_SEEK && npred < MCRX_SPEC_MAX) { if (l == 0) a.pred[(size_t)ch * MCRX_SPEC_MAX + npred] = spec_key(s.cur, s.timer); npred++; }
-                if (P > 0 && s.last_fresh > 0) {
-                    int64_t p = s.last_fresh + P;
-                    if (p < s.cur) p += (s.cur - p + P - 1) / P * P;
-                    for (; npred < MCRX_SPEC_MAX && p < a.end + (a.end - a.buf_first); p += P) {
-                        if (l == 0) a.pred[(size_t)ch * MCRX_SPEC_MAX + npred] = spec_key(p, (uint32_t)L);
-                        npred++;
-                    }
+            // predictions for the next speculative pass (the next round of this launch if the scout stopped, else the
+            // next launch): the exact state the scout stands in, if it is SEEK, and the frame cadence continued from
+            // the last post-frame state -- to the end of this buffer, or one buffer length past it
+            npred = 0;
+            if (s.state == SY_SEEK) { if (l == 0) a.pred[(size_t)ch * MCRX_SPEC_MAX] = spec_key(s.cur, s.timer); npred = 1; }
+            const int64_t anchor = (s.state == SY_SEEK && s.timer == (uint32_t)L) ? s.cur : s.last_fresh;
+            if (P > 0 && anchor > 0) {
+                int64_t p = anchor + P;
+                if (p < s.cur) p += (s.cur - p + P - 1) / P * P;
+                const int64_t limit = stopped ? a.end : a.end + (a.end - a.buf_first);
+                for (; npred < MCRX_SPEC_MAX && p < limit; p += P) {
+                    if (l == 0) a.pred[(size_t)ch * MCRX_SPEC_MAX + npred] = spec_key(p, (uint32_t)L);
+                    npred++;
                 }
             }
             if (l == 0) { a.pred_n[ch] = npred; if (a.spec_hint && npred > *a.spec_hint) *a.spec_hint = npred; }
@@ -1648,12 +1667,32 @@ __global__ __launch_bounds__(WV) void sync_kernel(SyncArgs a)
     const uint32_t ch = blockIdx.x;
     if (ch >= a.nch) return;
     Walker<E> w(a, ch);
-    w.run();
+    w.template run<SYM_FULL>();
+}
+
+// the lean scout (lean configurations only): one wave per channel, acquisition + header + hand-off
+// (E <= 2: held to three waves per SIMD = 168 registers, so that a scout fits on a SIMD beside four payload workers of
+//  the previous push (4 x 80 of the 512) instead of waiting for a SIMD to drain.  These two kernels are built in their own part with
+//  the basic vector-register allocator: under this budget hipcc 7.2's default one reloads 64-bit spills into
+//  odd-aligned pairs, which its own verifier rejects.)
+#if SY_PART == 3
+#define SY_ACQ_WAVES 3
+#else
+#define SY_ACQ_WAVES 1
+#endif
+template <int E>
+__global__ __launch_bounds__(WV, SY_ACQ_WAVES) void sync_lean_kernel(SyncArgs a)
+{
+    launder(a);
+    const uint32_t ch = blockIdx.x;
+    if (ch >= a.nch) return;
+    Walker<E> w(a, ch);
+    w.template run<SYM_LEAN>();
 }
 
 // speculative acquisition: one wave per (channel, predicted position); lean path only
 template <int E>
-__global__ __launch_bounds__(WV) void sync_spec_kernel(SyncArgs a)
+__global__ __launch_bounds__(WV, SY_ACQ_WAVES) void sync_spec_kernel(SyncArgs a)
 {
     launder(a);
     const uint32_t ch = blockIdx.x / a.spec_cap, k = blockIdx.x % a.spec_cap;
@@ -1667,7 +1706,7 @@ __global__ __launch_bounds__(WV) void sync_spec_kernel(SyncArgs a)
 // picks per design, so neither carries the other's registers.
 // (four waves per SIMD up to M = 256; wider symbols hold 2 E window registers twice over and get a larger budget)
 template <int E, bool FAST>
-__global__ __launch_bounds__(WV, (E <= 4 ? 4 : (E <= 8 ? 2 : 1))) void payload_kernel(SyncArgs a)
+__global__ __launch_bounds__(WV, ((E == 1 && FAST) ? 6 : E <= 4 ? 4 : (E <= 8 ? 2 : 1))) void payload_kernel(SyncArgs a)
 {
     launder(a);
     const uint32_t j = blockIdx.x;
@@ -1803,7 +1842,7 @@ __global__ __launch_bounds__(DK_T) void decode_kernel(SyncArgs a, uint32_t lds_s
     uint8_t *soft = a.jsoft + (size_t)j * 8 * c.max_enc_len;
     uint8_t *tmpa = a.jtmp + (size_t)j * 2 * tstride, *tmpb = tmpa + tstride;
     const uint32_t crc_len = (crc == 6) ? 4u : 0u, n0 = n_msg + crc_len;
-    const bool prof = (a.debug & 2) && j == 7;
+    const bool prof = SY_PROF(a) && j == 7;
     long long tk[8]; int ntk = 0;
 #define DK_TICK() if (prof) tk[ntk++] = (long long)__builtin_readcyclecounter();
     DK_TICK()
@@ -2004,13 +2043,34 @@ hipError_t sync_reset_launch(ChanState *st, uint32_t nch, int64_t cur, float2 *h
 
 // ---- launchers.  The file is compiled in three parts (-DSY_PART=0/1/2: symbol widths E = 1,2 / 4,8 / 16) so that
 // the template instantiations build in parallel; every part defines the per-width launchers of its widths.
-enum { SYK_SCOUT = 0, SYK_SPEC = 1, SYK_PAYLOAD_FAST = 2, SYK_PAYLOAD_GENERAL = 3 };
+enum { SYK_SCOUT = 0, SYK_SPEC = 1, SYK_PAYLOAD_FAST = 2, SYK_PAYLOAD_GENERAL = 3, SYK_LEAN = 4 };
+// acquisition kernels of the narrow symbols (E = 1, 2): part 3, built with -mllvm -vgpr-regalloc=basic (see SY_ACQ_BUDGET)
+hipError_t sy_launch_acq_e1(int what, const SyncArgs &a, unsigned grid, size_t lds, hipStream_t st);
+hipError_t sy_launch_acq_e2(int what, const SyncArgs &a, unsigned grid, size_t lds, hipStream_t st);
+template <int EE>
+static hipError_t sy_launch_acq_width(int what, const SyncArgs &a, unsigned grid, size_t lds, hipStream_t st)
+{
+    if (what == SYK_SPEC) hipLaunchKernelGGL((sync_spec_kernel<EE>), dim3(grid), dim3(WV), lds, st, a);
+    else hipLaunchKernelGGL((sync_lean_kernel<EE>), dim3(grid), dim3(WV), lds, st, a);
+    return hipGetLastError();
+}
 template <int EE>
 static hipError_t sy_launch_width(int what, const SyncArgs &a, unsigned grid, size_t lds, hipStream_t st)
 {
     switch (what) {
     case SYK_SCOUT:           hipLaunchKernelGGL((sync_kernel<EE>), dim3(grid), dim3(WV), lds, st, a); break;
-    case SYK_SPEC:            hipLaunchKernelGGL((sync_spec_kernel<EE>), dim3(grid), dim3(WV), lds, st, a); break;
+    case SYK_SPEC:
+        if constexpr (EE == 1) return sy_launch_acq_e1(what, a, grid, lds, st);
+        else if constexpr (EE == 2) return sy_launch_acq_e2(what, a, grid, lds, st);
+        else hipLaunchKernelGGL((sync_spec_kernel<EE>), dim3(grid), dim3(WV), lds, st, a);
+        break;
+    case SYK_LEAN:
+        // (wider symbols keep the full kernel as their scout: hipcc 7.2 cannot allocate the lean one's 64-bit values
+        //  at E >= 4 under any budget worth having)
+        if constexpr (EE == 1) return sy_launch_acq_e1(what, a, grid, lds, st);
+        else if constexpr (EE == 2) return sy_launch_acq_e2(what, a, grid, lds, st);
+        else hipLaunchKernelGGL((sync_kernel<EE>), dim3(grid), dim3(WV), lds, st, a);
+        break;
     case SYK_PAYLOAD_FAST:    hipLaunchKernelGGL((payload_kernel<EE, true>), dim3(grid), dim3(WV), lds, st, a); break;
     case SYK_PAYLOAD_GENERAL: hipLaunchKernelGGL((payload_kernel<EE, false>), dim3(grid), dim3(WV), lds, st, a); break;
     default: return hipErrorInvalidValue;
@@ -2033,6 +2093,10 @@ hipError_t sy_launch_e8(int what, const SyncArgs &a, unsigned grid, size_t lds, 
 #if SY_PART < 0 || SY_PART == 2
 hipError_t sy_launch_e16(int what, const SyncArgs &a, unsigned grid, size_t lds, hipStream_t st) { return sy_launch_width<16>(what, a, grid, lds, st); }
 #endif
+#if SY_PART < 0 || SY_PART == 3
+hipError_t sy_launch_acq_e1(int what, const SyncArgs &a, unsigned grid, size_t lds, hipStream_t st) { return sy_launch_acq_width<1>(what, a, grid, lds, st); }
+hipError_t sy_launch_acq_e2(int what, const SyncArgs &a, unsigned grid, size_t lds, hipStream_t st) { return sy_launch_acq_width<2>(what, a, grid, lds, st); }
+#endif
 
 #if SY_PART <= 0
 static hipError_t sy_launch(int what, const SyncArgs &a, unsigned grid, size_t lds, hipStream_t st)
@@ -2052,6 +2116,13 @@ hipError_t sync_launch(const SyncArgs &a, hipStream_t st)
     if (a.nch == 0) return hipSuccess;
     if (a.c.M > SY_MAXM) return hipErrorInvalidValue;
     return sy_launch(SYK_SCOUT, a, a.nch, SY_LDS_BYTES(a.c.M), st);
+}
+
+hipError_t sync_launch_lean(const SyncArgs &a, hipStream_t st)
+{
+    if (a.nch == 0) return hipSuccess;
+    if (a.c.M > SY_MAXM) return hipErrorInvalidValue;
+    return sy_launch(SYK_LEAN, a, a.nch, SY_LDS_BYTES(a.c.M), st);
 }
 
 hipError_t sync_launch_spec(const SyncArgs &a, hipStream_t st)
