@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=8, help="frames per channel per slab")
     ap.add_argument("--slabs", type=int, default=3, help="different slabs per step and GPU")
     ap.add_argument("--payload", type=int, default=1200)
-    ap.add_argument("--rounds", type=int, default=6, help="--gpus > 1: exchange rounds per step")
+    ap.add_argument("--rounds", type=int, default=3, help="--gpus > 1: exchange rounds per step (a round = one sub-slab per rank)")
     ap.add_argument("--serial-steps", type=int, default=8, help="steps of the unpipelined pass that times each kernel alone")
     ap.add_argument("--harvest-steps", type=int, default=10)
     ap.add_argument("--cpu-reps", type=int, default=1, help="passes over the first slab timed on the CPU oracle")
@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--slab-blocks", type=int, default=0)
     ap.add_argument("--chunk-blocks", type=int, default=0, help="split every push into sub-slabs of this many blocks")
     ap.add_argument("--serial", action="store_true", help="time the unpipelined receiver (every kernel in order on one stream)")
+    ap.add_argument("--pipeline", action="store_true", help="--gpus 1 through the multi-GPU code path (sharding.Pipeline, exchange = local copy)")
     return ap.parse_args()
 
 
@@ -109,8 +110,12 @@ def main():
     period_blocks = sum(slab_blocks)
     slab_start = np.concatenate([[0], np.cumsum(slab_blocks)])          # channel-rate sample (= block) index of every slab in the period
 
-    max_frames = N * args.frames + 64 if world == 1 else cg * args.frames * nslab + 64
+    max_frames = N * args.frames + 64 if (world == 1 and not args.pipeline) else cg * args.frames * nslab + 64
     cfg = dict(max_payload_len=max(args.payload, 64), max_frames=max_frames)
+    if world > 1 or args.pipeline:
+        # rounds cut the stream anywhere: a frame that straddles two rounds is acquired again by the next round (whole, by
+        # the parallel path) instead of being walked symbol by symbol -- the history in front of every round covers a frame
+        cfg["defer_samples"] = 16384
     if args.slab_blocks:
         cfg["slab_blocks"] = args.slab_blocks
     if args.chunk_blocks:
@@ -135,7 +140,7 @@ def main():
     ser_stats = ser.kernel_stats()
     ser.close()
 
-    if world == 1:
+    if world == 1 and not args.pipeline:
         rx = prod.multichannelrx(N, M, cp, taper, serial=1 if args.serial else 0, **cfg)
 
         def step(harvest_rx=None):
@@ -217,7 +222,7 @@ def main():
     value = samples_per_step * args.steps / elapsed / 1e6
     out = None
     harvest = None
-    if world == 1 and not args.no_harvest:
+    if world == 1 and not args.no_harvest and not args.pipeline:
         harvest = harvest_legs(prod, N, M, cp, taper, cfg, slabs, K, args, torch)
     if rank == 0:
         per = {k: v[0] / max(v[1], 1) for k, v in ser_stats.items()}          # mean ms per launch, kernel alone
@@ -273,7 +278,7 @@ def main():
         if harvest:
             out.update(harvest)
         if not args.no_cpu and world == 1:                     # the CPU leg is reported at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(ora, prod, slabs[0], N, M, cp, taper, args.cpu_reps, cfg)
+            out["cpu_baseline"] = cpu_baseline(ora, prod, slabs[0] if slabs is not None else slabs_keep0, N, M, cp, taper, args.cpu_reps, cfg)
     rx.close()
     if world > 1:
         dist.barrier()

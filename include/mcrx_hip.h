@@ -63,6 +63,11 @@ typedef struct {
                                     kernels of consecutive pushes run on three internal streams with three sets of buffers */
     uint32_t chunk_blocks;       /* execute_device: split a push into sub-slabs of this many blocks (multiple of 8) so that
                                     the stages of ONE call overlap too; 0 = one launch sequence per call */
+    uint32_t defer_samples;      /* > 0: every push keeps this many channel-rate samples of history (plus a symbol) in front of its
+                                    channel tiles, and a frame that begins less than that before the end of a push and does not
+                                    end in it is acquired again by the next push -- whole, by the parallel path -- instead of
+                                    being walked symbol by symbol across the boundary by one wave.  0 = off.  Stage-level callers
+                                    (mcrx_hip_sync) must supply mcrx_hip_history_tiles() tiles of history themselves */
     uint32_t skip_framesyms;     /* 1 = harvests leave the equalised symbols in HBM (frames report num_framesyms = 0): 1.2 KB
                                     instead of 59 KB per frame over the host link at the benchmark's frame size */
 } mcrx_hip_config;
@@ -111,6 +116,7 @@ int  mcrx_hip_stream_wait(mcrx_hip_t q, void *stream);
 /* ... or only for synchronizer launch number `launch` (0-based; mcrx_hip_launches() - 1 right after a
  * mcrx_hip_sync / execute_device call): what a rotating stage-level buffer needs before it is overwritten */
 uint64_t mcrx_hip_launches(mcrx_hip_t q);
+unsigned mcrx_hip_history_tiles(mcrx_hip_t q);      /* tiles of channel-rate history a mcrx_hip_sync buffer must start with */
 int  mcrx_hip_stream_wait_launch(mcrx_hip_t q, uint64_t launch, void *stream);
 /* frames the per-channel scouts acquired themselves / took over from speculative waves since the last reset of
  * the statistics (synchronises the device) */

@@ -41,7 +41,7 @@ class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("max_payload_len", C.c_uint32), ("max_frames", C.c_uint32),
                 ("payload_soft", C.c_uint32), ("slab_blocks", C.c_uint32), ("channel_first", C.c_uint32),
                 ("channel_count", C.c_uint32), ("batch_samples", C.c_uint32), ("single_channel", C.c_uint32),
-                ("serial", C.c_uint32), ("chunk_blocks", C.c_uint32), ("skip_framesyms", C.c_uint32)]
+                ("serial", C.c_uint32), ("chunk_blocks", C.c_uint32), ("defer_samples", C.c_uint32), ("skip_framesyms", C.c_uint32)]
 
 
 class FrameC(C.Structure):
@@ -65,6 +65,7 @@ _EXPORTS = {
     "mcrx_hip_discard": (C.c_int, [C.c_void_p]),
     "mcrx_hip_stream_wait": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mcrx_hip_launches": (C.c_uint64, [C.c_void_p]),
+    "mcrx_hip_history_tiles": (C.c_uint, [C.c_void_p]),
     "mcrx_hip_stream_wait_launch": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
     "mcrx_hip_spec_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]),
     "mcrx_hip_frames_pending": (C.c_size_t, [C.c_void_p]),
@@ -317,7 +318,7 @@ class multichannelrx(object):
     @property
     def hist_tiles(self):
         """tiles of channel-rate history a stage-level sync needs in front of new samples"""
-        return (self.M + self.cp + 8 + 7) // 8 + 1
+        return int(lib().mcrx_hip_history_tiles(self._h))
 
     def restart(self, stream=None):
         _check(lib().mcrx_hip_restart(self._h, _stream_ptr(stream)))

@@ -156,6 +156,10 @@ struct SyncArgs {
     uint32_t enc_hint;          // the value the host last saw there (0: none yet)
     int stop_after_walk;        // 1: a scout standing in a post-frame (or the entry) state nobody predicted stops there and predicts
                                 //    the frames that follow from it (cadence re-anchored inside the launch); the next round continues
+    int64_t defer_limit;        // > 0: the next push carries this many channel-rate samples of history, so a frame whose payload
+                                //    does not fit this buffer and that began less than that before its end is not walked serially
+                                //    by the tail kernel: the lean scout rewinds to the SEEK state it detected the frame from
+                                //    and the next push acquires it again, whole (0: never)
     int tail_only;              // sync_kernel as the lean configurations' tail kernel: only channels with a payload in progress.
                                 //    1 (before the acquisition rounds): the frame a previous push left unfinished, to its end;
                                 //    2 (after them): a frame the lean scout could not hand off -- it straddles the end of the buffer,

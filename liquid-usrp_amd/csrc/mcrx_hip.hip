@@ -143,7 +143,7 @@ struct mcrx_hip_s {
     float2 *d_in = nullptr;                 // device staging (stage_cap samples)
     float2 *h_stage = nullptr; size_t stage_cap = 0, stage_fill = 0;   // pinned host staging (samples)
     float2 *d_chan[MCRX_SLOTS] = {}; size_t chan_cap_tiles = 0;
-    unsigned hist_tiles = 0;
+    unsigned hist_tiles = 0; uint64_t defer = 0;
     hipStream_t stream = nullptr;
     // large host buffers skip the staging copy: chunks go from the caller's memory to one of two device buffers
     float2 *d_direct[2] = { nullptr, nullptr }; size_t direct_cap = 0; int direct_idx = 0; bool direct_used[2] = { false, false };
@@ -357,7 +357,10 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
           q->ncu = (uint32_t)n; }
     q->taps = bypass ? std::vector<float>(14, 0.f) : pfb_prototype(q->K, 7, 60.0f);
     q->dtheta = bypass ? 0u : channel_center_step(N);
-    q->hist_tiles = (M + cp + 8 + 7) / 8 + 1;
+    // channel-rate history in front of every push's tiles: a symbol window, plus -- if frames straddling two pushes are
+    // to be deferred rather than walked serially -- the longest frame start-to-push-end distance to be covered
+    q->defer = (q->cfg.struct_size >= offsetof(mcrx_hip_config, defer_samples) + sizeof(uint32_t)) ? q->cfg.defer_samples : 0;
+    q->hist_tiles = (unsigned)((q->defer + M + cp + 8 + 7) / 8 + 1);
 
     auto bail = [&](int rc) { mcrx_hip_destroy(q); return rc; };
     int rc;
@@ -548,7 +551,7 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     }
     if (!q->scout) HIPCHK(hipMemsetAsync(a.njobs, 0, sizeof(uint32_t), sa));     // (with the scout, the previous launch's placement kernel zeroed it)
     RC(q->ev_begin(1, sa));
-    a.stop_after_walk = 0; a.tail_only = 0;
+    a.stop_after_walk = 0; a.tail_only = 0; a.defer_limit = (int64_t)q->defer;
     if (q->spec) {
         // lean configurations: a payload that straddles two pushes is walked by the tail kernel (before the rounds:
         // the frame the previous push left in progress; after them: the one this push ends in), everything else by
@@ -827,6 +830,7 @@ extern "C" int mcrx_hip_stream_wait(mcrx_hip_t q, void *stream)
     return join_into(q, stream ? (hipStream_t)stream : q->stream);
 }
 extern "C" uint64_t mcrx_hip_launches(mcrx_hip_t q) { return q ? q->seq : 0; }
+extern "C" unsigned mcrx_hip_history_tiles(mcrx_hip_t q) { return q ? q->hist_tiles : 0; }
 extern "C" int mcrx_hip_stream_wait_launch(mcrx_hip_t q, uint64_t launch, void *stream)
 {
     // the event ring holds the last MCRX_SLOTS launches; an older launch shares its slot with a later one that

@@ -1256,7 +1256,14 @@ struct Walker {
                 const bool ho = try_handoff(t_ev);
                 if (prof) ph[5] += (long long)__builtin_readcyclecounter() - k0;
                 if (ho) return 2;
-                if constexpr (MODE == SYM_LEAN) return 3;
+                if constexpr (MODE == SYM_LEAN) {
+                    // not handed off.  If only because its payload runs past the end of this buffer, and the next push
+                    // still holds the frame's beginning: defer it (4) -- else the tail kernel walks it (3)
+                    const int64_t nsym = (int64_t)((s.mod_len + (uint32_t)c.M_data - 1) / (uint32_t)c.M_data);
+                    const bool fits_limits = s.enc_len <= c.max_enc_len && s.mod_len <= c.max_syms && s.payload_len <= c.max_payload_len;
+                    const bool past_end = t_ev + nsym * (int64_t)c.L >= a.end;
+                    return (fits_limits && past_end && a.defer_limit > 0 && a.end - sk_cur <= a.defer_limit) ? 4 : 3;
+                }
             }
             else { if constexpr (MODE != SYM_SPEC) emit(t_ev, false, false); return 1; }
         }
@@ -1438,6 +1445,7 @@ struct Walker {
     // equalisers are copied into the job list in one pipelined pass after it.  Nothing on the scout's
     // serial chain waits for memory because of an adoption.
     int64_t sp_start[2], sp_tlast[2]; uint32_t nadopted; uint32_t nwalked = 0;
+    int64_t sk_cur = 0; uint32_t sk_timer = 0;      // lean scout: the SEEK state before the last seek event (where a frame is re-acquired from if deferred)
     __device__ __forceinline__ void load_spec_headers()
     {
         const SpecSlot *sl = a.spec + (size_t)ch * MCRX_SPEC_MAX;
@@ -1563,6 +1571,7 @@ struct Walker {
                 if (a.stop_after_walk) { stopped = true; break; }
             }
             entry = false;
+            if (s.state == SY_SEEK) { sk_cur = s.cur; sk_timer = s.timer; }
             // sample index of the next state-machine event
             int64_t t_ev;
             if (s.state == SY_SEEK)       t_ev = s.cur + ((s.timer + 1 >= (uint32_t)M) ? 0 : (int64_t)(M - 1 - (int)s.timer));
@@ -1586,6 +1595,10 @@ struct Walker {
                 if constexpr (MODE == SYM_LEAN) fr = rx_event_fast<SYM_LEAN>(t_ev);
                 else fr = fastp ? rx_event_fast<SYM_FULL>(t_ev) : rx_event(t_ev);
                 if (fr == 3) break;                 // lean scout: valid header, payload for the tail kernel (state saved below)
+                if (fr == 4) {                      // ... or deferred: back to the state the frame was detected from; the next push re-acquires it
+                    void_reservation(); reset_framesync(); s.cur = sk_cur; s.timer = sk_timer;
+                    break;
+                }
                 if (fr == 1) {
                     void_reservation(); reset_framesync(); s.timer = (uint32_t)L; nwalked++;
                     if (MODE == SYM_FULL && a.tail_only == 1) break;    // tail kernel before the rounds: the frame in progress is done,

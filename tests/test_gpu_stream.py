@@ -151,3 +151,51 @@ def test_discard_keeps_the_stream_going(product):
     assert rx.frames_dropped() == 0
     assert len(rx.frames) == 2 * nf * N and all(f.payload_valid for f in rx.frames)
     rx.close()
+
+
+@pytest.mark.parametrize("defer", [0, 4096])
+def test_frames_straddling_pushes(oracle, product, defer):
+    """Pushes that cut every frame somewhere.  defer_samples = 0: the tail kernel walks a straddling payload across
+    the boundary; > 0: the lean scout rewinds and the next push acquires the frame again, whole.  Either way the
+    frames are the oracle's, in order -- and with deferral nearly nothing is left to the serial walk."""
+    torch = _torch()
+    N, M, cp, nf, plen = 8, 64, 8, 6, 300
+    (iq, sent), = _slabs(product, N, M, cp, 1, nf, plen, (16,))
+    x = iq.cpu().numpy()
+    ora = oracle.MultiChannelRx(N, M, cp, 4)
+    ora.execute(x)
+    assert len(ora.frames) == nf * N
+    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=plen, defer_samples=defer)
+    K = 2 * N
+    nb = int(iq.numel()) // K
+    rng = np.random.RandomState(3)
+    i = 0
+    while i < nb:
+        step = 8 * int(rng.randint(40, 160))            # 320 .. 1280 blocks: a frame is ~2600 samples long
+        rx.Execute(iq[i * K:min(i + step, nb) * K]); i += step
+    rx.Flush()
+    by = lambda fr: {c: [_key(f) for f in fr if f.channel == c] for c in range(N)}
+    assert by(rx.frames) == by(ora.frames)
+    o = {}
+    for f in ora.frames:
+        o.setdefault(f.channel, []).append(f)
+    g = {}
+    for f in rx.frames:
+        g.setdefault(f.channel, []).append(f)
+    worst = max(float(np.max(np.abs(a.framesyms - b.framesyms)) / np.max(np.abs(b.framesyms)))
+                for c in range(N) for a, b in zip(g[c], o[c]))
+    assert worst <= 1e-5, worst
+    rx.close()
+
+
+def test_chunked_push_with_deferral_overlaps_without_serial_walks(product):
+    """chunk_blocks + defer_samples: one big push processed as sub-slabs whose stages overlap, frames cut by a
+    sub-slab boundary re-acquired by the next one; same frames as the unsplit push."""
+    N, M, cp, nf, plen = 8, 64, 8, 6, 300
+    (iq, sent), = _slabs(product, N, M, cp, 1, nf, plen, (0,))
+    ref = product.multichannelrx(N, M, cp, 4, max_payload_len=plen)
+    ref.Execute(iq); ref.Flush()
+    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=plen, chunk_blocks=1000, defer_samples=4096)
+    rx.Execute(iq); rx.Flush()
+    assert sorted(_key(f) for f in rx.frames) == sorted(_key(f) for f in ref.frames) and len(ref.frames) == nf * N
+    ref.close(); rx.close()
