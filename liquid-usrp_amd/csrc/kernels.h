@@ -30,6 +30,14 @@ uint32_t channelizer_auto_slab(unsigned K, size_t nblocks, unsigned ncu);
 hipError_t channelizer_launch(unsigned K, const ChanArgs &a, hipStream_t st);
 
 // ---------------------------------------------------------------- ofdmsync.hip
+// The two named deviations from liquid-dsp's ofdmframesync in the S1 stage -- the same
+// switches as LL_S1_BACKOFF_CORRECTION / LL_S1_METRIC_G0_NORMALISED in oracle/liquidlite.h; keep them equal.
+#ifndef MCRX_S1_BACKOFF_CORRECTION
+#define MCRX_S1_BACKOFF_CORRECTION 0        /* D6: 1 = G[k] *= e^{j 2 pi k backoff / M} after the S1 gain estimate */
+#endif
+#ifndef MCRX_S1_METRIC_G0_NORMALISED
+#define MCRX_S1_METRIC_G0_NORMALISED 1      /* D7: 1 = S1 metric scaled by the S0-stage gain g0 */
+#endif
 enum { SY_SEEK = 0, SY_S0A, SY_S0B, SY_S1, SY_RX };
 enum { FX_HEADER = 0, FX_PAYLOAD };
 
@@ -168,6 +176,7 @@ struct SyncArgs {
     int no_fast;               // MCRX_NO_FAST=1: payload workers use the general symbol path (A/B experiments)
 };
 hipError_t sync_launch(const SyncArgs &a, hipStream_t st);           // full state machine, one wave per channel (general configurations; tail kernel)
+hipError_t sync_launch_tail(const SyncArgs &a, hipStream_t st);      // lean configurations: payloads in progress, to the frame's end (a.tail_only = 1)
 hipError_t sync_launch_lean(const SyncArgs &a, hipStream_t st);      // lean scout: acquisition + header + hand-off, one wave per channel
 hipError_t sync_launch_spec(const SyncArgs &a, hipStream_t st);      // speculative acquisition: one wave per (channel, predicted position)
 // stage 0: record placement (one workgroup), 1: payload workers (one wave per handed-off frame),

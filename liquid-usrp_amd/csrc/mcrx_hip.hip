@@ -559,14 +559,14 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
         // last round a scout stops at a state nobody predicted and re-anchors the predictions there
         SyncArgs t = a;
         t.tail_only = 1; t.pred = nullptr; t.pred_n = nullptr; t.spec_cap = 0; t.spec_hint = nullptr; t.stats = nullptr;
-        HIPCHK(sync_launch(t, sa));
+        HIPCHK(sync_launch_tail(t, sa));
         for (int r = 0; r < q->scout_rounds; r++) {
             a.stop_after_walk = (r + 1 < q->scout_rounds) ? 1 : 0;
             HIPCHK(sync_launch_spec(a, sa));
             HIPCHK(sync_launch_lean(a, sa));
         }
-        t.tail_only = 2;
-        HIPCHK(sync_launch(t, sa));
+        // a frame the lean scout could neither hand off nor defer runs past the end of this buffer: walked up to there
+        HIPCHK(sync_launch_tail(t, sa));
     } else {
         HIPCHK(sync_launch(a, sa));           // general configurations: one wave per channel walks everything
     }

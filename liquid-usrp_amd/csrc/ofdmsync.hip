@@ -1257,12 +1257,25 @@ struct Walker {
                 if (prof) ph[5] += (long long)__builtin_readcyclecounter() - k0;
                 if (ho) return 2;
                 if constexpr (MODE == SYM_LEAN) {
-                    // not handed off.  If only because its payload runs past the end of this buffer, and the next push
-                    // still holds the frame's beginning: defer it (4) -- else the tail kernel walks it (3)
+                    // Not handed off.  The lean scout never walks a payload itself:
                     const int64_t nsym = (int64_t)((s.mod_len + (uint32_t)c.M_data - 1) / (uint32_t)c.M_data);
-                    const bool fits_limits = s.enc_len <= c.max_enc_len && s.mod_len <= c.max_syms && s.payload_len <= c.max_payload_len;
-                    const bool past_end = t_ev + nsym * (int64_t)c.L >= a.end;
-                    return (fits_limits && past_end && a.defer_limit > 0 && a.end - sk_cur <= a.defer_limit) ? 4 : 3;
+                    const int64_t t_last = t_ev + nsym * (int64_t)c.L;
+                    const bool oversize = s.enc_len > c.max_enc_len || s.mod_len > c.max_syms || s.payload_len > c.max_payload_len;
+                    if (oversize) {
+                        // longer than this handle decodes: reported now (header only, payload_valid = 0, the end time it will
+                        // have) and jumped over -- after its last symbol liquid is in the fresh state whatever the symbols were
+                        emit(t_last, true, false, true);
+                        handoff_last = t_last;
+                        return 2;
+                    }
+                    if (t_last >= a.end)
+                        // its payload runs past the end of this buffer: deferred (4: the next push still holds the frame's
+                        // beginning and acquires it again, whole) or left to the tail kernels (3)
+                        return (a.defer_limit > 0 && a.end - sk_cur <= a.defer_limit) ? 4 : 3;
+                    // it fits, but the job list (= the record pool) is full: dropped and counted
+                    if (l == 0) atomicAdd(a.nrec + 1, 1u);
+                    handoff_last = t_last;
+                    return 2;
                 }
             }
             else { if constexpr (MODE != SYM_SPEC) emit(t_ev, false, false); return 1; }
@@ -1359,7 +1372,11 @@ struct Walker {
                 acc = cadd(acc, cmulc(ldsc[kn], x[e]));
             }
             acc = wave_csum(acc);
+#if MCRX_S1_METRIC_G0_NORMALISED
             float2 gh = cscale(acc, s.g0 / (float)c.M_S1);
+#else
+            float2 gh = cscale(acc, 1.0f / (float)c.M_S1);
+#endif
             gh = cmul(gh, c.backoff_rot);
             const float mag = sqrtf(gh.x * gh.x + gh.y * gh.y);
             if (mag > c.sync_thresh && fabsf(atan2f(gh.y, gh.x)) < 0.1f * PI_F) {
@@ -1371,7 +1388,12 @@ struct Walker {
                 wave_sync_lds();
 #pragma unroll
                 for (int e = 0; e < E; e++) if (erank[e] >= 0) {
+#if MCRX_S1_BACKOFF_CORRECTION
+                    float sb_, cb_; sincos_u32((uint32_t)(((uint64_t)(unsigned)k[e] * (unsigned)c.backoff << 32) / (unsigned)c.M), sb_, cb_);
+                    const float2 G = cmul(cscale(x[e], g), make_float2(cb_, sb_));
+#else
                     const float2 G = cscale(x[e], g);
+#endif
                     yabs[erank[e]] = sqrtf(G.x * G.x + G.y * G.y);
                     yarg[erank[e]] = atan2f(G.y, G.x);
                 }
@@ -1536,6 +1558,26 @@ struct Walker {
         if (l == 0) { slot->start = ok ? key : -1; slot->t_last = handoff_last; slot->status = ok ? 1 : 0; }
     }
 
+    // Lean configurations' tail kernel: a channel with a payload in progress (a frame that straddles two pushes and
+    // could not be deferred, is oversize, or found the job list full) has its symbols walked here, to the frame's end
+    // or the end of the buffer.  Nothing else -- no acquisition, no speculation -- so that the kernel stays small
+    // enough to be scheduled beside the payload workers of the previous push.
+    __device__ __forceinline__ void run_tail()
+    {
+        s = a.st[ch];
+        if (!(s.state == SY_RX && s.fstate == FX_PAYLOAD)) return;
+        init_consts();
+        const int L = c.L;
+        while (true) {
+            const int64_t t_ev = s.cur + (int64_t)s.timer - 1;
+            if (t_ev >= a.end) { s.timer -= (uint32_t)(a.end - s.cur); s.cur = a.end; break; }
+            s.cur = t_ev + 1;
+            const int fr = rx_event_fast<SYM_FULL>(t_ev);
+            if (fr == 1) { reset_framesync(); s.timer = (uint32_t)L; break; }      // frame over: the lean scouts go on from here
+        }
+        if (l == 0) a.st[ch] = s;
+    }
+
     // MODE SYM_FULL: the whole state machine (general configurations; with a.tail_only the tail kernel of the lean
     // configurations: only channels with a payload in progress, and only to that frame's end).
     // MODE SYM_LEAN: the lean scout -- acquisition, header, hand-off; a payload in progress is not its business.
@@ -1571,6 +1613,7 @@ struct Walker {
                 if (a.stop_after_walk) { stopped = true; break; }
             }
             entry = false;
+            if (MODE == SYM_LEAN && s.cur >= a.end) break;      // (a frame jumped over may end beyond this buffer)
             if (s.state == SY_SEEK) { sk_cur = s.cur; sk_timer = s.timer; }
             // sample index of the next state-machine event
             int64_t t_ev;
@@ -1673,6 +1716,11 @@ __device__ __forceinline__ void launder(SyncArgs &a)
 }
 #undef LAUNDER
 
+#if SY_PART == 3
+#define SY_ACQ_WAVES 3
+#else
+#define SY_ACQ_WAVES 1
+#endif
 template <int E>
 __global__ __launch_bounds__(WV) void sync_kernel(SyncArgs a)
 {
@@ -1683,19 +1731,26 @@ __global__ __launch_bounds__(WV) void sync_kernel(SyncArgs a)
     w.template run<SYM_FULL>();
 }
 
+template <int E>
+__global__ __launch_bounds__(WV, SY_ACQ_WAVES) void sync_tail_kernel(SyncArgs a)
+{
+    __builtin_amdgcn_s_setprio(3);      // a chain of dependent events every payload launch waits for: win the issue arbitration against the workers sharing the SIMD
+    launder(a);
+    const uint32_t ch = blockIdx.x;
+    if (ch >= a.nch) return;
+    Walker<E> w(a, ch);
+    w.run_tail();
+}
+
 // the lean scout (lean configurations only): one wave per channel, acquisition + header + hand-off
 // (E <= 2: held to three waves per SIMD = 168 registers, so that a scout fits on a SIMD beside four payload workers of
 //  the previous push (4 x 80 of the 512) instead of waiting for a SIMD to drain.  These two kernels are built in their own part with
 //  the basic vector-register allocator: under this budget hipcc 7.2's default one reloads 64-bit spills into
 //  odd-aligned pairs, which its own verifier rejects.)
-#if SY_PART == 3
-#define SY_ACQ_WAVES 3
-#else
-#define SY_ACQ_WAVES 1
-#endif
 template <int E>
 __global__ __launch_bounds__(WV, SY_ACQ_WAVES) void sync_lean_kernel(SyncArgs a)
 {
+    __builtin_amdgcn_s_setprio(3);      // a chain of dependent events every payload launch waits for: win the issue arbitration against the workers sharing the SIMD
     launder(a);
     const uint32_t ch = blockIdx.x;
     if (ch >= a.nch) return;
@@ -1707,6 +1762,7 @@ __global__ __launch_bounds__(WV, SY_ACQ_WAVES) void sync_lean_kernel(SyncArgs a)
 template <int E>
 __global__ __launch_bounds__(WV, SY_ACQ_WAVES) void sync_spec_kernel(SyncArgs a)
 {
+    __builtin_amdgcn_s_setprio(3);      // a chain of dependent events every payload launch waits for: win the issue arbitration against the workers sharing the SIMD
     launder(a);
     const uint32_t ch = blockIdx.x / a.spec_cap, k = blockIdx.x % a.spec_cap;
     if (ch >= a.nch) return;
@@ -2056,7 +2112,7 @@ hipError_t sync_reset_launch(ChanState *st, uint32_t nch, int64_t cur, float2 *h
 
 // ---- launchers.  The file is compiled in three parts (-DSY_PART=0/1/2: symbol widths E = 1,2 / 4,8 / 16) so that
 // the template instantiations build in parallel; every part defines the per-width launchers of its widths.
-enum { SYK_SCOUT = 0, SYK_SPEC = 1, SYK_PAYLOAD_FAST = 2, SYK_PAYLOAD_GENERAL = 3, SYK_LEAN = 4 };
+enum { SYK_SCOUT = 0, SYK_SPEC = 1, SYK_PAYLOAD_FAST = 2, SYK_PAYLOAD_GENERAL = 3, SYK_LEAN = 4, SYK_TAIL = 5 };
 // acquisition kernels of the narrow symbols (E = 1, 2): part 3, built with -mllvm -vgpr-regalloc=basic (see SY_ACQ_BUDGET)
 hipError_t sy_launch_acq_e1(int what, const SyncArgs &a, unsigned grid, size_t lds, hipStream_t st);
 hipError_t sy_launch_acq_e2(int what, const SyncArgs &a, unsigned grid, size_t lds, hipStream_t st);
@@ -2064,6 +2120,7 @@ template <int EE>
 static hipError_t sy_launch_acq_width(int what, const SyncArgs &a, unsigned grid, size_t lds, hipStream_t st)
 {
     if (what == SYK_SPEC) hipLaunchKernelGGL((sync_spec_kernel<EE>), dim3(grid), dim3(WV), lds, st, a);
+    else if (what == SYK_TAIL) hipLaunchKernelGGL((sync_tail_kernel<EE>), dim3(grid), dim3(WV), lds, st, a);
     else hipLaunchKernelGGL((sync_lean_kernel<EE>), dim3(grid), dim3(WV), lds, st, a);
     return hipGetLastError();
 }
@@ -2076,6 +2133,11 @@ static hipError_t sy_launch_width(int what, const SyncArgs &a, unsigned grid, si
         if constexpr (EE == 1) return sy_launch_acq_e1(what, a, grid, lds, st);
         else if constexpr (EE == 2) return sy_launch_acq_e2(what, a, grid, lds, st);
         else hipLaunchKernelGGL((sync_spec_kernel<EE>), dim3(grid), dim3(WV), lds, st, a);
+        break;
+    case SYK_TAIL:
+        if constexpr (EE == 1) return sy_launch_acq_e1(what, a, grid, lds, st);
+        else if constexpr (EE == 2) return sy_launch_acq_e2(what, a, grid, lds, st);
+        else hipLaunchKernelGGL((sync_kernel<EE>), dim3(grid), dim3(WV), lds, st, a);       // (a.tail_only set by the caller)
         break;
     case SYK_LEAN:
         // (wider symbols keep the full kernel as their scout: hipcc 7.2 cannot allocate the lean one's 64-bit values
@@ -2136,6 +2198,12 @@ hipError_t sync_launch_lean(const SyncArgs &a, hipStream_t st)
     if (a.nch == 0) return hipSuccess;
     if (a.c.M > SY_MAXM) return hipErrorInvalidValue;
     return sy_launch(SYK_LEAN, a, a.nch, SY_LDS_BYTES(a.c.M), st);
+}
+
+hipError_t sync_launch_tail(const SyncArgs &a, hipStream_t st)
+{
+    if (a.nch == 0) return hipSuccess;
+    return sy_launch(SYK_TAIL, a, a.nch, SY_LDS_BYTES(a.c.M), st);
 }
 
 hipError_t sync_launch_spec(const SyncArgs &a, hipStream_t st)

@@ -191,6 +191,19 @@ void ll_ofdmflexframesync_reset(ll_ofdmflexframesync q);
 void ll_ofdmflexframesync_set_soft(ll_ofdmflexframesync q, int payload_soft);
 void ll_ofdmflexframesync_execute(ll_ofdmflexframesync q, const ll_cf *x, unsigned n);
 
+/* ---- named deviations from liquid-dsp's ofdmframesync (liquid-dsp is not available to confirm
+ * either way, so both are switches: flip them the day a libliquid can be put beside this file.  The GPU kernels carry
+ * the same two switches, MCRX_S1_BACKOFF_CORRECTION / MCRX_S1_METRIC_G0_NORMALISED in csrc/kernels.h -- keep them equal) */
+#ifndef LL_S1_BACKOFF_CORRECTION
+#define LL_S1_BACKOFF_CORRECTION 0      /* D6: 1 = apply liquid's "timing backoff correction" G[k] *= e^{j 2 pi k backoff / M}
+                                           after the S1 gain estimate.  0 here: the S1 window and every data window sit the
+                                           same `backoff` samples inside the cyclic prefix, so 1/G already removes that ramp */
+#endif
+#ifndef LL_S1_METRIC_G0_NORMALISED
+#define LL_S1_METRIC_G0_NORMALISED 1    /* D7: 1 = the S1 detection metric is scaled by the S0-stage gain g0 (level independent,
+                                           like the S0 metric); 0 = raw */
+#endif
+
 /* ---- multi-stage arbitrary resampler (liquid: src/filter/src/msresamp*.c) -- */
 typedef struct ll_msresamp_s *ll_msresamp;
 ll_msresamp ll_msresamp_create(float rate, float As);

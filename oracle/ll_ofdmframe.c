@@ -489,7 +489,9 @@ static void execute_S1(ll_ofdmframesync q)
         g_hat.re += t.re; g_hat.im += t.im;
     }
     g_hat.re /= (float)q->M_S1; g_hat.im /= (float)q->M_S1;
-    g_hat.re *= q->g0; g_hat.im *= q->g0;   /* level normalisation, as for the S0 metric */
+#if LL_S1_METRIC_G0_NORMALISED
+    g_hat.re *= q->g0; g_hat.im *= q->g0;   /* level normalisation, as for the S0 metric (D7) */
+#endif
     g_hat = cmul(g_hat, q->B[1]);      /* e^{j 2 pi backoff / M} */
     DBG("S1: |g|=%g arg=%g n=%u\n", cabs_(g_hat), carg_(g_hat), q->num_symbols);
     if (cabs_(g_hat) > q->plcp_sync_thresh && fabsf(carg_(g_hat)) < 0.1f * (float)M_PI) {
@@ -504,6 +506,9 @@ static void execute_S1(ll_ofdmframesync q)
              * so G already carries the data windows' phase ramp and 1/G removes it.  liquid
              * lists a "timing backoff correction" G *= B here; with identical alignments it
              * would re-introduce the ramp, so it is not applied. */
+#if LL_S1_BACKOFF_CORRECTION
+            t = cmul(t, q->B[i]);           /* D6 */
+#endif
             q->G[i] = t;
         }
         estimate_eqgain_poly(q);

@@ -7,9 +7,10 @@ import csv, json, os, sys, collections
 tag = sys.argv[1]
 src = os.path.join("gpurun_out", "prof_" + tag)
 dst = "profiles"
+pre = sys.argv[2] if len(sys.argv) > 2 else "r1"
 ours = ("mcrx::",)
 rows = list(csv.DictReader(open(os.path.join(src, "stats_kernel_stats.csv"))))
-with open(os.path.join(dst, "r1_%s_kernel_stats.csv" % tag), "w") as f:
+with open(os.path.join(dst, "%s_%s_kernel_stats.csv" % (pre, tag)), "w") as f:
     w = csv.DictWriter(f, fieldnames=rows[0].keys()); w.writeheader()
     for r in rows:
         if any(o in r["Name"] for o in ours): w.writerow(r)
@@ -23,7 +24,7 @@ for fn in sorted(os.listdir(src)):
         per[(name, r["Counter_Name"], r["Dispatch_Id"])] += float(r["Counter_Value"])
     for (name, cn, _), v in per.items():
         a = acc[(name, cn)]; a[0] += v; a[1] += 1
-with open(os.path.join(dst, "r1_%s_pmc.csv" % tag), "w") as f:
+with open(os.path.join(dst, "%s_%s_pmc.csv" % (pre, tag)), "w") as f:
     f.write("kernel,counter,dispatches,mean_per_dispatch\n")
     for (k, c), (s, n) in sorted(acc.items()): f.write('"%s",%s,%d,%.1f\n' % (k, c, n, s / n))
 traffic = {}
@@ -36,7 +37,7 @@ for k, t in traffic.items():
 bench = json.load(open(os.path.join(src, "bench.json")))
 json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --no-cpu --steps 5 --warmup 2`",
            "correction": "hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE counts wide coalesced reads at half size)",
-           "workload": bench["config"]["workload"], "kernels": traffic}, open(os.path.join(dst, "r1_%s_traffic.json" % tag), "w"), indent=1)
-json.dump(bench, open(os.path.join(dst, "r1_%s_bench.json" % tag), "w"))
+           "workload": bench["config"]["workload"], "kernels": traffic}, open(os.path.join(dst, "%s_%s_traffic.json" % (pre, tag)), "w"), indent=1)
+json.dump(bench, open(os.path.join(dst, "%s_%s_bench.json" % (pre, tag)), "w"))
 for k, t in traffic.items(): print(k, {a: round(b / 1e6, 1) for a, b in t.items()})
-print(open(os.path.join(dst, "r1_%s_kernel_stats.csv" % tag)).read())
+print(open(os.path.join(dst, "%s_%s_kernel_stats.csv" % (pre, tag))).read())

@@ -231,7 +231,9 @@ def test_resampled_front_end_feeds_the_receiver(oracle, product):
     n = int(d_y.numel()) // (16 * N) * (16 * N)
     rx.Execute(d_y[:n].contiguous())
     rx.Flush()
-    check_frames(rx.frames, ora.frames, rel=5e-5)
+    w = check_frames(rx.frames, ora.frames, rel=1.0)
+    print("resampled chain worst framesyms rel err %.3g" % w)
+    assert w <= REL, w
     rx.close(); rs.close()
 
 
@@ -328,7 +330,9 @@ def test_noisy_channel_same_decisions_as_oracle(oracle, product, snr_db, mod, fe
     rx = product.multichannelrx(N, M, cp, 4, max_payload_len=300)
     rx.Execute(x); rx.Flush()
     assert len(ora.frames) >= 3 * N - 1
-    check_frames(rx.frames, ora.frames, rel=2e-5)
+    w = check_frames(rx.frames, ora.frames, rel=1.0)
+    print("noisy channel snr %.0f worst framesyms rel err %.3g" % (snr_db, w))
+    assert w <= REL, w
     rx.close()
 
 
