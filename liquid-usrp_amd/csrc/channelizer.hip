@@ -317,8 +317,76 @@ static hipError_t launch_one(const ChanArgs &a, hipStream_t st)
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Any other channel count the reference constructor accepts (lib/multichannelrx.cc:54-66 only asks for N >= 1;
+// liquid's firpfbch takes any K): the same arithmetic without the register window and the radix-4 plan -- a
+// workgroup per tile of 8 blocks, FIR columns straight from global memory (the 14-fold reuse is the caches'), then a
+// direct DFT of the kept bins with an exact integer twiddle index.  A fallback for odd sizes, O(K N) per block:
+// the power-of-two kernel above is the product's fast path.
+#define CG_T 256
+__global__ __launch_bounds__(CG_T) void channelizer_generic_kernel(ChanArgs a, uint32_t K)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 gl[];        // V[CH_R][K], then W[K]
+    float2 *V = gl, *W = gl + (size_t)CH_R * K;
+    const uint32_t N = K / 2;
+    const int tid = threadIdx.x;
+    const long long b0 = (long long)blockIdx.x * CH_R;
+    const uint32_t dth = a.dtheta, t0 = a.first_sample_lo;
+    for (uint32_t i = tid; i < K; i += CG_T) {
+        float sn, cs; sincos_u32((uint32_t)((((uint64_t)i) << 32) / K), sn, cs);
+        W[i] = make_float2(cs, -sn);                                    // exp(-j 2 pi i / K)
+    }
+    for (uint32_t n = tid; n < K; n += CG_T) {
+        float2 acc[CH_R];
+#pragma unroll
+        for (int r = 0; r < CH_R; r++) acc[r] = make_float2(0.f, 0.f);
+        // mixed samples of column n, blocks b0-13 .. b0+7, oldest first; each feeds up to 8 rows
+        for (int i = 0; i < CH_H + CH_R; i++) {
+            const long long b = b0 - CH_H + i;
+            float2 x = make_float2(0.f, 0.f);
+            bool valid = false;
+            if (b >= 0 && b < (long long)a.nblocks) { x = a.x[(size_t)b * K + n]; valid = true; }
+            else if (b < 0 && a.halo != nullptr && b + CH_H >= 0) { x = a.halo[(size_t)(b + CH_H) * K + n]; valid = true; }
+            float2 u = make_float2(0.f, 0.f);
+            if (valid) u = mix_down_hw(x, (t0 + (uint32_t)(b * (long long)K + n)) * dth);
+#pragma unroll
+            for (int r = 0; r < CH_R; r++) {
+                const int j = CH_H + r - i;                             // tap branch this block is for row r
+                if (j >= 0 && j < CH_P) {
+                    const float h = a.taps[(K - 1 - n) + (uint32_t)j * K];
+                    acc[r].x += h * u.x; acc[r].y += h * u.y;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < CH_R; r++) V[(size_t)r * K + n] = acc[r];
+    }
+    __syncthreads();
+    const long long tl = b0 / CH_R;
+    for (uint32_t k = tid; k < N; k += CG_T) {
+        float2 y[CH_R];
+#pragma unroll
+        for (int r = 0; r < CH_R; r++) y[r] = make_float2(0.f, 0.f);
+        uint32_t idx = 0;
+        for (uint32_t n = 0; n < K; n++) {
+            const float2 w = W[idx];
+#pragma unroll
+            for (int r = 0; r < CH_R; r++) {
+                const float2 v = V[(size_t)r * K + n];
+                y[r].x += v.x * w.x - v.y * w.y; y[r].y += v.x * w.y + v.y * w.x;
+            }
+            idx += k; if (idx >= K) idx -= K;
+        }
+        const uint32_t g = k / a.cg, c = k % a.cg;
+        float4 *dst = reinterpret_cast<float4 *>(a.out + (((size_t)g * a.ntiles + (size_t)tl) * a.cg + c) * CH_R);
+#pragma unroll
+        for (int r = 0; r < CH_R; r += 2) dst[r / 2] = make_float4(y[r].x, y[r].y, y[r + 1].x, y[r + 1].y);
+    }
+}
+
+static bool pow2_fast(unsigned K) { return K >= 2 && K <= 1024 && (K & (K - 1)) == 0; }
 int channelizer_supported(unsigned K)
-{ return (K >= 2 && K <= 1024 && (K & (K - 1)) == 0) ? 1 : 0; }
+{ return (pow2_fast(K) || (K >= 2 && K % 2 == 0 && K <= 2048)) ? 1 : 0; }
 
 // Slab sizing.  A slab costs a 13-block halo re-read, and a grid that is not a whole number of
 // waves over the CUs idles part of the chip in its last wave (K = 1024: one 512-thread workgroup
@@ -338,6 +406,14 @@ uint32_t channelizer_auto_slab(unsigned K, size_t nblocks, unsigned ncu)
 
 hipError_t channelizer_launch(unsigned K, const ChanArgs &a, hipStream_t st)
 {
+    if (!pow2_fast(K)) {
+        if (a.nblocks == 0) return hipSuccess;
+        const size_t lds = (size_t)(CH_R + 1) * K * sizeof(float2);
+        hipError_t e = hipFuncSetAttribute((const void *)channelizer_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(channelizer_generic_kernel, dim3(a.nblocks / CH_R), dim3(CG_T), lds, st, a, (uint32_t)K);
+        return hipGetLastError();
+    }
     switch (K) {
     case 2:    return launch_one<2, 1, 256>(a, st);
     case 4:    return launch_one<4, 2, 256>(a, st);

@@ -310,7 +310,7 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     if (taper > cp) return fail(MCRX_EINVAL, "error: multichannelrx, taper length cannot exceed cyclic prefix length");
     const bool bypass = cfg && cfg->struct_size >= offsetof(mcrx_hip_config, single_channel) + sizeof(uint32_t) && cfg->single_channel;
     if (bypass && N != 1) return fail(MCRX_EINVAL, "single_channel needs num_channels == 1");
-    if (!bypass && !channelizer_supported(2 * N)) return fail(MCRX_EUNSUPP, "channelizer size 2N must be a power of two <= 1024");
+    if (!bypass && !channelizer_supported(2 * N)) return fail(MCRX_EUNSUPP, "at most 1024 channels");
     if (M > 1024) return fail(MCRX_EUNSUPP, "at most 1024 subcarriers");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
