@@ -68,6 +68,12 @@ typedef struct {
                                     end in it is acquired again by the next push -- whole, by the parallel path -- instead of
                                     being walked symbol by symbol across the boundary by one wave.  0 = off.  Stage-level callers
                                     (mcrx_hip_sync) must supply mcrx_hip_history_tiles() tiles of history themselves */
+    uint32_t front_end;          /* 0 = the reference's analysis bank: critically sampled firpfbch, 2N channels, lower N kept
+                                    (lib/multichannelrx.cc:89-91).  1 = the oversampled bank BASELINE.json names: firpfbch2 with 2N
+                                    channels (twice the channel rate, prototype cut off at the neighbour's centre) followed per kept
+                                    channel by a half-band decimator back to the channel rate -- less aliasing at the channel edges,
+                                    24 + 12 instead of 12 algorithmic bytes per sample; execute_host / execute_device only (power-of-two
+                                    channel counts) */
     uint32_t skip_framesyms;     /* 1 = harvests leave the equalised symbols in HBM (frames report num_framesyms = 0): 1.2 KB
                                     instead of 59 KB per frame over the host link at the benchmark's frame size */
 } mcrx_hip_config;

@@ -41,7 +41,7 @@ class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("max_payload_len", C.c_uint32), ("max_frames", C.c_uint32),
                 ("payload_soft", C.c_uint32), ("slab_blocks", C.c_uint32), ("channel_first", C.c_uint32),
                 ("channel_count", C.c_uint32), ("batch_samples", C.c_uint32), ("single_channel", C.c_uint32),
-                ("serial", C.c_uint32), ("chunk_blocks", C.c_uint32), ("defer_samples", C.c_uint32), ("skip_framesyms", C.c_uint32)]
+                ("serial", C.c_uint32), ("chunk_blocks", C.c_uint32), ("defer_samples", C.c_uint32), ("front_end", C.c_uint32), ("skip_framesyms", C.c_uint32)]
 
 
 class FrameC(C.Structure):

@@ -3,6 +3,7 @@
 // harvesting.  Host code only; the kernels live in channelizer.hip / ofdmsync.hip.
 #include "../../include/mcrx_hip.h"
 #include "design.hpp"
+#include "devmath.h"
 #include "kernels.h"
 #include "txcode.hpp"
 
@@ -72,6 +73,43 @@ __global__ void hist_update_kernel(const float2 *old_hist, const float2 *x, uint
     if (i >= nh) return;
     uint64_t pos = nx + i;
     new_hist[i] = (pos < nh) ? old_hist[pos] : x[pos - nh];
+}
+
+// oversampled front end (cfg.front_end = 1): the oscillator as its own pass (the oversampled bank takes plain samples) ...
+__global__ void nco_mix_kernel(const float2 *x, float2 *y, uint64_t n, uint32_t first_lo, uint32_t dtheta)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    y[i] = mix_down_hw(x[i], (first_lo + (uint32_t)i) * dtheta);
+}
+// ... and the rate 2 -> 1 adapter behind it: per kept channel liquid's half-band decimator (resamp2_crcf, m = 7):
+//     y[k] = 0.5 * ( Y[2k - 13] + sum_{i < 14} h1[i] Y[2 (k - 13 + i)] )
+// over the bank's steps Y[s][0 .. M-1] (32 steps of history sit in front of s = 0), written as the synchronizers'
+// (channel, tile) granules.  A thread takes one granule: channels are consecutive across a wave, so every read of a
+// step row is one contiguous line and the 64-byte granules of a wave form one 4 KB store.
+__global__ void halfband_adapter_kernel(const float2 *Y, uint32_t M, uint32_t N, uint32_t ntiles, const float *h1, float2 *out)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x, tile = blockIdx.y;
+    if (c >= N || tile >= ntiles) return;
+    float h[14];
+#pragma unroll
+    for (int i = 0; i < 14; i++) h[i] = h1[i];
+    const long long k0 = (long long)tile * 8;
+    float2 ev[21];                                  // even steps 2 (k0 - 13) .. 2 (k0 + 7)
+#pragma unroll
+    for (int i = 0; i < 21; i++) ev[i] = Y[(2 * (k0 - 13 + i)) * (long long)M + c];
+    float4 *dst = reinterpret_cast<float4 *>(out + ((size_t)tile * N + c) * 8);
+    float2 y[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 14; i++) { acc.x += h[i] * ev[t + i].x; acc.y += h[i] * ev[t + i].y; }
+        const float2 d = Y[(2 * (k0 + t) - 13) * (long long)M + c];
+        y[t] = make_float2(0.5f * (d.x + acc.x), 0.5f * (d.y + acc.y));
+    }
+#pragma unroll
+    for (int t = 0; t < 8; t += 2) dst[t / 2] = make_float4(y[t].x, y[t].y, y[t + 1].x, y[t + 1].y);
 }
 
 // ---------------------------------------------------------------- handle
@@ -144,6 +182,11 @@ struct mcrx_hip_s {
     float2 *h_stage = nullptr; size_t stage_cap = 0, stage_fill = 0;   // pinned host staging (samples)
     float2 *d_chan[MCRX_SLOTS] = {}; size_t chan_cap_tiles = 0;
     unsigned hist_tiles = 0; uint64_t defer = 0;
+    // oversampled front end (cfg.front_end = 1): the bank, its input (28 N samples of history in front) and output (32
+    // steps of history in front), both double buffered so that a push's history comes from the other buffer
+    bool oversampled = false; mcrx_hip_pfb2_t pfb2 = nullptr; const float *d_h1 = nullptr;
+    float2 *d_pfin[2] = { nullptr, nullptr }, *d_pfout[2] = { nullptr, nullptr }; size_t pf_cap_blocks = 0; int pf_cur = 0;
+    uint64_t pf_in_valid = 0, pf_steps = 0; size_t pf_last_blocks = 0; bool pf_have_last = false;
     hipStream_t stream = nullptr;
     // large host buffers skip the staging copy: chunks go from the caller's memory to one of two device buffers
     float2 *d_direct[2] = { nullptr, nullptr }; size_t direct_cap = 0; int direct_idx = 0; bool direct_used[2] = { false, false };
@@ -285,6 +328,7 @@ static int restart_async(mcrx_hip_t q, hipStream_t st, bool from_zero)
     q->stage_fill = 0; q->stage_first = q->total_samples;
     q->hist_cur = 0;
     q->last_slot = -1; q->last_ntiles = 0;
+    q->pf_in_valid = 0; q->pf_steps = 0; q->pf_have_last = false;
     RC(join_into(q, st));
     // (both result generations: counters zeroed; the prediction lists only survive a Reset(), not a restart from zero)
     for (int g = 0; g < MCRX_GENS; g++) {
@@ -355,6 +399,8 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     { int dev = 0, n = 0;
       if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
           q->ncu = (uint32_t)n; }
+    q->oversampled = !bypass && q->cfg.struct_size >= offsetof(mcrx_hip_config, front_end) + sizeof(uint32_t) && q->cfg.front_end == 1;
+    if (q->oversampled && ((q->K & (q->K - 1)) || q->K > 1024 || q->K < 2)) { delete q; return fail(MCRX_EUNSUPP, "the oversampled front end needs a power-of-two channel count <= 512"); }
     q->taps = bypass ? std::vector<float>(14, 0.f) : pfb_prototype(q->K, 7, 60.0f);
     q->dtheta = bypass ? 0u : channel_center_step(N);
     // channel-rate history in front of every push's tiles: a symbol window, plus -- if frames straddling two pushes are
@@ -366,6 +412,14 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     int rc;
     if ((rc = q->upload(&q->d_taps, q->taps.data(), q->taps.size()))) return bail(rc);
     if ((rc = build_tables(q))) return bail(rc);
+    if (q->oversampled) {
+        if (mcrx_hip_pfb2_create(&q->pfb2, q->K, 7, 60.0f) != MCRX_OK) return bail(fail(MCRX_EHIP, mcrx_hip_pfb2_last_error()));
+        // half-band branch filter of liquid's resamp2 (as in msresamp.hip): odd taps of a 29-tap Kaiser design, reversed
+        std::vector<float> hh = firdes_kaiser(29, 0.25f, 60.0f), h1(14);
+        unsigned j = 0;
+        for (unsigned i = 1; i < 29; i += 2) h1[j++] = hh[29 - i - 1];
+        if ((rc = q->upload(&q->d_h1, h1.data(), h1.size()))) return bail(rc);
+    }
     if ((rc = q->alloc(&q->d_st, q->nch))) return bail(rc);
     if ((rc = q->alloc(&q->d_hbits, (size_t)q->nch * MCRX_HDR_SYMS))) return bail(rc);
     if ((rc = q->alloc(&q->d_R, (size_t)q->nch * M))) return bail(rc);
@@ -459,6 +513,8 @@ extern "C" int mcrx_hip_destroy(mcrx_hip_t q)
     }
     for (void *p : q->owned) (void)hipFree(p);
     for (int i = 0; i < MCRX_SLOTS; i++) if (q->d_chan[i]) (void)hipFree(q->d_chan[i]);
+    for (int i = 0; i < 2; i++) { if (q->d_pfin[i]) (void)hipFree(q->d_pfin[i]); if (q->d_pfout[i]) (void)hipFree(q->d_pfout[i]); }
+    if (q->pfb2) (void)mcrx_hip_pfb2_destroy(q->pfb2);
     if (q->h_stage) (void)hipHostFree(q->h_stage);
     q->arena_host.release(); q->sarena_host.release();
     {
@@ -596,6 +652,7 @@ extern "C" int mcrx_hip_channelize(mcrx_hip_t q, const void *d_iq, size_t nblock
                                    const void *d_halo, void *d_out, unsigned groups, void *stream)
 {
     if (q && q->bypass) return fail(MCRX_EUNSUPP, "single_channel handle has no channelizer");
+    if (q && q->oversampled) return fail(MCRX_EUNSUPP, "the oversampled front end runs inside execute_host / execute_device only");
     if (!q || !d_iq || !d_out) return fail(MCRX_EINVAL, "null argument");
     hipStream_t st = stream ? (hipStream_t)stream : q->stream;
     return launch_channelizer(q, (const float2 *)d_iq, nblocks, first_sample, (const float2 *)d_halo,
@@ -653,6 +710,55 @@ static int ensure_chan(mcrx_hip_t q, size_t tiles)
     return MCRX_OK;
 }
 
+// cfg.front_end = 1: oscillator -> 2N-channel oversampled bank (two steps per block) -> half-band decimator per kept
+// channel -> the synchronizers' tiles.  Input and bank output are double buffered with their filter history in front.
+static int run_oversampled(mcrx_hip_t q, const float2 *x, size_t nblocks, uint64_t first_abs, float2 *tiles, hipStream_t sc)
+{
+    const size_t M = q->K, N = q->N, lead = (size_t)28 * N, hsteps = 32, nsteps = 2 * nblocks, nin = nblocks * q->K;
+    if (nblocks > q->pf_cap_blocks) {
+        HIPCHK(hipDeviceSynchronize());
+        float2 *ni[2] = { nullptr, nullptr }, *no[2] = { nullptr, nullptr };
+        for (int i = 0; i < 2; i++) {
+            HIPCHK(hipMalloc((void **)&ni[i], (lead + nblocks * q->K) * sizeof(float2)));
+            HIPCHK(hipMalloc((void **)&no[i], (hsteps + 2 * nblocks) * M * sizeof(float2)));
+            HIPCHK(hipMemset(ni[i], 0, lead * sizeof(float2)));
+            HIPCHK(hipMemset(no[i], 0, hsteps * M * sizeof(float2)));
+        }
+        if (q->pf_have_last) {      // carry the filter histories over: the tails of the last push
+            const int c = q->pf_cur;
+            HIPCHK(hipMemcpy(ni[c] + q->pf_last_blocks * q->K, q->d_pfin[c] + q->pf_last_blocks * q->K, lead * sizeof(float2), hipMemcpyDeviceToDevice));
+            HIPCHK(hipMemcpy(no[c] + 2 * q->pf_last_blocks * M, q->d_pfout[c] + 2 * q->pf_last_blocks * M, hsteps * M * sizeof(float2), hipMemcpyDeviceToDevice));
+        }
+        for (int i = 0; i < 2; i++) {
+            if (q->d_pfin[i]) (void)hipFree(q->d_pfin[i]);
+            if (q->d_pfout[i]) (void)hipFree(q->d_pfout[i]);
+            q->d_pfin[i] = ni[i]; q->d_pfout[i] = no[i];
+        }
+        q->pf_cap_blocks = nblocks;
+    }
+    const int prev = q->pf_cur, cur = prev ^ 1;
+    float2 *in = q->d_pfin[cur], *out = q->d_pfout[cur];
+    if (q->pf_have_last) {
+        HIPCHK(hipMemcpyAsync(in, q->d_pfin[prev] + q->pf_last_blocks * q->K, lead * sizeof(float2), hipMemcpyDeviceToDevice, sc));
+        HIPCHK(hipMemcpyAsync(out, q->d_pfout[prev] + 2 * q->pf_last_blocks * M, hsteps * M * sizeof(float2), hipMemcpyDeviceToDevice, sc));
+    } else {
+        HIPCHK(hipMemsetAsync(in, 0, lead * sizeof(float2), sc));
+        HIPCHK(hipMemsetAsync(out, 0, hsteps * M * sizeof(float2), sc));
+    }
+    hipLaunchKernelGGL(nco_mix_kernel, dim3((unsigned)((nin + 255) / 256)), dim3(256), 0, sc, x, in + lead, (uint64_t)nin, (uint32_t)first_abs, q->dtheta);
+    HIPCHK(hipGetLastError());
+    RC(q->ev_begin(0, sc));
+    if (mcrx_hip_pfb2_analyze(q->pfb2, in + lead, (size_t)std::min<uint64_t>(q->pf_in_valid, lead), nsteps, q->pf_steps, out + hsteps * M, sc) != MCRX_OK)
+        return fail(MCRX_EHIP, mcrx_hip_pfb2_last_error());
+    hipLaunchKernelGGL(halfband_adapter_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)(nblocks / MCRX_TILE)), dim3(64), 0, sc,
+                       out + hsteps * M, (uint32_t)M, (uint32_t)N, (uint32_t)(nblocks / MCRX_TILE), q->d_h1, tiles);
+    HIPCHK(hipGetLastError());
+    RC(q->ev_end(0, sc));
+    q->pf_cur = cur; q->pf_last_blocks = nblocks; q->pf_have_last = true;
+    q->pf_in_valid += nin; q->pf_steps += nsteps;
+    return MCRX_OK;
+}
+
 // channelize + synchronize `nblocks` (multiple of 8) blocks sitting in device memory, readable in `st`'s order.
 // Launch k writes the channel tiles of slot k % 3: [history: the last hist_tiles tiles of launch k-1][ntiles new].
 static int run_blocks(mcrx_hip_t q, const float2 *x, size_t nblocks, uint64_t first_abs, hipStream_t st)
@@ -676,10 +782,12 @@ static int run_blocks(mcrx_hip_t q, const float2 *x, size_t nblocks, uint64_t fi
                               (size_t)q->hist_tiles * tile_elems * sizeof(float2), hipMemcpyDeviceToDevice, sc));
     if (q->bypass)      // the input already is the channel's sample stream (8 samples per tile, contiguous)
         HIPCHK(hipMemcpyAsync(buf + q->hist_tiles * tile_elems, x, nblocks * sizeof(float2), hipMemcpyDeviceToDevice, sc));
+    else if (q->oversampled)
+        RC(run_oversampled(q, x, nblocks, first_abs, buf + q->hist_tiles * tile_elems, sc));
     else
         RC(launch_channelizer(q, x, nblocks, first_abs, q->d_hist[q->hist_cur], buf + q->hist_tiles * tile_elems, 1, ntiles, sc));
     // FIR history: last 13 blocks of (history, x)
-    if (!q->bypass) {
+    if (!q->bypass && !q->oversampled) {
         const uint64_t nh = (uint64_t)HIST_BLOCKS * q->K;
         hipLaunchKernelGGL(hist_update_kernel, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, sc,
                            q->d_hist[q->hist_cur], x, (uint64_t)nblocks * q->K, q->d_hist[1 - q->hist_cur], nh);

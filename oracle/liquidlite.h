@@ -223,6 +223,9 @@ void     ll_mcrx_execute(ll_mcrx q, const ll_cf *x, unsigned n);
 void     ll_mcrx_execute_parallel(ll_mcrx q, const ll_cf *x, unsigned n, int nthreads);   /* OpenMP: banks over time, synchronizers over channels */
 /* stage tap for parity tests: NCO + analyzer only, keeps bins [0,N): out[nblocks][N] */
 void     ll_mcrx_channelize(ll_mcrx q, const ll_cf *x, unsigned nblocks, ll_cf *out);
+/* alternate front end: firpfbch2 (2x oversampled, 2N channels) + half-band decimator per channel, see ll_multichannel.c */
+void     ll_mcrx_set_front_end(ll_mcrx q, int oversampled);
+void     ll_mcrx_channelize_oversampled(ll_mcrx q, const ll_cf *x, unsigned nblocks, ll_cf *out);
 
 typedef struct ll_mctx_s *ll_mctx;
 ll_mctx  ll_mctx_create(unsigned N, unsigned M, unsigned cp, unsigned taper, const unsigned char *p);

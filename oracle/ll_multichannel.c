@@ -26,8 +26,11 @@
 #include <stdio.h>
 
 /* ================================================================== multichannelrx */
+struct ll_resamp2_s;
 struct ll_mcrx_s {
     unsigned N, M, cp, taper;
+    /* alternate front end (ll_mcrx_set_front_end(q, 1)): 2N-channel 2x-oversampled bank + a half-band decimator per channel */
+    int front_end; ll_firpfbch2 ch2; struct ll_resamp2_s *hb; ll_cf *Y2, *pair; unsigned step;
     ll_firpfbch ch;
     ll_cf *x, *X;
     unsigned buffer_index;
@@ -72,15 +75,19 @@ ll_mcrx ll_mcrx_create(unsigned N, unsigned M, unsigned cp, unsigned taper, cons
     ll_mcrx_reset(q);
     return q;
 }
+static void mcrx_free_oversampled(ll_mcrx q);
 void ll_mcrx_destroy(ll_mcrx q)
 {
     if (!q) return;
+    mcrx_free_oversampled(q);
     for (unsigned i = 0; i < q->N; i++) ll_ofdmflexframesync_destroy(q->fs[i]);
     ll_firpfbch_destroy(q->ch);
     free(q->fs); free(q->X); free(q->x); free(q->par_buf); free(q);
 }
+static void mcrx_reset_oversampled(ll_mcrx q);
 void ll_mcrx_reset(ll_mcrx q)
 {
+    mcrx_reset_oversampled(q);
     for (unsigned i = 0; i < q->N; i++) ll_ofdmflexframesync_reset(q->fs[i]);
     ll_firpfbch_reset(q->ch);
     memset(q->X, 0, sizeof(ll_cf) * 2 * q->N);
@@ -90,8 +97,10 @@ void ll_mcrx_reset(ll_mcrx q)
 void ll_mcrx_set_soft(ll_mcrx q, int s)
 { for (unsigned i = 0; i < q->N; i++) ll_ofdmflexframesync_set_soft(q->fs[i], s); }
 
+static void mcrx_execute_oversampled(ll_mcrx q, const ll_cf *xin, unsigned n);
 void ll_mcrx_execute(ll_mcrx q, const ll_cf *xin, unsigned n)
 {
+    if (q->front_end) { mcrx_execute_oversampled(q, xin, n); return; }
     unsigned K = 2 * q->N;
     for (unsigned i = 0; i < n; i++) {
         q->x[q->buffer_index] = ll_nco_mix_down(&q->nco, xin[i]);
@@ -244,7 +253,7 @@ void ll_mctx_generate_samples(ll_mctx q, ll_cf *buf)
 
 /* ================================================================== msresamp */
 #define RS_PHASE_BITS 24
-typedef struct { unsigned m; float *h1; ll_cf *w0, *w1; } ll_resamp2;   /* half-band decimator */
+typedef struct ll_resamp2_s { unsigned m; float *h1; ll_cf *w0, *w1; } ll_resamp2;   /* half-band decimator */
 
 struct ll_msresamp_s {
     float rate, As;
@@ -406,4 +415,73 @@ void ll_msresamp_execute(ll_msresamp q, const ll_cf *x, unsigned nx, ll_cf *y, u
         n += resamp_arb(q, v, y + n);
     }
     *ny = n;
+}
+
+/* ================================================================== multichannelrx, oversampled front end
+ * The channelizer BASELINE.json's north_star names: liquid's firpfbch2_crcf (2N channels, every N input samples one
+ * sample on each channel = twice the channel rate, prototype cut off at the neighbouring channel's centre) in place of
+ * the critically sampled firpfbch of lib/multichannelrx.cc:89-91, followed per kept channel by a half-band decimator
+ * (liquid resamp2_crcf, m = 7, 60 dB) that brings the stream back to the rate the frame synchronizers expect.  Same
+ * oscillator, same channel <-> bin assignment, same synchronizers; not the reference's receiver (different filters),
+ * so it is compared with the GPU build of the same chain, and with what the transmitter sent. */
+void ll_mcrx_set_front_end(ll_mcrx q, int oversampled)
+{
+    q->front_end = oversampled ? 1 : 0;
+    if (q->front_end && !q->ch2) {
+        q->ch2 = ll_firpfbch2_create_kaiser(2 * q->N, 7, 60.0f);
+        q->hb = (ll_resamp2 *)calloc(q->N, sizeof(ll_resamp2));
+        for (unsigned c = 0; c < q->N; c++) resamp2_init(&q->hb[c], 7, 60.0f);
+        q->Y2 = (ll_cf *)calloc(2 * q->N, sizeof(ll_cf));
+        q->pair = (ll_cf *)calloc(q->N, sizeof(ll_cf));
+    }
+    q->step = 0; q->buffer_index = 0;
+}
+static void mcrx_reset_oversampled(ll_mcrx q)
+{
+    if (!q->ch2) return;
+    ll_firpfbch2_reset(q->ch2);
+    for (unsigned c = 0; c < q->N; c++) {
+        memset(q->hb[c].w0, 0, sizeof(ll_cf) * 2 * q->hb[c].m);
+        memset(q->hb[c].w1, 0, sizeof(ll_cf) * 2 * q->hb[c].m);
+    }
+    q->step = 0;
+}
+static void mcrx_free_oversampled(ll_mcrx q)
+{
+    if (!q->ch2) return;
+    ll_firpfbch2_destroy(q->ch2);
+    for (unsigned c = 0; c < q->N; c++) { free(q->hb[c].h1); free(q->hb[c].w0); free(q->hb[c].w1); }
+    free(q->hb); free(q->Y2); free(q->pair);
+}
+static void mcrx_execute_oversampled(ll_mcrx q, const ll_cf *xin, unsigned n)
+{
+    const unsigned N = q->N;
+    for (unsigned i = 0; i < n; i++) {
+        q->x[q->buffer_index] = ll_nco_mix_down(&q->nco, xin[i]);
+        ll_nco_step(&q->nco);
+        if (++q->buffer_index == N) {                       /* one step of the oversampled bank per N samples */
+            q->buffer_index = 0;
+            ll_firpfbch2_analyzer_execute(q->ch2, q->x, q->Y2);
+            if (q->step & 1) {
+                for (unsigned c = 0; c < N; c++) {
+                    ll_cf y = resamp2_decim(&q->hb[c], q->pair[c], q->Y2[c]);
+                    ll_ofdmflexframesync_execute(q->fs[c], &y, 1);
+                }
+            } else memcpy(q->pair, q->Y2, sizeof(ll_cf) * N);
+            q->step++;
+        }
+    }
+}
+/* the channel streams after the adapter, [block][N], for stage-level parity */
+void ll_mcrx_channelize_oversampled(ll_mcrx q, const ll_cf *xin, unsigned nblocks, ll_cf *out)
+{
+    const unsigned N = q->N;
+    ll_mcrx_set_front_end(q, 1);
+    for (unsigned b = 0; b < nblocks; b++)
+        for (unsigned half = 0; half < 2; half++) {
+            for (unsigned i = 0; i < N; i++) { q->x[i] = ll_nco_mix_down(&q->nco, xin[((size_t)2 * b + half) * N + i]); ll_nco_step(&q->nco); }
+            ll_firpfbch2_analyzer_execute(q->ch2, q->x, q->Y2);
+            if (half) for (unsigned c = 0; c < N; c++) out[(size_t)b * N + c] = resamp2_decim(&q->hb[c], q->pair[c], q->Y2[c]);
+            else memcpy(q->pair, q->Y2, sizeof(ll_cf) * N);
+        }
 }

@@ -126,6 +126,8 @@ def lib():
     sig("ll_mcrx_reset", None, vp)
     sig("ll_mcrx_set_soft", None, vp, i)
     sig("ll_mcrx_execute", None, vp, vp, u)
+    sig("ll_mcrx_set_front_end", None, vp, C.c_int)
+    sig("ll_mcrx_channelize_oversampled", None, vp, vp, u, vp)
     sig("ll_mcrx_execute_parallel", None, vp, vp, u, i)
     sig("ll_mcrx_channelize", None, vp, vp, u, vp)
     sig("ll_mctx_create", vp, u, u, u, u, vp)
@@ -446,9 +448,10 @@ class FlexFrameSync:
 class MultiChannelRx:
     """Oracle mirror of the reference class (lib/multichannelrx.cc)."""
 
-    def __init__(self, N, M, cp, taper, p=None, soft=True, count_only=False):
+    def __init__(self, N, M, cp, taper, p=None, soft=True, count_only=False, front_end=0):
         """count_only: frames are only counted, in C (self.counts()), instead of being handed to Python --
-        for timing the receiver itself."""
+        for timing the receiver itself.  front_end=1: the 2x-oversampled bank + half-band adapter in place of the
+        critically sampled bank."""
         self.N, self.K = N, 2 * N
         self.frames = []
         if count_only:
@@ -466,6 +469,15 @@ class MultiChannelRx:
         if not self.q:
             raise ValueError("invalid multichannelrx arguments")
         lib().ll_mcrx_set_soft(self.q, 1 if soft else 0)
+        if front_end:
+            lib().ll_mcrx_set_front_end(self.q, 1)
+
+    def channelize_oversampled(self, x):
+        x = np.ascontiguousarray(x, np.complex64)
+        nb = len(x) // self.K
+        out = np.zeros((nb, self.N), np.complex64)
+        lib().ll_mcrx_channelize_oversampled(self.q, _ptr(x), nb, _ptr(out))
+        return out
 
     def execute(self, x):
         x = np.ascontiguousarray(x, np.complex64)

@@ -458,3 +458,39 @@ def test_oversampled_bank_argument_errors(product):
     for M, m in [(0, 4), (7, 4), (8, 0)]:                                # firpfbch2_crcf_create: even M, m >= 1
         with pytest.raises(ValueError):
             product.firpfbch2(M, m)
+
+
+@pytest.mark.parametrize("N,M,cp,mod,fec1,plen", [(8, 64, 8, 40, 6, 400), (4, 256, 32, 27, 7, 300), (64, 64, 8, 40, 6, 120), (512, 64, 8, 40, 6, 64)])
+def test_oversampled_front_end_full_chain(oracle, product, N, M, cp, mod, fec1, plen):
+    """front_end = 1: the 2x-oversampled bank BASELINE.json names (firpfbch2, 2N channels) with its rate 2 -> 1
+    half-band adapter in front of the synchronizers, against the same chain in the oracle: every frame, bit for bit,
+    equalised symbols within 1e-5 -- in one push and in uneven pieces -- and what the transmitter sent."""
+    torch = _torch()
+    tx = product.multichanneltx(N, M, cp, 4)
+    iq, sent = tx.generate(2, plen, mod=mod, fec1=fec1, seed=N + M)
+    tx.close()
+    K = 2 * N
+    n = int(iq.numel()) // (16 * N) * (16 * N)
+    x = iq[:n].cpu().numpy()
+    ora = oracle.MultiChannelRx(N, M, cp, 4, front_end=1)
+    for i in range(0, n, 1 << 22):
+        ora.execute(x[i:i + (1 << 22)])
+    assert len(ora.frames) == 2 * N and all(f.payload_valid for f in ora.frames)
+    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=max(plen, 64), front_end=1)
+    rx.Execute(iq[:n]); rx.Flush()
+    worst = check_frames(rx.frames, ora.frames)
+    for f in rx.frames:
+        assert sent[f.channel][(f.header[0] << 8) | f.header[1]] == (f.header, f.payload)
+    rx.close()
+    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=max(plen, 64), front_end=1)
+    rng = np.random.RandomState(5)
+    i = 0
+    while i < n:
+        step = 16 * N * int(rng.randint(1, 40) if N <= 64 else rng.randint(200, 900))
+        rx.Execute(iq[i:min(i + step, n)]); i += step
+    rx.Flush()
+    check_frames(rx.frames, ora.frames)
+    rx.close()
+    with pytest.raises(Exception):
+        product.multichannelrx(3, 64, 8, 4, front_end=1)
+    print("oversampled front end N=%d M=%d worst framesyms rel err %.3g" % (N, M, worst))
