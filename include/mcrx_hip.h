@@ -207,6 +207,26 @@ size_t mctx_hip_blocks_for(mctx_hip_t q, unsigned frames_per_channel, unsigned p
 int    mctx_hip_generate(mctx_hip_t q, void *d_iq, size_t nblocks, unsigned frames_per_channel,
                          unsigned payload_len, int mod, int fec0, int fec1, float gain, uint32_t seed,
                          uint8_t *hdr, uint8_t *pay, void *stream);
+/* Sharded form (the transmit side of src/multichannel_txrx.cc over several GPUs; mirror image of the receiver's
+ * stage interface): frame generators are channel-sharded (multichanneltx.cc:230-242 steps N independent
+ * ofdmflexframegen objects), the synthesis bank + oscillator (multichanneltx.cc:192-227) time-sharded.
+ *   traffic_create    frames of channels [ch_first, ch_first+ch_count), the traffic recipe and seeds of
+ *                     mctx_hip_generate; hdr[c][frame][8] / pay[c][frame][payload_len] may be NULL
+ *   traffic_tiles     their channel-rate samples for blocks [first_block, first_block+nblocks) as granules
+ *                     d_tiles[tile][c][8] (cf32; zeros before block 0 and after the last frame); nblocks % 8 == 0
+ *   synthesize_tiles  d_tiles[groups][(lead+nblocks)/8][N/groups][8] (granules as received from `groups` channel
+ *                     shards, covering blocks [first_block-lead, first_block+nblocks)) -> wideband samples of blocks
+ *                     [first_block-keep, first_block+nblocks) into d_iq; lead >= 25 + keep blocks of filter history,
+ *                     lead % 8 == 0.  Equals the same blocks of mctx_hip_generate's stream bit for bit. */
+typedef struct mctx_hip_traffic_s *mctx_hip_traffic_t;
+int    mctx_hip_traffic_create(mctx_hip_t q, mctx_hip_traffic_t *out, unsigned ch_first, unsigned ch_count,
+                               unsigned frames_per_channel, unsigned payload_len, int mod, int fec0, int fec1,
+                               uint32_t seed, uint8_t *hdr, uint8_t *pay, void *stream);
+int    mctx_hip_traffic_destroy(mctx_hip_traffic_t t);
+int    mctx_hip_traffic_tiles(mctx_hip_traffic_t t, long long first_block, size_t nblocks, void *d_tiles, void *stream);
+int    mctx_hip_synthesize_tiles(mctx_hip_t q, const void *d_tiles, unsigned groups, long long first_block,
+                                 size_t nblocks, size_t lead_blocks, size_t keep_blocks, float gain, void *d_iq,
+                                 void *stream);
 /* Streaming form = the class interface of lib/multichanneltx.cc, one call per reference method:
  *   stream_begin    starts streaming with frame slots for payloads up to max_payload_len (slots grow on demand)
  *   stream_ready    IsChannelReadyForData (:147-162): 1 ready, 0 frame still going out, <0 error

@@ -97,6 +97,12 @@ _EXPORTS = {
     "mctx_hip_blocks_for": (C.c_size_t, [C.c_void_p, C.c_uint, C.c_uint, C.c_int, C.c_int, C.c_int]),
     "mctx_hip_generate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint, C.c_uint, C.c_int, C.c_int, C.c_int,
                                     C.c_float, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mctx_hip_traffic_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_int, C.c_int,
+                                          C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mctx_hip_traffic_destroy": (C.c_int, [C.c_void_p]),
+    "mctx_hip_traffic_tiles": (C.c_int, [C.c_void_p, C.c_longlong, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "mctx_hip_synthesize_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_longlong, C.c_size_t, C.c_size_t, C.c_size_t,
+                                            C.c_float, C.c_void_p, C.c_void_p]),
     "mctx_hip_frame_len": (C.c_size_t, [C.c_void_p, C.c_uint, C.c_int, C.c_int, C.c_int]),
     "mctx_hip_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_float,
                                  C.c_void_p, C.c_size_t]),
@@ -401,6 +407,50 @@ class msresamp(object):
             pass
 
 
+class TxTraffic(object):
+    """The frames of one channel shard of a multichanneltx, modulated and resident in HBM (mctx_hip_traffic_*).
+    sent[c] = [(header, payload), ...] for local channel c (global channel = channel_first + c)."""
+
+    def __init__(self, tx, channel_first, channel_count, frames, payload_len, mod, fec0, fec1, seed, stream=None):
+        import torch
+        self._t = C.c_void_p()
+        self.tx, self.channel_first, self.channel_count = tx, channel_first, channel_count
+        hdr = np.zeros((channel_count, frames, 8), np.uint8)
+        pay = np.zeros((channel_count, frames, max(payload_len, 1)), np.uint8)
+        st = stream if stream is not None else torch.cuda.current_stream()
+        rc = lib().mctx_hip_traffic_create(tx._h, C.byref(self._t), channel_first, channel_count, frames, payload_len, mod, fec0,
+                                           fec1, seed & 0xFFFFFFFF, hdr.ctypes.data, pay.ctypes.data, _stream_ptr(st))
+        if rc != MCRX_OK:
+            self._t = C.c_void_p()
+            msg = lib().mctx_hip_last_error().decode()
+            if rc == MCRX_EINVAL:
+                raise ValueError(msg)
+            raise McrxError("mctx_hip_traffic_create failed (%d): %s" % (rc, msg))
+        self.blocks = int(lib().mctx_hip_blocks_for(tx._h, frames, payload_len, mod, fec0, fec1))
+        self.sent = [[(bytes(hdr[c, f]), bytes(pay[c, f, :payload_len])) for f in range(frames)] for c in range(channel_count)]
+
+    def tiles(self, first_block, nblocks, out, stream=None):
+        """Channel-rate granules out[tile][c][8] of blocks [first_block, first_block+nblocks) (zeros outside the traffic)."""
+        import torch
+        assert nblocks % 8 == 0 and out.numel() >= nblocks * self.channel_count
+        st = stream if stream is not None else torch.cuda.current_stream(out.device)
+        rc = lib().mctx_hip_traffic_tiles(self._t, first_block, nblocks, _dptr(out), _stream_ptr(st))
+        if rc != MCRX_OK:
+            raise McrxError("mctx_hip_traffic_tiles failed (%d): %s" % (rc, lib().mctx_hip_last_error().decode()))
+        return out
+
+    def close(self):
+        if getattr(self, "_t", None) is not None and self._t:
+            lib().mctx_hip_traffic_destroy(self._t)
+            self._t = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class multichanneltx(object):
     """GPU multichannel OFDM transmitter used as the synthetic IQ source
     (reference: lib/multichanneltx.cc + the traffic loop of src/multichannel_tx.cc:163-213).
@@ -443,6 +493,25 @@ class multichanneltx(object):
         sent = [[(bytes(hdr[c, f]), bytes(pay[c, f, :payload_len])) for f in range(frames_per_channel)]
                 for c in range(self.N)]
         return iq, sent
+
+    # ---- sharded form: channel-sharded frame generators, time-sharded synthesis bank (see sharding.TxPipeline)
+    def traffic(self, channel_first, channel_count, frames_per_channel, payload_len, mod=LIQUID_MODEM_QPSK,
+                fec0=LIQUID_FEC_NONE, fec1=LIQUID_FEC_HAMMING128, seed=0xC0FFEE, stream=None):
+        """Frames of a channel shard (same recipe and seeds as generate()): a TxTraffic with .tiles() and .sent."""
+        return TxTraffic(self, channel_first, channel_count, frames_per_channel, payload_len, mod, fec0, fec1, seed, stream)
+
+    def synthesize(self, tiles, groups, first_block, nblocks, lead_blocks, keep_blocks=0, gain=None, out=None, stream=None):
+        """Wideband samples of blocks [first_block-keep, first_block+nblocks) from exchanged channel-rate granules
+        tiles[groups][(lead+nblocks)/8][N/groups][8] (mctx_hip_synthesize_tiles)."""
+        import torch
+        if out is None:
+            out = torch.empty((keep_blocks + nblocks) * self.K, dtype=torch.complex64, device=tiles.device)
+        assert tiles.numel() >= (lead_blocks + nblocks) * self.N and out.numel() >= (keep_blocks + nblocks) * self.K
+        g = (1.0 / self.N) if gain is None else gain
+        st = stream if stream is not None else torch.cuda.current_stream(tiles.device)
+        self._chk(lib().mctx_hip_synthesize_tiles(self._h, _dptr(tiles), groups, first_block, nblocks, lead_blocks, keep_blocks,
+                                                  g, _dptr(out), _stream_ptr(st)), "mctx_hip_synthesize_tiles")
+        return out
 
     # ---- class interface of the reference (lib/multichanneltx.cc:126-227), served by the GPU one symbol period at a time
     def _begin(self, payload_len):

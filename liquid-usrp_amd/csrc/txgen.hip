@@ -170,6 +170,10 @@ struct TxSynthArgs {
     uint32_t xstride;           // symbols per channel slot in xsym
     long long b_first;          // absolute index of this launch's block 0
     int hist;                   // blocks of inverse-FFT history stored in front of v (0: cold start)
+    // sharded synthesis (mctx_hip_synthesize_tiles): the bank's inputs come from exchanged channel-rate tiles
+    const float2 *tiles = nullptr;  // [groups][ntiles][cg][8], channel = g*cg + c (NULL: frame_sample of xsym)
+    uint32_t ntiles = 0, cg = 1;
+    uint32_t out_first = 0;       // blocks in front of this one only feed the filter: out holds blocks >= out_first
 };
 
 // frame sample t of channel ch: cyclic prefix + raised-cosine overlap of consecutive symbols
@@ -218,7 +222,13 @@ __global__ void txifft_kernel(TxSynthArgs a)
     __shared__ float2 buf[2][K];
     const uint32_t b = blockIdx.x;
     const int tid = threadIdx.x;
-    for (int k = tid; k < K; k += T) buf[0][k] = (k < (int)a.N) ? frame_sample(a, (uint32_t)k, b) : make_float2(0.f, 0.f);
+    if (a.tiles) {
+        for (int k = tid; k < K; k += T)
+            buf[0][k] = (k < (int)a.N) ? a.tiles[(((size_t)((uint32_t)k / a.cg) * a.ntiles + (b >> 3)) * a.cg + (uint32_t)k % a.cg) * 8 + (b & 7)]
+                                       : make_float2(0.f, 0.f);
+    } else {
+        for (int k = tid; k < K; k += T) buf[0][k] = (k < (int)a.N) ? frame_sample(a, (uint32_t)k, b) : make_float2(0.f, 0.f);
+    }
     __syncthreads();
     int cur = 0;
     // Stockham autosort, decimation in frequency: stage with n = current sub-length, s = stride
@@ -267,6 +277,7 @@ __global__ void txfir_kernel(TxSynthArgs a, uint32_t K)
     for (int r = 0; r < 8; r++) {
         const long long b = b0 + r;
         if (b >= (long long)a.nblocks) break;
+        if (b < (long long)a.out_first) continue;
         float2 acc = make_float2(0.f, 0.f);
 #pragma unroll
         for (int j = TX_P - 1; j >= 0; j--) {       // oldest first, like the window dot product
@@ -275,8 +286,26 @@ __global__ void txfir_kernel(TxSynthArgs a, uint32_t K)
         }
         const uint32_t t = a.first_sample_lo + (uint32_t)((unsigned long long)b * K + i);
         float2 y = mix_up(acc, t * a.dtheta);
-        a.out[(size_t)b * K + i] = make_float2(y.x * a.gain, y.y * a.gain);
+        a.out[(size_t)(b - (long long)a.out_first) * K + i] = make_float2(y.x * a.gain, y.y * a.gain);
     }
+}
+
+// channel-rate samples of a channel shard for blocks [first_block, first_block + 8 ntiles) as granules
+// tiles[tile][c][8] (zeros outside the traffic): what one rank contributes to another rank's time slab
+__global__ void txtiles_kernel(TxSynthArgs a, long long first_block, uint32_t ntiles, uint32_t nch, float2 *tiles)
+{
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= ntiles * nch) return;
+    const uint32_t tile = id / nch, c = id % nch;
+    float2 v[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const long long b = first_block + (long long)tile * 8 + t;
+        v[t] = (b >= 0 && b < 0xffffffffll) ? frame_sample(a, c, (uint32_t)b) : make_float2(0.f, 0.f);
+    }
+    float4 *dst = reinterpret_cast<float4 *>(tiles + (size_t)id * 8);
+#pragma unroll
+    for (int t = 0; t < 4; t++) dst[t] = make_float4(v[2 * t].x, v[2 * t].y, v[2 * t + 1].x, v[2 * t + 1].y);
 }
 
 }  // namespace mcrx
@@ -306,6 +335,7 @@ struct mctx_hip_s {
     std::vector<long long> ft0; std::vector<int> fS, fS_new; std::vector<uint8_t> assembled, pending;
     long long period = 0, blocks_out = 0; unsigned out_pos = 0;
     hipStream_t sst = nullptr;
+    float2 *d_synv = nullptr; size_t syn_cap = 0;       // sharded synthesis: inverse-FFT outputs of one slab (+ lead)
     template <class T> int up(const T **dst, const T *src, size_t n)
     {
         T *p = nullptr;
@@ -356,7 +386,7 @@ extern "C" int mctx_hip_destroy(mctx_hip_t q)
     (void)hipDeviceSynchronize();
     for (void *p : q->owned) (void)hipFree(p);
     for (void *p : { (void *)q->d_shdr, (void *)q->d_spay, (void *)q->d_sxsym, (void *)q->d_ft0, (void *)q->d_fS,
-                     (void *)q->d_sv[0], (void *)q->d_sv[1], (void *)q->d_sout }) if (p) (void)hipFree(p);
+                     (void *)q->d_sv[0], (void *)q->d_sv[1], (void *)q->d_sout, (void *)q->d_synv }) if (p) (void)hipFree(p);
     if (q->h_sout) (void)hipHostFree(q->h_sout);
     if (q->sst) (void)hipStreamDestroy(q->sst);
     delete q;
@@ -441,6 +471,130 @@ extern "C" int mctx_hip_generate(mctx_hip_t q, void *d_iq, size_t nblocks, unsig
     TXCHK(hipGetLastError());
     TXCHK(hipStreamSynchronize(st));
     (void)hipFree(d_hdr); (void)hipFree(d_pay); (void)hipFree(d_xsym); (void)hipFree(d_v);
+    return MCRX_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Sharded form of the generator (multi-GPU transmit side of src/multichannel_txrx.cc): the frame generators are
+// independent per channel, the synthesis bank couples all channels inside one block but is independent across
+// blocks up to its 25 blocks of filter memory -- the mirror image of the receiver.  So a rank
+//   1. traffic_create   assembles and modulates the frames of ITS channel shard (same seeds -> same frames as
+//                       mctx_hip_generate makes for those channels),
+//   2. traffic_tiles    writes their channel-rate samples for another rank's time slab as granules [tile][c][8],
+//   (all-to-all: channel shards -> time shards)
+//   3. synthesize_tiles runs the 2N-point inverse FFT, synthesis FIR and NCO over ITS time slab from the
+//                       received granules [source rank][tile][c][8]; `lead` blocks in front only fill the filter.
+struct mctx_hip_traffic_s {
+    mctx_hip_t q;
+    unsigned ch_first, ch_count, frames, S;
+    float2 *d_xsym;
+};
+
+extern "C" int mctx_hip_traffic_create(mctx_hip_t q, mctx_hip_traffic_t *out, unsigned ch_first, unsigned ch_count,
+                                       unsigned frames, unsigned payload_len, int mod, int fec0, int fec1, uint32_t seed,
+                                       uint8_t *hdr_out, uint8_t *pay_out, void *stream)
+{
+    if (!q || !out || !mod_bps(mod)) { g_tx_err = "bad argument"; return MCRX_EINVAL; }
+    *out = nullptr;
+    if (!ch_count || ch_first + ch_count > q->N || !frames) { g_tx_err = "channel shard outside the transmitter"; return MCRX_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    unsigned Sh, Sp, S; frame_geometry(q, payload_len, mod, fec0, fec1, Sh, Sp, S);
+    const unsigned Md = q->od.M_data, M = q->M;
+    std::vector<uint8_t> hdr((size_t)ch_count * frames * Sh * Md), pay((size_t)ch_count * frames * Sp * Md);
+    FrameSymbols fsym;
+    for (unsigned c = 0; c < ch_count; c++) {
+        const unsigned ch = ch_first + c;
+        std::mt19937 rng(seed + ch);                                    // the recipe of mctx_hip_generate, channel by channel
+        for (unsigned f = 0; f < frames; f++) {
+            uint8_t h8[8] = { (uint8_t)(f >> 8), (uint8_t)f, (uint8_t)ch, 0, 0, 0, 0, 0 };
+            for (int i = 3; i < 8; i++) h8[i] = (uint8_t)(rng() & 0xff);
+            std::vector<uint8_t> pl(payload_len);
+            for (auto &b : pl) b = (uint8_t)(rng() & 0xff);
+            assemble_frame(h8, pl, mod, fec0, fec1, Md, Sh, Sp, fsym);
+            memcpy(&hdr[((size_t)c * frames + f) * Sh * Md], fsym.hdr.data(), fsym.hdr.size());
+            memcpy(&pay[((size_t)c * frames + f) * Sp * Md], fsym.pay.data(), fsym.pay.size());
+            if (hdr_out) memcpy(hdr_out + ((size_t)c * frames + f) * 8, h8, 8);
+            if (pay_out && payload_len) memcpy(pay_out + ((size_t)c * frames + f) * payload_len, pl.data(), payload_len);
+        }
+    }
+    uint8_t *d_hdr = nullptr, *d_pay = nullptr; float2 *d_xsym = nullptr;
+    const size_t nsym = (size_t)frames * S;
+    TXCHK(hipMalloc((void **)&d_hdr, hdr.size())); TXCHK(hipMalloc((void **)&d_pay, std::max<size_t>(pay.size(), 1)));
+    TXCHK(hipMalloc((void **)&d_xsym, (size_t)ch_count * nsym * M * sizeof(float2)));
+    TXCHK(hipMemcpyAsync(d_hdr, hdr.data(), hdr.size(), hipMemcpyHostToDevice, st));
+    TXCHK(hipMemcpyAsync(d_pay, pay.data(), pay.size(), hipMemcpyHostToDevice, st));
+    TxSymArgs sa;
+    sa.M = (int)M; sa.log2M = 0; while ((1u << sa.log2M) < M) sa.log2M++;
+    sa.cp = (int)q->cp; sa.taper = (int)q->taper; sa.L = (int)(M + q->cp); sa.M_pilot = (int)q->od.M_pilot; sa.M_data = (int)Md;
+    sa.S = (int)S; sa.S_hdr = (int)Sh; sa.S_pay = (int)Sp; sa.frames = (int)frames; sa.bps = (int)mod_bps(mod); sa.mod = mod;
+    sa.g_data = 1.0f / sqrtf((float)(q->od.M_pilot + q->od.M_data));
+    sa.sctype = q->d_sctype; sa.data_rank = q->d_drank; sa.pilot_rank = q->d_prank; sa.pilot_seq = q->d_pseq;
+    sa.s0t = q->d_s0t; sa.s1t = q->d_s1t; sa.hdr = d_hdr; sa.pay = d_pay; sa.xsym = d_xsym; sa.nch = ch_count;
+    { int rc = tx_launch_sym(q, sa, (unsigned)nsym, ch_count, st); if (rc) return rc; }
+    TXCHK(hipStreamSynchronize(st));
+    (void)hipFree(d_hdr); (void)hipFree(d_pay);
+    mctx_hip_traffic_t t = new mctx_hip_traffic_s();
+    t->q = q; t->ch_first = ch_first; t->ch_count = ch_count; t->frames = frames; t->S = S; t->d_xsym = d_xsym;
+    *out = t;
+    return MCRX_OK;
+}
+
+extern "C" int mctx_hip_traffic_destroy(mctx_hip_traffic_t t)
+{
+    if (!t) return MCRX_OK;
+    (void)hipDeviceSynchronize();
+    if (t->d_xsym) (void)hipFree(t->d_xsym);
+    delete t;
+    return MCRX_OK;
+}
+
+extern "C" int mctx_hip_traffic_tiles(mctx_hip_traffic_t t, long long first_block, size_t nblocks, void *d_tiles, void *stream)
+{
+    if (!t || !d_tiles || (nblocks % 8)) { g_tx_err = "bad argument (blocks come in granules of 8)"; return MCRX_EINVAL; }
+    if (!nblocks) return MCRX_OK;
+    mctx_hip_t q = t->q;
+    TxSynthArgs ya;
+    ya.M = (int)q->M; ya.cp = (int)q->cp; ya.taper = (int)q->taper; ya.L = (int)(q->M + q->cp); ya.S = (int)t->S; ya.frames = (int)t->frames;
+    ya.taperwin = q->d_taper; ya.xsym = t->d_xsym; ya.taps = q->d_taps; ya.v = nullptr; ya.out = nullptr;
+    ya.nblocks = (uint32_t)nblocks; ya.N = t->ch_count; ya.dtheta = 0; ya.first_sample_lo = 0; ya.gain = 1.0f;
+    ya.ft0 = nullptr; ya.fS = nullptr; ya.xstride = 0; ya.b_first = 0; ya.hist = 0;
+    const uint32_t ntiles = (uint32_t)(nblocks / 8), n = ntiles * t->ch_count;
+    hipLaunchKernelGGL(txtiles_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, ya, first_block, ntiles, t->ch_count,
+                       (float2 *)d_tiles);
+    TXCHK(hipGetLastError());
+    return MCRX_OK;
+}
+
+static int tx_launch_ifft(mctx_hip_t q, const TxSynthArgs &ya, unsigned nblocks, hipStream_t st);
+
+extern "C" int mctx_hip_synthesize_tiles(mctx_hip_t q, const void *d_tiles, unsigned groups, long long first_block, size_t nblocks,
+                                         size_t lead_blocks, size_t keep_blocks, float gain, void *d_iq, void *stream)
+{
+    if (!q || !d_tiles || !d_iq || !groups || (q->N % groups) || (nblocks % 8) || (lead_blocks % 8) || keep_blocks > lead_blocks) {
+        g_tx_err = "bad argument (granules of 8 blocks, groups dividing the channel count, keep <= lead)"; return MCRX_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned K = q->K;
+    const size_t tot = lead_blocks + nblocks;
+    if (tot > q->syn_cap) {
+        if (q->d_synv) { TXCHK(hipDeviceSynchronize()); TXCHK(hipFree(q->d_synv)); q->d_synv = nullptr; q->syn_cap = 0; }
+        TXCHK(hipMalloc((void **)&q->d_synv, tot * K * sizeof(float2)));
+        q->syn_cap = tot;
+    }
+    TxSynthArgs ya;
+    ya.M = (int)q->M; ya.cp = (int)q->cp; ya.taper = (int)q->taper; ya.L = (int)(q->M + q->cp); ya.S = 0; ya.frames = 0;
+    ya.taperwin = q->d_taper; ya.xsym = nullptr; ya.taps = q->d_taps; ya.v = q->d_synv; ya.out = (float2 *)d_iq;
+    ya.nblocks = (uint32_t)tot; ya.N = q->N; ya.dtheta = q->dtheta; ya.gain = gain;
+    // oscillator phase of local block 0 = absolute block first_block - lead (mod 2^32 samples, like the 32-bit accumulator)
+    ya.first_sample_lo = (uint32_t)((unsigned long long)(first_block - (long long)lead_blocks) * (unsigned long long)K);
+    ya.ft0 = nullptr; ya.fS = nullptr; ya.xstride = 0; ya.b_first = 0; ya.hist = 0;
+    ya.tiles = (const float2 *)d_tiles; ya.ntiles = (uint32_t)(tot / 8); ya.cg = q->N / groups;
+    ya.out_first = (uint32_t)(lead_blocks - keep_blocks);
+    { int rc = tx_launch_ifft(q, ya, (unsigned)tot, st); if (rc) return rc; }
+    const unsigned tb = K < 256 ? 64 : 256;
+    hipLaunchKernelGGL(txfir_kernel, dim3((K + tb - 1) / tb, (unsigned)((tot + 7) / 8)), dim3(tb), 0, st, ya, K);
+    TXCHK(hipGetLastError());
     return MCRX_OK;
 }
 

@@ -96,13 +96,15 @@ class Pipeline(object):
         rnd = self.rounds if rnd is None else rnd
         return (rnd * self.world + self.rank) * self.Tc * self.K
 
-    def push(self, iq_sub, halo=None):
+    def push(self, iq_sub, halo=None, after=None):
         import torch
         c, i, nb = self.rounds, self.rounds % self.nbuf, self.nbuf
         out, recv = self.out[i], self.recv[i]
         new = recv[self.hist_elems:]
         # ---- A: channelize this rank's sub-slab into per-destination groups
         if self.cuda:
+            if after is not None:
+                self.sA.wait_event(after)                       # whoever produced iq_sub (e.g. TxPipeline.push)
             if c >= nb:
                 self.sA.wait_event(self.evB[i])                 # the exchange that last read out[i]
             with torch.cuda.stream(self.sA):
@@ -142,6 +144,90 @@ class Pipeline(object):
                 recv[:self.hist_elems].copy_(self.recv[(c - 1) % nb][-self.hist_elems:])
             self.tickets[i] = self.be.sync(recv, first_chan, nsamp, stream=None)
         self.rounds += 1
+
+
+class TxPipeline(object):
+    """The transmit side of the full-duplex loop sharded the other way round (src/multichannel_txrx.cc:105-259 run
+    over G GPUs): frame generators are per channel, the synthesis bank couples all channels of one block, so
+
+        frames:      rank r modulates the frames of ITS channel shard once        (tx.traffic)
+        tiles:       out[g][tile][c][8] = their channel-rate samples over the blocks rank g will synthesize:
+                     sub-slab c*G + g plus `lead` blocks of filter history in front  (traffic.tiles, per destination)
+        all-to-all:  chunk g of rank r -> chunk r of rank g : channel shards -> time shards
+        synthesize:  recv[s][tile][c][8] -> inverse FFT over all N channels, synthesis FIR, oscillator -> the wideband
+                     samples of sub-slab c*G + r, with `keep` (>= 13) blocks in front of it
+
+    push() returns (iq, event): iq[keep*K:] is exactly the sub-slab the receiver's Pipeline.push wants from this rank
+    in the same round and iq[(keep-13)*K:keep*K] its halo, so in the full-duplex job no wideband sample ever leaves
+    the GPU that made it.  Three streams, `nbuf` rotating buffer sets, like Pipeline.
+    """
+
+    def __init__(self, tx, traffic, rank, world, dist, num_channels, sub_blocks, lead_blocks=48, keep_blocks=16,
+                 device=None, nbuf=3, gain=None):
+        import torch
+        assert sub_blocks % TILE == 0 and lead_blocks % TILE == 0 and num_channels % world == 0
+        assert lead_blocks >= 25 + keep_blocks, "the synthesis filter remembers 25 blocks"
+        self.tx, self.traffic, self.rank, self.world, self.dist = tx, traffic, rank, world, dist
+        self.N, self.K, self.Tc, self.lead, self.keep, self.nbuf = num_channels, 2 * num_channels, sub_blocks, lead_blocks, keep_blocks, nbuf
+        self.cg = num_channels // world
+        self.gain = gain
+        self.per = (lead_blocks + sub_blocks) * self.cg
+        self.cuda = device is not None and torch.device(device).type == "cuda"
+        self.out = [torch.zeros(world * self.per, dtype=torch.complex64, device=device) for _ in range(nbuf)]
+        self.recv = [torch.zeros(world * self.per, dtype=torch.complex64, device=device) for _ in range(nbuf)]
+        self.iq = [torch.zeros((keep_blocks + sub_blocks) * self.K, dtype=torch.complex64, device=device) for _ in range(nbuf)]
+        self.rounds = 0
+        if self.cuda:
+            self.sA, self.sB, self.sC = (torch.cuda.Stream(device=device) for _ in range(3))
+            self.evA = [torch.cuda.Event() for _ in range(nbuf)]
+            self.evB = [torch.cuda.Event() for _ in range(nbuf)]
+            self.evC = [torch.cuda.Event() for _ in range(nbuf)]
+
+    def push(self, consumed=None):
+        """One round.  `consumed`: event after which iq buffer of round c - nbuf is free again (None: caller's problem)."""
+        import torch
+        c, i, nb = self.rounds, self.rounds % self.nbuf, self.nbuf
+        out, recv, iq = self.out[i], self.recv[i], self.iq[i]
+        nblk = self.lead + self.Tc
+
+        def stage_a(st):
+            for g in range(self.world):
+                self.traffic.tiles((c * self.world + g) * self.Tc - self.lead, nblk, out[g * self.per:(g + 1) * self.per], stream=st)
+
+        def stage_c(st):
+            self.tx.synthesize(recv, self.world, (c * self.world + self.rank) * self.Tc, self.Tc, self.lead, self.keep,
+                               gain=self.gain, out=iq, stream=st)
+        if not self.cuda:
+            stage_a(None)
+            if self.world == 1:
+                recv.copy_(out)
+            else:
+                exchange(out, recv, self.world, self.dist)
+            stage_c(None)
+            self.rounds += 1
+            return iq, None
+        if c >= nb:
+            self.sA.wait_event(self.evB[i])                     # the exchange that last read out[i]
+        with torch.cuda.stream(self.sA):
+            stage_a(self.sA)
+            self.evA[i].record(self.sA)
+        self.sB.wait_event(self.evA[i])
+        if c >= nb:
+            self.sB.wait_event(self.evC[i])                     # the synthesis that last read recv[i]
+        with torch.cuda.stream(self.sB):
+            if self.world == 1:
+                recv.copy_(out, non_blocking=True)
+            else:
+                exchange(out, recv, self.world, self.dist)
+            self.evB[i].record(self.sB)
+        self.sC.wait_event(self.evB[i])
+        if consumed is not None:
+            self.sC.wait_event(consumed)
+        with torch.cuda.stream(self.sC):
+            stage_c(self.sC)
+            self.evC[i].record(self.sC)
+        self.rounds += 1
+        return iq, self.evC[i]
 
 
 def pack_groups(blocks, world):

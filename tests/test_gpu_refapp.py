@@ -134,8 +134,13 @@ def test_unchanged_multichannel_txrx_app_hears_its_own_bursts(oracle, product, t
     for i in range(0, len(iq), 256 * 64):
         rx.Execute(iq[i:i + 256 * 64])
     rx.Flush()
-    key = lambda f: ((f.header[0] << 8) | f.header[1], len(f.payload), f.channel, int(f.header_valid), int(f.payload_valid))
-    assert sorted(key(f) for f in rx.frames) == sorted(key(f) for f in orx.frames)
+    # (the header bytes of a frame whose header CRC fails are decisions on noise -- such a lock on -60 dB leakage has
+    # an EVM of +19 dB -- and change when the oracle's own input is perturbed by 1e-6: scratch/refapp_hunt.py; they
+    # are compared for every frame whose header is valid, and per channel in stream order)
+    key = lambda f: (((f.header[0] << 8) | f.header[1]) if f.header_valid else -1, len(f.payload), int(f.header_valid), int(f.payload_valid))
+    for c in range(N):
+        assert [key(f) for f in rx.frames if f.channel == c] == [key(f) for f in orx.frames if f.channel == c], c
+    assert len(rx.frames) == len(orx.frames)
     rx.close()
     # the live callbacks: the same list up to what two free-running worker threads and a wall clock do to the stand-in's
     # air (a receive worker that lags is handed the stream with a sample gap; the recording has none)

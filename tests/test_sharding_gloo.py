@@ -246,3 +246,113 @@ def test_exchange_moves_complex_tensors_as_float_pairs():
     for r in range(world):
         want = np.concatenate([base(s)[r * 4:(r + 1) * 4] for s in range(world)])
         assert np.array_equal(res[r], want)
+
+
+# ---- transmit side: channel-sharded frame generators -> all-to-all -> time-sharded synthesis (sharding.TxPipeline)
+class OracleTraffic(object):
+    """CPU stand-in for the product's TxTraffic: the frames of a channel shard (traffic recipe of
+    oracle.synth_traffic, one frame generator per channel, frames back to back) as channel-rate streams."""
+
+    def __init__(self, O, N, M, cp, tp, ch_first, ch_count, nframes, plen, seed):
+        self.sent, streams = [], []
+        for ch in range(ch_first, ch_first + ch_count):
+            rng = np.random.RandomState((seed + ch) & 0x7FFFFFFF)
+            fg = O.FlexFrameGen(M, cp, tp)
+            s, sent = [], []
+            for pid in range(nframes):
+                hdr = bytes([(pid >> 8) & 0xff, pid & 0xff, ch & 0xff]) + bytes(rng.randint(0, 256, 5).astype(np.uint8))
+                pl = bytes(rng.randint(0, 256, plen).astype(np.uint8))
+                s.append(fg.frame(hdr, pl)); sent.append((hdr, pl))
+            streams.append(np.concatenate(s)); self.sent.append(sent)
+        self.streams = np.stack(streams)                    # [c][block]
+
+    def tiles(self, first_block, nblocks, out, stream=None):
+        cg, T = self.streams.shape
+        x = np.zeros((cg, nblocks), np.complex64)
+        lo, hi = max(first_block, 0), min(first_block + nblocks, T)
+        if hi > lo:
+            x[:, lo - first_block:hi - first_block] = self.streams[:, lo:hi]
+        out.copy_(torch.from_numpy(np.ascontiguousarray(x.reshape(cg, nblocks // 8, 8).transpose(1, 0, 2)).reshape(-1)))
+
+
+class OracleSynth(object):
+    """CPU stand-in for multichanneltx.synthesize: the oracle's synthesis bank started `lead` blocks early from a
+    zero state (its memory is 25 blocks), oscillator phase set from the absolute sample index."""
+
+    def __init__(self, O, N):
+        self.O, self.N, self.K = O, N, 2 * N
+        f = np.float32(-0.5) * np.float32(N - 1) / np.float32(N)
+        p = float(np.float32(float(f) * np.pi)) / (2 * np.pi)
+        self.dtheta = int(np.rint((p - np.floor(p)) * 2.0 ** 32)) & 0xFFFFFFFF
+
+    def synthesize(self, tiles, groups, first_block, nblocks, lead, keep, gain=None, out=None, stream=None):
+        K, N, cg = self.K, self.N, self.N // groups
+        tot = lead + nblocks
+        t = tiles.numpy().reshape(groups, tot // 8, cg, 8)                       # [g][tile][c][t]
+        X = np.zeros((tot, K), np.complex64)
+        X[:, :N] = t.transpose(1, 3, 0, 2).reshape(tot, N)
+        y = self.O.Channelizer(self.O.SYNTHESIZER, K, 13).synthesize(X).reshape(-1)
+        n = (np.arange(tot * K, dtype=np.uint64) + np.uint64((first_block - lead) * K % (1 << 32))) * np.uint64(self.dtheta)
+        th = (n & np.uint64(0xFFFFFFFF)).astype(np.float64) * (2 * np.pi / 2.0 ** 32)
+        y = (y.astype(np.complex128) * np.exp(1j * th)).astype(np.complex64) * np.float32(1.0 / N if gain is None else gain)
+        out.copy_(torch.from_numpy(y[(lead - keep) * K:]))
+        return out
+
+
+def _tx_worker(rank, world, port, q, rounds, Tc):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from __graft_entry__ import load_product
+    load_product()
+    import oracle as O
+    from liquid_usrp_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    N, M, cp, tp = 4, 64, 8, 4
+    c0, cg = sharding.shard_of(rank, world, N)
+    tr = OracleTraffic(O, N, M, cp, tp, c0, cg, 2, 60, 99)
+    pipe = sharding.TxPipeline(OracleSynth(O, N), tr, rank, world, dist, N, Tc, lead_blocks=48, keep_blocks=16, device=None)
+    slabs = []
+    for c in range(rounds):
+        iq, _ = pipe.push()
+        slabs.append(iq.numpy().copy())
+    q.put((rank, slabs, tr.sent))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_transmitter_reproduces_the_single_process_stream(oracle, world):
+    """sharding.TxPipeline under gloo: every rank modulates its channel shard, one all-to-all per round turns channel
+    shards into time shards, every rank synthesizes its sub-slab (+16 blocks in front = the receiver's halo).
+    The sub-slabs, put back in round-robin order, are the oracle multichanneltx's stream over all channels."""
+    N, M, cp, tp, Tc = 4, 64, 8, 4, 128
+    K = 2 * N
+    iq, sent = oracle.synth_traffic(N, M, cp, tp, 2, payload_len=60, seed=99)
+    rounds = (len(iq) // K + world * Tc - 1) // (world * Tc)
+    ref = np.concatenate([iq, np.zeros(rounds * world * Tc * K - len(iq), np.complex64)])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 25000 + (os.getpid() % 2000) + 10 * world
+    procs = [ctx.Process(target=_tx_worker, args=(r, world, port, q, rounds, Tc)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, slabs, s = q.get(timeout=180)
+        got[r] = (slabs, s)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cg = N // world
+    scale = float(np.max(np.abs(ref)))
+    worst = 0.0
+    for r in range(world):
+        slabs, s = got[r]
+        assert s == sent[r * cg:(r + 1) * cg]
+        for c, y in enumerate(slabs):
+            u = c * world + r
+            want = ref[(u * Tc - 16) * K:(u + 1) * Tc * K] if u else np.concatenate([np.zeros(16 * K, np.complex64), ref[:Tc * K]])
+            worst = max(worst, float(np.max(np.abs(y - want))) / scale)
+    assert worst <= 1e-5, worst
