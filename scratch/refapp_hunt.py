@@ -7,7 +7,7 @@ from __graft_entry__ import load_product, load_oracle
 prod, ora = load_product(), load_oracle()
 N, K = 4, 8
 TXRX = os.path.join(ROOT, "liquid-usrp_amd", "lib", "multichannel_txrx_ref")
-key = lambda f: ((f.header[0] << 8) | f.header[1], len(f.payload), f.channel, int(f.header_valid), int(f.payload_valid))
+key = lambda f: (((f.header[0] << 8) | f.header[1]) if f.header_valid else -1, len(f.payload), f.channel, int(f.header_valid), int(f.payload_valid))
 
 
 def gpu(iq, step=256 * 64, **env):
@@ -45,7 +45,7 @@ for attempt in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
     iq = np.fromfile(tee, np.complex64)
     iq = iq[:len(iq) // (16 * N) * (16 * N)]
     of, gf = oracle(iq), gpu(iq)
-    same = sorted(key(f) for f in of) == sorted(key(f) for f in gf)
+    same = all([key(f) for f in of if f.channel == c] == [key(f) for f in gf if f.channel == c] for c in range(N))
     print("attempt", attempt, "samples", len(iq), "oracle", len(of), "gpu", len(gf), "equal", same, flush=True)
     if same:
         continue
