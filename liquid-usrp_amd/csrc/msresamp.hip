@@ -31,57 +31,116 @@ using namespace mcrx;
 #define RS_PHASE_BITS 24
 #define RS_KEEP 32                  // samples of history retained per stage (>= 27)
 
-// in: samples with absolute index [in_base, ...); out[k - k0] for k in [k0, k1)
-__global__ void halfband_kernel(const float2 *in, long long in_base, float2 *out, long long k0, long long k1,
-                                const float *h1)
+#define RS_OB 1024                  // outputs per workgroup (256 threads x 4)
+#define RS_HROW 16                  // floats per row of the padded branch table (14 taps + 2): one row = 4 x 16-B loads
+
+// A stage input: samples [tail_base, cur_base) in `tail` (the retained end of the previous call's input, may be NULL),
+// [cur_base, end) in `cur`; everything before sample 0 is zero.
+struct RsIn { const float2 *tail; long long tail_base; const float2 *cur; long long cur_base, end; };
+
+__device__ __forceinline__ float2 rs_fetch(const RsIn &s, long long t)
 {
-    const long long k = k0 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= k1) return;
-    float2 acc = make_float2(0.f, 0.f);
-#pragma unroll
-    for (int i = 0; i < RS_TAPS; i++) {
-        const long long t = 2 * (k - (RS_TAPS - 1) + i);
-        if (t >= 0) { const float2 v = in[t - in_base]; const float h = h1[i]; acc.x += h * v.x; acc.y += h * v.y; }
-    }
-    const long long td = 2 * k - (RS_TAPS - 1);            // delay branch: x[2k-13]
-    float2 d = make_float2(0.f, 0.f);
-    if (td >= 0) d = in[td - in_base];
-    out[k - k0] = make_float2(0.5f * (d.x + acc.x), 0.5f * (d.y + acc.y));
+    if (t >= s.cur_base) return t < s.end ? s.cur[t - s.cur_base] : make_float2(0.f, 0.f);
+    if (s.tail && t >= s.tail_base && t >= 0) return s.tail[t - s.tail_base];
+    return make_float2(0.f, 0.f);
 }
 
-// half-band interpolator: inputs k in [k0, k1) -> outputs 2k, 2k+1 at out[2 (k - k0)]
-__global__ void halfband_interp_kernel(const float2 *in, long long in_base, float2 *out, long long k0, long long k1,
-                                       const float *h1)
+// Half-band decimator, outputs k in [k0, k1) -> out[k - k0].  A workgroup stages the 2 x (1024 + 13) input samples of
+// its 1024 outputs in LDS, de-interleaved (the filter branch reads even samples, the delay branch odd ones), with
+// coalesced loads; every thread then makes 4 outputs from conflict-free LDS reads.  HBM: 8 B in + 4 B out per input sample.
+__global__ __launch_bounds__(256) void halfband_kernel(RsIn in, float2 *out, long long k0, long long k1, const float *h1)
 {
-    const long long k = k0 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= k1) return;
-    float2 acc = make_float2(0.f, 0.f);
-#pragma unroll
-    for (int i = 0; i < RS_TAPS; i++) {
-        const long long t = k - (RS_TAPS - 1) + i;
-        if (t >= 0) { const float2 v = in[t - in_base]; const float h = h1[i]; acc.x += h * v.x; acc.y += h * v.y; }
+    __shared__ float2 ev[RS_OB + RS_TAPS], od[RS_OB + RS_TAPS];
+    const long long kb = k0 + (long long)blockIdx.x * RS_OB;
+    const int tid = threadIdx.x;
+    const long long tb = 2 * (kb - (RS_TAPS - 1));          // sample behind ev[0]
+    const int np = (int)min((long long)RS_OB, k1 - kb) + RS_TAPS - 1;
+    for (int p = tid; p < np; p += 256) {
+        ev[p] = rs_fetch(in, tb + 2 * p);
+        od[p] = rs_fetch(in, tb + 2 * p + 1);
     }
-    const long long td = k - RS_M;
-    const float2 d = td >= 0 ? in[td - in_base] : make_float2(0.f, 0.f);
-    reinterpret_cast<float4 *>(out)[k - k0] = make_float4(d.x, d.y, acc.x, acc.y);
+    __syncthreads();
+    float h[RS_TAPS];
+#pragma unroll
+    for (int i = 0; i < RS_TAPS; i++) h[i] = h1[i];
+#pragma unroll
+    for (int r = 0; r < RS_OB / 256; r++) {
+        const int o = tid + 256 * r;
+        const long long k = kb + o;
+        if (k >= k1) break;
+        float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < RS_TAPS; i++) { const float2 v = ev[o + i]; acc.x += h[i] * v.x; acc.y += h[i] * v.y; }
+        const float2 d = od[o + RS_M - 1];                  // x[2k-13]
+        out[k - k0] = make_float2(0.5f * (d.x + acc.x), 0.5f * (d.y + acc.y));
+    }
 }
 
-__global__ void arbitrary_kernel(const float2 *in, long long in_base, float2 *out, long long j0, long long j1,
-                                 unsigned long long step, const float *hpfb)
+// Half-band interpolator: inputs k in [k0, k1) -> outputs 2k, 2k+1 at out[2 (k - k0)]
+__global__ __launch_bounds__(256) void halfband_interp_kernel(RsIn in, float2 *out, long long k0, long long k1, const float *h1)
 {
-    const long long j = j0 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= j1) return;
-    const unsigned long long P = (unsigned long long)j * step;
-    const long long n = (long long)(P >> RS_PHASE_BITS);
-    const unsigned b = (unsigned)((P & ((1ull << RS_PHASE_BITS) - 1)) >> (RS_PHASE_BITS - 8));
-    const float *h = hpfb + (size_t)b * RS_TAPS;
-    float2 acc = make_float2(0.f, 0.f);
+    __shared__ float2 x[RS_OB + RS_TAPS];
+    const long long kb = k0 + (long long)blockIdx.x * RS_OB;
+    const int tid = threadIdx.x;
+    const int np = (int)min((long long)RS_OB, k1 - kb) + RS_TAPS - 1;
+    for (int p = tid; p < np; p += 256) x[p] = rs_fetch(in, kb - (RS_TAPS - 1) + p);
+    __syncthreads();
+    float h[RS_TAPS];
 #pragma unroll
-    for (int k = 0; k < RS_TAPS; k++) {
-        const long long t = n - (RS_TAPS - 1) + k;
-        if (t >= 0) { const float2 v = in[t - in_base]; acc.x += h[k] * v.x; acc.y += h[k] * v.y; }
+    for (int i = 0; i < RS_TAPS; i++) h[i] = h1[i];
+#pragma unroll
+    for (int r = 0; r < RS_OB / 256; r++) {
+        const int o = tid + 256 * r;
+        const long long k = kb + o;
+        if (k >= k1) break;
+        float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < RS_TAPS; i++) { const float2 v = x[o + i]; acc.x += h[i] * v.x; acc.y += h[i] * v.y; }
+        const float2 d = x[o + RS_TAPS - 1 - RS_M];         // u[k-7]
+        reinterpret_cast<float4 *>(out)[k - k0] = make_float4(d.x, d.y, acc.x, acc.y);
     }
-    out[j - j0] = acc;
+}
+
+// Arbitrary stage, outputs j in [j0, j1): input index and branch are closed forms of j (64-bit phase).  The input span
+// of a workgroup's 1024 outputs (<= 2048 + 14 samples: step <= 2 samples per output) is staged in LDS once; the 14 taps
+// of a branch come as four 16-byte loads from the padded table (16 KB, cache resident).
+__global__ __launch_bounds__(256) void arbitrary_kernel(RsIn in, float2 *out, long long j0, long long j1,
+                                                        unsigned long long step, const float *hpfb)
+{
+    __shared__ float2 x[2 * RS_OB + RS_TAPS + 2];
+    const long long jb = j0 + (long long)blockIdx.x * RS_OB;
+    const long long je = min(jb + (long long)RS_OB, j1);
+    const int tid = threadIdx.x;
+    const long long nf = (long long)(((unsigned long long)jb * step) >> RS_PHASE_BITS);
+    const long long nl = (long long)(((unsigned long long)(je - 1) * step) >> RS_PHASE_BITS);
+    const int np = (int)(nl - nf) + RS_TAPS;
+    for (int p = tid; p < np; p += 256) x[p] = rs_fetch(in, nf - (RS_TAPS - 1) + p);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_OB / 256; r++) {
+        const long long j = jb + tid + 256 * r;
+        if (j >= je) break;
+        const unsigned long long P = (unsigned long long)j * step;
+        const int o = (int)((long long)(P >> RS_PHASE_BITS) - nf);
+        const unsigned b = (unsigned)((P & ((1ull << RS_PHASE_BITS) - 1)) >> (RS_PHASE_BITS - 8));
+        const float4 *hp = reinterpret_cast<const float4 *>(hpfb + (size_t)b * RS_HROW);
+        const float4 ha = hp[0], hb = hp[1], hc = hp[2], hd = hp[3];
+        const float h[RS_HROW] = { ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w, hc.x, hc.y, hc.z, hc.w, hd.x, hd.y, hd.z, hd.w };
+        float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < RS_TAPS; k++) { const float2 v = x[o + k]; acc.x += h[k] * v.x; acc.y += h[k] * v.y; }
+        out[j - j0] = acc;
+    }
+}
+
+// the last RS_KEEP samples of a two-segment input become the next call's tail (one workgroup, staged through registers
+// because source and destination may overlap)
+__global__ void tail_save_kernel(RsIn in, float2 *tail, long long new_base)
+{
+    const int i = threadIdx.x;
+    const float2 v = rs_fetch(in, new_base + i);
+    __syncthreads();
+    if (new_base + i < in.end) tail[i] = v;
 }
 
 static thread_local std::string g_rs_err;
@@ -110,6 +169,15 @@ static int stage_reserve(msresamp_hip_t q, StageBuf &b, size_t extra, hipStream_
     size_t have = (size_t)(b.end - b.base);
     if (have + extra <= b.cap) return MCRX_OK;
     size_t keep = std::min(have, (size_t)RS_KEEP);
+    if (keep + extra <= b.cap) {                        // slide the tail to the front (stream ordered, no allocation)
+        if (keep) {
+            const RsIn me = { nullptr, 0, b.d, b.base, b.end };
+            hipLaunchKernelGGL(tail_save_kernel, dim3(1), dim3(RS_KEEP), 0, st, me, b.d, b.end - (long long)keep);
+            RSCHK(hipGetLastError());
+        }
+        b.base = b.end - (long long)keep;
+        return MCRX_OK;
+    }
     size_t ncap = std::max(b.cap, 2 * (keep + extra) + 64);
     float2 *nd = nullptr;
     RSCHK(hipMalloc((void **)&nd, ncap * sizeof(float2)));
@@ -120,6 +188,9 @@ static int stage_reserve(msresamp_hip_t q, StageBuf &b, size_t extra, hipStream_
     (void)q;
     return MCRX_OK;
 }
+
+// in[0] only ever holds the retained tail of the caller's input: the stages read the new samples where they lie
+static inline RsIn stage_in(const StageBuf &b) { return RsIn{ nullptr, 0, b.d, b.base, b.end }; }
 
 extern "C" int msresamp_hip_create(msresamp_hip_t *out, float rate, float As)
 {
@@ -138,12 +209,12 @@ extern "C" int msresamp_hip_create(msresamp_hip_t *out, float rate, float As)
     // arbitrary resampler bank, unity DC gain per branch
     float fc = 0.515f * (float)q->rate_arb; if (fc > 0.49f) fc = 0.49f;
     const unsigned n = 2 * RS_M * RS_NPFB + 1;
-    std::vector<float> hf = firdes_kaiser(n, fc / (float)RS_NPFB, As), hp((size_t)RS_NPFB * RS_TAPS);
+    std::vector<float> hf = firdes_kaiser(n, fc / (float)RS_NPFB, As), hp((size_t)RS_NPFB * RS_HROW, 0.0f);
     double gain = 0; for (float v : hf) gain += v;
     gain = (double)RS_NPFB / gain;
     for (unsigned b = 0; b < RS_NPFB; b++)
         for (unsigned k = 0; k < RS_TAPS; k++)
-            hp[(size_t)b * RS_TAPS + (RS_TAPS - 1 - k)] = (float)((double)hf[b + k * RS_NPFB] * gain);
+            hp[(size_t)b * RS_HROW + (RS_TAPS - 1 - k)] = (float)((double)hf[b + k * RS_NPFB] * gain);
     q->step = (unsigned long long)std::llrint((double)(1u << RS_PHASE_BITS) / q->rate_arb);
     if (hipMalloc((void **)&q->d_h1, h1.size() * sizeof(float)) != hipSuccess ||
         hipMalloc((void **)&q->d_hpfb, hp.size() * sizeof(float)) != hipSuccess ||
@@ -192,16 +263,26 @@ extern "C" int msresamp_hip_execute_device(msresamp_hip_t q, const void *d_in, s
     if (!q || !nout || (!d_in && nin) || !d_out) { g_rs_err = "null argument"; return MCRX_EINVAL; }
     hipStream_t st = stream ? (hipStream_t)stream : q->stream;
     *nout = 0;
-    // append the new samples to the first stage buffer
+    // the first stage reads [retained tail | the caller's new samples]; nothing is copied
     StageBuf &b0 = q->in[0];
     int rc;
-    if ((rc = stage_reserve(q, b0, nin, st))) return rc;
-    if (nin) RSCHK(hipMemcpyAsync(b0.d + (b0.end - b0.base), d_in, nin * sizeof(float2), hipMemcpyDeviceToDevice, st));
-    b0.end += (long long)nin;
+    if (!b0.d) { RSCHK(hipMalloc((void **)&b0.d, RS_KEEP * sizeof(float2))); b0.cap = RS_KEEP; }
+    const long long end0 = b0.end + (long long)nin;
+    const RsIn src0 = { b0.end > b0.base ? b0.d : nullptr, b0.base, (const float2 *)d_in, b0.end, end0 };
+    auto keep_tail = [&]() -> int {
+        const long long nb = std::max(b0.base, end0 - (long long)RS_KEEP);
+        if (end0 > nb) {
+            hipLaunchKernelGGL(tail_save_kernel, dim3(1), dim3(RS_KEEP), 0, st, src0, b0.d, nb);
+            RSCHK(hipGetLastError());
+        }
+        b0.base = nb; b0.end = end0;
+        return MCRX_OK;
+    };
+    const unsigned OB = RS_OB;
     if (q->interp) {
-        // arbitrary stage over in[0]: outputs j with n_j < end go to the first half-band interpolator's input (or out)
+        // arbitrary stage over the input: outputs j with n_j < end go to the first half-band interpolator's input (or out)
         const long long j0 = q->out_count;
-        const unsigned long long lim = (unsigned long long)b0.end << RS_PHASE_BITS;
+        const unsigned long long lim = (unsigned long long)end0 << RS_PHASE_BITS;
         long long j1 = (long long)((lim + q->step - 1) / q->step);
         if (j1 < j0) j1 = j0;
         const size_t total_out = (size_t)(j1 - j0) << q->num_stages;
@@ -215,10 +296,11 @@ extern "C" int msresamp_hip_execute_device(msresamp_hip_t q, const void *d_in, s
         }
         if (j1 > j0) {
             const unsigned n = (unsigned)(j1 - j0);
-            hipLaunchKernelGGL(arbitrary_kernel, dim3((n + 255) / 256), dim3(256), 0, st, b0.d, b0.base, dst, j0, j1, q->step, q->d_hpfb);
+            hipLaunchKernelGGL(arbitrary_kernel, dim3((n + OB - 1) / OB), dim3(256), 0, st, src0, dst, j0, j1, q->step, q->d_hpfb);
             RSCHK(hipGetLastError());
         }
         q->out_count = j1;
+        if ((rc = keep_tail())) return rc;
         // half-band interpolators: stage s consumes the new samples of in[1 + s] (all of them: no look-ahead needed)
         long long k0 = j0;
         for (unsigned s = 0; s < q->num_stages; s++) {
@@ -233,7 +315,7 @@ extern "C" int msresamp_hip_execute_device(msresamp_hip_t q, const void *d_in, s
             }
             if (k1 > k0) {
                 const unsigned n = (unsigned)(k1 - k0);
-                hipLaunchKernelGGL(halfband_interp_kernel, dim3((n + 255) / 256), dim3(256), 0, st, bi.d, bi.base, o, k0, k1, q->d_h1);
+                hipLaunchKernelGGL(halfband_interp_kernel, dim3((n + OB - 1) / OB), dim3(256), 0, st, stage_in(bi), o, k0, k1, q->d_h1);
                 RSCHK(hipGetLastError());
             }
             k0 *= 2;
@@ -241,34 +323,36 @@ extern "C" int msresamp_hip_execute_device(msresamp_hip_t q, const void *d_in, s
         *nout = total_out;
         return MCRX_OK;
     }
-    // half-band stages: stage s consumes in[s], appends to in[s+1]
+    // half-band stages: stage s consumes in[s] (s = 0: the caller's samples), appends to in[s+1]
     for (unsigned s = 0; s < q->num_stages; s++) {
-        StageBuf &bi = q->in[s], &bo = q->in[s + 1];
-        const long long k0 = bo.end, k1 = bi.end / 2;       // output k exists once x[2k+1] has arrived
+        StageBuf &bo = q->in[s + 1];
+        const long long iend = s ? q->in[s].end : end0;
+        const long long k0 = bo.end, k1 = iend / 2;         // output k exists once x[2k+1] has arrived
         if (k1 > k0) {
             if ((rc = stage_reserve(q, bo, (size_t)(k1 - k0), st))) return rc;
             const unsigned n = (unsigned)(k1 - k0);
-            hipLaunchKernelGGL(halfband_kernel, dim3((n + 255) / 256), dim3(256), 0, st,
-                               bi.d, bi.base, bo.d + (bo.end - bo.base), k0, k1, q->d_h1);
+            hipLaunchKernelGGL(halfband_kernel, dim3((n + OB - 1) / OB), dim3(256), 0, st,
+                               s ? stage_in(q->in[s]) : src0, bo.d + (bo.end - bo.base), k0, k1, q->d_h1);
             RSCHK(hipGetLastError());
             bo.end = k1;
         }
     }
     // arbitrary stage over in[num_stages]: outputs j with n_j < end
-    StageBuf &ba = q->in[q->num_stages];
+    const long long aend = q->num_stages ? q->in[q->num_stages].end : end0;
     const long long j0 = q->out_count;
     // largest j with (j*step >> 24) < end  <=>  j*step < end << 24
-    const unsigned long long lim = (unsigned long long)ba.end << RS_PHASE_BITS;
+    const unsigned long long lim = (unsigned long long)aend << RS_PHASE_BITS;
     long long j1 = (long long)((lim + q->step - 1) / q->step);          // first j with j*step >= lim
     if (j1 < j0) j1 = j0;
     if ((size_t)(j1 - j0) > out_cap) { g_rs_err = "output buffer too small"; return MCRX_EINVAL; }
     if (j1 > j0) {
         const unsigned n = (unsigned)(j1 - j0);
-        hipLaunchKernelGGL(arbitrary_kernel, dim3((n + 255) / 256), dim3(256), 0, st,
-                           ba.d, ba.base, (float2 *)d_out, j0, j1, q->step, q->d_hpfb);
+        hipLaunchKernelGGL(arbitrary_kernel, dim3((n + OB - 1) / OB), dim3(256), 0, st,
+                           q->num_stages ? stage_in(q->in[q->num_stages]) : src0, (float2 *)d_out, j0, j1, q->step, q->d_hpfb);
         RSCHK(hipGetLastError());
     }
     q->out_count = j1;
+    if ((rc = keep_tail())) return rc;
     *nout = (size_t)(j1 - j0);
     return MCRX_OK;
 }
