@@ -90,16 +90,18 @@ __device__ __forceinline__ void fft_reg(float2 (&v)[F])
     }
 }   // result: v[i] holds X[bitrev(i)]; callers store v[i] at index bitrev_c(i, log2 F)
 
-template <int K, int C, int T>
-__global__ __launch_bounds__(T) void channelizer_kernel(ChanArgs a)
+// EDGE = false: every block the workgroup touches (history, the slabs, the prefetch past the last round) lies inside
+// the stream, so loads need no clamping, the oscillator no zeroing and the stores no guard -- all but the first and the
+// last workgroup of a launch.  Addresses that do not change from round to round (the butterflies' LDS positions, the
+// granule stores' LDS sources and HBM destinations) are computed once per launch, not once per use.
+template <int K, int C, int T, bool EDGE>
+__device__ __forceinline__ void channelizer_rounds(const ChanArgs &a, float2 *tile)
 {
     constexpr int TPS = K / C;              // threads per slab
     constexpr int NS = T / TPS;             // slabs per workgroup
     constexpr int N = K / 2;
     constexpr int S = Plan<K>::S, F = Plan<K>::F, ROWP = Plan<K>::ROWP;
     static_assert(TPS * C == K && NS * TPS == T && NS >= 1, "bad channelizer geometry");
-
-    extern __shared__ __attribute__((aligned(16))) float2 tile[];     // [NS][CH_R][ROWP]
 
     const int tid = threadIdx.x;
     const int sl = tid / TPS, cg = tid % TPS;
@@ -144,11 +146,13 @@ __global__ __launch_bounds__(T) void channelizer_kernel(ChanArgs a)
     // Branch free on purpose: a load inside a divergent `if` gets an s_waitcnt vmcnt(0) at the
     // join, which would serialise the round's loads into one HBM round trip each.
     auto load_raw = [&](long long b, float2 (&dst)[C]) {
-        const bool inx = b >= 0 && b < (long long)a.nblocks;
-        const bool inh = b < 0 && a.halo != nullptr;
         const float2 *src = a.x + n0;                                   // always mapped
-        if (inx) src = a.x + (size_t)b * K + n0;
-        if (inh) src = a.halo + (size_t)(b + CH_H) * K + n0;
+        if constexpr (EDGE) {
+            const bool inx = b >= 0 && b < (long long)a.nblocks;
+            const bool inh = b < 0 && a.halo != nullptr;
+            if (inx) src = a.x + (size_t)b * K + n0;
+            if (inh) src = a.halo + (size_t)(b + CH_H) * K + n0;
+        } else src = a.x + (size_t)b * K + n0;
         // the value is not touched here (that would wait for it): the mixer zeroes blocks outside the stream
         if constexpr (C == 2) {
             const float4 v = *reinterpret_cast<const float4 *>(src);
@@ -170,8 +174,10 @@ __global__ __launch_bounds__(T) void channelizer_kernel(ChanArgs a)
     auto mix_with = [&](long long b, float sn, float cs, float2 (&dst)[C]) {
         // blocks outside the stream become zeros: a zeroed oscillator (by value; the caller's copy keeps turning)
         // zeroes both columns, two selects per block instead of four.  (Clamped loads return finite samples.)
-        const bool valid = (b >= 0 && b < (long long)a.nblocks) || (b < 0 && a.halo != nullptr);
-        sn = valid ? sn : 0.f; cs = valid ? cs : 0.f;
+        if constexpr (EDGE) {
+            const bool valid = (b >= 0 && b < (long long)a.nblocks) || (b < 0 && a.halo != nullptr);
+            sn = valid ? sn : 0.f; cs = valid ? cs : 0.f;
+        }
 #pragma unroll
         for (int c = 0; c < C; c++) {
             if (c > 0) { const float s2 = fmaf(sn, cd1, cs * sd1), c2 = fmaf(cs, cd1, -(sn * sd1)); sn = s2; cs = c2; }
@@ -198,6 +204,44 @@ __global__ __launch_bounds__(T) void channelizer_kernel(ChanArgs a)
 #pragma unroll
         for (int i = 5; i < 13; i++) { mix_with(bs - 13 + i, sn, cs, s[i]); osc_next_block(sn, cs); }
     }
+
+    // ---- round-invariant addresses
+    constexpr int NBF4 = NS * CH_R * (K / 4);           // radix-4 butterflies per stage
+    constexpr int NG = NS * CH_R * (K / F);             // F-point groups
+    constexpr int NOPS = NS * N * (CH_R / 2);           // 16-byte stores per round
+    static_assert(S == 0 || (NBF4 % T == 0 && T % (K / 4) == 0), "a thread's butterflies must differ by whole rows");
+    static_assert(NG % T == 0 || NG < T, "F-point groups per thread");
+    static_assert(NOPS % T == 0, "granule stores per thread");
+    constexpr int BTRIPS = S > 0 ? NBF4 / T : 0, BSTEP = S > 0 ? (T / (K / 4)) * ROWP : 0;
+    int fa[S > 0 ? S : 1];                              // padded LDS index of a butterfly's first element, trip 0
+#pragma unroll
+    for (int st = 0; st < S; st++) {
+        const int L = K >> (2 * st), q4 = L >> 2;
+        const int f = tid / (K / 4), j = tid % (K / 4);
+        fa[st] = f * ROWP + pad<K>((j / q4) * L + j % q4);
+    }
+    constexpr int GTRIPS = (NG + T - 1) / T;
+    int fg[GTRIPS];
+#pragma unroll
+    for (int i = 0; i < GTRIPS; i++) { const int g = tid + i * T; fg[i] = (g / (K / F)) * ROWP + (g % (K / F)) * (F + 1); }
+    constexpr int OTRIPS = NOPS / T;
+    int ssrc[OTRIPS];                                   // LDS source of granule store k
+    uint32_t sdst[OTRIPS];                              // its destination in round 0 (16-byte units from a.out); every round is one tile further
+    int srem[OTRIPS];                                   // blocks of the stream from its slab's first one on (EDGE: stores past the end are masked)
+#pragma unroll
+    for (int k = 0; k < OTRIPS; k++) {
+        const int o = tid + k * T;
+        const int osl = o / (N * (CH_R / 2)), rem = o % (N * (CH_R / 2));
+        const int ch = rem / (CH_R / 2), rp = rem % (CH_R / 2);
+        const long long ob = ((long long)blockIdx.x * NS + osl) * (long long)a.slab_blocks;
+        const int g = ch / a.cg, c = ch % a.cg;
+        ssrc[k] = (osl * CH_R + 2 * rp) * ROWP + pad<K>(dif_pos<K>(ch));
+        sdst[k] = (uint32_t)(((((size_t)g * a.ntiles + (size_t)(ob / CH_R)) * a.cg + c) * CH_R + 2 * rp) / 2);   // (launch_one checks the range)
+        const long long left = (long long)a.nblocks - ob;
+        srem[k] = left < 0 ? 0 : (left > 0x40000000ll ? 0x40000000 : (int)left);
+    }
+    const uint32_t tile_step = a.cg * (CH_R / 2);            // 16-byte units between consecutive tiles of a channel group
+    float4 *out4 = reinterpret_cast<float4 *>(a.out);
 
     const int rounds = a.slab_blocks / CH_R;
     for (int rd = 0; rd < rounds; rd++) {
@@ -240,32 +284,29 @@ __global__ __launch_bounds__(T) void channelizer_kernel(ChanArgs a)
         lds_barrier();
 
         // ---- NS*CH_R independent K-point FFTs, in place
-        if constexpr (S > 0) if (!(a.ablate & 2)) {
-            constexpr int NBF4 = NS * CH_R * (K / 4);       // radix-4 butterflies per stage
+        if constexpr (S > 0) {
 #pragma unroll
             for (int st = 0; st < S; st++) {
                 const int L = K >> (2 * st), q4 = L >> 2;
-                for (int q = tid; q < NBF4; q += T) {
-                    const int f = q / (K / 4), j = q % (K / 4);
-                    const int grp = j / q4, pos = j % q4;
-                    float2 *row = tile + f * ROWP;
-                    const int e0 = grp * L + pos;
-                    const int i0 = pad<K>(e0), i1 = pad<K>(e0 + q4), i2 = pad<K>(e0 + 2 * q4), i3 = pad<K>(e0 + 3 * q4);
-                    const float2 x0 = row[i0], x1 = row[i1], x2 = row[i2], x3 = row[i3];
+                const int D = q4 + q4 / F;              // padded distance of the butterfly's legs (q4 is a multiple of F)
+#pragma unroll
+                for (int i = 0; i < BTRIPS; i++) {
+                    float2 *p = tile + fa[st] + i * BSTEP;
+                    const float2 x0 = p[0], x1 = p[D], x2 = p[2 * D], x3 = p[3 * D];
                     const float2 a0 = cadd(x0, x2), a1 = csub(x0, x2), a2 = cadd(x1, x3), a3 = cmulnj(csub(x1, x3));
-                    row[i0] = cadd(a0, a2);
-                    row[i1] = cmul(cadd(a1, a3), tw[st][0]);
-                    row[i2] = cmul(csub(a0, a2), tw[st][1]);
-                    row[i3] = cmul(csub(a1, a3), tw[st][2]);
+                    p[0] = cadd(a0, a2);
+                    p[D] = cmul(cadd(a1, a3), tw[st][0]);
+                    p[2 * D] = cmul(csub(a0, a2), tw[st][1]);
+                    p[3 * D] = cmul(csub(a1, a3), tw[st][2]);
                 }
                 lds_barrier();
             }
         }
-        if (!(a.ablate & 4)) {
-            constexpr int NG = NS * CH_R * (K / F);         // F-point groups
-            for (int g = tid; g < NG; g += T) {
-                const int f = g / (K / F), gi = g % (K / F);
-                float2 *p = tile + f * ROWP + gi * (F + 1);  // == pad(gi * F)
+        {
+#pragma unroll
+            for (int i = 0; i < GTRIPS; i++) {
+                if (NG % T != 0 && tid + i * T >= NG) break;
+                float2 *p = tile + fg[i];                    // == pad(gi * F) in row f
                 float2 v[F];
 #pragma unroll
                 for (int m = 0; m < F; m++) v[m] = p[m];
@@ -277,27 +318,30 @@ __global__ __launch_bounds__(T) void channelizer_kernel(ChanArgs a)
         }
 
         // ---- store bins 0..N-1 as (channel, tile) granules of 8 time samples (64 B)
-        constexpr int NOPS = NS * N * (CH_R / 2);       // 16-byte stores per round
-        for (int o = tid; o < NOPS; o += T) {
-            const int osl = o / (N * (CH_R / 2)), rem = o % (N * (CH_R / 2));
-            const int ch = rem / (CH_R / 2), rp = rem % (CH_R / 2);
-            const long long oslab = (long long)blockIdx.x * NS + osl;
-            const long long ob0 = oslab * (long long)a.slab_blocks + (long long)rd * CH_R;
-            if (ob0 < (long long)a.nblocks && !(a.ablate & 8)) {
-                const int pos = pad<K>(dif_pos<K>(ch));
-                const float2 *src = tile + (osl * CH_R + 2 * rp) * ROWP + pos;
-                float2 v0 = src[0], v1 = src[ROWP];
-                const long long tl = ob0 / CH_R;
-                const int g = ch / a.cg, c = ch % a.cg;
-                float4 *dst = reinterpret_cast<float4 *>(
-                    a.out + (((size_t)g * a.ntiles + (size_t)tl) * a.cg + c) * CH_R + 2 * rp);
-                *dst = make_float4(v0.x, v0.y, v1.x, v1.y);
+#pragma unroll
+        for (int k = 0; k < OTRIPS; k++) {
+            bool ok = true;
+            if constexpr (EDGE) ok = rd * CH_R < srem[k];
+            if (ok) {
+                const float2 *src = tile + ssrc[k];
+                const float2 v0 = src[0], v1 = src[ROWP];
+                out4[(size_t)(sdst[k] + (uint32_t)rd * tile_step)] = make_float4(v0.x, v0.y, v1.x, v1.y);
             }
         }
         lds_barrier();
     }
 }
 
+template <int K, int C, int T>
+__global__ __launch_bounds__(T) void channelizer_kernel(ChanArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 tile[];     // [NS][CH_R][ROWP]
+    constexpr int NS = T / (K / C);
+    const long long s0 = (long long)blockIdx.x * NS;
+    const long long first = s0 * (long long)a.slab_blocks - CH_H, last = (s0 + NS) * (long long)a.slab_blocks + CH_R;
+    if (first >= 0 && last <= (long long)a.nblocks) channelizer_rounds<K, C, T, false>(a, tile);
+    else channelizer_rounds<K, C, T, true>(a, tile);
+}
 template <int K, int C, int T>
 static hipError_t launch_one(const ChanArgs &a, hipStream_t st)
 {
@@ -306,6 +350,9 @@ static hipError_t launch_one(const ChanArgs &a, hipStream_t st)
     long long nslabs = ((long long)a.nblocks + a.slab_blocks - 1) / a.slab_blocks;
     unsigned grid = (unsigned)((nslabs + NS - 1) / NS);
     if (grid == 0) return hipSuccess;
+    // granule stores are addressed by 32-bit offsets in 16-byte units: 64 GB of output per launch
+    if ((unsigned long long)(K / 2) * ((unsigned long long)a.ntiles + (unsigned long long)NS * a.slab_blocks / CH_R) * (CH_R / 2) >= (1ull << 32))
+        return hipErrorInvalidValue;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)channelizer_kernel<K, C, T>,
@@ -424,7 +471,8 @@ hipError_t channelizer_launch(unsigned K, const ChanArgs &a, hipStream_t st)
     case 128:  return launch_one<128, 2, 256>(a, st);
     case 256:  return launch_one<256, 2, 256>(a, st);
     case 512:  return launch_one<512, 2, 256>(a, st);
-    case 1024: return launch_one<1024, 2, 512>(a, st);
+    case 1024: { static const int c1 = getenv("MCRX_CHAN_C1") ? atoi(getenv("MCRX_CHAN_C1")) : 0;
+                 return c1 ? launch_one<1024, 1, 1024>(a, st) : launch_one<1024, 2, 512>(a, st); }
     default:   return hipErrorInvalidValue;
     }
 }
