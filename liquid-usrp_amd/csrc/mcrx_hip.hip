@@ -172,7 +172,7 @@ struct mcrx_hip_s {
     bool spec = false;
     uint32_t *h_hint = nullptr, *d_hint = nullptr;     // pinned, device-mapped: longest coded frame of the last launch
     uint8_t *d_jsoft[MCRX_SLOTS] = {}, *d_jtmp[MCRX_SLOTS] = {};
-    bool scout = true; int scout_rounds = 2;
+    bool scout = true; int scout_rounds = 3; bool narrow_first = true;
     // streaming state
     uint64_t total_samples = 0;             // wideband samples accepted since creation (NCO phase)
     uint64_t stage_first = 0;               // absolute index of h_stage[0]
@@ -455,6 +455,7 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
         const bool lean = q->sc.log2M >= 6 && q->sc.M == 64 * q->sc.E && q->sc.M_pilot <= 64;
         q->spec = lean && q->d_hint && getenv("MCRX_NO_SPEC") == nullptr;
         if (getenv("MCRX_SCOUT_ROUNDS")) q->scout_rounds = std::max(1, std::min(8, atoi(getenv("MCRX_SCOUT_ROUNDS"))));
+        if (getenv("MCRX_NARROW_FIRST")) q->narrow_first = atoi(getenv("MCRX_NARROW_FIRST")) != 0;
         if (q->spec) {
             if ((rc = q->alloc(&q->d_spec, (size_t)q->nch * MCRX_SPEC_MAX))) return bail(rc);
             if ((rc = q->alloc(&q->d_spec_R, (size_t)q->nch * MCRX_SPEC_MAX * M))) return bail(rc);
@@ -616,11 +617,17 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
         SyncArgs t = a;
         t.tail_only = 1; t.pred = nullptr; t.pred_n = nullptr; t.spec_cap = 0; t.spec_hint = nullptr; t.stats = nullptr;
         HIPCHK(sync_launch_tail(t, sa));
+        // Round 0 is narrow: only the state the previous launch's scout stood in is speculated on (one wave per channel);
+        // the cadence predictions carried over from the previous buffer are right only if no gap followed it, and after
+        // the first adopted frame the scout re-anchors them anyway -- the full-width rounds run from there.
+        const uint32_t cap = a.spec_cap;
         for (int r = 0; r < q->scout_rounds; r++) {
             a.stop_after_walk = (r + 1 < q->scout_rounds) ? 1 : 0;
+            a.spec_cap = (r == 0 && q->narrow_first && q->scout_rounds > 1 && cap > 1) ? 1u : cap;
             HIPCHK(sync_launch_spec(a, sa));
             HIPCHK(sync_launch_lean(a, sa));
         }
+        a.spec_cap = cap;
         // a frame the lean scout could neither hand off nor defer runs past the end of this buffer: walked up to there
         HIPCHK(sync_launch_tail(t, sa));
     } else {
