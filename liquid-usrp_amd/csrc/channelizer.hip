@@ -69,8 +69,10 @@ __device__ __forceinline__ float2 w16(int k)
 }
 constexpr int bitrev_c(int i, int bits) { int r = 0; for (int b = 0; b < bits; b++) if (i & (1 << b)) r |= 1 << (bits - 1 - b); return r; }
 
-// F-point forward DFT in registers: natural order in, bit-reversed order out
-template <int F>
+// F-point forward DFT in registers: natural order in, bit-reversed order out.  LOWER: only the outputs X[0 .. F/2-1] are
+// wanted (the receiver keeps bins 0 .. N-1, which sit in the lower half of every final group): they are the sums of the last
+// stage -- v[i] for even i -- so its differences are not formed
+template <int F, bool LOWER = false>
 __device__ __forceinline__ void fft_reg(float2 (&v)[F])
 {
 #pragma unroll
@@ -80,6 +82,7 @@ __device__ __forceinline__ void fft_reg(float2 (&v)[F])
             if ((i & h) == 0) {
                 const float2 u = v[i], w = v[i + h];
                 v[i] = cadd(u, w);
+                if (LOWER && h == 1) continue;
                 const float2 d = csub(u, w);
                 const int tk = (i & (h - 1)) * (8 / h);       // W_{2h}^{i mod h} as a power of W_16
                 if (tk == 0) v[i + h] = d;
@@ -310,9 +313,9 @@ __device__ __forceinline__ void channelizer_rounds(const ChanArgs &a, float2 *ti
                 float2 v[F];
 #pragma unroll
                 for (int m = 0; m < F; m++) v[m] = p[m];
-                fft_reg<F>(v);
+                fft_reg<F, (F >= 2)>(v);                    // bins >= N (the upper half of every group) are never stored
 #pragma unroll
-                for (int m = 0; m < F; m++) p[bitrev_c(m, Log2<F>::v)] = v[m];
+                for (int m = 0; m < F; m++) if (F < 2 || bitrev_c(m, Log2<F>::v) < F / 2) p[bitrev_c(m, Log2<F>::v)] = v[m];
             }
             lds_barrier();
         }
