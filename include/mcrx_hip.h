@@ -129,6 +129,9 @@ int  mcrx_hip_stream_wait_launch(mcrx_hip_t q, uint64_t launch, void *stream);
 int  mcrx_hip_spec_stats(mcrx_hip_t q, uint64_t *walked, uint64_t *adopted, int reset);
 size_t mcrx_hip_frames_pending(mcrx_hip_t q);
 int  mcrx_hip_next_frame(mcrx_hip_t q, mcrx_frame *out);      /* 1 = frame written, 0 = none */
+/* a caller's delivery loop without a per-frame FFI crossing: walks every pending frame through mcrx_hip_next_frame,
+ * touches its payload, and reports how many there were, how many with valid header and payload, and their payload bytes */
+int  mcrx_hip_drain_count(mcrx_hip_t q, uint64_t *frames, uint64_t *valid, uint64_t *payload_bytes);
 uint64_t mcrx_hip_frames_dropped(mcrx_hip_t q);
 
 /* ---- stage level (multi-GPU split, parity tests, benchmarks) ------------------------- */

@@ -70,6 +70,7 @@ _EXPORTS = {
     "mcrx_hip_spec_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]),
     "mcrx_hip_frames_pending": (C.c_size_t, [C.c_void_p]),
     "mcrx_hip_next_frame": (C.c_int, [C.c_void_p, C.POINTER(FrameC)]),
+    "mcrx_hip_drain_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "mcrx_hip_frames_dropped": (C.c_uint64, [C.c_void_p]),
     "mcrx_hip_channelize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p]),
     "mcrx_hip_sync": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_size_t, C.c_void_p]),
@@ -256,17 +257,11 @@ class multichannelrx(object):
         return int(lib().mcrx_hip_frames_pending(self._h))
 
     def drain_count(self):
-        """Walk the harvested frames through the C-ABI (mcrx_hip_next_frame) without building Python objects;
-        returns (frames, valid payloads, payload bytes)."""
-        f = FrameC()
-        n = ok = nbytes = 0
-        nxt = lib().mcrx_hip_next_frame
-        ref = C.byref(f)
-        while nxt(self._h, ref) == 1:
-            n += 1
-            ok += 1 if (f.header_valid and f.payload_valid) else 0
-            nbytes += f.payload_len
-        return n, ok, nbytes
+        """Walk the harvested frames through the C-ABI (mcrx_hip_drain_count: the loop a C caller writes around
+        mcrx_hip_next_frame) without building Python objects; returns (frames, valid payloads, payload bytes)."""
+        n, ok, nb = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        _check(lib().mcrx_hip_drain_count(self._h, C.byref(n), C.byref(ok), C.byref(nb)))
+        return int(n.value), int(ok.value), int(nb.value)
 
     def stream_wait(self, stream=None, launch=None):
         if launch is None:

@@ -193,6 +193,7 @@ struct mcrx_hip_s {
     hipStream_t copy_stream = nullptr; hipEvent_t ev_dcopy[2] = { nullptr, nullptr }, ev_ddone[2] = { nullptr, nullptr };
     uint64_t min_frame = 1;                 // channel-rate samples of the shortest possible frame
     uint64_t pending_bound = 0;             // upper bound of frame records produced since the last harvest
+    uint64_t drain_touch = 0;
     double t_copy = 0, t_harvest = 0, t_run = 0, t_wait = 0, t_d2h = 0, b_d2h = 0, t_grow = 0;   // MCRX_DEBUG=8: host seconds spent per phase of the bulk path
     // per-kernel HIP event rings (MCRX_NKERNELS of them, see mcrx_hip.h); pairs (start, stop)
     std::vector<hipEvent_t> evring[MCRX_NKERNELS];
@@ -1113,6 +1114,22 @@ extern "C" int mcrx_hip_next_frame(mcrx_hip_t q, mcrx_frame *out)
     out->payload = r.payload_len ? q->arena_host.p + r.payload_off : nullptr;
     out->framesyms = r.num_framesyms ? reinterpret_cast<const float *>(q->sarena_host.p + r.syms_off) : nullptr;
     return 1;
+}
+
+extern "C" int mcrx_hip_drain_count(mcrx_hip_t q, uint64_t *frames, uint64_t *valid, uint64_t *bytes)
+{
+    if (!q) return fail(MCRX_EINVAL, "null handle");
+    uint64_t n = 0, ok = 0, nb = 0, touch = 0;
+    mcrx_frame f;
+    while (mcrx_hip_next_frame(q, &f) == 1) {
+        n++; ok += (f.header_valid && f.payload_valid) ? 1 : 0; nb += f.payload_len;
+        if (f.payload_len) touch += f.payload[0] + f.payload[f.payload_len - 1];       // the payload really is in host memory
+    }
+    q->drain_touch += touch;
+    if (frames) *frames = n;
+    if (valid) *valid = ok;
+    if (bytes) *bytes = nb;
+    return MCRX_OK;
 }
 
 extern "C" int mcrx_hip_reset(mcrx_hip_t q)
