@@ -1790,6 +1790,208 @@ __global__ __launch_bounds__(WV, ((E == 1 && FAST) ? 6 : E <= 4 ? 4 : (E <= 8 ? 
 }
 
 #if SY_PART <= 0        // kernels that do not depend on the symbol width live in part 0 only
+// ------------------------------------------------------------------ payload workers, FR frames per wave (M = 64)
+// The one-frame-per-wave worker above spends a third of its instructions on things that do not grow with the symbol:
+// the pilot phase fit (atan2, unwrap scan, two projections -- executed by 64 lanes for 6 pilots), the oscillator trim,
+// the loop itself.  Here a wave takes FR hand-offs, one per group of G = 64 / FR lanes: lane (g, i) holds samples
+// i, i + G, ... of its frame's symbol window, the 64-point transform is log2(FR) in-register stages and log2(G) stages
+// across the lanes of the group, every group fits its own pilots with row scans in its first DPP row, and what was
+// wave-uniform scalar state is group-uniform vector state.  Same arithmetic per sample as run_job_fast (same butterfly
+// order and twiddles, same fit, same trim), so the symbols agree with it to the rounding of the fma shapes.
+template <int FR>
+__global__ __launch_bounds__(WV) void payload_multi_kernel(SyncArgs a)
+{
+    constexpr int G = WV / FR, E = FR;
+    static_assert(FR == 1 || FR == 2 || FR == 4, "groups are whole DPP rows");
+    launder(a);
+    __shared__ float2 qpil[FR * 16];
+    __shared__ uint32_t qps[64];
+    const SyncConsts &c = a.c;
+    const int l = lane_id(), g = l / G, i = l % G;
+    uint32_t nj = *a.njobs;
+    if (nj > a.max_jobs) nj = a.max_jobs;
+    const uint32_t j0 = (uint32_t)FR * blockIdx.x, j = j0 + (uint32_t)g;
+    if (j0 >= nj) return;
+    bool active = j < nj;
+    const uint32_t jj = active ? j : j0;                                // idle groups shadow the first job, store nothing
+    const PayloadJob *job = a.jobs + jj;
+    const uint32_t ch = job->ch;
+    active = active && ch < a.nch && job->arena_off != ~0ull;
+    qps[l] = reinterpret_cast<const uint32_t *>(c.pilot_seq)[l];        // 256 bytes, one word per lane
+    wave_sync_lds();
+    const uint8_t *pseq = reinterpret_cast<const uint8_t *>(qps);
+
+    // ---- per-lane constants: after the transform, sample position p = i + G e holds subcarrier bitrev6(p)
+    float2 R[E]; float fxr[E]; int dr[E], pr[E];
+    const float2 *bR = a.jR + (size_t)jj * c.M;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int kk = (int)(__brev((unsigned)(i + G * e)) >> 26);
+        dr[e] = c.data_rank[kk]; pr[e] = c.pilot_rank[kk];
+        fxr[e] = ((kk > c.M2) ? (float)kk - (float)c.M : (float)kk) * 0.15915494309189535f;
+        R[e] = c.sctype[kk] ? bR[kk] : make_float2(0.f, 0.f);
+    }
+    float2 twc[6]; float sgc[6];                                        // cross-lane stages h = 32 >> st (used for h < G)
+#pragma unroll
+    for (int st = 0; st < 6; st++) {
+        const int h = 32 >> st;
+        const bool up = (i & h) != 0;
+        const float rev = (float)(i & (h - 1)) * (0.5f / (float)h);
+        twc[st] = up ? make_float2(__builtin_amdgcn_cosf(rev), -__builtin_amdgcn_sinf(rev)) : make_float2(1.f, 0.f);
+        sgc[st] = up ? -1.f : 1.f;
+    }
+    const int Mp = c.M_pilot;
+    const float pf0 = (i < Mp) ? c.Pfit[i] : 0.f, pf1 = (i < Mp) ? c.Pfit[Mp + i] : 0.f;
+    // a value of lane 15 of every group's first row, in all lanes of the group
+    auto group_total = [&](float v) {
+        float r = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 15));
+#pragma unroll
+        for (int k = 1; k < FR; k++) {
+            const float t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k * G + 15));
+            r = g == k ? t : r;
+        }
+        return r;
+    };
+
+    // ---- group-uniform state (one frame per wave: wave-uniform, told to the compiler so that it lives in scalars)
+    auto uni = [](uint32_t v) { return FR == 1 ? rfl(v) : v; };
+    const int L = c.L, cb = c.cp - c.backoff, Md = c.M_data;
+    const uint32_t mod = uni(job->s.mod_scheme), bps = uni(job->s.bps), mod_len = uni(job->s.mod_len), nbits = uni(8u * job->s.enc_len);
+    const uint32_t nsym = (mod_len + (uint32_t)Md - 1u) / (uint32_t)Md;
+    const int64_t t_ev0 = job->s.cur + (int64_t)job->s.timer - 1;
+    const int64_t ws0 = t_ev0 - L + 1 + cb;
+    uint32_t dth = uni(job->s.nco_dtheta);
+    uint32_t th_ws = uni(job->s.nco_theta_ref + (uint32_t)(ws0 - job->s.nco_t_ref) * job->s.nco_dtheta);
+    uint32_t pc = uni(job->s.pilot_count);
+    float phi_prime = job->s.phi_prime, p1_prime = job->s.p1_prime;
+    int32_t r_ws = (int32_t)uni((uint32_t)(ws0 - a.buf_first));
+    const float2 *chb = a.chan + ((size_t)a.chan_off + ch) * MCRX_TILE_S;
+    const size_t tstride = (size_t)a.chan_stride * MCRX_TILE_S;
+    uint8_t *soft = a.jsoft + (size_t)jj * 8 * c.max_enc_len;
+    float2 *syms = reinterpret_cast<float2 *>(a.sarena + job->syms_off);
+    const bool soft_mode = c.payload_soft != 0;
+    uint32_t nmax = 0;
+#pragma unroll
+    for (int k = 0; k < FR; k++) {
+        const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)(active ? nsym : 0u), k * G);
+        nmax = v > nmax ? v : nmax;
+    }
+    const int32_t r_max = (int32_t)(a.end - a.buf_first) - 1;
+
+    auto load_win = [&](int32_t rw, float2 (&x)[E]) {
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            int32_t r = rw + i + G * e;
+            r = r < 0 ? 0 : (r > r_max ? r_max : r);                    // (groups that have finished keep reading in range)
+            x[e] = chb[(size_t)(r >> 3) * tstride + (size_t)(r & 7)];
+        }
+    };
+    float2 cur[E], nxt[E];
+    load_win(r_ws, cur);
+    uint32_t psi = 0;
+    for (uint32_t n = 0; n < nmax; n++) {
+        const bool live = active && n < nsym;
+        load_win(r_ws + L, nxt);
+        // ---- oscillator, 64-point DIF transform
+#pragma unroll
+        for (int e = 0; e < E; e++) cur[e] = rot_down(cur[e], u32rev(th_ws + (uint32_t)(i + G * e) * dth));
+#pragma unroll
+        for (int J = E / 2; J >= 1; J >>= 1) {                          // in-register stages, span h = G J
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                if ((e & J) == 0) {
+                    const float2 u = cur[e], v = cur[e + J];
+                    const float rev = (float)((i + G * e) & (G * J - 1)) * (0.5f / (float)(G * J));
+                    cur[e] = cadd(u, v); cur[e + J] = rot_down(csub(u, v), rev);
+                }
+            }
+        }
+#define SY_QSTAGE(ST, H)                                                                           \
+        if constexpr (H < G) {                                                                     \
+            _Pragma("unroll") for (int e = 0; e < E; e++) {                                        \
+                const float sx = bfly_leg<H>(cur[e].x, sgc[ST]), sy = bfly_leg<H>(cur[e].y, sgc[ST]);  \
+                if (H == 1) cur[e] = make_float2(sx, sy);                                          \
+                else cur[e] = make_float2(sx * twc[ST].x - sy * twc[ST].y, sx * twc[ST].y + sy * twc[ST].x); \
+            }                                                                                      \
+        }
+        SY_QSTAGE(0, 32) SY_QSTAGE(1, 16) SY_QSTAGE(2, 8) SY_QSTAGE(3, 4) SY_QSTAGE(4, 2) SY_QSTAGE(5, 1)
+#undef SY_QSTAGE
+        // ---- equaliser, pilots of this group to the first lanes of its first row
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            cur[e] = cmul(cur[e], R[e]);
+            if (pr[e] >= 0) qpil[16 * g + pr[e]] = cur[e];
+        }
+        wave_sync_lds();
+        float2 P = qpil[16 * g + (i < Mp ? i : 0)];
+        uint32_t pi_ = pc + (uint32_t)(i < 16 ? i : 0); pi_ = pi_ >= 255u ? pi_ - 255u : pi_;
+        const bool pneg = pseq[pi_ < 255u ? pi_ : 0u] == 0;
+        wave_sync_lds();
+        if (pneg) { P.x = -P.x; P.y = -P.y; }
+        const float v = atan2_fast(P.y, P.x);
+        const float prev = dpp_mov<0x111, false>(v, v);                 // row_shr:1, lane 0 of the row keeps its own
+        const float turns = rintf((v - prev) * 0.15915494309189535f);
+        const float y = fmaf(-TWO_PI_F, row_scan_fast(turns), v);
+        const float p0 = group_total(row_scan_fast(pf0 * y));
+        float p1 = group_total(row_scan_fast(pf1 * y));
+        pc += (uint32_t)Mp; pc = pc >= 255u ? pc - 255u : pc;
+        p1 = 0.3f * p1 + (1.0f - 0.3f) * p1_prime;
+        p1_prime = p1;
+        // ---- de-rotate, soft bits.  The modem is group state; the groups are served one distinct modem at a time
+        // (normally one pass) so that the demodulator's case analysis is scalar
+        const float p0r = p0 * 0.15915494309189535f;
+        const bool full = (psi + (uint32_t)Md) * bps <= nbits;
+        float2 Z[E];
+#pragma unroll
+        for (int e = 0; e < E; e++) Z[e] = rot_down(cur[e], fmaf(p1, fxr[e], p0r));
+        unsigned long long pending = __ballot(live);
+        while (pending) {
+            const int src = __builtin_ctzll(pending);
+            const uint32_t umod = (uint32_t)__builtin_amdgcn_readlane((int)mod, src), ubps = (uint32_t)__builtin_amdgcn_readlane((int)bps, src);
+            const bool sel = live && mod == umod;
+            pending &= ~__ballot(sel);
+            const uint8_t *unbt = umod == 27 ? c.cod.qam16_nb : c.cod.qam64_nb;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const uint32_t idx = psi + (uint32_t)dr[e];
+                const bool ok = sel && dr[e] >= 0 && idx < mod_len;
+                uint8_t sb[6];
+                const unsigned hs = demod_soft(unbt, umod, Z[e], sb);
+                if (!soft_mode) {
+#pragma unroll
+                    for (int kb = 0; kb < 6; kb++) sb[kb] = (uint8_t)(((hs >> ((ubps - 1 - kb) & 7)) & 1) ? 255 : 0);
+                }
+                if (!ok) continue;
+                syms[idx] = Z[e];
+                uint8_t *dst = soft + (size_t)idx * ubps;
+                if (full) {
+                    if (ubps == 2)      *reinterpret_cast<uint16_t *>(dst) = (uint16_t)(sb[0] | (sb[1] << 8));
+                    else if (ubps == 1) dst[0] = sb[0];
+                    else {
+                        *reinterpret_cast<uint16_t *>(dst) = (uint16_t)(sb[0] | (sb[1] << 8));
+                        *reinterpret_cast<uint16_t *>(dst + 2) = (uint16_t)(sb[2] | (sb[3] << 8));
+                        if (ubps == 6) *reinterpret_cast<uint16_t *>(dst + 4) = (uint16_t)(sb[4] | (sb[5] << 8));
+                    }
+                } else {
+                    for (unsigned kb = 0; kb < ubps; kb++) if (idx * ubps + kb < nbits) dst[kb] = sb[kb];
+                }
+            }
+        }
+        psi += (uint32_t)Md;
+        // ---- oscillator trim (liquid ofdmframesync: the phase at the next window start uses the old step up to this event)
+        float dphi = p0 - phi_prime;
+        dphi -= TWO_PI_F * rintf(dphi * 0.15915494309189535f);
+        phi_prime = p0;
+        const uint32_t dnew = dth + uni((uint32_t)__float2int_rn(dphi * (1e-3f * 683565275.5764316f)));
+        th_ws += (uint32_t)(L - cb) * dth + (uint32_t)cb * dnew;
+        if (live) dth = dnew;
+        r_ws += L;
+#pragma unroll
+        for (int e = 0; e < E; e++) cur[e] = nxt[e];
+    }
+    if (i == 0 && active) a.jobs[j].s.nco_dtheta = dth;
+}
+
 // ------------------------------------------------------------------ packet decode, a workgroup per frame
 // The payload workers leave 8 soft bits per coded byte in HBM.  De-interleaving them there costs
 // four passes of scattered 8-byte read-modify-writes per frame (measured: 4.7x the algorithmic HBM
@@ -2232,6 +2434,16 @@ hipError_t sync_launch_payload(const SyncArgs &a, int stage, hipStream_t st)
         if (soft_lds < 4096) soft_lds = 4096;
         const size_t msg_lds = ((size_t)a.c.max_payload_len + 4 + 15) & ~(size_t)15;
         hipLaunchKernelGGL(decode_kernel, dim3(nj), dim3(DK_T), soft_lds + msg_lds + 16, st, a, (uint32_t)soft_lds, (uint32_t)msg_lds);
+        return hipGetLastError();
+    }
+    // M = 64 with the pilots inside one DPP row: payload_multi_kernel, MCRX_PAYLOAD_FR frames per wave (default 1;
+    // 0 = the width-generic worker).  Measured on the bench stream: 1 -> 141.7 Gsample/s, 0 -> 138, 2 -> 138, 4 -> 118.
+    const char *fre = getenv("MCRX_PAYLOAD_FR");                         // (read per launch: the tests compare the builds)
+    const int fr = fre ? atoi(fre) : 1;
+    if (fast && a.c.M == WV && a.c.M_pilot <= 16 && fr > 0 && !(a.no_fast & 6)) {
+        if (fr == 4)      hipLaunchKernelGGL(payload_multi_kernel<4>, dim3((nj + 3) / 4), dim3(WV), 0, st, a);
+        else if (fr == 2) hipLaunchKernelGGL(payload_multi_kernel<2>, dim3((nj + 1) / 2), dim3(WV), 0, st, a);
+        else              hipLaunchKernelGGL(payload_multi_kernel<1>, dim3(nj), dim3(WV), 0, st, a);
         return hipGetLastError();
     }
     return sy_launch(fast ? SYK_PAYLOAD_FAST : SYK_PAYLOAD_GENERAL, a, nj, SY_LDS_BYTES(a.c.M), st);

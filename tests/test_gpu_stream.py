@@ -199,3 +199,31 @@ def test_chunked_push_with_deferral_overlaps_without_serial_walks(product):
     rx.Execute(iq); rx.Flush()
     assert sorted(_key(f) for f in rx.frames) == sorted(_key(f) for f in ref.frames) and len(ref.frames) == nf * N
     ref.close(); rx.close()
+
+
+@pytest.mark.parametrize("fr", [0, 2, 4])
+def test_payload_worker_builds_agree(oracle, product, fr, monkeypatch):
+    """The M = 64 payload worker exists as one frame per wave (default), two and four frames per wave (groups of 32 / 16
+    lanes, in-register transform stages) and as the width-generic kernel (0): same frames as the oracle, symbols <= 1e-5."""
+    N, M, cp, nf, plen = 8, 64, 8, 5, 333
+    slabs = _slabs(product, N, M, cp, 2, nf, plen, (0, 48))
+    x = np.concatenate([iq.cpu().numpy() for iq, _ in slabs])
+    ora = oracle.MultiChannelRx(N, M, cp, 4)
+    ora.execute(x)
+    assert len(ora.frames) == 2 * nf * N
+    monkeypatch.setenv("MCRX_PAYLOAD_FR", str(fr))
+    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=plen)
+    for iq, _ in slabs:
+        rx.Execute(iq)
+    rx.Flush()
+    by = lambda fr_: {c: [_key(f) for f in fr_ if f.channel == c] for c in range(N)}
+    assert by(rx.frames) == by(ora.frames)
+    o, g = {}, {}
+    for f in ora.frames:
+        o.setdefault(f.channel, []).append(f)
+    for f in rx.frames:
+        g.setdefault(f.channel, []).append(f)
+    worst = max(float(np.max(np.abs(a.framesyms - b.framesyms)) / np.max(np.abs(b.framesyms)))
+                for c in range(N) for a, b in zip(g[c], o[c]))
+    assert worst <= 1e-5, worst
+    rx.close()
