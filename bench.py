@@ -45,10 +45,11 @@ B_SYNC = 4.0                   # algorithmic bytes / wideband sample: the kept b
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--channels", type=int, default=512)
-    ap.add_argument("--frames", type=int, default=8, help="frames per channel per slab")
+    ap.add_argument("--frames", type=int, default=16, help="frames per channel per slab (16 -> 207.7 M wideband samples, 1.66 GB per push; rounds 1-2 "
+                                                           "used 8: throughput by slab size is in DESIGN.md section 4.5)")
     ap.add_argument("--slabs", type=int, default=3, help="different slabs per step and GPU")
     ap.add_argument("--payload", type=int, default=1200)
     ap.add_argument("--rounds", type=int, default=3, help="--gpus > 1: exchange rounds per step (a round = one sub-slab per rank)")
@@ -322,13 +323,14 @@ def measured_traffic(kernel, N, frames, payload):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r*_traffic.json:
     2 x FETCH_SIZE + WRITE_SIZE, collected on this workload by scratch/prof.sh); None when the run's
     configuration is not the profiled one.  Counters cannot be read from inside the timed run."""
-    import glob
-    if (N, frames, payload) != (512, 8, 1200):
-        return None
+    import glob, re
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
     if not files:
         return None
     prof = json.load(open(files[-1]))
+    m = re.search(r"(\d+)-ch multichannelrx.*?(\d+)B payloads, (\d+) frames/ch/slab", prof.get("workload", ""))
+    if not m or (int(m.group(1)), int(m.group(3)), int(m.group(2))) != (N, frames, payload):
+        return None                                     # the committed counters are of another workload
     for name, t in prof.get("kernels", {}).items():
         if kernel in name:
             return round(t["hbm_bytes_per_launch"], 0)

@@ -2228,20 +2228,23 @@ __global__ __launch_bounds__(PJ_T) void place_jobs_kernel(SyncArgs a)
         pay16 = (a.jobs[j].s.payload_len + 15u) >> 4;
         return 8u * a.jobs[j].s.mod_len;
     };
-    const unsigned long long base = a.arena_used[0], sbase = a.arena_used[1];
-    const uint32_t rbase = a.nrec[0];
-    if (nj <= PJ_CAP) {
+    // chunks of PJ_CAP jobs, each placed in parallel if all of it fits behind what is already placed; from the first
+    // chunk that does not, one thread places the rest exactly, job by job (a full pool: rare, and then speed is moot)
+    unsigned long long base = a.arena_used[0], sbase = a.arena_used[1];
+    uint32_t rbase = a.nrec[0];
+    uint32_t c0 = 0;
+    for (; c0 < nj; c0 += PJ_CAP) {
+        const uint32_t cn = nj - c0 < PJ_CAP ? nj - c0 : PJ_CAP;
         uint32_t me = 0;
-        for (uint32_t j = threadIdx.x; j < nj; j += PJ_T) {                             // all requests in flight at once
-            uint32_t p16; need_l[j] = need_of(j, p16); pay_l[j] = (uint16_t)p16;
-            const uint32_t e = a.jobs[j].ch < a.nch ? a.jobs[j].s.enc_len : 0u;
+        for (uint32_t j = threadIdx.x; j < cn; j += PJ_T) {                             // all requests in flight at once
+            uint32_t p16; need_l[j] = need_of(c0 + j, p16); pay_l[j] = (uint16_t)p16;
+            const uint32_t e = a.jobs[c0 + j].ch < a.nch ? a.jobs[c0 + j].s.enc_len : 0u;
             me = e > me ? e : me;
         }
         if (me) atomicMax(&maxenc, me);
         __syncthreads();
-        if (threadIdx.x == 0 && a.hint && maxenc) *a.hint = maxenc;                     // host-mapped: sizes the next launch's LDS
-        const uint32_t per = (nj + PJ_T - 1) / PJ_T;
-        const uint32_t j0 = threadIdx.x * per, j1 = (j0 + per < nj) ? j0 + per : nj;
+        const uint32_t per = (cn + PJ_T - 1) / PJ_T;
+        const uint32_t j0 = threadIdx.x * per < cn ? threadIdx.x * per : cn, j1 = (j0 + per < cn) ? j0 + per : cn;
         unsigned long long mine = 0; uint32_t mine2 = 0;
         for (uint32_t j = j0; j < j1; j++) if (need_l[j]) { mine += (1ull << 40) | need_l[j]; mine2 += pay_l[j]; }
         part[threadIdx.x] = mine; part2[threadIdx.x] = mine2;
@@ -2255,24 +2258,22 @@ __global__ __launch_bounds__(PJ_T) void place_jobs_kernel(SyncArgs a)
         }
         const unsigned long long tot = part[PJ_T - 1];
         const unsigned long long tot_sym = tot & ((1ull << 40) - 1), tot_cnt = tot >> 40, tot_pay = 16ull * part2[PJ_T - 1];
-        if (base + tot_pay <= a.arena_cap && sbase + tot_sym <= a.sarena_cap && rbase + tot_cnt <= a.max_rec) {
-            const unsigned long long excl = part[threadIdx.x] - mine;
-            unsigned long long soff = sbase + (excl & ((1ull << 40) - 1));
-            unsigned long long off = base + 16ull * (part2[threadIdx.x] - mine2);
-            uint32_t ridx = rbase + (uint32_t)(excl >> 40);
-            for (uint32_t j = j0; j < j1; j++) if (need_l[j]) {
-                a.jobs[j].arena_off = off; a.jobs[j].syms_off = soff; a.jobs[j].pad = ridx++;
-                off += 16ull * pay_l[j]; soff += need_l[j];
-            }
-            if (threadIdx.x == 0) { a.arena_used[0] = base + tot_pay; a.arena_used[1] = sbase + tot_sym; a.nrec[0] = rbase + (uint32_t)tot_cnt; }
-            return;
+        if (!(base + tot_pay <= a.arena_cap && sbase + tot_sym <= a.sarena_cap && rbase + tot_cnt <= a.max_rec)) break;
+        const unsigned long long excl = part[threadIdx.x] - mine;
+        unsigned long long soff = sbase + (excl & ((1ull << 40) - 1));
+        unsigned long long off = base + 16ull * (part2[threadIdx.x] - mine2);
+        uint32_t ridx = rbase + (uint32_t)(excl >> 40);
+        for (uint32_t j = j0; j < j1; j++) if (need_l[j]) {
+            a.jobs[c0 + j].arena_off = off; a.jobs[c0 + j].syms_off = soff; a.jobs[c0 + j].pad = ridx++;
+            off += 16ull * pay_l[j]; soff += need_l[j];
         }
-        __syncthreads();
+        base += tot_pay; sbase += tot_sym; rbase += (uint32_t)tot_cnt;
+        __syncthreads();                                                                // the staging is reused by the next chunk
     }
-    // not everything fits (or more jobs than the staging holds): exact sequential placement
+    if (threadIdx.x == 0 && a.hint && maxenc) *a.hint = maxenc;                         // host-mapped: sizes the next launch's LDS
     if (threadIdx.x == 0) {
         unsigned long long off = base, soff = sbase; uint32_t ridx = rbase, dropped = 0;
-        for (uint32_t j = 0; j < nj; j++) {
+        for (uint32_t j = c0; j < nj; j++) {                                            // (empty when every chunk fitted)
             uint32_t p16; const uint32_t nd = need_of(j, p16);
             if (!nd) continue;
             if (off + 16ull * p16 <= a.arena_cap && soff + nd <= a.sarena_cap && ridx < a.max_rec) {
