@@ -24,7 +24,8 @@ typedef enum { LIQUID_CRC_UNKNOWN = 0, LIQUID_CRC_NONE, LIQUID_CRC_CHECKSUM, LIQ
                LIQUID_CRC_16, LIQUID_CRC_24, LIQUID_CRC_32 } crc_scheme;
 typedef enum { LIQUID_FEC_UNKNOWN = 0, LIQUID_FEC_NONE, LIQUID_FEC_REP3, LIQUID_FEC_REP5,
                LIQUID_FEC_HAMMING74, LIQUID_FEC_HAMMING84, LIQUID_FEC_HAMMING128,
-               LIQUID_FEC_GOLAY2412 } fec_scheme;
+               LIQUID_FEC_GOLAY2412, LIQUID_FEC_SECDED2216, LIQUID_FEC_SECDED3932, LIQUID_FEC_SECDED7264,
+               LIQUID_FEC_CONV_V27 /* = 11: r = 1/2, K = 7 */ } fec_scheme;
 typedef enum { LIQUID_MODEM_UNKNOWN = 0, LIQUID_MODEM_QAM16 = 27, LIQUID_MODEM_QAM64 = 29,
                LIQUID_MODEM_BPSK = 39, LIQUID_MODEM_QPSK = 40 } modulation_scheme;
 enum { LIQUID_ANALYZER = 0, LIQUID_SYNTHESIZER = 1 };

@@ -22,7 +22,7 @@ MCRX_OK, MCRX_EINVAL, MCRX_ENOMEM, MCRX_EHIP, MCRX_EUNSUPP, MCRX_EOVERFLOW, MCRX
 TILE = 8
 
 LIQUID_CRC_NONE, LIQUID_CRC_32 = 1, 6
-LIQUID_FEC_NONE, LIQUID_FEC_HAMMING128, LIQUID_FEC_GOLAY2412 = 1, 6, 7
+LIQUID_FEC_NONE, LIQUID_FEC_HAMMING128, LIQUID_FEC_GOLAY2412, LIQUID_FEC_CONV_V27 = 1, 6, 7, 11
 LIQUID_MODEM_QAM16, LIQUID_MODEM_QAM64, LIQUID_MODEM_BPSK, LIQUID_MODEM_QPSK = 27, 29, 39, 40
 
 

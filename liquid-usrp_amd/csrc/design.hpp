@@ -19,7 +19,7 @@ struct cf { float re, im; };
 
 enum { SC_NULL = 0, SC_PILOT = 1, SC_DATA = 2 };
 enum { CRC_UNKNOWN = 0, CRC_NONE = 1, CRC_32 = 6 };
-enum { FEC_UNKNOWN = 0, FEC_NONE = 1, FEC_HAMMING128 = 6, FEC_GOLAY2412 = 7 };
+enum { FEC_UNKNOWN = 0, FEC_NONE = 1, FEC_HAMMING128 = 6, FEC_GOLAY2412 = 7, FEC_CONV_V27 = 11 };
 enum { MOD_UNKNOWN = 0, MOD_QAM16 = 27, MOD_QAM64 = 29, MOD_BPSK = 39, MOD_QPSK = 40 };
 
 // ---------------------------------------------------------------- Kaiser prototype
@@ -336,6 +336,7 @@ inline unsigned fec_enc_len(int fs, unsigned n)
 {
     if (fs == FEC_HAMMING128) return (n / 2) * 3 + (n % 2) * 2;
     if (fs == FEC_GOLAY2412) return (n / 3) * 6 + (n % 3) * 3;
+    if (fs == FEC_CONV_V27) return 2 * n + 2;               // r = 1/2, K = 7: 2 (8 n + 6) bits
     return n;
 }
 inline unsigned packet_enc_len(unsigned n, int crc, int fec0, int fec1)

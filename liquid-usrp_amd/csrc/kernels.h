@@ -150,6 +150,8 @@ struct SyncArgs {
     // scout -> payload worker hand-off (frame-parallel payload processing)
     int scout;                  // 1: scouts hand complete in-buffer frames to payload workers
     PayloadJob *jobs; uint32_t *njobs; uint32_t max_jobs;
+    uint32_t *gen_list;         // [0] = number of hand-offs the LDS decode path does not take, [1 ..] their job indices (place_jobs_kernel)
+    uint32_t dec_lds_soft;      // bytes of LDS the decode launch of this push gives a frame's soft bits (decides which path a frame takes)
     uint32_t *njobs_next;       // the next launch's job counter: zeroed by this launch's placement kernel
     float2 *jR;                 // [max_jobs][M]
     uint8_t *jsoft;             // [max_jobs][8*max_enc_len]
@@ -174,6 +176,7 @@ struct SyncArgs {
                                 //    is oversize, or the job list is full -- and then on to the end of the buffer
     uint32_t *stats;            // [0] frames the scouts acquired themselves, [1] frames adopted from speculative waves (NULL: not counted)
     int no_fast;               // MCRX_NO_FAST=1: payload workers use the general symbol path (A/B experiments)
+    uint32_t vit_off;          // byte offset of the convolutional decoder's 8 KB block scratch in the launch's dynamic LDS (0: none; set by the launchers)
 };
 hipError_t sync_launch(const SyncArgs &a, hipStream_t st);           // full state machine, one wave per channel (general configurations; tail kernel)
 hipError_t sync_launch_tail(const SyncArgs &a, hipStream_t st);      // lean configurations: payloads in progress, to the frame's end (a.tail_only = 1)

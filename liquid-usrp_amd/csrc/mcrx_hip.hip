@@ -158,6 +158,7 @@ struct mcrx_hip_s {
     uint64_t sarena_cap = 0;
     // per-launch slots
     PayloadJob *d_jobs[MCRX_SLOTS] = {}; uint32_t *d_njobs = nullptr; float2 *d_jR[MCRX_SLOTS] = {};
+    uint32_t *d_gen[MCRX_SLOTS] = {};
     uint64_t seq = 0;                       // synchronizer launches so far (slot = seq % nslots)
     unsigned nslots = 5;                    // buffer sets in use: the channelizer and the acquisition chain of up to nslots - 1 pushes run ahead of the payload workers
     uint32_t *d_stats = nullptr;            // speculation statistics (SyncArgs::stats)
@@ -448,6 +449,7 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     if (q->scout) {
         for (unsigned sl = 0; sl < q->nslots; sl++) {
             if ((rc = q->alloc(&q->d_jobs[sl], q->max_rec))) return bail(rc);
+            if ((rc = q->alloc(&q->d_gen[sl], (size_t)q->max_rec + 1))) return bail(rc);
             if ((rc = q->alloc(&q->d_jR[sl], (size_t)q->max_rec * M))) return bail(rc);
             if ((rc = q->alloc(&q->d_jsoft[sl], (size_t)q->max_rec * 8 * q->max_enc))) return bail(rc);
             if ((rc = q->alloc(&q->d_jtmp[sl], (size_t)q->max_rec * 2 * (q->max_enc + 16)))) return bail(rc);
@@ -589,8 +591,10 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     a.arena_cap = q->arena_cap; a.sarena_cap = q->sarena_cap; a.max_rec = q->max_rec;
     a.debug = getenv("MCRX_DEBUG") ? atoi(getenv("MCRX_DEBUG")) : 0;
     a.no_fast = getenv("MCRX_NO_FAST") ? atoi(getenv("MCRX_NO_FAST")) : 0;
+    a.vit_off = 0;
     a.scout = q->scout ? 1 : 0;
     a.jobs = q->d_jobs[slot]; a.njobs = q->d_njobs + slot; a.njobs_next = q->d_njobs + next; a.max_jobs = q->max_rec;
+    a.gen_list = q->d_gen[slot]; a.dec_lds_soft = 0;
     a.jR = q->d_jR[slot]; a.jsoft = q->d_jsoft[slot]; a.jtmp = q->d_jtmp[slot];
     a.stats = q->d_stats;
     a.hint = q->d_hint; a.enc_hint = (q->h_hint && q->d_hint) ? *(volatile uint32_t *)q->h_hint : 0u;

@@ -40,6 +40,7 @@ __device__ __forceinline__ unsigned fec_enc_len_d(unsigned fs, unsigned n)
 {
     if (fs == 6) return (n / 2) * 3 + (n % 2) * 2;      // Hamming(12,8)
     if (fs == 7) return (n / 3) * 6 + (n % 3) * 3;      // Golay(24,12)
+    if (fs == 11) return 2 * n + 2;                     // r = 1/2, K = 7 convolutional: 2 (8 n + 6) bits
     return n;
 }
 __device__ __forceinline__ unsigned mod_bps_d(unsigned m)
@@ -238,6 +239,94 @@ __device__ unsigned golay_dec_sym(unsigned r)
     return (rm ^ em) & 0xfff;
 }
 
+// ---- r = 1/2, K = 7 convolutional code (liquid LIQUID_FEC_CONV_V27 = libfec viterbi27): one wave, lane = trellis state.
+// Maximum-likelihood Viterbi over 8-bit soft symbols exactly as oracle/ll_fec.c states it (branch metric = sum of
+// |symbol - expected|, 32-bit path metrics, ties to the predecessor with the older bit 0, full traceback from state 0).
+// A full traceback needs a 64-bit decision word per trellis step -- 77 KB for a 1200-byte payload, which no buffer of the
+// frame has room for.  So the forward pass keeps only the path metrics at every VIT_B-th step (64 x 16 bits, normalised:
+// differences between states never exceed 6 x 510), and the traceback walks the blocks from the last to the first,
+// re-running each block's forward pass from its checkpoint into an LDS scratch of VIT_B decision words and then tracing
+// back through it: the same survivors as one pass with all decisions kept, at twice the add-compare-select work.
+#define VIT_B 1024u
+struct VitSym {                 // the two soft symbols of a step: from soft bytes, or from packed hard bits (0 / 255)
+    const uint8_t *p; bool hard;
+    // symbols of step t0 + lane as sa | sb << 8 (steps >= T: anything); one load per 64 steps instead of two per step
+    __device__ __forceinline__ unsigned chunk(unsigned t0, unsigned T) const
+    {
+        unsigned t = t0 + (unsigned)lane_id(); t = t < T ? t : T - 1;
+        if (!hard) return *reinterpret_cast<const uint16_t *>(p + 2 * (size_t)t);
+        const unsigned b = 2 * t, v = p[b >> 3];
+        return (((v >> (7 - (b & 7))) & 1u) ? 255u : 0u) | ((((v >> (6 - (b & 7))) & 1u) ? 255u : 0u) << 8);
+    }
+};
+// forward pass over steps [t0, t1), t0 a multiple of 64: pm = this lane's path metric; decision words to `dec` (LDS) if not null
+__device__ __forceinline__ int vit_forward(const VitSym &sy, unsigned t0, unsigned t1, unsigned T, int pm, unsigned long long *dec)
+{
+    const int s = lane_id();
+    const int p0 = s >> 1, p1 = (s >> 1) | 32;
+    const bool oa = __builtin_popcount((unsigned)s & 0x6d) & 1, ob = __builtin_popcount((unsigned)s & 0x4f) & 1;
+    for (unsigned tc = t0; tc < t1; tc += 64) {
+        const unsigned sy64 = sy.chunk(tc, T);
+        const unsigned cn = t1 - tc < 64 ? t1 - tc : 64;
+        for (unsigned k = 0; k < cn; k++) {
+            const unsigned v = (unsigned)__builtin_amdgcn_readlane((int)sy64, (int)k);
+            const int sa = (int)(v & 0xffu), sb = (int)(v >> 8);
+            const int bm0 = (oa ? 255 - sa : sa) + (ob ? 255 - sb : sb);
+            const int m0 = __shfl(pm, p0, WV) + bm0, m1 = __shfl(pm, p1, WV) + (510 - bm0);
+            const bool take1 = m1 < m0;
+            pm = take1 ? m1 : m0;
+            if (dec) { const unsigned long long w = __ballot(take1); if (s == 0) dec[tc - t0 + k] = w; }
+        }
+    }
+    return pm;
+}
+// n decoded bytes from 2 (8 n + 6) symbols; `ckpt`: >= 128 * ceil(T / VIT_B) bytes of scratch in HBM; `lds`: VIT_B x 8 bytes
+__device__ void conv27_decode_wave(const VitSym sy, unsigned n, uint8_t *dec, uint16_t *ckpt, unsigned long long *lds)
+{
+    const int s = lane_id();
+    const unsigned T = 8 * n + 6, nblk = (T + VIT_B - 1) / VIT_B;
+    int pm = s ? (1 << 20) : 0;                             // the encoder starts in state 0
+    for (unsigned b = 0; b < nblk; b++) {                   // checkpoints: normalised metrics at the start of every block
+        int mn = pm;
+#pragma unroll
+        for (int h = 32; h >= 1; h >>= 1) { const int o = __shfl_xor(mn, h, WV); mn = o < mn ? o : mn; }
+        pm -= mn; if (pm > 0xffff) pm = 0xffff;             // (only the unreachable states of the first steps saturate)
+        ckpt[64 * b + s] = (uint16_t)pm;
+        const unsigned t1 = (b + 1) * VIT_B < T ? (b + 1) * VIT_B : T;
+        pm = vit_forward(sy, b * VIT_B, t1, T, pm, nullptr);
+    }
+    unsigned state = 0;                                     // the tail bits return the encoder to state 0
+    for (unsigned b = nblk; b-- > 0;) {
+        const unsigned t0 = b * VIT_B, t1 = t0 + VIT_B < T ? t0 + VIT_B : T;
+        (void)vit_forward(sy, t0, t1, T, (int)ckpt[64 * b + s], lds);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // trace back through the block in chunks of 64 steps (aligned: a chunk owns whole bytes of the message): lane k
+        // holds the decision word of step c0 + k
+        for (unsigned c1 = t1; c1 > t0;) {
+            const unsigned c0 = (c1 - 1) & ~63u, cn = c1 - c0;
+            const unsigned long long w = (unsigned)s < cn ? lds[c0 - t0 + s] : 0ull;
+            unsigned long long bits = 0;                    // decoded bit of step c0 + k at bit k
+            for (unsigned k = cn; k-- > 0;) {
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)w, (int)k);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(w >> 32), (int)k);
+                const unsigned long long wk = ((unsigned long long)hi << 32) | lo;
+                bits |= (unsigned long long)(state & 1u) << k;
+                state = (state >> 1) | ((unsigned)((wk >> state) & 1ull) << 5);
+            }
+            // step t -> byte t / 8, bit 7 - t % 8 (steps >= 8 n are the tail): the first eight lanes take the chunk's bytes
+            const unsigned by = (c0 >> 3) + (unsigned)s;
+            if (s < 8 && by < n) {
+                unsigned v = 0;
+#pragma unroll
+                for (unsigned kb = 0; kb < 8; kb++) v |= (unsigned)((bits >> (8 * (unsigned)s + kb)) & 1ull) << (7 - kb);
+                dec[by] = (uint8_t)v;
+            }
+            c1 = c0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 // hard decode `enc` -> `dec` (dec_len bytes), lanes in parallel
 __device__ void fec_decode_hard(unsigned fs, unsigned n, const uint8_t *enc, uint8_t *dec)
 {
@@ -287,25 +376,32 @@ __device__ void soft_pack(const uint8_t *soft, unsigned nbytes, uint8_t *out, bo
 // (8-byte aligned).  Result message in tmpb[0..n_msg); returns validity.
 __device__ bool packet_decode(const CodingDev cod, bool soft_mode, bool scrambled, unsigned n_msg,
                               unsigned crc, unsigned fec0, unsigned fec1,
-                              uint8_t *soft, uint8_t *tmpa, uint8_t *tmpb, unsigned ablate = 0)
+                              uint8_t *soft, uint8_t *tmpa, uint8_t *tmpb, unsigned long long *vit_lds = nullptr, unsigned ablate = 0)
 {
     const int l = lane_id();
     const unsigned crc_len = (crc == 6) ? 4u : 0u;
     const unsigned n0 = n_msg + crc_len;
     const unsigned e0 = fec_enc_len_d(fec0, n0), e1 = fec_enc_len_d(fec1, e0);
-    const unsigned d0 = (fec0 == 6 || fec0 == 7) ? 4u : 0u, d1 = (fec1 == 6 || fec1 == 7) ? 4u : 0u;
+    const unsigned d0 = (fec0 == 6 || fec0 == 7 || fec0 == 11) ? 4u : 0u, d1 = (fec1 == 6 || fec1 == 7 || fec1 == 11) ? 4u : 0u;
+    if ((fec0 == 11 || fec1 == 11) && !vit_lds) return false;      // (every launch that can get here provides the scratch)
     if (soft_mode && fec1 == 6) {
         if (!(ablate & 8)) deinterleave<true>(soft, e1, d1);
         if (!(ablate & 16)) for (unsigned i = (unsigned)l; i < e0; i += WV) tmpa[i] = (uint8_t)h128_dec_soft_fast(soft + 12 * (size_t)i);
+        __syncthreads();
+    } else if (soft_mode && fec1 == 11) {
+        deinterleave<true>(soft, e1, d1);
+        conv27_decode_wave(VitSym{ soft, false }, e0, tmpa, reinterpret_cast<uint16_t *>(tmpb), vit_lds);   // checkpoints: e0 + 128 bytes
         __syncthreads();
     } else {
         if (soft_mode) deinterleave<true>(soft, e1, d1);
         soft_pack(soft, e1, tmpb, scrambled);
         if (!soft_mode) deinterleave<false>(tmpb, e1, d1);
-        fec_decode_hard(fec1, e0, tmpb, tmpa);
+        if (fec1 == 11) { conv27_decode_wave(VitSym{ tmpb, true }, e0, tmpa, reinterpret_cast<uint16_t *>(soft), vit_lds); __syncthreads(); }   // (the soft bits are spent)
+        else fec_decode_hard(fec1, e0, tmpb, tmpa);
     }
     deinterleave<false>(tmpa, e0, d0);
-    fec_decode_hard(fec0, n0, tmpa, tmpb);
+    if (fec0 == 11) { conv27_decode_wave(VitSym{ tmpa, true }, n0, tmpb, reinterpret_cast<uint16_t *>(soft), vit_lds); __syncthreads(); }
+    else fec_decode_hard(fec0, n0, tmpa, tmpb);
     if (crc_len == 0 || (ablate & 32)) return true;
     uint32_t key = ((uint32_t)tmpb[n_msg] << 24) | ((uint32_t)tmpb[n_msg + 1] << 16) |
                    ((uint32_t)tmpb[n_msg + 2] << 8) | (uint32_t)tmpb[n_msg + 3];
@@ -318,9 +414,9 @@ __device__ bool packet_decode(const CodingDev cod, bool soft_mode, bool scramble
 // mis-scheduled: right bytes, wrong CRC verdict, depending on unrelated edits).
 __device__ __attribute__((noinline)) bool packet_decode_call(const CodingDev *cod, bool soft_mode, bool scrambled, unsigned n_msg,
                                                              unsigned crc, unsigned fec0, unsigned fec1,
-                                                             uint8_t *soft, uint8_t *tmpa, uint8_t *tmpb)
+                                                             uint8_t *soft, uint8_t *tmpa, uint8_t *tmpb, unsigned long long *vit_lds)
 {
-    return packet_decode(*cod, soft_mode, scrambled, n_msg, crc, fec0, fec1, soft, tmpa, tmpb);
+    return packet_decode(*cod, soft_mode, scrambled, n_msg, crc, fec0, fec1, soft, tmpa, tmpb, vit_lds);
 }
 
 // ------------------------------------------------------------------ modem
@@ -426,6 +522,16 @@ __device__ __forceinline__ int64_t spec_key(int64_t pos, uint32_t timer) { retur
 // payload of a frame straddling two pushes), a speculative acquisition wave, or the lean per-channel scout
 // (acquisition + header only: a frame whose payload does not fit the buffer is left to the tail kernel)
 enum { SYM_FULL = 0, SYM_SPEC = 1, SYM_LEAN = 2 };
+
+// a fast worker that has finished a frame's symbols: frames the LDS decode path does not take go on the list of
+// decode_general_kernel (place_jobs_kernel zeroed its counter)
+__device__ __forceinline__ void note_general_decode(const SyncArgs &a, uint32_t j, const ChanState &st)
+{
+    if (!a.gen_list) return;
+    const bool lds_path = a.c.payload_soft && st.fec0 == 1 && (st.fec1 == 6 || st.fec1 == 7 || st.fec1 == 1) &&
+                          8u * st.enc_len <= a.dec_lds_soft && !(a.no_fast & 8);
+    if (!lds_path) { typedef __attribute__((address_space(1))) uint32_t GU; uint32_t *gl = (uint32_t *)(GU *)a.gen_list; gl[1u + atomicAdd(gl, 1u)] = j; }
+}
 
 template <int E>
 struct Walker {
@@ -818,7 +924,7 @@ struct Walker {
         __syncthreads();
         for (int i = l; i < MCRX_HDR_SYMS; i += WV) soft[i] = hb[i] ? 255 : 0;
         __syncthreads();
-        bool ok = packet_decode_call(&c.cod, false, true, MCRX_HDR_DEC, 6, 7, 1, soft, ta, tb);
+        bool ok = packet_decode_call(&c.cod, false, true, MCRX_HDR_DEC, 6, 7, 1, soft, ta, tb, nullptr);
 #pragma unroll
         for (int w = 0; w < 4; w++) {
             uint32_t v = 0;
@@ -837,7 +943,7 @@ struct Walker {
         const unsigned check = (hbyte(12) >> 5) & 7, fec0 = hbyte(12) & 0x1f, fec1 = hbyte(13) & 0x1f;
         const unsigned bps = mod_bps_d(mod);
         if (proto != 104 || bps == 0 || !(check == 1 || check == 6) ||
-            !(fec0 == 1 || fec0 == 6 || fec0 == 7) || !(fec1 == 1 || fec1 == 6 || fec1 == 7)) ok = false;
+            !(fec0 == 1 || fec0 == 6 || fec0 == 7 || fec0 == 11) || !(fec1 == 1 || fec1 == 6 || fec1 == 7 || fec1 == 11)) ok = false;
         s.header_valid = ok ? 1 : 0;
         if (ok) {
             s.payload_len = plen; s.mod_scheme = mod; s.bps = bps; s.check = check; s.fec0 = fec0; s.fec1 = fec1;
@@ -906,7 +1012,7 @@ struct Walker {
             if (!oversize) {
                 __syncthreads();
                 valid = packet_decode_call(&c.cod, c.payload_soft != 0, false, s.payload_len, s.check, s.fec0, s.fec1, soft,
-                                           btmpa, btmpb);
+                                           btmpa, btmpb, a.vit_off ? reinterpret_cast<unsigned long long *>(reinterpret_cast<uint8_t *>(sy_lds) + a.vit_off) : nullptr);
             }
             emit(t_ev, true, valid, oversize);
             return 1;
@@ -1172,7 +1278,7 @@ struct Walker {
         }
         // ---- frame complete: decode and emit (same tail as flex_symbol)
         // ---- symbols done: decode_kernel (a workgroup per frame) takes the packet from here
-        if (l == 0) a.jobs[j].s.nco_dtheta = dth;
+        if (l == 0) { a.jobs[j].s.nco_dtheta = dth; note_general_decode(a, j, s); }
     }
 
     // scout, lean RXSYMBOLS event: the counterpart of rx_core on the Walker's state
@@ -1989,7 +2095,7 @@ __global__ __launch_bounds__(WV) void payload_multi_kernel(SyncArgs a)
 #pragma unroll
         for (int e = 0; e < E; e++) cur[e] = nxt[e];
     }
-    if (i == 0 && active) a.jobs[j].s.nco_dtheta = dth;
+    if (i == 0 && active) { a.jobs[j].s.nco_dtheta = dth; note_general_decode(a, j, job->s); }
 }
 
 // ------------------------------------------------------------------ packet decode, a workgroup per frame
@@ -2109,9 +2215,7 @@ __global__ __launch_bounds__(DK_T) void decode_kernel(SyncArgs a, uint32_t lds_s
     const SyncConsts &c = a.c;
     const uint32_t n_msg = a.jobs[j].s.payload_len, crc = a.jobs[j].s.check, fec0 = a.jobs[j].s.fec0, fec1 = a.jobs[j].s.fec1;
     const uint32_t e1 = a.jobs[j].s.enc_len;
-    const size_t tstride = (size_t)c.max_enc_len + 16;
     uint8_t *soft = a.jsoft + (size_t)j * 8 * c.max_enc_len;
-    uint8_t *tmpa = a.jtmp + (size_t)j * 2 * tstride, *tmpb = tmpa + tstride;
     const uint32_t crc_len = (crc == 6) ? 4u : 0u, n0 = n_msg + crc_len;
     const bool prof = SY_PROF(a) && j == 7;
     long long tk[8]; int ntk = 0;
@@ -2119,6 +2223,7 @@ __global__ __launch_bounds__(DK_T) void decode_kernel(SyncArgs a, uint32_t lds_s
     DK_TICK()
     // LDS path: soft decisions, no inner code, outer code Hamming(12,8) (soft decoder), Golay(24,12) (sliced) or none
     const bool lds_path = c.payload_soft && fec0 == 1 && (fec1 == 6 || fec1 == 7 || fec1 == 1) && 8u * e1 <= lds_soft_bytes && !(a.no_fast & 8);
+    if (!lds_path) return;                  // everything else: decode_general_kernel (one wave per frame, in place in HBM)
     if (lds_path) {
         const unsigned long long *g64 = reinterpret_cast<const unsigned long long *>(soft);
         for (uint32_t b0 = 0; b0 < e1; b0 += 8 * DK_T) {           // eight requests per thread in flight
@@ -2180,28 +2285,51 @@ __global__ __launch_bounds__(DK_T) void decode_kernel(SyncArgs a, uint32_t lds_s
         reinterpret_cast<uint32_t *>(dk_soft)[threadIdx.x] = c.cod.crc_byte[threadIdx.x];     // soft bits are spent: byte table in their place
         __syncthreads();
         if (threadIdx.x >= WV) return;
-    } else {
-        if (threadIdx.x >= WV) return;          // general schemes: one wave, in place in HBM
     }
-    bool valid;
-    if (lds_path) {
-        valid = true;
-        if (crc_len) {
-            const uint8_t *msg = reinterpret_cast<const uint8_t *>(dk_soft) + lds_soft_bytes;
-            const uint32_t key = ((uint32_t)msg[n_msg] << 24) | ((uint32_t)msg[n_msg + 1] << 16) |
-                                 ((uint32_t)msg[n_msg + 2] << 8) | (uint32_t)msg[n_msg + 3];
-            valid = crc32_tree(c.cod, 0u, lds_soft_bytes, n_msg) == key;
-        }
-    } else valid = packet_decode(c.cod, c.payload_soft != 0, false, n_msg, crc, fec0, fec1, soft, tmpa, tmpb);
+    bool valid = true;
+    if (crc_len) {
+        const uint8_t *msg = reinterpret_cast<const uint8_t *>(dk_soft) + lds_soft_bytes;
+        const uint32_t key = ((uint32_t)msg[n_msg] << 24) | ((uint32_t)msg[n_msg + 1] << 16) |
+                             ((uint32_t)msg[n_msg + 2] << 8) | (uint32_t)msg[n_msg + 3];
+        valid = crc32_tree(c.cod, 0u, lds_soft_bytes, n_msg) == key;
+    }
     DK_TICK()
     Walker<1> w(a, ch);
     const PayloadJob job = a.jobs[j];
     if (!w.bind_job(j, job)) return;
     const int64_t nsym = (int64_t)((w.s.mod_len + (uint32_t)c.M_data - 1) / (uint32_t)c.M_data);
-    w.emit(w.s.cur + (int64_t)w.s.timer - 1 + (nsym - 1) * (int64_t)c.L, true, valid, false, /*copy_payload=*/!lds_path);
+    w.emit(w.s.cur + (int64_t)w.s.timer - 1 + (nsym - 1) * (int64_t)c.L, true, valid, false, /*copy_payload=*/false);
     DK_TICK()
     if (prof && threadIdx.x == 0) printf("[prof] decode wg7 cycles: stage %lld  passes %lld  h128 %lld  crc %lld  emit %lld\n", tk[1]-tk[0], tk[2]-tk[1], tk[3]-tk[2], tk[4]-tk[3], tk[5]-tk[4]);
 #undef DK_TICK
+}
+
+// The frames the LDS path does not take (hard decisions, an inner code, the convolutional code, frames longer than the
+// LDS sized for this launch): one wave per frame decodes in place in HBM with the walker's general decoder -- a separate
+// kernel so that its registers (the Viterbi decoder's among them) do not set the occupancy of the one above.
+__global__ __launch_bounds__(WV) void decode_general_kernel(SyncArgs a)
+{
+    launder(a);
+    const uint32_t *gl = as_global(a.gen_list);
+    uint32_t ng = gl[0];
+    if (ng > a.max_jobs) ng = a.max_jobs;
+    const SyncConsts &c = a.c;
+    for (uint32_t k = blockIdx.x; k < ng; k += gridDim.x) {        // (a handful of workgroups; the list is normally empty)
+        const uint32_t j = gl[1 + k];
+        const uint32_t ch = a.jobs[j].ch;
+        if (ch >= a.nch || a.jobs[j].arena_off == ~0ull) continue;
+        const uint32_t n_msg = a.jobs[j].s.payload_len, crc = a.jobs[j].s.check, fec0 = a.jobs[j].s.fec0, fec1 = a.jobs[j].s.fec1;
+        const size_t tstride = (size_t)c.max_enc_len + 16;
+        uint8_t *soft = a.jsoft + (size_t)j * 8 * c.max_enc_len;
+        uint8_t *tmpa = a.jtmp + (size_t)j * 2 * tstride, *tmpb = tmpa + tstride;
+        const bool valid = packet_decode(c.cod, c.payload_soft != 0, false, n_msg, crc, fec0, fec1, soft, tmpa, tmpb, dk_soft);   // 8 KB of LDS: the Viterbi block scratch
+        Walker<1> w(a, ch);
+        const PayloadJob job = a.jobs[j];
+        if (!w.bind_job(j, job)) continue;
+        const int64_t nsym = (int64_t)((w.s.mod_len + (uint32_t)c.M_data - 1) / (uint32_t)c.M_data);
+        w.emit(w.s.cur + (int64_t)w.s.timer - 1 + (nsym - 1) * (int64_t)c.L, true, valid, false, /*copy_payload=*/true);
+        __syncthreads();
+    }
 }
 
 // Record space for the handed-off frames: an exclusive prefix sum of their sizes in job order
@@ -2216,9 +2344,10 @@ __global__ __launch_bounds__(PJ_T) void place_jobs_kernel(SyncArgs a)
     __shared__ uint32_t need_l[PJ_CAP];             // symbol-arena bytes of job j (0 = void slot: a live frame always has symbols)
     __shared__ uint16_t pay_l[PJ_CAP];              // payload-arena bytes of job j in 16-byte units
     __shared__ uint32_t maxenc;
-    if (threadIdx.x == 0) maxenc = 0;
+    if (threadIdx.x == 0) { maxenc = 0; if (a.gen_list) as_global(a.gen_list)[0] = 0; }
     __syncthreads();
     launder(a);
+    a.gen_list = a.gen_list ? as_global(a.gen_list) : nullptr;
     uint32_t nj = *a.njobs;
     if (nj > a.max_jobs) nj = a.max_jobs;
     if (threadIdx.x == 0 && a.njobs_next) *a.njobs_next = 0;
@@ -2240,6 +2369,7 @@ __global__ __launch_bounds__(PJ_T) void place_jobs_kernel(SyncArgs a)
             uint32_t p16; need_l[j] = need_of(c0 + j, p16); pay_l[j] = (uint16_t)p16;
             const uint32_t e = a.jobs[c0 + j].ch < a.nch ? a.jobs[c0 + j].s.enc_len : 0u;
             me = e > me ? e : me;
+
         }
         if (me) atomicMax(&maxenc, me);
         __syncthreads();
@@ -2377,8 +2507,15 @@ hipError_t sy_launch_acq_e2(int what, const SyncArgs &a, unsigned grid, size_t l
 #endif
 
 #if SY_PART <= 0
-static hipError_t sy_launch(int what, const SyncArgs &a, unsigned grid, size_t lds, hipStream_t st)
+static hipError_t sy_launch(int what, const SyncArgs &a0, unsigned grid, size_t lds, hipStream_t st)
 {
+    // kernels that can end up decoding a packet themselves get the Viterbi decoder's block scratch behind their LDS
+    SyncArgs a = a0;
+    a.vit_off = 0;
+    if (what == SYK_SCOUT || what == SYK_TAIL || what == SYK_PAYLOAD_GENERAL || (what == SYK_LEAN && a.c.E > 2)) {
+        a.vit_off = (uint32_t)((lds + 15) & ~(size_t)15);
+        lds = a.vit_off + (size_t)VIT_B * 8;
+    }
     switch (a.c.E) {
     case 1:  return sy_launch_e1(what, a, grid, lds, st);
     case 2:  return sy_launch_e2(what, a, grid, lds, st);
@@ -2415,26 +2552,36 @@ hipError_t sync_launch_spec(const SyncArgs &a, hipStream_t st)
     return sy_launch(SYK_SPEC, a, a.nch * a.spec_cap, SY_LDS_BYTES(a.c.M), st);
 }
 
-hipError_t sync_launch_payload(const SyncArgs &a, int stage, hipStream_t st)
+// bytes of LDS a frame's soft bits get in this push's decode launch: 8 per coded byte, at most 56 KiB (longer frames
+// decode in HBM); sized from the longest frame the previous launch saw -- a.enc_hint, read without a sync -- so that more
+// workgroups fit a CU; 0 = no history yet: size for the configured maximum
+static uint32_t decode_soft_lds(const SyncArgs &a)
 {
-    if (a.nch == 0 || !a.scout || a.max_jobs == 0) return hipSuccess;
+    const uint32_t enc_cap = a.enc_hint ? ((a.enc_hint + 127u) & ~127u) : a.c.max_enc_len;
+    size_t soft_lds = (size_t)8 * (enc_cap < a.c.max_enc_len ? enc_cap : a.c.max_enc_len);
+    if (soft_lds > 56 * 1024) soft_lds = 56 * 1024;
+    if (soft_lds < 4096) soft_lds = 4096;
+    return (uint32_t)soft_lds;
+}
+
+hipError_t sync_launch_payload(const SyncArgs &a0, int stage, hipStream_t st)
+{
+    if (a0.nch == 0 || !a0.scout || a0.max_jobs == 0) return hipSuccess;
+    SyncArgs a = a0;
     const unsigned nj = a.max_jobs;
     const bool fast = a.c.log2M >= 6 && a.c.M == WV * a.c.E && a.c.M_pilot <= WV && !(a.no_fast & 1);
+    a.dec_lds_soft = fast ? decode_soft_lds(a) : 0u;
+    if (!fast) a.gen_list = nullptr;
     if (stage == 0) {
         hipLaunchKernelGGL(place_jobs_kernel, dim3(1), dim3(PJ_T), 0, st, a);
         return hipGetLastError();
     }
     if (stage == 2) {
         if (!fast) return hipSuccess;
-        // soft bits of one frame in LDS: 8 bytes per coded byte, at most 56 KiB (longer frames decode in HBM);
-        // sized from the longest frame the previous launch saw -- a.enc_hint, read without a sync -- so
-        // that more workgroups fit a CU; 0 = no history yet: size for the configured maximum
-        const uint32_t enc_cap = a.enc_hint ? ((a.enc_hint + 127u) & ~127u) : a.c.max_enc_len;
-        size_t soft_lds = (size_t)8 * (enc_cap < a.c.max_enc_len ? enc_cap : a.c.max_enc_len);
-        if (soft_lds > 56 * 1024) soft_lds = 56 * 1024;
-        if (soft_lds < 4096) soft_lds = 4096;
+        const size_t soft_lds = a.dec_lds_soft;
         const size_t msg_lds = ((size_t)a.c.max_payload_len + 4 + 15) & ~(size_t)15;
         hipLaunchKernelGGL(decode_kernel, dim3(nj), dim3(DK_T), soft_lds + msg_lds + 16, st, a, (uint32_t)soft_lds, (uint32_t)msg_lds);
+        hipLaunchKernelGGL(decode_general_kernel, dim3(nj < 256 ? nj : 256), dim3(WV), (size_t)VIT_B * 8, st, a);
         return hipGetLastError();
     }
     // M = 64 with the pilots inside one DPP row: payload_multi_kernel, MCRX_PAYLOAD_FR frames per wave (default 1;

@@ -60,6 +60,17 @@ inline void fec_encode(int fs, const std::vector<uint8_t> &dec, std::vector<uint
             enc[j] = (uint8_t)(m0 >> 16); enc[j + 1] = (uint8_t)(m0 >> 8); enc[j + 2] = (uint8_t)m0;
             j += 3;
         }
+    } else if (fs == FEC_CONV_V27) {
+        // liquid fec_conv.c / libfec: polynomials 0x6d, 0x4f on sr = (sr << 1) | bit, message bits MSB first, six zero tail bits
+        auto par = [](unsigned v) { v ^= v >> 4; v ^= v >> 2; v ^= v >> 1; return v & 1u; };
+        unsigned sr = 0, acc = 0, nb = 0;
+        for (size_t i = 0; i < 8 * n + 6; i++) {
+            const unsigned bit = i < 8 * n ? (dec[i >> 3] >> (7 - (i & 7))) & 1u : 0u;
+            sr = ((sr << 1) | bit) & 0x7f;
+            acc = (acc << 1) | par(sr & 0x6d); acc = (acc << 1) | par(sr & 0x4f); nb += 2;
+            if (nb == 8) { enc[j++] = (uint8_t)acc; acc = 0; nb = 0; }
+        }
+        if (nb) enc[j++] = (uint8_t)(acc << (8 - nb));
     } else enc = dec;
 }
 // liquid's interleaver: pass = swap masked bits of x[2i] and x[2j+1], j(i) from the column walk
@@ -93,8 +104,8 @@ inline void packet_encode(const std::vector<uint8_t> &msg, int crc, int fec0, in
         uint32_t key = crc32_bytes(msg.data(), msg.size());
         b0.push_back((uint8_t)(key >> 24)); b0.push_back((uint8_t)(key >> 16)); b0.push_back((uint8_t)(key >> 8)); b0.push_back((uint8_t)key);
     }
-    fec_encode(fec0, b0, b1); interleave(b1, (fec0 == FEC_HAMMING128 || fec0 == FEC_GOLAY2412) ? 4 : 0);
-    fec_encode(fec1, b1, b0); interleave(b0, (fec1 == FEC_HAMMING128 || fec1 == FEC_GOLAY2412) ? 4 : 0);
+    fec_encode(fec0, b0, b1); interleave(b1, (fec0 == FEC_HAMMING128 || fec0 == FEC_GOLAY2412 || fec0 == FEC_CONV_V27) ? 4 : 0);
+    fec_encode(fec1, b1, b0); interleave(b0, (fec1 == FEC_HAMMING128 || fec1 == FEC_GOLAY2412 || fec1 == FEC_CONV_V27) ? 4 : 0);
     pkt.swap(b0);
 }
 

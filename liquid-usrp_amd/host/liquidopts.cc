@@ -10,7 +10,7 @@ static const struct { const char *name; modulation_scheme ms; } mods[] = {
     { "bpsk", LIQUID_MODEM_BPSK }, { "qpsk", LIQUID_MODEM_QPSK }, { "qam16", LIQUID_MODEM_QAM16 }, { "qam64", LIQUID_MODEM_QAM64 } };
 static const struct { const char *name; fec_scheme fs; } fecs[] = {
     { "none", LIQUID_FEC_NONE }, { "rep3", LIQUID_FEC_REP3 }, { "rep5", LIQUID_FEC_REP5 }, { "h74", LIQUID_FEC_HAMMING74 },
-    { "h84", LIQUID_FEC_HAMMING84 }, { "h128", LIQUID_FEC_HAMMING128 }, { "g2412", LIQUID_FEC_GOLAY2412 } };
+    { "h84", LIQUID_FEC_HAMMING84 }, { "h128", LIQUID_FEC_HAMMING128 }, { "g2412", LIQUID_FEC_GOLAY2412 }, { "v27", LIQUID_FEC_CONV_V27 } };
 
 extern "C" modulation_scheme liquid_getopt_str2mod(const char *_str)
 {

@@ -33,7 +33,8 @@ typedef struct { float re, im; } ll_cf;
 /* ---- enums (numeric values follow liquid.h of the v1.2/v1.3 era) ---------- */
 enum { LL_CRC_UNKNOWN=0, LL_CRC_NONE, LL_CRC_CHECKSUM, LL_CRC_8, LL_CRC_16, LL_CRC_24, LL_CRC_32 };
 enum { LL_FEC_UNKNOWN=0, LL_FEC_NONE, LL_FEC_REP3, LL_FEC_REP5, LL_FEC_HAMMING74,
-       LL_FEC_HAMMING84, LL_FEC_HAMMING128, LL_FEC_GOLAY2412 };
+       LL_FEC_HAMMING84, LL_FEC_HAMMING128, LL_FEC_GOLAY2412,
+       LL_FEC_CONV_V27 = 11 };     /* liquid's numbering: SECDED 8..10, then the convolutional codes (r = 1/2, K = 7 first) */
 enum { LL_MODEM_UNKNOWN=0, LL_MODEM_QAM16=27, LL_MODEM_QAM64=29, LL_MODEM_BPSK=39, LL_MODEM_QPSK=40,
        LL_MODEM_NUM_SCHEMES=52 };
 enum { LL_ANALYZER=0, LL_SYNTHESIZER=1 };

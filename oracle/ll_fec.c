@@ -178,10 +178,61 @@ unsigned ll_golay2412_decode_symbol(unsigned r)
     return (rm ^ (found ? em : 0)) & 0xfff;
 }
 
+/* ------------------------------------------------------------------ r = 1/2, K = 7 convolutional code
+ * liquid fec_conv.c (LIQUID_FEC_CONV_V27) over libfec's viterbi27: generator polynomials 0x6d, 0x4f on the shift register
+ * sr = (sr << 1) | bit, message bits MSB first, K-1 zero tail bits, output bits MSB first, last byte zero padded:
+ * 2 (8 n + 6) bits = 2 n + 2 bytes.  The decoder is the maximum-likelihood Viterbi decoder over 8-bit soft symbols
+ * (0 = certainly 0, 255 = certainly 1; hard decisions are 0 / 255), branch metric = sum of |symbol - expected|, path metrics
+ * in 32-bit integers (no renormalisation needed below 2^31 / 510 steps), ties to the predecessor with the older bit 0,
+ * full traceback from state 0.  (libfec keeps 64-bit decision words per step and traces back the same way; its
+ * tie-breaking is not visible from the reference -- parity unpinned like the rest of this file.) */
+static unsigned conv27_parity(unsigned v) { v ^= v >> 4; v ^= v >> 2; v ^= v >> 1; return v & 1u; }
+static void conv27_encode(unsigned n, const unsigned char *dec, unsigned char *enc)
+{
+    unsigned sr = 0, acc = 0, nb = 0, j = 0;
+    for (unsigned i = 0; i < 8 * n + 6; i++) {
+        unsigned bit = i < 8 * n ? (dec[i >> 3] >> (7 - (i & 7))) & 1u : 0u;
+        sr = ((sr << 1) | bit) & 0x7f;
+        acc = (acc << 1) | conv27_parity(sr & 0x6d); acc = (acc << 1) | conv27_parity(sr & 0x4f); nb += 2;
+        if (nb == 8) { enc[j++] = (unsigned char)acc; acc = 0; nb = 0; }
+    }
+    if (nb) enc[j++] = (unsigned char)(acc << (8 - nb));
+}
+/* sym: 2 soft symbols per step */
+static void conv27_viterbi(unsigned n, const unsigned char *sym, unsigned char *dec)
+{
+    const unsigned T = 8 * n + 6;
+    unsigned long long *d = (unsigned long long *)malloc(sizeof(unsigned long long) * (T ? T : 1));
+    int pm[64], nm[64];
+    for (int s = 0; s < 64; s++) pm[s] = s ? (1 << 28) : 0;               /* the encoder starts in state 0 */
+    for (unsigned t = 0; t < T; t++) {
+        const int sa = sym[2 * t], sb = sym[2 * t + 1];
+        unsigned long long w = 0;
+        for (int s = 0; s < 64; s++) {                                      /* new state s = (prev << 1 | bit) & 63 */
+            const int p0 = s >> 1, p1 = (s >> 1) | 32;
+            const int bm0 = (conv27_parity((unsigned)s & 0x6d) ? 255 - sa : sa) + (conv27_parity((unsigned)s & 0x4f) ? 255 - sb : sb);
+            const int m0 = pm[p0] + bm0, m1 = pm[p1] + (510 - bm0);       /* both polynomials tap the oldest bit */
+            const int take1 = m1 < m0;
+            nm[s] = take1 ? m1 : m0;
+            w |= (unsigned long long)take1 << s;
+        }
+        d[t] = w;
+        memcpy(pm, nm, sizeof(pm));
+    }
+    memset(dec, 0, n);
+    unsigned state = 0;
+    for (unsigned t = T; t-- > 0;) {
+        if (t < 8 * n) dec[t >> 3] |= (unsigned char)((state & 1u) << (7 - (t & 7)));
+        state = (state >> 1) | ((unsigned)((d[t] >> state) & 1ull) << 5);
+    }
+    free(d);
+}
+
 /* ------------------------------------------------------------------ FEC block codecs */
 unsigned ll_fec_enc_len(int scheme, unsigned n)
 {
     switch (scheme) {
+    case LL_FEC_CONV_V27:   return 2 * n + 2;
     case LL_FEC_HAMMING128: return (n / 2) * 3 + (n % 2) * 2;
     case LL_FEC_GOLAY2412:  return (n / 3) * 6 + (n % 3) * 3;
     default: return n;
@@ -224,6 +275,7 @@ void ll_fec_encode(int scheme, unsigned n, const unsigned char *dec, unsigned ch
             j += 3;
         }
     } break;
+    case LL_FEC_CONV_V27: conv27_encode(n, dec, enc); break;
     default: memmove(enc, dec, n);
     }
 }
@@ -232,6 +284,13 @@ void ll_fec_decode(int scheme, unsigned n, const unsigned char *enc, unsigned ch
 {
     unsigned i, j = 0;
     switch (scheme) {
+    case LL_FEC_CONV_V27: {
+        const unsigned T = 8 * n + 6;
+        unsigned char *sym = (unsigned char *)malloc(2 * T);
+        for (i = 0; i < 2 * T; i++) sym[i] = ((enc[i >> 3] >> (7 - (i & 7))) & 1u) ? 255 : 0;
+        conv27_viterbi(n, sym, dec);
+        free(sym);
+    } break;
     case LL_FEC_HAMMING128: {
         unsigned r = n % 2;
         for (i = 0; i < n - r; i += 2) {
@@ -279,6 +338,7 @@ void ll_fec_decode_soft(int scheme, unsigned n, const unsigned char *soft, unsig
         if (r) dec[n - 1] = (unsigned char)h128_decode_soft_symbol(soft + k);
         return;
     }
+    if (scheme == LL_FEC_CONV_V27) { conv27_viterbi(n, soft, dec); return; }
     /* no soft decoder: slice at 127, pack MSB first, hard decode */
     unsigned enc_len = ll_fec_enc_len(scheme, n);
     unsigned char *hard = (unsigned char *)malloc(enc_len ? enc_len : 1);

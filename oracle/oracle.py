@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "liboracle.so")
 
 CRC_NONE, CRC_32 = 1, 6
-FEC_NONE, FEC_HAMMING128, FEC_GOLAY2412 = 1, 6, 7
+FEC_NONE, FEC_HAMMING128, FEC_GOLAY2412, FEC_CONV_V27 = 1, 6, 7, 11
 MODEM_QAM16, MODEM_QAM64, MODEM_BPSK, MODEM_QPSK = 27, 29, 39, 40
 ANALYZER, SYNTHESIZER = 0, 1
 

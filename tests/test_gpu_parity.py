@@ -371,6 +371,62 @@ def test_noisy_channel_same_decisions_as_oracle(oracle, product, snr_db, mod, fe
     rx.close()
 
 
+@pytest.mark.parametrize("mod,fec0,fec1,soft,snr_db", [(40, 1, 11, 1, None), (40, 1, 11, 1, 6.0), (27, 1, 11, 1, 14.0), (40, 1, 11, 0, 7.0),
+                                                       (40, 11, 6, 1, None), (40, 11, 11, 1, 9.0)])
+def test_convolutional_k7_rate_half_viterbi(oracle, product, mod, fec0, fec1, soft, snr_db):
+    """BASELINE configs[2]'s "r = 1/2 FEC" in liquid's own sense: LIQUID_FEC_CONV_V27 (K = 7; libfec's Viterbi decoder in
+    the reference) as outer and / or inner code, soft and hard decisions, at SNRs where the decoder corrects thousands of
+    bit errors per frame: the GPU's checkpointed-traceback Viterbi gives the oracle's bytes, frame for frame."""
+    N, M, cp, plen = 4, 64, 8, 700
+    tx = product.multichanneltx(N, M, cp, 4)
+    iq, sent = tx.generate(3, plen, mod=mod, fec0=fec0, fec1=fec1, seed=5)
+    tx.close()
+    x = iq.cpu().numpy()
+    if snr_db is not None:
+        rng = np.random.RandomState(2)
+        sig = np.sqrt(np.mean(np.abs(x) ** 2)) * np.sqrt(2.0 * N / (2 * N))       # (per-channel SNR ~ wideband SNR + 3 dB: half the band is empty)
+        nstd = sig * 10.0 ** (-snr_db / 20.0) / np.sqrt(2.0)
+        x = (x + nstd * (rng.randn(len(x)) + 1j * rng.randn(len(x)))).astype(np.complex64)
+    x = x[:len(x) // (16 * N) * (16 * N)]
+    ora = oracle.MultiChannelRx(N, M, cp, 4, soft=bool(soft))
+    ora.execute(x)
+    assert len(ora.frames) >= 3 * N - 1
+    nvalid = sum(1 for f in ora.frames if f.payload_valid)
+    assert nvalid >= len(ora.frames) - 2, nvalid                   # the code does its job at these SNRs
+    if snr_db is None:
+        for f in ora.frames:
+            assert sent[f.channel][(f.header[0] << 8) | f.header[1]] == (f.header, f.payload)
+    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=plen, payload_soft=soft)
+    rx.Execute(x); rx.Flush()
+    w = check_frames(rx.frames, ora.frames, rel=1.0)
+    assert w <= REL, w
+    assert all((f.fec0, f.fec1) == (fec0, fec1) for f in rx.frames if f.header_valid)
+    rx.close()
+
+
+@pytest.mark.parametrize("M,cp,step_blocks", [(64, 8, 40), (48, 6, 0)])
+def test_convolutional_code_on_the_serial_paths(oracle, product, M, cp, step_blocks):
+    """The same code where a whole frame is decoded by one wave of a walker kernel: pushes that cut every frame (the tail
+    kernel finishes the payload and decodes it) and a configuration outside the fast path (M = 48: general workers)."""
+    N, plen = 4, 300
+    iq, sent = oracle.synth_traffic(N, M, cp, 4, 3, payload_len=plen, fec1=oracle.FEC_CONV_V27, seed=12)
+    x = iq[:len(iq) // (16 * N) * (16 * N)]
+    ora = oracle.MultiChannelRx(N, M, cp, 4)
+    ora.execute(x)
+    assert len(ora.frames) == 3 * N and all(f.payload_valid for f in ora.frames)
+    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=plen)
+    if step_blocks:
+        step = 2 * N * 8 * step_blocks
+        for i in range(0, len(x), step):
+            rx.Execute(x[i:i + step])
+    else:
+        rx.Execute(x)
+    rx.Flush()
+    w = check_frames(rx.frames, ora.frames, rel=1.0)
+    assert w <= REL, w
+    rx.close()
+
+
 def test_speculation_survives_wrong_predictions(oracle, product):
     """The scout's frame-level speculation predicts where frames start from the previous launch.  Feed it a
     stream whose frame length changes (predictions from the first half are wrong for the second), in pieces,

@@ -117,8 +117,45 @@ def test_scrambler_is_involution(oracle):
     assert np.array_equal(y, x)
 
 
+def test_conv_v27_is_the_k7_rate_half_code(oracle):
+    """liquid LIQUID_FEC_CONV_V27 (libfec viterbi27): generators 0x6d / 0x4f (octal 155 / 117 read the other way round:
+    the standard K = 7 pair with free distance 10), 2 (8 n + 6) output bits, and a maximum-likelihood decoder: any 4 bit
+    errors in a block are corrected (d_free = 10), soft decisions decode what the hard slicer cannot."""
+    L = oracle.lib()
+    n = 40
+    rng = np.random.RandomState(7)
+    msg = rng.randint(0, 256, n).astype(np.uint8)
+    k = L.ll_fec_enc_len(11, n)
+    assert k == 2 * n + 2                                  # ceil(2 (8 n + 6) / 8): liquid fec_conv_get_enc_msg_len
+    enc = np.zeros(k, np.uint8)
+    L.ll_fec_encode(11, n, msg.ctypes.data, enc.ctypes.data)
+    # impulse response of the encoder = the two generator polynomials, MSB = newest bit
+    one = np.zeros(2, np.uint8); one[0] = 0x80
+    e1 = np.zeros(L.ll_fec_enc_len(11, 2), np.uint8)
+    L.ll_fec_encode(11, 2, one.ctypes.data, e1.ctypes.data)
+    bits = np.unpackbits(e1)[:14].reshape(7, 2)
+    assert int("".join(map(str, bits[:, 0])), 2) == 0b1011011 and int("".join(map(str, bits[:, 1])), 2) == 0b1111001   # 0x6d, 0x4f reversed
+    assert bits.sum() == 10                                # d_free of the (171, 133) code
+    dec = np.zeros(n, np.uint8)
+    for trial in range(20):
+        bad = np.unpackbits(enc)
+        pos = rng.choice(len(bad) - 16, 4, replace=False)
+        bad[pos] ^= 1
+        b = np.packbits(bad)
+        L.ll_fec_decode(11, n, b.ctypes.data, dec.ctypes.data)
+        assert np.array_equal(dec, msg), trial
+    # soft: three adjacent symbols erased to 127/128 plus two confident errors nearby -- decodes; sliced hard it is 5 errors in a span
+    soft = (np.unpackbits(enc).astype(np.int32) * 255)
+    soft[100:103] = 127 + (soft[100:103] > 0)             # (nearly) erased, sliced to the right side
+    soft[110] = 255 - soft[110]; soft[117] = 255 - soft[117]
+    sb = soft.astype(np.uint8)
+    L.ll_fec_decode_soft(11, n, sb.ctypes.data, dec.ctypes.data)
+    assert np.array_equal(dec, msg)
+
+
 @pytest.mark.parametrize("n,fec0,fec1,enc", [(14, 7, 1, 36), (1200, 1, 6, 1806), (1200, 1, 7, 2409),
-                                             (1200, 1, 1, 1204), (0, 1, 6, 6), (5, 6, 7, 30)])
+                                             (1200, 1, 1, 1204), (0, 1, 6, 6), (5, 6, 7, 30),
+                                             (1200, 1, 11, 2410), (100, 11, 6, 315), (0, 1, 11, 10)])
 def test_packetizer_lengths_roundtrip_and_error_correction(oracle, n, fec0, fec1, enc):
     p = oracle.Packetizer(n, oracle.CRC_32, fec0, fec1)
     assert p.enc_len == enc
