@@ -68,6 +68,31 @@ ORX = os.path.join(ROOT, "liquid-usrp_amd", "lib", "ofdmflexframe_rx_ref")
 
 
 @pytest.mark.skipif(not (os.path.exists(OTX) and os.path.exists(ORX)), reason="reference app binaries not built")
+def test_unchanged_apps_with_the_convolutional_code(oracle, product, tmp_path):
+    """The same two applications with `-k v27` (liquid's r = 1/2, K = 7 convolutional code as the outer code, QAM16):
+    liquid_getopt_str2fec knows the name, the GPU transmitter encodes it, the receiver application's Viterbi decoder
+    returns every packet; the capture is also decoded by the oracle."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "liquid-usrp_amd", "host"), "-s"])
+    f = tmp_path / "tx.bin"
+    nframes, P = 8, 500
+    env = dict(os.environ, MCTX_IQ_FILE=str(f), MCTX_IQ_SAMPLES=str(1 << 30))
+    out = subprocess.run([OTX, "-N", str(nframes), "-P", str(P), "-m", "qam16", "-k", "v27"], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    iq = np.fromfile(f, np.complex64)
+    ora = oracle.FlexFrameSync(48, 6, 4)
+    ora.execute(np.concatenate([iq, np.zeros(200, np.complex64)]))
+    assert [((fr.header[0] << 8) | fr.header[1], fr.payload_valid, len(fr.payload)) for fr in ora.frames] == [(i, 1, P) for i in range(nframes)]
+    assert all((fr.mod_scheme, fr.fec1) == (27, 11) for fr in ora.frames)
+    np.concatenate([iq, np.zeros(4096, np.complex64)]).tofile(f)
+    env = dict(os.environ, MCRX_IQ_FILE=str(f), MCRX_IQ_PACKET="4096")
+    out = subprocess.run([ORX, "-t", "0.5"], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    ids = [int(x) for x in re.findall(r"rx packet id:\s+(\d+)\n", out.stdout)]
+    assert len(ids) >= nframes and set(ids) == set(range(nframes)), out.stdout[-3000:]
+    assert "INVALID" not in out.stdout
+
+
+@pytest.mark.skipif(not (os.path.exists(OTX) and os.path.exists(ORX)), reason="reference app binaries not built")
 def test_unchanged_ofdmflexframe_tx_and_rx_apps_loop_back(oracle, product, tmp_path):
     """BASELINE configs[0] as the reference runs it: src/ofdmflexframe_tx.cc -> (file instead of a radio) ->
     src/ofdmflexframe_rx.cc, both unchanged, on the GPU ofdmtxrx class, at the applications' default

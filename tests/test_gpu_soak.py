@@ -19,7 +19,7 @@ def test_random_traffic_matches_oracle(oracle, product, seed):
         tx = product.multichanneltx(N, M, cp, 4)
         parts = []
         for seg in range(rng.randint(1, 4)):
-            mod = int(rng.choice([39, 40, 27, 29])); fec1 = int(rng.choice([1, 6, 7]))
+            mod = int(rng.choice([39, 40, 27, 29])); fec1 = int(rng.choice([1, 6, 7, 11]))
             plen = int(rng.randint(0, 600)); nf = int(rng.randint(1, 5))
             x, _ = tx.generate(nf, plen, mod=mod, fec1=fec1, seed=int(rng.randint(1 << 30)), gain=float(rng.uniform(0.2, 1.0)) / N)
             parts.append(x)
