@@ -2581,6 +2581,10 @@ hipError_t sync_launch_payload(const SyncArgs &a0, int stage, hipStream_t st)
         const size_t soft_lds = a.dec_lds_soft;
         const size_t msg_lds = ((size_t)a.c.max_payload_len + 4 + 15) & ~(size_t)15;
         hipLaunchKernelGGL(decode_kernel, dim3(nj), dim3(DK_T), soft_lds + msg_lds + 16, st, a, (uint32_t)soft_lds, (uint32_t)msg_lds);
+        return hipGetLastError();
+    }
+    if (stage == 3) {                       // the frames on the general list (filled by the payload workers of stage 1)
+        if (!fast) return hipSuccess;
         hipLaunchKernelGGL(decode_general_kernel, dim3(nj < 256 ? nj : 256), dim3(WV), (size_t)VIT_B * 8, st, a);
         return hipGetLastError();
     }
