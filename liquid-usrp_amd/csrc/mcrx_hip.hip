@@ -166,8 +166,7 @@ struct mcrx_hip_s {
     // Launch k+1's acquisition -- a chain of dependent events per channel, a few waves per CU -- runs under launch
     // k's payload/decode kernels, and launch k+1's channelizer as soon as CUs free up.
     bool pipelined = true;
-    hipStream_t s_scout = nullptr, s_work = nullptr, s_copy = nullptr, s_aux = nullptr;
-    hipEvent_t ev_pay[MCRX_SLOTS] = {}, ev_aux[MCRX_SLOTS] = {};
+    hipStream_t s_scout = nullptr, s_work = nullptr, s_copy = nullptr;
     hipEvent_t ev_ready[MCRX_SLOTS] = {}, ev_scout[MCRX_SLOTS] = {}, ev_done[MCRX_SLOTS] = {}, ev_in = nullptr, ev_consumed = nullptr, ev_tmp[3] = {};
     int last_slot = -1; size_t last_ntiles = 0;     // where the synchronizer history (tail of the previous launch) sits
     SpecSlot *d_spec = nullptr; float2 *d_spec_R = nullptr; int64_t *d_pred = nullptr; uint32_t *d_pred_n = nullptr;
@@ -486,13 +485,12 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
             return bail(fail(MCRX_EHIP, "hipStreamCreate failed"));
     }
     if (hipStreamCreate(&q->s_work) != hipSuccess) return bail(fail(MCRX_EHIP, "hipStreamCreate failed"));
-    if (hipStreamCreate(&q->s_aux) != hipSuccess) return bail(fail(MCRX_EHIP, "hipStreamCreate failed"));
     if (hipStreamCreateWithFlags(&q->s_copy, hipStreamNonBlocking) != hipSuccess) return bail(fail(MCRX_EHIP, "hipStreamCreate failed"));
     {
         hipEvent_t *evs[] = { &q->ev_in, &q->ev_consumed, &q->ev_tmp[0], &q->ev_tmp[1], &q->ev_tmp[2] };
         for (hipEvent_t *e : evs) if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return bail(fail(MCRX_EHIP, "hipEventCreate failed"));
         for (int sl = 0; sl < MCRX_SLOTS; sl++) {
-            hipEvent_t *ev3[] = { &q->ev_ready[sl], &q->ev_scout[sl], &q->ev_done[sl], &q->ev_pay[sl], &q->ev_aux[sl] };
+            hipEvent_t *ev3[] = { &q->ev_ready[sl], &q->ev_scout[sl], &q->ev_done[sl] };
             for (hipEvent_t *e : ev3) if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return bail(fail(MCRX_EHIP, "hipEventCreate failed"));
         }
     }
@@ -531,10 +529,8 @@ extern "C" int mcrx_hip_destroy(mcrx_hip_t q)
             if (q->ev_ready[sl]) (void)hipEventDestroy(q->ev_ready[sl]);
             if (q->ev_scout[sl]) (void)hipEventDestroy(q->ev_scout[sl]);
             if (q->ev_done[sl]) (void)hipEventDestroy(q->ev_done[sl]);
-            if (q->ev_pay[sl]) (void)hipEventDestroy(q->ev_pay[sl]);
-            if (q->ev_aux[sl]) (void)hipEventDestroy(q->ev_aux[sl]);
         }
-        hipStream_t sts[] = { q->s_scout, q->s_work, q->s_copy, q->s_aux };
+        hipStream_t sts[] = { q->s_scout, q->s_work, q->s_copy };
         for (hipStream_t t : sts) if (t) (void)hipStreamDestroy(t);
     }
     for (int i = 0; i < 2; i++) {
@@ -651,23 +647,16 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
             HIPCHK(hipEventRecord(q->ev_scout[slot], sa));
             HIPCHK(hipStreamWaitEvent(sw, q->ev_scout[slot], 0));
         }
-        // payload workers; then the LDS-path packet decoder, and beside it (its own stream when pipelined: it is
-        // nearly always an empty launch, which in line would cost a dispatch bubble per push) the general decoder
+        // payload workers; the LDS-path packet decoder; the general decoder (nearly always an empty launch: ~12 us.
+        // Giving it a stream of its own was tried: a fifth stream makes the harvest's copy stream share a hardware
+        // queue with a busy one, and every poll then waits a slab's time for its 16-byte copies -- harvest 123 -> 98 Gsample/s)
         RC(q->ev_begin(3, sw));
         HIPCHK(sync_launch_payload(a, 1, sw));
         RC(q->ev_end(3, sw));
-        const bool aside = sw != st && q->s_aux;
-        if (aside) {
-            HIPCHK(hipEventRecord(q->ev_pay[slot], sw));
-            HIPCHK(hipStreamWaitEvent(q->s_aux, q->ev_pay[slot], 0));
-            HIPCHK(sync_launch_payload(a, 3, q->s_aux));
-            HIPCHK(hipEventRecord(q->ev_aux[slot], q->s_aux));
-        }
         RC(q->ev_begin(4, sw));
         HIPCHK(sync_launch_payload(a, 2, sw));
-        if (!aside) HIPCHK(sync_launch_payload(a, 3, sw));
+        HIPCHK(sync_launch_payload(a, 3, sw));
         RC(q->ev_end(4, sw));
-        if (aside) HIPCHK(hipStreamWaitEvent(sw, q->ev_aux[slot], 0));
     }
     HIPCHK(hipEventRecord(q->ev_done[slot], sw));
     HIPCHK(hipEventRecord(q->ev_gen[g], sw));

@@ -7,10 +7,10 @@ from __graft_entry__ import load_product
 P = load_product()
 N, M, cp = 512, 64, 8
 tx = P.multichanneltx(N, M, cp, 4)
-slabs = [tx.generate(8, 1200, seed=1 + i, nblocks=int(P.lib().mctx_hip_blocks_for(tx._h, 8, 1200, 40, 1, 6)) + 24 * i)[0] for i in range(3)]
+slabs = [tx.generate(16, 1200, seed=1 + i, nblocks=int(P.lib().mctx_hip_blocks_for(tx._h, 16, 1200, 40, 1, 6)) + 24 * i)[0] for i in range(3)]
 tx.close()
 for skip, wait in ((1, True), (0, True)):
-    rx = P.multichannelrx(N, M, cp, 4, max_payload_len=1200, max_frames=N * 8 + 64, skip_framesyms=skip)
+    rx = P.multichannelrx(N, M, cp, 4, max_payload_len=1200, max_frames=N * 16 + 64, skip_framesyms=skip)
     for d in slabs:
         rx.Execute(d); rx.Poll(deliver=False); rx.drain_count()
     rx.Flush(); rx.drain_count(); torch.cuda.synchronize()
