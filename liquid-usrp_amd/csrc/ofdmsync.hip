@@ -523,16 +523,6 @@ __device__ __forceinline__ int64_t spec_key(int64_t pos, uint32_t timer) { retur
 // (acquisition + header only: a frame whose payload does not fit the buffer is left to the tail kernel)
 enum { SYM_FULL = 0, SYM_SPEC = 1, SYM_LEAN = 2 };
 
-// a fast worker that has finished a frame's symbols: frames the LDS decode path does not take go on the list of
-// decode_general_kernel (place_jobs_kernel zeroed its counter)
-__device__ __forceinline__ void note_general_decode(const SyncArgs &a, uint32_t j, const ChanState &st)
-{
-    if (!a.gen_list) return;
-    const bool lds_path = a.c.payload_soft && st.fec0 == 1 && (st.fec1 == 6 || st.fec1 == 7 || st.fec1 == 1) &&
-                          8u * st.enc_len <= a.dec_lds_soft && !(a.no_fast & 8);
-    if (!lds_path) { typedef __attribute__((address_space(1))) uint32_t GU; uint32_t *gl = (uint32_t *)(GU *)a.gen_list; gl[1u + atomicAdd(gl, 1u)] = j; }
-}
-
 template <int E>
 struct Walker {
     const SyncArgs &a;
@@ -1278,7 +1268,7 @@ struct Walker {
         }
         // ---- frame complete: decode and emit (same tail as flex_symbol)
         // ---- symbols done: decode_kernel (a workgroup per frame) takes the packet from here
-        if (l == 0) { a.jobs[j].s.nco_dtheta = dth; note_general_decode(a, j, s); }
+        if (l == 0) a.jobs[j].s.nco_dtheta = dth;
     }
 
     // scout, lean RXSYMBOLS event: the counterpart of rx_core on the Walker's state
@@ -2095,7 +2085,7 @@ __global__ __launch_bounds__(WV) void payload_multi_kernel(SyncArgs a)
 #pragma unroll
         for (int e = 0; e < E; e++) cur[e] = nxt[e];
     }
-    if (i == 0 && active) { a.jobs[j].s.nco_dtheta = dth; note_general_decode(a, j, job->s); }
+    if (i == 0 && active) a.jobs[j].s.nco_dtheta = dth;
 }
 
 // ------------------------------------------------------------------ packet decode, a workgroup per frame
@@ -2223,7 +2213,10 @@ __global__ __launch_bounds__(DK_T) void decode_kernel(SyncArgs a, uint32_t lds_s
     DK_TICK()
     // LDS path: soft decisions, no inner code, outer code Hamming(12,8) (soft decoder), Golay(24,12) (sliced) or none
     const bool lds_path = c.payload_soft && fec0 == 1 && (fec1 == 6 || fec1 == 7 || fec1 == 1) && 8u * e1 <= lds_soft_bytes && !(a.no_fast & 8);
-    if (!lds_path) return;                  // everything else: decode_general_kernel (one wave per frame, in place in HBM)
+    if (!lds_path) {                        // everything else: onto the list of decode_general_kernel (one wave per frame, in place in HBM)
+        if (threadIdx.x == 0 && a.gen_list) { uint32_t *gl = as_global(a.gen_list); gl[1u + atomicAdd(gl, 1u)] = j; }
+        return;
+    }
     if (lds_path) {
         const unsigned long long *g64 = reinterpret_cast<const unsigned long long *>(soft);
         for (uint32_t b0 = 0; b0 < e1; b0 += 8 * DK_T) {           // eight requests per thread in flight
@@ -2583,7 +2576,7 @@ hipError_t sync_launch_payload(const SyncArgs &a0, int stage, hipStream_t st)
         hipLaunchKernelGGL(decode_kernel, dim3(nj), dim3(DK_T), soft_lds + msg_lds + 16, st, a, (uint32_t)soft_lds, (uint32_t)msg_lds);
         return hipGetLastError();
     }
-    if (stage == 3) {                       // the frames on the general list (filled by the payload workers of stage 1)
+    if (stage == 3) {                       // the frames on the general list (filled by decode_kernel)
         if (!fast) return hipSuccess;
         hipLaunchKernelGGL(decode_general_kernel, dim3(nj < 256 ? nj : 256), dim3(WV), (size_t)VIT_B * 8, st, a);
         return hipGetLastError();
