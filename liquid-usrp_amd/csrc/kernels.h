@@ -162,6 +162,7 @@ struct SyncArgs {
     int64_t *pred; uint32_t *pred_n;     // predicted fresh-state positions for the next launch: [nch][MCRX_SPEC_MAX], [nch]
     uint32_t spec_cap;                   // slots per channel the speculative kernel fills in this launch (0: off)
     uint32_t *spec_hint;                 // host-mapped word: largest prediction count, sizes the next launch's grid
+    uint32_t *walk_hint;                 // host-mapped word: frames the scouts had to acquire themselves so far (the host adds a full-width round while it moves)
     uint32_t *hint;             // host-mapped word: longest coded frame (bytes) among this launch's jobs
     uint32_t enc_hint;          // the value the host last saw there (0: none yet)
     int stop_after_walk;        // 1: a scout standing in a post-frame (or the entry) state nobody predicted stops there and predicts

@@ -173,7 +173,8 @@ struct mcrx_hip_s {
     bool spec = false;
     uint32_t *h_hint = nullptr, *d_hint = nullptr;     // pinned, device-mapped: longest coded frame of the last launch
     uint8_t *d_jsoft[MCRX_SLOTS] = {}, *d_jtmp[MCRX_SLOTS] = {};
-    bool scout = true; int scout_rounds = 3; bool narrow_first = true;
+    bool scout = true; int scout_rounds = 2; bool narrow_first = true;
+    bool rounds_fixed = false; uint32_t walk_seen = 0; int extra_round_for = 0;     // adaptive third round, see launch_sync
     // streaming state
     uint64_t total_samples = 0;             // wideband samples accepted since creation (NCO phase)
     uint64_t stage_first = 0;               // absolute index of h_stage[0]
@@ -442,8 +443,8 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     if (!q->pipelined) q->nslots = 2;
     if ((rc = q->alloc(&q->d_njobs, MCRX_SLOTS))) return bail(rc);      // one counter per slot: a launch's placement kernel zeroes the next slot's
     if ((rc = q->alloc(&q->d_stats, 4))) return bail(rc);
-    if (hipHostMalloc((void **)&q->h_hint, 2 * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess) {
-        q->h_hint[0] = 0; q->h_hint[1] = 0;
+    if (hipHostMalloc((void **)&q->h_hint, 4 * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess) {
+        q->h_hint[0] = 0; q->h_hint[1] = 0; q->h_hint[2] = 0; q->h_hint[3] = 0;
         if (hipHostGetDevicePointer((void **)&q->d_hint, q->h_hint, 0) != hipSuccess) q->d_hint = nullptr;
     }
     if (q->scout) {
@@ -457,7 +458,7 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
         // speculative acquisition (lean path only): slots, their equalisers, the prediction lists
         const bool lean = q->sc.log2M >= 6 && q->sc.M == 64 * q->sc.E && q->sc.M_pilot <= 64;
         q->spec = lean && q->d_hint && getenv("MCRX_NO_SPEC") == nullptr;
-        if (getenv("MCRX_SCOUT_ROUNDS")) q->scout_rounds = std::max(1, std::min(8, atoi(getenv("MCRX_SCOUT_ROUNDS"))));
+        if (getenv("MCRX_SCOUT_ROUNDS")) { q->scout_rounds = std::max(1, std::min(8, atoi(getenv("MCRX_SCOUT_ROUNDS")))); q->rounds_fixed = true; }
         if (getenv("MCRX_NARROW_FIRST")) q->narrow_first = atoi(getenv("MCRX_NARROW_FIRST")) != 0;
         if (q->spec) {
             if ((rc = q->alloc(&q->d_spec, (size_t)q->nch * MCRX_SPEC_MAX))) return bail(rc);
@@ -598,7 +599,7 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     a.jR = q->d_jR[slot]; a.jsoft = q->d_jsoft[slot]; a.jtmp = q->d_jtmp[slot];
     a.stats = q->d_stats;
     a.hint = q->d_hint; a.enc_hint = (q->h_hint && q->d_hint) ? *(volatile uint32_t *)q->h_hint : 0u;
-    a.spec = q->d_spec; a.spec_R = q->d_spec_R; a.pred = nullptr; a.pred_n = nullptr; a.spec_cap = 0; a.spec_hint = nullptr;
+    a.spec = q->d_spec; a.spec_R = q->d_spec_R; a.pred = nullptr; a.pred_n = nullptr; a.spec_cap = 0; a.spec_hint = nullptr; a.walk_hint = nullptr;
     if (q->spec) {
         a.pred = q->d_pred; a.pred_n = q->d_pred_n; a.spec_hint = q->d_hint + 1;
         const uint32_t seen = ((volatile uint32_t *)q->h_hint)[1];         // largest prediction list so far (read without a sync)
@@ -625,10 +626,21 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
         // Round 0 is narrow: only the state the previous launch's scout stood in is speculated on (one wave per channel);
         // the cadence predictions carried over from the previous buffer are right only if no gap followed it, and after
         // the first adopted frame the scout re-anchors them anyway -- the full-width rounds run from there.
+        // Rounds: the narrow one and one full-width round serve a stream whose gaps fall between pushes.  A gap INSIDE a
+        // push leaves the frames behind it to the scouts' own walk; they say so in a host-mapped counter (read here without
+        // a sync, so a launch or two late), and while it moves a second full-width round re-anchors behind such gaps.  An
+        // idle full-width round is not free (~35 us: 512 x spec_cap waves that only find nothing to do), hence not by default.
+        int rounds = q->scout_rounds;
+        if (!q->rounds_fixed && q->h_hint && q->d_hint) {
+            const uint32_t w = ((volatile uint32_t *)q->h_hint)[2];
+            if (w != q->walk_seen) { q->walk_seen = w; q->extra_round_for = 16; }
+            if (q->extra_round_for > 0) { q->extra_round_for--; rounds++; }
+            a.walk_hint = q->d_hint + 2;
+        }
         const uint32_t cap = a.spec_cap;
-        for (int r = 0; r < q->scout_rounds; r++) {
-            a.stop_after_walk = (r + 1 < q->scout_rounds) ? 1 : 0;
-            a.spec_cap = (r == 0 && q->narrow_first && q->scout_rounds > 1 && cap > 1) ? 1u : cap;
+        for (int r = 0; r < rounds; r++) {
+            a.stop_after_walk = (r + 1 < rounds) ? 1 : 0;
+            a.spec_cap = (r == 0 && q->narrow_first && rounds > 1 && cap > 1) ? 1u : cap;
             HIPCHK(sync_launch_spec(a, sa));
             HIPCHK(sync_launch_lean(a, sa));
         }

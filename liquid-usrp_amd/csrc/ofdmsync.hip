@@ -1760,6 +1760,7 @@ struct Walker {
         void_reservation();
         publish_adopted();
         if (a.stats && l == 0) { if (nwalked) atomicAdd(a.stats, nwalked); if (nadopted) atomicAdd(a.stats + 1, nadopted); }
+        if (a.walk_hint && l == 0 && nwalked && MODE == SYM_LEAN) atomicAdd(a.walk_hint, nwalked);
         if (a.pred) {
             const int64_t period_seen = pred_last - pred_prev;
             if (nfresh >= 2 && period_seen > 0 && period_seen < (int64_t)0x7fffffff) s.period_hint = (uint32_t)period_seen;
@@ -1808,7 +1809,7 @@ __device__ __forceinline__ void launder(SyncArgs &a)
     LAUNDER(chan); LAUNDER(st); LAUNDER(hbits); LAUNDER(R); LAUNDER(soft); LAUNDER(tmpa); LAUNDER(tmpb);
     LAUNDER(syms); LAUNDER(rec); LAUNDER(arena); LAUNDER(sarena); LAUNDER(nrec); LAUNDER(arena_used);
     LAUNDER(jobs); LAUNDER(njobs); LAUNDER(jR); LAUNDER(jsoft); LAUNDER(jtmp);
-    LAUNDER(spec); LAUNDER(spec_R); LAUNDER(pred); LAUNDER(pred_n); LAUNDER(stats);
+    LAUNDER(spec); LAUNDER(spec_R); LAUNDER(pred); LAUNDER(pred_n); LAUNDER(stats); LAUNDER(walk_hint);
 }
 #undef LAUNDER
 
