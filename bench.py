@@ -36,6 +36,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the receiver handle uses four HIP streams beside the caller's; ROCm maps streams onto four hardware queues by default and a
+# shared queue makes the harvest's small copies wait behind long kernels: ask for eight (set before
+# the HIP runtime starts; a value the caller exported wins)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec); 6.29 TB/s measured for a float4 copy
 B_CHANNELIZER = 12.0           # algorithmic bytes / wideband sample: 8 read + 4 written (N of 2N bins)
