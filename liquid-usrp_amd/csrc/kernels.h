@@ -67,6 +67,8 @@ struct SyncConsts {
     const float2 *dft_tw;       // [M]  W_M^k
     CodingDev cod;
     uint32_t max_payload_len, max_enc_len, max_syms;
+    const uint32_t *crc_pos;    // [crc_pos_n][256]: CRC-32 contribution of byte value b at distance d from the end of the message (NULL: none)
+    uint32_t crc_pos_n;
     int payload_soft;
 };
 

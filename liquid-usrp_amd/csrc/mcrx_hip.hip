@@ -298,6 +298,21 @@ static int build_tables(mcrx_hip_t q)
     RC(q->upload(&c.dft_tw, tw.data(), od.M));
     RC(coding_tables(&c.cod));
     c.max_payload_len = q->max_payload; c.max_enc_len = q->max_enc; c.max_syms = q->max_syms;
+    // CRC-32 is linear once the 0xFFFFFFFF preset is folded into the first four message bytes: crc = ~ XOR_i T[n-1-i][m_i],
+    // T[0] = the byte table, T[d+1][b] = T[d][b] advanced through one zero byte.  With the table in HBM (1 KB per byte of
+    // the longest payload; L2 resident) the decoder's check is one batch of independent loads per thread and an XOR
+    // reduction instead of a chain of dependent operator look-ups down a tree.
+    c.crc_pos = nullptr; c.crc_pos_n = 0;
+    if (q->max_payload >= 4 && q->max_payload <= 8192) {
+        CodingTables *t = new CodingTables();
+        std::vector<uint32_t> pos((size_t)q->max_payload * 256);
+        for (unsigned b = 0; b < 256; b++) pos[b] = t->crc_byte[b];
+        for (size_t d = 1; d < q->max_payload; d++)
+            for (unsigned b = 0; b < 256; b++) { const uint32_t v = pos[(d - 1) * 256 + b]; pos[d * 256 + b] = (v >> 8) ^ t->crc_byte[v & 0xff]; }
+        delete t;
+        RC(q->upload(&c.crc_pos, pos.data(), pos.size()));
+        c.crc_pos_n = q->max_payload;
+    }
     c.payload_soft = q->cfg.payload_soft ? 1 : 0;
     return MCRX_OK;
 }

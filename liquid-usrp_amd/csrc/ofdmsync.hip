@@ -1804,7 +1804,7 @@ __device__ __forceinline__ void launder(SyncArgs &a)
 {
     LAUNDER(c.sctype); LAUNDER(c.S0); LAUNDER(c.S1); LAUNDER(c.s0t); LAUNDER(c.smk); LAUNDER(c.smn); LAUNDER(c.Pfit);
     LAUNDER(c.data_rank); LAUNDER(c.pilot_rank); LAUNDER(c.en_rank); LAUNDER(c.pilot_seq); LAUNDER(c.dft_tw);
-    LAUNDER(c.cod.crc_byte);
+    LAUNDER(c.cod.crc_byte); LAUNDER(c.crc_pos);
     LAUNDER(c.cod.crc_zadv); LAUNDER(c.cod.qam16_nb); LAUNDER(c.cod.qam64_nb);
     LAUNDER(chan); LAUNDER(st); LAUNDER(hbits); LAUNDER(R); LAUNDER(soft); LAUNDER(tmpa); LAUNDER(tmpb);
     LAUNDER(syms); LAUNDER(rec); LAUNDER(arena); LAUNDER(sarena); LAUNDER(nrec); LAUNDER(arena_used);
@@ -2276,6 +2276,18 @@ __global__ __launch_bounds__(DK_T) void decode_kernel(SyncArgs a, uint32_t lds_s
             const uint32_t *src = reinterpret_cast<const uint32_t *>(msg);
             for (uint32_t i = threadIdx.x; i < (n_msg + 3) / 4; i += DK_T) dst[i] = src[i];   // record space is padded to 16 bytes
         }
+        // CRC-32 by position (SyncConsts::crc_pos): every thread XORs the table entries of its bytes, the workgroup
+        // XOR-reduces -- one round of independent loads instead of the tree's six dependent operator look-ups
+        const bool by_pos = crc_len && c.crc_pos && n_msg >= 4 && n_msg <= c.crc_pos_n;
+        if (by_pos) {
+            uint32_t acc = 0;
+            for (uint32_t i = threadIdx.x; i < n_msg; i += DK_T) {
+                const uint32_t b = (uint32_t)msg[i] ^ (i < 4 ? 0xffu : 0u);
+                acc ^= c.crc_pos[(size_t)(n_msg - 1 - i) * 256 + b];
+            }
+            acc = wave_xor_u32(acc);
+            if ((threadIdx.x & (WV - 1)) == 0) reinterpret_cast<uint32_t *>(dk_soft)[256 + threadIdx.x / WV] = acc;      // (behind the byte table below)
+        }
         reinterpret_cast<uint32_t *>(dk_soft)[threadIdx.x] = c.cod.crc_byte[threadIdx.x];     // soft bits are spent: byte table in their place
         __syncthreads();
         if (threadIdx.x >= WV) return;
@@ -2285,7 +2297,14 @@ __global__ __launch_bounds__(DK_T) void decode_kernel(SyncArgs a, uint32_t lds_s
         const uint8_t *msg = reinterpret_cast<const uint8_t *>(dk_soft) + lds_soft_bytes;
         const uint32_t key = ((uint32_t)msg[n_msg] << 24) | ((uint32_t)msg[n_msg + 1] << 16) |
                              ((uint32_t)msg[n_msg + 2] << 8) | (uint32_t)msg[n_msg + 3];
-        valid = crc32_tree(c.cod, 0u, lds_soft_bytes, n_msg) == key;
+        const bool by_pos = c.crc_pos && n_msg >= 4 && n_msg <= c.crc_pos_n;
+        if (by_pos) {
+            const uint32_t *part = reinterpret_cast<const uint32_t *>(dk_soft) + 256;
+            uint32_t tot = 0;
+#pragma unroll
+            for (int wv = 0; wv < DK_T / WV; wv++) tot ^= part[wv];
+            valid = ~tot == key;
+        } else valid = crc32_tree(c.cod, 0u, lds_soft_bytes, n_msg) == key;
     }
     DK_TICK()
     Walker<1> w(a, ch);
