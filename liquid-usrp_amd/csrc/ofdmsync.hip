@@ -1903,6 +1903,7 @@ __global__ __launch_bounds__(WV) void payload_multi_kernel(SyncArgs a)
     launder(a);
     __shared__ float2 qpil[FR * 16];
     __shared__ uint32_t qps[64];
+    __shared__ uint32_t qnb16[16], qnb64[64];                           // the soft demodulator's nearest-neighbour tables: read on every QAM symbol's chain
     const SyncConsts &c = a.c;
     const int l = lane_id(), g = l / G, i = l % G;
     uint32_t nj = *a.njobs;
@@ -1915,6 +1916,8 @@ __global__ __launch_bounds__(WV) void payload_multi_kernel(SyncArgs a)
     const uint32_t ch = job->ch;
     active = active && ch < a.nch && job->arena_off != ~0ull;
     qps[l] = reinterpret_cast<const uint32_t *>(c.pilot_seq)[l];        // 256 bytes, one word per lane
+    qnb64[l] = reinterpret_cast<const uint32_t *>(c.cod.qam64_nb)[l];
+    if (l < 16) qnb16[l] = reinterpret_cast<const uint32_t *>(c.cod.qam16_nb)[l];
     wave_sync_lds();
     const uint8_t *pseq = reinterpret_cast<const uint8_t *>(qps);
 
@@ -2047,7 +2050,7 @@ __global__ __launch_bounds__(WV) void payload_multi_kernel(SyncArgs a)
             const uint32_t umod = (uint32_t)__builtin_amdgcn_readlane((int)mod, src), ubps = (uint32_t)__builtin_amdgcn_readlane((int)bps, src);
             const bool sel = live && mod == umod;
             pending &= ~__ballot(sel);
-            const uint8_t *unbt = umod == 27 ? c.cod.qam16_nb : c.cod.qam64_nb;
+            const uint8_t *unbt = reinterpret_cast<const uint8_t *>(umod == 27 ? qnb16 : qnb64);
 #pragma unroll
             for (int e = 0; e < E; e++) {
                 const uint32_t idx = psi + (uint32_t)dr[e];
