@@ -167,7 +167,8 @@ const char *mcrx_hip_last_error(void);
  *      (rate > 1: msresamp_crcf_create(2.0, 60), src/flexframe_tx.cc:170) -------------
  * Replaces msresamp_crcf_create(rate, As) / _execute / _destroy as the reference applications
  * call it in front of a synchronizer (src/flexframe_rx.cc:179,240,275; rate computed as in
- * src/multichannel_rx.cc:129-138).  Buffers are device pointers (cf32). */
+ * src/multichannel_rx.cc:129-138).  Buffers are device pointers (cf32).  `stream` is a hipStream_t; NULL = the legacy
+ * default stream (so a receiver handle fed next, which orders against that stream, sees the samples written). */
 typedef struct msresamp_hip_s *msresamp_hip_t;
 int    msresamp_hip_create(msresamp_hip_t *out, float rate, float As);
 int    msresamp_hip_destroy(msresamp_hip_t q);

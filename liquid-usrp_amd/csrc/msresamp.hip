@@ -261,7 +261,10 @@ extern "C" int msresamp_hip_execute_device(msresamp_hip_t q, const void *d_in, s
                                            size_t out_cap, size_t *nout, void *stream)
 {
     if (!q || !nout || (!d_in && nin) || !d_out) { g_rs_err = "null argument"; return MCRX_EINVAL; }
-    hipStream_t st = stream ? (hipStream_t)stream : q->stream;
+    // NULL = the legacy default stream, like the other stage operators: what a caller enqueues next -- on that stream or on a
+    // receiver handle's own (blocking) streams -- is ordered behind the resampler's kernels.  (A private stream here left
+    // msresamp -> multichannelrx chains on the default stream unordered: the bank could read samples not yet written.)
+    hipStream_t st = (hipStream_t)stream;
     *nout = 0;
     // the first stage reads [retained tail | the caller's new samples]; nothing is copied
     StageBuf &b0 = q->in[0];

@@ -1702,6 +1702,7 @@ struct Walker {
                 const int64_t key = spec_key(s.cur, s.timer);
                 if (s.timer == (uint32_t)L) { pred_prev = pred_last; pred_last = s.cur; nfresh++; }
                 entry = false;
+                if ((a.debug & 16) && l == 0 && ch == 0) printf("[spec] ch0 fresh state cur %lld timer %u (period hint %u, last fresh %lld, pred_n %u, pred[0..2] %lld %lld %lld)\n", (long long)s.cur, s.timer, s.period_hint, (long long)s.last_fresh, a.pred_n[ch], (long long)(a.pred[(size_t)ch * MCRX_SPEC_MAX] & 0xFFFFFFFFFFFFll), (long long)(a.pred[(size_t)ch * MCRX_SPEC_MAX + 1] & 0xFFFFFFFFFFFFll), (long long)(a.pred[(size_t)ch * MCRX_SPEC_MAX + 2] & 0xFFFFFFFFFFFFll));
                 if (a.spec_cap && adopt_speculative(key)) continue;
                 // nobody predicted this state.  In all but the last acquisition round the scout stops here instead of
                 // acquiring the frame itself: the next round's speculative waves start from this exact state and from
@@ -1760,11 +1761,12 @@ struct Walker {
         void_reservation();
         publish_adopted();
         if (a.stats && l == 0) { if (nwalked) atomicAdd(a.stats, nwalked); if (nadopted) atomicAdd(a.stats + 1, nadopted); }
-        if (a.walk_hint && l == 0 && nwalked && MODE == SYM_LEAN) atomicAdd(a.walk_hint, nwalked);
+        if (a.walk_hint && l == 0 && nwalked && !a.tail_only) atomicAdd(a.walk_hint, nwalked);     // (the lean scout, or the full kernel standing in for it at E >= 4)
         if (a.pred) {
             const int64_t period_seen = pred_last - pred_prev;
-            if (nfresh >= 2 && period_seen > 0 && period_seen < (int64_t)0x7fffffff) s.period_hint = (uint32_t)period_seen;
-            if (nfresh >= 1) s.last_fresh = pred_last;
+            const int64_t P_old = (int64_t)s.period_hint;            // a second hypothesis when the spacing just seen differs: the first frame
+            if (nfresh >= 2 && period_seen > 0 && period_seen < (int64_t)0x7fffffff) s.period_hint = (uint32_t)period_seen;     // behind a gap is timed from
+            if (nfresh >= 1) s.last_fresh = pred_last;               // an arbitrary detector phase and can sit a sample off the cadence of those behind it
             const int64_t P = (int64_t)s.period_hint;
             // predictions for the next speculative pass (the next round of this launch if the scout stopped, else the
             // next launch): the exact state the scout stands in, if it is SEEK, and the frame cadence continued from
@@ -1776,9 +1778,16 @@ struct Walker {
                 int64_t p = anchor + P;
                 if (p < s.cur) p += (s.cur - p + P - 1) / P * P;
                 const int64_t limit = stopped ? a.end : a.end + (a.end - a.buf_first);
-                for (; npred < MCRX_SPEC_MAX && p < limit; p += P) {
+                const bool two = P_old > 0 && P_old != P;
+                int64_t p2 = anchor + P_old;
+                if (two && p2 < s.cur) p2 += (s.cur - p2 + P_old - 1) / P_old * P_old;
+                for (; npred < MCRX_SPEC_MAX && p < limit; p += P, p2 += P_old) {
                     if (l == 0) a.pred[(size_t)ch * MCRX_SPEC_MAX + npred] = spec_key(p, (uint32_t)L);
                     npred++;
+                    if (two && p2 != p && p2 < limit && npred < MCRX_SPEC_MAX) {
+                        if (l == 0) a.pred[(size_t)ch * MCRX_SPEC_MAX + npred] = spec_key(p2, (uint32_t)L);
+                        npred++;
+                    }
                 }
             }
             if (l == 0) { a.pred_n[ch] = npred; if (a.spec_hint && npred > *a.spec_hint) *a.spec_hint = npred; }
