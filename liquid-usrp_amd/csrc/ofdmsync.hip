@@ -247,7 +247,7 @@ __device__ unsigned golay_dec_sym(unsigned r)
 // differences between states never exceed 6 x 510), and the traceback walks the blocks from the last to the first,
 // re-running each block's forward pass from its checkpoint into an LDS scratch of VIT_B decision words and then tracing
 // back through it: the same survivors as one pass with all decisions kept, at twice the add-compare-select work.
-#define VIT_B 1024u
+#define VIT_B 960u             /* steps per block: a multiple of 64 (traceback chunks own whole bytes) and of 6 (the lane layout's period) */
 struct VitSym {                 // the two soft symbols of a step: from soft bytes, or from packed hard bits (0 / 255)
     const uint8_t *p; bool hard;
     // symbols of step t0 + lane as sa | sb << 8 (steps >= T: anything); one load per 64 steps instead of two per step
@@ -259,31 +259,67 @@ struct VitSym {                 // the two soft symbols of a step: from soft byt
         return (((v >> (7 - (b & 7))) & 1u) ? 255u : 0u) | ((((v >> (6 - (b & 7))) & 1u) ? 255u : 0u) << 8);
     }
 };
-// forward pass over steps [t0, t1), t0 a multiple of 64: pm = this lane's path metric; decision words to `dec` (LDS) if not null
+// forward pass over steps [t0, t1), t0 a multiple of 64: pm = this lane's path metric; decision words to `dec` (LDS) if not null.
+// Lane layout: at time t the lane l holds the state rotl6(l, t mod 6).  A new state n = (p << 1 | b) & 63 is then stored in
+// the lane of one of its two predecessors p = (n >> 1) | (x << 5) and the other predecessor is the lane one bit away
+// (bit q = (6 - (t+1) mod 6) mod 6) -- so an add-compare-select step is ONE lane exchange (DPP / permlane) instead of two
+// LDS-crossbar permutes, which is what the step time was.  Metrics, tie rule and decisions are those of the natural layout.
+__device__ __forceinline__ unsigned rotl6(unsigned v, unsigned r) { return ((v << r) | (v >> (6u - r))) & 63u; }
+template <unsigned R1>             // one add-compare-select step whose (t + 1) mod 6 is R1
+__device__ __forceinline__ int vit_step(int pm, unsigned v, unsigned s, unsigned OA, unsigned OB, int bp32, bool &take1)
+{
+    constexpr unsigned q = R1 ? 6u - R1 : 0u;
+    const int sa = (int)(v & 0xffu), sb = (int)(v >> 8);
+    const bool oa = (OA >> R1) & 1u, ob = (OB >> R1) & 1u;
+    const int bm0 = (oa ? 255 - sa : sa) + (ob ? 255 - sb : sb);
+    int p0, p1;                                             // metrics of the predecessors with x = 0 / x = 1 (x = bit q of the lane index)
+    if constexpr (q >= 4) {                                 // v_permlane32_swap / v_permlane16_swap on two copies: lower partner, upper partner
+        p0 = pm; p1 = pm;
+        if constexpr (q == 5) asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(p0), "+v"(p1));
+        else                  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(p0), "+v"(p1));
+    } else {
+        int other;
+        if constexpr (q == 2) other = __builtin_bit_cast(int, xor4_dpp(__builtin_bit_cast(float, pm)));
+        else                  other = __builtin_bit_cast(int, xor_lane<(1 << q)>(__builtin_bit_cast(float, pm), bp32));
+        const bool xq = (s >> q) & 1u;
+        p0 = xq ? other : pm; p1 = xq ? pm : other;
+    }
+    const int m0 = p0 + bm0, m1 = p1 + (510 - bm0);
+    take1 = m1 < m0;
+    return take1 ? m1 : m0;
+}
 __device__ __forceinline__ int vit_forward(const VitSym &sy, unsigned t0, unsigned t1, unsigned T, int pm, unsigned long long *dec)
 {
-    const int s = lane_id();
-    const int p0 = s >> 1, p1 = (s >> 1) | 32;
-    const bool oa = __builtin_popcount((unsigned)s & 0x6d) & 1, ob = __builtin_popcount((unsigned)s & 0x4f) & 1;
-    for (unsigned tc = t0; tc < t1; tc += 64) {
-        const unsigned sy64 = sy.chunk(tc, T);
-        const unsigned cn = t1 - tc < 64 ? t1 - tc : 64;
-        for (unsigned k = 0; k < cn; k++) {
-            const unsigned v = (unsigned)__builtin_amdgcn_readlane((int)sy64, (int)k);
-            const int sa = (int)(v & 0xffu), sb = (int)(v >> 8);
-            const int bm0 = (oa ? 255 - sa : sa) + (ob ? 255 - sb : sb);
-            const int m0 = __shfl(pm, p0, WV) + bm0, m1 = __shfl(pm, p1, WV) + (510 - bm0);
-            const bool take1 = m1 < m0;
-            pm = take1 ? m1 : m0;
-            if (dec) { const unsigned long long w = __ballot(take1); if (s == 0) dec[tc - t0 + k] = w; }
+    const unsigned s = (unsigned)lane_id();
+    unsigned OA = 0, OB = 0;                                // bit r: output parities of the state this lane holds when (t+1) mod 6 = r
+#pragma unroll
+    for (unsigned r = 0; r < 6; r++) {
+        const unsigned n = rotl6(s, r);
+        OA |= (unsigned)(__builtin_popcount(n & 0x6d) & 1) << r; OB |= (unsigned)(__builtin_popcount(n & 0x4f) & 1) << r;
+    }
+    const int bp32 = lane_bperm32();
+    // chunks of 60 steps (t0 is a multiple of 6, so is every chunk start: the phases inside a chunk are compile-time)
+    for (unsigned tc = t0; tc < t1; tc += 60) {
+        const unsigned sy60 = sy.chunk(tc, T);
+        const unsigned cn = t1 - tc < 60 ? t1 - tc : 60;
+        for (unsigned k = 0; k < cn; k += 6) {
+#define VIT_STEP(R1, J)                                                                                        \
+            if (k + J < cn) {                                                                              \
+                bool tk;                                                                                   \
+                pm = vit_step<R1>(pm, (unsigned)__builtin_amdgcn_readlane((int)sy60, (int)(k + J)), s, OA, OB, bp32, tk); \
+                if (dec) { const unsigned long long w = __ballot(tk); if (s == 0) dec[tc - t0 + k + J] = w; } \
+            }
+            VIT_STEP(1, 0) VIT_STEP(2, 1) VIT_STEP(3, 2) VIT_STEP(4, 3) VIT_STEP(5, 4) VIT_STEP(0, 5)
+#undef VIT_STEP
         }
     }
     return pm;
 }
 // n decoded bytes from 2 (8 n + 6) symbols; `ckpt`: >= 128 * ceil(T / VIT_B) bytes of scratch in HBM; `lds`: VIT_B x 8 bytes
-__device__ void conv27_decode_wave(const VitSym sy, unsigned n, uint8_t *dec, uint16_t *ckpt, unsigned long long *lds)
+__device__ void conv27_decode_wave(const VitSym sy, unsigned n_, uint8_t *dec, uint16_t *ckpt, unsigned long long *lds)
 {
     const int s = lane_id();
+    const unsigned n = (unsigned)__builtin_amdgcn_readfirstlane((int)n_);    // wave-uniform: the step loops branch on the scalar unit
     const unsigned T = 8 * n + 6, nblk = (T + VIT_B - 1) / VIT_B;
     int pm = s ? (1 << 20) : 0;                             // the encoder starts in state 0
     for (unsigned b = 0; b < nblk; b++) {                   // checkpoints: normalised metrics at the start of every block
@@ -306,12 +342,15 @@ __device__ void conv27_decode_wave(const VitSym sy, unsigned n, uint8_t *dec, ui
             const unsigned c0 = (c1 - 1) & ~63u, cn = c1 - c0;
             const unsigned long long w = (unsigned)s < cn ? lds[c0 - t0 + s] : 0ull;
             unsigned long long bits = 0;                    // decoded bit of step c0 + k at bit k
+            unsigned r1 = (c0 + cn) % 6;                    // (t + 1) mod 6 of the chunk's last step
             for (unsigned k = cn; k-- > 0;) {
                 const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)w, (int)k);
                 const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(w >> 32), (int)k);
                 const unsigned long long wk = ((unsigned long long)hi << 32) | lo;
                 bits |= (unsigned long long)(state & 1u) << k;
-                state = (state >> 1) | ((unsigned)((wk >> state) & 1ull) << 5);
+                const unsigned ln = r1 ? rotl6(state, 6u - r1) : state;     // the lane that held this state after step c0 + k (see vit_forward)
+                state = (state >> 1) | ((unsigned)((wk >> ln) & 1ull) << 5);
+                r1 = r1 ? r1 - 1u : 5u;
             }
             // step t -> byte t / 8, bit 7 - t % 8 (steps >= 8 n are the tail): the first eight lanes take the chunk's bytes
             const unsigned by = (c0 >> 3) + (unsigned)s;
@@ -2610,7 +2649,7 @@ hipError_t sync_launch_payload(const SyncArgs &a0, int stage, hipStream_t st)
     }
     if (stage == 3) {                       // the frames on the general list (filled by decode_kernel)
         if (!fast) return hipSuccess;
-        hipLaunchKernelGGL(decode_general_kernel, dim3(nj < 256 ? nj : 256), dim3(WV), (size_t)VIT_B * 8, st, a);
+        hipLaunchKernelGGL(decode_general_kernel, dim3(nj < 4096 ? nj : 4096), dim3(WV), (size_t)VIT_B * 8, st, a);
         return hipGetLastError();
     }
     // M = 64 with the pilots inside one DPP row: payload_multi_kernel, MCRX_PAYLOAD_FR frames per wave (default 1;
