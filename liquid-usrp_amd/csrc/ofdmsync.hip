@@ -265,13 +265,14 @@ struct VitSym {                 // the two soft symbols of a step: from soft byt
 // (bit q = (6 - (t+1) mod 6) mod 6) -- so an add-compare-select step is ONE lane exchange (DPP / permlane) instead of two
 // LDS-crossbar permutes, which is what the step time was.  Metrics, tie rule and decisions are those of the natural layout.
 __device__ __forceinline__ unsigned rotl6(unsigned v, unsigned r) { return ((v << r) | (v >> (6u - r))) & 63u; }
-template <unsigned R1>             // one add-compare-select step whose (t + 1) mod 6 is R1
-__device__ __forceinline__ int vit_step(int pm, unsigned v, unsigned s, unsigned OA, unsigned OB, int bp32, bool &take1)
+// One add-compare-select step whose (t + 1) mod 6 is R1.  sa, sb: the step's soft symbols (wave-uniform), san = sa ^ 255,
+// sbn = sb ^ 255; ma, mb: 255 where this lane's state expects a 1 on the first / second output, else 0 -- so
+// sa ^ ma = |sa - expected| and the two candidates are two v_xad_u32 each.
+template <unsigned R1>
+__device__ __forceinline__ int vit_step(int pm, unsigned sa, unsigned sb, unsigned san, unsigned sbn, unsigned ma, unsigned mb,
+                                        unsigned s, int bp32, bool &take1)
 {
     constexpr unsigned q = R1 ? 6u - R1 : 0u;
-    const int sa = (int)(v & 0xffu), sb = (int)(v >> 8);
-    const bool oa = (OA >> R1) & 1u, ob = (OB >> R1) & 1u;
-    const int bm0 = (oa ? 255 - sa : sa) + (ob ? 255 - sb : sb);
     int p0, p1;                                             // metrics of the predecessors with x = 0 / x = 1 (x = bit q of the lane index)
     if constexpr (q >= 4) {                                 // v_permlane32_swap / v_permlane16_swap on two copies: lower partner, upper partner
         p0 = pm; p1 = pm;
@@ -284,34 +285,53 @@ __device__ __forceinline__ int vit_step(int pm, unsigned v, unsigned s, unsigned
         const bool xq = (s >> q) & 1u;
         p0 = xq ? other : pm; p1 = xq ? pm : other;
     }
-    const int m0 = p0 + bm0, m1 = p1 + (510 - bm0);
+    const int m0 = (int)(((unsigned)p0 + (sa ^ ma)) + (sb ^ mb));
+    const int m1 = (int)(((unsigned)p1 + (san ^ ma)) + (sbn ^ mb));     // = p1 + 510 - (branch metric of x = 0)
     take1 = m1 < m0;
     return take1 ? m1 : m0;
 }
+template <bool DEC>                // DEC: keep the decision words (lane k of a chunk: step tc + k) in `dec`
 __device__ __forceinline__ int vit_forward(const VitSym &sy, unsigned t0, unsigned t1, unsigned T, int pm, unsigned long long *dec)
 {
     const unsigned s = (unsigned)lane_id();
-    unsigned OA = 0, OB = 0;                                // bit r: output parities of the state this lane holds when (t+1) mod 6 = r
+    unsigned ma[6], mb[6];                                  // [r]: for the state this lane holds when (t + 1) mod 6 = r
 #pragma unroll
     for (unsigned r = 0; r < 6; r++) {
         const unsigned n = rotl6(s, r);
-        OA |= (unsigned)(__builtin_popcount(n & 0x6d) & 1) << r; OB |= (unsigned)(__builtin_popcount(n & 0x4f) & 1) << r;
+        ma[r] = (__builtin_popcount(n & 0x6d) & 1) ? 255u : 0u; mb[r] = (__builtin_popcount(n & 0x4f) & 1) ? 255u : 0u;
     }
     const int bp32 = lane_bperm32();
     // chunks of 60 steps (t0 is a multiple of 6, so is every chunk start: the phases inside a chunk are compile-time)
+    unsigned sy_next = sy.chunk(t0, T);
     for (unsigned tc = t0; tc < t1; tc += 60) {
-        const unsigned sy60 = sy.chunk(tc, T);
+        const unsigned sy60 = sy_next;
+        sy_next = sy.chunk(tc + 60, T);                     // (clamped to the last step inside) in flight while this chunk's 60 steps run
         const unsigned cn = t1 - tc < 60 ? t1 - tc : 60;
-        for (unsigned k = 0; k < cn; k += 6) {
+        int wlo = 0, whi = 0;                               // lane k: the decision word of step tc + k
+        // (a taken branch costs more than the step it guards: whole groups of six run unguarded, the last partial group apart)
 #define VIT_STEP(R1, J)                                                                                        \
-            if (k + J < cn) {                                                                              \
+            {                                                                                              \
+                const unsigned v = (unsigned)__builtin_amdgcn_readlane((int)sy60, (int)(k + J));           \
+                const unsigned sa = v & 0xffu, sb = v >> 8;                                                \
                 bool tk;                                                                                   \
-                pm = vit_step<R1>(pm, (unsigned)__builtin_amdgcn_readlane((int)sy60, (int)(k + J)), s, OA, OB, bp32, tk); \
-                if (dec) { const unsigned long long w = __ballot(tk); if (s == 0) dec[tc - t0 + k + J] = w; } \
+                pm = vit_step<R1>(pm, sa, sb, sa ^ 255u, sb ^ 255u, ma[R1], mb[R1], s, bp32, tk);          \
+                if constexpr (DEC) {                                                                       \
+                    const unsigned long long w = __ballot(tk);                                             \
+                    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(wlo) : "s"((int)(unsigned)w), "s"((int)(k + J)) : "m0");         \
+                    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(whi) : "s"((int)(unsigned)(w >> 32)), "s"((int)(k + J)) : "m0"); \
+                }                                                                                          \
             }
-            VIT_STEP(1, 0) VIT_STEP(2, 1) VIT_STEP(3, 2) VIT_STEP(4, 3) VIT_STEP(5, 4) VIT_STEP(0, 5)
-#undef VIT_STEP
+        unsigned k = 0;
+        for (; k + 6 <= cn; k += 6) { VIT_STEP(1, 0) VIT_STEP(2, 1) VIT_STEP(3, 2) VIT_STEP(4, 3) VIT_STEP(5, 4) VIT_STEP(0, 5) }
+        if (k < cn) {
+            VIT_STEP(1, 0)
+            if (k + 1 < cn) VIT_STEP(2, 1)
+            if (k + 2 < cn) VIT_STEP(3, 2)
+            if (k + 3 < cn) VIT_STEP(4, 3)
+            if (k + 4 < cn) VIT_STEP(5, 4)
         }
+#undef VIT_STEP
+        if (DEC && s < cn) dec[tc - t0 + s] = ((unsigned long long)(unsigned)whi << 32) | (unsigned)wlo;
     }
     return pm;
 }
@@ -329,37 +349,44 @@ __device__ void conv27_decode_wave(const VitSym sy, unsigned n_, uint8_t *dec, u
         pm -= mn; if (pm > 0xffff) pm = 0xffff;             // (only the unreachable states of the first steps saturate)
         ckpt[64 * b + s] = (uint16_t)pm;
         const unsigned t1 = (b + 1) * VIT_B < T ? (b + 1) * VIT_B : T;
-        pm = vit_forward(sy, b * VIT_B, t1, T, pm, nullptr);
+        pm = vit_forward<false>(sy, b * VIT_B, t1, T, pm, nullptr);
     }
     unsigned state = 0;                                     // the tail bits return the encoder to state 0
     for (unsigned b = nblk; b-- > 0;) {
         const unsigned t0 = b * VIT_B, t1 = t0 + VIT_B < T ? t0 + VIT_B : T;
-        (void)vit_forward(sy, t0, t1, T, (int)ckpt[64 * b + s], lds);
+        (void)vit_forward<true>(sy, t0, t1, T, (int)ckpt[64 * b + s], lds);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // trace back through the block in chunks of 64 steps (aligned: a chunk owns whole bytes of the message): lane k
         // holds the decision word of step c0 + k
         for (unsigned c1 = t1; c1 > t0;) {
             const unsigned c0 = (c1 - 1) & ~63u, cn = c1 - c0;
             const unsigned long long w = (unsigned)s < cn ? lds[c0 - t0 + s] : 0ull;
-            unsigned long long bits = 0;                    // decoded bit of step c0 + k at bit k
             unsigned r1 = (c0 + cn) % 6;                    // (t + 1) mod 6 of the chunk's last step
-            for (unsigned k = cn; k-- > 0;) {
-                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)w, (int)k);
-                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(w >> 32), (int)k);
-                const unsigned long long wk = ((unsigned long long)hi << 32) | lo;
-                bits |= (unsigned long long)(state & 1u) << k;
-                const unsigned ln = r1 ? rotl6(state, 6u - r1) : state;     // the lane that held this state after step c0 + k (see vit_forward)
-                state = (state >> 1) | ((unsigned)((wk >> ln) & 1ull) << 5);
-                r1 = r1 ? r1 - 1u : 5u;
+            const unsigned wlo = (unsigned)w, whi = (unsigned)(w >> 32);
+            // `state` before VIT_BACK(K) = the encoder state after step c0 + K: input bits of steps K, K-1 .. K-5 from bit 0 up.
+            // The lane that held it (see vit_forward) is its rotation right by r1 = the low six bits of (state * 65) >> r1.
+#define VIT_BACK(K)                                                                                            \
+            {                                                                                              \
+                const unsigned long long wk = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)whi, (int)(K)) << 32) | \
+                                              (unsigned)__builtin_amdgcn_readlane((int)wlo, (int)(K));      \
+                const unsigned ln = ((state * 65u) >> r1) & 63u;                                            \
+                state = (state >> 1) | ((unsigned)((wk >> ln) & 1ull) << 5);                               \
+                r1 = r1 ? r1 - 1u : 5u;                                                                    \
             }
-            // step t -> byte t / 8, bit 7 - t % 8 (steps >= 8 n are the tail): the first eight lanes take the chunk's bytes
+            unsigned k = cn;
+            while (k & 7u) { k--; VIT_BACK(k) }             // (the tail steps 8 n .. 8 n + 5: no message bits, and only the last chunk has them)
+            unsigned long long bytes = 0;                   // byte c0 / 8 + i of the message at bits 8 i ..
+            while (k) {                                     // eight steps = one byte (step t -> byte t / 8, bit 7 - t % 8), read off the state twice
+                k -= 8;
+                const unsigned s1 = state;                  // inputs of steps k+7 (bit 0) .. k+2 (bit 5)
+                VIT_BACK(k + 7) VIT_BACK(k + 6) VIT_BACK(k + 5) VIT_BACK(k + 4) VIT_BACK(k + 3) VIT_BACK(k + 2)
+                const unsigned s2 = state;                  // inputs of steps k+1 (bit 0), k (bit 1)
+                VIT_BACK(k + 1) VIT_BACK(k)
+                bytes |= (unsigned long long)(((s2 & 3u) << 6) | (s1 & 63u)) << k;
+            }
+#undef VIT_BACK
             const unsigned by = (c0 >> 3) + (unsigned)s;
-            if (s < 8 && by < n) {
-                unsigned v = 0;
-#pragma unroll
-                for (unsigned kb = 0; kb < 8; kb++) v |= (unsigned)((bits >> (8 * (unsigned)s + kb)) & 1ull) << (7 - kb);
-                dec[by] = (uint8_t)v;
-            }
+            if (s < 8 && by < n) dec[by] = (uint8_t)(bytes >> (8 * (unsigned)s));
             c1 = c0;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -428,8 +455,8 @@ __device__ bool packet_decode(const CodingDev cod, bool soft_mode, bool scramble
         if (!(ablate & 16)) for (unsigned i = (unsigned)l; i < e0; i += WV) tmpa[i] = (uint8_t)h128_dec_soft_fast(soft + 12 * (size_t)i);
         __syncthreads();
     } else if (soft_mode && fec1 == 11) {
-        deinterleave<true>(soft, e1, d1);
-        conv27_decode_wave(VitSym{ soft, false }, e0, tmpa, reinterpret_cast<uint16_t *>(tmpb), vit_lds);   // checkpoints: e0 + 128 bytes
+        if (!(ablate & 64)) deinterleave<true>(soft, e1, d1);
+        if (!(ablate & 128)) conv27_decode_wave(VitSym{ soft, false }, e0, tmpa, reinterpret_cast<uint16_t *>(tmpb), vit_lds);   // checkpoints: e0 + 128 bytes
         __syncthreads();
     } else {
         if (soft_mode) deinterleave<true>(soft, e1, d1);
@@ -2386,7 +2413,7 @@ __global__ __launch_bounds__(WV) void decode_general_kernel(SyncArgs a)
         const size_t tstride = (size_t)c.max_enc_len + 16;
         uint8_t *soft = a.jsoft + (size_t)j * 8 * c.max_enc_len;
         uint8_t *tmpa = a.jtmp + (size_t)j * 2 * tstride, *tmpb = tmpa + tstride;
-        const bool valid = packet_decode(c.cod, c.payload_soft != 0, false, n_msg, crc, fec0, fec1, soft, tmpa, tmpb, dk_soft);   // 8 KB of LDS: the Viterbi block scratch
+        const bool valid = packet_decode(c.cod, c.payload_soft != 0, false, n_msg, crc, fec0, fec1, soft, tmpa, tmpb, dk_soft, (unsigned)a.debug >> 8 << 6);   // 8 KB of LDS: the Viterbi block scratch; MCRX_DEBUG=256 / 512: profiling runs without the soft deinterleaver / the Viterbi decoder
         Walker<1> w(a, ch);
         const PayloadJob job = a.jobs[j];
         if (!w.bind_job(j, job)) continue;
