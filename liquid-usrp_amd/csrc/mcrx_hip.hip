@@ -174,7 +174,7 @@ struct mcrx_hip_s {
     uint32_t *h_hint = nullptr, *d_hint = nullptr;     // pinned, device-mapped: longest coded frame of the last launch
     uint8_t *d_jsoft[MCRX_SLOTS] = {}, *d_jtmp[MCRX_SLOTS] = {};
     bool scout = true; int scout_rounds = 2; bool narrow_first = true;
-    bool rounds_fixed = false; uint32_t walk_seen = 0; int extra_round_for = 0;     // adaptive third round, see launch_sync
+    bool rounds_fixed = false; uint32_t walk_seen = 0; int extra_round_for = 0, extra_len = 16; uint64_t extra_end = 0;     // adaptive third round, see launch_sync
     // streaming state
     uint64_t total_samples = 0;             // wideband samples accepted since creation (NCO phase)
     uint64_t stage_first = 0;               // absolute index of h_stage[0]
@@ -458,7 +458,9 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     if (!q->pipelined) q->nslots = 2;
     if ((rc = q->alloc(&q->d_njobs, MCRX_SLOTS))) return bail(rc);      // one counter per slot: a launch's placement kernel zeroes the next slot's
     if ((rc = q->alloc(&q->d_stats, 4))) return bail(rc);
-    if (hipHostMalloc((void **)&q->h_hint, 4 * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess) {
+    // (coherent: with hipHostMallocMapped alone the allocation is non-coherent and a free-running host -- one that never
+    //  synchronizes with the device -- does not see the kernels' updates at all)
+    if (hipHostMalloc((void **)&q->h_hint, 4 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
         q->h_hint[0] = 0; q->h_hint[1] = 0; q->h_hint[2] = 0; q->h_hint[3] = 0;
         if (hipHostGetDevicePointer((void **)&q->d_hint, q->h_hint, 0) != hipSuccess) q->d_hint = nullptr;
     }
@@ -621,6 +623,13 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
         a.spec_cap = seen < MCRX_SPEC_MAX ? seen : MCRX_SPEC_MAX;
     }
     hipStream_t sa = st, sw = st;
+    // The host never waits for the device on this path (slots are handed over by stream waits), so a free-running caller
+    // can be any number of launches ahead -- and the hints the kernels leave for the next launch (widest prediction list,
+    // scouts that had to walk) would arrive after everything is enqueued.  Bound the lead to the slots: wait here for the
+    // launch that last used this one (the device still has nslots - 1 launches queued behind it) -- once per turn of the
+    // slots, i.e. a lead of nslots .. 2 nslots - 1 launches: a wait per launch costs a short-slab stream (8 channels,
+    // 0.36 ms per push) 4 %.
+    if (q->pipelined && q->scout && q->spec && !q->rounds_fixed && q->seq >= q->nslots && slot == 0 && !getenv("MCRX_FREE_RUN")) HIPCHK(hipEventSynchronize(q->ev_done[slot]));
     if (q->pipelined && q->scout) {
         sa = q->s_scout; sw = q->s_work;
         HIPCHK(hipEventRecord(q->ev_ready[slot], st));
@@ -648,8 +657,14 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
         int rounds = q->scout_rounds;
         if (!q->rounds_fixed && q->h_hint && q->d_hint) {
             const uint32_t w = ((volatile uint32_t *)q->h_hint)[2];
-            if (w != q->walk_seen) { q->walk_seen = w; q->extra_round_for = 16; }
-            if (q->extra_round_for > 0) { q->extra_round_for--; rounds++; }
+            if (w != q->walk_seen) {
+                // walking again right after the extra rounds ran out = a stream that needs them all the time (e.g. behind a
+                // resampler whose delay times the first frame after every gap one sample off): twice as long every time
+                if (q->extra_round_for == 0) q->extra_len = (q->seq - q->extra_end < 32 && q->extra_len) ? std::min(2 * q->extra_len, 4096) : 16;
+                q->walk_seen = w; q->extra_round_for = q->extra_len;
+            }
+            if (q->extra_round_for > 0) { if (--q->extra_round_for == 0) q->extra_end = q->seq; rounds++; }
+            if (a.debug & 4) fprintf(stderr, "[host] launch %llu walk counter %u extra_round_for %d rounds %d\n", (unsigned long long)q->seq, w, q->extra_round_for, rounds);
             a.walk_hint = q->d_hint + 2;
         }
         const uint32_t cap = a.spec_cap;

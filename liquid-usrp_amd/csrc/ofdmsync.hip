@@ -890,7 +890,7 @@ struct Walker {
         idx = (uint32_t)__shfl((int)idx, 0, WV);
         off = (unsigned long long)__shfl((long long)off, 0, WV);
         soff = (unsigned long long)__shfl((long long)soff, 0, WV);
-        if ((a.debug & 16) && l == 0) printf("[emit] ch %u t_ev %lld payload %d valid %d placed %d idx %u off %llu len %u\n", ch, (long long)t_ev, (int)with_payload, (int)payload_valid, (int)(pre_off >= 0), idx, off, plen);
+        if ((a.debug & 16) && l == 0 && ch == 0) printf("[emit] ch %u t_ev %lld payload %d valid %d placed %d idx %u off %llu len %u\n", ch, (long long)t_ev, (int)with_payload, (int)payload_valid, (int)(pre_off >= 0), idx, off, plen);
         if (idx == 0xFFFFFFFFu) return;
         if (l == 0) {
             FrameRec r;
@@ -1827,7 +1827,7 @@ struct Walker {
         void_reservation();
         publish_adopted();
         if (a.stats && l == 0) { if (nwalked) atomicAdd(a.stats, nwalked); if (nadopted) atomicAdd(a.stats + 1, nadopted); }
-        if (a.walk_hint && l == 0 && nwalked && !a.tail_only) atomicAdd(a.walk_hint, nwalked);     // (the lean scout, or the full kernel standing in for it at E >= 4)
+        if (a.walk_hint && l == 0 && nwalked && !a.tail_only) atomicAdd_system(a.walk_hint, nwalked);     // (the lean scout, or the full kernel standing in for it at E >= 4)
         if (a.pred) {
             const int64_t period_seen = pred_last - pred_prev;
             const int64_t P_old = (int64_t)s.period_hint;            // a second hypothesis when the spacing just seen differs: the first frame
@@ -1857,7 +1857,7 @@ struct Walker {
                 }
             }
             if (l == 0) { a.pred_n[ch] = npred; if (a.spec_hint && npred > *a.spec_hint) *a.spec_hint = npred; }
-            if ((a.debug & 4) && l == 0 && ch == 0) printf("[spec] ch0 predictions %u adopted %u walked %u stopped %d spec_cap %u\n", npred, nadopted, nwalked, (int)stopped, a.spec_cap);
+            if ((a.debug & 4) && l == 0) printf("[spec] ch %u predictions %u adopted %u walked %u stopped %d spec_cap %u\n", ch, npred, nadopted, nwalked, (int)stopped, a.spec_cap);
         }
         // a header in progress continues in the next launch: its bits move from LDS to the channel's HBM slot
         if (fastp && s.state == SY_RX && s.fstate == FX_HEADER && s.header_symbol_index > 0)
