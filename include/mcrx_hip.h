@@ -105,7 +105,9 @@ unsigned mcrx_hip_num_channels(mcrx_hip_t q);
  * samples were all processed but the frame pool filled up and frames were dropped (mcrx_hip_frames_dropped). */
 int  mcrx_hip_execute_host(mcrx_hip_t q, const float *iq, size_t nsamples);
 /* same with the samples already in device memory; `stream` is a hipStream_t (NULL = default).
- * nsamples must be a multiple of 2*num_channels. */
+ * nsamples must be a multiple of 2*num_channels.  Asynchronous, with a bounded lead: the call returns when the work is
+ * enqueued, but waits first (once per turn of the handle's buffer sets) for the launch one turn back, so the host stays
+ * within 2 * MCRX_SLOTS launches of the device and the acquisition's feedback words reach the next launches. */
 int  mcrx_hip_execute_device(mcrx_hip_t q, const void *d_iq, size_t nsamples, void *stream);
 
 /* wait for all pushed samples, gather decoded frames (ordered by end time, then channel). */
