@@ -2,7 +2,7 @@
 """BASELINE configs[4]: 256-channel full-duplex multichanneltxrx (src/multichannel_txrx.cc) as a multi-GPU job.
 A secondary measurement -- bench.py holds the headline metric.
 
-    python bench_duplex.py [--gpus N --steps K --warmup W]         (N > 1: python -m torch.distributed.run ... like bench.py)
+    python bench_duplex.py [--gpus N --steps K --warmup W]         (N > 1 starts its own ranks, or runs under torch.distributed.run like bench.py)
 
 Per round every rank: channel-rate granules of its channel shard for every rank's sub-slab -> all-to-all -> synthesis
 bank + oscillator over its own sub-slab (sharding.TxPipeline) -> the same samples, still on the GPU that made them,
@@ -27,13 +27,17 @@ def main():
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--payload", type=int, default=1200)
     ap.add_argument("--sub-blocks", type=int, default=32768, help="blocks of 2N samples one rank synthesizes / channelizes per round")
+    ap.add_argument("--dry-run-launch", action="store_true", help="start the ranks, rendezvous under gloo, print one JSON line and exit (no GPU needed)")
     args = ap.parse_args()
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mcrx_launch", os.path.join(ROOT, "liquid-usrp_amd", "launch.py"))
+    launch = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(launch)
+    if args.dry_run_launch:
+        sys.exit(launch.dry_run(args.gpus))
+    rank, world, local = launch.ensure_ranks(args.gpus)         # --gpus N > 1 without a launcher: the ranks are started here
     import torch
     from __graft_entry__ import load_product
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus
     assert torch.cuda.is_available(), "needs a GPU: the HIP kernels are the only implementation"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)

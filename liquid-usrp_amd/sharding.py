@@ -84,8 +84,13 @@ class Pipeline(object):
         self.hist_elems = hist_tiles * self.cg * TILE
         self.rounds = 0
         self.tickets = [None] * nbuf
+        self.time_exchange = False                  # bench.py: HIP events around every exchange (exchange_ms)
+        self._xev = []
         if self.cuda:
             self.sA, self.sB, self.sC = (torch.cuda.Stream(device=device) for _ in range(3))
+            # the buffers above were zeroed on the current stream; round 0 relies on those zeros (no history copy yet)
+            for s in (self.sA, self.sB, self.sC):
+                s.wait_stream(torch.cuda.current_stream(device))
             self.evA = [torch.cuda.Event() for _ in range(nbuf)]
             self.evB = [torch.cuda.Event() for _ in range(nbuf)]
             self.evC = [torch.cuda.Event() for _ in range(nbuf)]
@@ -119,10 +124,16 @@ class Pipeline(object):
                 self.be.stream_wait(self.sB, launch=self.tickets[i])   # the synchronizers that last read recv[i]
                 self.sB.wait_event(self.evC[(i + 1) % nb])             # ... and the history copy that read its tail
             with torch.cuda.stream(self.sB):
+                if self.time_exchange:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(self.sB)
                 if self.world == 1:
                     new.copy_(out, non_blocking=True)
                 else:
                     exchange(out, new, self.world, self.dist)
+                if self.time_exchange:
+                    e1.record(self.sB)
+                    self._xev.append((e0, e1))
                 self.evB[i].record(self.sB)
         else:
             if self.world == 1:
@@ -144,6 +155,24 @@ class Pipeline(object):
                 recv[:self.hist_elems].copy_(self.recv[(c - 1) % nb][-self.hist_elems:])
             self.tickets[i] = self.be.sync(recv, first_chan, nsamp, stream=None)
         self.rounds += 1
+
+
+    def exchange_ms(self, reset=True):
+        """(total ms, rounds) of the exchanges timed since time_exchange was set: event pairs on the exchange stream, i.e.
+        the all-to-all as the device saw it (queueing behind the previous round's exchange excluded, waiting for a slow
+        peer included)."""
+        tot = 0.0
+        for e0, e1 in self._xev:
+            e1.synchronize()
+            tot += e0.elapsed_time(e1)
+        n = len(self._xev)
+        if reset:
+            self._xev = []
+        return tot, n
+
+    def bytes_sent_per_round(self):
+        """Bytes this rank's all-to-all sends to OTHER ranks in one round (4 B per wideband sample x (G-1)/G)."""
+        return self.tiles * self.cg * TILE * 8 * (self.world - 1)
 
 
 class TxPipeline(object):
@@ -179,6 +208,8 @@ class TxPipeline(object):
         self.rounds = 0
         if self.cuda:
             self.sA, self.sB, self.sC = (torch.cuda.Stream(device=device) for _ in range(3))
+            for s in (self.sA, self.sB, self.sC):               # the zeroed lead tiles above were written on the current stream
+                s.wait_stream(torch.cuda.current_stream(device))
             self.evA = [torch.cuda.Event() for _ in range(nbuf)]
             self.evB = [torch.cuda.Event() for _ in range(nbuf)]
             self.evC = [torch.cuda.Event() for _ in range(nbuf)]

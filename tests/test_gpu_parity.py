@@ -7,7 +7,11 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-REL = 1e-5
+REL = 1e-5          # the bar: max |gpu - oracle| relative to the largest |oracle| of the frame (full-scale relative)
+REL_ELEM = 4e-5     # reported beside it: element-wise |gpu - oracle| / |oracle| over every element above 1e-3 of full scale.
+                    # The two pipelines differ by float rounding of sums of full-scale terms (an M-point transform), so the
+                    # error of an element does not shrink with the element: inner QAM points (|s| = 0.32 against 1.34 for a
+                    # 16-QAM corner) and weak channelizer bins sit proportionally higher.  DESIGN.md section 4.5 has the numbers.
 
 
 def _torch():
@@ -18,6 +22,16 @@ def _torch():
 
 def relerr(a, b):
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30))
+
+
+def relerr_elem(a, b, floor=1e-3):
+    a, b = np.asarray(a), np.asarray(b)
+    mag = np.abs(b)
+    full = max(float(np.max(mag)), 1e-30)
+    return float(np.max(np.abs(a - b) / np.maximum(mag, floor * full)))
+
+
+WORST = {"max_norm": 0.0, "element_wise": 0.0}      # over the whole session (printed by the last test of this file)
 
 
 def match_frames(gpu_frames, ora_frames):
@@ -38,7 +52,7 @@ def match_frames(gpu_frames, ora_frames):
 
 def check_frames(gpu_frames, ora_frames, rel=REL):
     pairs = match_frames(gpu_frames, ora_frames)
-    worst = 0.0
+    worst = worst_e = 0.0
     for fg, fo in pairs:
         assert fg.header_valid == fo.header_valid and fg.payload_valid == fo.payload_valid
         assert fg.header == fo.header and fg.payload == fo.payload           # bit exact
@@ -46,9 +60,13 @@ def check_frames(gpu_frames, ora_frames, rel=REL):
         assert len(fg.framesyms) == len(fo.framesyms)
         if len(fo.framesyms):
             worst = max(worst, relerr(fg.framesyms, fo.framesyms))
+            worst_e = max(worst_e, relerr_elem(fg.framesyms, fo.framesyms))
         assert abs(fg.rssi - fo.rssi) < 1e-3 and abs(fg.cfo - fo.cfo) < 1e-6
         assert abs(fg.evm - fo.evm) < 0.05 or fo.evm < -60
     assert worst <= rel, worst
+    assert worst_e <= max(REL_ELEM, 4 * rel), (worst, worst_e)
+    WORST["max_norm"] = max(WORST["max_norm"], worst); WORST["element_wise"] = max(WORST["element_wise"], worst_e)
+    check_frames.last = (worst, worst_e)
     return worst
 
 
