@@ -117,7 +117,8 @@ int  mcrx_hip_flush(mcrx_hip_t q);
  * launches -- and marks what was pushed since for the next poll.  With one push + one poll per slab, slab k-1's
  * frames cross the host link while the GPU works on slab k. */
 int  mcrx_hip_poll(mcrx_hip_t q);
-/* as poll, but the frames are dropped on the device (no host wait, no copy): steady-state benchmarking */
+/* as poll, but the frames are dropped on the device (no host wait, no copy): steady-state benchmarking.  Dropped frames are
+ * never delivered by a later poll / flush. */
 int  mcrx_hip_discard(mcrx_hip_t q);
 /* make `stream` wait (on the device) for everything pushed so far, e.g. before a stage-level buffer is reused */
 int  mcrx_hip_stream_wait(mcrx_hip_t q, void *stream);

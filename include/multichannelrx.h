@@ -17,7 +17,8 @@
 
 class multichannelrx {
 public:
-    // num_channels >= 1 (2*num_channels a power of two <= 1024), M >= 8 subcarriers, cp_len >= 1,
+    // num_channels >= 1 (any count up to 1024; 2*num_channels a power of two <= 1024 takes the fast channelizer), M >= 8
+    // subcarriers (<= 1024), cp_len >= 1,
     // taper_len <= cp_len, p = subcarrier allocation or NULL, per-channel userdata / callbacks
     // (both arrays are copied).  Invalid arguments: message on stderr and `throw 0`, like the
     // reference (lib/multichannelrx.cc:54-66).

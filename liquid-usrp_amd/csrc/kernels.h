@@ -22,7 +22,6 @@ struct ChanArgs {
     uint32_t dtheta;            // NCO phase increment per sample
     uint32_t ntiles;            // tiles per group in `out`
     uint32_t cg;                // channels per group
-    uint32_t ablate;            // MCRX_ABLATE bit mask: skip phases (profiling experiments only)
 };
 int channelizer_supported(unsigned K);
 // blocks per workgroup slab such that the grid is a whole number of waves over `ncu` compute units

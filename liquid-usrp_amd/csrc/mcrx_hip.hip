@@ -152,7 +152,9 @@ struct mcrx_hip_s {
     // the other one) and copies it out once its last launch has finished -- the GPU keeps working meanwhile.
     FrameRec *d_rec[MCRX_GENS] = {}; uint8_t *d_arena[MCRX_GENS] = {}, *d_sarena[MCRX_GENS] = {};
     uint32_t *d_nrec[MCRX_GENS] = {}; unsigned long long *d_arena_used[MCRX_GENS] = {};
-    int gen = 0; bool gen_used[MCRX_GENS] = {}, gen_closed[MCRX_GENS] = {};
+    int gen = 0; bool gen_used[MCRX_GENS] = {}, gen_closed[MCRX_GENS] = {}, gen_abandoned[MCRX_GENS] = {};
+    int debug = 0, no_fast = 0; bool free_run = false;      // MCRX_DEBUG (trace bits), MCRX_NO_FAST, MCRX_FREE_RUN: read once, at creation
+    hipStream_t acq_stream = nullptr;        // the stream the last launch's acquisition / placement kernels ran on (they write the generation's counters)
     uint64_t gen_close_seq[MCRX_GENS] = {}, close_counter = 0;      // order in which generations were closed (= delivery order)
     hipEvent_t ev_gen[MCRX_GENS] = {};       // recorded behind the last launch that wrote into the generation
     uint64_t sarena_cap = 0;
@@ -353,7 +355,7 @@ static int restart_async(mcrx_hip_t q, hipStream_t st, bool from_zero)
         HIPCHK(sync_reset_launch(q->d_st, q->nch, q->chan_samples, g == 0 ? q->d_hist[0] : nullptr, g == 0 ? q->d_hist[1] : nullptr,
                                  (size_t)HIST_BLOCKS * q->K, q->d_nrec[g], q->d_arena_used[g],
                                  (from_zero && g == 0) ? q->d_pred_n : nullptr, st));
-        q->gen_used[g] = false; q->gen_closed[g] = false;
+        q->gen_used[g] = false; q->gen_closed[g] = false; q->gen_abandoned[g] = false;
     }
     q->gen = 0;
     RC(fork_from(q, st));
@@ -385,7 +387,10 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     else q->cfg.payload_soft = 1;
     q->max_payload = q->cfg.max_payload_len ? q->cfg.max_payload_len : 2048;
     q->max_enc = 4 * (q->max_payload + 4) + 16;
-    if (q->max_enc < 64) q->max_enc = 64;
+    // floor: the per-frame scratch rows (max_enc + 16 bytes) also hold the soft Viterbi decoder's checkpoints, 128 bytes
+    // per 960 trellis steps = 128 * ceil((8 e0 + 6) / 960) <= 0.54 max_enc + 128 bytes for a frame that fits (e0 <= max_enc / 2
+    // behind the rate-1/2 code): covered from max_enc = 256 on (smaller rows were overrun by 128 bytes)
+    if (q->max_enc < 256) q->max_enc = 256;
     q->max_enc = (q->max_enc + 15) & ~15u;
     q->max_syms = 8 * q->max_enc;
     q->ch_first = q->cfg.channel_first;
@@ -454,6 +459,9 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
         if (hipEventCreateWithFlags(&q->ev_gen[g], hipEventDisableTiming) != hipSuccess) return bail(fail(MCRX_EHIP, "hipEventCreate failed"));
     }
     q->scout = getenv("MCRX_NO_SCOUT") == nullptr;
+    q->debug = getenv("MCRX_DEBUG") ? atoi(getenv("MCRX_DEBUG")) : 0;
+    q->no_fast = getenv("MCRX_NO_FAST") ? atoi(getenv("MCRX_NO_FAST")) : 0;
+    q->free_run = getenv("MCRX_FREE_RUN") != nullptr;
     if (getenv("MCRX_SLOTS")) q->nslots = (unsigned)std::max(2, std::min(MCRX_SLOTS, atoi(getenv("MCRX_SLOTS"))));
     if (!q->pipelined) q->nslots = 2;
     if ((rc = q->alloc(&q->d_njobs, MCRX_SLOTS))) return bail(rc);      // one counter per slot: a launch's placement kernel zeroes the next slot's
@@ -526,9 +534,9 @@ extern "C" int mcrx_hip_destroy(mcrx_hip_t q)
 {
     if (!q) return MCRX_OK;
     (void)hipDeviceSynchronize();
-    if (getenv("MCRX_DEBUG") && (atoi(getenv("MCRX_DEBUG")) & 8))
+    if (q->debug & 8)
         fprintf(stderr, "mcrx bulk path: copy %.4f s, launch %.4f s, waiting for the GPU %.4f s, harvest (incl. that wait) %.4f s of which frame D2H %.4f s for %.1f MB, host arena growth %.4f s\n", q->t_copy, q->t_run, q->t_wait, q->t_harvest, q->t_d2h, q->b_d2h / 1e6, q->t_grow);
-    if (getenv("MCRX_DEBUG") && (atoi(getenv("MCRX_DEBUG")) & 32) && q->d_stats) {
+    if ((q->debug & 32) && q->d_stats) {
         uint32_t v[4] = {};
         (void)hipMemcpy(v, q->d_stats, sizeof(v), hipMemcpyDeviceToHost);
         fprintf(stderr, "mcrx stats: walked %u adopted %u last failed crc: key %08x computed %08x\n", v[0], v[1], v[2], v[3]);
@@ -586,7 +594,6 @@ static int launch_channelizer(mcrx_hip_t q, const float2 *x, size_t nblocks, uin
     a.slab_blocks = q->slab_blocks ? q->slab_blocks : channelizer_auto_slab(q->K, nblocks, q->ncu);
     a.first_sample_lo = (uint32_t)first_sample; a.dtheta = q->dtheta;
     a.ntiles = (uint32_t)ntiles_stride; a.cg = q->N / groups;
-    a.ablate = getenv("MCRX_ABLATE") ? (uint32_t)atoi(getenv("MCRX_ABLATE")) : 0u;
     RC(q->ev_begin(0, st));
     HIPCHK(channelizer_launch(q->K, a, st));
     RC(q->ev_end(0, st));
@@ -607,8 +614,7 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     a.syms = q->d_syms; a.rec = q->d_rec[g]; a.arena = q->d_arena[g]; a.sarena = q->d_sarena[g];
     a.nrec = q->d_nrec[g]; a.arena_used = q->d_arena_used[g];
     a.arena_cap = q->arena_cap; a.sarena_cap = q->sarena_cap; a.max_rec = q->max_rec;
-    a.debug = getenv("MCRX_DEBUG") ? atoi(getenv("MCRX_DEBUG")) : 0;
-    a.no_fast = getenv("MCRX_NO_FAST") ? atoi(getenv("MCRX_NO_FAST")) : 0;
+    a.debug = q->debug; a.no_fast = q->no_fast;
     a.vit_off = 0;
     a.scout = q->scout ? 1 : 0;
     a.jobs = q->d_jobs[slot]; a.njobs = q->d_njobs + slot; a.njobs_next = q->d_njobs + next; a.max_jobs = q->max_rec;
@@ -629,7 +635,7 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     // launch that last used this one (the device still has nslots - 1 launches queued behind it) -- once per turn of the
     // slots, i.e. a lead of nslots .. 2 nslots - 1 launches: a wait per launch costs a short-slab stream (8 channels,
     // 0.36 ms per push) 4 %.
-    if (q->pipelined && q->scout && q->spec && !q->rounds_fixed && q->seq >= q->nslots && slot == 0 && !getenv("MCRX_FREE_RUN")) HIPCHK(hipEventSynchronize(q->ev_done[slot]));
+    if (q->pipelined && q->scout && q->spec && !q->rounds_fixed && q->seq >= q->nslots && slot == 0 && !q->free_run) HIPCHK(hipEventSynchronize(q->ev_done[slot]));
     if (q->pipelined && q->scout) {
         sa = q->s_scout; sw = q->s_work;
         HIPCHK(hipEventRecord(q->ev_ready[slot], st));
@@ -637,6 +643,7 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
         if (q->seq + 1 >= q->nslots) HIPCHK(hipStreamWaitEvent(sa, q->ev_done[next], 0));     // launch seq + 1 - nslots
     }
     if (!q->scout) HIPCHK(hipMemsetAsync(a.njobs, 0, sizeof(uint32_t), sa));     // (with the scout, the previous launch's placement kernel zeroed it)
+    q->acq_stream = sa;
     RC(q->ev_begin(1, sa));
     a.stop_after_walk = 0; a.tail_only = 0; a.defer_limit = (int64_t)q->defer;
     if (q->spec) {
@@ -1018,6 +1025,13 @@ static int collect(mcrx_hip_t q, int g)
     HIPCHK(hipEventSynchronize(q->ev_gen[g]));
     q->t_wait += now_s() - t0;
     uint32_t cnt[2] = { 0, 0 }; unsigned long long used[2] = { 0, 0 };
+    if (q->gen_abandoned[g]) {              // dropped by mcrx_hip_discard: never delivered, only cleaned
+        HIPCHK(hipMemsetAsync(q->d_nrec[g], 0, 2 * sizeof(uint32_t), q->s_copy));
+        HIPCHK(hipMemsetAsync(q->d_arena_used[g], 0, 2 * sizeof(unsigned long long), q->s_copy));
+        HIPCHK(hipStreamSynchronize(q->s_copy));
+        q->gen_closed[g] = false; q->gen_used[g] = false; q->gen_abandoned[g] = false;
+        return MCRX_OK;
+    }
     HIPCHK(hipMemcpyAsync(cnt, q->d_nrec[g], sizeof(cnt), hipMemcpyDeviceToHost, q->s_copy));
     HIPCHK(hipMemcpyAsync(used, q->d_arena_used[g], sizeof(used), hipMemcpyDeviceToHost, q->s_copy));
     HIPCHK(hipStreamSynchronize(q->s_copy));
@@ -1121,12 +1135,16 @@ extern "C" int mcrx_hip_discard(mcrx_hip_t q)
         HIPCHK(hipMemsetAsync(q->d_nrec[next], 0, 2 * sizeof(uint32_t), q->s_copy));
         HIPCHK(hipMemsetAsync(q->d_arena_used[next], 0, 2 * sizeof(unsigned long long), q->s_copy));
         HIPCHK(hipEventRecord(q->ev_gen[next], q->s_copy));
-        // the next launches into that generation start behind the zeroing
+        // the next launches into that generation start behind the zeroing: on the stream the acquisition kernels (which
+        // place records and advance these counters) were last launched on -- the caller's own stream on a serial handle
+        // driven through execute_device(stream), the handle's otherwise -- and on the handle's default ones as well
         hipStream_t sa = (q->pipelined && q->scout) ? q->s_scout : q->stream;
         HIPCHK(hipStreamWaitEvent(sa, q->ev_gen[next], 0));
-        q->gen_closed[next] = false; q->gen_used[next] = false;
+        if (q->acq_stream && q->acq_stream != sa) HIPCHK(hipStreamWaitEvent(q->acq_stream, q->ev_gen[next], 0));
+        q->gen_closed[next] = false; q->gen_used[next] = false; q->gen_abandoned[next] = false;
     }
-    q->gen_closed[g] = true; q->gen_close_seq[g] = ++q->close_counter;      // abandoned (a later flush would still deliver it)
+    // abandoned: a later poll / flush cleans it without delivering anything
+    q->gen_closed[g] = true; q->gen_abandoned[g] = true; q->gen_close_seq[g] = ++q->close_counter;
     q->gen = next;
     q->pending_bound = 0;
     return MCRX_OK;

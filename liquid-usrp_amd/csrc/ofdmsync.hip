@@ -30,6 +30,13 @@ namespace mcrx {
 #define SY_PROFILE 0        /* 1: MCRX_DEBUG=2 cycle counters per event / phase (they cost ~40 registers in the scout) */
 #endif
 #define SY_PROF(a) (SY_PROFILE && ((a).debug & 2) != 0)
+// Phase-skipping switches (profiling ablations: MCRX_DEBUG=256 / 512 run the general decoder without the soft de-interleaver /
+// the Viterbi decoder) exist in development builds only (-DMCRX_DEVEL); the release library cannot be told to skip work.
+#ifdef MCRX_DEVEL
+#define MCRX_DEVEL_ABLATE(a) ((unsigned)(a).debug >> 8 << 6)
+#else
+#define MCRX_DEVEL_ABLATE(a) 0u
+#endif
 #define TWO_PI_F 6.283185307179586f
 #define PI_F 3.14159265358979323846f
 
@@ -456,7 +463,7 @@ __device__ bool packet_decode(const CodingDev cod, bool soft_mode, bool scramble
         __syncthreads();
     } else if (soft_mode && fec1 == 11) {
         if (!(ablate & 64)) deinterleave<true>(soft, e1, d1);
-        if (!(ablate & 128)) conv27_decode_wave(VitSym{ soft, false }, e0, tmpa, reinterpret_cast<uint16_t *>(tmpb), vit_lds);   // checkpoints: e0 + 128 bytes
+        if (!(ablate & 128)) conv27_decode_wave(VitSym{ soft, false }, e0, tmpa, reinterpret_cast<uint16_t *>(tmpb), vit_lds);   // checkpoints: 128 * ceil((8 e0 + 6) / 960) bytes <= max_enc_len + 16 (mcrx_hip_create keeps max_enc_len >= 256)
         __syncthreads();
     } else {
         if (soft_mode) deinterleave<true>(soft, e1, d1);
@@ -2413,7 +2420,7 @@ __global__ __launch_bounds__(WV) void decode_general_kernel(SyncArgs a)
         const size_t tstride = (size_t)c.max_enc_len + 16;
         uint8_t *soft = a.jsoft + (size_t)j * 8 * c.max_enc_len;
         uint8_t *tmpa = a.jtmp + (size_t)j * 2 * tstride, *tmpb = tmpa + tstride;
-        const bool valid = packet_decode(c.cod, c.payload_soft != 0, false, n_msg, crc, fec0, fec1, soft, tmpa, tmpb, dk_soft, (unsigned)a.debug >> 8 << 6);   // 8 KB of LDS: the Viterbi block scratch; MCRX_DEBUG=256 / 512: profiling runs without the soft deinterleaver / the Viterbi decoder
+        const bool valid = packet_decode(c.cod, c.payload_soft != 0, false, n_msg, crc, fec0, fec1, soft, tmpa, tmpb, dk_soft, MCRX_DEVEL_ABLATE(a));   // 8 KB of LDS: the Viterbi block scratch
         Walker<1> w(a, ch);
         const PayloadJob job = a.jobs[j];
         if (!w.bind_job(j, job)) continue;

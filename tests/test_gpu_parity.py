@@ -445,6 +445,25 @@ def test_convolutional_code_on_the_serial_paths(oracle, product, M, cp, step_blo
     rx.close()
 
 
+def test_convolutional_code_on_a_handle_sized_for_tiny_payloads(oracle, product):
+    """with max_payload_len < 20 the per-frame scratch rows were shorter than the 128 bytes of Viterbi
+    checkpoints a soft-decoded K = 7 frame writes into them.  Many short frames per channel (rows next to each other are
+    in use at the same time), every payload against the oracle."""
+    N, M, cp, plen = 8, 64, 8, 8
+    iq, sent = oracle.synth_traffic(N, M, cp, 4, 12, payload_len=plen, fec1=oracle.FEC_CONV_V27, seed=21)
+    x = iq[:len(iq) // (16 * N) * (16 * N)]
+    ora = oracle.MultiChannelRx(N, M, cp, 4)
+    ora.execute(x)
+    assert len(ora.frames) == 12 * N and all(f.payload_valid for f in ora.frames)
+    for soft in (1, 0):
+        rx = product.multichannelrx(N, M, cp, 4, max_payload_len=plen, payload_soft=soft)
+        rx.Execute(x); rx.Flush()
+        assert len(rx.frames) == 12 * N
+        for f in rx.frames:
+            assert f.payload_valid and sent[f.channel][(f.header[0] << 8) | f.header[1]] == (f.header, f.payload)
+        rx.close()
+
+
 def test_speculation_survives_wrong_predictions(oracle, product):
     """The scout's frame-level speculation predicts where frames start from the previous launch.  Feed it a
     stream whose frame length changes (predictions from the first half are wrong for the second), in pieces,
