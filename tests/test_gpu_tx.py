@@ -51,7 +51,7 @@ def test_gpu_tx_waveform_matches_oracle(oracle, product, N, M, cp, mod, fec1, pl
     print("GPU multichanneltx vs oracle, N=%d M=%d: %d blocks, max-norm rel err %.3g, rms rel err %.3g" % (N, M, nb, err, rms))
     for c in range(N):                                      # traffic recipe: pid, channel id in the header
         for f, (h, p) in enumerate(sent[c]):
-            assert h[0] == (f >> 8) and h[1] == (f & 0xff) and h[2] == c and len(p) == plen
+            assert h[0] == (f >> 8) and h[1] == (f & 0xff) and h[2] == (c & 0xff) and len(p) == plen      # (the channel id is one header byte, src/multichannel_tx.cc:175)
     tx.close()
 
 
