@@ -214,6 +214,15 @@ size_t mctx_hip_blocks_for(mctx_hip_t q, unsigned frames_per_channel, unsigned p
 int    mctx_hip_generate(mctx_hip_t q, void *d_iq, size_t nblocks, unsigned frames_per_channel,
                          unsigned payload_len, int mod, int fec0, int fec1, float gain, uint32_t seed,
                          uint8_t *hdr, uint8_t *pay, void *stream);
+/* Ragged traffic, the kind src/multichannel_txrx.cc:227-267 sends (every packet `rand() % payload_len` bytes, handed to
+ * whichever channel is free): per channel, seeded, frames of len_lo .. len_hi payload bytes, 0 .. gap_max idle OFDM symbols
+ * before each, with probability 1 / long_every (0: never) a silence of 16 .. 16 + long_max symbols instead; placed until the
+ * stream is full.  Host outputs (may be NULL), sized for max_frames per channel: count[ch], hdr[ch][f][8], len[ch][f],
+ * pay[ch][f][len_hi], start[ch][f] = block index of the frame's first sample. */
+int    mctx_hip_generate_ragged(mctx_hip_t q, void *d_iq, size_t nblocks, unsigned max_frames, unsigned len_lo, unsigned len_hi,
+                                unsigned gap_max, unsigned long_every, unsigned long_max, int mod, int fec0, int fec1,
+                                float gain, uint32_t seed, uint32_t *count, uint8_t *hdr, uint32_t *len, uint8_t *pay,
+                                uint64_t *start, void *stream);
 /* Sharded form (the transmit side of src/multichannel_txrx.cc over several GPUs; mirror image of the receiver's
  * stage interface): frame generators are channel-sharded (multichanneltx.cc:230-242 steps N independent
  * ofdmflexframegen objects), the synthesis bank + oscillator (multichanneltx.cc:192-227) time-sharded.

@@ -96,6 +96,9 @@ _EXPORTS = {
     "mctx_hip_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_void_p]),
     "mctx_hip_destroy": (C.c_int, [C.c_void_p]),
     "mctx_hip_blocks_for": (C.c_size_t, [C.c_void_p, C.c_uint, C.c_uint, C.c_int, C.c_int, C.c_int]),
+    "mctx_hip_generate_ragged": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint,
+                                           C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p]),
     "mctx_hip_generate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint, C.c_uint, C.c_int, C.c_int, C.c_int,
                                     C.c_float, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mctx_hip_traffic_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_int, C.c_int,
@@ -455,7 +458,7 @@ class multichanneltx(object):
 
     def __init__(self, num_channels, M, cp_len, taper_len, p=None, max_payload_len=2048):
         self._h = C.c_void_p()
-        self.N, self.K = num_channels, 2 * num_channels
+        self.N, self.K, self.M, self.cp = num_channels, 2 * num_channels, M, cp_len
         self.max_payload_len, self._stream_max = max_payload_len, -1
         parr = None if p is None else np.ascontiguousarray(np.frombuffer(bytes(bytearray(p)), np.uint8))
         rc = lib().mctx_hip_create(C.byref(self._h), num_channels, M, cp_len, taper_len,
@@ -488,6 +491,30 @@ class multichanneltx(object):
         sent = [[(bytes(hdr[c, f]), bytes(pay[c, f, :payload_len])) for f in range(frames_per_channel)]
                 for c in range(self.N)]
         return iq, sent
+
+    def generate_ragged(self, nblocks, len_lo=64, len_hi=1200, gap_max=3, long_every=8, long_max=184, mod=LIQUID_MODEM_QPSK,
+                        fec0=LIQUID_FEC_NONE, fec1=LIQUID_FEC_HAMMING128, gain=None, seed=0xC0FFEE, device=None):
+        """Ragged traffic (src/multichannel_txrx.cc:227-267): frames of len_lo .. len_hi bytes after 0 .. gap_max idle symbols,
+        a longer silence (16 .. 16 + long_max symbols) once in long_every frames, until `nblocks` blocks are full.
+        -> (iq, sent, starts): sent[ch] = [(header, payload)], starts[ch] = [block index of each frame's first sample]."""
+        import torch
+        nb = (int(nblocks) + 7) // 8 * 8
+        L = self.M + self.cp
+        shortest = int(lib().mctx_hip_blocks_for(self._h, 1, len_lo, mod, fec0, fec1)) - 64
+        maxf = nb // max(shortest, L) + 2
+        iq = torch.empty(nb * self.K, dtype=torch.complex64, device=device or "cuda")
+        cnt = np.zeros(self.N, np.uint32); hdr = np.zeros((self.N, maxf, 8), np.uint8); ln = np.zeros((self.N, maxf), np.uint32)
+        pay = np.zeros((self.N, maxf, max(len_hi, 1)), np.uint8); start = np.zeros((self.N, maxf), np.uint64)
+        g = (1.0 / self.N) if gain is None else gain
+        stream = torch.cuda.current_stream(iq.device)
+        rc = lib().mctx_hip_generate_ragged(self._h, _dptr(iq), nb, maxf, len_lo, len_hi, gap_max, long_every, long_max, mod, fec0, fec1,
+                                            g, seed & 0xFFFFFFFF, cnt.ctypes.data, hdr.ctypes.data, ln.ctypes.data, pay.ctypes.data,
+                                            start.ctypes.data, _stream_ptr(stream))
+        if rc != MCRX_OK:
+            raise McrxError("mctx_hip_generate_ragged failed (%d): %s" % (rc, lib().mctx_hip_last_error().decode()))
+        sent = [[(bytes(hdr[c, f]), bytes(pay[c, f, :ln[c, f]])) for f in range(int(cnt[c]))] for c in range(self.N)]
+        starts = [[int(start[c, f]) for f in range(int(cnt[c]))] for c in range(self.N)]
+        return iq, sent, starts
 
     # ---- sharded form: channel-sharded frame generators, time-sharded synthesis bank (see sharding.TxPipeline)
     def traffic(self, channel_first, channel_count, frames_per_channel, payload_len, mod=LIQUID_MODEM_QPSK,

@@ -158,6 +158,7 @@ struct SyncArgs {
     uint8_t *jsoft;             // [max_jobs][8*max_enc_len]
     uint8_t *jtmp;              // [max_jobs][2*(max_enc_len+16)]
     int debug;                 // MCRX_DEBUG=1: trace state-machine events of channel 0
+    int seek_burst;            // idle stretches: SEEK events four at a time, their windows requested together (Walker::seek_burst)
     // speculation (see SpecSlot)
     SpecSlot *spec; float2 *spec_R;      // [nch][MCRX_SPEC_MAX], [nch][MCRX_SPEC_MAX][M]
     int64_t *pred; uint32_t *pred_n;     // predicted fresh-state positions for the next launch: [nch][MCRX_SPEC_MAX], [nch]
@@ -182,6 +183,7 @@ struct SyncArgs {
 };
 hipError_t sync_launch(const SyncArgs &a, hipStream_t st);           // full state machine, one wave per channel (general configurations; tail kernel)
 hipError_t sync_launch_tail(const SyncArgs &a, hipStream_t st);      // lean configurations: payloads in progress, to the frame's end (a.tail_only = 1)
+hipError_t sync_launch_walk(const SyncArgs &a, hipStream_t st);      // the lean scout built without a register budget: for streams it has to walk by itself
 hipError_t sync_launch_lean(const SyncArgs &a, hipStream_t st);      // lean scout: acquisition + header + hand-off, one wave per channel
 hipError_t sync_launch_spec(const SyncArgs &a, hipStream_t st);      // speculative acquisition: one wave per (channel, predicted position)
 // stage 0: record placement (one workgroup), 1: payload workers (one wave per handed-off frame),

@@ -153,7 +153,7 @@ struct mcrx_hip_s {
     FrameRec *d_rec[MCRX_GENS] = {}; uint8_t *d_arena[MCRX_GENS] = {}, *d_sarena[MCRX_GENS] = {};
     uint32_t *d_nrec[MCRX_GENS] = {}; unsigned long long *d_arena_used[MCRX_GENS] = {};
     int gen = 0; bool gen_used[MCRX_GENS] = {}, gen_closed[MCRX_GENS] = {}, gen_abandoned[MCRX_GENS] = {};
-    int debug = 0, no_fast = 0; bool free_run = false;      // MCRX_DEBUG (trace bits), MCRX_NO_FAST, MCRX_FREE_RUN: read once, at creation
+    int debug = 0, no_fast = 0, seek_burst = 1, acq_mode = 0; bool free_run = false;      // MCRX_DEBUG (trace bits), MCRX_NO_FAST, MCRX_FREE_RUN: read once, at creation
     hipStream_t acq_stream = nullptr;        // the stream the last launch's acquisition / placement kernels ran on (they write the generation's counters)
     uint64_t gen_close_seq[MCRX_GENS] = {}, close_counter = 0;      // order in which generations were closed (= delivery order)
     hipEvent_t ev_gen[MCRX_GENS] = {};       // recorded behind the last launch that wrote into the generation
@@ -169,6 +169,7 @@ struct mcrx_hip_s {
     // k's payload/decode kernels, and launch k+1's channelizer as soon as CUs free up.
     bool pipelined = true;
     hipStream_t s_scout = nullptr, s_work = nullptr, s_copy = nullptr;
+
     hipEvent_t ev_ready[MCRX_SLOTS] = {}, ev_scout[MCRX_SLOTS] = {}, ev_done[MCRX_SLOTS] = {}, ev_in = nullptr, ev_consumed = nullptr, ev_tmp[3] = {};
     int last_slot = -1; size_t last_ntiles = 0;     // where the synchronizer history (tail of the previous launch) sits
     SpecSlot *d_spec = nullptr; float2 *d_spec_R = nullptr; int64_t *d_pred = nullptr; uint32_t *d_pred_n = nullptr;
@@ -177,6 +178,9 @@ struct mcrx_hip_s {
     uint8_t *d_jsoft[MCRX_SLOTS] = {}, *d_jtmp[MCRX_SLOTS] = {};
     bool scout = true; int scout_rounds = 2; bool narrow_first = true;
     bool rounds_fixed = false; uint32_t walk_seen = 0; int extra_round_for = 0, extra_len = 16; uint64_t extra_end = 0;     // adaptive third round, see launch_sync
+    // speculation pays only where frame positions can be predicted: the host compares what the scouts had to walk with what
+    // they adopted (host-mapped counters) and switches the speculative rounds off while walking dominates (launch_sync)
+    uint32_t pol_walk = 0, pol_adopt = 0, pol_same = 0, pol_fresh = 0; int pol_count = 0, pol_bad = 0; bool spec_adaptive = true, walk_mode = false;
     // streaming state
     uint64_t total_samples = 0;             // wideband samples accepted since creation (NCO phase)
     uint64_t stage_first = 0;               // absolute index of h_stage[0]
@@ -462,14 +466,16 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     q->debug = getenv("MCRX_DEBUG") ? atoi(getenv("MCRX_DEBUG")) : 0;
     q->no_fast = getenv("MCRX_NO_FAST") ? atoi(getenv("MCRX_NO_FAST")) : 0;
     q->free_run = getenv("MCRX_FREE_RUN") != nullptr;
+    if (getenv("MCRX_SEEK_BURST")) q->seek_burst = atoi(getenv("MCRX_SEEK_BURST"));
+    if (getenv("MCRX_ACQ_MODE")) q->acq_mode = atoi(getenv("MCRX_ACQ_MODE"));
     if (getenv("MCRX_SLOTS")) q->nslots = (unsigned)std::max(2, std::min(MCRX_SLOTS, atoi(getenv("MCRX_SLOTS"))));
     if (!q->pipelined) q->nslots = 2;
     if ((rc = q->alloc(&q->d_njobs, MCRX_SLOTS))) return bail(rc);      // one counter per slot: a launch's placement kernel zeroes the next slot's
-    if ((rc = q->alloc(&q->d_stats, 4))) return bail(rc);
+    if ((rc = q->alloc(&q->d_stats, 8))) return bail(rc);
     // (coherent: with hipHostMallocMapped alone the allocation is non-coherent and a free-running host -- one that never
     //  synchronizes with the device -- does not see the kernels' updates at all)
-    if (hipHostMalloc((void **)&q->h_hint, 4 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
-        q->h_hint[0] = 0; q->h_hint[1] = 0; q->h_hint[2] = 0; q->h_hint[3] = 0;
+    if (hipHostMalloc((void **)&q->h_hint, 8 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+        for (int i = 0; i < 8; i++) q->h_hint[i] = 0;     // [0] longest coded frame, [1] widest prediction list, [2] walked, [3] adopted, [4] frames on a cadence, [5] frames seen
         if (hipHostGetDevicePointer((void **)&q->d_hint, q->h_hint, 0) != hipSuccess) q->d_hint = nullptr;
     }
     if (q->scout) {
@@ -485,6 +491,7 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
         q->spec = lean && q->d_hint && getenv("MCRX_NO_SPEC") == nullptr;
         if (getenv("MCRX_SCOUT_ROUNDS")) { q->scout_rounds = std::max(1, std::min(8, atoi(getenv("MCRX_SCOUT_ROUNDS")))); q->rounds_fixed = true; }
         if (getenv("MCRX_NARROW_FIRST")) q->narrow_first = atoi(getenv("MCRX_NARROW_FIRST")) != 0;
+        if (getenv("MCRX_SPEC_ADAPTIVE")) q->spec_adaptive = atoi(getenv("MCRX_SPEC_ADAPTIVE")) != 0;
         if (q->spec) {
             if ((rc = q->alloc(&q->d_spec, (size_t)q->nch * MCRX_SPEC_MAX))) return bail(rc);
             if ((rc = q->alloc(&q->d_spec_R, (size_t)q->nch * MCRX_SPEC_MAX * M))) return bail(rc);
@@ -614,7 +621,7 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     a.syms = q->d_syms; a.rec = q->d_rec[g]; a.arena = q->d_arena[g]; a.sarena = q->d_sarena[g];
     a.nrec = q->d_nrec[g]; a.arena_used = q->d_arena_used[g];
     a.arena_cap = q->arena_cap; a.sarena_cap = q->sarena_cap; a.max_rec = q->max_rec;
-    a.debug = q->debug; a.no_fast = q->no_fast;
+    a.debug = q->debug; a.no_fast = q->no_fast; a.seek_burst = q->seek_burst;
     a.vit_off = 0;
     a.scout = q->scout ? 1 : 0;
     a.jobs = q->d_jobs[slot]; a.njobs = q->d_njobs + slot; a.njobs_next = q->d_njobs + next; a.max_jobs = q->max_rec;
@@ -662,6 +669,37 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
         // a sync, so a launch or two late), and while it moves a second full-width round re-anchors behind such gaps.  An
         // idle full-width round is not free (~35 us: 512 x spec_cap waves that only find nothing to do), hence not by default.
         int rounds = q->scout_rounds;
+        // Ragged traffic (every frame its own length, src/multichannel_txrx.cc:227-267): where a frame starts is not known
+        // before the header of the one in front of it has been decoded -- per channel the acquisitions are a chain by
+        // information, cadence predictions miss, and every speculative wave on a wrong position is an acquisition attempt
+        // thrown away (measured: 6.0 ms of acquisition per 207 M-sample slab with the rounds, 11 % of the frames adopted).
+        // There the lean scout's unbudgeted build walks the channels alone (1.4 ms).  The scouts count what they walked /
+        // adopted and how many frames followed their predecessor at the distance of the pair before (what a cadence
+        // would have hit); place_jobs_kernel copies the totals to host-mapped words and every 8 launches the host
+        // compares: rounds -> walking when walked > adopted twice in a row (not once: a cold start or the first pushes
+        // after a silence walk a window's worth by themselves), walking -> rounds when > 3/4 of the frames sat on a cadence
+        // twice in a row.  MCRX_ACQ_MODE=1 / 2 pins either.
+        bool spec_round = !q->walk_mode;
+        if (q->spec_adaptive && !q->rounds_fixed && q->h_hint && q->d_hint) {
+            if (++q->pol_count >= 8) {
+                volatile uint32_t *h = (volatile uint32_t *)q->h_hint;
+                const uint32_t w = h[2], ad = h[3], sm = h[4], fr = h[5];
+                const uint32_t dw = w >= q->pol_walk ? w - q->pol_walk : 0u, da = ad >= q->pol_adopt ? ad - q->pol_adopt : 0u;     // (mcrx_hip_spec_stats may have reset them)
+                const uint32_t ds = sm >= q->pol_same ? sm - q->pol_same : 0u, df = fr >= q->pol_fresh ? fr - q->pol_fresh : 0u;
+                if (!q->walk_mode) { if (dw > da && dw > q->nch / 4) { if (++q->pol_bad >= 2) { q->walk_mode = true; q->pol_bad = 0; } } else q->pol_bad = 0; }
+                else { if (df > q->nch && 4ull * ds > 3ull * df) { if (++q->pol_bad >= 2) { q->walk_mode = false; q->pol_bad = 0; } } else q->pol_bad = 0; }
+                q->pol_walk = w; q->pol_adopt = ad; q->pol_same = sm; q->pol_fresh = fr; q->pol_count = 0;
+                if (a.debug & 4) fprintf(stderr, "[host] launch %llu policy: walked %u adopted %u on-cadence %u of %u -> %s\n", (unsigned long long)q->seq, dw, da, ds, df, q->walk_mode ? "walk" : "rounds");
+            }
+            a.walk_hint = q->d_hint + 2;
+        }
+        if (q->acq_mode == 1) spec_round = true; else if (q->acq_mode == 2) spec_round = false;
+        if (!spec_round) {
+            const uint32_t cap0 = a.spec_cap;
+            a.spec_cap = 0; a.stop_after_walk = 0;
+            HIPCHK(sync_launch_walk(a, sa));
+            a.spec_cap = cap0;
+        } else {
         if (!q->rounds_fixed && q->h_hint && q->d_hint) {
             const uint32_t w = ((volatile uint32_t *)q->h_hint)[2];
             if (w != q->walk_seen) {
@@ -682,6 +720,7 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
             HIPCHK(sync_launch_lean(a, sa));
         }
         a.spec_cap = cap;
+        }
         // a frame the lean scout could neither hand off nor defer runs past the end of this buffer: walked up to there
         HIPCHK(sync_launch_tail(t, sa));
     } else {
@@ -1158,7 +1197,7 @@ extern "C" int mcrx_hip_spec_stats(mcrx_hip_t q, uint64_t *walked, uint64_t *ado
     HIPCHK(hipMemcpy(v, q->d_stats, sizeof(v), hipMemcpyDeviceToHost));
     if (walked) *walked = v[0];
     if (adopted) *adopted = v[1];
-    if (reset) HIPCHK(hipMemset(q->d_stats, 0, sizeof(v)));
+    if (reset) HIPCHK(hipMemset(q->d_stats, 0, 8 * sizeof(uint32_t)));
     return MCRX_OK;
 }
 

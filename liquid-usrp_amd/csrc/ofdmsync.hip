@@ -864,6 +864,56 @@ struct Walker {
         wave_sync_lds();
         return cscale(acc, 1.0f / (float)c.M_S0);
     }
+    // S0 metric on a window that is already in registers (SEEK: the oscillator is not running yet)
+    __device__ __forceinline__ float2 s0_metric_of(float2 (&x)[E], float &power)
+    {
+        float pw = 0.f;
+#pragma unroll
+        for (int e = 0; e < E; e++) pw += x[e].x * x[e].x + x[e].y * x[e].y;
+        power = wave_sum(pw);
+        fft(x);
+        const float gain = sqrtf((float)c.M_S0) / (float)c.M;
+        wave_sync_lds();
+#pragma unroll
+        for (int e = 0; e < E; e++) if (k[e] >= 0) { x[e] = cscale(x[e], S0v[e] * gain); ldsc[k[e]] = x[e]; }
+        wave_sync_lds();
+        float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int e = 0; e < E; e++) if (k[e] >= 0 && (k[e] & 1) == 0) {
+            int kn = k[e] + 2; if (kn >= c.M) kn -= c.M;
+            acc = cadd(acc, cmulc(ldsc[kn], x[e]));
+        }
+        acc = wave_csum(acc);
+        wave_sync_lds();
+        return cscale(acc, 1.0f / (float)c.M_S0);
+    }
+    // An idle channel is a chain of SEEK events M samples apart, each one HBM round trip plus a transform: SEEK_B of them
+    // at a time, the windows requested together so that their latencies overlap, then the same events in the same order
+    // (a detection ends the burst; the windows behind it are dropped).  Called in SEEK with timer == 0 and SEEK_B whole
+    // events inside the buffer; the arithmetic of every event is sync_event()'s.
+    static constexpr int SEEK_B = 4;
+    __device__ __forceinline__ void seek_burst()
+    {
+        const int M = c.M, M2 = c.M2;
+        float2 xw[SEEK_B][E];
+#pragma unroll
+        for (int j = 0; j < SEEK_B; j++) load_raw_direct(s.cur + (int64_t)j * M, xw[j]);
+        pf_t = INT64_MIN;                               // (the one-window lookahead is stale behind a burst)
+#pragma unroll
+        for (int j = 0; j < SEEK_B; j++) {
+            float pw; float2 sh = s0_metric_of(xw[j], pw);
+            const float g = (float)M / pw;
+            sh = cscale(sh, g);
+            const float tau = atan2f(sh.y, sh.x) * (float)M2 / TWO_PI_F;
+            s.g0 = g; s.timer = 0; s.cur += M;
+            if (sqrtf(sh.x * sh.x + sh.y * sh.y) > c.detect_thresh) {
+                const int dt = (int)roundf(tau);
+                s.timer = (uint32_t)(M + dt) % (uint32_t)M2 + (uint32_t)M;
+                s.state = SY_S0A;
+                return;
+            }
+        }
+    }
     __device__ __forceinline__ unsigned hbyte(int i) const { return (s.hw[i >> 2] >> (8 * (i & 3))) & 0xffu; }
     __device__ __forceinline__ void reset_framesync()
     {
@@ -1750,7 +1800,7 @@ struct Walker {
     // MODE SYM_FULL: the whole state machine (general configurations; with a.tail_only the tail kernel of the lean
     // configurations: only channels with a payload in progress, and only to that frame's end).
     // MODE SYM_LEAN: the lean scout -- acquisition, header, hand-off; a payload in progress is not its business.
-    template <int MODE = SYM_FULL>
+    template <int MODE = SYM_FULL, bool BURST = true>
     __device__ __forceinline__ void run()
     {
         s = a.st[ch];
@@ -1764,7 +1814,7 @@ struct Walker {
         }
         const int M = c.M, M2 = c.M2, L = c.L;
         long long prof_cyc[5] = {0, 0, 0, 0, 0}; int prof_n[5] = {0, 0, 0, 0, 0};
-        uint32_t npred = 0, nfresh = 0; int64_t pred_prev = 0, pred_last = 0; bool entry = true;
+        uint32_t npred = 0, nfresh = 0, nsame = 0; int64_t pred_prev = 0, pred_last = 0; bool entry = true;
         bool stopped = false;
         nadopted = 0;
         if (a.spec_cap) load_spec_headers();
@@ -1773,7 +1823,12 @@ struct Walker {
                 // a SEEK state a speculative wave may have started from -- the one this launch starts in, and the fresh
                 // one after every frame: take the frame from that wave if it started from exactly this state
                 const int64_t key = spec_key(s.cur, s.timer);
-                if (s.timer == (uint32_t)L) { pred_prev = pred_last; pred_last = s.cur; nfresh++; }
+                if (s.timer == (uint32_t)L) {
+                    // (frames at the same distance as the pair before them: what cadence speculation would have hit -- the
+                    //  host's acquisition policy reads the totals, launch_sync)
+                    if (nfresh >= 2 && s.cur - pred_last == pred_last - pred_prev) nsame++;
+                    pred_prev = pred_last; pred_last = s.cur; nfresh++;
+                }
                 entry = false;
                 if ((a.debug & 16) && l == 0 && ch == 0) printf("[spec] ch0 fresh state cur %lld timer %u (period hint %u, last fresh %lld, pred_n %u, pred[0..2] %lld %lld %lld)\n", (long long)s.cur, s.timer, s.period_hint, (long long)s.last_fresh, a.pred_n[ch], (long long)(a.pred[(size_t)ch * MCRX_SPEC_MAX] & 0xFFFFFFFFFFFFll), (long long)(a.pred[(size_t)ch * MCRX_SPEC_MAX + 1] & 0xFFFFFFFFFFFFll), (long long)(a.pred[(size_t)ch * MCRX_SPEC_MAX + 2] & 0xFFFFFFFFFFFFll));
                 if (a.spec_cap && adopt_speculative(key)) continue;
@@ -1785,6 +1840,12 @@ struct Walker {
             entry = false;
             if (MODE == SYM_LEAN && s.cur >= a.end) break;      // (a frame jumped over may end beyond this buffer)
             if (s.state == SY_SEEK) { sk_cur = s.cur; sk_timer = s.timer; }
+            if (BURST && a.seek_burst && s.state == SY_SEEK && s.timer == 0 && s.cur >= a.buf_first && s.cur + (int64_t)SEEK_B * M <= a.end) {
+                seek_burst();                               // idle stretch: SEEK_B events per HBM round trip
+                if (s.state == SY_SEEK) continue;
+                sk_cur = s.cur - M; sk_timer = 0;           // detected in the burst: the SEEK state that event was taken from
+                continue;
+            }
             // sample index of the next state-machine event
             int64_t t_ev;
             if (s.state == SY_SEEK)       t_ev = s.cur + ((s.timer + 1 >= (uint32_t)M) ? 0 : (int64_t)(M - 1 - (int)s.timer));
@@ -1833,8 +1894,14 @@ struct Walker {
             printf("[prof] ch0 rx phases: load %lld  core %lld  derot+nco %lld  flex %lld (header decode %lld, hand-off %lld)\n", ph[0], ph[1], ph[2], ph[3], ph[4], ph[5]);
         void_reservation();
         publish_adopted();
-        if (a.stats && l == 0) { if (nwalked) atomicAdd(a.stats, nwalked); if (nadopted) atomicAdd(a.stats + 1, nadopted); }
-        if (a.walk_hint && l == 0 && nwalked && !a.tail_only) atomicAdd_system(a.walk_hint, nwalked);     // (the lean scout, or the full kernel standing in for it at E >= 4)
+        if (a.stats && l == 0) {
+            if (nwalked) atomicAdd(a.stats, nwalked);
+            if (nadopted) atomicAdd(a.stats + 1, nadopted);
+            if (nsame) atomicAdd(a.stats + 4, nsame);
+            if (nfresh > 2) atomicAdd(a.stats + 5, nfresh - 2);
+        }
+        // (what the scouts walked and adopted reaches the host through place_jobs_kernel: one pair of stores per launch into
+        //  the host-mapped words instead of a system-scope atomic per channel)
         if (a.pred) {
             const int64_t period_seen = pred_last - pred_prev;
             const int64_t P_old = (int64_t)s.period_hint;            // a second hypothesis when the spacing just seen differs: the first frame
@@ -1930,6 +1997,21 @@ template <int E>
 __global__ __launch_bounds__(WV, SY_ACQ_WAVES) void sync_lean_kernel(SyncArgs a)
 {
     __builtin_amdgcn_s_setprio(3);      // a chain of dependent events every payload launch waits for: win the issue arbitration against the workers sharing the SIMD
+    launder(a);
+    const uint32_t ch = blockIdx.x;
+    if (ch >= a.nch) return;
+    Walker<E> w(a, ch);
+    w.template run<SYM_LEAN, false>();      // (no seek bursts under the register budget: behind the speculative waves / the chain it adopts, it does not seek)
+}
+
+// The lean scout's code without its register budget, for traffic whose frame positions cannot be predicted (every frame its own
+// length: launch_sync switches the speculative rounds off there): the budgeted build above spills ~300 registers, harmless
+// while it only adopts what the speculative waves found, ruinous when it acquires every frame itself (6.2 ms per slab
+// against 1.7 for the full kernel on the same stream).
+template <int E>
+__global__ __launch_bounds__(WV) void sync_walk_kernel(SyncArgs a)
+{
+    __builtin_amdgcn_s_setprio(3);
     launder(a);
     const uint32_t ch = blockIdx.x;
     if (ch >= a.nch) return;
@@ -2449,6 +2531,13 @@ __global__ __launch_bounds__(PJ_T) void place_jobs_kernel(SyncArgs a)
     uint32_t nj = *a.njobs;
     if (nj > a.max_jobs) nj = a.max_jobs;
     if (threadIdx.x == 0 && a.njobs_next) *a.njobs_next = 0;
+    if (threadIdx.x == 0 && a.walk_hint && a.stats) {
+        // frames the scouts acquired themselves / adopted from speculative waves so far: the host reads them without a sync
+        // and sets its acquisition policy by them (mcrx_hip.hip launch_sync)
+        volatile uint32_t *h = a.walk_hint;
+        h[0] = a.stats[0]; h[1] = a.stats[1]; h[2] = a.stats[4]; h[3] = a.stats[5];
+        __threadfence_system();
+    }
     auto need_of = [&](uint32_t j, uint32_t &pay16) -> uint32_t {
         pay16 = 0;
         if (a.jobs[j].ch >= a.nch) return 0u;
@@ -2543,7 +2632,7 @@ hipError_t sync_reset_launch(ChanState *st, uint32_t nch, int64_t cur, float2 *h
 
 // ---- launchers.  The file is compiled in three parts (-DSY_PART=0/1/2: symbol widths E = 1,2 / 4,8 / 16) so that
 // the template instantiations build in parallel; every part defines the per-width launchers of its widths.
-enum { SYK_SCOUT = 0, SYK_SPEC = 1, SYK_PAYLOAD_FAST = 2, SYK_PAYLOAD_GENERAL = 3, SYK_LEAN = 4, SYK_TAIL = 5 };
+enum { SYK_SCOUT = 0, SYK_SPEC = 1, SYK_PAYLOAD_FAST = 2, SYK_PAYLOAD_GENERAL = 3, SYK_LEAN = 4, SYK_TAIL = 5, SYK_WALK = 6 };
 // acquisition kernels of the narrow symbols (E = 1, 2): part 3, built with -mllvm -vgpr-regalloc=basic (see SY_ACQ_BUDGET)
 hipError_t sy_launch_acq_e1(int what, const SyncArgs &a, unsigned grid, size_t lds, hipStream_t st);
 hipError_t sy_launch_acq_e2(int what, const SyncArgs &a, unsigned grid, size_t lds, hipStream_t st);
@@ -2575,6 +2664,10 @@ static hipError_t sy_launch_width(int what, const SyncArgs &a, unsigned grid, si
         //  at E >= 4 under any budget worth having)
         if constexpr (EE == 1) return sy_launch_acq_e1(what, a, grid, lds, st);
         else if constexpr (EE == 2) return sy_launch_acq_e2(what, a, grid, lds, st);
+        else hipLaunchKernelGGL((sync_kernel<EE>), dim3(grid), dim3(WV), lds, st, a);
+        break;
+    case SYK_WALK:
+        if constexpr (EE <= 2) hipLaunchKernelGGL((sync_walk_kernel<EE>), dim3(grid), dim3(WV), lds, st, a);
         else hipLaunchKernelGGL((sync_kernel<EE>), dim3(grid), dim3(WV), lds, st, a);
         break;
     case SYK_PAYLOAD_FAST:    hipLaunchKernelGGL((payload_kernel<EE, true>), dim3(grid), dim3(WV), lds, st, a); break;
@@ -2610,7 +2703,7 @@ static hipError_t sy_launch(int what, const SyncArgs &a0, unsigned grid, size_t 
     // kernels that can end up decoding a packet themselves get the Viterbi decoder's block scratch behind their LDS
     SyncArgs a = a0;
     a.vit_off = 0;
-    if (what == SYK_SCOUT || what == SYK_TAIL || what == SYK_PAYLOAD_GENERAL || (what == SYK_LEAN && a.c.E > 2)) {
+    if (what == SYK_SCOUT || what == SYK_TAIL || what == SYK_PAYLOAD_GENERAL || ((what == SYK_LEAN || what == SYK_WALK) && a.c.E > 2)) {
         a.vit_off = (uint32_t)((lds + 15) & ~(size_t)15);
         lds = a.vit_off + (size_t)VIT_B * 8;
     }
@@ -2636,6 +2729,13 @@ hipError_t sync_launch_lean(const SyncArgs &a, hipStream_t st)
     if (a.nch == 0) return hipSuccess;
     if (a.c.M > SY_MAXM) return hipErrorInvalidValue;
     return sy_launch(SYK_LEAN, a, a.nch, SY_LDS_BYTES(a.c.M), st);
+}
+
+hipError_t sync_launch_walk(const SyncArgs &a, hipStream_t st)
+{
+    if (a.nch == 0) return hipSuccess;
+    if (a.c.M > SY_MAXM) return hipErrorInvalidValue;
+    return sy_launch(SYK_WALK, a, a.nch, SY_LDS_BYTES(a.c.M), st);
 }
 
 hipError_t sync_launch_tail(const SyncArgs &a, hipStream_t st)

@@ -35,7 +35,12 @@ struct TxSymArgs {
     const uint8_t *pay;         // [ch][frame][S_pay*M_data]
     float2 *xsym;               // [ch][frames*S][M]
     uint32_t nch;
+    // ragged traffic (mctx_hip_generate_ragged): frames of different lengths anywhere on the channel's symbol axis.
+    // frames = 1, S = symbols of the whole axis; symdesc[ch][S] says what symbol gs is: kind | s << 8 | row << 32
+    // (kind: TXK_* below; s: index inside its frame; row: its M_data bytes in hdr / pay)
+    const unsigned long long *symdesc = nullptr;
 };
+enum { TXK_IDLE = 0, TXK_S0A = 1, TXK_S0B = 2, TXK_S1 = 3, TXK_HDR = 4, TXK_PAY = 5, TXK_TAIL = 6 };
 
 __device__ __forceinline__ unsigned gray_dec_t(unsigned x) { unsigned y = x; while (x >>= 1) y ^= x; return y; }
 __device__ __forceinline__ float2 modulate(int mod, unsigned sym)
@@ -55,16 +60,25 @@ __global__ __launch_bounds__(TXW) void txsym_kernel(TxSymArgs a)
 {
     const int l = threadIdx.x & 63;
     const uint32_t gs = blockIdx.x, ch = blockIdx.y;
-    const int f = gs / a.S, s = gs % a.S;
+    int f = gs / a.S, s = gs % a.S;
     float2 *dst = a.xsym + ((size_t)ch * a.frames * a.S + gs) * a.M;
-    if (s < 3 || s == a.S - 1) {                    // S0a, S0b, S1 bodies come from the tables; tail has none
+    bool table = s < 3 || s == a.S - 1, zero = s == a.S - 1, is_hdr = s < 3 + a.S_hdr;
+    const uint8_t *bits = nullptr;
+    if (a.symdesc) {
+        const unsigned long long d = a.symdesc[(size_t)ch * a.S + gs];
+        const int kind = (int)(d & 0xff);
+        s = (int)((d >> 8) & 0xffff);
+        table = kind != TXK_HDR && kind != TXK_PAY; zero = kind == TXK_IDLE || kind == TXK_TAIL; is_hdr = kind == TXK_HDR;
+        bits = (is_hdr ? a.hdr : a.pay) + (size_t)(d >> 32) * a.M_data;
+    }
+    if (table) {                                    // S0a, S0b, S1 bodies come from the tables; tail (and idle symbols) have none
         const float2 *src = (s == 2) ? a.s1t : a.s0t;
-        for (int i = l; i < a.M; i += TXW) dst[i] = (s == a.S - 1) ? make_float2(0.f, 0.f) : src[i];
+        for (int i = l; i < a.M; i += TXW) dst[i] = zero ? make_float2(0.f, 0.f) : src[i];
         return;
     }
-    const bool is_hdr = s < 3 + a.S_hdr;
-    const uint8_t *bits = is_hdr ? a.hdr + ((size_t)ch * a.frames + f) * a.S_hdr * a.M_data + (size_t)(s - 3) * a.M_data
-                                 : a.pay + ((size_t)ch * a.frames + f) * a.S_pay * a.M_data + (size_t)(s - 3 - a.S_hdr) * a.M_data;
+    if (!a.symdesc)
+        bits = is_hdr ? a.hdr + ((size_t)ch * a.frames + f) * a.S_hdr * a.M_data + (size_t)(s - 3) * a.M_data
+                      : a.pay + ((size_t)ch * a.frames + f) * a.S_pay * a.M_data + (size_t)(s - 3 - a.S_hdr) * a.M_data;
     const uint32_t pcount = (uint32_t)(s - 3) * (uint32_t)a.M_pilot;      // pilot generator resets per frame
     float2 x[E];
 #pragma unroll
@@ -174,6 +188,8 @@ struct TxSynthArgs {
     const float2 *tiles = nullptr;  // [groups][ntiles][cg][8], channel = g*cg + c (NULL: frame_sample of xsym)
     uint32_t ntiles = 0, cg = 1;
     uint32_t out_first = 0;       // blocks in front of this one only feed the filter: out holds blocks >= out_first
+    // ragged traffic: symkind[ch][S] (TXK_*), frames = 1, S = symbols of the whole axis
+    const uint8_t *symkind = nullptr;
 };
 
 // frame sample t of channel ch: cyclic prefix + raised-cosine overlap of consecutive symbols
@@ -191,7 +207,12 @@ __device__ __forceinline__ float2 frame_sample(const TxSynthArgs &a, uint32_t ch
     }
     const uint32_t gs = t / (uint32_t)a.L, i = t % (uint32_t)a.L;
     if (gs >= nsym) return make_float2(0.f, 0.f);
-    const int s = (int)(gs % (uint32_t)S);
+    int s = (int)(gs % (uint32_t)S);
+    if (a.symkind) {                                // ragged traffic: the symbol's role comes from the map
+        const int kind = a.symkind[(size_t)ch * nsym + gs];
+        if (kind == TXK_IDLE) return make_float2(0.f, 0.f);
+        s = kind == TXK_S0A ? 0 : (kind == TXK_S0B ? 1 : (kind == TXK_TAIL ? S - 1 : 2));
+    }
     const float2 *x = xb + (size_t)gs * a.M;
     const int M = a.M, cp = a.cp;
     if (s == 0) {                                   // S0a: shifted copy, ramp up only
@@ -394,6 +415,7 @@ extern "C" int mctx_hip_destroy(mctx_hip_t q)
 }
 
 static int tx_launch_sym(mctx_hip_t q, const TxSymArgs &sa, unsigned nsym, unsigned nch, hipStream_t st);
+static int tx_launch_ifft(mctx_hip_t q, const TxSynthArgs &ya, unsigned nblocks, hipStream_t st);
 
 static void frame_geometry(mctx_hip_t q, unsigned payload_len, int mod, int fec0, int fec1,
                            unsigned &S_hdr, unsigned &S_pay, unsigned &S)
@@ -474,6 +496,95 @@ extern "C" int mctx_hip_generate(mctx_hip_t q, void *d_iq, size_t nblocks, unsig
     return MCRX_OK;
 }
 
+
+// Ragged traffic: what src/multichannel_txrx.cc:227-267 puts on the air -- every packet its own length
+// (`rand() % payload_len` there; uniform in [len_lo, len_hi] here), handed to whichever channel is free, so a channel's
+// frames follow each other after short, irregular pauses, with a long silence now and then (the bursts).  Frames start on
+// OFDM symbol boundaries (the class steps all frame generators one symbol at a time, lib/multichanneltx.cc:230-242).
+// Per channel (seeded): gap of 0 .. gap_max symbols before every frame, with probability 1 / long_every a silence of
+// 16 .. 16 + long_max symbols instead; frames are placed until the next one would not end 64 blocks before the end of
+// the stream.  count[ch] frames were placed; frame f of channel ch: hdr[ch][f][8], len[ch][f], pay[ch][f][len_hi],
+// start[ch][f] = block index of its first sample (host arrays sized for max_frames per channel; may be NULL).
+extern "C" int mctx_hip_generate_ragged(mctx_hip_t q, void *d_iq, size_t nblocks, unsigned max_frames, unsigned len_lo, unsigned len_hi,
+                                        unsigned gap_max, unsigned long_every, unsigned long_max, int mod, int fec0, int fec1,
+                                        float gain, uint32_t seed, uint32_t *count_out, uint8_t *hdr_out, uint32_t *len_out,
+                                        uint8_t *pay_out, uint64_t *start_out, void *stream)
+{
+    if (!q || !d_iq || !mod_bps(mod) || len_hi < len_lo || !max_frames) { g_tx_err = "bad argument"; return MCRX_EINVAL; }
+    if (q->M & (q->M - 1)) { g_tx_err = "ragged traffic needs a power-of-two subcarrier count"; return MCRX_EUNSUPP; }
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned Md = q->od.M_data, N = q->N, M = q->M, K = q->K, L = M + q->cp;
+    const size_t T = nblocks / L;                                   // symbols on a channel's axis
+    if (T < 8) { g_tx_err = "stream too short"; return MCRX_EINVAL; }
+    std::vector<unsigned long long> desc((size_t)N * T, 0ull);
+    std::vector<uint8_t> kind((size_t)N * T, (uint8_t)TXK_IDLE);
+    std::vector<uint8_t> hdr, pay;
+    FrameSymbols fsym;
+    for (unsigned ch = 0; ch < N; ch++) {
+        std::mt19937 rng(seed + 7919u * ch);
+        size_t t = 0; unsigned f = 0;
+        while (f < max_frames) {
+            const unsigned plen = len_lo + (unsigned)(rng() % (len_hi - len_lo + 1));
+            unsigned gap = gap_max ? (unsigned)(rng() % (gap_max + 1)) : 0;
+            if (long_every && (rng() % long_every) == 0) gap = 16 + (long_max ? (unsigned)(rng() % (long_max + 1)) : 0);
+            unsigned Sh, Sp, S; frame_geometry(q, plen, mod, fec0, fec1, Sh, Sp, S);
+            if ((t + gap + S) * L + 64 > nblocks) break;
+            t += gap;
+            uint8_t h8[8] = { (uint8_t)(f >> 8), (uint8_t)f, (uint8_t)ch, 0, 0, 0, 0, 0 };
+            for (int i = 3; i < 8; i++) h8[i] = (uint8_t)(rng() & 0xff);
+            std::vector<uint8_t> pl(plen);
+            for (auto &b : pl) b = (uint8_t)(rng() & 0xff);
+            assemble_frame(h8, pl, mod, fec0, fec1, Md, Sh, Sp, fsym);
+            const size_t hrow = hdr.size() / Md, prow = pay.size() / Md;
+            hdr.insert(hdr.end(), fsym.hdr.begin(), fsym.hdr.end());
+            pay.insert(pay.end(), fsym.pay.begin(), fsym.pay.end());
+            for (unsigned s = 0; s < S; s++) {
+                int k; unsigned long long row = 0;
+                if (s == 0) k = TXK_S0A; else if (s == 1) k = TXK_S0B; else if (s == 2) k = TXK_S1;
+                else if (s == S - 1) k = TXK_TAIL;
+                else if (s < 3 + Sh) { k = TXK_HDR; row = hrow + (s - 3); }
+                else { k = TXK_PAY; row = prow + (s - 3 - Sh); }
+                kind[(size_t)ch * T + t + s] = (uint8_t)k;
+                desc[(size_t)ch * T + t + s] = (unsigned long long)k | ((unsigned long long)s << 8) | (row << 32);
+            }
+            if (hdr_out) memcpy(hdr_out + ((size_t)ch * max_frames + f) * 8, h8, 8);
+            if (len_out) len_out[(size_t)ch * max_frames + f] = plen;
+            if (pay_out && plen) memcpy(pay_out + ((size_t)ch * max_frames + f) * len_hi, pl.data(), plen);
+            if (start_out) start_out[(size_t)ch * max_frames + f] = (uint64_t)t * L;
+            t += S; f++;
+        }
+        if (count_out) count_out[ch] = f;
+    }
+    uint8_t *d_hdr = nullptr, *d_pay = nullptr, *d_kind = nullptr; unsigned long long *d_desc = nullptr; float2 *d_xsym = nullptr, *d_v = nullptr;
+    TXCHK(hipMalloc((void **)&d_hdr, std::max<size_t>(hdr.size(), 1))); TXCHK(hipMalloc((void **)&d_pay, std::max<size_t>(pay.size(), 1)));
+    TXCHK(hipMalloc((void **)&d_kind, kind.size())); TXCHK(hipMalloc((void **)&d_desc, desc.size() * sizeof(unsigned long long)));
+    TXCHK(hipMalloc((void **)&d_xsym, (size_t)N * T * M * sizeof(float2)));
+    TXCHK(hipMalloc((void **)&d_v, nblocks * K * sizeof(float2)));
+    TXCHK(hipMemcpyAsync(d_hdr, hdr.data(), hdr.size(), hipMemcpyHostToDevice, st));
+    TXCHK(hipMemcpyAsync(d_pay, pay.data(), pay.size(), hipMemcpyHostToDevice, st));
+    TXCHK(hipMemcpyAsync(d_kind, kind.data(), kind.size(), hipMemcpyHostToDevice, st));
+    TXCHK(hipMemcpyAsync(d_desc, desc.data(), desc.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
+    TxSymArgs sa;
+    sa.M = (int)M; sa.log2M = 0; while ((1u << sa.log2M) < M) sa.log2M++;
+    sa.cp = (int)q->cp; sa.taper = (int)q->taper; sa.L = (int)L; sa.M_pilot = (int)q->od.M_pilot; sa.M_data = (int)Md;
+    sa.S = (int)T; sa.S_hdr = 0; sa.S_pay = 0; sa.frames = 1; sa.bps = (int)mod_bps(mod); sa.mod = mod;
+    sa.g_data = 1.0f / sqrtf((float)(q->od.M_pilot + q->od.M_data));
+    sa.sctype = q->d_sctype; sa.data_rank = q->d_drank; sa.pilot_rank = q->d_prank; sa.pilot_seq = q->d_pseq;
+    sa.s0t = q->d_s0t; sa.s1t = q->d_s1t; sa.hdr = d_hdr; sa.pay = d_pay; sa.xsym = d_xsym; sa.nch = N; sa.symdesc = d_desc;
+    { int rc = tx_launch_sym(q, sa, (unsigned)T, N, st); if (rc) return rc; }
+    TxSynthArgs ya;
+    ya.M = (int)M; ya.cp = (int)q->cp; ya.taper = (int)q->taper; ya.L = (int)L; ya.S = (int)T; ya.frames = 1;
+    ya.taperwin = q->d_taper; ya.xsym = d_xsym; ya.taps = q->d_taps; ya.v = d_v; ya.out = (float2 *)d_iq;
+    ya.nblocks = (uint32_t)nblocks; ya.N = N; ya.dtheta = q->dtheta; ya.first_sample_lo = 0; ya.gain = gain;
+    ya.ft0 = nullptr; ya.fS = nullptr; ya.xstride = 0; ya.b_first = 0; ya.hist = 0; ya.symkind = d_kind;
+    { int rc = tx_launch_ifft(q, ya, (unsigned)nblocks, st); if (rc) return rc; }
+    const unsigned tb = K < 256 ? 64 : 256;
+    hipLaunchKernelGGL(txfir_kernel, dim3((K + tb - 1) / tb, (unsigned)((nblocks + 7) / 8)), dim3(tb), 0, st, ya, K);
+    TXCHK(hipGetLastError());
+    TXCHK(hipStreamSynchronize(st));
+    (void)hipFree(d_hdr); (void)hipFree(d_pay); (void)hipFree(d_kind); (void)hipFree(d_desc); (void)hipFree(d_xsym); (void)hipFree(d_v);
+    return MCRX_OK;
+}
 
 // ------------------------------------------------------------------------------------------------
 // Sharded form of the generator (multi-GPU transmit side of src/multichannel_txrx.cc): the frame generators are

@@ -227,3 +227,32 @@ def test_payload_worker_builds_agree(oracle, product, fr, monkeypatch):
                 for c in range(N) for a, b in zip(g[c], o[c]))
     assert worst <= 1e-5, worst
     rx.close()
+
+
+def test_acquisition_policy_switches_with_the_traffic(oracle, product):
+    """Periodic traffic is acquired by cadence speculation, ragged traffic (every frame its own length) by the walking scouts;
+    the host switches between the two from the scouts' counters (mcrx_hip.hip launch_sync).  A stream that goes periodic ->
+    ragged -> periodic in many small pushes: whatever the policy does and whenever it switches, the frames are the oracle's."""
+    import torch
+    from test_gpu_parity import check_frames
+    N, M, cp = 8, 64, 8
+    L = M + cp
+    tx = product.multichanneltx(N, M, cp, 4)
+    a, _ = tx.generate(40, 90, seed=5)
+    b, _, _ = tx.generate_ragged(L * 2600 // 8 * 8, len_lo=10, len_hi=200, gap_max=3, long_every=6, long_max=30, seed=6)
+    c, _ = tx.generate(40, 60, seed=7)
+    tx.close()
+    iq = torch.cat([a, b, c])
+    n = int(iq.numel()) // (16 * N) * (16 * N)
+    x = iq[:n].cpu().numpy()
+    ora = oracle.MultiChannelRx(N, M, cp, 4)
+    ora.execute(x)
+    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=200)
+    step = 16 * N * 26                                   # ~ 3 frames per channel and push: > 100 pushes
+    for i in range(0, n, step):
+        rx.Execute(iq[i:min(i + step, n)])
+    rx.Flush()
+    walked, adopted = rx.spec_stats()
+    check_frames(rx.frames, ora.frames)
+    assert len(rx.frames) >= 80 * N and walked > 0 and adopted > 0, (len(rx.frames), walked, adopted)
+    rx.close()
