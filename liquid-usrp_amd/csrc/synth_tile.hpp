@@ -1,0 +1,306 @@
+// synth_tile.hpp -- fused synthesis bank of the GPU multichanneltx (included by txgen.hip behind TxSynthArgs / frame_sample).
+//
+// Replaces, per block of K = 2N wideband samples, multichanneltx::GenerateSamples (lib/multichanneltx.cc:192-227):
+//   firpfbch_crcf_synthesizer_execute (K channels, m = 13: inverse FFT, polyphase FIR of p = 26 taps per branch)
+//   nco_crcf_mix_up / nco_crcf_step
+// in ONE kernel -- the mirror image of channelizer.hip:
+//   X_b[k]  = channel k's sample of block b (k < N; bins N..K-1 are zero)        4 B read per wideband sample
+//   v_b     = K-point inverse FFT of X_b, unnormalised                           LDS tile, radix-4 + 16-point register stage
+//   y_b[n]  = sum_{j<26} h[n + jK] v_{b-j}[n]                                    register window down the time axis
+//   out     = gain * y_b[n] * exp(+j t dtheta), t = absolute sample index        8 B written per wideband sample
+// Round 2 ran this as two kernels with the inverse-FFT outputs in HBM between them (one workgroup per block, radix-2 Stockham
+// with a sincos per butterfly; 28 B per sample, 7.5 + 5.0 GB of measured traffic per 207 M samples): 2.68 ms.  Here a workgroup owns
+// a time slab; a thread owns two adjacent columns and keeps their last 25 inverse-FFT outputs in registers (the analysis bank's
+// plan -- its window is 13 deep, this one 25: rounds of 4 blocks instead of 8 keep it at 116 registers), the taps live in LDS as
+// the symmetric half of the prototype, and a slab starts 28 blocks early to fill its window (7 % recomputed at 400-block slabs).
+// The inverse transform is the forward one on conjugated data (conj on the way into the tile and on the way out), so the
+// butterflies are channelizer.hip's.
+#pragma once
+
+namespace mcrx {
+namespace syn {
+
+#define SYN_P 26            // taps per branch (m = 13)
+#define SYN_H (SYN_P - 1)   // blocks of history
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <class T> __device__ __forceinline__ T *uniform_ptr(T *p)
+{
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    typedef __attribute__((address_space(1))) T GT;
+    return (T *)reinterpret_cast<GT *>(((unsigned long long)hi << 32) | lo);
+}
+
+template <int K> struct Plan {
+    static constexpr int stages() { int L = K, s = 0; while (L > 16) { L /= 4; s++; } return s; }
+    static constexpr int final_size() { int L = K; while (L > 16) L /= 4; return L; }
+    enum { S = stages(), F = final_size(), RL = K + K / F, ROWP = RL + 1 };
+    static constexpr int tw_off(int st) { int o = 0; for (int i = 0; i < st; i++) o += 3 * ((K >> (2 * i)) >> 2); return o; }
+    enum { TW = tw_off(stages()) };
+};
+template <int K> __device__ __forceinline__ int pad(int e) { return e + e / Plan<K>::F; }
+template <int K> __device__ __forceinline__ int dif_pos(int k)
+{
+    int L = K, pos = 0;
+#pragma unroll
+    for (int s = 0; s < Plan<K>::S; s++) { pos += (k & 3) * (L >> 2); k >>= 2; L >>= 2; }
+    return pos + k;
+}
+__device__ __forceinline__ float2 w16(int k)
+{
+    const float c[8] = { 1.0f, 0.92387953251f, 0.70710678119f, 0.38268343236f, 0.0f, -0.38268343236f, -0.70710678119f, -0.92387953251f };
+    const float s[8] = { 0.0f, -0.38268343236f, -0.70710678119f, -0.92387953251f, -1.0f, -0.92387953251f, -0.70710678119f, -0.38268343236f };
+    return make_float2(c[k], s[k]);
+}
+constexpr int bitrev_c(int i, int bits) { int r = 0; for (int b = 0; b < bits; b++) if (i & (1 << b)) r |= 1 << (bits - 1 - b); return r; }
+template <int K> struct Log2 { enum { v = 1 + Log2<K / 2>::v }; };
+template <> struct Log2<1> { enum { v = 0 }; };
+// F-point forward DFT in registers, natural order in, bit-reversed out
+template <int F>
+__device__ __forceinline__ void fft_reg(float2 (&v)[F])
+{
+#pragma unroll
+    for (int h = F / 2; h >= 1; h >>= 1) {
+#pragma unroll
+        for (int i = 0; i < F; i++) {
+            if ((i & h) == 0) {
+                const float2 u = v[i], w = v[i + h];
+                v[i] = cadd(u, w);
+                const float2 d = csub(u, w);
+                const int tk = (i & (h - 1)) * (8 / h);
+                if (tk == 0) v[i + h] = d;
+                else if (tk == 4) v[i + h] = cmulnj(d);
+                else v[i + h] = cmul(d, w16(tk));
+            }
+        }
+    }
+}
+
+template <int K, int R> struct Lds {
+    static constexpr int TAPF = (SYN_P * K / 2 + 1 + 1) & ~1;       // floats: h[0 .. pK/2], the symmetric half
+    static constexpr size_t bytes() { return (size_t)(R * Plan<K>::ROWP) * sizeof(float2) + (size_t)TAPF * sizeof(float) + (size_t)(Plan<K>::TW > 0 ? Plan<K>::TW : 1) * sizeof(float2); }
+};
+
+// K >= 128 (T = K/2 >= 64 threads: thread t is channel t when the inputs are gathered, columns 2t, 2t+1 afterwards)
+template <int K, int R>
+__global__ __launch_bounds__(K / 2) void synth_kernel(TxSynthArgs a, uint32_t slab_blocks)
+{
+    constexpr int T = K / 2, N = K / 2, C = 2;
+    constexpr int S = Plan<K>::S, F = Plan<K>::F, ROWP = Plan<K>::ROWP, TAPF = Lds<K, R>::TAPF;
+    constexpr int LEAD = (SYN_H + R - 1) / R * R;                   // blocks a slab starts early to fill its window
+    extern __shared__ __attribute__((aligned(16))) float2 tile[];   // [R][ROWP], taps, twiddles
+    const int tid = threadIdx.x;
+    const int n0 = tid * C;
+    float *ltap = reinterpret_cast<float *>(tile + R * ROWP);
+    {
+        constexpr int NT = SYN_P * K / 2 + 1, PER = (NT + T - 1) / T;
+        float tv[PER];
+#pragma unroll
+        for (int i = 0; i < PER; i++) { const int idx = tid + i * T; tv[i] = a.taps[idx < NT ? idx : 0]; }
+#pragma unroll
+        for (int i = 0; i < PER; i++) { const int idx = tid + i * T; if (idx < NT) ltap[idx] = tv[i]; }
+    }
+    float2 *ltw = reinterpret_cast<float2 *>(ltap + TAPF);
+#pragma unroll
+    for (int st = 0; st < S; st++) {
+        const int L = K >> (2 * st), q4 = L >> 2;
+        for (int e = tid; e < 3 * q4; e += T) {
+            const int r = e / q4 + 1, pos = e % q4;
+            float sn, cs; sincos_u32((uint32_t)(r * pos) * (uint32_t)(4294967296.0 / L), sn, cs);
+            ltw[Plan<K>::tw_off(st) + e] = make_float2(cs, -sn);
+        }
+    }
+    __syncthreads();
+
+    // my slab of output blocks (local indices, block 0 = a.first_sample_lo): [o0, o1), entered LEAD blocks early
+    const long long o0 = (long long)a.out_first + (long long)blockIdx.x * slab_blocks;
+    long long o1 = o0 + slab_blocks; if (o1 > (long long)a.nblocks) o1 = (long long)a.nblocks;
+    if (o0 >= o1) return;
+    const long long bstart = o0 - LEAD;
+
+    const int tapb = opaque(R * ROWP * 2 + n0);                     // direct branches j < p/2: h[n + jK]            (floats from `tile`)
+    const int tapm = opaque(R * ROWP * 2 + (K - 1 - n0));           // mirrored, j >= p/2: h[(p-j) K - n]: + (p-1-j) K, column c at -c
+    const int xrow = opaque(pad<K>(tid));                           // where channel tid's input goes in a row
+    const int vsrc0 = opaque(pad<K>(dif_pos<K>(n0))), vsrc1 = opaque(pad<K>(dif_pos<K>(n0 + 1)));
+    const float *ltf = reinterpret_cast<const float *>(tile);
+    constexpr int NBF4 = R * (K / 4), NG = R * (K / F);
+    constexpr bool SPLIT = (2 * NG == T) && F >= 4;
+    static_assert(S == 0 || (NBF4 % T == 0 && T % (K / 4) == 0), "a thread's butterflies differ by whole rows");
+    static_assert(NG % T == 0 || SPLIT, "F-point groups per thread");
+    constexpr int BTRIPS = S > 0 ? NBF4 / T : 0, BSTEP = S > 0 ? (T / (K / 4)) * ROWP : 0;
+    auto stage_index = [&](int st, int t) {
+        const int L = K >> (2 * st), q4 = L >> 2;
+        const int f = t / (K / 4), j = t % (K / 4);
+        return f * ROWP + pad<K>((j / q4) * L + j % q4);
+    };
+    auto group_index = [&](int g) { return (g / (K / F)) * ROWP + (g % (K / F)) * (F + 1); };
+
+    float2 s[SYN_H + R][C];                                         // s[0..24] history (oldest first), s[25..] the round's blocks
+#pragma unroll
+    for (int i = 0; i < SYN_H + R; i++)
+#pragma unroll
+        for (int c = 0; c < C; c++) s[i][c] = make_float2(0.f, 0.f);
+    char *outb = reinterpret_cast<char *>(a.out);
+    const uint32_t ooff = (uint32_t)n0 * (uint32_t)sizeof(float2);
+    // Oscillator e^{+j t dtheta}: exact 32-bit phase through v_sin / v_cos at the first column of every group of 8 blocks
+    // (groups start on multiples of 8 of the launch's block axis, which callers keep aligned with the absolute one), then
+    // turned by the per-block step K dtheta and, for the second column, by dtheta -- explicit fma shapes, so a block's
+    // samples are a fixed function of its absolute index whatever slab, launch or rank makes them.
+    float sd1, cd1; sincos_u32(a.dtheta, sd1, cd1);
+    float sk8, ck8; sincos_u32((uint32_t)K * a.dtheta, sk8, ck8);
+    sd1 = __builtin_bit_cast(float, uniform_i(__builtin_bit_cast(int, sd1))); cd1 = __builtin_bit_cast(float, uniform_i(__builtin_bit_cast(int, cd1)));
+    sk8 = __builtin_bit_cast(float, uniform_i(__builtin_bit_cast(int, sk8))); ck8 = __builtin_bit_cast(float, uniform_i(__builtin_bit_cast(int, ck8)));
+    float osn = 0.f, ocs = 1.f;
+
+    const int rounds = (int)((o1 - bstart + R - 1) / R);
+    for (int rd = 0; rd < rounds; rd++) {
+        const long long b0 = bstart + (long long)rd * R;
+        const int tq = opaque(tid);
+        // ---- inputs: channel tid of blocks b0 .. b0+R-1, conjugated (inverse transform = conj(forward(conj))); bins >= N are zero
+        float2 xin[R];
+        if (a.tiles) {
+            // granules received from the channel shards: [g][tile][c][8], channel = g cg + c; R consecutive blocks of a
+            // granule are contiguous (R divides 8 and rounds start on multiples of R)
+            const uint32_t g = (uint32_t)tid / a.cg, c = (uint32_t)tid % a.cg;
+#pragma unroll
+            for (int r = 0; r < R; r += 2) {
+                const long long b = b0 + r;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (b >= 0 && b + 1 < (long long)a.nblocks)
+                    v = *reinterpret_cast<const float4 *>(a.tiles + (((size_t)g * a.ntiles + (size_t)(b >> 3)) * a.cg + c) * 8 + (size_t)(b & 7));
+                xin[r] = make_float2(v.x, v.y); xin[r + 1] = make_float2(v.z, v.w);
+            }
+        } else {
+            // batch / ragged layout: the channel's frame axis, symbol gs = b / L, position i = b % L -- one division per
+            // round, then the position walks on (frame_sample_at: the role of symbol gs is looked up where it changes)
+            const long long bc = b0 < 0 ? 0 : b0;
+            uint32_t gs = (uint32_t)bc / (uint32_t)a.L, i = (uint32_t)bc % (uint32_t)a.L;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const long long b = b0 + r;
+                const bool in = b >= 0 && b < (long long)a.nblocks;
+                xin[r] = in ? frame_sample_at(a, (uint32_t)tid, gs, i) : make_float2(0.f, 0.f);
+                if (in) { i++; if (i == (uint32_t)a.L) { i = 0; gs++; } }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            float2 *row = tile + r * ROWP;
+            row[xrow] = make_float2(xin[r].x, -xin[r].y);
+            row[pad<K>(N) + xrow] = make_float2(0.f, 0.f);          // (pad(N + t) = pad(N) + pad(t): N is a multiple of F)
+        }
+        lds_barrier();
+        // ---- R forward K-point transforms in place (channelizer.hip's plan)
+        if constexpr (S > 0) {
+#pragma unroll
+            for (int st = 0; st < S; st++) {
+                const int L = K >> (2 * st), q4 = L >> 2;
+                const int D = q4 + q4 / F;
+                const float2 *twp = tile + R * ROWP + TAPF / 2 + Plan<K>::tw_off(st) + tq % q4;
+                const int fa_st = stage_index(st, tq);
+                const float2 tw1 = twp[0], tw2 = twp[q4], tw3 = twp[2 * q4];
+#pragma unroll
+                for (int i = 0; i < BTRIPS; i++) {
+                    float2 *p = tile + fa_st + i * BSTEP;
+                    const float2 x0 = p[0], x1 = p[D], x2 = p[2 * D], x3 = p[3 * D];
+                    const float2 a0 = cadd(x0, x2), a1 = csub(x0, x2), a2 = cadd(x1, x3), a3 = cmulnj(csub(x1, x3));
+                    p[0] = cadd(a0, a2);
+                    p[D] = cmul(cadd(a1, a3), tw1);
+                    p[2 * D] = cmul(csub(a0, a2), tw2);
+                    p[3 * D] = cmul(csub(a1, a3), tw3);
+                }
+                lds_barrier();
+            }
+        }
+        if constexpr (SPLIT) {
+            // half as many F-point groups as threads: waves 0 .. NG/64-1 transform the sums x[i] + x[i+F/2] (even bins), the
+            // others the twiddled differences (odd bins); both read the whole group and write into it, hence the barrier
+            const int role = uniform_i(tq / NG);
+            float2 *p = tile + group_index(tq - role * NG);
+            float2 x[F], v[F / 2];
+#pragma unroll
+            for (int m = 0; m < F; m++) x[m] = p[m];
+            lds_barrier();
+            if (role == 0) {
+#pragma unroll
+                for (int i = 0; i < F / 2; i++) v[i] = cadd(x[i], x[i + F / 2]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < F / 2; i++) {
+                    const float2 d = csub(x[i], x[i + F / 2]);
+                    const int tk = i * (16 / F);
+                    if (tk == 0) v[i] = d; else if (tk == 4) v[i] = cmulnj(d); else v[i] = cmul(d, w16(tk));
+                }
+            }
+            fft_reg<F / 2>(v);
+#pragma unroll
+            for (int m = 0; m < F / 2; m++) p[2 * bitrev_c(m, Log2<F / 2>::v) + role] = v[m];
+            lds_barrier();
+        } else {
+            constexpr int GTRIPS = NG / T;
+#pragma unroll
+            for (int i = 0; i < GTRIPS; i++) {
+                float2 *p = tile + group_index(tq + i * T);
+                float2 v[F];
+#pragma unroll
+                for (int m = 0; m < F; m++) v[m] = p[m];
+                fft_reg<F>(v);
+#pragma unroll
+                for (int m = 0; m < F; m++) p[bitrev_c(m, Log2<F>::v)] = v[m];
+            }
+            lds_barrier();
+        }
+        // ---- my two columns of the R new blocks (conjugated back), into the window
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const float2 u0 = tile[r * ROWP + vsrc0], u1 = tile[r * ROWP + vsrc1];
+            s[SYN_H + r][0] = make_float2(u0.x, -u0.y); s[SYN_H + r][1] = make_float2(u1.x, -u1.y);
+        }
+        // ---- synthesis FIR, oscillator, gain, store (rounds that only fill the window skip it)
+        if (b0 + R > o0) {
+            float tap[SYN_P][C];
+#pragma unroll
+            for (int j = 0; j < SYN_P; j++)
+#pragma unroll
+                for (int c = 0; c < C; c++)
+                    tap[j][c] = (j >= SYN_P / 2) ? ltf[tapm - c + (SYN_P - 1 - j) * K + 1] : ltf[tapb + c + j * K];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const long long b = b0 + r;
+                float2 acc[C];
+#pragma unroll
+                for (int c = 0; c < C; c++) acc[c] = make_float2(0.f, 0.f);
+#pragma unroll
+                for (int j = SYN_P - 1; j >= 0; j--) {               // oldest first, like the window dot product
+#pragma unroll
+                    for (int c = 0; c < C; c++) {
+                        acc[c].x += tap[j][c] * s[SYN_H + r - j][c].x;
+                        acc[c].y += tap[j][c] * s[SYN_H + r - j][c].y;
+                    }
+                }
+                if ((b & 7) == 0)       // first block of a group (slabs start on multiples of 8, so a slab's first output block is one)
+                    sincos_u32_hw((a.first_sample_lo + (uint32_t)((unsigned long long)b * K + (unsigned)n0)) * a.dtheta, osn, ocs);
+                if (b >= o0 && b < o1) {
+                    const float s1 = fmaf(osn, cd1, ocs * sd1), c1 = fmaf(ocs, cd1, -(osn * sd1));            // the second column
+                    const float2 y0 = make_float2(fmaf(acc[0].x, ocs, -(acc[0].y * osn)), fmaf(acc[0].y, ocs, acc[0].x * osn));
+                    const float2 y1 = make_float2(fmaf(acc[1].x, c1, -(acc[1].y * s1)), fmaf(acc[1].y, c1, acc[1].x * s1));
+                    *reinterpret_cast<float4 *>(uniform_ptr(outb + (size_t)(b - (long long)a.out_first) * K * sizeof(float2)) + ooff) =
+                        make_float4(y0.x * a.gain, y0.y * a.gain, y1.x * a.gain, y1.y * a.gain);
+                }
+                { const float s2 = fmaf(osn, ck8, ocs * sk8), c2 = fmaf(ocs, ck8, -(osn * sk8)); osn = s2; ocs = c2; }      // next block
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < SYN_H; i++)
+#pragma unroll
+            for (int c = 0; c < C; c++) s[i][c] = s[i + R][c];
+        lds_barrier();
+    }
+}
+
+}  // namespace syn
+}  // namespace mcrx

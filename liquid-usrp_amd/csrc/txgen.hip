@@ -192,6 +192,12 @@ struct TxSynthArgs {
     const uint8_t *symkind = nullptr;
 };
 
+__device__ __forceinline__ float2 frame_sample_sym(const TxSynthArgs &a, uint32_t ch, const float2 *xb, int S, uint32_t nsym, uint32_t gs, uint32_t i);
+// batch / ragged layout only (no streaming slots): the caller walks (gs, i) itself
+__device__ __forceinline__ float2 frame_sample_at(const TxSynthArgs &a, uint32_t ch, uint32_t gs, uint32_t i)
+{
+    return frame_sample_sym(a, ch, a.xsym + (size_t)ch * a.frames * a.S * a.M, a.S, (uint32_t)(a.frames * a.S), gs, i);
+}
 // frame sample t of channel ch: cyclic prefix + raised-cosine overlap of consecutive symbols
 // (liquid ofdmframegen_gensymbol / write_S0a / write_S0b / writetail)
 __device__ __forceinline__ float2 frame_sample(const TxSynthArgs &a, uint32_t ch, uint32_t b)
@@ -206,6 +212,11 @@ __device__ __forceinline__ float2 frame_sample(const TxSynthArgs &a, uint32_t ch
         xb = a.xsym + (size_t)ch * a.xstride * a.M;
     }
     const uint32_t gs = t / (uint32_t)a.L, i = t % (uint32_t)a.L;
+    return frame_sample_sym(a, ch, xb, S, nsym, gs, i);
+}
+// ... of symbol gs (counted along the channel's frame axis), position i in it
+__device__ __forceinline__ float2 frame_sample_sym(const TxSynthArgs &a, uint32_t ch, const float2 *xb, int S, uint32_t nsym, uint32_t gs, uint32_t i)
+{
     if (gs >= nsym) return make_float2(0.f, 0.f);
     int s = (int)(gs % (uint32_t)S);
     if (a.symkind) {                                // ragged traffic: the symbol's role comes from the map
@@ -331,13 +342,16 @@ __global__ void txtiles_kernel(TxSynthArgs a, long long first_block, uint32_t nt
 
 }  // namespace mcrx
 
+#include "synth_tile.hpp"       // the fused synthesis bank (needs TxSynthArgs / frame_sample above)
+
 using namespace mcrx;
 
 static thread_local std::string g_tx_err;
 #define TXCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_tx_err = std::string(#x) + ": " + hipGetErrorString(e_); return MCRX_EHIP; } } while (0)
 
 struct mctx_hip_s {
-    unsigned N, K, M, cp, taper;
+    unsigned N, K, M, cp, taper, ncu = 256;
+    bool taps_symmetric = false;                        // h[i] == h[pK - i] bit for bit (the fused synthesis kernel keeps half of it)
     OfdmDesign od;
     std::vector<float> taps;
     uint32_t dtheta;
@@ -388,6 +402,14 @@ extern "C" int mctx_hip_create(mctx_hip_t *out, unsigned N, unsigned M, unsigned
     if (q->od.init(M, cp, taper, p) != 0) { delete q; g_tx_err = "invalid subcarrier allocation"; return MCRX_EINVAL; }
     q->taps = pfb_prototype(K, 13, 60.0f);
     q->dtheta = channel_center_step(N);
+    {   // the windowed-sinc prototype is evaluated at +-t: h[i] == h[pK - i]; the fused kernel relies on it bit for bit
+        const size_t n = q->taps.size();
+        bool sym = n == (size_t)26 * K;
+        for (size_t i = 1; sym && i < n; i++) sym = memcmp(&q->taps[i], &q->taps[n - i], sizeof(float)) == 0;
+        q->taps_symmetric = sym;
+        int dev = 0, ncu = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0) q->ncu = (unsigned)ncu;
+    }
     std::vector<int16_t> dr(M), pr(M);
     for (unsigned i = 0; i < M; i++) { dr[i] = (int16_t)q->od.data_rank[i]; pr[i] = (int16_t)q->od.pilot_rank[i]; }
     int rc;
@@ -416,6 +438,8 @@ extern "C" int mctx_hip_destroy(mctx_hip_t q)
 
 static int tx_launch_sym(mctx_hip_t q, const TxSymArgs &sa, unsigned nsym, unsigned nch, hipStream_t st);
 static int tx_launch_ifft(mctx_hip_t q, const TxSynthArgs &ya, unsigned nblocks, hipStream_t st);
+static int tx_synthesize(mctx_hip_t q, const TxSynthArgs &ya, hipStream_t st);
+static bool tx_fused_ok(mctx_hip_t q, const TxSynthArgs &ya);
 
 static void frame_geometry(mctx_hip_t q, unsigned payload_len, int mod, int fec0, int fec1,
                            unsigned &S_hdr, unsigned &S_pay, unsigned &S)
@@ -463,7 +487,8 @@ extern "C" int mctx_hip_generate(mctx_hip_t q, void *d_iq, size_t nblocks, unsig
     const size_t nsym = (size_t)frames * S;
     TXCHK(hipMalloc((void **)&d_hdr, hdr.size())); TXCHK(hipMalloc((void **)&d_pay, std::max<size_t>(pay.size(), 1)));
     TXCHK(hipMalloc((void **)&d_xsym, (size_t)N * nsym * M * sizeof(float2)));
-    TXCHK(hipMalloc((void **)&d_v, nblocks * K * sizeof(float2)));
+    { TxSynthArgs probe; probe.ft0 = nullptr; probe.hist = 0; probe.out_first = 0;
+      if (!tx_fused_ok(q, probe)) TXCHK(hipMalloc((void **)&d_v, nblocks * K * sizeof(float2))); }      // (inverse-FFT outputs of the two-kernel path)
     TXCHK(hipMemcpyAsync(d_hdr, hdr.data(), hdr.size(), hipMemcpyHostToDevice, st));
     TXCHK(hipMemcpyAsync(d_pay, pay.data(), pay.size(), hipMemcpyHostToDevice, st));
     TxSymArgs sa;
@@ -479,18 +504,7 @@ extern "C" int mctx_hip_generate(mctx_hip_t q, void *d_iq, size_t nblocks, unsig
     ya.taperwin = q->d_taper; ya.xsym = d_xsym; ya.taps = q->d_taps; ya.v = d_v; ya.out = (float2 *)d_iq;
     ya.nblocks = (uint32_t)nblocks; ya.N = N; ya.dtheta = q->dtheta; ya.first_sample_lo = 0; ya.gain = gain;
     ya.ft0 = nullptr; ya.fS = nullptr; ya.xstride = 0; ya.b_first = 0; ya.hist = 0;
-#define TX_IFFT(KK) hipLaunchKernelGGL((txifft_kernel<KK>), dim3((unsigned)nblocks), dim3((KK) / 2 < 64 ? 64 : (KK) / 2), 0, st, ya)
-    switch (K) {
-    case 2: TX_IFFT(2); break;       case 4: TX_IFFT(4); break;     case 8: TX_IFFT(8); break;     case 16: TX_IFFT(16); break;
-    case 32: TX_IFFT(32); break;     case 64: TX_IFFT(64); break;   case 128: TX_IFFT(128); break; case 256: TX_IFFT(256); break;
-    case 512: TX_IFFT(512); break;   case 1024: TX_IFFT(1024); break;
-    default: g_tx_err = "unsupported channel count"; return MCRX_EUNSUPP;
-    }
-#undef TX_IFFT
-    TXCHK(hipGetLastError());
-    const unsigned tb = K < 256 ? 64 : 256;
-    hipLaunchKernelGGL(txfir_kernel, dim3((K + tb - 1) / tb, (unsigned)((nblocks + 7) / 8)), dim3(tb), 0, st, ya, K);
-    TXCHK(hipGetLastError());
+    { int rc = tx_synthesize(q, ya, st); if (rc) return rc; }
     TXCHK(hipStreamSynchronize(st));
     (void)hipFree(d_hdr); (void)hipFree(d_pay); (void)hipFree(d_xsym); (void)hipFree(d_v);
     return MCRX_OK;
@@ -559,7 +573,8 @@ extern "C" int mctx_hip_generate_ragged(mctx_hip_t q, void *d_iq, size_t nblocks
     TXCHK(hipMalloc((void **)&d_hdr, std::max<size_t>(hdr.size(), 1))); TXCHK(hipMalloc((void **)&d_pay, std::max<size_t>(pay.size(), 1)));
     TXCHK(hipMalloc((void **)&d_kind, kind.size())); TXCHK(hipMalloc((void **)&d_desc, desc.size() * sizeof(unsigned long long)));
     TXCHK(hipMalloc((void **)&d_xsym, (size_t)N * T * M * sizeof(float2)));
-    TXCHK(hipMalloc((void **)&d_v, nblocks * K * sizeof(float2)));
+    { TxSynthArgs probe; probe.ft0 = nullptr; probe.hist = 0; probe.out_first = 0;
+      if (!tx_fused_ok(q, probe)) TXCHK(hipMalloc((void **)&d_v, nblocks * K * sizeof(float2))); }
     TXCHK(hipMemcpyAsync(d_hdr, hdr.data(), hdr.size(), hipMemcpyHostToDevice, st));
     TXCHK(hipMemcpyAsync(d_pay, pay.data(), pay.size(), hipMemcpyHostToDevice, st));
     TXCHK(hipMemcpyAsync(d_kind, kind.data(), kind.size(), hipMemcpyHostToDevice, st));
@@ -577,10 +592,7 @@ extern "C" int mctx_hip_generate_ragged(mctx_hip_t q, void *d_iq, size_t nblocks
     ya.taperwin = q->d_taper; ya.xsym = d_xsym; ya.taps = q->d_taps; ya.v = d_v; ya.out = (float2 *)d_iq;
     ya.nblocks = (uint32_t)nblocks; ya.N = N; ya.dtheta = q->dtheta; ya.first_sample_lo = 0; ya.gain = gain;
     ya.ft0 = nullptr; ya.fS = nullptr; ya.xstride = 0; ya.b_first = 0; ya.hist = 0; ya.symkind = d_kind;
-    { int rc = tx_launch_ifft(q, ya, (unsigned)nblocks, st); if (rc) return rc; }
-    const unsigned tb = K < 256 ? 64 : 256;
-    hipLaunchKernelGGL(txfir_kernel, dim3((K + tb - 1) / tb, (unsigned)((nblocks + 7) / 8)), dim3(tb), 0, st, ya, K);
-    TXCHK(hipGetLastError());
+    { int rc = tx_synthesize(q, ya, st); if (rc) return rc; }
     TXCHK(hipStreamSynchronize(st));
     (void)hipFree(d_hdr); (void)hipFree(d_pay); (void)hipFree(d_kind); (void)hipFree(d_desc); (void)hipFree(d_xsym); (void)hipFree(d_v);
     return MCRX_OK;
@@ -688,7 +700,8 @@ extern "C" int mctx_hip_synthesize_tiles(mctx_hip_t q, const void *d_tiles, unsi
     hipStream_t st = (hipStream_t)stream;
     const unsigned K = q->K;
     const size_t tot = lead_blocks + nblocks;
-    if (tot > q->syn_cap) {
+    TxSynthArgs probe; probe.ft0 = nullptr; probe.hist = 0; probe.out_first = (uint32_t)(lead_blocks - keep_blocks);
+    if (!tx_fused_ok(q, probe) && tot > q->syn_cap) {
         if (q->d_synv) { TXCHK(hipDeviceSynchronize()); TXCHK(hipFree(q->d_synv)); q->d_synv = nullptr; q->syn_cap = 0; }
         TXCHK(hipMalloc((void **)&q->d_synv, tot * K * sizeof(float2)));
         q->syn_cap = tot;
@@ -702,11 +715,7 @@ extern "C" int mctx_hip_synthesize_tiles(mctx_hip_t q, const void *d_tiles, unsi
     ya.ft0 = nullptr; ya.fS = nullptr; ya.xstride = 0; ya.b_first = 0; ya.hist = 0;
     ya.tiles = (const float2 *)d_tiles; ya.ntiles = (uint32_t)(tot / 8); ya.cg = q->N / groups;
     ya.out_first = (uint32_t)(lead_blocks - keep_blocks);
-    { int rc = tx_launch_ifft(q, ya, (unsigned)tot, st); if (rc) return rc; }
-    const unsigned tb = K < 256 ? 64 : 256;
-    hipLaunchKernelGGL(txfir_kernel, dim3((K + tb - 1) / tb, (unsigned)((tot + 7) / 8)), dim3(tb), 0, st, ya, K);
-    TXCHK(hipGetLastError());
-    return MCRX_OK;
+    return tx_synthesize(q, ya, st);
 }
 
 
@@ -745,6 +754,50 @@ static int tx_launch_ifft(mctx_hip_t q, const TxSynthArgs &ya, unsigned nblocks,
     default: g_tx_err = "unsupported channel count"; return MCRX_EUNSUPP;
     }
 #undef TX_IFFT
+    TXCHK(hipGetLastError());
+    return MCRX_OK;
+}
+
+// The synthesis bank + oscillator over blocks [ya.out_first, ya.nblocks) of the launch's local block axis: the fused kernel
+// (synth_tile.hpp) where it exists -- a power-of-two K >= 128, a prototype that is bit-for-bit symmetric, the batch / ragged /
+// sharded forms -- else the two-kernel path through `v` (inverse-FFT outputs in HBM).  MCTX_SYNTH=0 forces the latter.
+static bool tx_fused_ok(mctx_hip_t q, const TxSynthArgs &ya)
+{
+    static const int env = getenv("MCTX_SYNTH") ? atoi(getenv("MCTX_SYNTH")) : 1;
+    return env != 0 && q->taps_symmetric && !ya.ft0 && ya.hist == 0 && (q->K == 128 || q->K == 256 || q->K == 512 || q->K == 1024) &&
+           (ya.out_first % 8) == 0;
+}
+template <int KK, int R>
+static int tx_launch_fused(mctx_hip_t q, const TxSynthArgs &ya, hipStream_t st)
+{
+    const size_t lds = syn::Lds<KK, R>::bytes();
+    static bool attr = false;
+    if (!attr) { TXCHK(hipFuncSetAttribute((const void *)syn::synth_kernel<KK, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    const size_t nout = ya.nblocks - ya.out_first;
+    // slab per workgroup: a whole number of workgroup waves over the CUs, at most 512 blocks (28 blocks of lead-in each)
+    const size_t cap = (size_t)q->ncu * (KK >= 1024 ? 1 : 2);
+    const size_t k = (nout + cap * 512 - 1) / (cap * 512);
+    size_t slab = ((nout + cap * k - 1) / (cap * k) + 7) & ~(size_t)7;
+    if (slab < 256) slab = 256;                     // (28 blocks of lead-in per slab)
+    const unsigned grid = (unsigned)((nout + slab - 1) / slab);
+    hipLaunchKernelGGL((syn::synth_kernel<KK, R>), dim3(grid), dim3(KK / 2), lds, st, ya, (uint32_t)slab);
+    TXCHK(hipGetLastError());
+    return MCRX_OK;
+}
+static int tx_synthesize(mctx_hip_t q, const TxSynthArgs &ya, hipStream_t st)
+{
+    if (tx_fused_ok(q, ya)) {
+        switch (q->K) {
+        case 128: return tx_launch_fused<128, 4>(q, ya, st);
+        case 256: return tx_launch_fused<256, 4>(q, ya, st);
+        case 512: { static const int r8 = getenv("MCTX_R8") ? atoi(getenv("MCTX_R8")) : 1; return r8 ? tx_launch_fused<512, 8>(q, ya, st) : tx_launch_fused<512, 4>(q, ya, st); }
+        default:  { static const int r8 = getenv("MCTX_R8") ? atoi(getenv("MCTX_R8")) : 1; return r8 ? tx_launch_fused<1024, 8>(q, ya, st) : tx_launch_fused<1024, 4>(q, ya, st); }
+        }
+    }
+    if (!ya.v) { g_tx_err = "two-kernel synthesis needs its inverse-FFT buffer"; return MCRX_EINVAL; }
+    { int rc = tx_launch_ifft(q, ya, ya.nblocks, st); if (rc) return rc; }
+    const unsigned K = q->K, tb = K < 256 ? 64 : 256;
+    hipLaunchKernelGGL(txfir_kernel, dim3((K + tb - 1) / tb, (unsigned)((ya.nblocks + 7) / 8)), dim3(tb), 0, st, ya, K);
     TXCHK(hipGetLastError());
     return MCRX_OK;
 }

@@ -62,7 +62,9 @@ def check_frames(gpu_frames, ora_frames, rel=REL):
             worst = max(worst, relerr(fg.framesyms, fo.framesyms))
             worst_e = max(worst_e, relerr_elem(fg.framesyms, fo.framesyms))
         assert abs(fg.rssi - fo.rssi) < 1e-3 and abs(fg.cfo - fo.cfo) < 1e-6
-        assert abs(fg.evm - fo.evm) < 0.05 or fo.evm < -60
+        # (error vector magnitude over the header symbols: compared where there was a header -- on a false lock, e.g. an idle
+        #  channel on its neighbours' leakage, it is the magnitude of noise and moves by 0.1 dB with the last bits of the input)
+        assert abs(fg.evm - fo.evm) < 0.05 or fo.evm < -60 or not fo.header_valid
     assert worst <= rel, worst
     assert worst_e <= max(REL_ELEM, 4 * rel), (worst, worst_e)
     WORST["max_norm"] = max(WORST["max_norm"], worst); WORST["element_wise"] = max(WORST["element_wise"], worst_e)
