@@ -68,6 +68,10 @@ def parse():
     ap.add_argument("--chunk-blocks", type=int, default=0, help="split every push into sub-slabs of this many blocks")
     ap.add_argument("--serial", action="store_true", help="time the unpipelined receiver (every kernel in order on one stream)")
     ap.add_argument("--pipeline", action="store_true", help="--gpus 1 through the multi-GPU code path (sharding.Pipeline, exchange = local copy)")
+    ap.add_argument("--exchange", choices=["auto", "torch", "c"], default="auto",
+                    help="multi-GPU path: 'torch' = sharding.Pipeline (torch streams + torch.distributed all_to_all_single: the path the gloo "
+                         "tests drive), 'c' = the C-ABI pipeline (mcrx_hip_pipeline_*: HIP events + grouped ncclSend/ncclRecv).  auto: c on one "
+                         "GPU (--pipeline), torch on several -- the C exchange has only ever run at world = 1 (no multi-GPU lease so far)")
     ap.add_argument("--dry-run-launch", action="store_true", help="start the ranks, rendezvous under gloo, print one JSON line and exit (no GPU needed)")
     return ap.parse_args()
 
@@ -193,7 +197,16 @@ def main():
         torch.cuda.empty_cache()
         period_blocks = tot
         rx = prod.multichannelrx(N, M, cp, taper, channel_first=c0, channel_count=cg, **cfg)
-        pipe = sharding.Pipeline(rx, rank, world, dist, N, Tc, rx.hist_tiles, device=dev)
+        use_c = args.exchange == "c" or (args.exchange == "auto" and world == 1)
+        if use_c:
+            uid = None
+            if world > 1:                               # rank 0's ncclUniqueId to everybody (the C-ABI leaves the transport to the caller)
+                box = [prod.pipeline.unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                uid = box[0]
+            pipe = prod.pipeline(rx, rank, world, Tc, unique_id=uid)
+        else:
+            pipe = sharding.Pipeline(rx, rank, world, dist, N, Tc, rx.hist_tiles, device=dev)
         first_push = [True]
 
         def step(harvest_rx=None):
@@ -210,7 +223,7 @@ def main():
     rx.kernel_stats(reset=True)
     rx.spec_stats(reset=True)
     if pipe is not None:
-        pipe.time_exchange = True
+        pipe.time_exchange(True) if callable(getattr(pipe, "time_exchange", None)) else setattr(pipe, "time_exchange", True)
     t0 = time.perf_counter()
     for k in range(args.steps):
         step()
@@ -218,13 +231,13 @@ def main():
     elapsed = time.perf_counter() - t0
     xchg = None
     if pipe is not None:
-        pipe.time_exchange = False
+        pipe.time_exchange(False) if callable(getattr(pipe, "time_exchange", None)) else setattr(pipe, "time_exchange", False)
         xms, xn = pipe.exchange_ms()
         if xn:
             sent = pipe.bytes_sent_per_round()
             xchg = {"ms_per_round": round(xms / xn, 4), "rounds_timed": xn, "bytes_sent_per_rank_and_round": sent,
                     "GBps_out_of_each_rank": round(sent / (xms / xn * 1e-3) / 1e9, 2) if world > 1 else None,
-                    "what": "RCCL all_to_all_single, HIP events on the exchange stream of rank 0" if world > 1
+                    "what": ("RCCL, HIP events on the exchange stream of rank 0 (%s)" % ("grouped ncclSend/ncclRecv behind the C-ABI" if use_c else "torch.distributed all_to_all_single")) if world > 1
                             else "local copy standing in for the exchange (one GPU)"}
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -296,6 +309,7 @@ def main():
                                    % (args.payload, args.frames, args.slabs),
                        "channels": N, "subcarriers": M, "samples_per_step": samples_per_step,
                        "receiver": "serial (one stream)" if args.serial else "pipelined (3 internal streams, 3 buffer sets)",
+                       "multi_gpu_path": None if pipe is None else ("C-ABI pipeline (mcrx_hip_pipeline_*)" if use_c else "sharding.Pipeline (torch)"),
                        "parallelism": ("round-robin time-sharded channelizer -> all-to-all -> %d channels/GPU, %d rounds per step, "
                                        "exchange overlapped" % (cg, args.rounds)) if world > 1 else "single GPU"},
             "spec_hit_rate": round(adopted / total, 4) if total else None,

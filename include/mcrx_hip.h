@@ -197,6 +197,30 @@ int    mcrx_hip_pfb2_analyze(mcrx_hip_pfb2_t q, const void *d_x, size_t lead_sam
                              uint64_t first_step, void *d_out, void *stream);
 const char *mcrx_hip_pfb2_last_error(void);
 
+/* ---- multi-GPU receive pipeline (one process per GPU) ----------------------------------------
+ * The reference runs one multichannelrx on one host thread (lib/multichannelrx.cc:155-195).  Sharded: sub-slabs of
+ * `sub_blocks` blocks of the wideband stream go round robin to the ranks (sub-slab u -> rank u % world); per round every
+ * rank channelizes its sub-slab into per-destination groups, one grouped ncclSend / ncclRecv exchange over xGMI turns the
+ * time shards into channel shards, and the rank's handle -- created with channel_first / channel_count = its shard of
+ * N / world channels and defer_samples covering a frame -- synchronizes them; rounds overlap on three streams
+ * (channelize(c+1) || exchange(c) || synchronizers(c-1)), events only, nothing waits on the host.  world == 1 is the same
+ * code without the exchange.  RCCL is loaded at run time (librccl.so.1); the caller hands rank 0's 128-byte ncclUniqueId to
+ * every rank (MPI_Bcast, a file, torch.distributed).  Frames surface through the handle (poll / flush / next_frame) on the
+ * rank that owns their channel.  liquid-usrp_amd/sharding.py is the Python mirror of the same schedule. */
+typedef struct mcrx_hip_pipeline_s *mcrx_hip_pipeline_t;
+int      mcrx_hip_pipeline_unique_id(void *id128);                                   /* rank 0 */
+int      mcrx_hip_pipeline_create(mcrx_hip_pipeline_t *out, mcrx_hip_t rx, int rank, int world, const void *unique_id128,
+                                  size_t sub_blocks, unsigned nbuf /* rotating buffer sets, 0 = 3 */);
+/* one round: d_iq_sub = this rank's sub-slab (sub_blocks * 2N cf32 in HBM), d_halo = the 13 blocks in front of it in the
+ * stream (NULL = zeros: the stream's first sub-slab), after_stream = the stream that produced them (NULL: ready) */
+int      mcrx_hip_pipeline_push(mcrx_hip_pipeline_t p, const void *d_iq_sub, const void *d_halo, void *after_stream);
+int      mcrx_hip_pipeline_wait(mcrx_hip_pipeline_t p);                              /* host wait for everything pushed */
+int      mcrx_hip_pipeline_time_exchange(mcrx_hip_pipeline_t p, int on);            /* HIP events around every exchange */
+int      mcrx_hip_pipeline_exchange_ms(mcrx_hip_pipeline_t p, double *total_ms, uint64_t *rounds, int reset);
+uint64_t mcrx_hip_pipeline_bytes_sent_per_round(mcrx_hip_pipeline_t p);             /* to OTHER ranks */
+int      mcrx_hip_pipeline_destroy(mcrx_hip_pipeline_t p);
+const char *mcrx_hip_pipeline_last_error(void);
+
 /* ---- synthetic IQ source: multichanneltx on the GPU ------------------------------------
  * Replaces multichanneltx (lib/multichanneltx.cc:41-242: N x ofdmflexframegen -> 2N-channel
  * synthesis bank, m = 13 -> NCO mix-up) driven by the traffic loop of src/multichannel_tx.cc:

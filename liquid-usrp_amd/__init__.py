@@ -93,6 +93,15 @@ _EXPORTS = {
     "mcrx_hip_pfb2_get_taps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "mcrx_hip_pfb2_analyze": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint64, C.c_void_p, C.c_void_p]),
     "mcrx_hip_pfb2_last_error": (C.c_char_p, []),
+    "mcrx_hip_pipeline_unique_id": (C.c_int, [C.c_void_p]),
+    "mcrx_hip_pipeline_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_uint]),
+    "mcrx_hip_pipeline_push": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mcrx_hip_pipeline_wait": (C.c_int, [C.c_void_p]),
+    "mcrx_hip_pipeline_time_exchange": (C.c_int, [C.c_void_p, C.c_int]),
+    "mcrx_hip_pipeline_exchange_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
+    "mcrx_hip_pipeline_bytes_sent_per_round": (C.c_uint64, [C.c_void_p]),
+    "mcrx_hip_pipeline_destroy": (C.c_int, [C.c_void_p]),
+    "mcrx_hip_pipeline_last_error": (C.c_char_p, []),
     "mctx_hip_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_void_p]),
     "mctx_hip_destroy": (C.c_int, [C.c_void_p]),
     "mctx_hip_blocks_for": (C.c_size_t, [C.c_void_p, C.c_uint, C.c_uint, C.c_int, C.c_int, C.c_int]),
@@ -441,6 +450,63 @@ class TxTraffic(object):
         if getattr(self, "_t", None) is not None and self._t:
             lib().mctx_hip_traffic_destroy(self._t)
             self._t = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class pipeline(object):
+    """The C-ABI multi-GPU receive pipeline (mcrx_hip_pipeline_*: csrc/pipeline.hip) -- sharding.Pipeline's schedule without
+    Python between the stages, the exchange as grouped ncclSend / ncclRecv.  `rx` is this rank's receiver handle (its channel
+    shard, defer_samples set); world > 1: `unique_id` = the 128 bytes rank 0 got from pipeline.unique_id()."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        rc = lib().mcrx_hip_pipeline_unique_id(buf)
+        if rc != MCRX_OK:
+            raise McrxError("mcrx_hip_pipeline_unique_id failed (%d): %s" % (rc, lib().mcrx_hip_pipeline_last_error().decode()))
+        return bytes(buf)
+
+    def __init__(self, rx, rank, world, sub_blocks, unique_id=None, nbuf=3):
+        self._h = C.c_void_p()
+        self.rx, self.rank, self.world, self.Tc = rx, rank, world, sub_blocks
+        uid = None if unique_id is None else (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._chk(lib().mcrx_hip_pipeline_create(C.byref(self._h), rx._h, rank, world, uid, sub_blocks, nbuf), "create")
+        self.rounds = 0
+
+    def _chk(self, rc, what):
+        if rc != MCRX_OK:
+            raise McrxError("mcrx_hip_pipeline_%s failed (%d): %s" % (what, rc, lib().mcrx_hip_pipeline_last_error().decode()))
+
+    def push(self, iq_sub, halo=None, after=None):
+        """`after`: the torch stream that produced iq_sub / halo (default: the current one)."""
+        import torch
+        st = after if after is not None else torch.cuda.current_stream(iq_sub.device)
+        self._chk(lib().mcrx_hip_pipeline_push(self._h, _dptr(iq_sub), _dptr(halo), _stream_ptr(st)), "push")
+        self.rounds += 1
+
+    def wait(self):
+        self._chk(lib().mcrx_hip_pipeline_wait(self._h), "wait")
+
+    def time_exchange(self, on=True):
+        self._chk(lib().mcrx_hip_pipeline_time_exchange(self._h, 1 if on else 0), "time_exchange")
+
+    def exchange_ms(self, reset=True):
+        ms, n = C.c_double(), C.c_uint64()
+        self._chk(lib().mcrx_hip_pipeline_exchange_ms(self._h, C.byref(ms), C.byref(n), 1 if reset else 0), "exchange_ms")
+        return ms.value, int(n.value)
+
+    def bytes_sent_per_round(self):
+        return int(lib().mcrx_hip_pipeline_bytes_sent_per_round(self._h))
+
+    def close(self):
+        if self._h:
+            lib().mcrx_hip_pipeline_destroy(self._h)
+            self._h = C.c_void_p()
 
     def __del__(self):
         try:

@@ -1,0 +1,242 @@
+// pipeline.hip -- the multi-GPU receive pipeline behind the C-ABI (include/mcrx_hip.h: mcrx_hip_pipeline_*).
+//
+// One process per GPU.  Sub-slabs of the wideband stream go round robin to the ranks (sub-slab u -> rank u % G); a round is
+//   A  channelize this rank's sub-slab into per-destination groups            out[g][tile][c][8], channel = g*Cg + c
+//   B  exchange: chunk g of rank r -> chunk r of rank g                         RCCL, grouped ncclSend / ncclRecv over xGMI
+//   C  synchronizer bank of the rank's channel shard over the round             recv[s][tile][c][8] = [tile of the round][c][8]
+// on three HIP streams with `nbuf` rotating buffer sets, linked by events only -- channelize(c+1) || exchange(c) || sync(c-1) --
+// and nothing waits on the host.  This is liquid-usrp_amd/sharding.py's Pipeline (which stays as the mirror the gloo tests
+// drive on CPU) without Python between the stages.  world == 1 runs the same code with no exchange: the channelizer writes
+// straight into the synchronizers' buffer.
+//
+// RCCL is loaded at run time (dlopen "librccl.so.1": the copy a host process already holds -- e.g. PyTorch's -- is reused), so
+// the library has no link-time dependency on it and single-GPU users never touch it.  The caller distributes the 128-byte
+// ncclUniqueId of rank 0 (mcrx_hip_pipeline_unique_id) by whatever means it has (MPI, a file, torch.distributed).
+#include "../../include/mcrx_hip.h"
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_perr;
+int pfail(int code, const std::string &msg) { g_perr = msg; return code; }
+#define PCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return pfail(MCRX_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+#define PRC(x) do { int rc_ = (x); if (rc_ != MCRX_OK) return pfail(rc_, std::string(#x) + ": " + mcrx_hip_last_error()); } while (0)
+
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool load()
+    {
+        if (lib) return true;
+        for (const char *name : { "librccl.so.1", "librccl.so" }) { lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
+        if (!lib) return false;
+#define SYM(f, n) f = reinterpret_cast<decltype(f)>(dlsym(lib, n)); if (!f) return false
+        SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
+        SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv");
+        SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+        return true;
+    }
+};
+Rccl g_rccl;
+#define NCHK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return pfail(MCRX_EHIP, std::string(#x) + ": " + g_rccl.GetErrorString(r_)); } while (0)
+
+constexpr unsigned kMaxBuf = 8;
+
+}  // namespace
+
+struct mcrx_hip_pipeline_s {
+    mcrx_hip_t rx = nullptr;
+    int rank = 0, world = 1;
+    unsigned N = 0, K = 0, cg = 0, hist = 0, nbuf = 3;
+    size_t Tc = 0, tiles = 0, per = 0, hist_elems = 0;         // per: cf32 elements of one (source rank) chunk of a round
+    float *out[kMaxBuf] = {}, *recv[kMaxBuf] = {};             // cf32 buffers as float pairs (world == 1: out[i] aliases recv[i] + history)
+    hipStream_t sA = nullptr, sB = nullptr, sC = nullptr;
+    hipEvent_t evA[kMaxBuf] = {}, evB[kMaxBuf] = {}, evC[kMaxBuf] = {}, ev_after = nullptr;
+    uint64_t ticket[kMaxBuf] = {}; bool has_ticket[kMaxBuf] = {};
+    uint64_t rounds = 0;
+    ncclComm_t comm = nullptr;
+    bool timing = false; std::vector<std::pair<hipEvent_t, hipEvent_t>> xev; size_t xused = 0; double x_ms = 0; uint64_t x_n = 0;
+};
+
+extern "C" const char *mcrx_hip_pipeline_last_error(void) { return g_perr.c_str(); }
+
+extern "C" int mcrx_hip_pipeline_unique_id(void *id128)
+{
+    if (!id128) return pfail(MCRX_EINVAL, "null argument");
+    if (!g_rccl.load()) return pfail(MCRX_EUNSUPP, "librccl.so.1 not found");
+    ncclUniqueId id;
+    NCHK(g_rccl.GetUniqueId(&id));
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    memcpy(id128, &id, sizeof(id));
+    return MCRX_OK;
+}
+
+extern "C" int mcrx_hip_pipeline_destroy(mcrx_hip_pipeline_t p)
+{
+    if (!p) return MCRX_OK;
+    (void)hipDeviceSynchronize();
+    if (p->comm) (void)g_rccl.CommDestroy(p->comm);
+    for (unsigned i = 0; i < kMaxBuf; i++) {
+        if (p->recv[i]) (void)hipFree(p->recv[i]);
+        if (p->world > 1 && p->out[i]) (void)hipFree(p->out[i]);
+        hipEvent_t ev[3] = { p->evA[i], p->evB[i], p->evC[i] };
+        for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+    }
+    for (auto &pr : p->xev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    if (p->ev_after) (void)hipEventDestroy(p->ev_after);
+    hipStream_t ss[3] = { p->sA, p->sB, p->sC };
+    for (hipStream_t s : ss) if (s) (void)hipStreamDestroy(s);
+    delete p;
+    return MCRX_OK;
+}
+
+extern "C" int mcrx_hip_pipeline_create(mcrx_hip_pipeline_t *out, mcrx_hip_t rx, int rank, int world, const void *unique_id128,
+                                        size_t sub_blocks, unsigned nbuf)
+{
+    if (!out || !rx) return pfail(MCRX_EINVAL, "null argument");
+    *out = nullptr;
+    const unsigned N = mcrx_hip_num_channels(rx);
+    if (world < 1 || rank < 0 || rank >= world || N % (unsigned)world) return pfail(MCRX_EINVAL, "ranks must divide the channel count");
+    if (sub_blocks == 0 || sub_blocks % MCRX_TILE) return pfail(MCRX_EINVAL, "sub-slabs are whole tiles of 8 blocks");
+    if (nbuf < 2 || nbuf > kMaxBuf) nbuf = 3;
+    if (world > 1 && !unique_id128) return pfail(MCRX_EINVAL, "world > 1 needs rank 0's ncclUniqueId (mcrx_hip_pipeline_unique_id)");
+    mcrx_hip_pipeline_t p = new mcrx_hip_pipeline_s();
+    auto bail = [&](int rc) { mcrx_hip_pipeline_destroy(p); return rc; };
+    p->rx = rx; p->rank = rank; p->world = world; p->N = N; p->K = 2 * N; p->cg = N / (unsigned)world; p->nbuf = nbuf;
+    p->Tc = sub_blocks; p->tiles = sub_blocks / MCRX_TILE; p->hist = mcrx_hip_history_tiles(rx);
+    p->per = p->tiles * p->cg * MCRX_TILE; p->hist_elems = (size_t)p->hist * p->cg * MCRX_TILE;
+    const size_t recv_elems = p->hist_elems + (size_t)world * p->per;
+    for (unsigned i = 0; i < nbuf; i++) {
+        if (hipMalloc((void **)&p->recv[i], recv_elems * 2 * sizeof(float)) != hipSuccess) return bail(pfail(MCRX_ENOMEM, "hipMalloc failed"));
+        if (hipMemset(p->recv[i], 0, recv_elems * 2 * sizeof(float)) != hipSuccess) return bail(pfail(MCRX_EHIP, "hipMemset failed"));
+        if (world > 1) {
+            if (hipMalloc((void **)&p->out[i], (size_t)world * p->per * 2 * sizeof(float)) != hipSuccess) return bail(pfail(MCRX_ENOMEM, "hipMalloc failed"));
+        } else p->out[i] = p->recv[i] + 2 * p->hist_elems;          // one group = the synchronizers' own layout: no exchange, no copy
+        if (hipEventCreateWithFlags(&p->evA[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&p->evB[i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&p->evC[i], hipEventDisableTiming) != hipSuccess) return bail(pfail(MCRX_EHIP, "hipEventCreate failed"));
+    }
+    if (hipEventCreateWithFlags(&p->ev_after, hipEventDisableTiming) != hipSuccess) return bail(pfail(MCRX_EHIP, "hipEventCreate failed"));
+    if (hipStreamCreateWithFlags(&p->sA, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&p->sB, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&p->sC, hipStreamNonBlocking) != hipSuccess) return bail(pfail(MCRX_EHIP, "hipStreamCreate failed"));
+    if (hipDeviceSynchronize() != hipSuccess) return bail(pfail(MCRX_EHIP, "device synchronize failed"));      // (the zeroed buffers, before the non-blocking streams use them)
+    if (world > 1) {
+        if (!g_rccl.load()) return bail(pfail(MCRX_EUNSUPP, "librccl.so.1 not found"));
+        ncclUniqueId id; memcpy(&id, unique_id128, sizeof(id));
+        ncclResult_t r = g_rccl.CommInitRank(&p->comm, world, id, rank);
+        if (r != ncclSuccess) return bail(pfail(MCRX_EHIP, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r)));
+    }
+    *out = p;
+    return MCRX_OK;
+}
+
+extern "C" int mcrx_hip_pipeline_time_exchange(mcrx_hip_pipeline_t p, int on)
+{
+    if (!p) return pfail(MCRX_EINVAL, "null handle");
+    p->timing = on != 0;
+    return MCRX_OK;
+}
+
+extern "C" int mcrx_hip_pipeline_exchange_ms(mcrx_hip_pipeline_t p, double *total_ms, uint64_t *rounds, int reset)
+{
+    if (!p) return pfail(MCRX_EINVAL, "null handle");
+    for (size_t i = 0; i < p->xused; i++) {
+        float ms = 0;
+        PCHK(hipEventSynchronize(p->xev[i].second));
+        PCHK(hipEventElapsedTime(&ms, p->xev[i].first, p->xev[i].second));
+        p->x_ms += ms; p->x_n++;
+    }
+    p->xused = 0;
+    if (total_ms) *total_ms = p->x_ms;
+    if (rounds) *rounds = p->x_n;
+    if (reset) { p->x_ms = 0; p->x_n = 0; }
+    return MCRX_OK;
+}
+
+extern "C" uint64_t mcrx_hip_pipeline_bytes_sent_per_round(mcrx_hip_pipeline_t p)
+{
+    return p ? (uint64_t)p->per * 8ull * (uint64_t)(p->world - 1) : 0;
+}
+
+// One round: this rank's sub-slab (sub_blocks blocks resident in HBM; d_halo = the 13 blocks in front of it in the stream, NULL
+// = zeros), the exchange, the synchronizers of the rank's channel shard over the round.  `after_stream`: the stream that
+// produced d_iq_sub (NULL: it is ready).  Returns after enqueuing.
+extern "C" int mcrx_hip_pipeline_push(mcrx_hip_pipeline_t p, const void *d_iq_sub, const void *d_halo, void *after_stream)
+{
+    if (!p || !d_iq_sub) return pfail(MCRX_EINVAL, "null argument");
+    const uint64_t c = p->rounds; const unsigned nb = p->nbuf, i = (unsigned)(c % nb);
+    float *out = p->out[i], *recv = p->recv[i], *fresh = recv + 2 * p->hist_elems;
+    // ---- A: channelize into per-destination groups
+    if (after_stream) { PCHK(hipEventRecord(p->ev_after, (hipStream_t)after_stream)); PCHK(hipStreamWaitEvent(p->sA, p->ev_after, 0)); }
+    if (c >= nb) {
+        PCHK(hipStreamWaitEvent(p->sA, p->evB[i], 0));                         // the exchange that last read out[i]
+        if (p->world == 1) {                                                    // out[i] IS recv[i]: also its last readers
+            if (p->has_ticket[i]) PRC(mcrx_hip_stream_wait_launch(p->rx, p->ticket[i], p->sA));
+            PCHK(hipStreamWaitEvent(p->sA, p->evC[(i + 1) % nb], 0));
+        }
+    }
+    const uint64_t first = (c * (uint64_t)p->world + (uint64_t)p->rank) * (uint64_t)p->Tc * (uint64_t)p->K;
+    PRC(mcrx_hip_channelize(p->rx, d_iq_sub, p->Tc, first, d_halo, out, (unsigned)p->world, p->sA));
+    PCHK(hipEventRecord(p->evA[i], p->sA));
+    // ---- B: time shards -> channel shards
+    PCHK(hipStreamWaitEvent(p->sB, p->evA[i], 0));
+    if (p->world > 1) {
+        if (c >= nb) {
+            if (p->has_ticket[i]) PRC(mcrx_hip_stream_wait_launch(p->rx, p->ticket[i], p->sB));     // the synchronizers that last read recv[i]
+            PCHK(hipStreamWaitEvent(p->sB, p->evC[(i + 1) % nb], 0));                              // ... and the history copy that read its tail
+        }
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (p->timing) {
+            if (p->xused == p->xev.size()) {
+                hipEvent_t a, b; PCHK(hipEventCreate(&a)); PCHK(hipEventCreate(&b)); p->xev.emplace_back(a, b);
+            }
+            e0 = p->xev[p->xused].first; e1 = p->xev[p->xused].second; p->xused++;
+            PCHK(hipEventRecord(e0, p->sB));
+        }
+        const size_t cnt = p->per * 2;                                          // floats per peer (RCCL has no complex type)
+        NCHK(g_rccl.GroupStart());
+        for (int g = 0; g < p->world; g++) {
+            NCHK(g_rccl.Send(out + (size_t)g * cnt, cnt, ncclFloat, g, p->comm, p->sB));
+            NCHK(g_rccl.Recv(fresh + (size_t)g * cnt, cnt, ncclFloat, g, p->comm, p->sB));
+        }
+        NCHK(g_rccl.GroupEnd());
+        if (e1) PCHK(hipEventRecord(e1, p->sB));
+    }
+    PCHK(hipEventRecord(p->evB[i], p->sB));
+    // ---- C: synchronizer history in front (tail of the previous round), then the bank over the round
+    PCHK(hipStreamWaitEvent(p->sC, p->evB[i], 0));
+    if (c > 0) {
+        const float *prev = p->recv[(c - 1) % nb];
+        const size_t total = p->hist_elems + (size_t)p->world * p->per;
+        PCHK(hipMemcpyAsync(recv, prev + 2 * (total - p->hist_elems), p->hist_elems * 2 * sizeof(float), hipMemcpyDeviceToDevice, p->sC));
+    }
+    PCHK(hipEventRecord(p->evC[i], p->sC));
+    const int64_t first_chan = (int64_t)(c * (uint64_t)p->world * (uint64_t)p->Tc) - (int64_t)p->hist * MCRX_TILE;
+    const size_t nsamp = (size_t)p->hist * MCRX_TILE + (size_t)p->world * p->Tc;
+    PRC(mcrx_hip_sync(p->rx, recv, (uint64_t)first_chan, nsamp, p->sC));
+    p->ticket[i] = mcrx_hip_launches(p->rx) - 1; p->has_ticket[i] = true;
+    p->rounds++;
+    return MCRX_OK;
+}
+
+extern "C" int mcrx_hip_pipeline_wait(mcrx_hip_pipeline_t p)
+{
+    if (!p) return pfail(MCRX_EINVAL, "null handle");
+    PCHK(hipStreamSynchronize(p->sA)); PCHK(hipStreamSynchronize(p->sB)); PCHK(hipStreamSynchronize(p->sC));
+    return MCRX_OK;
+}
