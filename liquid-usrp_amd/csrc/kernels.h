@@ -68,6 +68,12 @@ struct SyncConsts {
     uint32_t max_payload_len, max_enc_len, max_syms;
     const uint32_t *crc_pos;    // [crc_pos_n][256]: CRC-32 contribution of byte value b at distance d from the end of the message (NULL: none)
     uint32_t crc_pos_n;
+    // de-interleaver as one gather (decode_kernel): the four passes of liquid's packet interleaver are a fixed permutation of
+    // the soft bits for a given coded length e -- soft bit kb of coded byte i comes from bit kb of coded byte il_map[8 (il_off[e] + i) + kb];
+    // il_off[e] = ~0: no map for that length (the passes run in LDS as before).  Built once per handle on the device.
+    const uint32_t *il_off;     // [il_n]
+    const uint16_t *il_map;
+    uint32_t il_n;
     int payload_soft;
 };
 
@@ -183,6 +189,8 @@ struct SyncArgs {
 };
 hipError_t sync_launch(const SyncArgs &a, hipStream_t st);           // full state machine, one wave per channel (general configurations; tail kernel)
 hipError_t sync_launch_tail(const SyncArgs &a, hipStream_t st);      // lean configurations: payloads in progress, to the frame's end (a.tail_only = 1)
+// fill `map` for the `nlen` coded lengths lens[k] at coded-byte offsets offs[k]; lo / hi: scratch of the map's size in bytes / 2 each
+hipError_t ilmap_build_launch(const uint32_t *d_lens, const uint32_t *d_offs, uint32_t nlen, uint8_t *d_lo, uint8_t *d_hi, uint16_t *d_map, hipStream_t st);
 hipError_t sync_launch_walk(const SyncArgs &a, hipStream_t st);      // the lean scout built without a register budget: for streams it has to walk by itself
 hipError_t sync_launch_lean(const SyncArgs &a, hipStream_t st);      // lean scout: acquisition + header + hand-off, one wave per channel
 hipError_t sync_launch_spec(const SyncArgs &a, hipStream_t st);      // speculative acquisition: one wave per (channel, predicted position)

@@ -176,7 +176,7 @@ struct mcrx_hip_s {
     bool spec = false;
     uint32_t *h_hint = nullptr, *d_hint = nullptr;     // pinned, device-mapped: longest coded frame of the last launch
     uint8_t *d_jsoft[MCRX_SLOTS] = {}, *d_jtmp[MCRX_SLOTS] = {};
-    bool scout = true; int scout_rounds = 2; bool narrow_first = true;
+    bool scout = true, scout_tables = true; int scout_rounds = 2; bool narrow_first = true;
     bool rounds_fixed = false; uint32_t walk_seen = 0; int extra_round_for = 0, extra_len = 16; uint64_t extra_end = 0;     // adaptive third round, see launch_sync
     // speculation pays only where frame positions can be predicted: the host compares what the scouts had to walk with what
     // they adopted (host-mapped counters) and switches the speculative rounds off while walking dominates (launch_sync)
@@ -320,6 +320,33 @@ static int build_tables(mcrx_hip_t q)
         c.crc_pos_n = q->max_payload;
     }
     c.payload_soft = q->cfg.payload_soft ? 1 : 0;
+    // De-interleaver gather tables (SyncConsts::il_map) for every coded length the LDS decode path can meet: CRC-32 + outer
+    // Hamming(12,8) or Golay(24,12), no inner code, payloads up to the handle's limit, coded frames up to the 56 KiB of soft bits
+    // a workgroup stages.  16 bytes per coded byte and length: 40 MB at 1200-byte payloads, 120 MB at the default 2048; built on
+    // the device by pushing indices through the inverse interleaver (ofdmsync.hip: ilmap_build_kernel).  MCRX_NO_ILMAP=1: none.
+    c.il_off = nullptr; c.il_map = nullptr; c.il_n = 0;
+    if (q->scout_tables && getenv("MCRX_NO_ILMAP") == nullptr) {
+        const uint32_t cap = std::min<uint32_t>(q->max_enc, 56u * 1024u / 8u);
+        std::vector<uint32_t> off(cap + 1, ~0u), lens, offs;
+        uint64_t total = 0;
+        for (unsigned fec1 = 6; fec1 <= 7; fec1++)
+            for (uint32_t n = 0; n <= q->max_payload; n++) {
+                const uint32_t e = packet_enc_len(n, CRC_32, 1, (int)fec1);
+                if (e == 0 || e > cap || off[e] != ~0u || e >= 65536u) continue;
+                off[e] = (uint32_t)total; lens.push_back(e); offs.push_back((uint32_t)total); total += e;
+            }
+        if (!lens.empty() && total * 8 < (1ull << 32)) {
+            uint16_t *d_map = nullptr; uint8_t *d_lo = nullptr, *d_hi = nullptr; const uint32_t *d_lens = nullptr, *d_offs = nullptr;
+            RC(q->alloc(&d_map, (size_t)total * 8));
+            HIPCHK(hipMalloc((void **)&d_lo, (size_t)total * 8)); HIPCHK(hipMalloc((void **)&d_hi, (size_t)total * 8));
+            RC(q->upload(&d_lens, lens.data(), lens.size())); RC(q->upload(&d_offs, offs.data(), offs.size()));
+            HIPCHK(ilmap_build_launch(d_lens, d_offs, (uint32_t)lens.size(), d_lo, d_hi, d_map, nullptr));
+            HIPCHK(hipDeviceSynchronize());
+            (void)hipFree(d_lo); (void)hipFree(d_hi);
+            RC(q->upload(&c.il_off, off.data(), off.size()));
+            c.il_map = d_map; c.il_n = cap + 1;
+        }
+    }
     return MCRX_OK;
 }
 

@@ -1953,7 +1953,7 @@ __device__ __forceinline__ void launder(SyncArgs &a)
 {
     LAUNDER(c.sctype); LAUNDER(c.S0); LAUNDER(c.S1); LAUNDER(c.s0t); LAUNDER(c.smk); LAUNDER(c.smn); LAUNDER(c.Pfit);
     LAUNDER(c.data_rank); LAUNDER(c.pilot_rank); LAUNDER(c.en_rank); LAUNDER(c.pilot_seq); LAUNDER(c.dft_tw);
-    LAUNDER(c.cod.crc_byte); LAUNDER(c.crc_pos);
+    LAUNDER(c.cod.crc_byte); LAUNDER(c.crc_pos); LAUNDER(c.il_off); LAUNDER(c.il_map);
     LAUNDER(c.cod.crc_zadv); LAUNDER(c.cod.qam16_nb); LAUNDER(c.cod.qam64_nb);
     LAUNDER(chan); LAUNDER(st); LAUNDER(hbits); LAUNDER(R); LAUNDER(soft); LAUNDER(tmpa); LAUNDER(tmpb);
     LAUNDER(syms); LAUNDER(rec); LAUNDER(arena); LAUNDER(sarena); LAUNDER(nrec); LAUNDER(arena_used);
@@ -2396,23 +2396,44 @@ __global__ __launch_bounds__(DK_T) void decode_kernel(SyncArgs a, uint32_t lds_s
         }
         __syncthreads();
         DK_TICK()
-        if (fec1 != 1) {                                                    // coded packets are interleaved (depth 4)
-            unsigned Mi, Ni; il_dims(e1, Mi, Ni);
-            const unsigned dummy = lds_soft_bytes / 8 + msg_bytes / 8;      // one spare group behind the message area
-            il_pass_lds(e1, Mi, Ni + 8, 0x33, dummy);
-            il_pass_lds(e1, Mi, Ni + 4, 0x55, dummy);
-            il_pass_lds(e1, Mi, Ni + 2, 0x0f, dummy);
-            il_pass_lds(e1, Mi, Ni, 0xff, dummy);
+        // coded packets are interleaved (depth 4): where this coded length has a gather table (every length the LDS path's
+        // codes produce up to the handle's payload limit), one pass builds the de-interleaved groups in the second half of
+        // the soft area -- 8 byte reads per coded byte -- instead of four in-place passes of swaps over the first
+        unsigned long long *cur = dk_soft;
+        if (fec1 != 1) {
+            const uint32_t moff = (c.il_off && e1 < c.il_n) ? c.il_off[e1] : ~0u;
+            if (moff != ~0u) {
+                const uint4 *mp = reinterpret_cast<const uint4 *>(c.il_map + (size_t)moff * 8);
+                const uint8_t *sb = reinterpret_cast<const uint8_t *>(dk_soft);
+                unsigned long long *dst = dk_soft + lds_soft_bytes / 8;
+                for (uint32_t i = threadIdx.x; i < e1; i += DK_T) {
+                    const uint4 m = mp[i];
+                    const unsigned src[8] = { m.x & 0xffffu, m.x >> 16, m.y & 0xffffu, m.y >> 16, m.z & 0xffffu, m.z >> 16, m.w & 0xffffu, m.w >> 16 };
+                    unsigned long long v = 0;
+#pragma unroll
+                    for (int kb = 0; kb < 8; kb++) v |= (unsigned long long)sb[8u * DKP(src[kb]) + (unsigned)kb] << (8 * kb);
+                    dst[DKP(i)] = v;
+                }
+                cur = dst;
+                __syncthreads();
+            } else {
+                unsigned Mi, Ni; il_dims(e1, Mi, Ni);
+                const unsigned dummy = 2 * (lds_soft_bytes / 8) + msg_bytes / 8;      // one spare group behind the message area
+                il_pass_lds(e1, Mi, Ni + 8, 0x33, dummy);
+                il_pass_lds(e1, Mi, Ni + 4, 0x55, dummy);
+                il_pass_lds(e1, Mi, Ni + 2, 0x0f, dummy);
+                il_pass_lds(e1, Mi, Ni, 0xff, dummy);
+            }
         }
         DK_TICK()
         // decoded bytes (message + CRC key) go to LDS behind the soft bits; the payload leaves for the
         // frame arena from there, coalesced, by the whole workgroup
-        const uint32_t *w32 = reinterpret_cast<const uint32_t *>(dk_soft);
-        uint8_t *msg = reinterpret_cast<uint8_t *>(dk_soft) + lds_soft_bytes;
+        const uint32_t *w32 = reinterpret_cast<const uint32_t *>(cur);
+        uint8_t *msg = reinterpret_cast<uint8_t *>(dk_soft) + 2 * lds_soft_bytes;
         auto word = [&](uint32_t w) { return w32[2u * DKP(w >> 1) + (w & 1u)]; };            // 12 soft bits = 3 words, group-swizzled
         // one coded byte = 8 soft bits sliced at 127, MSB first
         auto slice = [&](uint32_t g) -> unsigned {
-            const unsigned long long v = dk_soft[DKP(g)];
+            const unsigned long long v = cur[DKP(g)];
             unsigned b = 0;
 #pragma unroll
             for (int kb = 0; kb < 8; kb++) b = (b << 1) | ((((unsigned)(v >> (8 * kb)) & 0xffu) > 127u) ? 1u : 0u);
@@ -2461,7 +2482,7 @@ __global__ __launch_bounds__(DK_T) void decode_kernel(SyncArgs a, uint32_t lds_s
     }
     bool valid = true;
     if (crc_len) {
-        const uint8_t *msg = reinterpret_cast<const uint8_t *>(dk_soft) + lds_soft_bytes;
+        const uint8_t *msg = reinterpret_cast<const uint8_t *>(dk_soft) + 2 * lds_soft_bytes;
         const uint32_t key = ((uint32_t)msg[n_msg] << 24) | ((uint32_t)msg[n_msg + 1] << 16) |
                              ((uint32_t)msg[n_msg + 2] << 8) | (uint32_t)msg[n_msg + 3];
         const bool by_pos = c.crc_pos && n_msg >= 4 && n_msg <= c.crc_pos_n;
@@ -2471,7 +2492,7 @@ __global__ __launch_bounds__(DK_T) void decode_kernel(SyncArgs a, uint32_t lds_s
 #pragma unroll
             for (int wv = 0; wv < DK_T / WV; wv++) tot ^= part[wv];
             valid = ~tot == key;
-        } else valid = crc32_tree(c.cod, 0u, lds_soft_bytes, n_msg) == key;
+        } else valid = crc32_tree(c.cod, 0u, 2 * lds_soft_bytes, n_msg) == key;
     }
     DK_TICK()
     Walker<1> w(a, ch);
@@ -2601,6 +2622,27 @@ __global__ __launch_bounds__(PJ_T) void place_jobs_kernel(SyncArgs a)
         a.arena_used[0] = off; a.arena_used[1] = soff; a.nrec[0] = ridx;
         if (dropped) atomicAdd(a.nrec + 1, dropped);
     }
+}
+
+// The packet de-interleaver as a gather table: push the index of every coded byte (low and high half, as soft-bit groups)
+// through the inverse interleaver itself and read off where each soft bit came from.  One wave per coded length.
+__global__ __launch_bounds__(WV) void ilmap_build_kernel(const uint32_t *lens, const uint32_t *offs, uint8_t *lo, uint8_t *hi, uint16_t *map)
+{
+    const uint32_t e = lens[blockIdx.x];
+    const size_t o = (size_t)offs[blockIdx.x] * 8;
+    uint8_t *xl = lo + o, *xh = hi + o;
+    for (uint32_t i = threadIdx.x; i < 8 * e; i += WV) { xl[i] = (uint8_t)((i >> 3) & 0xff); xh[i] = (uint8_t)((i >> 3) >> 8); }
+    __syncthreads();
+    deinterleave<true>(xl, e, 4);
+    deinterleave<true>(xh, e, 4);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 8 * e; i += WV) map[o + i] = (uint16_t)(xl[i] | ((unsigned)xh[i] << 8));
+}
+hipError_t ilmap_build_launch(const uint32_t *d_lens, const uint32_t *d_offs, uint32_t nlen, uint8_t *d_lo, uint8_t *d_hi, uint16_t *d_map, hipStream_t st)
+{
+    if (!nlen) return hipSuccess;
+    hipLaunchKernelGGL(ilmap_build_kernel, dim3(nlen), dim3(WV), 0, st, d_lens, d_offs, d_lo, d_hi, d_map);
+    return hipGetLastError();
 }
 
 // restart in one launch: synchronizers back to SEEK, channelizer history cleared, result counters zeroed
@@ -2757,7 +2799,7 @@ static uint32_t decode_soft_lds(const SyncArgs &a)
 {
     const uint32_t enc_cap = a.enc_hint ? ((a.enc_hint + 127u) & ~127u) : a.c.max_enc_len;
     size_t soft_lds = (size_t)8 * (enc_cap < a.c.max_enc_len ? enc_cap : a.c.max_enc_len);
-    if (soft_lds > 56 * 1024) soft_lds = 56 * 1024;
+    if (soft_lds > 56 * 1024) soft_lds = 56 * 1024;      // (twice that is the workgroup's soft area: 112 KB + the message)
     if (soft_lds < 4096) soft_lds = 4096;
     return (uint32_t)soft_lds;
 }
@@ -2778,7 +2820,7 @@ hipError_t sync_launch_payload(const SyncArgs &a0, int stage, hipStream_t st)
         if (!fast) return hipSuccess;
         const size_t soft_lds = a.dec_lds_soft;
         const size_t msg_lds = ((size_t)a.c.max_payload_len + 4 + 15) & ~(size_t)15;
-        hipLaunchKernelGGL(decode_kernel, dim3(nj), dim3(DK_T), soft_lds + msg_lds + 16, st, a, (uint32_t)soft_lds, (uint32_t)msg_lds);
+        hipLaunchKernelGGL(decode_kernel, dim3(nj), dim3(DK_T), 2 * soft_lds + msg_lds + 16, st, a, (uint32_t)soft_lds, (uint32_t)msg_lds);      // soft bits as received | de-interleaved | message
         return hipGetLastError();
     }
     if (stage == 3) {                       // the frames on the general list (filled by decode_kernel)

@@ -248,7 +248,7 @@ def test_acquisition_policy_switches_with_the_traffic(oracle, product):
     ora = oracle.MultiChannelRx(N, M, cp, 4)
     ora.execute(x)
     rx = product.multichannelrx(N, M, cp, 4, max_payload_len=200)
-    step = 16 * N * 26                                   # ~ 3 frames per channel and push: > 100 pushes
+    step = 16 * N * 520                                  # 4160 blocks, ~ 3 frames per channel and push: 75 pushes
     for i in range(0, n, step):
         rx.Execute(iq[i:min(i + step, n)])
     rx.Flush()
