@@ -160,7 +160,7 @@ struct mcrx_hip_s {
     uint64_t sarena_cap = 0;
     // per-launch slots
     PayloadJob *d_jobs[MCRX_SLOTS] = {}; uint32_t *d_njobs = nullptr; float2 *d_jR[MCRX_SLOTS] = {};
-    uint32_t *d_gen[MCRX_SLOTS] = {};
+    uint32_t *d_gen[MCRX_SLOTS] = {}, *d_vit[MCRX_SLOTS] = {}; uint32_t vit_cap = 0;
     uint64_t seq = 0;                       // synchronizer launches so far (slot = seq % nslots)
     unsigned nslots = 5;                    // buffer sets in use: the channelizer and the acquisition chain of up to nslots - 1 pushes run ahead of the payload workers
     uint32_t *d_stats = nullptr;            // speculation statistics (SyncArgs::stats)
@@ -329,9 +329,10 @@ static int build_tables(mcrx_hip_t q)
         const uint32_t cap = std::min<uint32_t>(q->max_enc, 56u * 1024u / 8u);
         std::vector<uint32_t> off(cap + 1, ~0u), lens, offs;
         uint64_t total = 0;
-        for (unsigned fec1 = 6; fec1 <= 7; fec1++)
+        static const int outer[3] = { 6, 7, 11 };       // Hamming(12,8), Golay(24,12), r = 1/2 K = 7 convolutional
+        for (int oc = 0; oc < 3; oc++)
             for (uint32_t n = 0; n <= q->max_payload; n++) {
-                const uint32_t e = packet_enc_len(n, CRC_32, 1, (int)fec1);
+                const uint32_t e = packet_enc_len(n, CRC_32, 1, outer[oc]);
                 if (e == 0 || e > cap || off[e] != ~0u || e >= 65536u) continue;
                 off[e] = (uint32_t)total; lens.push_back(e); offs.push_back((uint32_t)total); total += e;
             }
@@ -509,6 +510,8 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
         for (unsigned sl = 0; sl < q->nslots; sl++) {
             if ((rc = q->alloc(&q->d_jobs[sl], q->max_rec))) return bail(rc);
             if ((rc = q->alloc(&q->d_gen[sl], (size_t)q->max_rec + 1))) return bail(rc);
+            q->vit_cap = (uint32_t)std::min<uint64_t>((uint64_t)q->max_rec * ((4ull * q->max_enc + 6 + 959) / 960), 1u << 24);      // trellis blocks of every frame of a launch
+            if ((rc = q->alloc(&q->d_vit[sl], (size_t)q->vit_cap + 1))) return bail(rc);
             if ((rc = q->alloc(&q->d_jR[sl], (size_t)q->max_rec * M))) return bail(rc);
             if ((rc = q->alloc(&q->d_jsoft[sl], (size_t)q->max_rec * 8 * q->max_enc))) return bail(rc);
             if ((rc = q->alloc(&q->d_jtmp[sl], (size_t)q->max_rec * 2 * (q->max_enc + 16)))) return bail(rc);
@@ -652,7 +655,7 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     a.vit_off = 0;
     a.scout = q->scout ? 1 : 0;
     a.jobs = q->d_jobs[slot]; a.njobs = q->d_njobs + slot; a.njobs_next = q->d_njobs + next; a.max_jobs = q->max_rec;
-    a.gen_list = q->d_gen[slot]; a.dec_lds_soft = 0;
+    a.gen_list = q->d_gen[slot]; a.dec_lds_soft = 0; a.vit_list = q->d_vit[slot]; a.vit_cap = q->vit_cap;
     a.jR = q->d_jR[slot]; a.jsoft = q->d_jsoft[slot]; a.jtmp = q->d_jtmp[slot];
     a.stats = q->d_stats;
     a.hint = q->d_hint; a.enc_hint = (q->h_hint && q->d_hint) ? *(volatile uint32_t *)q->h_hint : 0u;

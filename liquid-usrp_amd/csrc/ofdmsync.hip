@@ -400,6 +400,66 @@ __device__ void conv27_decode_wave(const VitSym sy, unsigned n_, uint8_t *dec, u
     }
 }
 
+// The same decoder, one BLOCK of VIT_B steps per wave, so that a frame's trellis is worked on by all its blocks at once
+// (viterbi_blocks_kernel) instead of three serial passes of one wave.  A block does not know the path metrics at its first
+// step nor the survivor's state at its last: it starts VIT_W steps early from equal metrics and runs VIT_W steps past its
+// end, tracing back from the best state there.  After a few constraint lengths every survivor has merged into the one the
+// full decoder keeps (K = 7: ~35 steps; VIT_W = 192 is 27 K), from there on the metric DIFFERENCES, hence every decision
+// and every tie, are the full decoder's -- the first block starts from the true metrics and the last one ends in the true
+// state 0.  Byte-equal to oracle/ll_fec.c's full traceback in tests/test_gpu_parity.py::test_convolutional_* and the soak.
+#define VIT_W 192u
+__device__ void conv27_decode_block(const VitSym sy, unsigned n_, unsigned b_, uint8_t *dec, unsigned long long *lds)
+{
+    const int s = lane_id();
+    const unsigned n = (unsigned)__builtin_amdgcn_readfirstlane((int)n_), b = (unsigned)__builtin_amdgcn_readfirstlane((int)b_);
+    const unsigned T = 8 * n + 6;
+    const unsigned t0 = b * VIT_B;
+    if (t0 >= T) return;
+    const unsigned t1 = t0 + VIT_B < T ? t0 + VIT_B : T;
+    const unsigned tw = t0 >= VIT_W ? t0 - VIT_W : 0u, te = t1 + VIT_W < T ? t1 + VIT_W : T;
+    int pm = (tw == 0u && s) ? (1 << 20) : 0;               // stream start: the encoder's state 0; elsewhere: nothing known
+    if (tw < t0) pm = vit_forward<false>(sy, tw, t0, T, pm, nullptr);
+    pm = vit_forward<true>(sy, t0, te, T, pm, lds);         // decision words of steps t0 .. te-1
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    unsigned state = 0;                                     // te == T: the tail bits return the encoder to state 0
+    if (te < T) {
+        int mn = pm;
+#pragma unroll
+        for (int h = 32; h >= 1; h >>= 1) { const int o = __shfl_xor(mn, h, WV); mn = o < mn ? o : mn; }
+        const unsigned lane = (unsigned)__builtin_ctzll(__ballot(pm == mn));
+        state = rotl6(lane, te % 6u);                       // the lane layout of vit_forward at time te
+    }
+    for (unsigned c1 = te; c1 > t0;) {
+        const unsigned c0 = (c1 - 1) & ~63u, cn = c1 - c0;
+        const unsigned long long w = (unsigned)s < cn ? lds[c0 - t0 + s] : 0ull;
+        unsigned r1 = (c0 + cn) % 6;
+        const unsigned wlo = (unsigned)w, whi = (unsigned)(w >> 32);
+#define VIT_BACK(K)                                                                                            \
+        {                                                                                                  \
+            const unsigned long long wk = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)whi, (int)(K)) << 32) | \
+                                          (unsigned)__builtin_amdgcn_readlane((int)wlo, (int)(K));          \
+            const unsigned ln = ((state * 65u) >> r1) & 63u;                                                \
+            state = (state >> 1) | ((unsigned)((wk >> ln) & 1ull) << 5);                                   \
+            r1 = r1 ? r1 - 1u : 5u;                                                                        \
+        }
+        unsigned k = cn;
+        while (k & 7u) { k--; VIT_BACK(k) }
+        unsigned long long bytes = 0;
+        while (k) {
+            k -= 8;
+            const unsigned s1 = state;
+            VIT_BACK(k + 7) VIT_BACK(k + 6) VIT_BACK(k + 5) VIT_BACK(k + 4) VIT_BACK(k + 3) VIT_BACK(k + 2)
+            const unsigned s2 = state;
+            VIT_BACK(k + 1) VIT_BACK(k)
+            bytes |= (unsigned long long)(((s2 & 3u) << 6) | (s1 & 63u)) << k;
+        }
+#undef VIT_BACK
+        const unsigned by = (c0 >> 3) + (unsigned)s;
+        if (c0 < t1 && s < 8 && by < n) dec[by] = (uint8_t)(bytes >> (8 * (unsigned)s));      // (chunks past t1 only steer the traceback)
+        c1 = c0;
+    }
+}
+
 // hard decode `enc` -> `dec` (dec_len bytes), lanes in parallel
 __device__ void fec_decode_hard(unsigned fs, unsigned n, const uint8_t *enc, uint8_t *dec)
 {
@@ -449,7 +509,8 @@ __device__ void soft_pack(const uint8_t *soft, unsigned nbytes, uint8_t *out, bo
 // (8-byte aligned).  Result message in tmpb[0..n_msg); returns validity.
 __device__ bool packet_decode(const CodingDev cod, bool soft_mode, bool scrambled, unsigned n_msg,
                               unsigned crc, unsigned fec0, unsigned fec1,
-                              uint8_t *soft, uint8_t *tmpa, uint8_t *tmpb, unsigned long long *vit_lds = nullptr, unsigned ablate = 0)
+                              uint8_t *soft, uint8_t *tmpa, uint8_t *tmpb, unsigned long long *vit_lds = nullptr, unsigned ablate = 0,
+                              bool pre_done = false)      // pre_done: soft de-interleaved and Viterbi-decoded into tmpa already (decode_kernel + viterbi_blocks_kernel)
 {
     const int l = lane_id();
     const unsigned crc_len = (crc == 6) ? 4u : 0u;
@@ -461,6 +522,8 @@ __device__ bool packet_decode(const CodingDev cod, bool soft_mode, bool scramble
         if (!(ablate & 8)) deinterleave<true>(soft, e1, d1);
         if (!(ablate & 16)) for (unsigned i = (unsigned)l; i < e0; i += WV) tmpa[i] = (uint8_t)h128_dec_soft_fast(soft + 12 * (size_t)i);
         __syncthreads();
+    } else if (soft_mode && fec1 == 11 && pre_done) {
+        // (nothing to do here)
     } else if (soft_mode && fec1 == 11) {
         if (!(ablate & 64)) deinterleave<true>(soft, e1, d1);
         if (!(ablate & 128)) conv27_decode_wave(VitSym{ soft, false }, e0, tmpa, reinterpret_cast<uint16_t *>(tmpb), vit_lds);   // checkpoints: 128 * ceil((8 e0 + 6) / 960) bytes <= max_enc_len + 16 (mcrx_hip_create keeps max_enc_len >= 256)
@@ -1957,7 +2020,7 @@ __device__ __forceinline__ void launder(SyncArgs &a)
     LAUNDER(c.cod.crc_zadv); LAUNDER(c.cod.qam16_nb); LAUNDER(c.cod.qam64_nb);
     LAUNDER(chan); LAUNDER(st); LAUNDER(hbits); LAUNDER(R); LAUNDER(soft); LAUNDER(tmpa); LAUNDER(tmpb);
     LAUNDER(syms); LAUNDER(rec); LAUNDER(arena); LAUNDER(sarena); LAUNDER(nrec); LAUNDER(arena_used);
-    LAUNDER(jobs); LAUNDER(njobs); LAUNDER(jR); LAUNDER(jsoft); LAUNDER(jtmp);
+    LAUNDER(jobs); LAUNDER(njobs); LAUNDER(jR); LAUNDER(jsoft); LAUNDER(jtmp); LAUNDER(vit_list);
     LAUNDER(spec); LAUNDER(spec_R); LAUNDER(pred); LAUNDER(pred_n); LAUNDER(stats); LAUNDER(walk_hint);
 }
 #undef LAUNDER
@@ -2382,7 +2445,39 @@ __global__ __launch_bounds__(DK_T) void decode_kernel(SyncArgs a, uint32_t lds_s
     // LDS path: soft decisions, no inner code, outer code Hamming(12,8) (soft decoder), Golay(24,12) (sliced) or none
     const bool lds_path = c.payload_soft && fec0 == 1 && (fec1 == 6 || fec1 == 7 || fec1 == 1) && 8u * e1 <= lds_soft_bytes && !(a.no_fast & 8);
     if (!lds_path) {                        // everything else: onto the list of decode_general_kernel (one wave per frame, in place in HBM)
-        if (threadIdx.x == 0 && a.gen_list) { uint32_t *gl = as_global(a.gen_list); gl[1u + atomicAdd(gl, 1u)] = j; }
+        // ... the K = 7 convolutional code as the outer code first gets its soft bits de-interleaved here (the same gather as below,
+        // written back in place) and its trellis blocks onto the list of viterbi_blocks_kernel: the general decoder then finds
+        // the decoded bytes waiting
+        const uint32_t moff = (c.il_off && e1 < c.il_n) ? c.il_off[e1] : ~0u;
+        const bool conv_pre = c.payload_soft && fec1 == 11 && a.vit_list && moff != ~0u && 8u * e1 <= lds_soft_bytes && !(a.no_fast & 8);
+        if (conv_pre) {
+            const unsigned long long *g64 = reinterpret_cast<const unsigned long long *>(soft);
+            for (uint32_t i = threadIdx.x; i < e1; i += DK_T) dk_soft[DKP(i)] = g64[i];
+            __syncthreads();
+            const uint4 *mp = reinterpret_cast<const uint4 *>(c.il_map + (size_t)moff * 8);
+            const uint8_t *sb = reinterpret_cast<const uint8_t *>(dk_soft);
+            unsigned long long *o64 = reinterpret_cast<unsigned long long *>(soft);
+            for (uint32_t i = threadIdx.x; i < e1; i += DK_T) {
+                const uint4 m = mp[i];
+                const unsigned src[8] = { m.x & 0xffffu, m.x >> 16, m.y & 0xffffu, m.y >> 16, m.z & 0xffffu, m.z >> 16, m.w & 0xffffu, m.w >> 16 };
+                unsigned long long v = 0;
+#pragma unroll
+                for (int kb = 0; kb < 8; kb++) v |= (unsigned long long)sb[8u * DKP(src[kb]) + (unsigned)kb] << (8 * kb);
+                o64[i] = v;
+            }
+        }
+        if (threadIdx.x == 0 && a.gen_list) {
+            uint32_t *gl = as_global(a.gen_list);
+            uint32_t tag = j;
+            if (conv_pre) {
+                const uint32_t e0 = fec_enc_len_d(fec0, n0), nblk = (8u * e0 + 6u + VIT_B - 1u) / VIT_B;
+                uint32_t *vl = as_global(a.vit_list);
+                const uint32_t at = atomicAdd(vl, nblk);
+                if (at + nblk <= a.vit_cap) { for (uint32_t b = 0; b < nblk; b++) vl[1u + at + b] = (j << 6) | b; tag |= 0x80000000u; }
+                else atomicSub(vl, nblk);             // (list full: this frame's trellis stays with the general decoder's single wave)
+            }
+            gl[1u + atomicAdd(gl, 1u)] = tag;
+        }
         return;
     }
     if (lds_path) {
@@ -2508,6 +2603,25 @@ __global__ __launch_bounds__(DK_T) void decode_kernel(SyncArgs a, uint32_t lds_s
 // The frames the LDS path does not take (hard decisions, an inner code, the convolutional code, frames longer than the
 // LDS sized for this launch): one wave per frame decodes in place in HBM with the walker's general decoder -- a separate
 // kernel so that its registers (the Viterbi decoder's among them) do not set the occupancy of the one above.
+// the trellis blocks decode_kernel listed: one wave each (conv27_decode_block)
+__global__ __launch_bounds__(WV) void viterbi_blocks_kernel(SyncArgs a)
+{
+    launder(a);
+    if (!a.vit_list) return;
+    const uint32_t *vl = as_global(a.vit_list);
+    uint32_t nb = vl[0];
+    if (nb > a.vit_cap) nb = a.vit_cap;
+    const SyncConsts &c = a.c;
+    for (uint32_t k = blockIdx.x; k < nb; k += gridDim.x) {
+        const uint32_t ent = vl[1 + k], j = ent >> 6, b = ent & 63u;
+        const uint32_t n_msg = a.jobs[j].s.payload_len, crc = a.jobs[j].s.check, fec0 = a.jobs[j].s.fec0;
+        const uint32_t n0 = n_msg + ((crc == 6) ? 4u : 0u), e0 = fec_enc_len_d(fec0, n0);
+        const size_t tstride = (size_t)c.max_enc_len + 16;
+        conv27_decode_block(VitSym{ a.jsoft + (size_t)j * 8 * c.max_enc_len, false }, e0, b, a.jtmp + (size_t)j * 2 * tstride, dk_soft);
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(WV) void decode_general_kernel(SyncArgs a)
 {
     launder(a);
@@ -2516,14 +2630,15 @@ __global__ __launch_bounds__(WV) void decode_general_kernel(SyncArgs a)
     if (ng > a.max_jobs) ng = a.max_jobs;
     const SyncConsts &c = a.c;
     for (uint32_t k = blockIdx.x; k < ng; k += gridDim.x) {        // (a handful of workgroups; the list is normally empty)
-        const uint32_t j = gl[1 + k];
+        const bool pre_done = (gl[1 + k] & 0x80000000u) != 0;      // de-interleaved and Viterbi-decoded already
+        const uint32_t j = gl[1 + k] & 0x7fffffffu;
         const uint32_t ch = a.jobs[j].ch;
         if (ch >= a.nch || a.jobs[j].arena_off == ~0ull) continue;
         const uint32_t n_msg = a.jobs[j].s.payload_len, crc = a.jobs[j].s.check, fec0 = a.jobs[j].s.fec0, fec1 = a.jobs[j].s.fec1;
         const size_t tstride = (size_t)c.max_enc_len + 16;
         uint8_t *soft = a.jsoft + (size_t)j * 8 * c.max_enc_len;
         uint8_t *tmpa = a.jtmp + (size_t)j * 2 * tstride, *tmpb = tmpa + tstride;
-        const bool valid = packet_decode(c.cod, c.payload_soft != 0, false, n_msg, crc, fec0, fec1, soft, tmpa, tmpb, dk_soft, MCRX_DEVEL_ABLATE(a));   // 8 KB of LDS: the Viterbi block scratch
+        const bool valid = packet_decode(c.cod, c.payload_soft != 0, false, n_msg, crc, fec0, fec1, soft, tmpa, tmpb, dk_soft, MCRX_DEVEL_ABLATE(a), pre_done);   // 8 KB of LDS: the Viterbi block scratch
         Walker<1> w(a, ch);
         const PayloadJob job = a.jobs[j];
         if (!w.bind_job(j, job)) continue;
@@ -2545,7 +2660,7 @@ __global__ __launch_bounds__(PJ_T) void place_jobs_kernel(SyncArgs a)
     __shared__ uint32_t need_l[PJ_CAP];             // symbol-arena bytes of job j (0 = void slot: a live frame always has symbols)
     __shared__ uint16_t pay_l[PJ_CAP];              // payload-arena bytes of job j in 16-byte units
     __shared__ uint32_t maxenc;
-    if (threadIdx.x == 0) { maxenc = 0; if (a.gen_list) as_global(a.gen_list)[0] = 0; }
+    if (threadIdx.x == 0) { maxenc = 0; if (a.gen_list) as_global(a.gen_list)[0] = 0; if (a.vit_list) as_global(a.vit_list)[0] = 0; }
     __syncthreads();
     launder(a);
     a.gen_list = a.gen_list ? as_global(a.gen_list) : nullptr;
@@ -2825,6 +2940,7 @@ hipError_t sync_launch_payload(const SyncArgs &a0, int stage, hipStream_t st)
     }
     if (stage == 3) {                       // the frames on the general list (filled by decode_kernel)
         if (!fast) return hipSuccess;
+        if (a.vit_list) hipLaunchKernelGGL(viterbi_blocks_kernel, dim3(8192), dim3(WV), (size_t)(VIT_B + VIT_W) * 8, st, a);
         hipLaunchKernelGGL(decode_general_kernel, dim3(nj < 4096 ? nj : 4096), dim3(WV), (size_t)VIT_B * 8, st, a);
         return hipGetLastError();
     }
