@@ -15,7 +15,10 @@ with every frame's record + payload copied to pinned host memory and walked thro
 (the reference's callbacks fire inside Execute, lib/multichannelrx.cc:193-194); `value_with_full_harvest` also
 moves the equalised symbols (59 KB per frame: host-link bound).
 
---gpus N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling.  Sub-slabs of the stream go
+`value_aperiodic` is the same loop on ragged traffic -- every frame its own length (uniform in [64, payload] bytes), irregular
+pauses, the recipe of src/multichannel_txrx.cc:227-267 -- where frame positions cannot be predicted.
+
+--gpus N > 1 (one rank per GPU; the script starts its own ranks when it was not launched by torch.distributed.run): weak scaling.  Sub-slabs of the stream go
 round robin to the ranks; per round every rank channelizes its sub-slab, one RCCL all-to-all turns the
 time-sharded output into channel shards (512/N channels per GPU), the rank synchronizes its shard; rounds are
 pipelined (channelize(c+1) || all_to_all(c) || synchronizers(c-1), liquid_usrp_amd/sharding.py).
