@@ -8,7 +8,9 @@
 //     order (frame end time, then channel index), not synchronously per sample;
 //   * samples are consumed in whole tiles of 8 channelizer blocks (16*N samples); a shorter
 //     tail waits for more input;
-//   * the reference's BST_DEBUG file dump at destruction (lib/multichannelrx.cc:118-122) is gone.
+//   * the reference's BST_DEBUG file dump at destruction (lib/multichannelrx.cc:118-122) is liquid's internal state; with
+//     $MCRX_DEBUG_DIR set the destructor writes the same file names (framesync_channel%u.m) with each channel's frame count
+//     and the equalised symbols of its last frame.
 #ifndef LIQUID_USRP_AMD_MULTICHANNELRX_H
 #define LIQUID_USRP_AMD_MULTICHANNELRX_H
 

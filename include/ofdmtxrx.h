@@ -8,14 +8,18 @@
 //   * callbacks fire on the receiver thread at flush points (every rx batch and in stop_rx()), not per sample;
 //   * a frame's samples are produced by one GPU call in assemble_frame()/transmit_packet(); write_symbol()
 //     hands them out one M+cp symbol at a time exactly as ofdmflexframegen_writesymbol would;
-//   * the "blocking" receiver worker (samples edited by another thread before synchronisation,
-//     lib/ofdmtxrx.cc:642-739) is not provided: the second constructor accepts the flag and ignores it;
-//   * debug_enable() has no file dump.
+//   * debug_enable(): no liquid-internal dump; with $MCRX_DEBUG_DIR set, the destructor writes the equalised symbols of
+//     the frames received while debugging was on to $MCRX_DEBUG_DIR/ofdmtxrx_framesyms.m (a stand-in for
+//     ofdmflexframesync_debug_print, lib/ofdmtxrx.cc:241-242).
+// The "blocking" receiver worker (lib/ofdmtxrx.cc:642-739; second constructor, _blocking_rx_worker = true) is provided with
+// the reference's public handshake: the worker fills *rx_buffer under rx_buffer_mutex, signals rx_buffer_filled_cond and
+// waits on rx_buffer_modified_cond; another thread edits the samples and signals that; then they are synchronized.
 #ifndef LIQUID_USRP_AMD_OFDMTXRX_H
 #define LIQUID_USRP_AMD_OFDMTXRX_H
 
 #include <complex>
 #include <vector>
+#include <pthread.h>
 #include <liquid/liquid.h>
 #include <uhd/usrp/multi_usrp.hpp>
 
@@ -63,11 +67,17 @@ public:
     unsigned int fgbuffer_len;                      // M + cp_len
     std::complex<float> *fgbuffer;
 
+    // receiver objects of the blocking worker (public in the reference: include/ofdmtxrx.h:134-137)
+    std::vector<std::complex<float> > *rx_buffer;   // the packet the worker has just received (valid between the two conditions)
+    pthread_mutex_t rx_buffer_mutex;
+    pthread_cond_t  rx_buffer_filled_cond;          // worker -> editor: *rx_buffer holds a packet
+    pthread_cond_t  rx_buffer_modified_cond;        // editor -> worker: go on, synchronize it
+
 private:
     ofdmtxrx(const ofdmtxrx &);
     ofdmtxrx &operator=(const ofdmtxrx &);
     void init(unsigned int _M, unsigned int _cp_len, unsigned int _taper_len, unsigned char *_p,
-              framesync_callback _callback, void *_userdata);
+              framesync_callback _callback, void *_userdata, bool _blocking);
     void send_buffer();
     struct impl;
     impl *pimpl;

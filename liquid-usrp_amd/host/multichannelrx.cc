@@ -2,6 +2,7 @@
 // Mirrors liquid-usrp's lib/multichannelrx.cc: ctor :45-104, dtor :107-132, Reset :135-153,
 // Execute :155-182; the DSP itself runs in the gfx950 kernels.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -15,6 +16,9 @@ struct multichannelrx::impl {
     std::vector<void *> userdata;
     std::vector<framesync_callback> callback;
     std::vector<unsigned char> payload;     // callbacks get mutable buffers, like liquid's
+    const char *debug_dir;                                          // $MCRX_DEBUG_DIR (NULL: no dump at destruction)
+    std::vector<std::vector<std::complex<float> > > debug_syms;    // [channel]: equalised symbols of its last frame
+    std::vector<unsigned long> debug_frames;
 };
 
 multichannelrx::multichannelrx(unsigned int _num_channels, unsigned int _M, unsigned int _cp_len,
@@ -23,6 +27,8 @@ multichannelrx::multichannelrx(unsigned int _num_channels, unsigned int _M, unsi
     : num_channels(_num_channels), pimpl(new impl)
 {
     pimpl->h = NULL;
+    pimpl->debug_dir = getenv("MCRX_DEBUG_DIR");
+    pimpl->debug_syms.resize(_num_channels); pimpl->debug_frames.assign(_num_channels, 0);
     mcrx_hip_config cfg;
     memset(&cfg, 0, sizeof(cfg));
     cfg.struct_size = sizeof(cfg);
@@ -46,6 +52,22 @@ multichannelrx::~multichannelrx()
         Deliver();
         mcrx_hip_destroy(pimpl->h);
     }
+    if (pimpl->debug_dir) {
+        // the reference, built with BST_DEBUG, leaves liquid's internal dump of every synchronizer behind
+        // (ofdmflexframesync_debug_print, lib/multichannelrx.cc:118-122: "framesync_channel%u.m"); here, with MCRX_DEBUG_DIR
+        // set, the same file names hold what this receiver can show: the equalised symbols of each channel's last frame
+        for (unsigned int i = 0; i < num_channels; i++) {
+            char fn[1024];
+            snprintf(fn, sizeof(fn), "%s/framesync_channel%u.m", pimpl->debug_dir, i);
+            FILE *fid = fopen(fn, "w");
+            if (!fid) continue;
+            fprintf(fid, "%% channel %u: %lu frames received; equalised payload symbols of the last one\nclear all; close all;\n", i, pimpl->debug_frames[i]);
+            fprintf(fid, "framesyms = [");
+            for (const auto &v : pimpl->debug_syms[i]) fprintf(fid, " %.6e%+.6ej", v.real(), v.imag());
+            fprintf(fid, " ];\nfigure; plot(real(framesyms), imag(framesyms), 'x'); axis square; grid on;\n");
+            fclose(fid);
+        }
+    }
     delete pimpl;
 }
 
@@ -53,6 +75,11 @@ void multichannelrx::Deliver()
 {
     mcrx_frame f;
     while (mcrx_hip_next_frame(pimpl->h, &f) == 1) {
+        if (pimpl->debug_dir && f.channel < num_channels && f.num_framesyms) {      // keep the last frame of every channel for the dump
+            const std::complex<float> *p = reinterpret_cast<const std::complex<float> *>(f.framesyms);
+            pimpl->debug_syms[f.channel].assign(p, p + f.num_framesyms);
+            pimpl->debug_frames[f.channel]++;
+        }
         if (f.channel >= num_channels || !pimpl->callback[f.channel]) continue;
         framesyncstats_s st;
         st.evm = f.evm; st.rssi = f.rssi; st.cfo = f.cfo;

@@ -5,8 +5,10 @@
 #include <cmath>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <string>
 #include <thread>
 
 #include "ofdmtxrx.h"
@@ -29,6 +31,9 @@ struct ofdmtxrx::impl {
     std::atomic<bool> rx_running, rx_thread_running;
     bool rx_idle;
     bool debug_enabled;
+    bool blocking;
+    ofdmtxrx *self;
+    std::vector<std::vector<std::complex<float> > > debug_syms;      // equalised symbols of the frames seen while debug_enable()d
 
     void deliver()
     {
@@ -42,6 +47,9 @@ struct ofdmtxrx::impl {
             st.mod_scheme = f.mod_scheme; st.mod_bps = f.mod_bps; st.check = f.check; st.fec0 = f.fec0; st.fec1 = f.fec1;
             unsigned char header[8];
             memcpy(header, f.header, 8);
+            if (debug_enabled && f.num_framesyms && debug_syms.size() < 4096)
+                debug_syms.emplace_back(reinterpret_cast<const std::complex<float> *>(f.framesyms),
+                                        reinterpret_cast<const std::complex<float> *>(f.framesyms) + f.num_framesyms);
             std::vector<unsigned char> payload(f.payload, f.payload + f.payload_len);
             callback(header, f.header_valid, payload.empty() ? NULL : &payload[0], f.payload_len, f.payload_valid, st, userdata);
         }
@@ -60,13 +68,24 @@ struct ofdmtxrx::impl {
                 rx_idle = false;
             }
             while (rx_running) {
-                size_t n = usrp_rx->get_device()->recv(&buffer.front(), buffer.size(), md,
+                size_t n;
+                if (blocking) {
+                    // lib/ofdmtxrx.cc:686-722: fill the public buffer under its mutex, tell the editor, wait until it is done
+                    pthread_mutex_lock(&self->rx_buffer_mutex);
+                    self->rx_buffer = &buffer;
+                    n = usrp_rx->get_device()->recv(&buffer.front(), buffer.size(), md,
+                                                    uhd::io_type_t::COMPLEX_FLOAT32, uhd::device::RECV_MODE_ONE_PACKET);
+                    pthread_cond_signal(&self->rx_buffer_filled_cond);
+                    if (rx_running) pthread_cond_wait(&self->rx_buffer_modified_cond, &self->rx_buffer_mutex);
+                } else
+                n = usrp_rx->get_device()->recv(&buffer.front(), buffer.size(), md,
                                                        uhd::io_type_t::COMPLEX_FLOAT32, uhd::device::RECV_MODE_ONE_PACKET);
                 // the synchronizer sees every sample in order (lib/ofdmtxrx.cc:620-626); frames surface per batch
                 std::lock_guard<std::recursive_mutex> fl(fs_mu);
                 int rc = mcrx_hip_execute_host(fs, reinterpret_cast<const float *>(&buffer.front()), n);
                 if (rc != MCRX_OK && rc != MCRX_EOVERFLOW) { fprintf(stderr, "ofdmtxrx rx worker: %s\n", mcrx_hip_last_error()); rx_running = false; }
                 deliver();
+                if (blocking) pthread_mutex_unlock(&self->rx_buffer_mutex);
             }
             std::lock_guard<std::recursive_mutex> fl(fs_mu);
             mcrx_hip_flush(fs);
@@ -76,17 +95,19 @@ struct ofdmtxrx::impl {
 };
 
 void ofdmtxrx::init(unsigned int _M, unsigned int _cp_len, unsigned int _taper_len, unsigned char *_p,
-                    framesync_callback _callback, void *_userdata)
+                    framesync_callback _callback, void *_userdata, bool _blocking)
 {
     if (_M < 8) { fprintf(stderr, "error: ofdmtxrx::ofdmtxrx(), number of subcarriers must be at least 8\n"); throw 0; }
     if (_cp_len < 1) { fprintf(stderr, "error: ofdmtxrx::ofdmtxrx(), cyclic prefix length must be at least 1\n"); throw 0; }
     if (_taper_len > _cp_len) { fprintf(stderr, "error: ofdmtxrx::ofdmtxrx(), taper length cannot exceed cyclic prefix length\n"); throw 0; }
     pimpl = new impl;
     pimpl->M = _M; pimpl->cp_len = _cp_len; pimpl->taper_len = _taper_len;
-    pimpl->fg = NULL; pimpl->fs = NULL;
+    pimpl->fg = NULL; pimpl->fs = NULL; pimpl->blocking = _blocking;
     pimpl->callback = _callback; pimpl->userdata = _userdata;
     pimpl->mod = LIQUID_MODEM_QPSK; pimpl->fec0 = LIQUID_FEC_NONE; pimpl->fec1 = LIQUID_FEC_HAMMING128;    // :80-83
     pimpl->frame_pos = 0; pimpl->assembled = false; pimpl->debug_enabled = false; pimpl->rx_idle = false;
+    pimpl->self = this; rx_buffer = NULL;
+    pthread_mutex_init(&rx_buffer_mutex, NULL); pthread_cond_init(&rx_buffer_filled_cond, NULL); pthread_cond_init(&rx_buffer_modified_cond, NULL);
     fgbuffer_len = _M + _cp_len;
     fgbuffer = new std::complex<float>[fgbuffer_len]();
     // like the reference (:78), both objects use the default subcarrier allocation whatever _p says
@@ -116,11 +137,12 @@ void ofdmtxrx::init(unsigned int _M, unsigned int _cp_len, unsigned int _taper_l
 
 ofdmtxrx::ofdmtxrx(unsigned int _M, unsigned int _cp_len, unsigned int _taper_len, unsigned char *_p,
                    framesync_callback _callback, void *_userdata)
-{ init(_M, _cp_len, _taper_len, _p, _callback, _userdata); }
+{ init(_M, _cp_len, _taper_len, _p, _callback, _userdata, false); }
 
+// second constructor: chooses between ofdmtxrx_rx_worker() and ofdmtxrx_rx_worker_blocking() (lib/ofdmtxrx.cc:133-206)
 ofdmtxrx::ofdmtxrx(unsigned int _M, unsigned int _cp_len, unsigned int _taper_len, unsigned char *_p,
-                   framesync_callback _callback, void *_userdata, bool)
-{ init(_M, _cp_len, _taper_len, _p, _callback, _userdata); }
+                   framesync_callback _callback, void *_userdata, bool _blocking_rx_worker)
+{ init(_M, _cp_len, _taper_len, _p, _callback, _userdata, _blocking_rx_worker); }
 
 ofdmtxrx::~ofdmtxrx()
 {
@@ -131,8 +153,25 @@ ofdmtxrx::~ofdmtxrx()
     }
     pimpl->rx_cond.notify_all();
     pimpl->rx_thread.join();
+    if (const char *dir = getenv("MCRX_DEBUG_DIR")) {
+        // stand-in for ofdmflexframesync_debug_print (lib/ofdmtxrx.cc:241-242): what this receiver can show of its inside
+        if (!pimpl->debug_syms.empty()) {
+            std::string fn = std::string(dir) + "/ofdmtxrx_framesyms.m";
+            if (FILE *f = fopen(fn.c_str(), "w")) {
+                fprintf(f, "%% equalised payload symbols of %zu frames (ofdmtxrx, debug_enable())\nclear all; close all;\n", pimpl->debug_syms.size());
+                for (size_t k = 0; k < pimpl->debug_syms.size(); k++) {
+                    fprintf(f, "framesyms{%zu} = [", k + 1);
+                    for (const auto &v : pimpl->debug_syms[k]) fprintf(f, " %.6e%+.6ej", v.real(), v.imag());
+                    fprintf(f, " ];\n");
+                }
+                fprintf(f, "figure; plot(real([framesyms{:}]), imag([framesyms{:}]), 'x'); axis square; grid on;\n");
+                fclose(f);
+            }
+        }
+    }
     mctx_hip_destroy(pimpl->fg);
     mcrx_hip_destroy(pimpl->fs);
+    pthread_mutex_destroy(&rx_buffer_mutex); pthread_cond_destroy(&rx_buffer_filled_cond); pthread_cond_destroy(&rx_buffer_modified_cond);
     delete[] fgbuffer;
     delete pimpl;
 }
@@ -237,6 +276,9 @@ void ofdmtxrx::start_rx()
 void ofdmtxrx::stop_rx()
 {
     pimpl->rx_running = false;
+    if (pimpl->blocking) {                          // a worker waiting for the editor must not wait for ever
+        pthread_mutex_lock(&rx_buffer_mutex); pthread_cond_broadcast(&rx_buffer_modified_cond); pthread_mutex_unlock(&rx_buffer_mutex);
+    }
     pimpl->usrp_rx->issue_stream_cmd(uhd::stream_cmd_t::STREAM_MODE_STOP_CONTINUOUS);
     std::unique_lock<std::mutex> lk(pimpl->rx_mutex);                   // returns once the worker has flushed and parked
     pimpl->rx_cond.wait(lk, [this] { return pimpl->rx_idle; });

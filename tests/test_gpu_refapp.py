@@ -21,13 +21,17 @@ def test_unchanged_reference_app_decodes_synthetic_traffic(oracle, tmp_path):
     iq.astype(np.complex64).tofile(f)
     # the class library is plain g++ code over the C-ABI: (re)build it where the test runs
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "liquid-usrp_amd", "host"), "-s"])
-    env = dict(os.environ, MCRX_IQ_FILE=str(f), MCRX_IQ_PACKET="4096")
+    env = dict(os.environ, MCRX_IQ_FILE=str(f), MCRX_IQ_PACKET="4096", MCRX_DEBUG_DIR=str(tmp_path))
     out = subprocess.run([EXE, "-n", str(N), "-M", str(M), "-C", str(cp), "-T", str(tp), "-t", "0.5", "-v"],
                          env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = re.findall(r"channel: (\d+) rx packet id:\s+(\d+)\n", out.stdout)
     assert len(lines) >= 3 * N, out.stdout[-2000:]
     assert {int(c) for c, _ in lines} == set(range(N))
+    # the stand-in for the reference's BST_DEBUG dump (lib/multichannelrx.cc:118-122): one framesync_channel%u.m per channel
+    for c in range(N):
+        txt = (tmp_path / ("framesync_channel%u.m" % c)).read_text()
+        assert "framesyms = [" in txt and "frames received" in txt
     assert "PAYLOAD INVALID" not in out.stdout.split("usrp data transfer started")[1][:2000]
 
 
@@ -206,3 +210,22 @@ def test_unchanged_fullduplex_app_receives_while_transmitting():
         if ids == list(range(200)):
             break
     assert ids == list(range(200)), (len(ids), out.stdout[-1500:])
+
+
+def test_ofdmtxrx_blocking_receiver_worker_and_debug_dump(tmp_path):
+    """The reference's second ofdmtxrx constructor selects ofdmtxrx_rx_worker_blocking (lib/ofdmtxrx.cc:642-739): another thread
+    edits every received packet between rx_buffer_filled_cond and rx_buffer_modified_cond.  host/blocking_test.cc turns the
+    samples by 180 degrees (every frame still arrives) and then zeroes them (nothing arrives); with MCRX_DEBUG_DIR set,
+    debug_enable() leaves the received frames' equalised symbols in a .m file at destruction."""
+    host = os.path.join(ROOT, "liquid-usrp_amd", "host")
+    subprocess.check_call(["make", "-C", host, "-s"])
+    subprocess.check_call(["make", "-C", host, "-s", "blocking_test"])
+    env = dict(os.environ, MCTX_LOOPBACK="1", MCRX_DEBUG_DIR=str(tmp_path))
+    out = subprocess.run([os.path.join(ROOT, "liquid-usrp_amd", "lib", "blocking_test")], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    m = re.search(r"phase1 (\d+) (\d+)  phase2 (\d+) (\d+)  packets_edited (\d+)", out.stdout)
+    assert m, out.stdout
+    sent1, got1, sent2, got2, edited = map(int, m.groups())
+    assert got1 >= sent1 - 1 and got2 == 0 and edited > 0, out.stdout
+    dump = tmp_path / "ofdmtxrx_framesyms.m"
+    assert dump.exists() and "framesyms{1}" in dump.read_text()
