@@ -165,6 +165,7 @@ struct SyncArgs {
     uint8_t *jtmp;              // [max_jobs][2*(max_enc_len+16)]
     int debug;                 // MCRX_DEBUG=1: trace state-machine events of channel 0
     uint32_t *vit_list; uint32_t vit_cap;   // trellis blocks for viterbi_blocks_kernel: [0] = count, then (job << 6 | block); filled by decode_kernel
+    uint32_t payload_lds_pad;  // bytes of unused dynamic LDS per payload worker: caps the workers' occupancy (walk mode, launch_sync)
     int seek_burst;            // idle stretches: SEEK events four at a time, their windows requested together (Walker::seek_burst)
     // speculation (see SpecSlot)
     SpecSlot *spec; float2 *spec_R;      // [nch][MCRX_SPEC_MAX], [nch][MCRX_SPEC_MAX][M]

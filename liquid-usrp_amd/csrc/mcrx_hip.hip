@@ -153,6 +153,7 @@ struct mcrx_hip_s {
     FrameRec *d_rec[MCRX_GENS] = {}; uint8_t *d_arena[MCRX_GENS] = {}, *d_sarena[MCRX_GENS] = {};
     uint32_t *d_nrec[MCRX_GENS] = {}; unsigned long long *d_arena_used[MCRX_GENS] = {};
     int gen = 0; bool gen_used[MCRX_GENS] = {}, gen_closed[MCRX_GENS] = {}, gen_abandoned[MCRX_GENS] = {};
+    uint32_t walk_lds_pad = 13312;   // walk mode: unused LDS per payload worker = at most three of them per SIMD, the fourth slot is the walking scouts' (95 -> 110 Gsample/s on ragged traffic)
     int debug = 0, no_fast = 0, seek_burst = 1, acq_mode = 0; bool free_run = false;      // MCRX_DEBUG (trace bits), MCRX_NO_FAST, MCRX_FREE_RUN: read once, at creation
     hipStream_t acq_stream = nullptr;        // the stream the last launch's acquisition / placement kernels ran on (they write the generation's counters)
     uint64_t gen_close_seq[MCRX_GENS] = {}, close_counter = 0;      // order in which generations were closed (= delivery order)
@@ -496,6 +497,7 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     q->free_run = getenv("MCRX_FREE_RUN") != nullptr;
     if (getenv("MCRX_SEEK_BURST")) q->seek_burst = atoi(getenv("MCRX_SEEK_BURST"));
     if (getenv("MCRX_ACQ_MODE")) q->acq_mode = atoi(getenv("MCRX_ACQ_MODE"));
+    if (getenv("MCRX_WALK_LDS_PAD")) q->walk_lds_pad = (uint32_t)atoi(getenv("MCRX_WALK_LDS_PAD"));
     if (getenv("MCRX_SLOTS")) q->nslots = (unsigned)std::max(2, std::min(MCRX_SLOTS, atoi(getenv("MCRX_SLOTS"))));
     if (!q->pipelined) q->nslots = 2;
     if ((rc = q->alloc(&q->d_njobs, MCRX_SLOTS))) return bail(rc);      // one counter per slot: a launch's placement kernel zeroes the next slot's
@@ -652,6 +654,7 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     a.nrec = q->d_nrec[g]; a.arena_used = q->d_arena_used[g];
     a.arena_cap = q->arena_cap; a.sarena_cap = q->sarena_cap; a.max_rec = q->max_rec;
     a.debug = q->debug; a.no_fast = q->no_fast; a.seek_burst = q->seek_burst;
+    a.payload_lds_pad = (q->walk_mode || q->acq_mode == 2) ? q->walk_lds_pad : 0u;
     a.vit_off = 0;
     a.scout = q->scout ? 1 : 0;
     a.jobs = q->d_jobs[slot]; a.njobs = q->d_njobs + slot; a.njobs_next = q->d_njobs + next; a.max_jobs = q->max_rec;

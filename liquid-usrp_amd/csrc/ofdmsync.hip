@@ -629,16 +629,17 @@ __device__ __forceinline__ unsigned demod_soft(const uint8_t *nbt, unsigned mod,
 // Wave-private LDS scratch, referenced by name so every access is a ds_* instruction.
 #define SY_MAXM 1024
 extern __shared__ __attribute__((aligned(16))) float2 sy_lds[];
-#define ldsc  sy_lds                                                          /* complex scratch [M]   */
-#define ldsf  (reinterpret_cast<float *>(sy_lds + c.M))                       /* float scratch  [2*M]  */
-#define ldspf (reinterpret_cast<float *>(sy_lds + c.M) + 2 * c.M)             /* pilot fit rows [M]    */
-#define ldsps (reinterpret_cast<uint8_t *>(reinterpret_cast<float *>(sy_lds + c.M) + 3 * c.M))  /* pilot bits [256] */
+#define sy_w  (sy_lds + lo)                                                     /* this wave's scratch (Walker::lo: 0 in one-wave workgroups) */
+#define ldsc  sy_w                                                            /* complex scratch [M]   */
+#define ldsf  (reinterpret_cast<float *>(sy_w + c.M))                         /* float scratch  [2*M]  */
+#define ldspf (reinterpret_cast<float *>(sy_w + c.M) + 2 * c.M)               /* pilot fit rows [M]    */
+#define ldsps (reinterpret_cast<uint8_t *>(reinterpret_cast<float *>(sy_w + c.M) + 3 * c.M))  /* pilot bits [256] */
 #define ldshm (reinterpret_cast<uint16_t *>(ldsps + 256))                      /* header bit map [288]  */
 #define ldshb (ldsps + 256 + 2 * MCRX_HDR_SYMS)                                /* header bits, decoded order [288] */
 #define ldshd (reinterpret_cast<uint16_t *>(ldsps + 256 + 3 * MCRX_HDR_SYMS))   /* Golay-decoded 12-bit words [12] */
 #define ldsad (ldsps + 256 + 3 * MCRX_HDR_SYMS + 32)                            /* adopted speculative slots [MCRX_SPEC_MAX] */
 #define ldsqn (ldsad + MCRX_SPEC_MAX)                                             /* QAM neighbour table of the frame's modem [256] */
-#define SY_LDS_BYTES(M) ((size_t)(M) * 8 + (size_t)(M) * 12 + 256 + 3 * MCRX_HDR_SYMS + 32 + MCRX_SPEC_MAX + 256)
+#define SY_LDS_BYTES(M) ((((size_t)(M) * 8 + (size_t)(M) * 12 + 256 + 3 * MCRX_HDR_SYMS + 32 + MCRX_SPEC_MAX + 256) + 15) & ~(size_t)15)
 
 // One wavefront per workgroup: LDS traffic of a wave is processed in order, so a compiler-level
 // fence is all the hand-off between lanes needs (no s_barrier, and no vmcnt(0) drain of the
@@ -665,6 +666,7 @@ struct Walker {
     const SyncConsts &c;
     const int l;                // lane
     const uint32_t ch;          // channel within shard
+    const int lo;               // this wave's LDS scratch, in float2 from sy_lds (workgroups of several waves: sync_walk_kernel)
     ChanState s;                // working copy of the channel state (wave uniform)
     // per (lane, e) constants
     int k[E];                   // subcarrier held after the FFT (-1: none)
@@ -690,8 +692,8 @@ struct Walker {
     int dr[E], pr[E]; float fxr[E];
     float pf0, pf1;
 
-    __device__ __forceinline__ Walker(const SyncArgs &a_, uint32_t ch_)
-        : a(a_), c(a_.c), l(lane_id()), ch(ch_)
+    __device__ __forceinline__ Walker(const SyncArgs &a_, uint32_t ch_, int lo_ = 0)
+        : a(a_), c(a_.c), l(lane_id()), ch(ch_), lo(lo_)
     {
         const size_t tstride = (size_t)c.max_enc_len + 16;
         bsoft = a.soft + (size_t)ch * 8 * c.max_enc_len;
@@ -2071,14 +2073,21 @@ __global__ __launch_bounds__(WV, SY_ACQ_WAVES) void sync_lean_kernel(SyncArgs a)
 // length: launch_sync switches the speculative rounds off there): the budgeted build above spills ~300 registers, harmless
 // while it only adopts what the speculative waves found, ruinous when it acquires every frame itself (6.2 ms per slab
 // against 1.7 for the full kernel on the same stream).
+// SY_WALK_WPB waves per workgroup, a channel and an LDS scratch each (no workgroup barrier: the waves never meet).  Measured with
+// four (the walkers on 128 CUs, the other 128 free for the channelizer, whose workgroups otherwise cannot start before the
+// one-per-SIMD walkers spread over every CU have finished): the channelizer does overlap then (1.65 -> 0.99 ms), but the
+// walkers, now sharing their CUs with all the workers the channelizer displaced, take 2.03 ms instead of 1.65 -- 91.8 against
+// 110 Gsample/s on ragged traffic.  One per workgroup it stays.
+#define SY_WALK_WPB 1
 template <int E>
-__global__ __launch_bounds__(WV) void sync_walk_kernel(SyncArgs a)
+__global__ __launch_bounds__(WV * SY_WALK_WPB) void sync_walk_kernel(SyncArgs a)
 {
     __builtin_amdgcn_s_setprio(3);
     launder(a);
-    const uint32_t ch = blockIdx.x;
+    const uint32_t wv = rfl(threadIdx.x / WV);
+    const uint32_t ch = blockIdx.x * SY_WALK_WPB + wv;
     if (ch >= a.nch) return;
-    Walker<E> w(a, ch);
+    Walker<E> w(a, ch, (int)(wv * (uint32_t)(SY_LDS_BYTES(E * WV) / sizeof(float2))));
     w.template run<SYM_LEAN>();
 }
 
@@ -2824,7 +2833,7 @@ static hipError_t sy_launch_width(int what, const SyncArgs &a, unsigned grid, si
         else hipLaunchKernelGGL((sync_kernel<EE>), dim3(grid), dim3(WV), lds, st, a);
         break;
     case SYK_WALK:
-        if constexpr (EE <= 2) hipLaunchKernelGGL((sync_walk_kernel<EE>), dim3(grid), dim3(WV), lds, st, a);
+        if constexpr (EE <= 2) hipLaunchKernelGGL((sync_walk_kernel<EE>), dim3((grid + SY_WALK_WPB - 1) / SY_WALK_WPB), dim3(WV * SY_WALK_WPB), SY_WALK_WPB * SY_LDS_BYTES(EE * WV), st, a);
         else hipLaunchKernelGGL((sync_kernel<EE>), dim3(grid), dim3(WV), lds, st, a);
         break;
     case SYK_PAYLOAD_FAST:    hipLaunchKernelGGL((payload_kernel<EE, true>), dim3(grid), dim3(WV), lds, st, a); break;
@@ -2951,7 +2960,7 @@ hipError_t sync_launch_payload(const SyncArgs &a0, int stage, hipStream_t st)
     if (fast && a.c.M == WV && a.c.M_pilot <= 16 && fr > 0 && !(a.no_fast & 6)) {
         if (fr == 4)      hipLaunchKernelGGL(payload_multi_kernel<4>, dim3((nj + 3) / 4), dim3(WV), 0, st, a);
         else if (fr == 2) hipLaunchKernelGGL(payload_multi_kernel<2>, dim3((nj + 1) / 2), dim3(WV), 0, st, a);
-        else              hipLaunchKernelGGL(payload_multi_kernel<1>, dim3(nj), dim3(WV), 0, st, a);
+        else              hipLaunchKernelGGL(payload_multi_kernel<1>, dim3(nj), dim3(WV), (size_t)a.payload_lds_pad, st, a);
         return hipGetLastError();
     }
     return sy_launch(fast ? SYK_PAYLOAD_FAST : SYK_PAYLOAD_GENERAL, a, nj, SY_LDS_BYTES(a.c.M), st);
