@@ -165,6 +165,14 @@ struct SyncArgs {
     uint8_t *jtmp;              // [max_jobs][2*(max_enc_len+16)]
     int debug;                 // MCRX_DEBUG=1: trace state-machine events of channel 0
     uint32_t *vit_list; uint32_t vit_cap;   // trellis blocks for viterbi_blocks_kernel: [0] = count, then (job << 6 | block); filled by decode_kernel
+    // list-driven launches that are nearly always empty (QAM payload workers, trellis blocks, general decoder): a launch of
+    // 8192 do-nothing workgroups still has to find 8192 wave slots, behind the channelizer's whole-CU workgroups -- measured
+    // 0.15-0.27 ms on the work stream.  The kernels walk their lists with a grid stride, so any grid is correct; the host
+    // sizes it from what the most recent launch published here (list_hint, host-mapped) and keeps a floor for the first
+    // frames of a kind it has not seen yet.
+    uint32_t *qam_list;         // [0] = hand-offs with a 16- / 64-QAM payload, [1 ..] their job indices (place_jobs_kernel)
+    uint32_t *list_hint;        // [0] QAM hand-offs, [1] trellis blocks, [2] frames on the general list, of the most recent launch
+    uint32_t grid_hint[3];      // what the host last read there (~0: no hint, full grids)
     uint32_t payload_lds_pad;  // bytes of unused dynamic LDS per payload worker: caps the workers' occupancy (walk mode, launch_sync)
     int seek_burst;            // idle stretches: SEEK events four at a time, their windows requested together (Walker::seek_burst)
     // speculation (see SpecSlot)

@@ -153,6 +153,8 @@ struct mcrx_hip_s {
     FrameRec *d_rec[MCRX_GENS] = {}; uint8_t *d_arena[MCRX_GENS] = {}, *d_sarena[MCRX_GENS] = {};
     uint32_t *d_nrec[MCRX_GENS] = {}; unsigned long long *d_arena_used[MCRX_GENS] = {};
     int gen = 0; bool gen_used[MCRX_GENS] = {}, gen_closed[MCRX_GENS] = {}, gen_abandoned[MCRX_GENS] = {};
+    uint32_t list_seen[3] = { 0, 0, 0 }, list_age[3] = { 64, 64, 64 };      // launch_sync: grids of the list-driven launches
+    uint32_t round_lds_pad = 0;      // the same cap outside walk mode (MCRX_PAYLOAD_LDS_PAD)
     uint32_t walk_lds_pad = 13312;   // walk mode: unused LDS per payload worker = at most three of them per SIMD, the fourth slot is the walking scouts' (95 -> 110 Gsample/s on ragged traffic)
     int debug = 0, no_fast = 0, seek_burst = 1, acq_mode = 0; bool free_run = false;      // MCRX_DEBUG (trace bits), MCRX_NO_FAST, MCRX_FREE_RUN: read once, at creation
     hipStream_t acq_stream = nullptr;        // the stream the last launch's acquisition / placement kernels ran on (they write the generation's counters)
@@ -161,7 +163,7 @@ struct mcrx_hip_s {
     uint64_t sarena_cap = 0;
     // per-launch slots
     PayloadJob *d_jobs[MCRX_SLOTS] = {}; uint32_t *d_njobs = nullptr; float2 *d_jR[MCRX_SLOTS] = {};
-    uint32_t *d_gen[MCRX_SLOTS] = {}, *d_vit[MCRX_SLOTS] = {}; uint32_t vit_cap = 0;
+    uint32_t *d_gen[MCRX_SLOTS] = {}, *d_vit[MCRX_SLOTS] = {}, *d_qam[MCRX_SLOTS] = {}; uint32_t vit_cap = 0;
     uint64_t seq = 0;                       // synchronizer launches so far (slot = seq % nslots)
     unsigned nslots = 5;                    // buffer sets in use: the channelizer and the acquisition chain of up to nslots - 1 pushes run ahead of the payload workers
     uint32_t *d_stats = nullptr;            // speculation statistics (SyncArgs::stats)
@@ -498,20 +500,23 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     if (getenv("MCRX_SEEK_BURST")) q->seek_burst = atoi(getenv("MCRX_SEEK_BURST"));
     if (getenv("MCRX_ACQ_MODE")) q->acq_mode = atoi(getenv("MCRX_ACQ_MODE"));
     if (getenv("MCRX_WALK_LDS_PAD")) q->walk_lds_pad = (uint32_t)atoi(getenv("MCRX_WALK_LDS_PAD"));
+    if (getenv("MCRX_PAYLOAD_LDS_PAD")) q->round_lds_pad = (uint32_t)atoi(getenv("MCRX_PAYLOAD_LDS_PAD"));
     if (getenv("MCRX_SLOTS")) q->nslots = (unsigned)std::max(2, std::min(MCRX_SLOTS, atoi(getenv("MCRX_SLOTS"))));
     if (!q->pipelined) q->nslots = 2;
     if ((rc = q->alloc(&q->d_njobs, MCRX_SLOTS))) return bail(rc);      // one counter per slot: a launch's placement kernel zeroes the next slot's
     if ((rc = q->alloc(&q->d_stats, 8))) return bail(rc);
     // (coherent: with hipHostMallocMapped alone the allocation is non-coherent and a free-running host -- one that never
     //  synchronizes with the device -- does not see the kernels' updates at all)
-    if (hipHostMalloc((void **)&q->h_hint, 8 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
-        for (int i = 0; i < 8; i++) q->h_hint[i] = 0;     // [0] longest coded frame, [1] widest prediction list, [2] walked, [3] adopted, [4] frames on a cadence, [5] frames seen
+    if (hipHostMalloc((void **)&q->h_hint, 12 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+        for (int i = 0; i < 12; i++) q->h_hint[i] = 0;    // [0] longest coded frame, [1] widest prediction list, [2] walked, [3] adopted, [4] frames on a cadence, [5] frames seen,
+                                                          // [8] QAM hand-offs, [9] trellis blocks, [10] general-list frames of the most recent launch (kernels.h: list_hint)
         if (hipHostGetDevicePointer((void **)&q->d_hint, q->h_hint, 0) != hipSuccess) q->d_hint = nullptr;
     }
     if (q->scout) {
         for (unsigned sl = 0; sl < q->nslots; sl++) {
             if ((rc = q->alloc(&q->d_jobs[sl], q->max_rec))) return bail(rc);
             if ((rc = q->alloc(&q->d_gen[sl], (size_t)q->max_rec + 1))) return bail(rc);
+            if ((rc = q->alloc(&q->d_qam[sl], (size_t)q->max_rec + 1))) return bail(rc);
             q->vit_cap = (uint32_t)std::min<uint64_t>((uint64_t)q->max_rec * ((4ull * q->max_enc + 6 + 959) / 960), 1u << 24);      // trellis blocks of every frame of a launch
             if ((rc = q->alloc(&q->d_vit[sl], (size_t)q->vit_cap + 1))) return bail(rc);
             if ((rc = q->alloc(&q->d_jR[sl], (size_t)q->max_rec * M))) return bail(rc);
@@ -654,11 +659,21 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     a.nrec = q->d_nrec[g]; a.arena_used = q->d_arena_used[g];
     a.arena_cap = q->arena_cap; a.sarena_cap = q->sarena_cap; a.max_rec = q->max_rec;
     a.debug = q->debug; a.no_fast = q->no_fast; a.seek_burst = q->seek_burst;
-    a.payload_lds_pad = (q->walk_mode || q->acq_mode == 2) ? q->walk_lds_pad : 0u;
+    a.payload_lds_pad = (q->walk_mode || q->acq_mode == 2) ? q->walk_lds_pad : q->round_lds_pad;
     a.vit_off = 0;
     a.scout = q->scout ? 1 : 0;
     a.jobs = q->d_jobs[slot]; a.njobs = q->d_njobs + slot; a.njobs_next = q->d_njobs + next; a.max_jobs = q->max_rec;
     a.gen_list = q->d_gen[slot]; a.dec_lds_soft = 0; a.vit_list = q->d_vit[slot]; a.vit_cap = q->vit_cap;
+    a.qam_list = q->d_qam[slot]; a.list_hint = nullptr;
+    for (int i = 0; i < 3; i++) a.grid_hint[i] = ~0u;
+    if (q->h_hint && q->d_hint && q->pipelined) {        // (sticky for a while: a list that was non-empty within the last 64 launches keeps its full grid)
+        a.list_hint = q->d_hint + 8;
+        for (int i = 0; i < 3; i++) {
+            const uint32_t v = ((volatile uint32_t *)q->h_hint)[8 + i];
+            if (v) { q->list_seen[i] = v; q->list_age[i] = 0; } else if (q->list_age[i] < 64) q->list_age[i]++; else q->list_seen[i] = 0;
+            a.grid_hint[i] = q->list_seen[i];
+        }
+    }
     a.jR = q->d_jR[slot]; a.jsoft = q->d_jsoft[slot]; a.jtmp = q->d_jtmp[slot];
     a.stats = q->d_stats;
     a.hint = q->d_hint; a.enc_hint = (q->h_hint && q->d_hint) ? *(volatile uint32_t *)q->h_hint : 0u;

@@ -2022,7 +2022,7 @@ __device__ __forceinline__ void launder(SyncArgs &a)
     LAUNDER(c.cod.crc_zadv); LAUNDER(c.cod.qam16_nb); LAUNDER(c.cod.qam64_nb);
     LAUNDER(chan); LAUNDER(st); LAUNDER(hbits); LAUNDER(R); LAUNDER(soft); LAUNDER(tmpa); LAUNDER(tmpb);
     LAUNDER(syms); LAUNDER(rec); LAUNDER(arena); LAUNDER(sarena); LAUNDER(nrec); LAUNDER(arena_used);
-    LAUNDER(jobs); LAUNDER(njobs); LAUNDER(jR); LAUNDER(jsoft); LAUNDER(jtmp); LAUNDER(vit_list);
+    LAUNDER(jobs); LAUNDER(njobs); LAUNDER(jR); LAUNDER(jsoft); LAUNDER(jtmp); LAUNDER(vit_list); LAUNDER(qam_list);
     LAUNDER(spec); LAUNDER(spec_R); LAUNDER(pred); LAUNDER(pred_n); LAUNDER(stats); LAUNDER(walk_hint);
 }
 #undef LAUNDER
@@ -2328,6 +2328,8 @@ __global__ __launch_bounds__(WV) void payload_multi_kernel(SyncArgs a)
     if (i == 0 && active) a.jobs[j].s.nco_dtheta = dth;
 }
 
+#include "payload_lean.hpp"
+
 // ------------------------------------------------------------------ packet decode, a workgroup per frame
 // The payload workers leave 8 soft bits per coded byte in HBM.  De-interleaving them there costs
 // four passes of scattered 8-byte read-modify-writes per frame (measured: 4.7x the algorithmic HBM
@@ -2619,6 +2621,7 @@ __global__ __launch_bounds__(WV) void viterbi_blocks_kernel(SyncArgs a)
     if (!a.vit_list) return;
     const uint32_t *vl = as_global(a.vit_list);
     uint32_t nb = vl[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.list_hint) a.list_hint[1] = nb;
     if (nb > a.vit_cap) nb = a.vit_cap;
     const SyncConsts &c = a.c;
     for (uint32_t k = blockIdx.x; k < nb; k += gridDim.x) {
@@ -2636,6 +2639,7 @@ __global__ __launch_bounds__(WV) void decode_general_kernel(SyncArgs a)
     launder(a);
     const uint32_t *gl = as_global(a.gen_list);
     uint32_t ng = gl[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.list_hint) a.list_hint[2] = ng;
     if (ng > a.max_jobs) ng = a.max_jobs;
     const SyncConsts &c = a.c;
     for (uint32_t k = blockIdx.x; k < ng; k += gridDim.x) {        // (a handful of workgroups; the list is normally empty)
@@ -2682,6 +2686,17 @@ __global__ __launch_bounds__(PJ_T) void place_jobs_kernel(SyncArgs a)
         volatile uint32_t *h = a.walk_hint;
         h[0] = a.stats[0]; h[1] = a.stats[1]; h[2] = a.stats[4]; h[3] = a.stats[5];
         __threadfence_system();
+    }
+    __shared__ uint32_t nqam;
+    if (a.qam_list) {                       // the hand-offs the lean workers' second launch takes (16- / 64-QAM), any order
+        if (threadIdx.x == 0) nqam = 0;
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < nj; j += PJ_T) {
+            const uint32_t m = a.jobs[j].s.mod_scheme;
+            if (a.jobs[j].ch < a.nch && m != 39 && m != 40) a.qam_list[1 + atomicAdd(&nqam, 1u)] = j;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { a.qam_list[0] = nqam; if (a.list_hint) a.list_hint[0] = nqam; }
     }
     auto need_of = [&](uint32_t j, uint32_t &pay16) -> uint32_t {
         pay16 = 0;
@@ -2949,8 +2964,9 @@ hipError_t sync_launch_payload(const SyncArgs &a0, int stage, hipStream_t st)
     }
     if (stage == 3) {                       // the frames on the general list (filled by decode_kernel)
         if (!fast) return hipSuccess;
-        if (a.vit_list) hipLaunchKernelGGL(viterbi_blocks_kernel, dim3(8192), dim3(WV), (size_t)(VIT_B + VIT_W) * 8, st, a);
-        hipLaunchKernelGGL(decode_general_kernel, dim3(nj < 4096 ? nj : 4096), dim3(WV), (size_t)VIT_B * 8, st, a);
+        // (grids from the lists' most recent sizes: kernels.h, list_hint)
+        if (a.vit_list) hipLaunchKernelGGL(viterbi_blocks_kernel, dim3(a.grid_hint[1] ? 8192 : 64), dim3(WV), (size_t)(VIT_B + VIT_W) * 8, st, a);
+        hipLaunchKernelGGL(decode_general_kernel, dim3(a.grid_hint[2] ? (nj < 4096 ? nj : 4096) : 64), dim3(WV), (size_t)VIT_B * 8, st, a);
         return hipGetLastError();
     }
     // M = 64 with the pilots inside one DPP row: payload_multi_kernel, MCRX_PAYLOAD_FR frames per wave (default 1;
@@ -2960,7 +2976,23 @@ hipError_t sync_launch_payload(const SyncArgs &a0, int stage, hipStream_t st)
     if (fast && a.c.M == WV && a.c.M_pilot <= 16 && fr > 0 && !(a.no_fast & 6)) {
         if (fr == 4)      hipLaunchKernelGGL(payload_multi_kernel<4>, dim3((nj + 3) / 4), dim3(WV), 0, st, a);
         else if (fr == 2) hipLaunchKernelGGL(payload_multi_kernel<2>, dim3((nj + 1) / 2), dim3(WV), 0, st, a);
-        else              hipLaunchKernelGGL(payload_multi_kernel<1>, dim3(nj), dim3(WV), (size_t)a.payload_lds_pad, st, a);
+        else {
+            // one frame per wave: the lean build (payload_lean.hpp) unless MCRX_PAYLOAD_LEAN=0; MCRX_PAYLOAD_XB picks which
+            // butterfly stages exchange through the LDS crossbar (bit H set: the stage with partners H lanes apart)
+            const char *le = getenv("MCRX_PAYLOAD_LEAN"), *xe = getenv("MCRX_PAYLOAD_XB");
+            const int xb = xe ? atoi(xe) : 63;
+            const size_t pad = (size_t)a.payload_lds_pad;
+            if (le && atoi(le) == 0) hipLaunchKernelGGL(payload_multi_kernel<1>, dim3(nj), dim3(WV), pad, st, a);
+            else {
+                unsigned nq = a.grid_hint[0] == ~0u ? nj : 2u * a.grid_hint[0];
+                nq = nq < 256u ? 256u : (nq > nj ? nj : nq);
+#define SY_LEAN(XB) do { hipLaunchKernelGGL(payload_lean_kernel<XB>, dim3(nj), dim3(WV), pad, st, a); \
+                         hipLaunchKernelGGL(payload_lean_qam_kernel<XB>, dim3(a.qam_list ? nq : nj), dim3(WV), pad, st, a); } while (0)
+                if (xb == 0) SY_LEAN(0);
+                else         SY_LEAN(63);
+#undef SY_LEAN
+            }
+        }
         return hipGetLastError();
     }
     return sy_launch(fast ? SYK_PAYLOAD_FAST : SYK_PAYLOAD_GENERAL, a, nj, SY_LDS_BYTES(a.c.M), st);

@@ -1,0 +1,287 @@
+// payload_lean.hpp -- payload workers for 64-subcarrier frames, one frame per wave, the instruction diet.
+// Included by ofdmsync.hip (part 0) inside namespace mcrx.
+//
+// Replaces ofdmflexframesync's per-symbol path for the payload (reference: liquid-dsp ofdmframesync_execute_rxsymbols ->
+// ofdmframesync_rxsymbol -> ofdmflexframesync_rxpayload, called per channel from src/multichannelrx.cc:185-204 through
+// the channelizer callback).  Same arithmetic per sample as payload_multi_kernel<1> (same butterflies, twiddles, pilot
+// fit, oscillator trim); what changed is where the instructions go.  payload_multi_kernel<1> issues 203 VALU
+// instructions per symbol and is VALU-bound (272.8 M per 207.7 M-sample slab = 0.44 of its 0.52 ms, profiles/r3_v2_pmc.csv):
+//   * window address: 15 VALU (two 64-bit multiplies per lane)      -> a scalar base that advances per symbol + a lane
+//     offset that only changes when the window's phase inside the 8-sample tiles does (never for L = 72);
+//   * the six butterfly stages: 50 VALU, of which 24 move data (v_mov_dpp, copies for v_permlane*_swap) -> the partner
+//     comes through the LDS crossbar (ds_swizzle / ds_bpermute: no VALU slot, no LDS memory), a stage is one packed fma
+//     for the butterfly and two for the twiddle;
+//   * pilots: LDS write + fence + read, polarity look-up with a modulo, two 4-step projections -> one ds_bpermute gather,
+//     polarity as a sign mask from a table that runs past the sequence's end, both projections in one 3-step reduction
+//     when there are at most 8 pilots (bit-identical sums: the dropped step only added zeros);
+//   * modem: the demodulator and the stores were compiled for every modem at once and selected per lane -> the symbol loop
+//     is instantiated per modem; stores take a scalar base + constant lane offsets.
+// MCRX_PAYLOAD_LEAN=0 launches payload_multi_kernel<1> instead (A/B and parity tests).
+
+namespace lean {
+
+typedef float v2f __attribute__((ext_vector_type(2)));       // a complex sample in an aligned register pair: the packed-f32 VALU takes it whole
+// a (c + j s), tw = (c, s): one packed multiply, one packed fma with the halves of `a` swapped and the low one negated
+__device__ __forceinline__ v2f cmul_pk(v2f a, v2f tw)
+{
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(tw));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(tw), "v"(t));
+    return r;
+}
+// a (c - j s)
+__device__ __forceinline__ v2f cmulc_pk(v2f a, v2f tw)
+{
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(tw));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(tw), "v"(t));
+    return r;
+}
+// a e^{-j 2 pi rev} on the transcendental unit
+__device__ __forceinline__ v2f rot_down_pk(v2f a, float rev)
+{
+    v2f cs; cs.x = __builtin_amdgcn_cosf(rev); cs.y = __builtin_amdgcn_sinf(rev);
+    return cmulc_pk(a, cs);
+}
+// sg x + p, sg = the low (HI = 0) or high (HI = 1) half of `sgp` for both components
+template <int HI>
+__device__ __forceinline__ v2f bfly_pk(v2f x, v2f sgp, v2f p)
+{
+    v2f r;
+    if constexpr (HI == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(x), "v"(sgp), "v"(p));
+    else                   asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(x), "v"(sgp), "v"(p));
+    return r;
+}
+
+template <int H>
+__device__ __forceinline__ float xch(float v, int bp32)         // v of lane l ^ H, through the LDS crossbar
+{
+    if constexpr (H == 32) return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bp32, __builtin_bit_cast(int, v)));
+    else return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (H << 10) | 0x1F));
+}
+// one radix-2 DIF stage across lanes H apart: lower lanes x + x', upper lanes (x' - x) W
+template <int H, int XB, int HI>
+__device__ __forceinline__ v2f stage(v2f x, v2f sgp, v2f tw, int bp32)
+{
+    v2f u;
+    if constexpr ((XB & H) != 0) { v2f p; p.x = xch<H>(x.x, bp32); p.y = xch<H>(x.y, bp32); u = bfly_pk<HI>(x, sgp, p); }
+    else { const float sg = HI ? sgp.y : sgp.x; u.x = bfly_leg<H>(x.x, sg); u.y = bfly_leg<H>(x.y, sg); }
+    if constexpr (H == 1) return u;
+    else return cmul_pk(u, tw);
+}
+
+// soft bits of one symbol, byte k = bit k (most significant first), and the hard symbol.  Same expressions as demod_soft
+template <int MOD>
+__device__ __forceinline__ uint64_t demod_pk(const uint8_t *nbt, v2f r, bool soft_mode)
+{
+    constexpr unsigned bps = MOD == 39 ? 1u : MOD == 40 ? 2u : MOD == 27 ? 4u : 6u;
+    if constexpr (MOD == 39) {
+        if (soft_mode) return soft_clamp((-2.0f * r.x * 4.0f) * 16.0f + 127.0f);
+        return r.x > 0 ? 0u : 255u;
+    } else if constexpr (MOD == 40) {
+        if (soft_mode) return (uint32_t)soft_clamp((-2.0f * r.y * 5.8f) * 16.0f + 127.0f) | ((uint32_t)soft_clamp((-2.0f * r.x * 5.8f) * 16.0f + 127.0f) << 8);
+        return (r.y > 0 ? 0u : 255u) | (r.x > 0 ? 0u : 0xff00u);
+    } else {
+        uint8_t sb[6];
+        const unsigned hs = demod_soft(nbt, (unsigned)MOD, make_float2(r.x, r.y), sb);
+        uint64_t w = 0;
+#pragma unroll
+        for (unsigned kb = 0; kb < bps; kb++) w |= (uint64_t)(soft_mode ? (unsigned)sb[kb] : (((hs >> (bps - 1 - kb)) & 1) ? 255u : 0u)) << (8 * kb);
+        return w;
+    }
+}
+
+template <int MOD> struct bits_per_symbol { static constexpr unsigned v = MOD == 39 ? 1u : MOD == 40 ? 2u : MOD == 27 ? 4u : 6u; };
+
+// the symbols of one frame.  Everything passed by value is wave-uniform unless it says "lane"
+template <int MOD, int XB>
+__device__ __forceinline__ uint32_t symbols(const SyncArgs &a, const PayloadJob *job, const uint32_t ch, const uint32_t j,
+                                            const uint32_t *qsg, const uint32_t *qnb, const int *qsrc)
+{
+    constexpr unsigned bps = bits_per_symbol<MOD>::v;
+    const SyncConsts &c = a.c;
+    const int l = lane_id();
+    const int bp32 = (l ^ 32) << 2;
+    // ---- lane constants: after the transform lane l holds subcarrier bitrev6(l)
+    const int kk = (int)(__brev((unsigned)l) >> 26);
+    const int dr = c.data_rank[kk];
+    const bool isdata = dr >= 0;
+    const float fxr = ((kk > c.M2) ? (float)kk - (float)c.M : (float)kk) * 0.15915494309189535f;
+    v2f R = {0.f, 0.f};
+    if (c.sctype[kk]) { const float2 g = (a.jR + (size_t)j * c.M)[kk]; R.x = g.x; R.y = g.y; }
+    v2f tw[6], sgp[3];                                                  // stage twiddles (1 in the lower lanes); butterfly signs, two stages to a pair
+#pragma unroll
+    for (int st = 0; st < 6; st++) {
+        const int h = 32 >> st;
+        const bool up = (l & h) != 0;
+        const float rev = (float)(l & (h - 1)) * (0.5f / (float)h);
+        tw[st].x = up ? __builtin_amdgcn_cosf(rev) : 1.f; tw[st].y = up ? -__builtin_amdgcn_sinf(rev) : 0.f;
+        if (st & 1) sgp[st >> 1].y = up ? -1.f : 1.f; else sgp[st >> 1].x = up ? -1.f : 1.f;
+    }
+    const int Mp = c.M_pilot;
+    const bool p8 = Mp <= 8;                                            // both projections in one row: pf0 in lanes 0..7, pf1 in lanes 8..15
+    const float pf0 = (l < Mp) ? c.Pfit[l] : 0.f, pf1 = (l < Mp) ? c.Pfit[Mp + l] : 0.f;
+    const float pfc = p8 ? ((l < 8) ? pf0 : ((l < 16 && l - 8 < Mp) ? c.Pfit[Mp + l - 8] : 0.f)) : pf0;
+    const int psrc = qsrc[l < Mp ? l : 0] << 2;                          // ds_bpermute address of the lane that holds pilot l
+    const uint32_t so_sym = (uint32_t)(isdata ? dr : 0) * 8u, so_soft = (uint32_t)(isdata ? dr : 0) * bps;
+
+    // ---- wave-uniform state
+    const int L = c.L, cb = c.cp - c.backoff, Md = c.M_data;
+    const uint32_t mod_len = rfl(job->s.mod_len), nbits = rfl(8u * job->s.enc_len);
+    const uint32_t nsym = (mod_len + (uint32_t)Md - 1u) / (uint32_t)Md;
+    const int64_t t_ev0 = job->s.cur + (int64_t)job->s.timer - 1;
+    const int64_t ws0 = t_ev0 - L + 1 + cb;
+    uint32_t dth = rfl(job->s.nco_dtheta);
+    uint32_t th_ws = rfl(job->s.nco_theta_ref + (uint32_t)(ws0 - job->s.nco_t_ref) * job->s.nco_dtheta);
+    uint32_t pc4 = rfl(job->s.pilot_count) * 4u;                         // byte offset into the polarity table
+    float phi_prime = job->s.phi_prime, p1_prime = job->s.p1_prime;
+    int32_t r_ws = (int32_t)rfl((uint32_t)(ws0 - a.buf_first));
+    const float2 *chb = a.chan + ((size_t)a.chan_off + ch) * MCRX_TILE_S;
+    const uint32_t tstride = a.chan_stride * (uint32_t)MCRX_TILE_S;      // elements between a channel's consecutive 8-sample tiles
+    const int32_t r_max = (int32_t)(a.end - a.buf_first) - 1;
+    const bool soft_mode = c.payload_soft != 0;
+    uint8_t *soft = a.jsoft + (size_t)j * 8 * c.max_enc_len;
+    const uint64_t syms_off = job->syms_off;
+    uint8_t *syms = a.sarena + (((uint64_t)rfl((uint32_t)(syms_off >> 32)) << 32) | rfl((uint32_t)syms_off));
+    const uint32_t l4 = (uint32_t)l * 4u;
+
+    int q0 = -1; uint32_t offl = 0;                                      // the window's phase inside the tiles, the lane offset that goes with it
+    auto load_win = [&](int32_t rw) -> v2f {
+        if (rw >= 0 && rw + (WV - 1) <= r_max) {
+            if ((rw & 7) != q0) { q0 = rw & 7; const uint32_t q = (uint32_t)q0 + (uint32_t)l; offl = ((q >> 3) * tstride + (q & 7u)) * 8u; }
+            const char *base = reinterpret_cast<const char *>(chb + (size_t)(uint32_t)(rw >> 3) * tstride);
+            return *reinterpret_cast<const v2f *>(base + offl);
+        }
+        int32_t r = rw + l;
+        r = r < 0 ? 0 : (r > r_max ? r_max : r);
+        return *reinterpret_cast<const v2f *>(chb + ((size_t)(r >> 3) * tstride + (size_t)(r & 7)));
+    };
+
+    v2f cur = load_win(r_ws), nxt = {0.f, 0.f};
+    uint32_t psi = 0;
+    for (uint32_t n = 0; n < nsym; n++) {
+        if (n + 1 < nsym) nxt = load_win(r_ws + L);
+        const uint32_t sgn = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(qsg) + (pc4 + (l < 16 ? l4 : 0u)));
+        // ---- oscillator, 64-point DIF transform, equaliser
+        v2f x = rot_down_pk(cur, u32rev(th_ws + (uint32_t)l * dth));
+        x = stage<32, XB, 0>(x, sgp[0], tw[0], bp32);
+        x = stage<16, XB, 1>(x, sgp[0], tw[1], bp32);
+        x = stage<8, XB, 0>(x, sgp[1], tw[2], bp32);
+        x = stage<4, XB, 1>(x, sgp[1], tw[3], bp32);
+        x = stage<2, XB, 0>(x, sgp[2], tw[4], bp32);
+        x = stage<1, XB, 1>(x, sgp[2], tw[5], bp32);
+        x = cmul_pk(x, R);
+        // ---- pilots to the first lanes, polarity, phase, unwrap, the two projections of the line fit
+        const float xr = x.x, xi = x.y;                                  // (copies: __builtin_bit_cast of a vector element reads element 0)
+        float2 P;
+        P.x = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(psrc, __builtin_bit_cast(int, xr)) ^ (int)sgn);
+        P.y = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(psrc, __builtin_bit_cast(int, xi)) ^ (int)sgn);
+        const float v = atan2_fast(P.y, P.x);
+        const float prev = dpp_mov<0x111, false>(v, v);                 // row_shr:1, lane 0 of the row keeps its own
+        const float turns = rintf((v - prev) * 0.15915494309189535f);
+        float p0, p1;
+        if (p8) {
+            float t = turns;
+            t += dpp_mov<0x111>(t); t += dpp_mov<0x112>(t); t += dpp_mov<0x114>(t);
+            const float y = fmaf(-TWO_PI_F, t, v);
+            const int yi = __builtin_bit_cast(int, y);
+            float z = pfc * __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(yi, yi, 0x118, 0xf, 0xc, false));   // lanes 8..15: y of lanes 0..7
+            z += dpp_mov<0x111>(z); z += dpp_mov<0x112>(z); z += dpp_mov<0x114>(z);
+            p0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z), 7));
+            p1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z), 15));
+        } else {
+            const float y = fmaf(-TWO_PI_F, row_scan_fast(turns), v);
+            p0 = row_total_dpp(pf0 * y);
+            p1 = row_total_dpp(pf1 * y);
+        }
+        pc4 += (uint32_t)Mp * 4u; pc4 = pc4 >= 255u * 4u ? pc4 - 255u * 4u : pc4;
+        p1 = 0.3f * p1 + (1.0f - 0.3f) * p1_prime;
+        p1_prime = p1;
+        // ---- de-rotate, soft bits
+        const v2f Z = rot_down_pk(x, fmaf(p1, fxr, p0 * 0.15915494309189535f));
+        const uint64_t sw = demod_pk<MOD>(reinterpret_cast<const uint8_t *>(qnb), Z, soft_mode);
+        uint8_t *ssym = syms + (size_t)psi * 8, *ssoft = soft + (size_t)psi * bps;
+        if (psi + (uint32_t)Md <= mod_len && (psi + (uint32_t)Md) * bps <= nbits) {
+            if (isdata) {
+                *reinterpret_cast<v2f *>(ssym + so_sym) = Z;
+                uint8_t *dst = ssoft + so_soft;
+                if constexpr (bps == 1) dst[0] = (uint8_t)sw;
+                else if constexpr (bps == 2) *reinterpret_cast<uint16_t *>(dst) = (uint16_t)sw;
+                else {                                                  // (4 or 6 bytes at a multiple of 2)
+                    *reinterpret_cast<uint16_t *>(dst) = (uint16_t)sw;
+                    *reinterpret_cast<uint16_t *>(dst + 2) = (uint16_t)(sw >> 16);
+                    if constexpr (bps == 6) *reinterpret_cast<uint16_t *>(dst + 4) = (uint16_t)(sw >> 32);
+                }
+            }
+        } else if (isdata && psi + (uint32_t)dr < mod_len) {             // the frame's last symbol: part of the subcarriers, part of their bits
+            *reinterpret_cast<v2f *>(ssym + so_sym) = Z;
+            const uint32_t b0 = (psi + (uint32_t)dr) * bps;
+#pragma unroll
+            for (unsigned kb = 0; kb < bps; kb++) if (b0 + kb < nbits) ssoft[so_soft + kb] = (uint8_t)(sw >> (8 * kb));
+        }
+        psi += (uint32_t)Md;
+        // ---- oscillator trim (liquid ofdmframesync: the phase at the next window start uses the old step up to this event)
+        float dphi = p0 - phi_prime;
+        dphi -= TWO_PI_F * rintf(dphi * 0.15915494309189535f);
+        phi_prime = p0;
+        const uint32_t dnew = dth + rfl((uint32_t)__float2int_rn(dphi * (1e-3f * 683565275.5764316f)));
+        th_ws += (uint32_t)(L - cb) * dth + (uint32_t)cb * dnew;
+        dth = dnew;
+        r_ws += L;
+        cur = nxt;
+    }
+    return dth;
+}
+
+}  // namespace lean
+
+// CLS 0: the frames with one or two bits per subcarrier (BPSK, QPSK), a wave per hand-off.  CLS 1: 16- and 64-QAM, a second
+// launch that walks place_jobs_kernel's list of them with a grid stride (normally empty; the host sizes the grid from the last
+// list it saw).  Two kernels because the QAM demodulator's registers (12 running minima, the neighbour walk) would otherwise
+// set the budget of the loop every frame of the periodic benchmark runs in: 56 VGPRs / 70 SGPRs = 8 waves per SIMD
+// (amdgpu_num_sgpr: at 86 SGPRs the scalar file admits 7, measured as 8192 waves taking two rounds).
+template <int XB, int CLS>
+__device__ __forceinline__ void payload_lean_body(SyncArgs &a)
+{
+    launder(a);
+    __shared__ uint32_t qsg[256 + 16];      // pilot polarity as a sign mask; the 255-long sequence continued past its end: no wrap inside a symbol
+    __shared__ uint32_t qnb[64];            // the soft demodulator's nearest-neighbour table of this frame's modem
+    __shared__ int qsrc[16];                // the lane that holds pilot r after the transform
+    const SyncConsts &c = a.c;
+    const int l = lane_id();
+    uint32_t nj = *a.njobs;
+    if (nj > a.max_jobs) nj = a.max_jobs;
+    uint32_t nlist = nj;
+    if (CLS == 1 && a.qam_list) { nlist = a.qam_list[0]; if (nlist > nj) nlist = nj; }
+    if (blockIdx.x >= nlist) return;
+    for (int k = l; k < 256 + 16; k += WV) qsg[k] = c.pilot_seq[k >= 255 ? k - 255 : k] == 0 ? 0x80000000u : 0u;
+    if (l < 16) qsrc[l] = 0;
+    wave_sync_lds();
+    { const int pr = c.pilot_rank[(int)(__brev((unsigned)l) >> 26)]; if (pr >= 0 && pr < 16) qsrc[pr] = l; }
+    wave_sync_lds();
+    for (uint32_t k = blockIdx.x; k < nlist; k += gridDim.x) {
+        const uint32_t j = (CLS == 1 && a.qam_list) ? rfl(a.qam_list[1 + k]) : k;
+        if (j >= nj) continue;
+        const PayloadJob *job = a.jobs + j;
+        const uint32_t ch = rfl(job->ch);
+        if (ch >= a.nch || job->arena_off == ~0ull) continue;
+        const uint32_t mod = rfl(job->s.mod_scheme);
+        if (((mod == 39 || mod == 40) ? 0 : 1) != CLS) continue;
+        uint32_t dth;
+        if constexpr (CLS == 0) {
+            if (mod == 39) dth = lean::symbols<39, XB>(a, job, ch, j, qsg, qnb, qsrc);
+            else           dth = lean::symbols<40, XB>(a, job, ch, j, qsg, qnb, qsrc);
+        } else {
+            wave_sync_lds();
+            if (mod == 27) { if (l < 16) qnb[l] = reinterpret_cast<const uint32_t *>(c.cod.qam16_nb)[l]; }
+            else qnb[l] = reinterpret_cast<const uint32_t *>(c.cod.qam64_nb)[l];
+            wave_sync_lds();
+            if (mod == 27) dth = lean::symbols<27, XB>(a, job, ch, j, qsg, qnb, qsrc);
+            else           dth = lean::symbols<29, XB>(a, job, ch, j, qsg, qnb, qsrc);
+        }
+        if (l == 0) a.jobs[j].s.nco_dtheta = dth;
+        if (CLS == 0) break;                // (one hand-off per wave: the grid is the job list)
+    }
+}
+template <int XB> __global__ __launch_bounds__(WV) __attribute__((amdgpu_num_sgpr(72))) void payload_lean_kernel(SyncArgs a) { payload_lean_body<XB, 0>(a); }
+template <int XB> __global__ __launch_bounds__(WV) void payload_lean_qam_kernel(SyncArgs a) { payload_lean_body<XB, 1>(a); }

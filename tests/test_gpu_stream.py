@@ -229,6 +229,67 @@ def test_payload_worker_builds_agree(oracle, product, fr, monkeypatch):
     rx.close()
 
 
+@pytest.mark.parametrize("env", [{}, {"MCRX_PAYLOAD_XB": "0"}, {"MCRX_PAYLOAD_LEAN": "0"}])
+def test_lean_payload_workers_every_modem_in_one_slab(oracle, product, env, monkeypatch):
+    """The 64-subcarrier payload workers (payload_lean.hpp) are two launches: BPSK / QPSK frames a wave each, 16- / 64-QAM frames
+    from the list place_jobs_kernel writes.  A stream whose channels change modem, code and length from frame to frame puts both
+    classes (and the partly filled last symbol of every length) into every launch: frames, bytes and order are the oracle's,
+    symbols <= 1e-5, in the default build, with the butterflies' exchanges on the VALU (MCRX_PAYLOAD_XB=0) and with the
+    round-2 worker (MCRX_PAYLOAD_LEAN=0)."""
+    from test_gpu_parity import check_frames
+    N, M, cp, nf = 8, 64, 8, 8
+    kinds = [(40, 6, 333), (27, 7, 150), (39, 1, 33), (29, 6, 257), (40, 1, 64), (27, 6, 1), (29, 1, 90), (39, 6, 500)]
+    tx = oracle.MultiChannelTx(N, M, cp, 4)
+    rngs = [np.random.RandomState(100 + c) for c in range(N)]
+    pid = [0] * N
+    chunks, idle = [], 0
+    while idle < 4:
+        for c in range(N):
+            if pid[c] < nf and tx.ready(c):
+                mod, fec1, plen = kinds[(pid[c] + c) % len(kinds)]
+                hdr = bytes([0, pid[c], c]) + bytes(rngs[c].randint(0, 256, 5).astype(np.uint8))
+                tx.update(c, hdr, bytes(rngs[c].randint(0, 256, plen).astype(np.uint8)), mod, 1, fec1)
+                pid[c] += 1
+        chunks.append(tx.generate(M + cp))
+        if all(pid[c] >= nf and tx.ready(c) for c in range(N)):
+            idle += 1
+    x = (np.concatenate(chunks) * np.float32(1.0 / N)).astype(np.complex64)
+    x = x[:len(x) // (16 * N) * (16 * N)]
+    ora = oracle.MultiChannelRx(N, M, cp, 4)
+    ora.execute(x)
+    assert len(ora.frames) == nf * N and all(f.payload_valid for f in ora.frames)
+    assert {f.mod_scheme for f in ora.frames} == {27, 29, 39, 40}
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=512)
+    half = len(x) // 2 // (16 * N) * (16 * N)
+    rx.Execute(x[:half]); rx.Execute(x[half:]); rx.Flush()       # (two pushes: frames of both classes straddle the cut)
+    check_frames(rx.frames, ora.frames)
+    rx.close()
+
+
+def test_qam_workers_walk_a_list_longer_than_their_grid(product):
+    """The QAM workers' launch is sized from the list the previous launches published (kernels.h: list_hint) with a floor of 256
+    workgroups: 64 channels x 6 frames of 16-QAM in the first push of a handle = 384 hand-offs on a 256-workgroup grid.  Every
+    frame arrives, bit-exact against what was sent, in the first push (grid stride) and in the pushes after it (full grid)."""
+    N, M, cp, nf, plen = 64, 64, 8, 6, 200
+    tx = product.multichanneltx(N, M, cp, 4)
+    slabs = [tx.generate(nf, plen, mod=27, fec1=7, seed=40 + k) for k in range(3)]
+    tx.close()
+    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=plen)
+    for k, (iq, sent) in enumerate(slabs):
+        rx.Execute(iq)
+    rx.Flush()
+    assert len(rx.frames) == 3 * nf * N
+    got = {}
+    for f in rx.frames:
+        assert f.header_valid and f.payload_valid and f.mod_scheme == 27
+        got.setdefault(f.channel, []).append((f.header, f.payload))
+    for c in range(N):
+        assert got[c] == [hp for _, sent in slabs for hp in sent[c]]
+    rx.close()
+
+
 def test_acquisition_policy_switches_with_the_traffic(oracle, product):
     """Periodic traffic is acquired by cadence speculation, ragged traffic (every frame its own length) by the walking scouts;
     the host switches between the two from the scouts' counters (mcrx_hip.hip launch_sync).  A stream that goes periodic ->
