@@ -157,13 +157,43 @@ __device__ __forceinline__ uint32_t symbols(const SyncArgs &a, const PayloadJob 
         return *reinterpret_cast<const v2f *>(chb + ((size_t)(r >> 3) * tstride + (size_t)(r & 7)));
     };
 
-    v2f cur = load_win(r_ws), nxt = {0.f, 0.f};
+    // Stores run one symbol late.  Loads and stores share one counter (vmcnt) and return out of order against each other, so
+    // waiting for a window that was requested before a symbol's stores waits for those stores' acknowledgements as well --
+    // several hundred cycles on every symbol's chain.  With the previous symbol's stores issued right after the wait and the
+    // next window requested right behind them, everything the next wait covers is a whole symbol old.
+    // (only a frame's last symbol can be partly filled -- mod_len = ceil(nbits / bps), so every earlier one ends below nbits --
+    //  and the last one is stored behind the loop: the stores inside it take the first branch without asking)
+    auto store_symbol = [&](uint32_t ps, v2f Z, uint64_t sw, bool inner) {
+        uint8_t *ssym = syms + (size_t)ps * 8, *ssoft = soft + (size_t)ps * bps;
+        if (inner || (ps + (uint32_t)Md <= mod_len && (ps + (uint32_t)Md) * bps <= nbits)) {
+            if (isdata) {
+                *reinterpret_cast<v2f *>(ssym + so_sym) = Z;
+                uint8_t *dst = ssoft + so_soft;
+                if constexpr (bps == 1) dst[0] = (uint8_t)sw;
+                else if constexpr (bps == 2) *reinterpret_cast<uint16_t *>(dst) = (uint16_t)sw;
+                else {                                                  // (4 or 6 bytes at a multiple of 2)
+                    *reinterpret_cast<uint16_t *>(dst) = (uint16_t)sw;
+                    *reinterpret_cast<uint16_t *>(dst + 2) = (uint16_t)(sw >> 16);
+                    if constexpr (bps == 6) *reinterpret_cast<uint16_t *>(dst + 4) = (uint16_t)(sw >> 32);
+                }
+            }
+        } else if (isdata && ps + (uint32_t)dr < mod_len) {              // the frame's last symbol: part of the subcarriers, part of their bits
+            *reinterpret_cast<v2f *>(ssym + so_sym) = Z;
+            const uint32_t b0 = (ps + (uint32_t)dr) * bps;
+#pragma unroll
+            for (unsigned kb = 0; kb < bps; kb++) if (b0 + kb < nbits) ssoft[so_soft + kb] = (uint8_t)(sw >> (8 * kb));
+        }
+    };
+    v2f cur = load_win(r_ws);
+    v2f Zp = {0.f, 0.f}; uint64_t swp = 0;                               // the previous symbol's results, not stored yet
     uint32_t psi = 0;
     for (uint32_t n = 0; n < nsym; n++) {
-        if (n + 1 < nsym) nxt = load_win(r_ws + L);
         const uint32_t sgn = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(qsg) + (pc4 + (l < 16 ? l4 : 0u)));
-        // ---- oscillator, 64-point DIF transform, equaliser
+        // ---- oscillator (the window's registers are free after it), the previous symbol's stores, the next window
         v2f x = rot_down_pk(cur, u32rev(th_ws + (uint32_t)l * dth));
+        if (n > 0) store_symbol(psi - (uint32_t)Md, Zp, swp, true);
+        if (n + 1 < nsym) cur = load_win(r_ws + L);
+        // ---- 64-point DIF transform, equaliser
         x = stage<32, XB, 0>(x, sgp[0], tw[0], bp32);
         x = stage<16, XB, 1>(x, sgp[0], tw[1], bp32);
         x = stage<8, XB, 0>(x, sgp[1], tw[2], bp32);
@@ -197,28 +227,9 @@ __device__ __forceinline__ uint32_t symbols(const SyncArgs &a, const PayloadJob 
         pc4 += (uint32_t)Mp * 4u; pc4 = pc4 >= 255u * 4u ? pc4 - 255u * 4u : pc4;
         p1 = 0.3f * p1 + (1.0f - 0.3f) * p1_prime;
         p1_prime = p1;
-        // ---- de-rotate, soft bits
-        const v2f Z = rot_down_pk(x, fmaf(p1, fxr, p0 * 0.15915494309189535f));
-        const uint64_t sw = demod_pk<MOD>(reinterpret_cast<const uint8_t *>(qnb), Z, soft_mode);
-        uint8_t *ssym = syms + (size_t)psi * 8, *ssoft = soft + (size_t)psi * bps;
-        if (psi + (uint32_t)Md <= mod_len && (psi + (uint32_t)Md) * bps <= nbits) {
-            if (isdata) {
-                *reinterpret_cast<v2f *>(ssym + so_sym) = Z;
-                uint8_t *dst = ssoft + so_soft;
-                if constexpr (bps == 1) dst[0] = (uint8_t)sw;
-                else if constexpr (bps == 2) *reinterpret_cast<uint16_t *>(dst) = (uint16_t)sw;
-                else {                                                  // (4 or 6 bytes at a multiple of 2)
-                    *reinterpret_cast<uint16_t *>(dst) = (uint16_t)sw;
-                    *reinterpret_cast<uint16_t *>(dst + 2) = (uint16_t)(sw >> 16);
-                    if constexpr (bps == 6) *reinterpret_cast<uint16_t *>(dst + 4) = (uint16_t)(sw >> 32);
-                }
-            }
-        } else if (isdata && psi + (uint32_t)dr < mod_len) {             // the frame's last symbol: part of the subcarriers, part of their bits
-            *reinterpret_cast<v2f *>(ssym + so_sym) = Z;
-            const uint32_t b0 = (psi + (uint32_t)dr) * bps;
-#pragma unroll
-            for (unsigned kb = 0; kb < bps; kb++) if (b0 + kb < nbits) ssoft[so_soft + kb] = (uint8_t)(sw >> (8 * kb));
-        }
+        // ---- de-rotate, soft bits (stored at the top of the next turn)
+        Zp = rot_down_pk(x, fmaf(p1, fxr, p0 * 0.15915494309189535f));
+        swp = demod_pk<MOD>(reinterpret_cast<const uint8_t *>(qnb), Zp, soft_mode);
         psi += (uint32_t)Md;
         // ---- oscillator trim (liquid ofdmframesync: the phase at the next window start uses the old step up to this event)
         float dphi = p0 - phi_prime;
@@ -228,8 +239,8 @@ __device__ __forceinline__ uint32_t symbols(const SyncArgs &a, const PayloadJob 
         th_ws += (uint32_t)(L - cb) * dth + (uint32_t)cb * dnew;
         dth = dnew;
         r_ws += L;
-        cur = nxt;
     }
+    if (nsym > 0) store_symbol(psi - (uint32_t)Md, Zp, swp, false);
     return dth;
 }
 
