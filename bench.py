@@ -469,7 +469,7 @@ def measured_traffic(kernel, N, frames, payload):
     m = re.search(r"(\d+)-ch multichannelrx.*?(\d+)B payloads, (\d+) frames/ch/slab", prof.get("workload", ""))
     if not m or (int(m.group(1)), int(m.group(3)), int(m.group(2))) != (N, frames, payload):
         return None                                     # the committed counters are of another workload
-    alias = {"payload_kernel": ("payload_multi_kernel", "payload_kernel"), "sync_kernel": ("sync_lean_kernel", "sync_kernel")}
+    alias = {"payload_kernel": ("payload_lean_kernel", "payload_multi_kernel", "payload_kernel"), "sync_kernel": ("sync_lean_kernel", "sync_kernel")}
     for want in alias.get(kernel, (kernel,)):
         for name, t in prof.get("kernels", {}).items():
             if want in name:
