@@ -191,8 +191,8 @@ __device__ __forceinline__ uint32_t symbols(const SyncArgs &a, const PayloadJob 
         const uint32_t sgn = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(qsg) + (pc4 + (l < 16 ? l4 : 0u)));
         // ---- oscillator (the window's registers are free after it), the previous symbol's stores, the next window
         v2f x = rot_down_pk(cur, u32rev(th_ws + (uint32_t)l * dth));
-        if (n > 0) store_symbol(psi - (uint32_t)Md, Zp, swp, true);
         if (n + 1 < nsym) cur = load_win(r_ws + L);
+        if (n > 0) store_symbol(psi - (uint32_t)Md, Zp, swp, true);
         // ---- 64-point DIF transform, equaliser
         x = stage<32, XB, 0>(x, sgp[0], tw[0], bp32);
         x = stage<16, XB, 1>(x, sgp[0], tw[1], bp32);
