@@ -23,6 +23,20 @@ namespace syn {
 #define SYN_P 26            // taps per branch (m = 13)
 #define SYN_H (SYN_P - 1)   // blocks of history
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+// acc += x * t.lo / t.hi in both components (one v_pk_fma_f32, the tap broadcast by op_sel)
+__device__ __forceinline__ void pk_fma_lo(float2 &acc, const float2 &x, v2f t)
+{
+    v2f a = { acc.x, acc.y }; const v2f xv = { x.x, x.y };
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(a) : "v"(xv), "v"(t));
+    acc.x = a.x; acc.y = a.y;
+}
+__device__ __forceinline__ void pk_fma_hi(float2 &acc, const float2 &x, v2f t)
+{
+    v2f a = { acc.x, acc.y }; const v2f xv = { x.x, x.y };
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(a) : "v"(xv), "v"(t));
+    acc.x = a.x; acc.y = a.y;
+}
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 __device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -86,7 +100,14 @@ template <int K, int R> struct Lds {
 };
 
 // K >= 128 (T = K/2 >= 64 threads: thread t is channel t when the inputs are gathered, columns 2t, 2t+1 afterwards)
-template <int K, int R>
+// IN: where the bank's inputs come from -- SYN_TILES exchanged granules, SYN_SYMS the aligned symbol loader (syn_aligned below
+// says when it applies), SYN_WALK frame_sample_at block by block (any geometry)
+enum { SYN_TILES = 0, SYN_SYMS = 1, SYN_WALK = 2 };
+__host__ __device__ inline bool syn_aligned(const TxSynthArgs &a)
+{
+    return !a.tiles && !a.ft0 && (a.L % 8) == 0 && (a.cp % 8) == 0 && (a.M % 8) == 0 && a.taper >= 0 && a.taper <= 4;
+}
+template <int K, int R, int IN>
 __global__ __launch_bounds__(K / 2) void synth_kernel(TxSynthArgs a, uint32_t slab_blocks)
 {
     constexpr int T = K / 2, N = K / 2, C = 2;
@@ -157,23 +178,103 @@ __global__ __launch_bounds__(K / 2) void synth_kernel(TxSynthArgs a, uint32_t sl
     float osn = 0.f, ocs = 1.f;
 
     const int rounds = (int)((o1 - bstart + R - 1) / R);
+    // Inputs of a round: channel tid of blocks b0 .. b0+R-1.  Granules received from the channel shards ([g][tile][c][8],
+    // channel = g cg + c; R consecutive blocks of a granule are contiguous: R divides 8 and rounds start on multiples of R) are
+    // requested one round ahead with clamped addresses -- no load sits under a branch, so the request stays in flight across
+    // the whole round -- and blocks outside the stream are zeroed when they are written to the tile.
+    constexpr bool tiled = IN == SYN_TILES;
+    const uint32_t tg = tiled ? (uint32_t)tid / a.cg : 0u, tc = tiled ? (uint32_t)tid % a.cg : 0u;
+    float4 xq[R / 2];
+    (void)tg; (void)tc;
+    auto request_tiles = [&](long long b0) {
+#pragma unroll
+        for (int r = 0; r < R; r += 2) {
+            long long b = b0 + r;
+            if (!(b >= 0 && b + 1 < (long long)a.nblocks)) b = 0;
+            xq[r / 2] = *reinterpret_cast<const float4 *>(a.tiles + (((size_t)tg * a.ntiles + (size_t)(b >> 3)) * a.cg + tc) * 8 + (size_t)(b & 7));
+        }
+    };
+    // Batch / ragged layout when a round of 8 blocks never straddles an OFDM symbol (8 | L, cp, M; rounds start on multiples of 8:
+    // every configuration of the reference's applications): the round's inputs are 64 contiguous, 64-byte aligned bytes of one
+    // symbol body -- four 16-byte loads with clamped addresses, requested one round ahead like the granules -- plus the first four
+    // samples of the previous body for the raised-cosine overlap; the symbol's role (ragged traffic: a byte per symbol and channel)
+    // is requested two rounds ahead so that no address waits for it.  What the samples mean is decided when they are consumed.
+    constexpr bool fastsym = IN == SYN_SYMS;
+    static_assert(!fastsym || R == 8, "the aligned loader works in rounds of 8 blocks");
+    const uint32_t nsym = (uint32_t)(a.frames * a.S);
+    const float2 *xch = a.xsym + (size_t)tid * a.frames * a.S * a.M;
+    float4 pq[2];
+    int role_q = 0;
+    uint32_t kq = 0;
+    auto sym_of = [&](long long b0, uint32_t &gs, uint32_t &i) -> bool {
+        const long long bc = b0 < 0 ? 0 : b0;
+        gs = (uint32_t)bc / (uint32_t)a.L; i = (uint32_t)bc % (uint32_t)a.L;
+        return b0 >= 0 && b0 < (long long)a.nblocks && gs < nsym;
+    };
+    auto request_kind = [&](long long b0) {
+        if (a.symkind) {
+            uint32_t gs, i; sym_of(b0, gs, i);
+            kq = a.symkind[(size_t)tid * nsym + (gs < nsym ? gs : nsym - 1)];
+        }
+    };
+    auto request_syms = [&](long long b0) {
+        if constexpr (R == 8) {
+            uint32_t gs, i; const bool ok = sym_of(b0, gs, i);
+            int role;                                                   // 0 nothing, 1 S0a, 2 plain cyclic extension, 3 tail, 4 extension + overlap
+            if (a.symkind) role = kq == TXK_IDLE ? 0 : (kq == TXK_S0A ? 1 : (kq == TXK_S0B ? 2 : (kq == TXK_TAIL ? 3 : 4)));
+            else { const int sidx = (int)(gs % (uint32_t)a.S); role = sidx == 0 ? 1 : (sidx == 1 ? 2 : (sidx == a.S - 1 ? 3 : 4)); }
+            if (!ok) role = 0;
+            role_q = role;
+            const uint32_t gsc = ok ? gs : 0u;
+            const float2 *x = xch + (size_t)gsc * a.M;
+            const uint32_t base = (i + (uint32_t)a.M - (role == 1 ? 2u : 1u) * (uint32_t)a.cp) % (uint32_t)a.M;
+            const float4 *xp = reinterpret_cast<const float4 *>(x + base);
+#pragma unroll
+            for (int q = 0; q < 4; q++) xq[q] = xp[q];
+            const float4 *pp = reinterpret_cast<const float4 *>(gsc > 0 ? x - a.M : x);
+            pq[0] = pp[0]; pq[1] = pp[1];
+        }
+    };
+    auto finish_syms = [&](long long b0, float2 (&xin)[R]) {
+        if constexpr (R == 8) {
+            uint32_t gs, i; sym_of(b0, gs, i);
+            const int role = role_q;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const float2 v = (r & 1) ? make_float2(xq[r / 2].z, xq[r / 2].w) : make_float2(xq[r / 2].x, xq[r / 2].y);
+                float2 res = (role == 0 || role == 3) ? make_float2(0.f, 0.f) : v;
+                if (r < 4) {
+                    if ((int)(i + r) < a.taper) {                       // (only a symbol's first round: i = 0)
+                        const float2 p = (r & 1) ? make_float2(pq[r / 2].z, pq[r / 2].w) : make_float2(pq[r / 2].x, pq[r / 2].y);
+                        const float wa = a.taperwin[i + r], wb = a.taperwin[a.taper - 1 - (int)(i + r)];
+                        if (role == 1) res = make_float2(v.x * wa, v.y * wa);
+                        else if (role == 3) res = make_float2(p.x * wb, p.y * wb);
+                        else if (role == 4) res = taper_blend(v, wa, p, wb);
+                    }
+                }
+                if (b0 + r >= (long long)a.nblocks) res = make_float2(0.f, 0.f);
+                xin[r] = res;
+            }
+        }
+    };
+    if constexpr (tiled) request_tiles(bstart);
+    else if constexpr (fastsym) { request_kind(bstart); request_syms(bstart); request_kind(bstart + R); }
     for (int rd = 0; rd < rounds; rd++) {
         const long long b0 = bstart + (long long)rd * R;
         const int tq = opaque(tid);
-        // ---- inputs: channel tid of blocks b0 .. b0+R-1, conjugated (inverse transform = conj(forward(conj))); bins >= N are zero
+        // ---- inputs, conjugated (inverse transform = conj(forward(conj))); bins >= N are zero and never stored: the first
+        //      radix-4 stage below knows it
         float2 xin[R];
-        if (a.tiles) {
-            // granules received from the channel shards: [g][tile][c][8], channel = g cg + c; R consecutive blocks of a
-            // granule are contiguous (R divides 8 and rounds start on multiples of R)
-            const uint32_t g = (uint32_t)tid / a.cg, c = (uint32_t)tid % a.cg;
+        if constexpr (tiled) {
 #pragma unroll
             for (int r = 0; r < R; r += 2) {
                 const long long b = b0 + r;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (b >= 0 && b + 1 < (long long)a.nblocks)
-                    v = *reinterpret_cast<const float4 *>(a.tiles + (((size_t)g * a.ntiles + (size_t)(b >> 3)) * a.cg + c) * 8 + (size_t)(b & 7));
-                xin[r] = make_float2(v.x, v.y); xin[r + 1] = make_float2(v.z, v.w);
+                const bool in = b >= 0 && b + 1 < (long long)a.nblocks;
+                xin[r] = in ? make_float2(xq[r / 2].x, xq[r / 2].y) : make_float2(0.f, 0.f);
+                xin[r + 1] = in ? make_float2(xq[r / 2].z, xq[r / 2].w) : make_float2(0.f, 0.f);
             }
+        } else if constexpr (fastsym) {
+            finish_syms(b0, xin);
         } else {
             // batch / ragged layout: the channel's frame axis, symbol gs = b / L, position i = b % L -- one division per
             // round, then the position walks on (frame_sample_at: the role of symbol gs is looked up where it changes)
@@ -188,10 +289,10 @@ __global__ __launch_bounds__(K / 2) void synth_kernel(TxSynthArgs a, uint32_t sl
             }
         }
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            float2 *row = tile + r * ROWP;
-            row[xrow] = make_float2(xin[r].x, -xin[r].y);
-            row[pad<K>(N) + xrow] = make_float2(0.f, 0.f);          // (pad(N + t) = pad(N) + pad(t): N is a multiple of F)
+        for (int r = 0; r < R; r++) tile[r * ROWP + xrow] = make_float2(xin[r].x, -xin[r].y);
+        if (rd + 1 < rounds) {
+            if constexpr (tiled) request_tiles(b0 + R);
+            else if constexpr (fastsym) { request_syms(b0 + R); request_kind(b0 + 2 * R); }
         }
         lds_barrier();
         // ---- R forward K-point transforms in place (channelizer.hip's plan)
@@ -203,6 +304,22 @@ __global__ __launch_bounds__(K / 2) void synth_kernel(TxSynthArgs a, uint32_t sl
                 const float2 *twp = tile + R * ROWP + TAPF / 2 + Plan<K>::tw_off(st) + tq % q4;
                 const int fa_st = stage_index(st, tq);
                 const float2 tw1 = twp[0], tw2 = twp[q4], tw3 = twp[2 * q4];
+                if (st == 0) {
+                    // legs 2 and 3 are the zero bins N .. K-1: a0 = a1 = x0, a2 = x1, a3 = -j x1 (the values the full butterfly
+                    // forms from x2 = x3 = 0)
+#pragma unroll
+                    for (int i = 0; i < BTRIPS; i++) {
+                        float2 *p = tile + fa_st + i * BSTEP;
+                        const float2 x0 = p[0], x1 = p[D];
+                        const float2 a3 = cmulnj(x1);
+                        p[0] = cadd(x0, x1);
+                        p[D] = cmul(cadd(x0, a3), tw1);
+                        p[2 * D] = cmul(csub(x0, x1), tw2);
+                        p[3 * D] = cmul(csub(x0, a3), tw3);
+                    }
+                    lds_barrier();
+                    continue;
+                }
 #pragma unroll
                 for (int i = 0; i < BTRIPS; i++) {
                     float2 *p = tile + fa_st + i * BSTEP;
@@ -262,32 +379,50 @@ __global__ __launch_bounds__(K / 2) void synth_kernel(TxSynthArgs a, uint32_t sl
         }
         // ---- synthesis FIR, oscillator, gain, store (rounds that only fill the window skip it)
         if (b0 + R > o0) {
-            float tap[SYN_P][C];
+            // taps outermost, oldest first (the order of the window dot product for every output): a tap pair is read from
+            // LDS where it is used and serves the round's R blocks, so the prototype costs two registers instead of 2 p
+            float2 acc[R][C];
 #pragma unroll
-            for (int j = 0; j < SYN_P; j++)
+            for (int r = 0; r < R; r++)
 #pragma unroll
-                for (int c = 0; c < C; c++)
-                    tap[j][c] = (j >= SYN_P / 2) ? ltf[tapm - c + (SYN_P - 1 - j) * K + 1] : ltf[tapb + c + j * K];
+                for (int c = 0; c < C; c++) acc[r][c] = make_float2(0.f, 0.f);
+            // A tap pair (columns n0, n0 + 1) is one 64-bit LDS read and feeds v_pk_fma_f32 as it stands: op_sel broadcasts its low
+            // or high half to both components of the product, so no (t, t) pairs are built (the compiler's form: two moves and two
+            // registers per tap and column -- what spilled the window).  Direct branches hold column 0 in the low half, mirrored
+            // ones in the high half.  Reads run two pairs ahead of the multiplies; the memory fences keep that order.
+            auto tap_pair = [&](int j) -> v2f {
+                v2f t;
+                if (j >= SYN_P / 2) { t.x = ltf[tapm - 1 + (SYN_P - 1 - j) * K + 1]; t.y = ltf[tapm + (SYN_P - 1 - j) * K + 1]; }
+                else { t.x = ltf[tapb + j * K]; t.y = ltf[tapb + 1 + j * K]; }
+                return t;
+            };
+            v2f tq0 = tap_pair(SYN_P - 1), tq1 = tap_pair(SYN_P - 2);
+#pragma unroll
+            for (int j = SYN_P - 1; j >= 0; j--) {
+                const v2f tp = tq0;
+                tq0 = tq1;
+                if (j >= 2) tq1 = tap_pair(j - 2);
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    if ((j >= SYN_P / 2) == false) {
+                        pk_fma_lo(acc[r][0], s[SYN_H + r - j][0], tp);
+                        pk_fma_hi(acc[r][1], s[SYN_H + r - j][1], tp);
+                    } else {
+                        pk_fma_hi(acc[r][0], s[SYN_H + r - j][0], tp);
+                        pk_fma_lo(acc[r][1], s[SYN_H + r - j][1], tp);
+                    }
+                }
+            }
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 const long long b = b0 + r;
-                float2 acc[C];
-#pragma unroll
-                for (int c = 0; c < C; c++) acc[c] = make_float2(0.f, 0.f);
-#pragma unroll
-                for (int j = SYN_P - 1; j >= 0; j--) {               // oldest first, like the window dot product
-#pragma unroll
-                    for (int c = 0; c < C; c++) {
-                        acc[c].x += tap[j][c] * s[SYN_H + r - j][c].x;
-                        acc[c].y += tap[j][c] * s[SYN_H + r - j][c].y;
-                    }
-                }
                 if ((b & 7) == 0)       // first block of a group (slabs start on multiples of 8, so a slab's first output block is one)
                     sincos_u32_hw((a.first_sample_lo + (uint32_t)((unsigned long long)b * K + (unsigned)n0)) * a.dtheta, osn, ocs);
                 if (b >= o0 && b < o1) {
                     const float s1 = fmaf(osn, cd1, ocs * sd1), c1 = fmaf(ocs, cd1, -(osn * sd1));            // the second column
-                    const float2 y0 = make_float2(fmaf(acc[0].x, ocs, -(acc[0].y * osn)), fmaf(acc[0].y, ocs, acc[0].x * osn));
-                    const float2 y1 = make_float2(fmaf(acc[1].x, c1, -(acc[1].y * s1)), fmaf(acc[1].y, c1, acc[1].x * s1));
+                    const float2 y0 = make_float2(fmaf(acc[r][0].x, ocs, -(acc[r][0].y * osn)), fmaf(acc[r][0].y, ocs, acc[r][0].x * osn));
+                    const float2 y1 = make_float2(fmaf(acc[r][1].x, c1, -(acc[r][1].y * s1)), fmaf(acc[r][1].y, c1, acc[r][1].x * s1));
                     *reinterpret_cast<float4 *>(uniform_ptr(outb + (size_t)(b - (long long)a.out_first) * K * sizeof(float2)) + ooff) =
                         make_float4(y0.x * a.gain, y0.y * a.gain, y1.x * a.gain, y1.y * a.gain);
                 }

@@ -193,6 +193,12 @@ struct TxSynthArgs {
 };
 
 __device__ __forceinline__ float2 frame_sample_sym(const TxSynthArgs &a, uint32_t ch, const float2 *xb, int S, uint32_t nsym, uint32_t gs, uint32_t i);
+// raised-cosine overlap of a symbol's first samples with the previous symbol's postfix: one fma shape wherever it is formed
+// (frame_sample_sym and the fused synthesis kernel's aligned loader must agree bit for bit)
+__device__ __forceinline__ float2 taper_blend(float2 v, float wa, float2 p, float wb)
+{
+    return make_float2(fmaf(v.x, wa, p.x * wb), fmaf(v.y, wa, p.y * wb));
+}
 // batch / ragged layout only (no streaming slots): the caller walks (gs, i) itself
 __device__ __forceinline__ float2 frame_sample_at(const TxSynthArgs &a, uint32_t ch, uint32_t gs, uint32_t i)
 {
@@ -241,7 +247,7 @@ __device__ __forceinline__ float2 frame_sample_sym(const TxSynthArgs &a, uint32_
     if ((int)i < a.taper) {
         const float2 p = (x - M)[i];                // first samples of the previous symbol body (S0b: s0)
         const float wa = a.taperwin[i], wb = a.taperwin[a.taper - 1 - i];
-        v = make_float2(v.x * wa + p.x * wb, v.y * wa + p.y * wb);
+        v = taper_blend(v, wa, p, wb);
     }
     return v;
 }
@@ -767,12 +773,12 @@ static bool tx_fused_ok(mctx_hip_t q, const TxSynthArgs &ya)
     return env != 0 && q->taps_symmetric && !ya.ft0 && ya.hist == 0 && (q->K == 128 || q->K == 256 || q->K == 512 || q->K == 1024) &&
            (ya.out_first % 8) == 0;
 }
-template <int KK, int R>
-static int tx_launch_fused(mctx_hip_t q, const TxSynthArgs &ya, hipStream_t st)
+template <int KK, int R, int IN>
+static int tx_launch_fused_in(mctx_hip_t q, const TxSynthArgs &ya, hipStream_t st)
 {
     const size_t lds = syn::Lds<KK, R>::bytes();
     static bool attr = false;
-    if (!attr) { TXCHK(hipFuncSetAttribute((const void *)syn::synth_kernel<KK, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    if (!attr) { TXCHK(hipFuncSetAttribute((const void *)syn::synth_kernel<KK, R, IN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
     const size_t nout = ya.nblocks - ya.out_first;
     // slab per workgroup: a whole number of workgroup waves over the CUs, at most 512 blocks (28 blocks of lead-in each)
     const size_t cap = (size_t)q->ncu * (KK >= 1024 ? 1 : 2);
@@ -780,9 +786,21 @@ static int tx_launch_fused(mctx_hip_t q, const TxSynthArgs &ya, hipStream_t st)
     size_t slab = ((nout + cap * k - 1) / (cap * k) + 7) & ~(size_t)7;
     if (slab < 256) slab = 256;                     // (28 blocks of lead-in per slab)
     const unsigned grid = (unsigned)((nout + slab - 1) / slab);
-    hipLaunchKernelGGL((syn::synth_kernel<KK, R>), dim3(grid), dim3(KK / 2), lds, st, ya, (uint32_t)slab);
+    hipLaunchKernelGGL((syn::synth_kernel<KK, R, IN>), dim3(grid), dim3(KK / 2), lds, st, ya, (uint32_t)slab);
     TXCHK(hipGetLastError());
     return MCRX_OK;
+}
+// the input side of the kernel is a compile-time choice (three loaders in one body spilled the window): exchanged granules,
+// the aligned symbol loader (rounds of 8 blocks only), or the block-by-block walk
+template <int KK, int R>
+static int tx_launch_fused(mctx_hip_t q, const TxSynthArgs &ya, hipStream_t st)
+{
+    if (ya.tiles) return tx_launch_fused_in<KK, R, syn::SYN_TILES>(q, ya, st);
+    if constexpr (R == 8) {
+        static const int al = getenv("MCTX_ALIGNED") ? atoi(getenv("MCTX_ALIGNED")) : 1;
+        if (al && syn::syn_aligned(ya)) return tx_launch_fused_in<KK, 8, syn::SYN_SYMS>(q, ya, st);
+    }
+    return tx_launch_fused_in<KK, R, syn::SYN_WALK>(q, ya, st);
 }
 static int tx_synthesize(mctx_hip_t q, const TxSynthArgs &ya, hipStream_t st)
 {
