@@ -20,6 +20,11 @@
 namespace mcrx {
 namespace syn {
 
+// development builds only (scratch/syn_ablate.sh: -DSYN_ABLATE=bits): 1 no radix-4 stages, 2 no register stage, 4 one tap instead
+// of 26, 8 no stores, 16 no input loads, 32 no window shift, 64 no early wait for the inputs.  The shipped library is built without it.
+#ifndef SYN_ABLATE
+#define SYN_ABLATE 0
+#endif
 #define SYN_P 26            // taps per branch (m = 13)
 #define SYN_H (SYN_P - 1)   // blocks of history
 
@@ -202,63 +207,94 @@ __global__ __launch_bounds__(K / 2) void synth_kernel(TxSynthArgs a, uint32_t sl
     constexpr bool fastsym = IN == SYN_SYMS;
     static_assert(!fastsym || R == 8, "the aligned loader works in rounds of 8 blocks");
     const uint32_t nsym = (uint32_t)(a.frames * a.S);
-    const float2 *xch = a.xsym + (size_t)tid * a.frames * a.S * a.M;
+    const float2 *xch = xs_channel(a, (uint32_t)tid);
+    const size_t xstep = xs_sym_of(a);
     float4 pq[2];
-    int role_q = 0;
-    uint32_t kq = 0;
-    auto sym_of = [&](long long b0, uint32_t &gs, uint32_t &i) -> bool {
-        const long long bc = b0 < 0 ? 0 : b0;
-        gs = (uint32_t)bc / (uint32_t)a.L; i = (uint32_t)bc % (uint32_t)a.L;
-        return b0 >= 0 && b0 < (long long)a.nblocks && gs < nsym;
+    float twin[4] = { 0.f, 0.f, 0.f, 0.f };                             // the raised-cosine ramp (taper <= 4 here), read once
+    if constexpr (fastsym) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (k < a.taper) twin[k] = a.taperwin[k];
+    }
+    // What a round's 64 bytes mean is decided by very little: txsym writes zeros into the bodies of idle and tail symbols, so
+    // outside a symbol's first round the samples are used as they arrive; S0a differs by its read offset (two prefixes back),
+    // and in a symbol's first round (i = 0, the same on every channel) the first `taper` samples are the raised-cosine overlap
+    // with the previous body -- for every role but S0b, whose reference form has none: a zero previous body (S0a) or a zero own
+    // body (tail) make frame_sample_sym's three special cases instances of the one fma shape.
+    uint32_t kq = 0;                                                    // ragged: kind of the symbol the NEXT request reads
+    int s0b_q = 0;                                                      // the round in xq belongs to an S0b symbol
+    // position of the next request on the symbol axis, walked (uniform): block bq, symbol gq, offset iq in it
+    long long bq = bstart;
+    uint32_t gq = (uint32_t)(bstart < 0 ? 0 : bstart) / (uint32_t)a.L, iq = (uint32_t)(bstart < 0 ? 0 : bstart) % (uint32_t)a.L;
+    gq = (uint32_t)uniform_i((int)gq); iq = (uint32_t)uniform_i((int)iq);
+    uint32_t gf = 0, if_ = 0; bool okf = false;                         // ... of the round whose samples are in xq
+    auto step = [&](long long &bb, uint32_t &g, uint32_t &i) {
+        if (bb >= 0) { i += R; if (i >= (uint32_t)a.L) { i -= (uint32_t)a.L; g++; } }
+        bb += R;
     };
-    auto request_kind = [&](long long b0) {
+    auto request_kind = [&]() {                                         // for the next request (the position has moved on to it)
         if (a.symkind) {
-            uint32_t gs, i; sym_of(b0, gs, i);
-            kq = a.symkind[(size_t)tid * nsym + (gs < nsym ? gs : nsym - 1)];
+            const uint32_t gk = gq < nsym ? gq : nsym - 1;
+            kq = a.symkind[a.ks_sym ? (size_t)tid * a.ks_ch + (size_t)gk * a.ks_sym : (size_t)tid * nsym + gk];
         }
     };
-    auto request_syms = [&](long long b0) {
+    auto request_syms = [&]() {
         if constexpr (R == 8) {
-            uint32_t gs, i; const bool ok = sym_of(b0, gs, i);
-            int role;                                                   // 0 nothing, 1 S0a, 2 plain cyclic extension, 3 tail, 4 extension + overlap
-            if (a.symkind) role = kq == TXK_IDLE ? 0 : (kq == TXK_S0A ? 1 : (kq == TXK_S0B ? 2 : (kq == TXK_TAIL ? 3 : 4)));
-            else { const int sidx = (int)(gs % (uint32_t)a.S); role = sidx == 0 ? 1 : (sidx == 1 ? 2 : (sidx == a.S - 1 ? 3 : 4)); }
-            if (!ok) role = 0;
-            role_q = role;
-            const uint32_t gsc = ok ? gs : 0u;
-            const float2 *x = xch + (size_t)gsc * a.M;
-            const uint32_t base = (i + (uint32_t)a.M - (role == 1 ? 2u : 1u) * (uint32_t)a.cp) % (uint32_t)a.M;
-            const float4 *xp = reinterpret_cast<const float4 *>(x + base);
+            const bool ok = bq >= 0 && bq < (long long)a.nblocks && gq < nsym;
+            bool s0a;
+            if (a.symkind) { s0a = kq == TXK_S0A; s0b_q = kq == TXK_S0B; }
+            else { const int sidx = (int)(gq % (uint32_t)a.S); s0a = sidx == 0; s0b_q = sidx == 1; }
+            gf = gq; if_ = iq; okf = ok;
+            const uint32_t gsc = ok ? gq : 0u;
+            const float2 *x = xch + (size_t)gsc * xstep;
+            const uint32_t base1 = (iq + (uint32_t)a.M - (uint32_t)a.cp) % (uint32_t)a.M, base2 = (iq + (uint32_t)a.M - 2u * (uint32_t)a.cp) % (uint32_t)a.M;
+            const float4 *xp = reinterpret_cast<const float4 *>(x + (s0a ? base2 : base1));
 #pragma unroll
             for (int q = 0; q < 4; q++) xq[q] = xp[q];
-            const float4 *pp = reinterpret_cast<const float4 *>(gsc > 0 ? x - a.M : x);
-            pq[0] = pp[0]; pq[1] = pp[1];
+            if (iq == 0) {                                              // (uniform) the previous body's first samples: the overlap
+                const float4 *pp = reinterpret_cast<const float4 *>(gsc > 0 ? x - xstep : x);
+                pq[0] = pp[0]; pq[1] = pp[1];
+            }
+            step(bq, gq, iq);
         }
     };
     auto finish_syms = [&](long long b0, float2 (&xin)[R]) {
         if constexpr (R == 8) {
-            uint32_t gs, i; sym_of(b0, gs, i);
-            const int role = role_q;
 #pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const float2 v = (r & 1) ? make_float2(xq[r / 2].z, xq[r / 2].w) : make_float2(xq[r / 2].x, xq[r / 2].y);
-                float2 res = (role == 0 || role == 3) ? make_float2(0.f, 0.f) : v;
-                if (r < 4) {
-                    if ((int)(i + r) < a.taper) {                       // (only a symbol's first round: i = 0)
+            for (int r = 0; r < 8; r++) xin[r] = (r & 1) ? make_float2(xq[r / 2].z, xq[r / 2].w) : make_float2(xq[r / 2].x, xq[r / 2].y);
+            if (!okf) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) xin[r] = make_float2(0.f, 0.f);
+            } else if (if_ == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    if (r < a.taper) {
                         const float2 p = (r & 1) ? make_float2(pq[r / 2].z, pq[r / 2].w) : make_float2(pq[r / 2].x, pq[r / 2].y);
-                        const float wa = a.taperwin[i + r], wb = a.taperwin[a.taper - 1 - (int)(i + r)];
-                        if (role == 1) res = make_float2(v.x * wa, v.y * wa);
-                        else if (role == 3) res = make_float2(p.x * wb, p.y * wb);
-                        else if (role == 4) res = taper_blend(v, wa, p, wb);
+                        const int kb = a.taper - 1 - r;
+                        const float wa = twin[r], wb = gf > 0 ? (kb == 0 ? twin[0] : (kb == 1 ? twin[1] : (kb == 2 ? twin[2] : twin[3]))) : 0.f;
+                        const float2 bl = taper_blend(xin[r], wa, p, wb);
+                        if (!s0b_q) xin[r] = bl;
                     }
                 }
-                if (b0 + r >= (long long)a.nblocks) res = make_float2(0.f, 0.f);
-                xin[r] = res;
+            }
+            if (b0 + R > (long long)a.nblocks) {                        // (the stream's last, partly filled round)
+#pragma unroll
+                for (int r = 0; r < 8; r++) if (b0 + r >= (long long)a.nblocks) xin[r] = make_float2(0.f, 0.f);
             }
         }
     };
-    if constexpr (tiled) request_tiles(bstart);
-    else if constexpr (fastsym) { request_kind(bstart); request_syms(bstart); request_kind(bstart + R); }
+    if constexpr (SYN_ABLATE & 16) { for (int q = 0; q < R / 2; q++) xq[q] = make_float4(1.f, 0.f, 0.f, 1.f); pq[0] = pq[1] = make_float4(0.f, 0.f, 0.f, 0.f); okf = true; if_ = 8; }
+    else if constexpr (tiled) request_tiles(bstart);
+    else if constexpr (fastsym) {
+        pq[0] = pq[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        request_kind(); request_syms(); request_kind();
+    }
+    // (the first round's inputs are waited for here, so that the loop is entered with nothing pending on either path and the
+    //  compiler puts no wait at its top -- see the wait in front of the stores)
+    if constexpr (tiled || fastsym) {
+#pragma unroll
+        for (int q = 0; q < R / 2; q++) asm volatile("" : "+v"(xq[q].x), "+v"(xq[q].y), "+v"(xq[q].z), "+v"(xq[q].w) :: "memory");
+    }
+    if constexpr (fastsym) asm volatile("" : "+v"(pq[0].x), "+v"(pq[0].y), "+v"(pq[0].z), "+v"(pq[0].w), "+v"(pq[1].x), "+v"(pq[1].y), "+v"(pq[1].z), "+v"(pq[1].w), "+v"(kq) :: "memory");
     for (int rd = 0; rd < rounds; rd++) {
         const long long b0 = bstart + (long long)rd * R;
         const int tq = opaque(tid);
@@ -290,13 +326,13 @@ __global__ __launch_bounds__(K / 2) void synth_kernel(TxSynthArgs a, uint32_t sl
         }
 #pragma unroll
         for (int r = 0; r < R; r++) tile[r * ROWP + xrow] = make_float2(xin[r].x, -xin[r].y);
-        if (rd + 1 < rounds) {
+        if ((SYN_ABLATE & 16) == 0 && rd + 1 < rounds) {
             if constexpr (tiled) request_tiles(b0 + R);
-            else if constexpr (fastsym) { request_syms(b0 + R); request_kind(b0 + 2 * R); }
+            else if constexpr (fastsym) { request_syms(); request_kind(); }
         }
         lds_barrier();
         // ---- R forward K-point transforms in place (channelizer.hip's plan)
-        if constexpr (S > 0) {
+        if constexpr (S > 0 && (SYN_ABLATE & 1) == 0) {
 #pragma unroll
             for (int st = 0; st < S; st++) {
                 const int L = K >> (2 * st), q4 = L >> 2;
@@ -333,7 +369,8 @@ __global__ __launch_bounds__(K / 2) void synth_kernel(TxSynthArgs a, uint32_t sl
                 lds_barrier();
             }
         }
-        if constexpr (SPLIT) {
+        if constexpr ((SYN_ABLATE & 2) != 0) {
+        } else if constexpr (SPLIT) {
             // half as many F-point groups as threads: waves 0 .. NG/64-1 transform the sums x[i] + x[i+F/2] (even bins), the
             // others the twiddled differences (odd bins); both read the whole group and write into it, hence the barrier
             const int role = uniform_i(tq / NG);
@@ -398,7 +435,7 @@ __global__ __launch_bounds__(K / 2) void synth_kernel(TxSynthArgs a, uint32_t sl
             };
             v2f tq0 = tap_pair(SYN_P - 1), tq1 = tap_pair(SYN_P - 2);
 #pragma unroll
-            for (int j = SYN_P - 1; j >= 0; j--) {
+            for (int j = SYN_P - 1; j >= ((SYN_ABLATE & 4) ? SYN_P - 1 : 0); j--) {
                 const v2f tp = tq0;
                 tq0 = tq1;
                 if (j >= 2) tq1 = tap_pair(j - 2);
@@ -414,12 +451,23 @@ __global__ __launch_bounds__(K / 2) void synth_kernel(TxSynthArgs a, uint32_t sl
                     }
                 }
             }
+            // Loads and stores share one counter and complete out of order against each other, so a wait for the prefetched inputs
+            // also waits for every store in flight.  Placed here -- behind a round of arithmetic, in front of this round's stores --
+            // it finds the inputs (requested at the top of the round) and the previous round's stores long complete; at the top of
+            // the next round, where the inputs are used, it would find this round's stores just issued.
+            if constexpr ((SYN_ABLATE & 64) == 0) {
+                if constexpr (tiled || fastsym) {
+#pragma unroll
+                    for (int q = 0; q < R / 2; q++) asm volatile("" : "+v"(xq[q].x), "+v"(xq[q].y), "+v"(xq[q].z), "+v"(xq[q].w) :: "memory");
+                }
+                if constexpr (fastsym) asm volatile("" : "+v"(pq[0].x), "+v"(pq[0].y), "+v"(pq[0].z), "+v"(pq[0].w), "+v"(pq[1].x), "+v"(pq[1].y), "+v"(pq[1].z), "+v"(pq[1].w), "+v"(kq) :: "memory");
+            }
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 const long long b = b0 + r;
                 if ((b & 7) == 0)       // first block of a group (slabs start on multiples of 8, so a slab's first output block is one)
                     sincos_u32_hw((a.first_sample_lo + (uint32_t)((unsigned long long)b * K + (unsigned)n0)) * a.dtheta, osn, ocs);
-                if (b >= o0 && b < o1) {
+                if (b >= o0 && b < o1 && (!(SYN_ABLATE & 8) || acc[r][0].x == 1.2345e30f)) {
                     const float s1 = fmaf(osn, cd1, ocs * sd1), c1 = fmaf(ocs, cd1, -(osn * sd1));            // the second column
                     const float2 y0 = make_float2(fmaf(acc[r][0].x, ocs, -(acc[r][0].y * osn)), fmaf(acc[r][0].y, ocs, acc[r][0].x * osn));
                     const float2 y1 = make_float2(fmaf(acc[r][1].x, c1, -(acc[r][1].y * s1)), fmaf(acc[r][1].y, c1, acc[r][1].x * s1));
@@ -429,10 +477,19 @@ __global__ __launch_bounds__(K / 2) void synth_kernel(TxSynthArgs a, uint32_t sl
                 { const float s2 = fmaf(osn, ck8, ocs * sk8), c2 = fmaf(ocs, ck8, -(osn * sk8)); osn = s2; ocs = c2; }      // next block
             }
         }
+        else if constexpr ((SYN_ABLATE & 64) == 0) {                  // (rounds that only fill the window: same wait, so that no path reaches the loop's top with loads pending)
+            if constexpr (tiled || fastsym) {
+#pragma unroll
+                for (int q = 0; q < R / 2; q++) asm volatile("" : "+v"(xq[q].x), "+v"(xq[q].y), "+v"(xq[q].z), "+v"(xq[q].w) :: "memory");
+            }
+            if constexpr (fastsym) asm volatile("" : "+v"(pq[0].x), "+v"(pq[0].y), "+v"(pq[0].z), "+v"(pq[0].w), "+v"(pq[1].x), "+v"(pq[1].y), "+v"(pq[1].z), "+v"(pq[1].w), "+v"(kq) :: "memory");
+        }
+        if constexpr ((SYN_ABLATE & 32) == 0) {
 #pragma unroll
         for (int i = 0; i < SYN_H; i++)
 #pragma unroll
             for (int c = 0; c < C; c++) s[i][c] = s[i + R][c];
+        }
         lds_barrier();
     }
 }

@@ -33,7 +33,8 @@ struct TxSymArgs {
     const float2 *s0t, *s1t;
     const uint8_t *hdr;         // [ch][frame][S_hdr*M_data]
     const uint8_t *pay;         // [ch][frame][S_pay*M_data]
-    float2 *xsym;               // [ch][frames*S][M]
+    float2 *xsym;               // [ch][frames*S][M], or symbol gs of channel ch at ch xs_ch + gs xs_sym when xs_sym != 0
+    size_t xs_ch = 0, xs_sym = 0;
     uint32_t nch;
     // ragged traffic (mctx_hip_generate_ragged): frames of different lengths anywhere on the channel's symbol axis.
     // frames = 1, S = symbols of the whole axis; symdesc[ch][S] says what symbol gs is: kind | s << 8 | row << 32
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(TXW) void txsym_kernel(TxSymArgs a)
     const int l = threadIdx.x & 63;
     const uint32_t gs = blockIdx.x, ch = blockIdx.y;
     int f = gs / a.S, s = gs % a.S;
-    float2 *dst = a.xsym + ((size_t)ch * a.frames * a.S + gs) * a.M;
+    float2 *dst = a.xsym + (a.xs_sym ? (size_t)ch * a.xs_ch + (size_t)gs * a.xs_sym : ((size_t)ch * a.frames * a.S + gs) * a.M);
     bool table = s < 3 || s == a.S - 1, zero = s == a.S - 1, is_hdr = s < 3 + a.S_hdr;
     const uint8_t *bits = nullptr;
     if (a.symdesc) {
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(TXW) void txsym_dft_kernel(TxSymArgs a)
     const int l = threadIdx.x & 63;
     const uint32_t gs = blockIdx.x, ch = blockIdx.y;
     const int f = gs / a.S, s = gs % a.S;
-    float2 *dst = a.xsym + ((size_t)ch * a.frames * a.S + gs) * a.M;
+    float2 *dst = a.xsym + (a.xs_sym ? (size_t)ch * a.xs_ch + (size_t)gs * a.xs_sym : ((size_t)ch * a.frames * a.S + gs) * a.M);
     if (s < 3 || s == a.S - 1) {
         const float2 *src = (s == 2) ? a.s1t : a.s0t;
         for (int i = l; i < a.M; i += TXW) dst[i] = (s == a.S - 1) ? make_float2(0.f, 0.f) : src[i];
@@ -171,7 +172,11 @@ __global__ __launch_bounds__(TXW) void txsym_dft_kernel(TxSymArgs a)
 struct TxSynthArgs {
     int M, cp, taper, L, S, frames;
     const float *taperwin;      // [taper]
-    const float2 *xsym;         // [ch][frames*S][M]
+    const float2 *xsym;         // [ch][frames*S][M]; batch / ragged generators: [frames*S][ch][M] through the strides below
+    // (the fused synthesis kernel reads 64 B of every channel per round: with the channel as the slow axis those are 512
+    // pages a round, with the symbol as the slow axis one 32 KB span)
+    size_t xs_ch = 0, xs_sym = 0;   // elements between channels / between a channel's consecutive symbols (0: the legacy layout)
+    size_t ks_ch = 0, ks_sym = 0;   // the same for symkind
     const float *taps;          // 26*K synthesis prototype
     float2 *v;                  // [nblocks][K] inverse-FFT outputs
     float2 *out;                // [nblocks][K] wideband samples
@@ -200,16 +205,21 @@ __device__ __forceinline__ float2 taper_blend(float2 v, float wa, float2 p, floa
     return make_float2(fmaf(v.x, wa, p.x * wb), fmaf(v.y, wa, p.y * wb));
 }
 // batch / ragged layout only (no streaming slots): the caller walks (gs, i) itself
+__device__ __forceinline__ size_t xs_sym_of(const TxSynthArgs &a) { return a.xs_sym ? a.xs_sym : (size_t)a.M; }
+__device__ __forceinline__ const float2 *xs_channel(const TxSynthArgs &a, uint32_t ch)
+{
+    return a.xsym + (a.xs_sym ? (size_t)ch * a.xs_ch : (size_t)ch * a.frames * a.S * a.M);
+}
 __device__ __forceinline__ float2 frame_sample_at(const TxSynthArgs &a, uint32_t ch, uint32_t gs, uint32_t i)
 {
-    return frame_sample_sym(a, ch, a.xsym + (size_t)ch * a.frames * a.S * a.M, a.S, (uint32_t)(a.frames * a.S), gs, i);
+    return frame_sample_sym(a, ch, xs_channel(a, ch), a.S, (uint32_t)(a.frames * a.S), gs, i);
 }
 // frame sample t of channel ch: cyclic prefix + raised-cosine overlap of consecutive symbols
 // (liquid ofdmframegen_gensymbol / write_S0a / write_S0b / writetail)
 __device__ __forceinline__ float2 frame_sample(const TxSynthArgs &a, uint32_t ch, uint32_t b)
 {
     uint32_t t = b; int S = a.S; uint32_t nsym = (uint32_t)(a.frames * a.S);
-    const float2 *xb = a.xsym + (size_t)ch * a.frames * a.S * a.M;
+    const float2 *xb = xs_channel(a, ch);
     if (a.ft0) {                                    // streaming: position inside the channel's current frame
         const long long rel = a.b_first + (long long)b - a.ft0[ch];
         S = a.fS[ch]; nsym = (uint32_t)S;
@@ -226,11 +236,12 @@ __device__ __forceinline__ float2 frame_sample_sym(const TxSynthArgs &a, uint32_
     if (gs >= nsym) return make_float2(0.f, 0.f);
     int s = (int)(gs % (uint32_t)S);
     if (a.symkind) {                                // ragged traffic: the symbol's role comes from the map
-        const int kind = a.symkind[(size_t)ch * nsym + gs];
+        const int kind = a.symkind[a.ks_sym ? (size_t)ch * a.ks_ch + (size_t)gs * a.ks_sym : (size_t)ch * nsym + gs];
         if (kind == TXK_IDLE) return make_float2(0.f, 0.f);
         s = kind == TXK_S0A ? 0 : (kind == TXK_S0B ? 1 : (kind == TXK_TAIL ? S - 1 : 2));
     }
-    const float2 *x = xb + (size_t)gs * a.M;
+    const size_t xs = xs_sym_of(a);
+    const float2 *x = xb + (size_t)gs * xs;
     const int M = a.M, cp = a.cp;
     if (s == 0) {                                   // S0a: shifted copy, ramp up only
         float2 v = x[(i + M - 2 * cp) % M];
@@ -240,12 +251,12 @@ __device__ __forceinline__ float2 frame_sample_sym(const TxSynthArgs &a, uint32_
     if (s == 1) return x[(i + M - cp) % M];         // S0b: plain cyclic extension
     if (s == S - 1) {                               // tail: previous symbol's postfix ramping down
         if ((int)i >= a.taper) return make_float2(0.f, 0.f);
-        const float2 p = (x - M)[i]; const float b = a.taperwin[a.taper - 1 - i];
+        const float2 p = (x - xs)[i]; const float b = a.taperwin[a.taper - 1 - i];
         return make_float2(p.x * b, p.y * b);
     }
     float2 v = x[(i + M - cp) % M];
     if ((int)i < a.taper) {
-        const float2 p = (x - M)[i];                // first samples of the previous symbol body (S0b: s0)
+        const float2 p = (x - xs)[i];                // first samples of the previous symbol body (S0b: s0)
         const float wa = a.taperwin[i], wb = a.taperwin[a.taper - 1 - i];
         v = taper_blend(v, wa, p, wb);
     }
@@ -503,11 +514,11 @@ extern "C" int mctx_hip_generate(mctx_hip_t q, void *d_iq, size_t nblocks, unsig
     sa.S = (int)S; sa.S_hdr = (int)Sh; sa.S_pay = (int)Sp; sa.frames = (int)frames; sa.bps = (int)mod_bps(mod); sa.mod = mod;
     sa.g_data = 1.0f / sqrtf((float)(q->od.M_pilot + q->od.M_data));
     sa.sctype = q->d_sctype; sa.data_rank = q->d_drank; sa.pilot_rank = q->d_prank; sa.pilot_seq = q->d_pseq;
-    sa.s0t = q->d_s0t; sa.s1t = q->d_s1t; sa.hdr = d_hdr; sa.pay = d_pay; sa.xsym = d_xsym; sa.nch = N;
+    sa.s0t = q->d_s0t; sa.s1t = q->d_s1t; sa.hdr = d_hdr; sa.pay = d_pay; sa.xsym = d_xsym; sa.nch = N; sa.xs_ch = M; sa.xs_sym = (size_t)N * M;   // symbol-major: see TxSynthArgs
     { int rc = tx_launch_sym(q, sa, (unsigned)nsym, N, st); if (rc) return rc; }
     TxSynthArgs ya;
     ya.M = (int)M; ya.cp = (int)q->cp; ya.taper = (int)q->taper; ya.L = (int)(M + q->cp); ya.S = (int)S; ya.frames = (int)frames;
-    ya.taperwin = q->d_taper; ya.xsym = d_xsym; ya.taps = q->d_taps; ya.v = d_v; ya.out = (float2 *)d_iq;
+    ya.taperwin = q->d_taper; ya.xsym = d_xsym; ya.xs_ch = M; ya.xs_sym = (size_t)N * M; ya.taps = q->d_taps; ya.v = d_v; ya.out = (float2 *)d_iq;
     ya.nblocks = (uint32_t)nblocks; ya.N = N; ya.dtheta = q->dtheta; ya.first_sample_lo = 0; ya.gain = gain;
     ya.ft0 = nullptr; ya.fS = nullptr; ya.xstride = 0; ya.b_first = 0; ya.hist = 0;
     { int rc = tx_synthesize(q, ya, st); if (rc) return rc; }
@@ -564,7 +575,7 @@ extern "C" int mctx_hip_generate_ragged(mctx_hip_t q, void *d_iq, size_t nblocks
                 else if (s == S - 1) k = TXK_TAIL;
                 else if (s < 3 + Sh) { k = TXK_HDR; row = hrow + (s - 3); }
                 else { k = TXK_PAY; row = prow + (s - 3 - Sh); }
-                kind[(size_t)ch * T + t + s] = (uint8_t)k;
+                kind[(size_t)(t + s) * N + ch] = (uint8_t)k;                    // [symbol][channel], like the symbol bodies
                 desc[(size_t)ch * T + t + s] = (unsigned long long)k | ((unsigned long long)s << 8) | (row << 32);
             }
             if (hdr_out) memcpy(hdr_out + ((size_t)ch * max_frames + f) * 8, h8, 8);
@@ -591,11 +602,11 @@ extern "C" int mctx_hip_generate_ragged(mctx_hip_t q, void *d_iq, size_t nblocks
     sa.S = (int)T; sa.S_hdr = 0; sa.S_pay = 0; sa.frames = 1; sa.bps = (int)mod_bps(mod); sa.mod = mod;
     sa.g_data = 1.0f / sqrtf((float)(q->od.M_pilot + q->od.M_data));
     sa.sctype = q->d_sctype; sa.data_rank = q->d_drank; sa.pilot_rank = q->d_prank; sa.pilot_seq = q->d_pseq;
-    sa.s0t = q->d_s0t; sa.s1t = q->d_s1t; sa.hdr = d_hdr; sa.pay = d_pay; sa.xsym = d_xsym; sa.nch = N; sa.symdesc = d_desc;
+    sa.s0t = q->d_s0t; sa.s1t = q->d_s1t; sa.hdr = d_hdr; sa.pay = d_pay; sa.xsym = d_xsym; sa.nch = N; sa.symdesc = d_desc; sa.xs_ch = M; sa.xs_sym = (size_t)N * M;
     { int rc = tx_launch_sym(q, sa, (unsigned)T, N, st); if (rc) return rc; }
     TxSynthArgs ya;
     ya.M = (int)M; ya.cp = (int)q->cp; ya.taper = (int)q->taper; ya.L = (int)L; ya.S = (int)T; ya.frames = 1;
-    ya.taperwin = q->d_taper; ya.xsym = d_xsym; ya.taps = q->d_taps; ya.v = d_v; ya.out = (float2 *)d_iq;
+    ya.taperwin = q->d_taper; ya.xsym = d_xsym; ya.xs_ch = M; ya.xs_sym = (size_t)N * M; ya.ks_ch = 1; ya.ks_sym = N; ya.taps = q->d_taps; ya.v = d_v; ya.out = (float2 *)d_iq;
     ya.nblocks = (uint32_t)nblocks; ya.N = N; ya.dtheta = q->dtheta; ya.first_sample_lo = 0; ya.gain = gain;
     ya.ft0 = nullptr; ya.fS = nullptr; ya.xstride = 0; ya.b_first = 0; ya.hist = 0; ya.symkind = d_kind;
     { int rc = tx_synthesize(q, ya, st); if (rc) return rc; }
