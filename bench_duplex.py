@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--payload", type=int, default=1200)
-    ap.add_argument("--sub-blocks", type=int, default=32768, help="blocks of 2N samples one rank synthesizes / channelizes per round")
+    ap.add_argument("--sub-blocks", type=int, default=262144, help="blocks of 2N samples one rank synthesizes / channelizes per round")
     ap.add_argument("--dry-run-launch", action="store_true", help="start the ranks, rendezvous under gloo, print one JSON line and exit (no GPU needed)")
     args = ap.parse_args()
     import importlib.util

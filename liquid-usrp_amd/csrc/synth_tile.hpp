@@ -303,11 +303,13 @@ __global__ __launch_bounds__(K / 2) void synth_kernel(TxSynthArgs a, uint32_t sl
         float2 xin[R];
         if constexpr (tiled) {
 #pragma unroll
-            for (int r = 0; r < R; r += 2) {
-                const long long b = b0 + r;
-                const bool in = b >= 0 && b + 1 < (long long)a.nblocks;
-                xin[r] = in ? make_float2(xq[r / 2].x, xq[r / 2].y) : make_float2(0.f, 0.f);
-                xin[r + 1] = in ? make_float2(xq[r / 2].z, xq[r / 2].w) : make_float2(0.f, 0.f);
+            for (int r = 0; r < R; r += 2) { xin[r] = make_float2(xq[r / 2].x, xq[r / 2].y); xin[r + 1] = make_float2(xq[r / 2].z, xq[r / 2].w); }
+            if (b0 < 0 || b0 + R >= (long long)a.nblocks) {             // (uniform, the stream's edges only: pairs outside it are zero)
+#pragma unroll
+                for (int r = 0; r < R; r += 2) {
+                    const long long b = b0 + r;
+                    if (!(b >= 0 && b + 1 < (long long)a.nblocks)) xin[r] = xin[r + 1] = make_float2(0.f, 0.f);
+                }
             }
         } else if constexpr (fastsym) {
             finish_syms(b0, xin);
@@ -488,7 +490,11 @@ __global__ __launch_bounds__(K / 2) void synth_kernel(TxSynthArgs a, uint32_t sl
 #pragma unroll
         for (int i = 0; i < SYN_H; i++)
 #pragma unroll
-            for (int c = 0; c < C; c++) s[i][c] = s[i + R][c];
+            for (int c = 0; c < C; c++) {                            // one packed move per sample (the compiler's form: two v_mov_b32)
+                v2f d; const v2f o = { s[i + R][c].x, s[i + R][c].y };
+                asm volatile("v_pk_mov_b32 %0, %1, %1 op_sel:[0,1]" : "=v"(d) : "v"(o));
+                s[i][c] = make_float2(d.x, d.y);
+            }
         }
         lds_barrier();
     }

@@ -347,12 +347,48 @@ __global__ void txtiles_kernel(TxSynthArgs a, long long first_block, uint32_t nt
     if (id >= ntiles * nch) return;
     const uint32_t tile = id / nch, c = id % nch;
     float2 v[8];
+    float4 *dst = reinterpret_cast<float4 *>(tiles + (size_t)id * 8);
+    const long long b0 = first_block + (long long)tile * 8;
+    // A granule that never straddles an OFDM symbol (8 | L, cp, M and first_block; no role map): 64 aligned bytes of one symbol
+    // body as they stand -- txsym zero-fills tail bodies, S0a reads two prefixes back -- and, in a symbol's first granule, the
+    // raised-cosine overlap with the previous body in frame_sample_sym's fma shape (S0b has none).  Same values, an eighth of
+    // the address arithmetic, whole cache lines.
+    if (!a.symkind && !a.ft0 && (a.L % 8) == 0 && (a.cp % 8) == 0 && (a.M % 8) == 0 && a.taper >= 0 && a.taper <= 4 && (first_block % 8) == 0 &&
+        b0 >= 0 && b0 + 7 < 0xffffffffll) {
+        const uint32_t nsym = (uint32_t)(a.frames * a.S);
+        const uint32_t gs = (uint32_t)b0 / (uint32_t)a.L, i = (uint32_t)b0 % (uint32_t)a.L;
+        if (gs >= nsym) {
+#pragma unroll
+            for (int t = 0; t < 4; t++) dst[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            return;
+        }
+        const int sidx = (int)(gs % (uint32_t)a.S);
+        const size_t xs = xs_sym_of(a);
+        const float2 *x = xs_channel(a, c) + (size_t)gs * xs;
+        const uint32_t base = (i + (uint32_t)a.M - (sidx == 0 ? 2u : 1u) * (uint32_t)a.cp) % (uint32_t)a.M;
+        const float4 *xp = reinterpret_cast<const float4 *>(x + base);
+        float4 q4[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) q4[t] = xp[t];
+        if (i == 0 && sidx != 1 && a.taper > 0) {
+            const float4 *pp = reinterpret_cast<const float4 *>(gs > 0 ? x - xs : x);
+            const float4 p0 = pp[0], p1 = pp[1];
+            const float2 pv[4] = { make_float2(p0.x, p0.y), make_float2(p0.z, p0.w), make_float2(p1.x, p1.y), make_float2(p1.z, p1.w) };
+            float2 xv[4] = { make_float2(q4[0].x, q4[0].y), make_float2(q4[0].z, q4[0].w), make_float2(q4[1].x, q4[1].y), make_float2(q4[1].z, q4[1].w) };
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (r < a.taper) xv[r] = taper_blend(xv[r], a.taperwin[r], pv[r], gs > 0 ? a.taperwin[a.taper - 1 - r] : 0.f);
+            q4[0] = make_float4(xv[0].x, xv[0].y, xv[1].x, xv[1].y); q4[1] = make_float4(xv[2].x, xv[2].y, xv[3].x, xv[3].y);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) dst[t] = q4[t];
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < 8; t++) {
-        const long long b = first_block + (long long)tile * 8 + t;
+        const long long b = b0 + t;
         v[t] = (b >= 0 && b < 0xffffffffll) ? frame_sample(a, c, (uint32_t)b) : make_float2(0.f, 0.f);
     }
-    float4 *dst = reinterpret_cast<float4 *>(tiles + (size_t)id * 8);
 #pragma unroll
     for (int t = 0; t < 4; t++) dst[t] = make_float4(v[2 * t].x, v[2 * t].y, v[2 * t + 1].x, v[2 * t + 1].y);
 }
@@ -670,7 +706,7 @@ extern "C" int mctx_hip_traffic_create(mctx_hip_t q, mctx_hip_traffic_t *out, un
     sa.S = (int)S; sa.S_hdr = (int)Sh; sa.S_pay = (int)Sp; sa.frames = (int)frames; sa.bps = (int)mod_bps(mod); sa.mod = mod;
     sa.g_data = 1.0f / sqrtf((float)(q->od.M_pilot + q->od.M_data));
     sa.sctype = q->d_sctype; sa.data_rank = q->d_drank; sa.pilot_rank = q->d_prank; sa.pilot_seq = q->d_pseq;
-    sa.s0t = q->d_s0t; sa.s1t = q->d_s1t; sa.hdr = d_hdr; sa.pay = d_pay; sa.xsym = d_xsym; sa.nch = ch_count;
+    sa.s0t = q->d_s0t; sa.s1t = q->d_s1t; sa.hdr = d_hdr; sa.pay = d_pay; sa.xsym = d_xsym; sa.nch = ch_count; sa.xs_ch = M; sa.xs_sym = (size_t)ch_count * M;      // symbol-major, like the generators
     { int rc = tx_launch_sym(q, sa, (unsigned)nsym, ch_count, st); if (rc) return rc; }
     TXCHK(hipStreamSynchronize(st));
     (void)hipFree(d_hdr); (void)hipFree(d_pay);
@@ -697,6 +733,7 @@ extern "C" int mctx_hip_traffic_tiles(mctx_hip_traffic_t t, long long first_bloc
     TxSynthArgs ya;
     ya.M = (int)q->M; ya.cp = (int)q->cp; ya.taper = (int)q->taper; ya.L = (int)(q->M + q->cp); ya.S = (int)t->S; ya.frames = (int)t->frames;
     ya.taperwin = q->d_taper; ya.xsym = t->d_xsym; ya.taps = q->d_taps; ya.v = nullptr; ya.out = nullptr;
+    ya.xs_ch = q->M; ya.xs_sym = (size_t)t->ch_count * q->M;
     ya.nblocks = (uint32_t)nblocks; ya.N = t->ch_count; ya.dtheta = 0; ya.first_sample_lo = 0; ya.gain = 1.0f;
     ya.ft0 = nullptr; ya.fS = nullptr; ya.xstride = 0; ya.b_first = 0; ya.hist = 0;
     const uint32_t ntiles = (uint32_t)(nblocks / 8), n = ntiles * t->ch_count;

@@ -82,6 +82,11 @@ class Pipeline(object):
         self.recv = [torch.zeros((hist_tiles * self.cg * TILE) + world * per, dtype=torch.complex64, device=device)
                      for _ in range(nbuf)]
         self.hist_elems = hist_tiles * self.cg * TILE
+        # one rank on a GPU: there is nothing to exchange, the channelizer writes where the synchronizers read (behind the
+        # history tiles) -- what the C pipeline does too (csrc/pipeline.hip: "out[i] IS recv[i]")
+        self.alias = world == 1 and self.cuda
+        if self.alias:
+            self.out = [r[self.hist_elems:] for r in self.recv]
         self.rounds = 0
         self.tickets = [None] * nbuf
         self.time_exchange = False                  # bench.py: HIP events around every exchange (exchange_ms)
@@ -110,8 +115,11 @@ class Pipeline(object):
         if self.cuda:
             if after is not None:
                 self.sA.wait_event(after)                       # whoever produced iq_sub (e.g. TxPipeline.push)
-            if c >= nb:
+            if c >= nb and not self.alias:
                 self.sA.wait_event(self.evB[i])                 # the exchange that last read out[i]
+            if c >= nb and self.alias:                          # out[i] is recv[i]: its last readers instead
+                self.be.stream_wait(self.sA, launch=self.tickets[i])
+                self.sA.wait_event(self.evC[(i + 1) % nb])
             with torch.cuda.stream(self.sA):
                 self.be.channelize(iq_sub, self.Tc, self.first_sample(c), out, groups=self.world, d_halo=halo, stream=self.sA)
                 self.evA[i].record(self.sA)
@@ -127,7 +135,9 @@ class Pipeline(object):
                 if self.time_exchange:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(self.sB)
-                if self.world == 1:
+                if self.alias:
+                    pass
+                elif self.world == 1:
                     new.copy_(out, non_blocking=True)
                 else:
                     exchange(out, new, self.world, self.dist)
@@ -206,6 +216,9 @@ class TxPipeline(object):
         self.recv = [torch.zeros(world * self.per, dtype=torch.complex64, device=device) for _ in range(nbuf)]
         self.iq = [torch.zeros((keep_blocks + sub_blocks) * self.K, dtype=torch.complex64, device=device) for _ in range(nbuf)]
         self.rounds = 0
+        self.alias = world == 1 and self.cuda                   # one rank: the granules are made where the synthesis reads them
+        if self.alias:
+            self.out = self.recv
         if self.cuda:
             self.sA, self.sB, self.sC = (torch.cuda.Stream(device=device) for _ in range(3))
             for s in (self.sA, self.sB, self.sC):               # the zeroed lead tiles above were written on the current stream
@@ -238,7 +251,7 @@ class TxPipeline(object):
             self.rounds += 1
             return iq, None
         if c >= nb:
-            self.sA.wait_event(self.evB[i])                     # the exchange that last read out[i]
+            self.sA.wait_event(self.evC[i] if self.alias else self.evB[i])   # the exchange that last read out[i] (aliased: the synthesis)
         with torch.cuda.stream(self.sA):
             stage_a(self.sA)
             self.evA[i].record(self.sA)
@@ -246,7 +259,9 @@ class TxPipeline(object):
         if c >= nb:
             self.sB.wait_event(self.evC[i])                     # the synthesis that last read recv[i]
         with torch.cuda.stream(self.sB):
-            if self.world == 1:
+            if self.alias:
+                pass
+            elif self.world == 1:
                 recv.copy_(out, non_blocking=True)
             else:
                 exchange(out, recv, self.world, self.dist)
