@@ -180,6 +180,11 @@ struct mcrx_hip_s {
     uint32_t *h_hint = nullptr, *d_hint = nullptr;     // pinned, device-mapped: longest coded frame of the last launch
     uint8_t *d_jsoft[MCRX_SLOTS] = {}, *d_jtmp[MCRX_SLOTS] = {};
     bool scout = true, scout_tables = true; int scout_rounds = 2; bool narrow_first = true;
+    // scouts of the acquisition rounds: 1 = the lean scout's unbudgeted build (sync_walk_kernel: 256 + 40 registers, no spills), 0 = the
+    // 168-register build (293 spilled) that round 2 made to fit beside four 80-register payload workers.  With eight 56-register
+    // workers per SIMD neither fits beside them any more, and a scout that adopts 100 frames of a channel pays for every spill:
+    // 8 channels 54.7 -> 64.8 Gsample/s, 512 channels 166.4 -> 169.9 (same box, same run; MCRX_LEAN_BUILD)
+    int lean_build = 1;
     bool rounds_fixed = false; uint32_t walk_seen = 0; int extra_round_for = 0, extra_len = 16; uint64_t extra_end = 0;     // adaptive third round, see launch_sync
     // speculation pays only where frame positions can be predicted: the host compares what the scouts had to walk with what
     // they adopted (host-mapped counters) and switches the speculative rounds off while walking dominates (launch_sync)
@@ -528,6 +533,7 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
         q->spec = lean && q->d_hint && getenv("MCRX_NO_SPEC") == nullptr;
         if (getenv("MCRX_SCOUT_ROUNDS")) { q->scout_rounds = std::max(1, std::min(8, atoi(getenv("MCRX_SCOUT_ROUNDS")))); q->rounds_fixed = true; }
         if (getenv("MCRX_NARROW_FIRST")) q->narrow_first = atoi(getenv("MCRX_NARROW_FIRST")) != 0;
+        if (getenv("MCRX_LEAN_BUILD")) q->lean_build = atoi(getenv("MCRX_LEAN_BUILD"));
         if (getenv("MCRX_SPEC_ADAPTIVE")) q->spec_adaptive = atoi(getenv("MCRX_SPEC_ADAPTIVE")) != 0;
         if (q->spec) {
             if ((rc = q->alloc(&q->d_spec, (size_t)q->nch * MCRX_SPEC_MAX))) return bail(rc);
@@ -765,7 +771,7 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
             a.stop_after_walk = (r + 1 < rounds) ? 1 : 0;
             a.spec_cap = (r == 0 && q->narrow_first && rounds > 1 && cap > 1) ? 1u : cap;
             HIPCHK(sync_launch_spec(a, sa));
-            HIPCHK(sync_launch_lean(a, sa));
+            if (q->lean_build == 1) HIPCHK(sync_launch_walk(a, sa)); else HIPCHK(sync_launch_lean(a, sa));
         }
         a.spec_cap = cap;
         }
