@@ -1765,16 +1765,16 @@ struct Walker {
         }
         nadopted = 0;
     }
-    __device__ __forceinline__ bool adopt_speculative(int64_t key)
+    // the slot that started from exactly `key`, if there is one: noted, and the sample its frame ended with returned
+    __device__ __forceinline__ bool adopt_match(int64_t key, int64_t &t_end)
     {
         static_assert(MCRX_SPEC_MAX <= 2 * WV, "two slot headers per lane");
         const unsigned long long b0 = __ballot(sp_start[0] == key), b1 = __ballot(sp_start[1] == key);
         if (!(b0 | b1)) return false;
         const int hl = b0 ? (int)__builtin_ctzll(b0) : (int)__builtin_ctzll(b1);
-        const int64_t t_last = __shfl(b0 ? sp_tlast[0] : sp_tlast[1], hl, WV);
+        t_end = __shfl(b0 ? sp_tlast[0] : sp_tlast[1], hl, WV);
         if (l == 0) ldsad[nadopted] = (uint8_t)(b0 ? hl : hl + WV);
         nadopted++;
-        reset_framesync(); s.timer = (uint32_t)c.L; s.cur = t_last + 1;
         return true;
     }
     __device__ __forceinline__ void publish_adopted()
@@ -1887,7 +1887,7 @@ struct Walker {
             if (a.pred && s.state == SY_SEEK && (s.timer == (uint32_t)L || entry)) {
                 // a SEEK state a speculative wave may have started from -- the one this launch starts in, and the fresh
                 // one after every frame: take the frame from that wave if it started from exactly this state
-                const int64_t key = spec_key(s.cur, s.timer);
+                int64_t key = spec_key(s.cur, s.timer);
                 if (s.timer == (uint32_t)L) {
                     // (frames at the same distance as the pair before them: what cadence speculation would have hit -- the
                     //  host's acquisition policy reads the totals, launch_sync)
@@ -1896,7 +1896,20 @@ struct Walker {
                 }
                 entry = false;
                 if ((a.debug & 16) && l == 0 && ch == 0) printf("[spec] ch0 fresh state cur %lld timer %u (period hint %u, last fresh %lld, pred_n %u, pred[0..2] %lld %lld %lld)\n", (long long)s.cur, s.timer, s.period_hint, (long long)s.last_fresh, a.pred_n[ch], (long long)(a.pred[(size_t)ch * MCRX_SPEC_MAX] & 0xFFFFFFFFFFFFll), (long long)(a.pred[(size_t)ch * MCRX_SPEC_MAX + 1] & 0xFFFFFFFFFFFFll), (long long)(a.pred[(size_t)ch * MCRX_SPEC_MAX + 2] & 0xFFFFFFFFFFFFll));
-                if (a.spec_cap && adopt_speculative(key)) continue;
+                if (a.spec_cap) {
+                    // A frame somebody predicted costs the scout the chain key -> slot -> frame end -> next key, and a channel with
+                    // a hundred frames in the buffer (few channels, long pushes) runs it a hundred times in a row: chased here on
+                    // the position alone, the synchronizer state written once behind the last adoption (every adoption leaves it
+                    // in the same fresh post-frame state, only the position differs).
+                    int64_t pos = s.cur, t_end = 0; bool any = false;
+                    while (nadopted < MCRX_SPEC_MAX && adopt_match(key, t_end)) {
+                        any = true; pos = t_end + 1;
+                        if (nfresh >= 2 && pos - pred_last == pred_last - pred_prev) nsame++;
+                        pred_prev = pred_last; pred_last = pos; nfresh++;
+                        key = spec_key(pos, (uint32_t)L);
+                    }
+                    if (any) { reset_framesync(); s.timer = (uint32_t)L; s.cur = pos; }
+                }
                 // nobody predicted this state.  In all but the last acquisition round the scout stops here instead of
                 // acquiring the frame itself: the next round's speculative waves start from this exact state and from
                 // the cadence continued from it, all in parallel
