@@ -17,6 +17,22 @@ __device__ __forceinline__ cfd cmulc(cfd a, cfd b)      // a * conj(b)
 { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
 __device__ __forceinline__ cfd cscale(cfd a, float g) { return make_float2(a.x * g, a.y * g); }
 __device__ __forceinline__ cfd cmulnj(cfd a) { return make_float2(a.y, -a.x); }      // a * (-j)
+// a + (-j) b and a - (-j) b in ONE packed add each: the operand swizzle (op_sel) and a negation of one half only (neg_lo / neg_hi) do
+// the rotation.  The compiler's form of cadd(a, cmulnj(b)) / csub(a, cmulnj(b)) is two packed adds (sum and difference of the
+// swizzled pair) and three moves that recombine their halves.  Same values: (a.x + b.y, a.y - b.x) and (a.x - b.y, a.y + b.x).
+typedef float devmath_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cfd cadd_nj(cfd a, cfd b)
+{
+    devmath_v2f r; const devmath_v2f av = { a.x, a.y }, bv = { b.x, b.y };
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(av), "v"(bv));
+    return make_float2(r.x, r.y);
+}
+__device__ __forceinline__ cfd csub_nj(cfd a, cfd b)
+{
+    devmath_v2f r; const devmath_v2f av = { a.x, a.y }, bv = { b.x, b.y };
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(av), "v"(bv));
+    return make_float2(r.x, r.y);
+}
 
 // sin/cos of a 32-bit phase (theta * 2 pi / 2^32): octant-centred reduction is exact in
 // integers, then degree-7/8 minimax polynomials on [-pi/4, pi/4] (abs error ~1e-7).

@@ -349,11 +349,10 @@ __global__ __launch_bounds__(K / 2) void synth_kernel(TxSynthArgs a, uint32_t sl
                     for (int i = 0; i < BTRIPS; i++) {
                         float2 *p = tile + fa_st + i * BSTEP;
                         const float2 x0 = p[0], x1 = p[D];
-                        const float2 a3 = cmulnj(x1);
                         p[0] = cadd(x0, x1);
-                        p[D] = cmul(cadd(x0, a3), tw1);
+                        p[D] = cmul(cadd_nj(x0, x1), tw1);
                         p[2 * D] = cmul(csub(x0, x1), tw2);
-                        p[3 * D] = cmul(csub(x0, a3), tw3);
+                        p[3 * D] = cmul(csub_nj(x0, x1), tw3);
                     }
                     lds_barrier();
                     continue;
@@ -362,11 +361,11 @@ __global__ __launch_bounds__(K / 2) void synth_kernel(TxSynthArgs a, uint32_t sl
                 for (int i = 0; i < BTRIPS; i++) {
                     float2 *p = tile + fa_st + i * BSTEP;
                     const float2 x0 = p[0], x1 = p[D], x2 = p[2 * D], x3 = p[3 * D];
-                    const float2 a0 = cadd(x0, x2), a1 = csub(x0, x2), a2 = cadd(x1, x3), a3 = cmulnj(csub(x1, x3));
+                    const float2 a0 = cadd(x0, x2), a1 = csub(x0, x2), a2 = cadd(x1, x3), d3 = csub(x1, x3);
                     p[0] = cadd(a0, a2);
-                    p[D] = cmul(cadd(a1, a3), tw1);
+                    p[D] = cmul(cadd_nj(a1, d3), tw1);              // a1 + (-j) d3: the rotation rides on the add (devmath.h)
                     p[2 * D] = cmul(csub(a0, a2), tw2);
-                    p[3 * D] = cmul(csub(a1, a3), tw3);
+                    p[3 * D] = cmul(csub_nj(a1, d3), tw3);
                 }
                 lds_barrier();
             }
