@@ -207,9 +207,11 @@ def main():
                 box = [prod.pipeline.unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(box, src=0)
                 uid = box[0]
-            pipe = prod.pipeline(rx, rank, world, Tc, unique_id=uid)
+            # (five rotating buffer sets = the receiver's own five slots: the channelizer runs as far ahead of the payload workers as in
+            #  the direct path -- 144 -> 148 Gsample/s on one GPU; six wait for a slot and halve it.  MCRX_PIPE_NBUF)
+            pipe = prod.pipeline(rx, rank, world, Tc, unique_id=uid, nbuf=int(os.environ.get("MCRX_PIPE_NBUF", "5")))
         else:
-            pipe = sharding.Pipeline(rx, rank, world, dist, N, Tc, rx.hist_tiles, device=dev)
+            pipe = sharding.Pipeline(rx, rank, world, dist, N, Tc, rx.hist_tiles, device=dev, nbuf=int(os.environ.get("MCRX_PIPE_NBUF", "5")))
         first_push = [True]
 
         def step(harvest_rx=None):
