@@ -119,7 +119,7 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def _pipeline_worker(rank, world, port, q, rounds):
+def _pipeline_worker(rank, world, port, q, rounds, nbuf=3):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from __graft_entry__ import load_product
@@ -137,7 +137,7 @@ def _pipeline_worker(rank, world, port, q, rounds):
     iq = iq[:nb * K]
     Tc = nb // (world * rounds)
     be = StreamingOracleBackend(O, N, M, cp, tp, iq, rank, world)
-    pipe = sharding.Pipeline(be, rank, world, dist, N, Tc, be.hist_tiles, device=None)
+    pipe = sharding.Pipeline(be, rank, world, dist, N, Tc, be.hist_tiles, device=None, nbuf=nbuf)
     for c in range(rounds):
         u = c * world + rank
         sub = torch.from_numpy(iq[u * Tc * K:(u + 1) * Tc * K].copy())
@@ -149,15 +149,16 @@ def _pipeline_worker(rank, world, port, q, rounds):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,rounds", [(2, 3), (4, 2)])
-def test_round_robin_pipeline_reproduces_single_process_result(oracle, world, rounds):
+# (nbuf: rotating buffer sets -- 2 wraps inside three rounds, 5 is what bench.py runs)
+@pytest.mark.parametrize("world,rounds,nbuf", [(2, 3, 3), (4, 2, 3), (2, 3, 2), (2, 3, 5)])
+def test_round_robin_pipeline_reproduces_single_process_result(oracle, world, rounds, nbuf):
     """sharding.Pipeline (what bench.py --gpus N runs): sub-slabs round robin over the ranks, one all-to-all per
     round, synchronizers continuing from round to round with their history tiles in front -- same frames as one
     process over the whole stream, each rank delivering exactly its channel shard."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 27000 + (os.getpid() % 2000) + 10 * world
-    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, q, rounds)) for r in range(world)]
+    port = 27000 + (os.getpid() % 2000) + 10 * world + nbuf
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, q, rounds, nbuf)) for r in range(world)]
     for p in procs:
         p.start()
     got = dict(q.get(timeout=180) for _ in range(world))
