@@ -60,8 +60,9 @@ def main():
     setup = time.time() - t0
     rx = prod.multichannelrx(N, M, cp, taper, max_payload_len=args.payload, channel_first=c0, channel_count=cg,
                              max_frames=cg * (world * Tc // per_frame + 2) + 64, defer_samples=16384)
-    txp = sharding.TxPipeline(tx, tr, rank, world, dist, N, Tc, device=dev)
-    rxp = sharding.Pipeline(rx, rank, world, dist, N, Tc, rx.hist_tiles, device=dev)
+    nbuf = int(os.environ.get("MCRX_PIPE_NBUF", "5"))              # rotating buffer sets of both pipelines (the receiver has five slots: 62.0 -> 64.8 Gsample/s against three)
+    txp = sharding.TxPipeline(tx, tr, rank, world, dist, N, Tc, device=dev, nbuf=nbuf)
+    rxp = sharding.Pipeline(rx, rank, world, dist, N, Tc, rx.hist_tiles, device=dev, nbuf=nbuf)
     keep = txp.keep
     state = {"c": 0}
 
