@@ -30,19 +30,26 @@ def run(N, M, cp, frames, plen, mod, fec1, resamp, steps=int(os.environ.get('CFG
     torch.cuda.synchronize(); tx.close()
     rx = prod.multichannelrx(N, M, cp, 4, max_payload_len=plen, max_frames=N * frames + 64)
     rs = prod.msresamp(0.5) if resamp else None
+    side = torch.cuda.Stream(device=dev)
+    USE_SIDE = os.environ.get('CFG_SIDE', '1') != '0'
+    alive = []
 
     def push(x):
         y = x
         if rs is not None:
-            rs.reset(); y = rs.execute(x)
+            # (on the caller's stream, like the receiver's push below: a resampler left on the NULL stream -- the legacy default
+            #  stream, which every blocking stream of the process waits for and which waits for all of them -- is a barrier between
+            #  consecutive pushes: nothing of push k + 1 starts before push k's decoder has finished.  43 -> see DESIGN 4.5)
+            rs.reset(); y = rs.execute(x, stream=side if USE_SIDE else None)
             y = y[:int(y.numel()) // (16 * N) * (16 * N)]
-        rx.Execute(y)
+            alive.append(y); del alive[:-4]         # (the receiver's channelizer may still read a push's samples when the next push is enqueued)
+        rx.Execute(y, stream=side if (USE_SIDE and rs is not None) else None)
 
     def step(keep=False):
         for x, _, _ in slabs:
             push(x)
             rx.Poll() if keep else rx.Discard()
-    side = torch.cuda.Stream(device=dev)            # an explicit caller stream: resampler and receiver order on it, nothing
+    # (side is created above push())  an explicit caller stream: resampler and receiver order on it, nothing
     side.wait_stream(torch.cuda.current_stream())   # serialises against the legacy default stream
     with torch.cuda.stream(side):
         for _ in range(warm): step()
