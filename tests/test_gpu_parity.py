@@ -501,6 +501,35 @@ def test_speculation_survives_wrong_predictions(oracle, product):
     rx.close(); tx.close()
 
 
+@pytest.mark.parametrize("build", ["0", "1"])
+def test_both_builds_of_the_rounds_scout_equal_the_oracle(oracle, product, monkeypatch, build):
+    """The acquisition rounds launch the lean scout's unbudgeted build by default (MCRX_LEAN_BUILD=1: sync_walk_kernel) and
+    the 168-register build on request (0: sync_lean_kernel); a periodic stream long enough for cadence speculation -- every
+    frame but the first adopted, a dozen per channel chased in one go -- pushed in pieces must give the oracle's frames
+    through either."""
+    import torch
+    monkeypatch.setenv("MCRX_LEAN_BUILD", build)          # (read once, when the handle is created)
+    N, M, cp = 8, 64, 8
+    tx = product.multichanneltx(N, M, cp, 4)
+    iq, _ = tx.generate(14, 200, seed=77)
+    n = int(iq.numel()) // (16 * N) * (16 * N)
+    x = iq[:n].cpu().numpy()
+    ora = oracle.MultiChannelRx(N, M, cp, 4)
+    ora.execute(x)
+    assert len(ora.frames) == 14 * N
+    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=200)
+    step = n // 3 // (16 * N) * (16 * N)
+    for rep in range(2):                                    # the second pass runs on the first one's cadence
+        for i in range(0, n, step):
+            rx.Execute(iq[i:min(i + step, n)])
+    rx.Flush()
+    assert len(rx.frames) == 2 * len(ora.frames)
+    check_frames(rx.frames[:len(ora.frames)], ora.frames)
+    walked, adopted = rx.spec_stats()
+    assert adopted >= 14 * N, (walked, adopted)             # the speculative path, not the scouts' own walk, did the work
+    rx.close(); tx.close()
+
+
 def test_bulk_host_execute_equals_device_path(product):
     """Execute(host buffer) takes whole tiles straight from the caller's memory in large chunks and stages only
     what does not fill a tile; however the buffer is cut, the frames must equal those of the device path."""
