@@ -185,7 +185,8 @@ struct mcrx_hip_s {
     // workers per SIMD neither fits beside them any more, and a scout that adopts 100 frames of a channel pays for every spill:
     // 8 channels 54.7 -> 64.8 Gsample/s, 512 channels 166.4 -> 169.9 (same box, same run; MCRX_LEAN_BUILD)
     int lean_build = 1;
-    bool rounds_fixed = false; uint32_t walk_seen = 0; int extra_round_for = 0, extra_len = 16; uint64_t extra_end = 0;     // adaptive third round, see launch_sync
+    bool rounds_fixed = false; uint32_t walk_seen = 0; int extra_round_for = 0, extra_len = 16; uint64_t extra_end = 0;     // adaptive extra rounds, see launch_sync
+    int extra_rounds = 1, extra_calm = 0;                                                                                   // ... how many of them, and launches without walking since they last grew
     // speculation pays only where frame positions can be predicted: the host compares what the scouts had to walk with what
     // they adopted (host-mapped counters) and switches the speculative rounds off while walking dominates (launch_sync)
     uint32_t pol_walk = 0, pol_adopt = 0, pol_same = 0, pol_fresh = 0; int pol_count = 0, pol_bad = 0; bool spec_adaptive = true, walk_mode = false;
@@ -740,7 +741,10 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
                 const uint32_t w = h[2], ad = h[3], sm = h[4], fr = h[5];
                 const uint32_t dw = w >= q->pol_walk ? w - q->pol_walk : 0u, da = ad >= q->pol_adopt ? ad - q->pol_adopt : 0u;     // (mcrx_hip_spec_stats may have reset them)
                 const uint32_t ds = sm >= q->pol_same ? sm - q->pol_same : 0u, df = fr >= q->pol_fresh ? fr - q->pol_fresh : 0u;
-                if (!q->walk_mode) { if (dw > da && dw > q->nch / 4) { if (++q->pol_bad >= 2) { q->walk_mode = true; q->pol_bad = 0; } } else q->pol_bad = 0; }
+                // (frames that sit on a cadence but were walked all the same -- bursts with a gap in front of each, several to a push:
+                //  a rank's round of an 8-GPU job holds 8 -- need more rounds, not the walking scouts: 3/4 on the cadence keeps the rounds)
+                const bool cadenced = df > q->nch && 4ull * ds > 3ull * df;
+                if (!q->walk_mode) { if (dw > da && dw > q->nch / 4 && !cadenced) { if (++q->pol_bad >= 2) { q->walk_mode = true; q->pol_bad = 0; } } else q->pol_bad = 0; }
                 else { if (df > q->nch && 4ull * ds > 3ull * df) { if (++q->pol_bad >= 2) { q->walk_mode = false; q->pol_bad = 0; } } else q->pol_bad = 0; }
                 q->pol_walk = w; q->pol_adopt = ad; q->pol_same = sm; q->pol_fresh = fr; q->pol_count = 0;
                 if (a.debug & 4) fprintf(stderr, "[host] launch %llu policy: walked %u adopted %u on-cadence %u of %u -> %s\n", (unsigned long long)q->seq, dw, da, ds, df, q->walk_mode ? "walk" : "rounds");
@@ -760,10 +764,15 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
                 // walking again right after the extra rounds ran out = a stream that needs them all the time (e.g. behind a
                 // resampler whose delay times the first frame after every gap one sample off): twice as long every time
                 if (q->extra_round_for == 0) q->extra_len = (q->seq - q->extra_end < 32 && q->extra_len) ? std::min(2 * q->extra_len, 4096) : 16;
+                // ... and walking on a scale of a frame per channel and launch WHILE the extra round runs = one more round is not
+                // enough: every gap inside a push costs a round (the scouts stop at the first state nobody predicted, the next round
+                // starts from there), and a push can hold many -- a rank's round of an 8-GPU job is 8 slabs long.  Twice as many
+                // rounds each time (at most 12), one fewer after 64 launches without such walking.
+                if (q->extra_round_for > 0 && w - q->walk_seen > q->nch / 2) { q->extra_rounds = std::min(2 * q->extra_rounds, 12); q->extra_calm = 0; }
                 q->walk_seen = w; q->extra_round_for = q->extra_len;
-            }
-            if (q->extra_round_for > 0) { if (--q->extra_round_for == 0) q->extra_end = q->seq; rounds++; }
-            if (a.debug & 4) fprintf(stderr, "[host] launch %llu walk counter %u extra_round_for %d rounds %d\n", (unsigned long long)q->seq, w, q->extra_round_for, rounds);
+            } else if (q->extra_rounds > 1 && ++q->extra_calm >= 64) { q->extra_rounds--; q->extra_calm = 0; }
+            if (q->extra_round_for > 0) { if (--q->extra_round_for == 0) q->extra_end = q->seq; rounds += q->extra_rounds; }
+            if (a.debug & 4) fprintf(stderr, "[host] launch %llu walk counter %u extra_round_for %d extra_rounds %d rounds %d\n", (unsigned long long)q->seq, w, q->extra_round_for, q->extra_rounds, rounds);
             a.walk_hint = q->d_hint + 2;
         }
         const uint32_t cap = a.spec_cap;

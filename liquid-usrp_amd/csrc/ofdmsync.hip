@@ -1824,7 +1824,12 @@ struct Walker {
             reset_framesync(); s.timer = (uint32_t)((uint64_t)key >> 48); s.cur = start;
             init_consts();
             ok = false;
+            int nseek = 0;
             for (int nev = 0; nev < 64; nev++) {
+                // A prediction is a fresh post-frame state: the frame it is for starts within a few idle symbols of it.  One that still
+                // seeks after 8 events stands in a gap or in the middle of a frame (a cadence continued across a gap) -- nothing a scout
+                // will ever adopt, and seeking on to the next frame costs a whole acquisition (64 events = 70 us) per wrong slot and round.
+                if (s.state == SY_SEEK && ++nseek > 8) break;
                 int64_t t_ev;
                 if (s.state == SY_SEEK)       t_ev = s.cur + ((s.timer + 1 >= (uint32_t)c.M) ? 0 : (int64_t)(c.M - 1 - (int)s.timer));
                 else if (s.state == SY_S0A || s.state == SY_S0B)
