@@ -93,6 +93,9 @@ struct ChanState {
     // frame cadence seen so far (speculation only; never part of the synchronizer's decisions)
     uint32_t period_hint;       // distance between the last two consecutive post-frame states (0: none yet)
     int64_t last_fresh;         // the most recent post-frame state's position
+    uint32_t burst_hint;        // frames a round adopted in a row before it met a state nobody predicted (0: not learnt): how far a
+                                // stopped scout predicts when pushes hold several bursts (SyncArgs::burst_limit)
+    uint32_t burst_pad;
 };
 
 // one decoded frame (device side); host copies payload / framesyms from the slot arrays
@@ -183,6 +186,10 @@ struct SyncArgs {
     uint32_t *walk_hint;                 // host-mapped word: frames the scouts had to acquire themselves so far (the host adds a full-width round while it moves)
     uint32_t *hint;             // host-mapped word: longest coded frame (bytes) among this launch's jobs
     uint32_t enc_hint;          // the value the host last saw there (0: none yet)
+    int round_idx;              // which acquisition round of the launch this is (a scout that stops in round >= 1 reports it: stats[6], the host
+                                // sizes the number of rounds by the last one that was needed)
+    int burst_limit;            // 1: a stopped scout predicts one burst ahead (ChanState::burst_hint), not to the end of the buffer: the host
+                                // sets it while it runs several extra rounds per launch -- every wrong slot is an acquisition attempt per round
     int stop_after_walk;        // 1: a scout standing in a post-frame (or the entry) state nobody predicted stops there and predicts
                                 //    the frames that follow from it (cadence re-anchored inside the launch); the next round continues
     int64_t defer_limit;        // > 0: the next push carries this many channel-rate samples of history, so a frame whose payload

@@ -707,7 +707,7 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     if (!q->scout) HIPCHK(hipMemsetAsync(a.njobs, 0, sizeof(uint32_t), sa));     // (with the scout, the previous launch's placement kernel zeroed it)
     q->acq_stream = sa;
     RC(q->ev_begin(1, sa));
-    a.stop_after_walk = 0; a.tail_only = 0; a.defer_limit = (int64_t)q->defer;
+    a.stop_after_walk = 0; a.tail_only = 0; a.defer_limit = (int64_t)q->defer; a.burst_limit = 0; a.round_idx = 0;
     if (q->spec) {
         // lean configurations: a payload that straddles two pushes is walked by the tail kernel (before the rounds:
         // the frame the previous push left in progress; after them: the one this push ends in), everything else by
@@ -772,11 +772,20 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
                 q->walk_seen = w; q->extra_round_for = q->extra_len;
             } else if (q->extra_rounds > 1 && ++q->extra_calm >= 64) { q->extra_rounds--; q->extra_calm = 0; }
             if (q->extra_round_for > 0) { if (--q->extra_round_for == 0) q->extra_end = q->seq; rounds += q->extra_rounds; }
-            if (a.debug & 4) fprintf(stderr, "[host] launch %llu walk counter %u extra_round_for %d extra_rounds %d rounds %d\n", (unsigned long long)q->seq, w, q->extra_round_for, q->extra_rounds, rounds);
+            a.burst_limit = (q->extra_round_for > 0 && q->extra_rounds > 1) ? 1 : 0;
+            if (a.burst_limit) {
+                // ... and no more rounds than the last launches needed: the scouts report the last round in which one of them had to
+                // stop (host-mapped word 6, a launch or two late); one round behind it finishes the push, one more is spare.  Walking
+                // that comes back raises extra_rounds above, and a round that stops later than before raises this bound with it.
+                const uint32_t used = ((volatile uint32_t *)q->h_hint)[6];
+                if (used) { const int want = (int)used + 2; if (want < rounds) rounds = want < 3 ? 3 : want; }
+            }
+            if (a.debug & 4) fprintf(stderr, "[host] launch %llu walk counter %u extra_round_for %d extra_rounds %d rounds %d (last round a scout stopped in: %u)\n", (unsigned long long)q->seq, w, q->extra_round_for, q->extra_rounds, rounds, ((volatile uint32_t *)q->h_hint)[6]);
             a.walk_hint = q->d_hint + 2;
         }
         const uint32_t cap = a.spec_cap;
         for (int r = 0; r < rounds; r++) {
+            a.round_idx = r;
             a.stop_after_walk = (r + 1 < rounds) ? 1 : 0;
             a.spec_cap = (r == 0 && q->narrow_first && rounds > 1 && cap > 1) ? 1u : cap;
             HIPCHK(sync_launch_spec(a, sa));

@@ -1918,7 +1918,11 @@ struct Walker {
                 // nobody predicted this state.  In all but the last acquisition round the scout stops here instead of
                 // acquiring the frame itself: the next round's speculative waves start from this exact state and from
                 // the cadence continued from it, all in parallel
-                if (a.stop_after_walk) { stopped = true; break; }
+                if (a.stop_after_walk) {
+                    stopped = true;
+                    if (a.stats && a.round_idx >= 1 && l == 0) atomicMax(a.stats + 6, (uint32_t)a.round_idx + 1u);      // (the narrow round always ends in a stop)
+                    break;
+                }
             }
             entry = false;
             if (MODE == SYM_LEAN && s.cur >= a.end) break;      // (a frame jumped over may end beyond this buffer)
@@ -2004,10 +2008,21 @@ struct Walker {
                 const bool two = P_old > 0 && P_old != P;
                 int64_t p2 = anchor + P_old;
                 if (two && p2 < s.cur) p2 += (s.cur - p2 + P_old - 1) / P_old * P_old;
-                for (; npred < MCRX_SPEC_MAX && p < limit; p += P, p2 += P_old) {
+                // Pushes that hold several bursts (a gap in front of each) take a round per burst: the scout stops behind the frame
+                // that opened the next one.  What lies beyond that burst's end is off the cadence again, so a stopped scout predicts
+                // one burst ahead -- the run of adoptions it has just seen, doubled when it ran out of predictions on the cadence --
+                // instead of to the end of the buffer (every slot beyond is an acquisition attempt thrown away, per round).
+                uint32_t maxp = MCRX_SPEC_MAX;
+                if (a.burst_limit && stopped) {
+                    uint32_t bh = s.burst_hint;
+                    if (nadopted >= 2) bh = (bh && nadopted > bh) ? 2u * nadopted : nadopted;
+                    s.burst_hint = bh;
+                    if (bh) { const uint32_t want = (bh + 3u) * (two ? 2u : 1u) + 1u; maxp = want < MCRX_SPEC_MAX ? want : MCRX_SPEC_MAX; }
+                }
+                for (; npred < maxp && p < limit; p += P, p2 += P_old) {
                     if (l == 0) a.pred[(size_t)ch * MCRX_SPEC_MAX + npred] = spec_key(p, (uint32_t)L);
                     npred++;
-                    if (two && p2 != p && p2 < limit && npred < MCRX_SPEC_MAX) {
+                    if (two && p2 != p && p2 < limit && npred < maxp) {
                         if (l == 0) a.pred[(size_t)ch * MCRX_SPEC_MAX + npred] = spec_key(p2, (uint32_t)L);
                         npred++;
                     }
@@ -2703,6 +2718,7 @@ __global__ __launch_bounds__(PJ_T) void place_jobs_kernel(SyncArgs a)
         // and sets its acquisition policy by them (mcrx_hip.hip launch_sync)
         volatile uint32_t *h = a.walk_hint;
         h[0] = a.stats[0]; h[1] = a.stats[1]; h[2] = a.stats[4]; h[3] = a.stats[5];
+        h[4] = a.stats[6]; a.stats[6] = 0;      // the last round of THIS launch in which a scout had to stop (0: none): per launch, not cumulative
         __threadfence_system();
     }
     __shared__ uint32_t nqam;
