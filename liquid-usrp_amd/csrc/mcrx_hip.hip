@@ -768,7 +768,9 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
                 // enough: every gap inside a push costs a round (the scouts stop at the first state nobody predicted, the next round
                 // starts from there), and a push can hold many -- a rank's round of an 8-GPU job is 8 slabs long.  Twice as many
                 // rounds each time (at most 12), one fewer after 64 launches without such walking.
-                if (q->extra_round_for > 0 && w - q->walk_seen > q->nch / 2) { q->extra_rounds = std::min(2 * q->extra_rounds, 12); q->extra_calm = 0; }
+                // (not in a handle's first 24 launches: the host runs up to two turns of the slots ahead of the device, what it reads then
+                //  was walked before any cadence existed -- a cold start is not a stream of bursts)
+                if (q->extra_round_for > 0 && q->seq >= 24 && w - q->walk_seen > q->nch / 2) { q->extra_rounds = std::min(2 * q->extra_rounds, 12); q->extra_calm = 0; }
                 q->walk_seen = w; q->extra_round_for = q->extra_len;
             } else if (q->extra_rounds > 1 && ++q->extra_calm >= 64) { q->extra_rounds--; q->extra_calm = 0; }
             if (q->extra_round_for > 0) { if (--q->extra_round_for == 0) q->extra_end = q->seq; rounds += q->extra_rounds; }

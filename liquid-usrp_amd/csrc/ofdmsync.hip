@@ -2015,7 +2015,9 @@ struct Walker {
                 uint32_t maxp = MCRX_SPEC_MAX;
                 if (a.burst_limit && stopped) {
                     uint32_t bh = s.burst_hint;
-                    if (nadopted >= 2) bh = (bh && nadopted > bh) ? 2u * nadopted : nadopted;
+                    // (ran out of predictions: twice the run; a shorter run ended at a gap or at the end of the buffer and says nothing
+                    //  about the bursts: the hint only grows, a restart forgets it)
+                    if (nadopted >= 2 && (!bh || nadopted > bh)) bh = bh ? 2u * nadopted : nadopted;
                     s.burst_hint = bh;
                     if (bh) { const uint32_t want = (bh + 3u) * (two ? 2u : 1u) + 1u; maxp = want < MCRX_SPEC_MAX ? want : MCRX_SPEC_MAX; }
                 }
