@@ -137,6 +137,10 @@ def main():
 
     max_frames = N * args.frames + 64 if (world == 1 and not args.pipeline) else cg * args.frames * nslab + 64
     cfg = dict(max_payload_len=max(args.payload, 64), max_frames=max_frames)
+    if world > 1:
+        # a rank's round holds `world` sub-slabs of time, i.e. about that many bursts with a gap in front of each: one acquisition round per
+        # burst from the first launch on instead of after the policy's ~50 launches of finding out
+        os.environ.setdefault("MCRX_EXTRA_ROUNDS", str(min(12, world + 4)))
     if world > 1 or args.pipeline:
         # rounds cut the stream anywhere: a frame that straddles two rounds is acquired again by the next round (whole, by
         # the parallel path) instead of being walked symbol by symbol -- the history in front of every round covers a frame

@@ -45,6 +45,8 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=dev)
+    if world > 1:                                            # about `world` bursts per round on every channel: see bench.py / DESIGN.md section 5
+        os.environ.setdefault("MCRX_EXTRA_ROUNDS", str(min(12, world + 4)))
     prod = load_product()
     from liquid_usrp_amd import sharding
     N, M, cp, taper, Tc = args.channels, 64, 8, 4, args.sub_blocks

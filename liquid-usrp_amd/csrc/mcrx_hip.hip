@@ -535,6 +535,10 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
         if (getenv("MCRX_SCOUT_ROUNDS")) { q->scout_rounds = std::max(1, std::min(8, atoi(getenv("MCRX_SCOUT_ROUNDS")))); q->rounds_fixed = true; }
         if (getenv("MCRX_NARROW_FIRST")) q->narrow_first = atoi(getenv("MCRX_NARROW_FIRST")) != 0;
         if (getenv("MCRX_LEAN_BUILD")) q->lean_build = atoi(getenv("MCRX_LEAN_BUILD"));
+        // a caller that knows its pushes hold several bursts (a rank of a G-GPU job: G sub-slabs of time per round) can say so instead of
+        // letting the policy find out over its first ~50 launches: that many extra rounds from the first launch on, trimmed by the
+        // scouts' report like any others (bench.py sets it for --gpus > 1)
+        if (getenv("MCRX_EXTRA_ROUNDS")) { q->extra_rounds = std::max(1, std::min(12, atoi(getenv("MCRX_EXTRA_ROUNDS")))); q->extra_len = 4096; q->extra_round_for = 4096; }
         if (getenv("MCRX_SPEC_ADAPTIVE")) q->spec_adaptive = atoi(getenv("MCRX_SPEC_ADAPTIVE")) != 0;
         if (q->spec) {
             if ((rc = q->alloc(&q->d_spec, (size_t)q->nch * MCRX_SPEC_MAX))) return bail(rc);
