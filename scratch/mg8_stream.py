@@ -11,7 +11,7 @@ from __graft_entry__ import load_product
 prod = load_product()
 dev = torch.device("cuda", 0)
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-N, M, cp, world = 512, 64, 8, 8
+N, M, cp, world = 512, 64, 8, int(os.environ.get("MG_WORLD", "8"))
 K, cg, TILE = 2 * N, N // world, 8
 tx = prod.multichanneltx(N, M, cp, 4)
 iq, sent = tx.generate(frames, 1200, seed=0xC0FFEE, device=dev)
