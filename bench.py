@@ -125,7 +125,7 @@ def main():
     base_blocks = int(prod.lib().mctx_hip_blocks_for(tx._h, args.frames, args.payload, 40, 1, 6))
     slabs, sents = [], []
     for i in range(nslab):
-        pad = (0, 72, 24, 136, 48, 104)[i % 6]                       # different idle gaps (blocks)
+        pad = (0, 80, 32, 144, 48, 112)[i % 6]                       # different idle gaps (blocks; whole tiles)
         d, s = tx.generate(args.frames, args.payload, seed=0xC0FFEE + 7919 * i, nblocks=base_blocks + pad, device=dev)
         slabs.append(d); sents.append(frame_index(s))
     torch.cuda.synchronize()
@@ -186,7 +186,7 @@ def main():
         # one period of the stream = nslab slabs; cut into rounds * world sub-slabs, sub-slab u -> rank u % world
         rounds = args.rounds
         stream = torch.cat(slabs)
-        unit = rounds * world * 8
+        unit = rounds * world * 16                                   # sub-slabs are whole tiles (MCRX_TILE blocks)
         tot = (period_blocks + unit - 1) // unit * unit
         if tot > period_blocks:
             stream = torch.cat([stream, torch.zeros((tot - period_blocks) * K, dtype=torch.complex64, device=dev)])

@@ -41,7 +41,8 @@ extern "C" {
 #define MCRX_EOVERFLOW  -5      /* frame pool exhausted: frames were dropped */
 #define MCRX_EBUSY      -6      /* multichanneltx::UpdateData on a channel whose frame is still going out */
 
-#define MCRX_TILE 8             /* time samples per (channel, tile) granule = 64 bytes */
+#define MCRX_TILE 16            /* time samples per (channel, tile) granule = 128 bytes: one channel per cache line, so a
+                                   synchronizer that reads one channel's time series never drags a neighbour channel's samples in */
 
 typedef struct mcrx_hip_s *mcrx_hip_t;
 
@@ -57,11 +58,11 @@ typedef struct {
     uint32_t batch_samples;      /* execute_host staging size [wideband samples]; 0 -> auto */
     uint32_t single_channel;     /* 1 = no channelizer: num_channels must be 1 and the samples pushed are that
                                     channel's own stream, i.e. one ofdmflexframesync (lib/ofdmtxrx.cc:91,620-626);
-                                    samples are consumed 8 at a time */
+                                    samples are consumed MCRX_TILE at a time */
     uint32_t serial;             /* 1 = every kernel of a push runs in order on the caller's stream (profiling, debugging).
                                     Default 0: the handle overlaps its own stages -- channelizer, acquisition and payload/decode
                                     kernels of consecutive pushes run on three internal streams with three sets of buffers */
-    uint32_t chunk_blocks;       /* execute_device: split a push into sub-slabs of this many blocks (multiple of 8) so that
+    uint32_t chunk_blocks;       /* execute_device: split a push into sub-slabs of this many blocks (rounded up to whole tiles) so that
                                     the stages of ONE call overlap too; 0 = one launch sequence per call */
     uint32_t defer_samples;      /* > 0: every push keeps this many channel-rate samples of history (plus a symbol) in front of its
                                     channel tiles, and a frame that begins less than that before the end of a push and does not
@@ -212,7 +213,10 @@ int      mcrx_hip_pipeline_unique_id(void *id128);                              
 int      mcrx_hip_pipeline_create(mcrx_hip_pipeline_t *out, mcrx_hip_t rx, int rank, int world, const void *unique_id128,
                                   size_t sub_blocks, unsigned nbuf /* rotating buffer sets, 0 = 3 */);
 /* one round: d_iq_sub = this rank's sub-slab (sub_blocks * 2N cf32 in HBM), d_halo = the 13 blocks in front of it in the
- * stream (NULL = zeros: the stream's first sub-slab), after_stream = the stream that produced them (NULL: ready) */
+ * stream (NULL = zeros: the stream's first sub-slab), after_stream = the hipStream_t that produced them: the round starts behind
+ * what is enqueued there now.  NULL is the legacy default stream (it is waited for like any other: the pipeline's own streams are
+ * non-blocking); MCRX_STREAM_READY = the buffers are complete, wait for nothing */
+#define MCRX_STREAM_READY ((void *)(intptr_t)-1)
 int      mcrx_hip_pipeline_push(mcrx_hip_pipeline_t p, const void *d_iq_sub, const void *d_halo, void *after_stream);
 int      mcrx_hip_pipeline_wait(mcrx_hip_pipeline_t p);                              /* host wait for everything pushed */
 int      mcrx_hip_pipeline_time_exchange(mcrx_hip_pipeline_t p, int on);            /* HIP events around every exchange */
@@ -230,7 +234,7 @@ typedef struct mctx_hip_s *mctx_hip_t;
 int    mctx_hip_create(mctx_hip_t *out, unsigned num_channels, unsigned M, unsigned cp_len,
                        unsigned taper_len, const unsigned char *p);
 int    mctx_hip_destroy(mctx_hip_t q);
-/* blocks of 2N samples needed for `frames_per_channel` frames plus the filter tail (multiple of 8) */
+/* blocks of 2N samples needed for `frames_per_channel` frames plus the filter tail (multiple of MCRX_TILE) */
 size_t mctx_hip_blocks_for(mctx_hip_t q, unsigned frames_per_channel, unsigned payload_len,
                            int mod, int fec0, int fec1);
 /* writes nblocks*2N cf32 samples to d_iq; the headers / payloads that were sent are returned in

@@ -19,7 +19,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBPATH = os.environ.get("MCRX_LIB") or os.path.join(_HERE, "lib", "libmcrx_hip.so")      # (MCRX_LIB: A/B builds)
 
 MCRX_OK, MCRX_EINVAL, MCRX_ENOMEM, MCRX_EHIP, MCRX_EUNSUPP, MCRX_EOVERFLOW, MCRX_EBUSY = 0, -1, -2, -3, -4, -5, -6
-TILE = 8
+TILE = 16         # MCRX_TILE (include/mcrx_hip.h)
+TX_TILE = 8       # granules of the transmit side (mctx_hip_traffic_tiles)
 
 LIQUID_CRC_NONE, LIQUID_CRC_32 = 1, 6
 LIQUID_FEC_NONE, LIQUID_FEC_HAMMING128, LIQUID_FEC_GOLAY2412, LIQUID_FEC_CONV_V27 = 1, 6, 7, 11
@@ -544,7 +545,7 @@ class multichanneltx(object):
         import torch
         nb = int(lib().mctx_hip_blocks_for(self._h, frames_per_channel, payload_len, mod, fec0, fec1))
         if nblocks is not None:
-            nb = max(nb, (int(nblocks) + 7) // 8 * 8)
+            nb = max(nb, (int(nblocks) + TILE - 1) // TILE * TILE)
         iq = torch.empty(nb * self.K, dtype=torch.complex64, device=device or "cuda")
         hdr = np.zeros((self.N, frames_per_channel, 8), np.uint8)
         pay = np.zeros((self.N, frames_per_channel, max(payload_len, 1)), np.uint8)
@@ -564,7 +565,7 @@ class multichanneltx(object):
         a longer silence (16 .. 16 + long_max symbols) once in long_every frames, until `nblocks` blocks are full.
         -> (iq, sent, starts): sent[ch] = [(header, payload)], starts[ch] = [block index of each frame's first sample]."""
         import torch
-        nb = (int(nblocks) + 7) // 8 * 8
+        nb = (int(nblocks) + TILE - 1) // TILE * TILE
         L = self.M + self.cp
         shortest = int(lib().mctx_hip_blocks_for(self._h, 1, len_lo, mod, fec0, fec1)) - 64
         maxf = nb // max(shortest, L) + 2
@@ -748,7 +749,7 @@ def ofdmflexframegen(M, cp_len, taper_len, p=None):
 
 
 def tiles_to_channels(chan, nch):
-    """[tile][ch][8] (torch or numpy, complex) -> [ch][time] numpy array (test helper)."""
+    """[tile][ch][TILE] (torch or numpy, complex) -> [ch][time] numpy array (test helper)."""
     a = chan.cpu().numpy() if hasattr(chan, "cpu") else np.asarray(chan)
     a = a.reshape(-1, nch, TILE)
     return np.ascontiguousarray(a.transpose(1, 0, 2)).reshape(nch, -1)

@@ -19,16 +19,21 @@
 //   * the remaining F-point (F = 2..16) transforms entirely in registers, one group per
 //     thread; the tile is padded by one element per F so that this stage, whose lanes are
 //     F elements apart, is LDS bank-conflict free.
-// The kept bins leave as 64-byte (channel, tile) granules
-//   out[g][tile][c][8],  channel = g*Cg + c
-// -- the layout the synchronizer streams and the per-destination chunking an xGMI
-// all-to-all needs.  HBM-bound by design: 8 B read + 4 B written per wideband sample.
+// The kept bins leave as 128-byte (channel, tile) granules of 16 time samples
+//   out[g][tile][c][16],  channel = g*Cg + c
+// -- one channel per cache line, so a synchronizer wave that streams one channel's time series moves
+// only that channel's bytes (with 64-byte granules two channels shared a line and the payload workers
+// fetched 1.85 x their algorithmic bytes: profiles/r3_v4_traffic.json) -- and the per-destination chunking an
+// xGMI all-to-all needs.  A round of 8 blocks fills one half of every granule; the next round of the same
+// workgroup fills the other (slabs are whole tiles), so the halves meet in that XCD's L2.
+// HBM-bound by design: 8 B read + 4 B written per wideband sample.
 #include "devmath.h"
 #include "kernels.h"
 
 namespace mcrx {
 
-#define CH_R 8          // blocks per round == MCRX_TILE
+#define CH_R 8          // blocks per round == half a (channel, tile) granule
+static_assert(MCRX_TILE_S == 2 * CH_R, "two rounds fill one granule");
 #define CH_P 14         // taps per branch (m = 7)
 #define CH_H (CH_P - 1) // history blocks
 
@@ -229,7 +234,7 @@ __device__ __forceinline__ void channelizer_rounds(const ChanArgs &a, float2 *ti
     for (int i = 0; i < GTRIPS; i++) { const int g = tid + i * T; fg[i] = (g / (K / F)) * ROWP + (g % (K / F)) * (F + 1); }
     constexpr int OTRIPS = NOPS / T;
     int ssrc[OTRIPS];                                   // LDS source of granule store k
-    uint32_t sdst[OTRIPS];                              // its destination in round 0 (16-byte units from a.out); every round is one tile further
+    uint32_t sdst[OTRIPS];                              // its destination in round 0 (16-byte units from a.out); odd rounds fill the granule's second half, every second round is one tile further
     int srem[OTRIPS];                                   // blocks of the stream from its slab's first one on (EDGE: stores past the end are masked)
 #pragma unroll
     for (int k = 0; k < OTRIPS; k++) {
@@ -239,11 +244,11 @@ __device__ __forceinline__ void channelizer_rounds(const ChanArgs &a, float2 *ti
         const long long ob = ((long long)blockIdx.x * NS + osl) * (long long)a.slab_blocks;
         const int g = ch / a.cg, c = ch % a.cg;
         ssrc[k] = (osl * CH_R + 2 * rp) * ROWP + pad<K>(dif_pos<K>(ch));
-        sdst[k] = (uint32_t)(((((size_t)g * a.ntiles + (size_t)(ob / CH_R)) * a.cg + c) * CH_R + 2 * rp) / 2);   // (launch_one checks the range)
+        sdst[k] = (uint32_t)((((size_t)g * a.ntiles + (size_t)(ob / MCRX_TILE_S)) * a.cg + c) * (MCRX_TILE_S / 2) + rp);   // (launch_one checks the range; slabs start on tiles)
         const long long left = (long long)a.nblocks - ob;
         srem[k] = left < 0 ? 0 : (left > 0x40000000ll ? 0x40000000 : (int)left);
     }
-    const uint32_t tile_step = a.cg * (CH_R / 2);            // 16-byte units between consecutive tiles of a channel group
+    const uint32_t tile_step = a.cg * (MCRX_TILE_S / 2);     // 16-byte units between consecutive tiles of a channel group
     float4 *out4 = reinterpret_cast<float4 *>(a.out);
 
     const int rounds = a.slab_blocks / CH_R;
@@ -320,7 +325,7 @@ __device__ __forceinline__ void channelizer_rounds(const ChanArgs &a, float2 *ti
             lds_barrier();
         }
 
-        // ---- store bins 0..N-1 as (channel, tile) granules of 8 time samples (64 B)
+        // ---- store bins 0..N-1: this round's 8 time samples = one half (64 B) of every channel's granule
 #pragma unroll
         for (int k = 0; k < OTRIPS; k++) {
             bool ok = true;
@@ -328,7 +333,7 @@ __device__ __forceinline__ void channelizer_rounds(const ChanArgs &a, float2 *ti
             if (ok) {
                 const float2 *src = tile + ssrc[k];
                 const float2 v0 = src[0], v1 = src[ROWP];
-                out4[(size_t)(sdst[k] + (uint32_t)rd * tile_step)] = make_float4(v0.x, v0.y, v1.x, v1.y);
+                out4[(size_t)(sdst[k] + ((uint32_t)rd >> 1) * tile_step + ((uint32_t)rd & 1u) * (CH_R / 2))] = make_float4(v0.x, v0.y, v1.x, v1.y);
             }
         }
         lds_barrier();
@@ -354,7 +359,7 @@ static hipError_t launch_one(const ChanArgs &a, hipStream_t st)
     unsigned grid = (unsigned)((nslabs + NS - 1) / NS);
     if (grid == 0) return hipSuccess;
     // granule stores are addressed by 32-bit offsets in 16-byte units: 64 GB of output per launch
-    if ((unsigned long long)(K / 2) * ((unsigned long long)a.ntiles + (unsigned long long)NS * a.slab_blocks / CH_R) * (CH_R / 2) >= (1ull << 32))
+    if ((unsigned long long)(K / 2) * ((unsigned long long)a.ntiles + (unsigned long long)NS * a.slab_blocks / MCRX_TILE_S + 1ull) * (MCRX_TILE_S / 2) >= (1ull << 32))
         return hipErrorInvalidValue;
     static bool attr_set = false;
     if (!attr_set) {
@@ -370,7 +375,7 @@ static hipError_t launch_one(const ChanArgs &a, hipStream_t st)
 // ------------------------------------------------------------------------------------------------
 // Any other channel count the reference constructor accepts (lib/multichannelrx.cc:54-66 only asks for N >= 1;
 // liquid's firpfbch takes any K): the same arithmetic without the register window and the radix-4 plan -- a
-// workgroup per tile of 8 blocks, FIR columns straight from global memory (the 14-fold reuse is the caches'), then a
+// workgroup per round of 8 blocks (half a tile), FIR columns straight from global memory (the 14-fold reuse is the caches'), then a
 // direct DFT of the kept bins with an exact integer twiddle index.  A fallback for odd sizes, O(K N) per block:
 // the power-of-two kernel above is the product's fast path.
 #define CG_T 256
@@ -412,7 +417,7 @@ __global__ __launch_bounds__(CG_T) void channelizer_generic_kernel(ChanArgs a, u
         for (int r = 0; r < CH_R; r++) V[(size_t)r * K + n] = acc[r];
     }
     __syncthreads();
-    const long long tl = b0 / CH_R;
+    const long long tl = b0 / MCRX_TILE_S; const int half = (int)((b0 / CH_R) & 1);
     for (uint32_t k = tid; k < N; k += CG_T) {
         float2 y[CH_R];
 #pragma unroll
@@ -428,7 +433,7 @@ __global__ __launch_bounds__(CG_T) void channelizer_generic_kernel(ChanArgs a, u
             idx += k; if (idx >= K) idx -= K;
         }
         const uint32_t g = k / a.cg, c = k % a.cg;
-        float4 *dst = reinterpret_cast<float4 *>(a.out + (((size_t)g * a.ntiles + (size_t)tl) * a.cg + c) * CH_R);
+        float4 *dst = reinterpret_cast<float4 *>(a.out + (((size_t)g * a.ntiles + (size_t)tl) * a.cg + c) * MCRX_TILE_S + half * CH_R);
 #pragma unroll
         for (int r = 0; r < CH_R; r += 2) dst[r / 2] = make_float4(y[r].x, y[r].y, y[r + 1].x, y[r + 1].y);
     }
@@ -449,7 +454,7 @@ uint32_t channelizer_auto_slab(unsigned K, size_t nblocks, unsigned ncu)
     const size_t capacity = (size_t)ncu * (K >= 1024 ? 1u : 2u) * ns;                   // slabs in one wave of workgroups
     const size_t k = (nblocks + capacity * 512 - 1) / (capacity * 512);
     size_t slab = (nblocks + capacity * k - 1) / (capacity * k);
-    slab = (slab + 7) & ~(size_t)7;
+    slab = (slab + MCRX_TILE_S - 1) & ~(size_t)(MCRX_TILE_S - 1);
     if (slab < 32) slab = 32;
     return (uint32_t)slab;
 }

@@ -5,7 +5,8 @@
 
 namespace mcrx {
 
-#define MCRX_TILE_S 8            // channel-rate samples per (channel, tile) granule
+#define MCRX_TILE_S 16           // channel-rate samples per (channel, tile) granule = 128 bytes = one cache line (== MCRX_TILE, include/mcrx_hip.h)
+#define MCRX_TILE_SH 4           // log2 of it
 #define MCRX_HDR_SYMS 288        // BPSK header symbols
 #define MCRX_HDR_ENC 36
 #define MCRX_HDR_DEC 14
@@ -15,9 +16,9 @@ struct ChanArgs {
     const float2 *x;            // new wideband samples, nblocks * K
     const float2 *halo;         // 13 blocks preceding x (NULL = zeros: cold start)
     const float *taps;          // p*K prototype taps
-    float2 *out;                // out[g][tile][c][8]
-    uint32_t nblocks;           // blocks in x (multiple of 8)
-    uint32_t slab_blocks;       // blocks per slab (multiple of 8)
+    float2 *out;                // out[g][tile][c][16]
+    uint32_t nblocks;           // blocks in x (multiple of 16)
+    uint32_t slab_blocks;       // blocks per slab (multiple of 16)
     uint32_t first_sample_lo;   // absolute sample index of x[0], low 32 bits (NCO phase)
     uint32_t dtheta;            // NCO phase increment per sample
     uint32_t ntiles;            // tiles per group in `out`
@@ -137,7 +138,7 @@ struct SpecSlot {
 
 struct SyncArgs {
     SyncConsts c;
-    const float2 *chan;         // [tile][chan_stride][8]; my channel c sits at chan_off + c
+    const float2 *chan;         // [tile][chan_stride][16]; my channel c sits at chan_off + c
     uint32_t chan_stride, chan_off;
     int64_t buf_first;          // absolute index of chan sample (tile 0, slot 0)
     int64_t end;                // absolute end (exclusive) of valid samples

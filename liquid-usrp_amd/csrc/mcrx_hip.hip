@@ -86,7 +86,7 @@ __global__ void nco_mix_kernel(const float2 *x, float2 *y, uint64_t n, uint32_t 
 //     y[k] = 0.5 * ( Y[2k - 13] + sum_{i < 14} h1[i] Y[2 (k - 13 + i)] )
 // over the bank's steps Y[s][0 .. M-1] (32 steps of history sit in front of s = 0), written as the synchronizers'
 // (channel, tile) granules.  A thread takes one granule: channels are consecutive across a wave, so every read of a
-// step row is one contiguous line and the 64-byte granules of a wave form one 4 KB store.
+// step row is one contiguous line and the 128-byte granules of a wave form one 8 KB store.
 __global__ void halfband_adapter_kernel(const float2 *Y, uint32_t M, uint32_t N, uint32_t ntiles, const float *h1, float2 *out)
 {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x, tile = blockIdx.y;
@@ -94,14 +94,15 @@ __global__ void halfband_adapter_kernel(const float2 *Y, uint32_t M, uint32_t N,
     float h[14];
 #pragma unroll
     for (int i = 0; i < 14; i++) h[i] = h1[i];
-    const long long k0 = (long long)tile * 8;
-    float2 ev[21];                                  // even steps 2 (k0 - 13) .. 2 (k0 + 7)
+    constexpr int TS = MCRX_TILE_S;
+    const long long k0 = (long long)tile * TS;
+    float2 ev[13 + TS];                             // even steps 2 (k0 - 13) .. 2 (k0 + TS - 1)
 #pragma unroll
-    for (int i = 0; i < 21; i++) ev[i] = Y[(2 * (k0 - 13 + i)) * (long long)M + c];
-    float4 *dst = reinterpret_cast<float4 *>(out + ((size_t)tile * N + c) * 8);
-    float2 y[8];
+    for (int i = 0; i < 13 + TS; i++) ev[i] = Y[(2 * (k0 - 13 + i)) * (long long)M + c];
+    float4 *dst = reinterpret_cast<float4 *>(out + ((size_t)tile * N + c) * TS);
+    float2 y[TS];
 #pragma unroll
-    for (int t = 0; t < 8; t++) {
+    for (int t = 0; t < TS; t++) {
         float2 acc = make_float2(0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < 14; i++) { acc.x += h[i] * ev[t + i].x; acc.y += h[i] * ev[t + i].y; }
@@ -109,7 +110,7 @@ __global__ void halfband_adapter_kernel(const float2 *Y, uint32_t M, uint32_t N,
         y[t] = make_float2(0.5f * (d.x + acc.x), 0.5f * (d.y + acc.y));
     }
 #pragma unroll
-    for (int t = 0; t < 8; t += 2) dst[t / 2] = make_float4(y[t].x, y[t].y, y[t + 1].x, y[t + 1].y);
+    for (int t = 0; t < TS; t += 2) dst[t / 2] = make_float4(y[t].x, y[t].y, y[t + 1].x, y[t + 1].y);
 }
 
 // ---------------------------------------------------------------- handle
@@ -459,7 +460,7 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     q->sarena_cap = (uint64_t)q->max_rec * (8ull * 8ull * (2ull * (q->max_payload + 4) + 8));
     if (q->sarena_cap > (8ull << 30)) q->sarena_cap = 8ull << 30;
     q->pipelined = !(q->cfg.struct_size >= offsetof(mcrx_hip_config, serial) + sizeof(uint32_t) && q->cfg.serial) && getenv("MCRX_SERIAL") == nullptr;
-    q->slab_blocks = q->cfg.slab_blocks ? ((q->cfg.slab_blocks + 7) & ~7u) : 0;      // 0: sized per launch
+    q->slab_blocks = q->cfg.slab_blocks ? ((q->cfg.slab_blocks + MCRX_TILE - 1) & ~(uint32_t)(MCRX_TILE - 1)) : 0;      // 0: sized per launch; slabs are whole tiles
     { int dev = 0, n = 0;
       if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
           q->ncu = (uint32_t)n; }
@@ -470,7 +471,7 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     // channel-rate history in front of every push's tiles: a symbol window, plus -- if frames straddling two pushes are
     // to be deferred rather than walked serially -- the longest frame start-to-push-end distance to be covered
     q->defer = (q->cfg.struct_size >= offsetof(mcrx_hip_config, defer_samples) + sizeof(uint32_t)) ? q->cfg.defer_samples : 0;
-    q->hist_tiles = (unsigned)((q->defer + M + cp + 8 + 7) / 8 + 1);
+    q->hist_tiles = (unsigned)((q->defer + M + cp + 8 + MCRX_TILE - 1) / MCRX_TILE + 1);
 
     auto bail = [&](int rc) { mcrx_hip_destroy(q); return rc; };
     int rc;
@@ -549,8 +550,8 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     }
     if ((rc = q->alloc(&q->d_hist[0], (size_t)HIST_BLOCKS * q->K))) return bail(rc);
     if ((rc = q->alloc(&q->d_hist[1], (size_t)HIST_BLOCKS * q->K))) return bail(rc);
-    // host staging for Execute(): whole tiles of 8 blocks
-    size_t tile_samples = (size_t)8 * q->K;
+    // host staging for Execute(): whole tiles of MCRX_TILE blocks
+    size_t tile_samples = (size_t)MCRX_TILE * q->K;
     size_t want = q->cfg.batch_samples ? q->cfg.batch_samples : ((size_t)1 << 20);
     q->stage_cap = std::max<size_t>(1, (want + tile_samples - 1) / tile_samples) * tile_samples;
     if (hipHostMalloc((void **)&q->h_stage, q->stage_cap * sizeof(float2), hipHostMallocDefault) != hipSuccess)
@@ -641,7 +642,7 @@ static int launch_channelizer(mcrx_hip_t q, const float2 *x, size_t nblocks, uin
                               const float2 *halo, float2 *out, unsigned groups, size_t ntiles_stride, hipStream_t st)
 {
     if (nblocks == 0) return MCRX_OK;
-    if (nblocks % MCRX_TILE) return fail(MCRX_EINVAL, "nblocks must be a multiple of 8");
+    if (nblocks % MCRX_TILE) return fail(MCRX_EINVAL, "nblocks must be a multiple of MCRX_TILE (16)");
     if (groups == 0 || q->N % groups) return fail(MCRX_EINVAL, "groups must divide the channel count");
     ChanArgs a;
     a.x = x; a.halo = halo; a.taps = q->d_taps; a.out = out;
@@ -942,7 +943,7 @@ static int run_oversampled(mcrx_hip_t q, const float2 *x, size_t nblocks, uint64
     return MCRX_OK;
 }
 
-// channelize + synchronize `nblocks` (multiple of 8) blocks sitting in device memory, readable in `st`'s order.
+// channelize + synchronize `nblocks` (multiple of MCRX_TILE) blocks sitting in device memory, readable in `st`'s order.
 // Launch k writes the channel tiles of slot k % 3: [history: the last hist_tiles tiles of launch k-1][ntiles new].
 static int run_blocks(mcrx_hip_t q, const float2 *x, size_t nblocks, uint64_t first_abs, hipStream_t st)
 {
@@ -963,7 +964,7 @@ static int run_blocks(mcrx_hip_t q, const float2 *x, size_t nblocks, uint64_t fi
     if (q->last_slot >= 0)
         HIPCHK(hipMemcpyAsync(buf, q->d_chan[q->last_slot] + q->last_ntiles * tile_elems,
                               (size_t)q->hist_tiles * tile_elems * sizeof(float2), hipMemcpyDeviceToDevice, sc));
-    if (q->bypass)      // the input already is the channel's sample stream (8 samples per tile, contiguous)
+    if (q->bypass)      // the input already is the channel's sample stream (one channel: its tiles are contiguous)
         HIPCHK(hipMemcpyAsync(buf + q->hist_tiles * tile_elems, x, nblocks * sizeof(float2), hipMemcpyDeviceToDevice, sc));
     else if (q->oversampled)
         RC(run_oversampled(q, x, nblocks, first_abs, buf + q->hist_tiles * tile_elems, sc));
@@ -990,7 +991,7 @@ static int run_blocks(mcrx_hip_t q, const float2 *x, size_t nblocks, uint64_t fi
 
 static int process_staged(mcrx_hip_t q)
 {
-    const size_t tile_samples = (size_t)8 * q->K;
+    const size_t tile_samples = (size_t)MCRX_TILE * q->K;
     const size_t n = (q->stage_fill / tile_samples) * tile_samples;
     if (n == 0) return MCRX_OK;
     HIPCHK(hipMemcpyAsync(q->d_in, q->h_stage, n * sizeof(float2), hipMemcpyHostToDevice, q->stream));
@@ -1006,14 +1007,14 @@ static int harvest(mcrx_hip_t q);
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // frame records `blocks` channelizer blocks can produce at most (every channel sending shortest frames back to back)
-static uint64_t record_bound(mcrx_hip_t q, uint64_t blocks) { return ((blocks + 8) / q->min_frame + 2) * q->nch; }
+static uint64_t record_bound(mcrx_hip_t q, uint64_t blocks) { return ((blocks + MCRX_TILE) / q->min_frame + 2) * q->nch; }
 
 // Bulk Execute(buf, n): whole tiles go straight from the caller's (pageable) memory into one of two device
 // buffers on a copy stream while the previous chunk is still being processed; frames are harvested only when
 // the record pool could otherwise fill up.  What does not fill a tile is left for the staging path.
 static int execute_direct(mcrx_hip_t q, const float2 *&src, size_t &nsamples, bool &overflow)
 {
-    const size_t tile_samples = (size_t)8 * q->K;
+    const size_t tile_samples = (size_t)MCRX_TILE * q->K;
     if (q->stage_fill || nsamples < 64 * tile_samples) return MCRX_OK;
     // largest chunk whose frames are sure to fit the record pool, at most 16 Mi samples
     uint64_t blocks_cap = q->max_rec / q->nch > 3 ? (uint64_t)(q->max_rec / q->nch - 3) * q->min_frame : 0;
@@ -1069,7 +1070,7 @@ extern "C" int mcrx_hip_execute_host(mcrx_hip_t q, const float *iq, size_t nsamp
     if (!q || (!iq && nsamples)) return fail(MCRX_EINVAL, "null argument");
     const float2 *src = reinterpret_cast<const float2 *>(iq);
     bool overflow = false;
-    const size_t tile_samples = (size_t)8 * q->K;
+    const size_t tile_samples = (size_t)MCRX_TILE * q->K;
     if (q->stage_fill && nsamples >= 64 * tile_samples) {
         // a partial tile is waiting: complete it from this buffer so that the bulk path can take over
         const size_t need = std::min(nsamples, (tile_samples - q->stage_fill % tile_samples) % tile_samples);
@@ -1097,13 +1098,13 @@ extern "C" int mcrx_hip_execute_device(mcrx_hip_t q, const void *d_iq, size_t ns
 {
     if (!q || (!d_iq && nsamples)) return fail(MCRX_EINVAL, "null argument");
     if (q->stage_fill) return fail(MCRX_EINVAL, "host samples are still staged: flush before pushing device buffers");
-    if (nsamples % ((size_t)8 * q->K)) return fail(MCRX_EINVAL, "device pushes must be whole tiles of 8 blocks (16*N samples)");
+    if (nsamples % ((size_t)MCRX_TILE * q->K)) return fail(MCRX_EINVAL, "device pushes must be whole tiles of MCRX_TILE = 16 blocks (32*N samples)");
     hipStream_t st = stream ? (hipStream_t)stream : q->stream;
     // optional split into sub-slabs: within one call, sub-slab i+1's channelizer and acquisition overlap sub-slab i's
     // payload workers (consecutive calls overlap in the same way without it)
     const size_t nblocks = nsamples / q->K;
     size_t chunk = q->cfg.struct_size >= offsetof(mcrx_hip_config, chunk_blocks) + sizeof(uint32_t) && q->cfg.chunk_blocks
-                       ? ((size_t)q->cfg.chunk_blocks + 7) / 8 * 8 : nblocks;
+                       ? ((size_t)q->cfg.chunk_blocks + MCRX_TILE - 1) / MCRX_TILE * MCRX_TILE : nblocks;
     const float2 *x = (const float2 *)d_iq;
     for (size_t b = 0; b < nblocks; b += chunk) {
         const size_t nb = std::min(chunk, nblocks - b);
@@ -1323,7 +1324,7 @@ extern "C" int mcrx_hip_reset(mcrx_hip_t q)
     // multichannelrx::Reset (lib/multichannelrx.cc:135-153): synchronizers and channelizer windows
     // reset, partial block dropped, NCO keeps running.  Everything pushed before the Reset has been
     // synchronized by the reference at this point, so the whole tiles still in the staging buffer are processed
-    // first and only the sub-tile tail (< 16 N samples; the reference drops < 2 N) is discarded.  Frames decoded
+    // first and only the sub-tile tail (< 32 N samples; the reference drops < 2 N) is discarded.  Frames decoded
     // so far stay deliverable.
     if (!q) return fail(MCRX_EINVAL, "null handle");
     RC(process_staged(q));

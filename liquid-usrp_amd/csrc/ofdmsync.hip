@@ -723,7 +723,7 @@ struct Walker {
     {
         if (t < 0 || t < a.buf_first) return make_float2(0.f, 0.f);
         const int64_t r = t - a.buf_first;
-        return a.chan[((size_t)(r >> 3) * a.chan_stride + a.chan_off + ch) * MCRX_TILE_S + (size_t)(r & 7)];
+        return a.chan[((size_t)(r >> MCRX_TILE_SH) * a.chan_stride + a.chan_off + ch) * MCRX_TILE_S + (size_t)(r & (MCRX_TILE_S - 1))];
     }
     __device__ __forceinline__ float2 mixed(int64_t t) const
     {
@@ -887,7 +887,7 @@ struct Walker {
         for (int e = 0; e < E; e++) {
             int64_t r = rc + l + WV * e;
             r = r < len ? r : len - 1;
-            pf_x[e] = a.chan[((size_t)(r >> 3) * a.chan_stride + a.chan_off + ch) * MCRX_TILE_S + (size_t)(r & 7)];
+            pf_x[e] = a.chan[((size_t)(r >> MCRX_TILE_SH) * a.chan_stride + a.chan_off + ch) * MCRX_TILE_S + (size_t)(r & (MCRX_TILE_S - 1))];
         }
         pf_t = ok ? tn : INT64_MIN;
     }
@@ -1404,12 +1404,12 @@ struct Walker {
 #pragma unroll
         for (int e = 0; e < E; e++) nxt[e] = make_float2(0.f, 0.f);
 #pragma unroll
-        for (int e = 0; e < E; e++) { const int r = r_ws + l + WV * e; cur[e] = chb[(size_t)(r >> 3) * tstride + (size_t)(r & 7)]; }
+        for (int e = 0; e < E; e++) { const int r = r_ws + l + WV * e; cur[e] = chb[(size_t)(r >> MCRX_TILE_SH) * tstride + (size_t)(r & (MCRX_TILE_S - 1))]; }
         uint32_t psi = 0;
         for (uint32_t n = 0; n < ((a.no_fast & 4) ? 1u : nsym); n++) {
             if (n + 1 < nsym) {
 #pragma unroll
-                for (int e = 0; e < E; e++) { const int r = r_ws + L + l + WV * e; nxt[e] = chb[(size_t)(r >> 3) * tstride + (size_t)(r & 7)]; }
+                for (int e = 0; e < E; e++) { const int r = r_ws + L + l + WV * e; nxt[e] = chb[(size_t)(r >> MCRX_TILE_SH) * tstride + (size_t)(r & (MCRX_TILE_S - 1))]; }
             }
             float p0, p1;
             fast_core(cur, th_ws, dth, pc, p1_prime, p0, p1);
@@ -2254,7 +2254,7 @@ __global__ __launch_bounds__(WV) void payload_multi_kernel(SyncArgs a)
         for (int e = 0; e < E; e++) {
             int32_t r = rw + i + G * e;
             r = r < 0 ? 0 : (r > r_max ? r_max : r);                    // (groups that have finished keep reading in range)
-            x[e] = chb[(size_t)(r >> 3) * tstride + (size_t)(r & 7)];
+            x[e] = chb[(size_t)(r >> MCRX_TILE_SH) * tstride + (size_t)(r & (MCRX_TILE_S - 1))];
         }
     };
     float2 cur[E], nxt[E];

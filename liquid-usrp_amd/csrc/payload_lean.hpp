@@ -7,7 +7,7 @@
 // fit, oscillator trim); what changed is where the instructions go.  payload_multi_kernel<1> issues 203 VALU
 // instructions per symbol and is VALU-bound (272.8 M per 207.7 M-sample slab = 0.44 of its 0.52 ms, profiles/r3_v2_pmc.csv):
 //   * window address: 15 VALU (two 64-bit multiplies per lane)      -> a scalar base that advances per symbol + a lane
-//     offset that only changes when the window's phase inside the 8-sample tiles does (never for L = 72);
+//     offset that only changes when the window's phase inside the tiles does (L = 72 with 16-sample tiles: every other symbol);
 //   * the six butterfly stages: 50 VALU, of which 24 move data (v_mov_dpp, copies for v_permlane*_swap) -> the partner
 //     comes through the LDS crossbar (ds_swizzle / ds_bpermute: no VALU slot, no LDS memory), a stage is one packed fma
 //     for the butterfly and two for the twiddle;
@@ -137,7 +137,7 @@ __device__ __forceinline__ uint32_t symbols(const SyncArgs &a, const PayloadJob 
     float phi_prime = job->s.phi_prime, p1_prime = job->s.p1_prime;
     int32_t r_ws = (int32_t)rfl((uint32_t)(ws0 - a.buf_first));
     const float2 *chb = a.chan + ((size_t)a.chan_off + ch) * MCRX_TILE_S;
-    const uint32_t tstride = a.chan_stride * (uint32_t)MCRX_TILE_S;      // elements between a channel's consecutive 8-sample tiles
+    const uint32_t tstride = a.chan_stride * (uint32_t)MCRX_TILE_S;      // elements between a channel's consecutive tiles
     const int32_t r_max = (int32_t)(a.end - a.buf_first) - 1;
     const bool soft_mode = c.payload_soft != 0;
     uint8_t *soft = a.jsoft + (size_t)j * 8 * c.max_enc_len;
@@ -145,16 +145,22 @@ __device__ __forceinline__ uint32_t symbols(const SyncArgs &a, const PayloadJob 
     uint8_t *syms = a.sarena + (((uint64_t)rfl((uint32_t)(syms_off >> 32)) << 32) | rfl((uint32_t)syms_off));
     const uint32_t l4 = (uint32_t)l * 4u;
 
-    int q0 = -1; uint32_t offl = 0;                                      // the window's phase inside the tiles, the lane offset that goes with it
+    // the window's phase inside the tiles and the lane offset that goes with it: the two most recent ones are kept (L = 72 over
+    // 16-sample tiles alternates between two phases), so the symbol loop never recomputes them
+    int q0 = -1, q1 = -1; uint32_t offl = 0, offl1 = 0;
     auto load_win = [&](int32_t rw) -> v2f {
         if (rw >= 0 && rw + (WV - 1) <= r_max) {
-            if ((rw & 7) != q0) { q0 = rw & 7; const uint32_t q = (uint32_t)q0 + (uint32_t)l; offl = ((q >> 3) * tstride + (q & 7u)) * 8u; }
-            const char *base = reinterpret_cast<const char *>(chb + (size_t)(uint32_t)(rw >> 3) * tstride);
+            const int ph = rw & (MCRX_TILE_S - 1);
+            if (ph != q0) {
+                const int tq = q0; const uint32_t to = offl; q0 = q1; offl = offl1; q1 = tq; offl1 = to;      // swap: the other cached phase
+                if (ph != q0) { q0 = ph; const uint32_t q = (uint32_t)ph + (uint32_t)l; offl = ((q >> MCRX_TILE_SH) * tstride + (q & (uint32_t)(MCRX_TILE_S - 1))) * 8u; }
+            }
+            const char *base = reinterpret_cast<const char *>(chb + (size_t)(uint32_t)(rw >> MCRX_TILE_SH) * tstride);
             return *reinterpret_cast<const v2f *>(base + offl);
         }
         int32_t r = rw + l;
         r = r < 0 ? 0 : (r > r_max ? r_max : r);
-        return *reinterpret_cast<const v2f *>(chb + ((size_t)(r >> 3) * tstride + (size_t)(r & 7)));
+        return *reinterpret_cast<const v2f *>(chb + ((size_t)(r >> MCRX_TILE_SH) * tstride + (size_t)(r & (MCRX_TILE_S - 1))));
     };
 
     // Stores run one symbol late.  Loads and stores share one counter (vmcnt) and return out of order against each other, so

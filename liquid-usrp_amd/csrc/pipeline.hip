@@ -19,6 +19,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -40,17 +41,28 @@ struct Rccl {
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    // every symbol is resolved into a candidate first and the table committed only when all of them were found (a partly filled
+    // table behind a non-null `lib` would crash the next caller); once per process, thread safe
+    std::once_flag once; bool ok = false;
     bool load()
     {
-        if (lib) return true;
-        for (const char *name : { "librccl.so.1", "librccl.so" }) { lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
-        if (!lib) return false;
-#define SYM(f, n) f = reinterpret_cast<decltype(f)>(dlsym(lib, n)); if (!f) return false
-        SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
-        SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv");
-        SYM(GetErrorString, "ncclGetErrorString");
+        std::call_once(once, [this] {
+            void *h = nullptr;
+            for (const char *name : { "librccl.so.1", "librccl.so" }) { h = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+            if (!h) return;
+            Rccl t;
+            bool all = true;
+#define SYM(f, n) t.f = reinterpret_cast<decltype(t.f)>(dlsym(h, n)); all = all && t.f != nullptr
+            SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
+            SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv");
+            SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
-        return true;
+            if (!all) { dlclose(h); return; }
+            lib = h; GetUniqueId = t.GetUniqueId; CommInitRank = t.CommInitRank; CommDestroy = t.CommDestroy; GroupStart = t.GroupStart;
+            GroupEnd = t.GroupEnd; Send = t.Send; Recv = t.Recv; GetErrorString = t.GetErrorString;
+            ok = true;
+        });
+        return ok;
     }
 };
 Rccl g_rccl;
@@ -113,7 +125,7 @@ extern "C" int mcrx_hip_pipeline_create(mcrx_hip_pipeline_t *out, mcrx_hip_t rx,
     *out = nullptr;
     const unsigned N = mcrx_hip_num_channels(rx);
     if (world < 1 || rank < 0 || rank >= world || N % (unsigned)world) return pfail(MCRX_EINVAL, "ranks must divide the channel count");
-    if (sub_blocks == 0 || sub_blocks % MCRX_TILE) return pfail(MCRX_EINVAL, "sub-slabs are whole tiles of 8 blocks");
+    if (sub_blocks == 0 || sub_blocks % MCRX_TILE) return pfail(MCRX_EINVAL, "sub-slabs are whole tiles of MCRX_TILE = 16 blocks");
     if (nbuf < 2 || nbuf > kMaxBuf) nbuf = 3;
     if (world > 1 && !unique_id128) return pfail(MCRX_EINVAL, "world > 1 needs rank 0's ncclUniqueId (mcrx_hip_pipeline_unique_id)");
     mcrx_hip_pipeline_t p = new mcrx_hip_pipeline_s();
@@ -175,14 +187,16 @@ extern "C" uint64_t mcrx_hip_pipeline_bytes_sent_per_round(mcrx_hip_pipeline_t p
 
 // One round: this rank's sub-slab (sub_blocks blocks resident in HBM; d_halo = the 13 blocks in front of it in the stream, NULL
 // = zeros), the exchange, the synchronizers of the rank's channel shard over the round.  `after_stream`: the stream that
-// produced d_iq_sub (NULL: it is ready).  Returns after enqueuing.
+// produced d_iq_sub (NULL: the legacy default stream; MCRX_STREAM_READY: nothing to wait for).  Returns after enqueuing.
 extern "C" int mcrx_hip_pipeline_push(mcrx_hip_pipeline_t p, const void *d_iq_sub, const void *d_halo, void *after_stream)
 {
     if (!p || !d_iq_sub) return pfail(MCRX_EINVAL, "null argument");
     const uint64_t c = p->rounds; const unsigned nb = p->nbuf, i = (unsigned)(c % nb);
     float *out = p->out[i], *recv = p->recv[i], *fresh = recv + 2 * p->hist_elems;
     // ---- A: channelize into per-destination groups
-    if (after_stream) { PCHK(hipEventRecord(p->ev_after, (hipStream_t)after_stream)); PCHK(hipStreamWaitEvent(p->sA, p->ev_after, 0)); }
+    // (the pipeline's streams are non-blocking: they do not order against the legacy default stream by themselves, so a NULL
+    //  after_stream -- the default stream, e.g. torch's current one -- gets its event like any other; only MCRX_STREAM_READY skips it)
+    if (after_stream != MCRX_STREAM_READY) { PCHK(hipEventRecord(p->ev_after, (hipStream_t)after_stream)); PCHK(hipStreamWaitEvent(p->sA, p->ev_after, 0)); }
     if (c >= nb) {
         PCHK(hipStreamWaitEvent(p->sA, p->evB[i], 0));                         // the exchange that last read out[i]
         if (p->world == 1) {                                                    // out[i] IS recv[i]: also its last readers

@@ -525,7 +525,7 @@ extern "C" size_t mctx_hip_blocks_for(mctx_hip_t q, unsigned frames_per_channel,
     if (!q || !mod_bps(mod)) return 0;
     unsigned Sh, Sp, S; frame_geometry(q, payload_len, mod, fec0, fec1, Sh, Sp, S);
     size_t nb = (size_t)frames_per_channel * S * (q->M + q->cp) + 64;     // + idle tail for the filter to ring out
-    return (nb + 7) / 8 * 8;
+    return (nb + 15) / 16 * 16;     // whole receiver tiles (MCRX_TILE blocks), so that the stream can be pushed as it is
 }
 
 extern "C" int mctx_hip_generate(mctx_hip_t q, void *d_iq, size_t nblocks, unsigned frames, unsigned payload_len,

@@ -6,9 +6,9 @@ serial in time.  So the stream is cut into sub-slabs of `sub_blocks` blocks that
 to the ranks -- sub-slab u to rank u % G -- and every round of G sub-slabs ends in one all-to-all
 that turns the time-sharded channelizer output into channel shards:
 
-    channelize:  out[g][tile][c][8]   g = destination rank, channel = g*Cg + c   (rank r, sub-slab c*G + r)
+    channelize:  out[g][tile][c][16]  g = destination rank, channel = g*Cg + c   (rank r, sub-slab c*G + r)
     all-to-all:  chunk g of rank r  ->  chunk r of rank g
-    sync:        chan[s][tile][c][8]  s = source rank  ==  [tile of the round][c][8], contiguous in time
+    sync:        chan[s][tile][c][16] s = source rank  ==  [tile of the round][c][16], contiguous in time
 
 Rounds are pipelined on three streams with rotating buffers:
 
@@ -21,7 +21,8 @@ inject a CPU stand-in so the orchestration runs under gloo without a GPU).
 """
 import numpy as np
 
-TILE = 8
+TILE = 16         # receive side: channel-rate samples per (channel, tile) granule = MCRX_TILE (one channel per 128-B line)
+TX_TILE = 8       # transmit side: granules of the frame generators' output (mctx_hip_traffic_tiles / synthesize_tiles)
 
 
 def shard_of(rank, world, num_channels):
@@ -204,7 +205,7 @@ class TxPipeline(object):
     def __init__(self, tx, traffic, rank, world, dist, num_channels, sub_blocks, lead_blocks=48, keep_blocks=16,
                  device=None, nbuf=3, gain=None):
         import torch
-        assert sub_blocks % TILE == 0 and lead_blocks % TILE == 0 and num_channels % world == 0
+        assert sub_blocks % TX_TILE == 0 and lead_blocks % TX_TILE == 0 and num_channels % world == 0
         assert lead_blocks >= 25 + keep_blocks, "the synthesis filter remembers 25 blocks"
         self.tx, self.traffic, self.rank, self.world, self.dist = tx, traffic, rank, world, dist
         self.N, self.K, self.Tc, self.lead, self.keep, self.nbuf = num_channels, 2 * num_channels, sub_blocks, lead_blocks, keep_blocks, nbuf
@@ -277,7 +278,7 @@ class TxPipeline(object):
 
 
 def pack_groups(blocks, world):
-    """[block][channel] -> the channelizer's grouped tile layout [g][tile][c][8] (numpy helper)."""
+    """[block][channel] -> the channelizer's grouped tile layout [g][tile][c][TILE] (numpy helper)."""
     nb, n = blocks.shape
     cg = n // world
     a = blocks.reshape(nb // TILE, TILE, world, cg)         # [tile][t][g][c]
@@ -285,6 +286,6 @@ def pack_groups(blocks, world):
 
 
 def unpack_shard(chan, world, cg):
-    """[s][tile][c][8] as received -> [c][time] for the rank's channel shard (numpy helper)."""
+    """[s][tile][c][TILE] as received -> [c][time] for the rank's channel shard (numpy helper)."""
     a = np.asarray(chan).reshape(-1, cg, TILE)              # [global tile][c][t]
     return np.ascontiguousarray(a.transpose(1, 0, 2)).reshape(cg, -1)

@@ -72,9 +72,9 @@ def test_gpu_sync_decodes_golden_frame(product, name):
     g = np.load(os.path.join(G, name + ".npz"))
     M, cp, tp = int(g["M"]), int(g["cp"]), int(g["taper"])
     rx_iq = g["rx"]
-    n = len(rx_iq) // 8 * 8
+    n = len(rx_iq) // product.TILE * product.TILE
     rx = product.multichannelrx(1, M, cp, tp)
-    d = torch.from_numpy(rx_iq[:n].copy()).cuda()         # one channel: [tile][1][8] is the stream itself
+    d = torch.from_numpy(rx_iq[:n].copy()).cuda()         # one channel: [tile][1][TILE] is the stream itself
     rx.sync(d, 0, n)
     rx.Flush()
     assert len(rx.frames) == 1
@@ -92,12 +92,13 @@ def test_gpu_multichannel_matches_golden(product):
     N, M, cp, tp = int(g["N"]), int(g["M"]), int(g["cp"]), int(g["taper"])
     rx = product.multichannelrx(N, M, cp, tp)
     iq = g["iq"]
-    nb = len(iq) // (2 * N)
-    d_x = torch.from_numpy(iq.copy()).cuda()
+    nb0 = len(iq) // (2 * N)
+    nb = -(-nb0 // product.TILE) * product.TILE              # whole tiles: zeros behind the recorded stream
+    d_x = torch.from_numpy(np.concatenate([iq, np.zeros((nb - nb0) * 2 * N, np.complex64)])).cuda()
     d_out = torch.zeros(nb * N, dtype=torch.complex64, device="cuda")
     rx.channelize(d_x, nb, 0, d_out)
     torch.cuda.synchronize()
-    got = product.tiles_to_channels(d_out, N).T
+    got = product.tiles_to_channels(d_out, N).T[:nb0]
     assert np.max(np.abs(got - g["chan"])) <= 1e-5 * np.max(np.abs(g["chan"]))
     rx.Execute(d_x)
     rx.Flush()

@@ -80,7 +80,7 @@ def test_config5_256_channels_receive_side_vs_oracle(oracle, product):
         ora.execute(x[i:i + (1 << 22)])
     assert len(ora.frames) == 2 * N and all(f.payload_valid for f in ora.frames)
     rx = product.multichannelrx(N, M, cp, 4, max_payload_len=1200)
-    n = int(iq.numel()) // (16 * N) * (16 * N)
+    n = int(iq.numel()) // (32 * N) * (32 * N)
     rx.Execute(iq[:n]); rx.Flush()
     worst = _compare(rx.frames, ora.frames)
     for f in rx.frames:
@@ -114,7 +114,7 @@ def test_config2_64_channels_m256_qam16_golay_resampled_vs_oracle(oracle, produc
     err_rs = float(np.max(np.abs(d_y.cpu().numpy()[:m] - o_y[:m])) / np.max(np.abs(o_y[:m])))
     assert err_rs <= REL, err_rs
     rx = product.multichannelrx(N, M, cp, 4, max_payload_len=1200)
-    n = int(d_y.numel()) // (16 * N) * (16 * N)
+    n = int(d_y.numel()) // (32 * N) * (32 * N)
     rx.Execute(d_y[:n].contiguous()); rx.Flush()
     worst = _compare(rx.frames, [f for f in ora.frames])
     for f in rx.frames:
@@ -135,12 +135,13 @@ def test_config3_eight_rank_round_robin_sharding_emulated(oracle, product):
     tx = product.multichanneltx(N, M, cp, 4)
     iq, sent = tx.generate(2, 400, seed=31)
     tx.close()
-    unit = 8 * world * rounds
+    unit = product.TILE * world * rounds
     T = int(iq.numel()) // K
     tot = (T + unit - 1) // unit * unit
     stream = torch.cat([iq, torch.zeros((tot - T) * K, dtype=torch.complex64, device="cuda")])
     Tc = tot // (world * rounds)
-    tiles = Tc // 8
+    TS = product.TILE
+    tiles = Tc // TS
     # reference: one handle over the whole stream
     one = product.multichannelrx(N, M, cp, 4, max_payload_len=400)
     one.Execute(stream); one.Flush()
@@ -155,17 +156,17 @@ def test_config3_eight_rank_round_robin_sharding_emulated(oracle, product):
         outs = []
         for r in range(world):
             u = c * world + r
-            o = torch.empty(world * tiles * cg * 8, dtype=torch.complex64, device="cuda")
+            o = torch.empty(world * tiles * cg * TS, dtype=torch.complex64, device="cuda")
             halo = stream[(u * Tc - 13) * K:u * Tc * K] if u > 0 else None
             rxs[r].channelize(stream[u * Tc * K:(u + 1) * Tc * K], Tc, u * Tc * K, o, groups=world, d_halo=halo)
             outs.append(o)
         torch.cuda.synchronize()
-        per = tiles * cg * 8
+        per = tiles * cg * TS
         for r in range(world):
             new = torch.cat([outs[s][r * per:(r + 1) * per] for s in range(world)])          # all_to_all_single
-            hist = prev[r][-H * cg * 8:] if prev[r] is not None else torch.zeros(H * cg * 8, dtype=torch.complex64, device="cuda")
+            hist = prev[r][-H * cg * TS:] if prev[r] is not None else torch.zeros(H * cg * TS, dtype=torch.complex64, device="cuda")
             buf = torch.cat([hist, new])
-            rxs[r].sync(buf, c * world * Tc - H * 8, H * 8 + world * Tc)
+            rxs[r].sync(buf, c * world * Tc - H * TS, H * TS + world * Tc)
             prev[r] = buf
         torch.cuda.synchronize()
     got = []

@@ -74,7 +74,7 @@ def test_config1_loopback_1e6_samples_matches_oracle(oracle, product):
 def test_single_synchronizer_other_schemes(oracle, product, M, cp, mod, fec0, fec1, plen):
     import torch
     iq, sent = traffic(oracle, M, cp, 4, 9, plen, mod, fec0, fec1, seed=M)
-    iq = np.concatenate([iq, np.zeros((-len(iq)) % 8, np.complex64)])
+    iq = np.concatenate([iq, np.zeros((-len(iq)) % product.TILE, np.complex64)])
     ora = oracle.FlexFrameSync(M, cp, 4)
     ora.execute(iq)
     rx = product.ofdmflexframesync(M, cp, 4)
@@ -93,11 +93,11 @@ def test_gpu_generator_to_gpu_synchronizer_and_reset(oracle, product):
     got = []
     rx.callback[0] = lambda h, hv, p, n, pv, st, ud: got.append((bytes(h), bytes(p), hv, pv)) or 0
     x = fg.frame(b"abcdefgh", b"payload one" * 20, gain=0.5)
-    half = len(x) // 2 // 8 * 8
+    half = len(x) // 2 // product.TILE * product.TILE
     rx.execute(x[:half]); rx.Flush()
     rx.reset()                                              # mid-frame reset: the first frame is lost (ofdmflexframesync_reset)
     y = fg.frame(b"12345678", b"payload two" * 30, gain=0.5)
-    rx.execute(np.concatenate([np.zeros(40, np.complex64), y, np.zeros(2 * (M + cp) + 8, np.complex64)])[: (40 + len(y) + 2 * (M + cp)) // 8 * 8])
+    rx.execute(np.concatenate([np.zeros(40, np.complex64), y, np.zeros(2 * (M + cp) + 16, np.complex64)])[: (40 + len(y) + 2 * (M + cp)) // 16 * 16])
     rx.Flush()
     assert got == [(b"12345678", b"payload two" * 30, 1, 1)]
     with pytest.raises(ValueError):

@@ -110,8 +110,9 @@ def test_channelizer_matches_oracle(oracle, product, N):
         d_g = torch.zeros_like(d_out)
         rx.channelize(d_x, nblocks, 0, d_g, groups=2)
         torch.cuda.synchronize()
-        g = d_g.cpu().numpy().reshape(2, nblocks // 8, N // 2, 8)
-        full = got.T.reshape(N, nblocks // 8, 8)                # [ch][tile][8]
+        T_ = product.TILE
+        g = d_g.cpu().numpy().reshape(2, nblocks // T_, N // 2, T_)
+        full = got.T.reshape(N, nblocks // T_, T_)              # [ch][tile][TILE]
         for gi in range(2):
             assert np.array_equal(g[gi].transpose(1, 0, 2), full[gi * (N // 2):(gi + 1) * (N // 2)])
     rx.close()
@@ -290,7 +291,7 @@ def test_resampled_front_end_feeds_the_receiver(oracle, product):
     d_y = rs.execute(torch.from_numpy(up).cuda())
     assert relerr(d_y.cpu().numpy()[:len(o_y)], o_y[:len(d_y)]) <= REL
     rx = product.multichannelrx(N, M, cp, 4)
-    n = int(d_y.numel()) // (16 * N) * (16 * N)
+    n = int(d_y.numel()) // (32 * N) * (32 * N)
     rx.Execute(d_y[:n].contiguous())
     rx.Flush()
     w = check_frames(rx.frames, ora.frames, rel=1.0)
@@ -305,7 +306,7 @@ def test_record_pool_overflow_is_counted_not_fatal(product):
     N, M, cp = 8, 64, 8
     tx = product.multichanneltx(N, M, cp, 4)
     iq, sent = tx.generate(3, 100, seed=5)
-    n = int(iq.numel()) // (16 * N) * (16 * N)
+    n = int(iq.numel()) // (32 * N) * (32 * N)
     rx = product.multichannelrx(N, M, cp, 4, max_frames=10)
     rx.Execute(iq[:n]); rx.Flush()
     assert len(rx.frames) == 10 and rx.frames_dropped() == 3 * N - 10
@@ -323,7 +324,7 @@ def test_wide_symbols_take_the_lean_path(oracle, product, M, cp, mod, fec1):
     N = 2
     tx = product.multichanneltx(N, M, cp, 4)
     iq, sent = tx.generate(2, 333, mod=mod, fec1=fec1, seed=9)
-    n = int(iq.numel()) // (16 * N) * (16 * N)
+    n = int(iq.numel()) // (32 * N) * (32 * N)
     x = iq[:n].cpu().numpy()
     ora = oracle.MultiChannelRx(N, M, cp, 4)
     ora.execute(x)
@@ -348,7 +349,7 @@ def test_two_rank_sharding_emulated_on_one_gpu(product):
     tx = product.multichanneltx(N, M, cp, 4)
     d_iq, sent = tx.generate(nf, plen, seed=21)
     T = int(d_iq.numel()) // K
-    assert T % 8 == 0
+    assert T % product.TILE == 0
     halo = d_iq[(T - 13) * K:].clone()
     rx, out = [], []
     for r in range(world):
@@ -386,7 +387,7 @@ def test_noisy_channel_same_decisions_as_oracle(oracle, product, snr_db, mod, fe
     nstd = sig * 10.0 ** (-snr_db / 20.0) / np.sqrt(2.0)
     n = np.arange(len(iq))
     x = (0.73 * iq * np.exp(1j * (2e-4 * n + 0.4)) + nstd * (rng.randn(len(iq)) + 1j * rng.randn(len(iq)))).astype(np.complex64)
-    x = x[:len(x) // (16 * N) * (16 * N)]
+    x = x[:len(x) // (32 * N) * (32 * N)]
     ora = oracle.MultiChannelRx(N, M, cp, 4)
     ora.execute(x)
     rx = product.multichannelrx(N, M, cp, 4, max_payload_len=300)
@@ -414,7 +415,7 @@ def test_convolutional_k7_rate_half_viterbi(oracle, product, mod, fec0, fec1, so
         sig = np.sqrt(np.mean(np.abs(x) ** 2)) * np.sqrt(2.0 * N / (2 * N))       # (per-channel SNR ~ wideband SNR + 3 dB: half the band is empty)
         nstd = sig * 10.0 ** (-snr_db / 20.0) / np.sqrt(2.0)
         x = (x + nstd * (rng.randn(len(x)) + 1j * rng.randn(len(x)))).astype(np.complex64)
-    x = x[:len(x) // (16 * N) * (16 * N)]
+    x = x[:len(x) // (32 * N) * (32 * N)]
     ora = oracle.MultiChannelRx(N, M, cp, 4, soft=bool(soft))
     ora.execute(x)
     assert len(ora.frames) >= 3 * N - 1
@@ -437,13 +438,13 @@ def test_convolutional_code_on_the_serial_paths(oracle, product, M, cp, step_blo
     kernel finishes the payload and decodes it) and a configuration outside the fast path (M = 48: general workers)."""
     N, plen = 4, 300
     iq, sent = oracle.synth_traffic(N, M, cp, 4, 3, payload_len=plen, fec1=oracle.FEC_CONV_V27, seed=12)
-    x = iq[:len(iq) // (16 * N) * (16 * N)]
+    x = iq[:len(iq) // (32 * N) * (32 * N)]
     ora = oracle.MultiChannelRx(N, M, cp, 4)
     ora.execute(x)
     assert len(ora.frames) == 3 * N and all(f.payload_valid for f in ora.frames)
     rx = product.multichannelrx(N, M, cp, 4, max_payload_len=plen)
     if step_blocks:
-        step = 2 * N * 8 * step_blocks
+        step = 2 * N * product.TILE * step_blocks
         for i in range(0, len(x), step):
             rx.Execute(x[i:i + step])
     else:
@@ -460,7 +461,7 @@ def test_convolutional_code_on_a_handle_sized_for_tiny_payloads(oracle, product)
     in use at the same time), every payload against the oracle."""
     N, M, cp, plen = 8, 64, 8, 8
     iq, sent = oracle.synth_traffic(N, M, cp, 4, 12, payload_len=plen, fec1=oracle.FEC_CONV_V27, seed=21)
-    x = iq[:len(iq) // (16 * N) * (16 * N)]
+    x = iq[:len(iq) // (32 * N) * (32 * N)]
     ora = oracle.MultiChannelRx(N, M, cp, 4)
     ora.execute(x)
     assert len(ora.frames) == 12 * N and all(f.payload_valid for f in ora.frames)
@@ -483,16 +484,16 @@ def test_speculation_survives_wrong_predictions(oracle, product):
     a, _ = tx.generate(3, 120, seed=31)
     b, _ = tx.generate(4, 431, seed=32)
     iq = torch.cat([a, b, a])
-    n = int(iq.numel()) // (16 * N) * (16 * N)
+    n = int(iq.numel()) // (32 * N) * (32 * N)
     x = iq[:n].cpu().numpy()
     ora = oracle.MultiChannelRx(N, M, cp, 4)
     ora.execute(x)
     assert len(ora.frames) >= (3 + 4 + 3) * N - N
-    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=500, batch_samples=16 * N * 40)
+    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=500, batch_samples=32 * N * 40)
     seen = 0
     for rep in range(3):
         rx.Reset() if rep else None
-        step = 16 * N * 97                              # launches cut frames at arbitrary places
+        step = 32 * N * 97                              # launches cut frames at arbitrary places
         for i in range(0, n, step):
             rx.Execute(iq[i:min(i + step, n)])
         rx.Flush()
@@ -512,13 +513,13 @@ def test_both_builds_of_the_rounds_scout_equal_the_oracle(oracle, product, monke
     N, M, cp = 8, 64, 8
     tx = product.multichanneltx(N, M, cp, 4)
     iq, _ = tx.generate(14, 200, seed=77)
-    n = int(iq.numel()) // (16 * N) * (16 * N)
+    n = int(iq.numel()) // (32 * N) * (32 * N)
     x = iq[:n].cpu().numpy()
     ora = oracle.MultiChannelRx(N, M, cp, 4)
     ora.execute(x)
     assert len(ora.frames) == 14 * N
     rx = product.multichannelrx(N, M, cp, 4, max_payload_len=200)
-    step = n // 3 // (16 * N) * (16 * N)
+    step = n // 3 // (32 * N) * (32 * N)
     for rep in range(2):                                    # the second pass runs on the first one's cadence
         for i in range(0, n, step):
             rx.Execute(iq[i:min(i + step, n)])
@@ -537,7 +538,7 @@ def test_bulk_host_execute_equals_device_path(product):
     N, M, cp = 8, 64, 8
     tx = product.multichanneltx(N, M, cp, 4)
     iq, sent = tx.generate(12, 300, seed=21)
-    n = int(iq.numel()) // (16 * N) * (16 * N)
+    n = int(iq.numel()) // (32 * N) * (32 * N)
     x = iq[:n].cpu().numpy()
     ref = product.multichannelrx(N, M, cp, 4, max_payload_len=300)
     ref.Execute(iq[:n]); ref.Flush()
@@ -547,11 +548,11 @@ def test_bulk_host_execute_equals_device_path(product):
     key = lambda f: (f.channel, f.end_sample, f.header, f.payload, f.payload_valid)
     want = sorted(map(key, ref.frames))
     rng = np.random.RandomState(4)
-    for cuts in ([n], [16 * N * 64 * 3 + 5, 7, 16 * N * 200 + 1], None):
+    for cuts in ([n], [32 * N * 64 * 3 + 5, 7, 32 * N * 200 + 1], None):
         rx = product.multichannelrx(N, M, cp, 4, max_payload_len=300)
         i = 0
         while i < n:
-            step = int(rng.randint(1, 16 * N * 300)) if cuts is None else (cuts.pop(0) if cuts else n)
+            step = int(rng.randint(1, 32 * N * 300)) if cuts is None else (cuts.pop(0) if cuts else n)
             rx.Execute(x[i:i + step]); i += step
         rx.Flush()
         assert sorted(map(key, rx.frames)) == want
@@ -601,7 +602,7 @@ def test_oversampled_front_end_full_chain(oracle, product, N, M, cp, mod, fec1, 
     iq, sent = tx.generate(2, plen, mod=mod, fec1=fec1, seed=N + M)
     tx.close()
     K = 2 * N
-    n = int(iq.numel()) // (16 * N) * (16 * N)
+    n = int(iq.numel()) // (32 * N) * (32 * N)
     x = iq[:n].cpu().numpy()
     ora = oracle.MultiChannelRx(N, M, cp, 4, front_end=1)
     for i in range(0, n, 1 << 22):
@@ -617,7 +618,7 @@ def test_oversampled_front_end_full_chain(oracle, product, N, M, cp, mod, fec1, 
     rng = np.random.RandomState(5)
     i = 0
     while i < n:
-        step = 16 * N * int(rng.randint(1, 40) if N <= 64 else rng.randint(200, 900))
+        step = 32 * N * int(rng.randint(1, 40) if N <= 64 else rng.randint(200, 900))
         rx.Execute(iq[i:min(i + step, n)]); i += step
     rx.Flush()
     check_frames(rx.frames, ora.frames)

@@ -46,7 +46,7 @@ def test_unchanged_reference_tx_app_feeds_both_receivers(oracle, product, tmp_pa
     N, M, cp, tp, P = 4, 64, 8, 4, 120
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "liquid-usrp_amd", "host"), "-s"])
     f = tmp_path / "tx.bin"
-    nsamp = 16 * N * 5000
+    nsamp = 32 * N * 5000
     env = dict(os.environ, MCTX_IQ_FILE=str(f), MCTX_IQ_SAMPLES=str(nsamp))
     out = subprocess.run([TXEXE, "-n", str(N), "-M", str(M), "-C", str(cp), "-T", str(tp), "-P", str(P), "-m", "qpsk",
                           "-c", "none", "-k", "h128", "-g", "0"], env=env, capture_output=True, text=True, timeout=120)
@@ -152,7 +152,7 @@ def test_unchanged_multichannel_txrx_app_hears_its_own_bursts(oracle, product, t
     nfail = len(re.findall(r"header:FAIL", out.stdout))
     assert len(sent) >= 1000 and not re.search(r"header:pass.*:FAIL", out.stdout)
     iq = np.fromfile(tee, np.complex64)
-    iq = iq[:len(iq) // (16 * N) * (16 * N)]
+    iq = iq[:len(iq) // (32 * N) * (32 * N)]
     orx = oracle.MultiChannelRx(N, 64, 8, 4)
     orx.execute(iq)
     want = [((f.header[0] << 8) | f.header[1], len(f.payload)) for f in orx.frames if f.header_valid]

@@ -25,7 +25,7 @@ def test_random_traffic_matches_oracle(oracle, product, seed):
             parts.append(x)
         tx.close()
         iq = torch.cat(parts)
-        n = int(iq.numel()) // (16 * N) * (16 * N)
+        n = int(iq.numel()) // (32 * N) * (32 * N)
         x = iq[:n].cpu().numpy()
         t = np.arange(n)
         snr = rng.uniform(22, 40)
@@ -33,14 +33,14 @@ def test_random_traffic_matches_oracle(oracle, product, seed):
         x = (x * np.exp(1j * (rng.uniform(-3e-4, 3e-4) * t + rng.uniform(0, 6.28))) +
              sig * 10 ** (-snr / 20) / np.sqrt(2) * (rng.randn(n) + 1j * rng.randn(n))).astype(np.complex64)
         o = oracle.MultiChannelRx(N, M, cp, 4); o.execute(x)
-        rx = product.multichannelrx(N, M, cp, 4, max_payload_len=640, batch_samples=16 * N * int(rng.randint(8, 200)))
+        rx = product.multichannelrx(N, M, cp, 4, max_payload_len=640, batch_samples=32 * N * int(rng.randint(8, 200)))
         xd = torch.from_numpy(x).cuda()
         seen = 0
         for rep in range(3):
             if rep: rx.Reset()
             i = 0
             while i < n:
-                step = 16 * N * int(rng.randint(1, 400))
+                step = 32 * N * int(rng.randint(1, 400))
                 rx.Execute(xd[i:min(i + step, n)]); i += step
             rx.Flush()
             got = rx.frames[seen:]; seen = len(rx.frames)

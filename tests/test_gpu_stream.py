@@ -171,7 +171,7 @@ def test_frames_straddling_pushes(oracle, product, defer):
     rng = np.random.RandomState(3)
     i = 0
     while i < nb:
-        step = 8 * int(rng.randint(40, 160))            # 320 .. 1280 blocks: a frame is ~2600 samples long
+        step = product.TILE * int(rng.randint(20, 80))   # 320 .. 1280 blocks: a frame is ~2600 samples long
         rx.Execute(iq[i * K:min(i + step, nb) * K]); i += step
     rx.Flush()
     by = lambda fr: {c: [_key(f) for f in fr if f.channel == c] for c in range(N)}
@@ -254,7 +254,7 @@ def test_lean_payload_workers_every_modem_in_one_slab(oracle, product, env, monk
         if all(pid[c] >= nf and tx.ready(c) for c in range(N)):
             idle += 1
     x = (np.concatenate(chunks) * np.float32(1.0 / N)).astype(np.complex64)
-    x = x[:len(x) // (16 * N) * (16 * N)]
+    x = x[:len(x) // (32 * N) * (32 * N)]
     ora = oracle.MultiChannelRx(N, M, cp, 4)
     ora.execute(x)
     assert len(ora.frames) == nf * N and all(f.payload_valid for f in ora.frames)
@@ -262,7 +262,7 @@ def test_lean_payload_workers_every_modem_in_one_slab(oracle, product, env, monk
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     rx = product.multichannelrx(N, M, cp, 4, max_payload_len=512)
-    half = len(x) // 2 // (16 * N) * (16 * N)
+    half = len(x) // 2 // (32 * N) * (32 * N)
     rx.Execute(x[:half]); rx.Execute(x[half:]); rx.Flush()       # (two pushes: frames of both classes straddle the cut)
     check_frames(rx.frames, ora.frames)
     rx.close()
@@ -300,16 +300,16 @@ def test_acquisition_policy_switches_with_the_traffic(oracle, product):
     L = M + cp
     tx = product.multichanneltx(N, M, cp, 4)
     a, _ = tx.generate(40, 90, seed=5)
-    b, _, _ = tx.generate_ragged(L * 2600 // 8 * 8, len_lo=10, len_hi=200, gap_max=3, long_every=6, long_max=30, seed=6)
+    b, _, _ = tx.generate_ragged(L * 2600 // 16 * 16, len_lo=10, len_hi=200, gap_max=3, long_every=6, long_max=30, seed=6)
     c, _ = tx.generate(40, 60, seed=7)
     tx.close()
     iq = torch.cat([a, b, c])
-    n = int(iq.numel()) // (16 * N) * (16 * N)
+    n = int(iq.numel()) // (32 * N) * (32 * N)
     x = iq[:n].cpu().numpy()
     ora = oracle.MultiChannelRx(N, M, cp, 4)
     ora.execute(x)
     rx = product.multichannelrx(N, M, cp, 4, max_payload_len=200)
-    step = 16 * N * 520                                  # 4160 blocks, ~ 3 frames per channel and push: 75 pushes
+    step = 32 * N * 260                                  # 4160 blocks, ~ 3 frames per channel and push: 75 pushes
     for i in range(0, n, step):
         rx.Execute(iq[i:min(i + step, n)])
     rx.Flush()

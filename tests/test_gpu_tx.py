@@ -86,7 +86,7 @@ def test_gpu_tx_to_gpu_rx_round_trip_stays_in_hbm(oracle, product):
     tx = product.multichanneltx(N, M, cp, 4)
     iq, sent = tx.generate(3, 400, seed=77)
     rx = product.multichannelrx(N, M, cp, 4)
-    n = int(iq.numel()) // (16 * N) * (16 * N)
+    n = int(iq.numel()) // (32 * N) * (32 * N)
     rx.Execute(iq[:n])
     rx.Flush()
     assert len(rx.frames) == 3 * N
@@ -198,7 +198,7 @@ def test_gpu_tx_streaming_feeds_gpu_rx(oracle, product):
         blocks.extend(tx.GenerateSamples().copy() for _ in range(L))
     iq = (np.concatenate(blocks) / np.float32(N)).astype(np.complex64)
     rx = product.multichannelrx(N, M, cp, 4)
-    n = len(iq) // (16 * N) * (16 * N)
+    n = len(iq) // (32 * N) * (32 * N)
     rx.Execute(torch.from_numpy(iq[:n]).cuda())
     rx.Flush()
     assert len(rx.frames) == len(sent) == 4 * N
@@ -247,7 +247,7 @@ def test_gpu_tx_ragged_traffic_matches_oracle_and_both_receivers_agree(oracle, p
     err = np.max(np.abs(got - ref)) / np.max(np.abs(ref))
     assert err <= 1e-5, err
     # ... and the two receivers decode it identically, every frame what was sent
-    x = got[:len(got) // (16 * N) * (16 * N)]
+    x = got[:len(got) // (32 * N) * (32 * N)]
     ora = oracle.MultiChannelRx(N, M, cp, 4)
     ora.execute(x)
     nsent = sum(len(s) for s in sent)
@@ -256,7 +256,7 @@ def test_gpu_tx_ragged_traffic_matches_oracle_and_both_receivers_agree(oracle, p
     good = [f for f in ora.frames if f.header_valid and f.payload_valid]
     assert len(good) >= nsent - N, (len(good), nsent)
     rx = product.multichannelrx(N, M, cp, 4, max_payload_len=300)
-    step = 16 * N * 61
+    step = 32 * N * 61
     for i in range(0, len(x), step):
         rx.Execute(x[i:i + step])
     rx.Flush()

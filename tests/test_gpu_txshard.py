@@ -92,8 +92,9 @@ def test_config5_full_duplex_eight_rank_emulation(product):
         c0, cnt = sharding.shard_of(r, world, N)
         rxs.append(product.multichannelrx(N, M, cp, 4, max_payload_len=plen, channel_first=c0, channel_count=cnt))
     H = rxs[0].hist_tiles
-    tiles = Tc // 8
-    per = tiles * cg * 8
+    TS = product.TILE
+    tiles = Tc // TS
+    per = tiles * cg * TS
     prev = [None] * world
     it = iter(slabs)
     for c in range(rounds):
@@ -109,9 +110,9 @@ def test_config5_full_duplex_eight_rank_emulation(product):
         torch.cuda.synchronize()
         for r in range(world):
             new = torch.cat([outs[s][r * per:(r + 1) * per] for s in range(world)])
-            hist = prev[r][-H * cg * 8:] if prev[r] is not None else torch.zeros(H * cg * 8, dtype=torch.complex64, device="cuda")
+            hist = prev[r][-H * cg * TS:] if prev[r] is not None else torch.zeros(H * cg * TS, dtype=torch.complex64, device="cuda")
             buf = torch.cat([hist, new])
-            rxs[r].sync(buf, c * world * Tc - H * 8, H * 8 + world * Tc)
+            rxs[r].sync(buf, c * world * Tc - H * TS, H * TS + world * Tc)
             prev[r] = buf
         torch.cuda.synchronize()
     got = []

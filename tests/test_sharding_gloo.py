@@ -68,21 +68,22 @@ class StreamingOracleBackend(OracleBackend):
     def sync(self, chan, first_sample, nsamples, stream=None):
         from liquid_usrp_amd import sharding
         c0, cg = sharding.shard_of(self.rank, self.world, self.N)
-        streams = np.ascontiguousarray(chan.numpy().view(np.complex64).reshape(-1, cg, 8).transpose(1, 0, 2)).reshape(cg, -1)
+        streams = np.ascontiguousarray(chan.numpy().view(np.complex64).reshape(-1, cg, sharding.TILE).transpose(1, 0, 2)).reshape(cg, -1)
         assert streams.shape == (cg, nsamples)
-        assert first_sample + self.hist_tiles * 8 == self.consumed            # new samples continue the stream
+        TS = sharding.TILE
+        assert first_sample + self.hist_tiles * TS == self.consumed            # new samples continue the stream
         if self.fs is None:
             self.fs = [self.O.FlexFrameSync(self.M, self.cp, self.taper) for _ in range(cg)]
         if self.consumed:                                                     # the history really is the previous tail
-            assert np.array_equal(streams[:, :self.hist_tiles * 8], self.tail)
-        new = streams[:, self.hist_tiles * 8:]
+            assert np.array_equal(streams[:, :self.hist_tiles * TS], self.tail)
+        new = streams[:, self.hist_tiles * TS:]
         for c in range(cg):
             n0 = len(self.fs[c].frames)
             self.fs[c].execute(new[c])
             for f in self.fs[c].frames[n0:]:
                 f.channel = c0 + c
                 self.frames.append(f)
-        self.tail = new[:, -self.hist_tiles * 8:].copy()
+        self.tail = new[:, -self.hist_tiles * TS:].copy()
         self.consumed += new.shape[1]
         self.launch += 1
         return self.launch - 1
@@ -104,12 +105,12 @@ def _worker(rank, world, port, q):
     N, M, cp, tp = 4, 64, 8, 4
     K = 2 * N
     iq, sent = O.synth_traffic(N, M, cp, tp, 4, payload_len=60, seed=99)
-    nb = len(iq) // K // (8 * world) * (8 * world)
+    nb = len(iq) // K // (sharding.TILE * world) * (sharding.TILE * world)
     iq = iq[:nb * K]
     T = nb // world
     mine = torch.from_numpy(iq[rank * T * K:(rank + 1) * T * K].copy().view(np.float32))
     cg = N // world
-    out = torch.zeros(world * (T // 8) * cg * 8 * 2, dtype=torch.float32)
+    out = torch.zeros(world * T * cg * 2, dtype=torch.float32)
     recv = torch.zeros_like(out)
     be = OracleBackend(O, N, M, cp, tp, iq, rank, world)
     sharding.step(be, mine, T, rank, world, dist, out, recv)
@@ -132,7 +133,7 @@ def _pipeline_worker(rank, world, port, q, rounds, nbuf=3):
     N, M, cp, tp = 4, 64, 8, 4
     K = 2 * N
     iq, sent = O.synth_traffic(N, M, cp, tp, 4, payload_len=60, seed=99)
-    unit = 8 * world * rounds
+    unit = 16 * world * rounds
     nb = len(iq) // K // unit * unit
     iq = iq[:nb * K]
     Tc = nb // (world * rounds)
@@ -167,7 +168,7 @@ def test_round_robin_pipeline_reproduces_single_process_result(oracle, world, ro
         assert p.exitcode == 0
     N, M, cp, tp = 4, 64, 8, 4
     iq, sent = oracle.synth_traffic(N, M, cp, tp, 4, payload_len=60, seed=99)
-    unit = 8 * world * rounds
+    unit = 16 * world * rounds
     nb = len(iq) // (2 * N) // unit * unit
     ref = oracle.MultiChannelRx(N, M, cp, tp)
     ref.execute(iq[:nb * 2 * N])
@@ -194,7 +195,7 @@ def test_two_rank_exchange_reproduces_single_process_result(oracle):
     # single-process reference over the same stream
     N, M, cp, tp = 4, 64, 8, 4
     iq, sent = oracle.synth_traffic(N, M, cp, tp, 4, payload_len=60, seed=99)
-    nb = len(iq) // (2 * N) // 16 * 16
+    nb = len(iq) // (2 * N) // 32 * 32
     ref = oracle.MultiChannelRx(N, M, cp, tp)
     ref.execute(iq[:nb * 2 * N])
     want = sorted((f.channel, f.header, f.payload, int(f.payload_valid)) for f in ref.frames)
@@ -210,7 +211,7 @@ def test_layout_helpers_roundtrip(product):
     blocks = (rng.randn(32, 8) + 1j * rng.randn(32, 8)).astype(np.complex64)
     for world in (1, 2, 4):
         g = sharding.pack_groups(blocks, world)
-        assert g.shape == (world, 4, 8 // world, 8)
+        assert g.shape == (world, 32 // sharding.TILE, 8 // world, sharding.TILE)
         for r in range(world):
             c0, cg = sharding.shard_of(r, world, 8)
             # a rank that received only its own chunk from a single slab sees its channels in time order
