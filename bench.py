@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-harvest", action="store_true")
     ap.add_argument("--no-aperiodic", action="store_true", help="skip the ragged-traffic leg (value_aperiodic)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE.json configurations (the `configs` block)")
+    ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed region of --steps steps: value = median, value_min / value_max beside it")
     ap.add_argument("--aperiodic-steps", type=int, default=20)
     ap.add_argument("--slab-blocks", type=int, default=0)
     ap.add_argument("--chunk-blocks", type=int, default=0, help="split every push into sub-slabs of this many blocks")
@@ -137,10 +139,6 @@ def main():
 
     max_frames = N * args.frames + 64 if (world == 1 and not args.pipeline) else cg * args.frames * nslab + 64
     cfg = dict(max_payload_len=max(args.payload, 64), max_frames=max_frames)
-    if world > 1:
-        # a rank's round holds `world` sub-slabs of time, i.e. about that many bursts with a gap in front of each: one acquisition round per
-        # burst from the first launch on instead of after the policy's ~50 launches of finding out
-        os.environ.setdefault("MCRX_EXTRA_ROUNDS", str(min(12, world + 4)))
     if world > 1 or args.pipeline:
         # rounds cut the stream anywhere: a frame that straddles two rounds is acquired again by the next round (whole, by
         # the parallel path) instead of being walked symbol by symbol -- the history in front of every round covers a frame
@@ -233,11 +231,21 @@ def main():
     rx.spec_stats(reset=True)
     if pipe is not None:
         pipe.time_exchange(True) if callable(getattr(pipe, "time_exchange", None)) else setattr(pipe, "time_exchange", True)
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    # the timed region, --reps times over: every repetition is exactly --steps steps between two fences;
+    # value = the median repetition, the spread is reported beside it
+    rep_s = []
+    for r in range(max(1, args.reps)):
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step()
+        fence()
+        rep_s.append(time.perf_counter() - t0)
+    if world > 1:                                      # a repetition takes as long as its slowest rank
+        tt = torch.tensor(rep_s, dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        rep_s = [float(v) for v in tt.tolist()]
+    elapsed = float(np.median(rep_s))
+    nsteps_timed = args.steps * len(rep_s)
     xchg = None
     if pipe is not None:
         pipe.time_exchange(False) if callable(getattr(pipe, "time_exchange", None)) else setattr(pipe, "time_exchange", False)
@@ -248,17 +256,13 @@ def main():
                     "GBps_out_of_each_rank": round(sent / (xms / xn * 1e-3) / 1e9, 2) if world > 1 else None,
                     "what": ("RCCL, HIP events on the exchange stream of rank 0 (%s)" % ("grouped ncclSend/ncclRecv behind the C-ABI" if use_c else "torch.distributed all_to_all_single")) if world > 1
                             else "local copy standing in for the exchange (one GPU)"}
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
     walked, adopted = rx.spec_stats()
     ovl_stats = rx.kernel_stats()
 
     # ---- verification (untimed): one more step of the continuing stream, harvested; every frame of the step
     # decoded, valid and equal to what the transmitter sent
     rx.Flush(); rx.frames.clear()
-    step_first = int(args.warmup + args.steps) * period_blocks           # channel-rate sample index where this step starts
+    step_first = int(args.warmup + nsteps_timed) * period_blocks         # channel-rate sample index where this step starts
     step(harvest_rx=rx)
     rx.Flush()
     nfr, n_ok = len(rx.frames), 0
@@ -279,6 +283,9 @@ def main():
     aper = None
     if world == 1 and not args.no_aperiodic and not args.pipeline:
         aper = aperiodic_leg(prod, N, M, cp, taper, slab_blocks[:args.slabs], K, args, torch, dev)
+    cfgs = None
+    if world == 1 and not args.no_configs and not args.pipeline:
+        cfgs = configs_block(prod, torch, dev, args)
     if rank == 0:
         per = {k: v[0] / max(v[1], 1) for k, v in ser_stats.items()}          # mean ms per launch, kernel alone
         ovl = {k: v[0] / max(v[1], 1) for k, v in ovl_stats.items()}
@@ -308,6 +315,8 @@ def main():
         out = {
             "metric": "complex Msamples/s through multichannelrx",
             "value": round(value, 3), "unit": "Msamples/s",
+            "value_min": round(samples_per_step * args.steps / max(rep_s) / 1e6, 3), "value_max": round(samples_per_step * args.steps / min(rep_s) / 1e6, 3),
+            "repetitions": len(rep_s), "timing": "median of %d repetitions of %d steps, each between two fences (barrier + device synchronize)" % (len(rep_s), args.steps),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -319,6 +328,7 @@ def main():
                        "channels": N, "subcarriers": M, "samples_per_step": samples_per_step,
                        "receiver": "serial (one stream)" if args.serial else "pipelined (3 internal streams, 3 buffer sets)",
                        "multi_gpu_path": None if pipe is None else ("C-ABI pipeline (mcrx_hip_pipeline_*)" if use_c else "sharding.Pipeline (torch)"),
+                       "receiver_hints_from_the_benchmark": "none (no MCRX_* environment is set by this script)",
                        "parallelism": ("round-robin time-sharded channelizer -> all-to-all -> %d channels/GPU, %d rounds per step, "
                                        "exchange overlapped" % (cg, args.rounds)) if world > 1 else "single GPU"},
             "spec_hit_rate": round(adopted / total, 4) if total else None,
@@ -349,6 +359,8 @@ def main():
         if aper:
             out.update(aper)
             out["value_aperiodic_over_value"] = round(aper["value_aperiodic"] / value, 4)
+        if cfgs:
+            out["configs"] = cfgs
         if not args.no_cpu and world == 1:                     # the CPU leg is reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(ora, prod, slabs[0] if slabs is not None else slabs_keep0, N, M, cp, taper, args.cpu_reps, cfg)
     rx.close()
@@ -359,6 +371,107 @@ def main():
         print(json.dumps(out))
     if not verified:
         sys.exit("rank %d: verification failed (%d/%d frames, %d ok)" % (rank, nfr, expect, n_ok))
+
+
+def config_leg(prod, torch, dev, N, M, cp, frames, plen, mod, fec1, resamp, steps, reps, what):
+    """One of the other BASELINE.json configurations as a continuous stream through ONE un-restarted receiver, like `value`:
+    two different slabs (seeds, idle tails) pushed alternately, frames dropped on the device, then one more step harvested and
+    every frame checked against what was sent.  resamp: the slabs are 2x oversampled (zero stuffing + half-band low-pass, made
+    once, untimed) and go through msresamp(0.5) in front of the receiver (src/multichannel_rx.cc:129-138); the unit is then a
+    sample entering the resampler, 20 algorithmic bytes each (8 read + 4 written by the resampler, 16 / 2 behind it)."""
+    K, taper = 2 * N, 4
+    tx = prod.multichanneltx(N, M, cp, taper)
+    base = int(prod.lib().mctx_hip_blocks_for(tx._h, frames, plen, mod, 1, fec1))
+    slabs, sents = [], []
+    for i in range(2):
+        d, sent = tx.generate(frames, plen, mod=mod, fec1=fec1, seed=0xBEEF + 7919 * i, nblocks=base + (0, 48)[i], device=dev)
+        slabs.append(d); sents.append(frame_index(sent))
+    torch.cuda.synchronize()
+    tx.close()
+    inputs, rs = slabs, None
+    if resamp:
+        from scipy.signal import firwin
+        h = torch.tensor(2.0 * firwin(63, 0.5), dtype=torch.float32, device=dev)
+        inputs = []
+        for d in slabs:
+            up = torch.zeros(2 * d.numel(), dtype=torch.complex64, device=dev); up[::2] = d
+            re = torch.nn.functional.conv1d(torch.view_as_real(up).T.reshape(2, 1, -1), h.view(1, 1, -1), padding=31)
+            inputs.append(torch.view_as_complex(re.reshape(2, -1).T.contiguous()))
+        del up, re
+        rs = prod.msresamp(0.5, 60.0)
+    rx = prod.multichannelrx(N, M, cp, taper, max_payload_len=plen, max_frames=N * frames + 64)
+    tile = prod.TILE * K
+
+    def step(keep=False):
+        for x in inputs:
+            y = x
+            if rs is not None:
+                y = rs.execute(x)
+                assert int(y.numel()) % tile == 0, "the decimated slab is not whole tiles (%d samples)" % int(y.numel())
+            rx.Execute(y)
+            rx.Poll() if keep else rx.Discard()
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    rx.kernel_stats(reset=True); rx.spec_stats(reset=True)
+    rep_s = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        rep_s.append(time.perf_counter() - t0)
+    walked, adopted = rx.spec_stats()
+    ovl = {k: round(v[0] / max(v[1], 1), 4) for k, v in rx.kernel_stats().items()}
+    rx.Flush(); rx.frames.clear()
+    step(keep=True); rx.Flush()
+    nfr = len(rx.frames)
+    ok = sum(1 for f in rx.frames if f.header_valid and f.payload_valid and
+             any(sn[f.channel].get((f.header[0] << 8) | f.header[1]) == (f.header, f.payload) for sn in sents))
+    rx.close()
+    if rs is not None:
+        rs.close()
+    n_in = sum(int(x.numel()) for x in inputs)
+    bytes_per = 20.0 if resamp else 16.0
+    med = float(np.median(rep_s))
+    val = n_in * steps / med / 1e6
+    tot = walked + adopted
+    return {"workload": what, "value": round(val, 1), "unit": "Msamples/s" + (" entering the resampler" if resamp else ""),
+            "value_min": round(n_in * steps / max(rep_s) / 1e6, 1), "value_max": round(n_in * steps / min(rep_s) / 1e6, 1),
+            "repetitions": reps, "steps": steps, "samples_per_step": n_in, "ms_per_step": round(med / steps * 1e3, 4),
+            "algorithmic_bytes_per_sample": bytes_per, "frac_of_roofline": round(val * 1e6 * bytes_per / (HBM_PEAK_GBS * 1e9), 5),
+            "frames_acquired": {"by_scout_walk": walked, "adopted_from_segment_waves": adopted, "walked_share": round(walked / tot, 5) if tot else None},
+            "kernels_ms_overlapped": ovl,
+            "verified": {"frames": nfr, "expected": 2 * N * frames, "bit_exact_payloads": ok, "ok": nfr == 2 * N * frames and ok == nfr}}
+
+
+def configs_block(prod, torch, dev, args):
+    """BASELINE.json configs[1], configs[1] with the K = 7 rate-1/2 code, configs[2] and configs[4] on one GPU (configs[3] is the
+    headline, configs[0] a CPU plumbing case covered by tests/test_gpu_baseline_shapes.py)."""
+    out = {}
+    legs = (("8ch", 8, 64, 8, 100, 1200, 40, 6, False, "configs[1]: 8-ch multichannelrx, M=64 cp=8 QPSK CRC32+Hamming128 1200B payloads, 100 frames/ch/slab"),
+            ("8ch_v27", 8, 64, 8, 100, 1200, 40, 11, False, "configs[1] with the K=7 r=1/2 convolutional code (soft Viterbi) as the outer code"),
+            ("64ch_m256_qam16_resamp", 64, 256, 32, 32, 1200, 27, 7, True,
+             "configs[2]: 64-ch multichannelrx, M=256 cp=32 QAM16 CRC32+Golay(24,12) 1200B payloads, 32 frames/ch/slab, msresamp(0.5) front end"))
+    for name, N, M, cp, fr, pl, mod, fec1, rsmp, what in legs:
+        try:
+            out[name] = config_leg(prod, torch, dev, N, M, cp, fr, pl, mod, fec1, rsmp, steps=6, reps=3, what=what)
+        except Exception as e:                                   # a leg that fails says so in the line; the headline stands
+            out[name] = {"workload": what, "error": repr(e), "verified": {"ok": False}}
+        torch.cuda.empty_cache()
+    try:
+        import bench_duplex
+        d, ok, msg = bench_duplex.measure(prod, torch, dev, 0, 1, None, steps=8, warmup=3)
+        out["256ch_duplex_one_gpu"] = {"workload": "configs[4] on ONE GPU: " + d["config"]["workload"], "value": d["value"],
+                                       "unit": "Msamples/s transmitted and received", "ms_per_step": d["ms_per_step"], "steps": 8,
+                                       "algorithmic_bytes_per_sample": 28.0,
+                                       "frac_of_roofline": round(d["value"] * 1e6 * 28.0 / (HBM_PEAK_GBS * 1e9), 5),
+                                       "verified": d["verified"],
+                                       "note": "28 B = 16 (receive) + 12 (transmit: 4 B of channel-rate granules read + 8 B written per wideband sample)"}
+    except Exception as e:
+        out["256ch_duplex_one_gpu"] = {"error": repr(e), "verified": {"ok": False}}
+    torch.cuda.empty_cache()
+    return out
 
 
 def aperiodic_leg(prod, N, M, cp, taper, slab_blocks, K, args, torch, dev):
@@ -511,15 +624,19 @@ def cpu_baseline(ora, prod, d_slab, N, M, cp, taper, reps, cfg):
     """The CPU oracle (a port: liquid-dsp itself is unavailable) on the first slab, one thread (the reference's
     multichannelrx is single threaded: lib/multichannelrx.cc:184); then its frames against the GPU's."""
     base = d_slab.cpu().numpy()
-    rx = ora.MultiChannelRx(N, M, cp, taper, count_only=True)      # frames are counted in C: only the receiver is timed
+    # one single-thread pass serves the timing AND the parity comparison below: it keeps its frames (a Python callback per
+    # frame -- 8192 of them in ~10 s of receiver time, well under 1 % of it)
+    rx = ora.MultiChannelRx(N, M, cp, taper)
     chunk = 1 << 22
     t0 = time.perf_counter()
     for _ in range(reps):
+        if _:
+            rx.frames.clear(); rx.reset()
         for i in range(0, len(base), chunk):
             rx.execute(base[i:i + chunk])
     dt = time.perf_counter() - t0
     n = len(base) * reps
-    ok = rx.counts()[2]
+    ok = sum(1 for f in rx.frames if f.payload_valid)
     out = {"value": round(n / dt / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": "port",
            "sample": "the benchmark's first slab x%d (%d samples, %d frames decoded), oracle "
                      "multichannelrx, single thread" % (reps, n, ok),
@@ -540,9 +657,7 @@ def cpu_baseline(ora, prod, d_slab, N, M, cp, taper, reps, cfg):
     try:
         # ---- parity on the benchmark's own slab (untimed): the oracle keeping its frames vs a fresh GPU receiver
         # (cold start, like the oracle)
-        rx2 = ora.MultiChannelRx(N, M, cp, taper)
-        for i in range(0, len(base), chunk):
-            rx2.execute(base[i:i + chunk])
+        rx2 = rx                                                # (the timed pass above kept its frames)
         g = prod.multichannelrx(N, M, cp, taper, **cfg)
         g.Execute(d_slab); g.Flush()
         key = lambda f: (f.channel, f.header)

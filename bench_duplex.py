@@ -45,9 +45,21 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=dev)
-    if world > 1:                                            # about `world` bursts per round on every channel: see bench.py / DESIGN.md section 5
-        os.environ.setdefault("MCRX_EXTRA_ROUNDS", str(min(12, world + 4)))
     prod = load_product()
+    out, ok, msg = measure(prod, torch, dev, rank, world, dist, args.channels, args.payload, args.sub_blocks, args.steps, args.warmup)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        sys.exit(msg)
+
+
+def measure(prod, torch, dev, rank, world, dist, channels=256, payload=1200, sub_blocks=262144, steps=20, warmup=5):
+    """One full-duplex measurement on the ranks that exist (world = 1: everything on one GPU).  Returns (JSON-able dict, ok, message)."""
+    import argparse
+    args = argparse.Namespace(channels=channels, payload=payload, sub_blocks=sub_blocks, steps=steps, warmup=warmup)
     from liquid_usrp_amd import sharding
     N, M, cp, taper, Tc = args.channels, 64, 8, 4, args.sub_blocks
     K = 2 * N
@@ -109,8 +121,9 @@ def main():
     lo = cg * (world * Tc // per_frame - 1)
     ok = nfr >= lo and n_ok == nfr
     value = world * Tc * K * args.steps / elapsed / 1e6
-    if rank == 0:
-        print(json.dumps({
+    out = None
+    if True:
+        out = ({
             "metric": "complex Msamples/s transmitted and received by a full-duplex multichanneltxrx", "value": round(value, 3),
             "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -122,13 +135,9 @@ def main():
                        "parallelism": ("TX: %d channels/GPU -> all-to-all -> time-sharded synthesis; RX: time-sharded channelizer -> "
                                        "all-to-all -> %d channels/GPU" % (cg, cg)) if world > 1 else "single GPU"},
             "verified": {"frames": nfr, "at_least": lo, "bit_exact_payloads": n_ok, "ok": ok, "note": "the round after the timed region"},
-            "setup_s": {"frame_assembly_and_modulation": round(setup, 2), "frames_per_channel": frames}}))
+            "setup_s": {"frame_assembly_and_modulation": round(setup, 2), "frames_per_channel": frames}})
     rx.close(); tr.close(); tx.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-    if not ok:
-        sys.exit("rank %d: verification failed (%d frames, at least %d expected, %d ok)" % (rank, nfr, lo, n_ok))
+    return out, ok, "rank %d: verification failed (%d frames, at least %d expected, %d ok)" % (rank, nfr, lo, n_ok)
 
 
 if __name__ == "__main__":

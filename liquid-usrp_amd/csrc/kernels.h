@@ -92,7 +92,7 @@ struct ChanState {
     int32_t header_valid;
     uint32_t hw[4];             // decoded header bytes 0..13, little-endian words
     // frame cadence seen so far (speculation only; never part of the synchronizer's decisions)
-    uint32_t period_hint;       // distance between the last two consecutive post-frame states (0: none yet)
+    uint32_t period_hint;       // distance between the last two consecutive post-frame states (0: none yet): where segment waves look for their first frame
     int64_t last_fresh;         // the most recent post-frame state's position
     uint32_t burst_hint;        // frames a round adopted in a row before it met a state nobody predicted (0: not learnt): how far a
                                 // stopped scout predicts when pushes hold several bursts (SyncArgs::burst_limit)
@@ -118,21 +118,28 @@ struct PayloadJob {
     uint64_t syms_off;          // ... and framesyms in the symbol arena (~0: no room, frame dropped)
 };
 
-// Frame-level speculation in the scout.  After a frame's last symbol liquid leaves the synchronizer in one
-// fixed state (SEEK, timer = M+cp, everything else reset), so a frame that starts where another one ended can be
-// acquired by an independent wave -- if the position is known.  Positions are predicted from the frame cadence:
-// the state the previous launch ended in and its cadence continued into this buffer, and -- because an idle gap
-// or a new burst breaks that cadence -- re-anchored inside the launch: the acquisition runs in rounds
-// (speculative waves, then scouts), and in all but the last round a scout that had to acquire a frame itself
-// stops right behind it and predicts the following frames from there.  A speculative wave per prediction
-// runs detection .. header decode from the fresh state and parks the hand-off in a SpecSlot; the per-channel
-// scout adopts a slot when it arrives at exactly that position in exactly that state, else walks on as before.
-#define MCRX_SPEC_MAX 128
+// Segment-parallel acquisition (round 4; replaces the cadence predictions of rounds 1-3).  A channel's synchronizer is a
+// chain by information -- where frame k+1 is looked for depends on where frame k ended, which is only known once its header
+// is decoded -- so one wave per channel is a serial walk over every frame of the push, whatever the traffic.  But after a
+// frame's last symbol liquid leaves the synchronizer in one fixed state (SEEK, timer = M+cp, everything else reset), so the
+// walk can be cut: the channel's stretch of the push is divided into `nseg` segments and each gets a wave (sync_seg_kernel)
+// that runs the state machine's own code through its segment, frame after frame, parking every frame's hand-off in a
+// SpecSlot KEYED BY THE EXACT STATE THE FRAME WAS ACQUIRED FROM.  Segment 0 starts from the channel's real state; the others
+// start in a fresh SEEK state just in front of the first preamble a cheap half-symbol autocorrelation finds in their segment
+// (their first frame is acquired from a state the real chain never stands in -- its slot has no key -- but it ends where the
+// real chain's does whenever both lock to the same symbol timing, and from there on the wave IS the real chain); every wave
+// runs on until it has acquired the first frame that begins in the NEXT segment, which links it to that segment's wave.
+// The per-channel scout then only hops from slot to slot: a slot is used iff its key equals the scout's state bit for bit, and
+// then the segment wave has executed exactly the events the scout would have, so the result is the sequential one; where no
+// slot matches (a timing that locked differently, an invalid header, an idle stretch) the scout walks on by itself --
+// slower, never different.  Nothing depends on the traffic having a cadence.
+#define MCRX_SPEC_MAX 256
 struct SpecSlot {
-    int64_t start;              // the SEEK state it started from: next sample | timer << 48 (spec_key)
-    int64_t t_last;             // event index of the frame's last payload symbol
-    int32_t status;             // 1: frame acquired and handed off (job valid), 0: nothing usable
-    uint32_t pad;
+    int64_t start;              // the state it was acquired from: next sample | timer << 48 | state << 61 (spec_key); -1: none
+    int64_t t_last;             // status 1: event index of the frame's last payload symbol; status 2: the SEEK position the frame was detected from
+    int32_t status;             // 1: frame acquired and handed off (job valid); 2: frame acquired, but its payload runs past the end of the
+                                //    buffer and the next push still holds its beginning: the scout goes back to (t_last, pad) -- deferred; 0: nothing usable
+    uint32_t pad;               // status 2: the timer of that SEEK state
     PayloadJob job;
 };
 
@@ -182,7 +189,16 @@ struct SyncArgs {
     // speculation (see SpecSlot)
     SpecSlot *spec; float2 *spec_R;      // [nch][MCRX_SPEC_MAX], [nch][MCRX_SPEC_MAX][M]
     int64_t *pred; uint32_t *pred_n;     // predicted fresh-state positions for the next launch: [nch][MCRX_SPEC_MAX], [nch]
-    uint32_t spec_cap;                   // slots per channel the speculative kernel fills in this launch (0: off)
+    uint32_t spec_cap;                   // slots per channel the segment waves fill in this launch = nseg * (slots per wave) (0: off)
+    uint32_t nseg;                       // segment waves per channel
+    // The two wasted acquisitions of a segment (its first frame from an arbitrary state, the frame that links it to the next
+    // segment) disappear where the traffic HAS a cadence: phase 1 (one wave per channel) acquires the first frame of the push from
+    // the channel's real state and leaves the position it ends at in anchor[ch]; phase 2 starts segment g in the exact fresh
+    // state at the first point of anchor + n * period_hint inside it -- if the half-symbol autocorrelation finds a preamble right
+    // behind that point -- and a wave whose chain arrives exactly at the next segment's validated start stops there.  A wrong or
+    // missing prediction costs nothing but the two acquisitions again (the coarse start); the results never depend on it.
+    int seg_phase;                       // 1: first frame from the entry state only (grid = channels); 2: the rest; 0: one launch, no cadence
+    int64_t *anchor;                     // [nch] where phase 1's frame ended + 1 (-1: it did not hand a frame off)
     uint32_t *spec_hint;                 // host-mapped word: largest prediction count, sizes the next launch's grid
     uint32_t *walk_hint;                 // host-mapped word: frames the scouts had to acquire themselves so far (the host adds a full-width round while it moves)
     uint32_t *hint;             // host-mapped word: longest coded frame (bytes) among this launch's jobs
@@ -211,7 +227,7 @@ hipError_t sync_launch_tail(const SyncArgs &a, hipStream_t st);      // lean con
 hipError_t ilmap_build_launch(const uint32_t *d_lens, const uint32_t *d_offs, uint32_t nlen, uint8_t *d_lo, uint8_t *d_hi, uint16_t *d_map, hipStream_t st);
 hipError_t sync_launch_walk(const SyncArgs &a, hipStream_t st);      // the lean scout built without a register budget: for streams it has to walk by itself
 hipError_t sync_launch_lean(const SyncArgs &a, hipStream_t st);      // lean scout: acquisition + header + hand-off, one wave per channel
-hipError_t sync_launch_spec(const SyncArgs &a, hipStream_t st);      // speculative acquisition: one wave per (channel, predicted position)
+hipError_t sync_launch_spec(const SyncArgs &a, hipStream_t st);      // segment-parallel acquisition: one wave per (channel, segment)
 // stage 0: record placement (one workgroup), 1: payload workers (one wave per handed-off frame),
 // 2: packet decode (one workgroup per frame; only after the lean workers -- the general ones decode in place)
 hipError_t sync_launch_payload(const SyncArgs &a, int stage, hipStream_t st);

@@ -176,21 +176,18 @@ struct mcrx_hip_s {
 
     hipEvent_t ev_ready[MCRX_SLOTS] = {}, ev_scout[MCRX_SLOTS] = {}, ev_done[MCRX_SLOTS] = {}, ev_in = nullptr, ev_consumed = nullptr, ev_tmp[3] = {};
     int last_slot = -1; size_t last_ntiles = 0;     // where the synchronizer history (tail of the previous launch) sits
-    SpecSlot *d_spec = nullptr; float2 *d_spec_R = nullptr; int64_t *d_pred = nullptr; uint32_t *d_pred_n = nullptr;
+    SpecSlot *d_spec = nullptr; float2 *d_spec_R = nullptr; int64_t *d_pred = nullptr, *d_anchor = nullptr; uint32_t *d_pred_n = nullptr;
     bool spec = false;
     uint32_t *h_hint = nullptr, *d_hint = nullptr;     // pinned, device-mapped: longest coded frame of the last launch
     uint8_t *d_jsoft[MCRX_SLOTS] = {}, *d_jtmp[MCRX_SLOTS] = {};
-    bool scout = true, scout_tables = true; int scout_rounds = 2; bool narrow_first = true;
+    bool scout = true, scout_tables = true;
+    uint32_t nseg_fixed = 0, seg_frames = 4; float frames_per_push = 0.f; uint64_t last_nsamp = 0;      // segment-parallel acquisition: launch_sync
+    bool cadenced = true; uint32_t cad_same = 0, cad_frames = 0; int cad_count = 0;                       // ... its anchor phase
     // scouts of the acquisition rounds: 1 = the lean scout's unbudgeted build (sync_walk_kernel: 256 + 40 registers, no spills), 0 = the
     // 168-register build (293 spilled) that round 2 made to fit beside four 80-register payload workers.  With eight 56-register
     // workers per SIMD neither fits beside them any more, and a scout that adopts 100 frames of a channel pays for every spill:
     // 8 channels 54.7 -> 64.8 Gsample/s, 512 channels 166.4 -> 169.9 (same box, same run; MCRX_LEAN_BUILD)
     int lean_build = 1;
-    bool rounds_fixed = false; uint32_t walk_seen = 0; int extra_round_for = 0, extra_len = 16; uint64_t extra_end = 0;     // adaptive extra rounds, see launch_sync
-    int extra_rounds = 1, extra_calm = 0;                                                                                   // ... how many of them, and launches without walking since they last grew
-    // speculation pays only where frame positions can be predicted: the host compares what the scouts had to walk with what
-    // they adopted (host-mapped counters) and switches the speculative rounds off while walking dominates (launch_sync)
-    uint32_t pol_walk = 0, pol_adopt = 0, pol_same = 0, pol_fresh = 0; int pol_count = 0, pol_bad = 0; bool spec_adaptive = true, walk_mode = false;
     // streaming state
     uint64_t total_samples = 0;             // wideband samples accepted since creation (NCO phase)
     uint64_t stage_first = 0;               // absolute index of h_stage[0]
@@ -533,19 +530,13 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
         // speculative acquisition (lean path only): slots, their equalisers, the prediction lists
         const bool lean = q->sc.log2M >= 6 && q->sc.M == 64 * q->sc.E && q->sc.M_pilot <= 64;
         q->spec = lean && q->d_hint && getenv("MCRX_NO_SPEC") == nullptr;
-        if (getenv("MCRX_SCOUT_ROUNDS")) { q->scout_rounds = std::max(1, std::min(8, atoi(getenv("MCRX_SCOUT_ROUNDS")))); q->rounds_fixed = true; }
-        if (getenv("MCRX_NARROW_FIRST")) q->narrow_first = atoi(getenv("MCRX_NARROW_FIRST")) != 0;
+        if (getenv("MCRX_NSEG")) q->nseg_fixed = (uint32_t)std::max(1, std::min(MCRX_SPEC_MAX / 2, atoi(getenv("MCRX_NSEG"))));           // experiments: segments per channel, fixed
+        if (getenv("MCRX_SEG_FRAMES")) q->seg_frames = (uint32_t)std::max(1, std::min(64, atoi(getenv("MCRX_SEG_FRAMES"))));            // ... or frames per segment aimed at
         if (getenv("MCRX_LEAN_BUILD")) q->lean_build = atoi(getenv("MCRX_LEAN_BUILD"));
-        // a caller that knows its pushes hold several bursts (a rank of a G-GPU job: G sub-slabs of time per round) can say so instead of
-        // letting the policy find out over its first ~50 launches: that many extra rounds from the first launch on, trimmed by the
-        // scouts' report like any others (bench.py sets it for --gpus > 1)
-        if (getenv("MCRX_EXTRA_ROUNDS")) { q->extra_rounds = std::max(1, std::min(12, atoi(getenv("MCRX_EXTRA_ROUNDS")))); q->extra_len = 4096; q->extra_round_for = 4096; }
-        if (getenv("MCRX_SPEC_ADAPTIVE")) q->spec_adaptive = atoi(getenv("MCRX_SPEC_ADAPTIVE")) != 0;
         if (q->spec) {
             if ((rc = q->alloc(&q->d_spec, (size_t)q->nch * MCRX_SPEC_MAX))) return bail(rc);
             if ((rc = q->alloc(&q->d_spec_R, (size_t)q->nch * MCRX_SPEC_MAX * M))) return bail(rc);
-            if ((rc = q->alloc(&q->d_pred, (size_t)q->nch * MCRX_SPEC_MAX))) return bail(rc);
-            if ((rc = q->alloc(&q->d_pred_n, q->nch))) return bail(rc);
+            if ((rc = q->alloc(&q->d_anchor, q->nch))) return bail(rc);
         }
     }
     if ((rc = q->alloc(&q->d_hist[0], (size_t)HIST_BLOCKS * q->K))) return bail(rc);
@@ -671,7 +662,7 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     a.nrec = q->d_nrec[g]; a.arena_used = q->d_arena_used[g];
     a.arena_cap = q->arena_cap; a.sarena_cap = q->sarena_cap; a.max_rec = q->max_rec;
     a.debug = q->debug; a.no_fast = q->no_fast; a.seek_burst = q->seek_burst;
-    a.payload_lds_pad = (q->walk_mode || q->acq_mode == 2) ? q->walk_lds_pad : q->round_lds_pad;
+    a.payload_lds_pad = q->acq_mode == 2 ? q->walk_lds_pad : q->round_lds_pad;
     a.vit_off = 0;
     a.scout = q->scout ? 1 : 0;
     a.jobs = q->d_jobs[slot]; a.njobs = q->d_njobs + slot; a.njobs_next = q->d_njobs + next; a.max_jobs = q->max_rec;
@@ -690,11 +681,7 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     a.stats = q->d_stats;
     a.hint = q->d_hint; a.enc_hint = (q->h_hint && q->d_hint) ? *(volatile uint32_t *)q->h_hint : 0u;
     a.spec = q->d_spec; a.spec_R = q->d_spec_R; a.pred = nullptr; a.pred_n = nullptr; a.spec_cap = 0; a.spec_hint = nullptr; a.walk_hint = nullptr;
-    if (q->spec) {
-        a.pred = q->d_pred; a.pred_n = q->d_pred_n; a.spec_hint = q->d_hint + 1;
-        const uint32_t seen = ((volatile uint32_t *)q->h_hint)[1];         // largest prediction list so far (read without a sync)
-        a.spec_cap = seen < MCRX_SPEC_MAX ? seen : MCRX_SPEC_MAX;
-    }
+    a.nseg = 0; a.seg_phase = 0; a.anchor = nullptr;
     hipStream_t sa = st, sw = st;
     // The host never waits for the device on this path (slots are handed over by stream waits), so a free-running caller
     // can be any number of launches ahead -- and the hints the kernels leave for the next launch (widest prediction list,
@@ -702,7 +689,7 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     // launch that last used this one (the device still has nslots - 1 launches queued behind it) -- once per turn of the
     // slots, i.e. a lead of nslots .. 2 nslots - 1 launches: a wait per launch costs a short-slab stream (8 channels,
     // 0.36 ms per push) 4 %.
-    if (q->pipelined && q->scout && q->spec && !q->rounds_fixed && q->seq >= q->nslots && slot == 0 && !q->free_run) HIPCHK(hipEventSynchronize(q->ev_done[slot]));
+    if (q->pipelined && q->scout && q->spec && q->seq >= q->nslots && slot == 0 && !q->free_run) HIPCHK(hipEventSynchronize(q->ev_done[slot]));
     if (q->pipelined && q->scout) {
         sa = q->s_scout; sw = q->s_work;
         HIPCHK(hipEventRecord(q->ev_ready[slot], st));
@@ -714,92 +701,56 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     RC(q->ev_begin(1, sa));
     a.stop_after_walk = 0; a.tail_only = 0; a.defer_limit = (int64_t)q->defer; a.burst_limit = 0; a.round_idx = 0;
     if (q->spec) {
-        // lean configurations: a payload that straddles two pushes is walked by the tail kernel (before the rounds:
-        // the frame the previous push left in progress; after them: the one this push ends in), everything else by
-        // acquisition rounds -- speculative waves, then the lean per-channel scouts that adopt them; in all but the
-        // last round a scout stops at a state nobody predicted and re-anchors the predictions there
+        // lean configurations: a payload that straddles two pushes is walked by the tail kernel (before the acquisition: the frame
+        // the previous push left in progress; after it: the one this push ends in); everything else is acquired by the segment
+        // waves (kernels.h, SpecSlot) and strung together by the per-channel scouts, which walk by themselves only where no
+        // segment wave stood in their exact state.
         SyncArgs t = a;
-        t.tail_only = 1; t.pred = nullptr; t.pred_n = nullptr; t.spec_cap = 0; t.spec_hint = nullptr; t.stats = nullptr;
+        t.tail_only = 1; t.pred = nullptr; t.pred_n = nullptr; t.spec_cap = 0; t.nseg = 0; t.spec_hint = nullptr; t.stats = nullptr;
         HIPCHK(sync_launch_tail(t, sa));
-        // Round 0 is narrow: only the state the previous launch's scout stood in is speculated on (one wave per channel);
-        // the cadence predictions carried over from the previous buffer are right only if no gap followed it, and after
-        // the first adopted frame the scout re-anchors them anyway -- the full-width rounds run from there.
-        // Rounds: the narrow one and one full-width round serve a stream whose gaps fall between pushes.  A gap INSIDE a
-        // push leaves the frames behind it to the scouts' own walk; they say so in a host-mapped counter (read here without
-        // a sync, so a launch or two late), and while it moves a second full-width round re-anchors behind such gaps.  An
-        // idle full-width round is not free (~35 us: 512 x spec_cap waves that only find nothing to do), hence not by default.
-        int rounds = q->scout_rounds;
-        // Ragged traffic (every frame its own length, src/multichannel_txrx.cc:227-267): where a frame starts is not known
-        // before the header of the one in front of it has been decoded -- per channel the acquisitions are a chain by
-        // information, cadence predictions miss, and every speculative wave on a wrong position is an acquisition attempt
-        // thrown away (measured: 6.0 ms of acquisition per 207 M-sample slab with the rounds, 11 % of the frames adopted).
-        // There the lean scout's unbudgeted build walks the channels alone (1.4 ms).  The scouts count what they walked /
-        // adopted and how many frames followed their predecessor at the distance of the pair before (what a cadence
-        // would have hit); place_jobs_kernel copies the totals to host-mapped words and every 8 launches the host
-        // compares: rounds -> walking when walked > adopted twice in a row (not once: a cold start or the first pushes
-        // after a silence walk a window's worth by themselves), walking -> rounds when > 3/4 of the frames sat on a cadence
-        // twice in a row.  MCRX_ACQ_MODE=1 / 2 pins either.
-        bool spec_round = !q->walk_mode;
-        if (q->spec_adaptive && !q->rounds_fixed && q->h_hint && q->d_hint) {
-            if (++q->pol_count >= 8) {
-                volatile uint32_t *h = (volatile uint32_t *)q->h_hint;
-                const uint32_t w = h[2], ad = h[3], sm = h[4], fr = h[5];
-                const uint32_t dw = w >= q->pol_walk ? w - q->pol_walk : 0u, da = ad >= q->pol_adopt ? ad - q->pol_adopt : 0u;     // (mcrx_hip_spec_stats may have reset them)
-                const uint32_t ds = sm >= q->pol_same ? sm - q->pol_same : 0u, df = fr >= q->pol_fresh ? fr - q->pol_fresh : 0u;
-                // (frames that sit on a cadence but were walked all the same -- bursts with a gap in front of each, several to a push:
-                //  a rank's round of an 8-GPU job holds 8 -- need more rounds, not the walking scouts: 3/4 on the cadence keeps the rounds)
-                const bool cadenced = df > q->nch && 4ull * ds > 3ull * df;
-                if (!q->walk_mode) { if (dw > da && dw > q->nch / 4 && !cadenced) { if (++q->pol_bad >= 2) { q->walk_mode = true; q->pol_bad = 0; } } else q->pol_bad = 0; }
-                else { if (df > q->nch && 4ull * ds > 3ull * df) { if (++q->pol_bad >= 2) { q->walk_mode = false; q->pol_bad = 0; } } else q->pol_bad = 0; }
-                q->pol_walk = w; q->pol_adopt = ad; q->pol_same = sm; q->pol_fresh = fr; q->pol_count = 0;
-                if (a.debug & 4) fprintf(stderr, "[host] launch %llu policy: walked %u adopted %u on-cadence %u of %u -> %s\n", (unsigned long long)q->seq, dw, da, ds, df, q->walk_mode ? "walk" : "rounds");
-            }
-            a.walk_hint = q->d_hint + 2;
+        // How many segments: enough waves to fill the chip and short chains (a wave's frames are acquired one after the other),
+        // but every segment costs two acquisitions that produce nothing (its first frame, taken from an arbitrary state, and the
+        // frame that links it to the next segment), and its share of the channel's MCRX_SPEC_MAX slots must hold its frames.
+        // F = frames per channel and push, from the hand-offs the most recent finished launch counted (host-mapped, read without
+        // a sync, a launch or two late); before the first report: one segment per 16 Ki samples.  Only speed depends on it.
+        const uint64_t nsamp = (uint64_t)(end - buf_first) > (uint64_t)q->hist_tiles * MCRX_TILE ? (uint64_t)(end - buf_first) - (uint64_t)q->hist_tiles * MCRX_TILE : 1;
+        uint32_t nseg = q->nseg_fixed;
+        if (!nseg) {
+            const uint32_t nj = q->h_hint ? ((volatile uint32_t *)q->h_hint)[7] : 0u;
+            if (nj) q->frames_per_push = 0.5f * q->frames_per_push + 0.5f * ((float)nj / (float)q->nch) * ((float)nsamp / (float)(q->last_nsamp ? q->last_nsamp : nsamp));
+            const float F = q->frames_per_push > 0.f ? q->frames_per_push : (float)nsamp / 16384.0f;
+            float want = F / (float)q->seg_frames;                                   // chains of seg_frames (+ 2) frames ...
+            const float fill = 1536.0f / (float)q->nch;                              // ... shorter while the chip is not full (1.5 waves per SIMD)
+            if (want < fill) want = fill < F / 2.0f ? fill : F / 2.0f;
+            const float room = ((float)MCRX_SPEC_MAX - 1.25f * F) / 3.0f;            // F / nseg * 1.25 + 3 slots per wave must fit
+            if (want > room) want = room;
+            nseg = want < 1.0f ? 1u : (want > 32.0f ? 32u : (uint32_t)(want + 0.5f));
         }
-        if (q->acq_mode == 1) spec_round = true; else if (q->acq_mode == 2) spec_round = false;
-        if (!spec_round) {
-            const uint32_t cap0 = a.spec_cap;
-            a.spec_cap = 0; a.stop_after_walk = 0;
-            HIPCHK(sync_launch_walk(a, sa));
-            a.spec_cap = cap0;
-        } else {
-        if (!q->rounds_fixed && q->h_hint && q->d_hint) {
-            const uint32_t w = ((volatile uint32_t *)q->h_hint)[2];
-            if (w != q->walk_seen) {
-                // walking again right after the extra rounds ran out = a stream that needs them all the time (e.g. behind a
-                // resampler whose delay times the first frame after every gap one sample off): twice as long every time
-                if (q->extra_round_for == 0) q->extra_len = (q->seq - q->extra_end < 32 && q->extra_len) ? std::min(2 * q->extra_len, 4096) : 16;
-                // ... and walking on a scale of a frame per channel and launch WHILE the extra round runs = one more round is not
-                // enough: every gap inside a push costs a round (the scouts stop at the first state nobody predicted, the next round
-                // starts from there), and a push can hold many -- a rank's round of an 8-GPU job is 8 slabs long.  Twice as many
-                // rounds each time (at most 12), one fewer after 64 launches without such walking.
-                // (not in a handle's first 24 launches: the host runs up to two turns of the slots ahead of the device, what it reads then
-                //  was walked before any cadence existed -- a cold start is not a stream of bursts)
-                if (q->extra_round_for > 0 && q->seq >= 24 && w - q->walk_seen > q->nch / 2) { q->extra_rounds = std::min(2 * q->extra_rounds, 12); q->extra_calm = 0; }
-                q->walk_seen = w; q->extra_round_for = q->extra_len;
-            } else if (q->extra_rounds > 1 && ++q->extra_calm >= 64) { q->extra_rounds--; q->extra_calm = 0; }
-            if (q->extra_round_for > 0) { if (--q->extra_round_for == 0) q->extra_end = q->seq; rounds += q->extra_rounds; }
-            a.burst_limit = (q->extra_round_for > 0 && q->extra_rounds > 1) ? 1 : 0;
-            if (a.burst_limit) {
-                // ... and no more rounds than the last launches needed: the scouts report the last round in which one of them had to
-                // stop (host-mapped word 6, a launch or two late); one round behind it finishes the push, one more is spare.  Walking
-                // that comes back raises extra_rounds above, and a round that stops later than before raises this bound with it.
-                const uint32_t used = ((volatile uint32_t *)q->h_hint)[6];
-                if (used) { const int want = (int)used + 2; if (want < rounds) rounds = want < 3 ? 3 : want; }
-            }
-            if (a.debug & 4) fprintf(stderr, "[host] launch %llu walk counter %u extra_round_for %d extra_rounds %d rounds %d (last round a scout stopped in: %u)\n", (unsigned long long)q->seq, w, q->extra_round_for, q->extra_rounds, rounds, ((volatile uint32_t *)q->h_hint)[6]);
-            a.walk_hint = q->d_hint + 2;
+        if (nseg > MCRX_SPEC_MAX / 2) nseg = MCRX_SPEC_MAX / 2;
+        // The anchor phase (kernels.h, SyncArgs::seg_phase) is one more launch and one frame's latency in front of everything else: worth it
+        // while most frames follow their predecessor at the distance of the pair before (the scouts count both, place_jobs_kernel
+        // copies the totals to host-mapped words), useless on traffic without a cadence.  Windows of 8 launches; MCRX_ACQ_MODE=3 / 1 pins it.
+        if (q->h_hint && ++q->cad_count >= 8) {
+            volatile uint32_t *h = (volatile uint32_t *)q->h_hint;
+            const uint32_t sm = h[4], fr = h[5];
+            const uint32_t ds = sm >= q->cad_same ? sm - q->cad_same : 0u, df = fr >= q->cad_frames ? fr - q->cad_frames : 0u;     // (mcrx_hip_spec_stats may have reset them)
+            if (df > q->nch) q->cadenced = 2ull * ds > df;
+            q->cad_same = sm; q->cad_frames = fr; q->cad_count = 0;
         }
-        const uint32_t cap = a.spec_cap;
-        for (int r = 0; r < rounds; r++) {
-            a.round_idx = r;
-            a.stop_after_walk = (r + 1 < rounds) ? 1 : 0;
-            a.spec_cap = (r == 0 && q->narrow_first && rounds > 1 && cap > 1) ? 1u : cap;
-            HIPCHK(sync_launch_spec(a, sa));
-            if (q->lean_build == 1) HIPCHK(sync_launch_walk(a, sa)); else HIPCHK(sync_launch_lean(a, sa));
+        if (q->acq_mode == 3) q->cadenced = true;
+        q->last_nsamp = nsamp;
+        a.nseg = nseg; a.spec_cap = nseg * (MCRX_SPEC_MAX / nseg);
+        a.walk_hint = q->d_hint ? q->d_hint + 2 : nullptr;
+        if (a.debug & 4) fprintf(stderr, "[host] launch %llu: %u segments per channel, %.1f frames per channel and push expected\n", (unsigned long long)q->seq, nseg, q->frames_per_push);
+        a.anchor = q->d_anchor;
+        if (q->acq_mode == 2) a.spec_cap = 0;                        // (MCRX_ACQ_MODE=2: no segment waves, the scouts walk everything)
+        else if (q->acq_mode == 1 || nseg == 1 || (q->acq_mode == 0 && !q->cadenced)) { a.seg_phase = 0; HIPCHK(sync_launch_spec(a, sa)); }     // one launch, coarse starts
+        else {
+            a.seg_phase = 1; HIPCHK(sync_launch_spec(a, sa));        // the first frame of every channel, from its real state: the cadence's anchor
+            a.seg_phase = 2; HIPCHK(sync_launch_spec(a, sa));        // everything behind it, segment-parallel
         }
-        a.spec_cap = cap;
-        }
+        a.seg_phase = 0;
+        if (q->lean_build == 1) HIPCHK(sync_launch_walk(a, sa)); else HIPCHK(sync_launch_lean(a, sa));
         // a frame the lean scout could neither hand off nor defer runs past the end of this buffer: walked up to there
         HIPCHK(sync_launch_tail(t, sa));
     } else {

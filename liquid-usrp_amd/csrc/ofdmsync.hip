@@ -29,6 +29,9 @@ namespace mcrx {
 #ifndef SY_PROFILE
 #define SY_PROFILE 0        /* 1: MCRX_DEBUG=2 cycle counters per event / phase (they cost ~40 registers in the scout) */
 #endif
+#ifndef SY_SEG_BURST
+#define SY_SEG_BURST 1      /* segment waves take idle stretches four SEEK events at a time (Walker::seek_burst) */
+#endif
 #define SY_PROF(a) (SY_PROFILE && ((a).debug & 2) != 0)
 // Phase-skipping switches (profiling ablations: MCRX_DEBUG=256 / 512 run the general decoder without the soft de-interleaver /
 // the Viterbi decoder) exist in development builds only (-DMCRX_DEVEL); the release library cannot be told to skip work.
@@ -651,9 +654,12 @@ __device__ __forceinline__ void wave_sync_lds()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// speculation key: a SEEK state is fully described by (next sample, timer) -- every path into SEEK resets the
-// rest -- so a slot is keyed by both, packed (timer in the top 16 bits; positions stay below 2^48)
-__device__ __forceinline__ int64_t spec_key(int64_t pos, uint32_t timer) { return (int64_t)(((uint64_t)timer << 48) | ((uint64_t)pos & 0xFFFFFFFFFFFFull)); }
+// slot key: a SEEK state is fully described by (next sample, timer) -- every path into SEEK resets the
+// rest -- so a slot is keyed by both, packed (timer in bits 48..60 -- it stays below 2 (M + cp) --, positions stay below
+// 2^48).  Bits 61..63 carry the synchronizer state of the one key that is not a SEEK state: the state a launch starts in when
+// the previous push ended in the middle of an acquisition (segment 0 clones it whole; nothing else can produce that key).
+__device__ __forceinline__ int64_t spec_key(int64_t pos, uint32_t timer, int state = 0)
+{ return (int64_t)(((uint64_t)(unsigned)state << 61) | ((uint64_t)(timer & 0x1FFFu) << 48) | ((uint64_t)pos & 0xFFFFFFFFFFFFull)); }
 
 // what a Walker instance is compiled for: everything (general configurations, and the tail kernel that walks the
 // payload of a frame straddling two pushes), a speculative acquisition wave, or the lean per-channel scout
@@ -1536,7 +1542,14 @@ struct Walker {
             s.evm = 10.0f * log10f(s.evm_hat / (float)MCRX_HDR_SYMS);
             if (s.header_valid) {
                 s.fstate = FX_PAYLOAD; s.payload_symbol_index = 0;
-                if constexpr (MODE == SYM_SPEC) return try_handoff_spec(t_ev) ? 2 : 1;
+                if constexpr (MODE == SYM_SPEC) {
+                    if (try_handoff_spec(t_ev)) return 2;
+                    // the lean scout's own verdict on a frame whose payload runs past the end of the buffer (below): deferred when
+                    // the next push still holds its beginning -- parked as such, so that the scout need not walk up to here to find out
+                    const int64_t nsym_ = (int64_t)((s.mod_len + (uint32_t)c.M_data - 1) / (uint32_t)c.M_data);
+                    const bool oversize_ = s.enc_len > c.max_enc_len || s.mod_len > c.max_syms || s.payload_len > c.max_payload_len;
+                    return (!oversize_ && t_ev + nsym_ * (int64_t)c.L >= a.end && a.defer_limit > 0 && a.end - sk_cur <= a.defer_limit) ? 4 : 1;
+                }
                 const bool ho = try_handoff(t_ev);
                 if (prof) ph[5] += (long long)__builtin_readcyclecounter() - k0;
                 if (ho) return 2;
@@ -1562,7 +1575,7 @@ struct Walker {
                     return 2;
                 }
             }
-            else { if constexpr (MODE != SYM_SPEC) emit(t_ev, false, false); return 1; }
+            else { if constexpr (MODE == SYM_SPEC) return 5; emit(t_ev, false, false); return 1; }       // (5: a segment wave parks the record for the scout to emit)
         }
         return 0;
     }
@@ -1750,31 +1763,44 @@ struct Walker {
     // and a ballot; the adopted slots are only noted (LDS) during the walk, and their parked jobs and
     // equalisers are copied into the job list in one pipelined pass after it.  Nothing on the scout's
     // serial chain waits for memory because of an adoption.
-    int64_t sp_start[2], sp_tlast[2]; uint32_t nadopted; uint32_t nwalked = 0;
+    static constexpr int SPH = MCRX_SPEC_MAX / WV;          // slot headers per lane
+    int64_t sp_start[SPH]; int32_t sp_tlast[SPH]; uint32_t sp_aux[SPH]; uint32_t nadopted; uint32_t nwalked = 0;
     int64_t sk_cur = 0; uint32_t sk_timer = 0;      // lean scout: the SEEK state before the last seek event (where a frame is re-acquired from if deferred)
     __device__ __forceinline__ void load_spec_headers()
     {
         const SpecSlot *sl = a.spec + (size_t)ch * MCRX_SPEC_MAX;
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
+        for (int h = 0; h < SPH; h++) {
             const uint32_t k = (uint32_t)l + WV * h;
             const bool live = k < a.spec_cap;
             const SpecSlot *q = sl + (live ? k : 0);
-            sp_start[h] = (live && q->status == 1) ? q->start : -1;
-            sp_tlast[h] = q->t_last;
+            const int32_t stt = q->status;
+            sp_start[h] = (live && stt >= 1 && stt <= 3) ? q->start : -1;
+            sp_tlast[h] = (int32_t)(q->t_last - a.buf_first);       // (positions inside the buffer: 31 bits are plenty)
+            sp_aux[h] = (uint32_t)stt | (q->pad << 8);
         }
         nadopted = 0;
     }
     // the slot that started from exactly `key`, if there is one: noted, and the sample its frame ended with returned
-    __device__ __forceinline__ bool adopt_match(int64_t key, int64_t &t_end)
+    // aux: the slot's status (1: frame handed off, t_end = its last symbol's event; 2: deferred, t_end = the SEEK position to go
+    // back to, aux >> 8 its timer; 3: a frame whose header failed its check, t_end = the event it was decoded at: the scout emits its record)
+    __device__ __forceinline__ bool adopt_match(int64_t key, int64_t &t_end, uint32_t &aux, uint32_t &kslot)
     {
-        static_assert(MCRX_SPEC_MAX <= 2 * WV, "two slot headers per lane");
-        const unsigned long long b0 = __ballot(sp_start[0] == key), b1 = __ballot(sp_start[1] == key);
-        if (!(b0 | b1)) return false;
-        const int hl = b0 ? (int)__builtin_ctzll(b0) : (int)__builtin_ctzll(b1);
-        t_end = __shfl(b0 ? sp_tlast[0] : sp_tlast[1], hl, WV);
-        if (l == 0) ldsad[nadopted] = (uint8_t)(b0 ? hl : hl + WV);
-        nadopted++;
+        static_assert(MCRX_SPEC_MAX % WV == 0 && MCRX_SPEC_MAX <= 256, "whole rows of slot headers; slot numbers are noted as bytes");
+        int hh = -1, hl = 0; int32_t tl = 0; uint32_t ax = 0;
+#pragma unroll
+        for (int h = 0; h < SPH; h++) {
+            const unsigned long long b = __ballot(sp_start[h] == key);
+            if (b && hh < 0) { hh = h; hl = (int)__builtin_ctzll(b); tl = sp_tlast[h]; ax = sp_aux[h]; }
+        }
+        if (hh < 0) return false;
+        t_end = a.buf_first + (int64_t)__shfl((int)tl, hl, WV);
+        aux = (uint32_t)__shfl((int)ax, hl, WV);
+        kslot = (uint32_t)(hl + WV * hh);
+        if ((aux & 0xffu) == 1u) {
+            if (l == 0) ldsad[nadopted] = (uint8_t)(hl + WV * hh);
+            nadopted++;
+        }
         return true;
     }
     __device__ __forceinline__ void publish_adopted()
@@ -1811,40 +1837,159 @@ struct Walker {
         if (lost && l == 0) atomicAdd(a.nrec + 1, lost);
     }
 
-    // speculative wave: acquire one frame from the fresh post-frame state at a predicted position
-    __device__ __forceinline__ void run_spec(uint32_t kslot)
+    // Coarse preamble finder for the segment waves (never part of the synchronizer's decisions: it only chooses where a wave
+    // starts).  S0 carries even subcarriers only, so the two S0 symbols are M/2-periodic in time: lane l takes the M samples
+    // at from + l M/2 and compares their lag-M/2 autocorrelation with their energy (1 inside the preamble, ~ sqrt(2/M) on data
+    // symbols or noise; exact zeros give NaN = no hit).  Returns the first grid position above 0.6, or -1 before `to`.
+    __device__ __forceinline__ int64_t coarse_scan(int64_t from, int64_t to)
     {
-        slot = a.spec + (size_t)ch * MCRX_SPEC_MAX + kslot;
-        bR = a.spec_R + ((size_t)ch * MCRX_SPEC_MAX + kslot) * c.M;
-        const int64_t key = (kslot < a.pred_n[ch]) ? a.pred[(size_t)ch * MCRX_SPEC_MAX + kslot] : -1;
-        const int64_t start = key < 0 ? -1 : (int64_t)((uint64_t)key & 0xFFFFFFFFFFFFull);
-        bool ok = start >= a.buf_first && start >= 0 && start < a.end;
-        if (ok) {
-            s = a.st[ch];                               // (only to give every field a defined value)
-            reset_framesync(); s.timer = (uint32_t)((uint64_t)key >> 48); s.cur = start;
-            init_consts();
-            ok = false;
-            int nseek = 0;
-            for (int nev = 0; nev < 64; nev++) {
-                // A prediction is a fresh post-frame state: the frame it is for starts within a few idle symbols of it.  One that still
-                // seeks after 8 events stands in a gap or in the middle of a frame (a cadence continued across a gap) -- nothing a scout
-                // will ever adopt, and seeking on to the next frame costs a whole acquisition (64 events = 70 us) per wrong slot and round.
-                if (s.state == SY_SEEK && ++nseek > 8) break;
+        const int M2 = c.M2;
+        if (to > a.end - c.M) to = a.end - c.M;                 // windows stay inside the buffer
+        for (int64_t p0 = from; p0 < to; p0 += (int64_t)WV * M2) {
+            const int64_t d = p0 + (int64_t)l * M2;
+            const bool in = d < to;
+            const int64_t dd = in ? d : p0;
+            float2 acc = make_float2(0.f, 0.f); float en = 0.f;
+            for (int n = 0; n < M2; n++) {
+                const float2 u = sample(dd + n), v = sample(dd + n + M2);
+                acc = cadd(acc, cmulc(u, v));
+                en += u.x * u.x + u.y * u.y + v.x * v.x + v.y * v.y;
+            }
+            const bool hit = in && (acc.x * acc.x + acc.y * acc.y) > 0.09f * en * en;        // |P| / (E / 2) > 0.6
+            const unsigned long long b = __ballot(hit);
+            if (b) return p0 + (int64_t)__builtin_ctzll(b) * M2;
+        }
+        return -1;
+    }
+
+    // Segment wave (kernels.h, SpecSlot): the synchronizer's own events -- sync_event, the header symbols, the header decode --
+    // from a start state through this wave's segment, frame after frame; every hand-off parked in the next slot of the wave's
+    // range under the key of the state the frame was acquired from.  No side effects outside the wave's slots (and anchor[ch]).
+    __device__ __forceinline__ void run_seg(uint32_t g)
+    {
+        const uint32_t spw = a.spec_cap / a.nseg;                // slots of this wave
+        SpecSlot *sl0 = a.spec + (size_t)ch * MCRX_SPEC_MAX + (size_t)g * spw;
+        float2 *R0 = a.spec_R + ((size_t)ch * MCRX_SPEC_MAX + (size_t)g * spw) * c.M;
+        const int M = c.M, M2 = c.M2, L = c.L;
+        const int phase = a.seg_phase;
+        s = a.st[ch];
+        const bool mid_payload = s.state == SY_RX && s.fstate == FX_PAYLOAD;      // (a payload that runs through this whole push: the tail kernel's)
+        const int64_t base = s.cur, span = a.end - base;
+        const int64_t seg_len = span > 0 ? (span + (int64_t)a.nseg - 1) / (int64_t)a.nseg : 0;
+        const int64_t seg_start = base + (int64_t)g * seg_len;
+        const bool last = g + 1 == a.nseg;
+        const int64_t seg_end = last ? INT64_MAX : seg_start + seg_len;          // a frame detected at or behind it is the next wave's first: my last
+        // idle for a whole segment behind mine: give up (the scout walks idle stretches).  Phase 1 is the one serial step every other
+        // wave of the launch waits for: a channel whose push begins in silence has no anchor (everybody takes the coarse start)
+        const int64_t seek_limit = phase == 1 ? base + 8 * (int64_t)M : (last ? INT64_MAX : seg_end + seg_len);
+        int64_t key = -1;
+        bool go = !mid_payload && seg_len > 0 && seg_start < a.end;
+        uint32_t j = 0, jmax = spw;
+        // cadence: the lattice anchor + n P of fresh post-frame states the frames of a periodic stream are acquired from
+        const int64_t A = (phase == 2 && a.anchor) ? a.anchor[ch] : -1, P = (int64_t)s.period_hint;
+        auto lattice = [&](int64_t from) -> int64_t {           // its first point at or behind `from`, strictly behind the anchor
+            if (A < 0 || P <= 0) return -1;
+            const int64_t f = from > A + 1 ? from : A + 1;
+            return A + (f - A + P - 1) / P * P;
+        };
+        auto preamble_behind = [&](int64_t p) -> bool {        // a frame does begin within a few symbols of p
+            if (p < 0 || p + 6 * (int64_t)L >= a.end) return false;
+            return coarse_scan(p, p + 4 * (int64_t)L + M2) >= 0;
+        };
+        int64_t p_next = -1;                                    // the next segment's start on the lattice, if that wave takes it
+        if (go) {
+            if (g == 0 && phase == 2 && A >= 0) {
+                // phase 2: on from where phase 1's frame ended (slot 0 is that frame's)
+                j = 1;
+                reset_framesync(); s.timer = (uint32_t)L; s.cur = A; key = spec_key(A, (uint32_t)L); init_consts();
+            } else if (g == 0) {
+                // the channel's real state, whatever it is (normally the fresh state behind the last frame of the previous push)
+                key = spec_key(s.cur, s.timer, s.state);
+                init_consts();                                  // (R from the channel's equaliser: an acquisition in progress has it)
+                if (fastp && s.state == SY_RX && s.fstate == FX_HEADER && s.header_symbol_index > 0) {
+                    for (int i = l; i < MCRX_HDR_SYMS; i += WV) ldshb[i] = bhbits[i];
+                    wave_sync_lds();
+                }
+                if (s.state == SY_RX) {
+#pragma unroll
+                    for (int e = 0; e < E; e++) if (k[e] >= 0) R0[k[e]] = R[e];     // the hand-off reads the slot's equaliser
+                }
+                if (phase == 1) jmax = 1;
+            } else {
+                reset_framesync(); s.timer = 0; s.cur = seg_start;
+                init_consts();
+                int64_t p_me = lattice(seg_start);
+                if (p_me >= 0 && !last && p_me >= seg_end) p_me = -1;              // the lattice skips my segment (that point is a later wave's): coarse start
+                if (preamble_behind(p_me)) { s.timer = (uint32_t)L; s.cur = p_me; key = spec_key(p_me, (uint32_t)L); }
+                else {
+                    const int64_t hit = coarse_scan(seg_start, seek_limit < a.end ? seek_limit : a.end);
+                    if (hit < 0) go = false;
+                    else { const int64_t p = hit - M; s.cur = p > seg_start ? p : seg_start; }
+                }
+            }
+            if (go && !last && phase != 1) {                    // (the next wave's own rule, on its own segment)
+                int64_t pn = lattice(seg_end);
+                if (pn >= 0 && g + 2 != a.nseg && pn >= seg_end + seg_len) pn = -1;
+                if (preamble_behind(pn)) p_next = pn;
+            }
+        }
+        while (go && j < jmax) {
+            slot = sl0 + j; bR = R0 + (size_t)j * c.M;
+            int verdict = 0;
+            while (true) {
+                if (s.state == SY_SEEK) {
+                    sk_cur = s.cur; sk_timer = s.timer;
+                    if (s.cur >= seek_limit) break;
+                    if (SY_SEG_BURST && a.seek_burst && s.timer == 0 && s.cur >= a.buf_first && s.cur + (int64_t)SEEK_B * M <= a.end) {
+                        seek_burst();                           // idle stretch: SEEK_B events per HBM round trip
+                        if (s.state != SY_SEEK) { sk_cur = s.cur - M; sk_timer = 0; }       // detected in the burst: the SEEK state that event was taken from
+                        continue;
+                    }
+                }
                 int64_t t_ev;
-                if (s.state == SY_SEEK)       t_ev = s.cur + ((s.timer + 1 >= (uint32_t)c.M) ? 0 : (int64_t)(c.M - 1 - (int)s.timer));
+                if (s.state == SY_SEEK)       t_ev = s.cur + ((s.timer + 1 >= (uint32_t)M) ? 0 : (int64_t)(M - 1 - (int)s.timer));
                 else if (s.state == SY_S0A || s.state == SY_S0B)
-                                              t_ev = s.cur + ((s.timer + 1 >= (uint32_t)c.M2) ? 0 : (int64_t)(c.M2 - 1 - (int)s.timer));
+                                              t_ev = s.cur + ((s.timer + 1 >= (uint32_t)M2) ? 0 : (int64_t)(M2 - 1 - (int)s.timer));
                 else                          t_ev = s.cur + (int64_t)s.timer - 1;
                 if (t_ev >= a.end) break;
                 s.cur = t_ev + 1;
                 if (s.state != SY_RX) { sync_event(t_ev); continue; }
                 const int fr = rx_event_fast<SYM_SPEC>(t_ev);
                 if (fr == 0) continue;
-                ok = fr == 2;                           // anything but a clean hand-off is left to the scout
+                verdict = fr;
                 break;
             }
+            if (verdict == 2) {                                 // handed off: the job sits in the slot (try_handoff_spec)
+                if (l == 0) { slot->start = key; slot->t_last = handoff_last; slot->status = 1; slot->pad = 0; }
+                j++;
+                if (phase == 1) { if (l == 0) a.anchor[ch] = handoff_last + 1; return; }
+                if (handoff_last + 1 == p_next) break;          // exactly the state the next segment's wave started from: linked
+                // ... else the first frame detected at or behind the place the next wave started looking from -- its lattice point if
+                // it took one, else the segment boundary -- is that wave's first frame: acquired from my (real) state it links us
+                if (sk_cur >= (p_next >= 0 ? p_next : seg_end)) break;
+                reset_framesync(); s.timer = (uint32_t)L; s.cur = handoff_last + 1;      // where liquid stands after the frame's last symbol
+                key = spec_key(s.cur, s.timer);
+                continue;
+            }
+            if (verdict == 5 && phase != 1) {                   // header decoded, check failed: the record is the scout's to write; liquid resets and seeks on
+                if (l == 0) { PayloadJob jb; jb.s = s; jb.ch = ch; jb.pad = 0; jb.arena_off = 0; jb.syms_off = 0; slot->job = jb;
+                              slot->start = key; slot->t_last = s.cur - 1; slot->status = 3; slot->pad = 0; }
+                j++;
+                reset_framesync(); s.timer = (uint32_t)L;
+                key = spec_key(s.cur, s.timer);
+                continue;
+            }
+            if (verdict == 4 && phase != 1) {                   // runs past the end of the buffer, the next push re-acquires it whole
+                if (l == 0) { slot->start = key; slot->t_last = sk_cur; slot->status = 2; slot->pad = sk_timer; }
+                j++;
+            }
+            break;                                              // anything else (invalid header, end of the buffer, idle) is the scout's
         }
-        if (l == 0) { slot->start = ok ? key : -1; slot->t_last = handoff_last; slot->status = ok ? 1 : 0; }
+        if (phase == 1) {                                       // no hand-off: no anchor; segment 0 starts over from the entry state in phase 2
+            if (l == 0) { a.anchor[ch] = -1; sl0[0].start = -1; sl0[0].status = 0; }
+            return;
+        }
+        for (uint32_t q = j + (uint32_t)l; q < spw; q += WV) { sl0[q].start = -1; sl0[q].status = 0; }
     }
 
     // Lean configurations' tail kernel: a channel with a payload in progress (a frame that straddles two pushes and
@@ -1884,45 +2029,44 @@ struct Walker {
         }
         const int M = c.M, M2 = c.M2, L = c.L;
         long long prof_cyc[5] = {0, 0, 0, 0, 0}; int prof_n[5] = {0, 0, 0, 0, 0};
-        uint32_t npred = 0, nfresh = 0, nsame = 0; int64_t pred_prev = 0, pred_last = 0; bool entry = true;
-        bool stopped = false;
+        bool entry = true;
+        int64_t fresh_prev = -1, fresh_last = -1;       // the last two fresh post-frame states (behind handed-off frames): the cadence the next push's segment waves try
+        uint32_t nfresh = 0, nsame = 0;                 // hand-offs seen, and how many of them followed their predecessor at the distance of the pair before
         nadopted = 0;
         if (a.spec_cap) load_spec_headers();
         while (true) {
-            if (a.pred && s.state == SY_SEEK && (s.timer == (uint32_t)L || entry)) {
-                // a SEEK state a speculative wave may have started from -- the one this launch starts in, and the fresh
-                // one after every frame: take the frame from that wave if it started from exactly this state
-                int64_t key = spec_key(s.cur, s.timer);
-                if (s.timer == (uint32_t)L) {
-                    // (frames at the same distance as the pair before them: what cadence speculation would have hit -- the
-                    //  host's acquisition policy reads the totals, launch_sync)
-                    if (nfresh >= 2 && s.cur - pred_last == pred_last - pred_prev) nsame++;
-                    pred_prev = pred_last; pred_last = s.cur; nfresh++;
-                }
-                entry = false;
-                if ((a.debug & 16) && l == 0 && ch == 0) printf("[spec] ch0 fresh state cur %lld timer %u (period hint %u, last fresh %lld, pred_n %u, pred[0..2] %lld %lld %lld)\n", (long long)s.cur, s.timer, s.period_hint, (long long)s.last_fresh, a.pred_n[ch], (long long)(a.pred[(size_t)ch * MCRX_SPEC_MAX] & 0xFFFFFFFFFFFFll), (long long)(a.pred[(size_t)ch * MCRX_SPEC_MAX + 1] & 0xFFFFFFFFFFFFll), (long long)(a.pred[(size_t)ch * MCRX_SPEC_MAX + 2] & 0xFFFFFFFFFFFFll));
-                if (a.spec_cap) {
-                    // A frame somebody predicted costs the scout the chain key -> slot -> frame end -> next key, and a channel with
-                    // a hundred frames in the buffer (few channels, long pushes) runs it a hundred times in a row: chased here on
-                    // the position alone, the synchronizer state written once behind the last adoption (every adoption leaves it
-                    // in the same fresh post-frame state, only the position differs).
-                    int64_t pos = s.cur, t_end = 0; bool any = false;
-                    while (nadopted < MCRX_SPEC_MAX && adopt_match(key, t_end)) {
-                        any = true; pos = t_end + 1;
-                        if (nfresh >= 2 && pos - pred_last == pred_last - pred_prev) nsame++;
-                        pred_prev = pred_last; pred_last = pos; nfresh++;
-                        key = spec_key(pos, (uint32_t)L);
+            if (a.spec_cap && (entry || (s.state == SY_SEEK && s.timer == (uint32_t)L))) {
+                // a state a segment wave may have started a frame from -- the one this launch starts in (whatever it is: segment 0
+                // cloned it) and the fresh one after every frame: the frame is taken from that wave if it started from exactly this
+                // state.  A channel with a hundred frames in the buffer runs key -> slot -> frame end -> next key a hundred times in
+                // a row: chased here on the position alone, the synchronizer state written once behind the last adoption (every
+                // adoption leaves it in the same fresh post-frame state, only the position differs).
+                int64_t key = spec_key(s.cur, s.timer, s.state);
+                int64_t pos = s.cur, t_end = 0; uint32_t aux = 0, kslot = 0; bool any = false, deferred = false;
+                while (nadopted < MCRX_SPEC_MAX && adopt_match(key, t_end, aux, kslot)) {
+                    if ((aux & 0xffu) == 2u) { deferred = true; break; }
+                    if ((aux & 0xffu) == 3u) {
+                        // a frame whose header did not pass its check (noise, a neighbour's leakage): the record the synchronizer
+                        // reports for it is written here, from the state the segment wave parked
+                        const ChanState keep = s;
+                        s = a.spec[(size_t)ch * MCRX_SPEC_MAX + kslot].job.s;
+                        emit(t_end, false, false);
+                        s = keep; nwalked++;
                     }
-                    if (any) { reset_framesync(); s.timer = (uint32_t)L; s.cur = pos; }
+                    any = true; pos = t_end + 1;
+                    if ((aux & 0xffu) == 1u) {
+                        if (fresh_prev >= 0 && pos - fresh_last == fresh_last - fresh_prev) nsame++;
+                        fresh_prev = fresh_last; fresh_last = pos; nfresh++;
+                    }
+                    key = spec_key(pos, (uint32_t)L);
                 }
-                // nobody predicted this state.  In all but the last acquisition round the scout stops here instead of
-                // acquiring the frame itself: the next round's speculative waves start from this exact state and from
-                // the cadence continued from it, all in parallel
-                if (a.stop_after_walk) {
-                    stopped = true;
-                    if (a.stats && a.round_idx >= 1 && l == 0) atomicMax(a.stats + 6, (uint32_t)a.round_idx + 1u);      // (the narrow round always ends in a stop)
+                if (deferred) {
+                    // the frame acquired from here runs past the end of this buffer and the next push re-acquires it whole: back to
+                    // the SEEK state it was detected from (what this scout does itself at `fr == 4` below)
+                    reset_framesync(); s.cur = t_end; s.timer = aux >> 8;
                     break;
                 }
+                if (any) { reset_framesync(); s.timer = (uint32_t)L; s.cur = pos; }
             }
             entry = false;
             if (MODE == SYM_LEAN && s.cur >= a.end) break;      // (a frame jumped over may end beyond this buffer)
@@ -1970,6 +2114,8 @@ struct Walker {
                     // payload handed to a worker: jump over it; liquid leaves the synchronizer in
                     // SEEK with timer = M+cp after the frame's last symbol
                     reset_framesync(); s.timer = (uint32_t)L; s.cur = handoff_last + 1;
+                    if (fresh_prev >= 0 && s.cur - fresh_last == fresh_last - fresh_prev) nsame++;
+                    fresh_prev = fresh_last; fresh_last = s.cur; nfresh++;
                 }
             }
             if (SY_PROF(a)) { prof_cyc[st_in] += (long long)__builtin_readcyclecounter() - tk0; prof_n[st_in]++; }
@@ -1984,55 +2130,14 @@ struct Walker {
         if (a.stats && l == 0) {
             if (nwalked) atomicAdd(a.stats, nwalked);
             if (nadopted) atomicAdd(a.stats + 1, nadopted);
-            if (nsame) atomicAdd(a.stats + 4, nsame);
+            if (nsame) atomicAdd(a.stats + 4, nsame);           // (what a cadence would have predicted: the host runs the anchor phase only while it pays)
             if (nfresh > 2) atomicAdd(a.stats + 5, nfresh - 2);
         }
-        // (what the scouts walked and adopted reaches the host through place_jobs_kernel: one pair of stores per launch into
-        //  the host-mapped words instead of a system-scope atomic per channel)
-        if (a.pred) {
-            const int64_t period_seen = pred_last - pred_prev;
-            const int64_t P_old = (int64_t)s.period_hint;            // a second hypothesis when the spacing just seen differs: the first frame
-            if (nfresh >= 2 && period_seen > 0 && period_seen < (int64_t)0x7fffffff) s.period_hint = (uint32_t)period_seen;     // behind a gap is timed from
-            if (nfresh >= 1) s.last_fresh = pred_last;               // an arbitrary detector phase and can sit a sample off the cadence of those behind it
-            const int64_t P = (int64_t)s.period_hint;
-            // predictions for the next speculative pass (the next round of this launch if the scout stopped, else the
-            // next launch): the exact state the scout stands in, if it is SEEK, and the frame cadence continued from
-            // the last post-frame state -- to the end of this buffer, or one buffer length past it
-            npred = 0;
-            if (s.state == SY_SEEK) { if (l == 0) a.pred[(size_t)ch * MCRX_SPEC_MAX] = spec_key(s.cur, s.timer); npred = 1; }
-            const int64_t anchor = (s.state == SY_SEEK && s.timer == (uint32_t)L) ? s.cur : s.last_fresh;
-            if (P > 0 && anchor > 0) {
-                int64_t p = anchor + P;
-                if (p < s.cur) p += (s.cur - p + P - 1) / P * P;
-                const int64_t limit = stopped ? a.end : a.end + (a.end - a.buf_first);
-                const bool two = P_old > 0 && P_old != P;
-                int64_t p2 = anchor + P_old;
-                if (two && p2 < s.cur) p2 += (s.cur - p2 + P_old - 1) / P_old * P_old;
-                // Pushes that hold several bursts (a gap in front of each) take a round per burst: the scout stops behind the frame
-                // that opened the next one.  What lies beyond that burst's end is off the cadence again, so a stopped scout predicts
-                // one burst ahead -- the run of adoptions it has just seen, doubled when it ran out of predictions on the cadence --
-                // instead of to the end of the buffer (every slot beyond is an acquisition attempt thrown away, per round).
-                uint32_t maxp = MCRX_SPEC_MAX;
-                if (a.burst_limit && stopped) {
-                    uint32_t bh = s.burst_hint;
-                    // (ran out of predictions: twice the run; a shorter run ended at a gap or at the end of the buffer and says nothing
-                    //  about the bursts: the hint only grows, a restart forgets it)
-                    if (nadopted >= 2 && (!bh || nadopted > bh)) bh = bh ? 2u * nadopted : nadopted;
-                    s.burst_hint = bh;
-                    if (bh) { const uint32_t want = (bh + 3u) * (two ? 2u : 1u) + 1u; maxp = want < MCRX_SPEC_MAX ? want : MCRX_SPEC_MAX; }
-                }
-                for (; npred < maxp && p < limit; p += P, p2 += P_old) {
-                    if (l == 0) a.pred[(size_t)ch * MCRX_SPEC_MAX + npred] = spec_key(p, (uint32_t)L);
-                    npred++;
-                    if (two && p2 != p && p2 < limit && npred < maxp) {
-                        if (l == 0) a.pred[(size_t)ch * MCRX_SPEC_MAX + npred] = spec_key(p2, (uint32_t)L);
-                        npred++;
-                    }
-                }
-            }
-            if (l == 0) { a.pred_n[ch] = npred; if (a.spec_hint && npred > *a.spec_hint) *a.spec_hint = npred; }
-            if ((a.debug & 4) && l == 0) printf("[spec] ch %u predictions %u adopted %u walked %u stopped %d spec_cap %u\n", ch, npred, nadopted, nwalked, (int)stopped, a.spec_cap);
+        if (fresh_last >= 0) {
+            if (fresh_prev >= 0 && fresh_last - fresh_prev < (int64_t)0x7fffffff) s.period_hint = (uint32_t)(fresh_last - fresh_prev);
+            s.last_fresh = fresh_last;
         }
+        if ((a.debug & 4) && l == 0) printf("[seg] ch %u adopted %u walked %u (slots %u in %u segments)\n", ch, nadopted, nwalked, a.spec_cap, a.nseg);
         // a header in progress continues in the next launch: its bits move from LDS to the channel's HBM slot
         if (fastp && s.state == SY_RX && s.fstate == FX_HEADER && s.header_symbol_index > 0)
             for (int i = l; i < MCRX_HDR_SYMS; i += WV) bhbits[i] = ldshb[i];
@@ -2058,12 +2163,14 @@ __device__ __forceinline__ void launder(SyncArgs &a)
     LAUNDER(chan); LAUNDER(st); LAUNDER(hbits); LAUNDER(R); LAUNDER(soft); LAUNDER(tmpa); LAUNDER(tmpb);
     LAUNDER(syms); LAUNDER(rec); LAUNDER(arena); LAUNDER(sarena); LAUNDER(nrec); LAUNDER(arena_used);
     LAUNDER(jobs); LAUNDER(njobs); LAUNDER(jR); LAUNDER(jsoft); LAUNDER(jtmp); LAUNDER(vit_list); LAUNDER(qam_list);
-    LAUNDER(spec); LAUNDER(spec_R); LAUNDER(pred); LAUNDER(pred_n); LAUNDER(stats); LAUNDER(walk_hint);
+    LAUNDER(spec); LAUNDER(spec_R); LAUNDER(pred); LAUNDER(pred_n); LAUNDER(stats); LAUNDER(walk_hint); LAUNDER(anchor);
 }
 #undef LAUNDER
 
-#if SY_PART == 3
-#define SY_ACQ_WAVES 3
+#if defined(SY_ACQ_WAVES_OVERRIDE)
+#define SY_ACQ_WAVES SY_ACQ_WAVES_OVERRIDE
+#elif SY_PART == 3
+#define SY_ACQ_WAVES 2
 #else
 #define SY_ACQ_WAVES 1
 #endif
@@ -2126,16 +2233,17 @@ __global__ __launch_bounds__(WV * SY_WALK_WPB) void sync_walk_kernel(SyncArgs a)
     w.template run<SYM_LEAN>();
 }
 
-// speculative acquisition: one wave per (channel, predicted position); lean path only
+// segment-parallel acquisition: one wave per (channel, segment of the push); lean path only.  Segments of one channel are
+// neighbours in the grid, so the waves that re-read the frame at a segment boundary share an XCD's L2 more often than not.
 template <int E>
 __global__ __launch_bounds__(WV, SY_ACQ_WAVES) void sync_spec_kernel(SyncArgs a)
 {
     __builtin_amdgcn_s_setprio(3);      // a chain of dependent events every payload launch waits for: win the issue arbitration against the workers sharing the SIMD
     launder(a);
-    const uint32_t ch = blockIdx.x / a.spec_cap, k = blockIdx.x % a.spec_cap;
+    const uint32_t ch = a.seg_phase == 1 ? blockIdx.x : blockIdx.x / a.nseg, g = a.seg_phase == 1 ? 0u : blockIdx.x % a.nseg;
     if (ch >= a.nch) return;
     Walker<E> w(a, ch);
-    w.run_spec(k);
+    w.run_seg(g);
 }
 
 // one wave per handed-off frame.  Two builds: the lean symbol loop (power-of-two M >= 64, <= 64
@@ -2720,7 +2828,8 @@ __global__ __launch_bounds__(PJ_T) void place_jobs_kernel(SyncArgs a)
         // and sets its acquisition policy by them (mcrx_hip.hip launch_sync)
         volatile uint32_t *h = a.walk_hint;
         h[0] = a.stats[0]; h[1] = a.stats[1]; h[2] = a.stats[4]; h[3] = a.stats[5];
-        h[4] = a.stats[6]; a.stats[6] = 0;      // the last round of THIS launch in which a scout had to stop (0: none): per launch, not cumulative
+        h[4] = a.stats[6]; a.stats[6] = 0;
+        h[5] = nj;                              // hand-offs of THIS launch: frames per channel and push, which sizes the next launches' segments
         __threadfence_system();
     }
     __shared__ uint32_t nqam;
@@ -2963,8 +3072,8 @@ hipError_t sync_launch_tail(const SyncArgs &a, hipStream_t st)
 
 hipError_t sync_launch_spec(const SyncArgs &a, hipStream_t st)
 {
-    if (a.nch == 0 || a.spec_cap == 0) return hipSuccess;
-    return sy_launch(SYK_SPEC, a, a.nch * a.spec_cap, SY_LDS_BYTES(a.c.M), st);
+    if (a.nch == 0 || a.spec_cap == 0 || a.nseg == 0) return hipSuccess;
+    return sy_launch(SYK_SPEC, a, a.seg_phase == 1 ? a.nch : a.nch * a.nseg, SY_LDS_BYTES(a.c.M), st);
 }
 
 // bytes of LDS a frame's soft bits get in this push's decode launch: 8 per coded byte, at most 56 KiB (longer frames

@@ -12,15 +12,15 @@ prod = load_product()
 dev = torch.device("cuda", 0)
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 N, M, cp, world = 512, 64, 8, int(os.environ.get("MG_WORLD", "8"))
-K, cg, TILE = 2 * N, N // world, 8
+K, cg, TILE = 2 * N, N // world, prod.TILE
 tx = prod.multichanneltx(N, M, cp, 4)
 iq, sent = tx.generate(frames, 1200, seed=0xC0FFEE, device=dev)
 torch.cuda.synchronize(); tx.close()
-T = iq.numel() // K // 8 * 8
+T = iq.numel() // K // TILE * TILE
 rx = prod.multichannelrx(N, M, cp, 4, max_payload_len=1200, channel_first=0, channel_count=cg, max_frames=cg * frames * world + 64, defer_samples=16384)
-out = torch.empty(world * (T // 8) * cg * 8, dtype=torch.complex64, device=dev)
+out = torch.empty(world * T * cg, dtype=torch.complex64, device=dev)
 rx.channelize(iq[:T * K], T, 0, out, groups=world)
-per = (T // 8) * cg * 8
+per = T * cg
 hist = rx.hist_tiles
 he = hist * cg * TILE
 bufs = []
@@ -34,7 +34,7 @@ def rnd(c):
     rx.sync(bufs[c % 3], c * world * T - hist * TILE, hist * TILE + world * T)
     rx.Discard()
 c = 0
-for _ in range(int(os.environ.get('MG8_WARM', '48'))): rnd(c); c += 1
+for _ in range(int(os.environ.get('MG8_WARM', '6'))): rnd(c); c += 1
 torch.cuda.synchronize(); rx.kernel_stats(reset=True); rx.spec_stats(reset=True)
 n = 24
 t0 = time.perf_counter()
