@@ -134,13 +134,16 @@ struct PayloadJob {
 // slot matches (a timing that locked differently, an invalid header, an idle stretch) the scout walks on by itself --
 // slower, never different.  Nothing depends on the traffic having a cadence.
 #define MCRX_SPEC_MAX 256
+// A segment wave writes its hand-offs straight into the launch's job list -- synchronizer state, equaliser, everything a payload
+// worker needs -- but with the owner field void (PayloadJob::ch = ~0: workers, placement and decoder skip such entries, as they skip
+// a reservation that came to nothing); the scout makes a frame real by storing the channel number there.  Nothing is copied.
 struct SpecSlot {
     int64_t start;              // the state it was acquired from: next sample | timer << 48 | state << 61 (spec_key); -1: none
-    int64_t t_last;             // status 1: event index of the frame's last payload symbol; status 2: the SEEK position the frame was detected from
-    int32_t status;             // 1: frame acquired and handed off (job valid); 2: frame acquired, but its payload runs past the end of the
-                                //    buffer and the next push still holds its beginning: the scout goes back to (t_last, pad) -- deferred; 0: nothing usable
-    uint32_t pad;               // status 2: the timer of that SEEK state
-    PayloadJob job;
+    int64_t t_last;             // status 1, 3: event index of the frame's last payload symbol / of its failed header; status 2: the SEEK position the frame was detected from
+    int32_t status;             // 1: frame acquired and handed off (its job list entry: pad); 2: frame acquired, but its payload runs past the end of
+                                //    the buffer and the next push still holds its beginning: the scout goes back to (t_last, pad) -- deferred;
+                                //    3: header decoded, check failed: the scout writes the record (state in job list entry pad); 0: nothing usable
+    uint32_t pad;               // status 1, 3: job list entry; status 2: the timer of that SEEK state
 };
 
 struct SyncArgs {
@@ -181,16 +184,26 @@ struct SyncArgs {
     // 0.15-0.27 ms on the work stream.  The kernels walk their lists with a grid stride, so any grid is correct; the host
     // sizes it from what the most recent launch published here (list_hint, host-mapped) and keeps a floor for the first
     // frames of a kind it has not seen yet.
-    uint32_t *qam_list;         // [0] = hand-offs with a 16- / 64-QAM payload, [1 ..] their job indices (place_jobs_kernel)
+    uint32_t *qam_list;         // [0] = hand-offs with a 16- / 64-QAM payload, [1 ..] their job indices (filled by the scouts: Walker::place_owned)
+    uint32_t *qam_next;         // the next launch's list: its count is zeroed by this launch's housekeeping kernel
+    // The job list has holes (entries of frames the segment waves acquired for nothing, blocks not used up, void reservations): workers and
+    // decoders go by the list of entries that got an owner, live[0] = count, live[1 ..] = job list entries (filled by the scouts a
+    // block per channel: Walker::place_owned), with a grid stride -- the host sizes their grids from the frames of the most recent
+    // launch (frames_hint) instead of the list's capacity
+    uint32_t *live, *live_next;
+    uint32_t frames_hint;       // ~0: unknown
+    uint32_t live_off;          // lean workers: the main launch's grid (payload_lean.hpp, REST)
     uint32_t *list_hint;        // [0] QAM hand-offs, [1] trellis blocks, [2] frames on the general list, of the most recent launch
     uint32_t grid_hint[3];      // what the host last read there (~0: no hint, full grids)
     uint32_t payload_lds_pad;  // bytes of unused dynamic LDS per payload worker: caps the workers' occupancy (walk mode, launch_sync)
     int seek_burst;            // idle stretches: SEEK events four at a time, their windows requested together (Walker::seek_burst)
     // speculation (see SpecSlot)
-    SpecSlot *spec; float2 *spec_R;      // [nch][MCRX_SPEC_MAX], [nch][MCRX_SPEC_MAX][M]
+    SpecSlot *spec; float2 *spec_R;      // [nch][MCRX_SPEC_MAX]; [nch][MCRX_SEG_MAX][M]: a segment wave's equaliser between the S1 fit and the hand-off
+#define MCRX_SEG_MAX 128
     int64_t *pred; uint32_t *pred_n;     // predicted fresh-state positions for the next launch: [nch][MCRX_SPEC_MAX], [nch]
     uint32_t spec_cap;                   // slots per channel the segment waves fill in this launch = nseg * (slots per wave) (0: off)
     uint32_t nseg;                       // segment waves per channel
+    uint32_t seg_jobs;                   // job list entries a segment wave reserves at a time (the frames it is expected to hand off)
     // The two wasted acquisitions of a segment (its first frame from an arbitrary state, the frame that links it to the next
     // segment) disappear where the traffic HAS a cadence: phase 1 (one wave per channel) acquires the first frame of the push from
     // the channel's real state and leaves the position it ends at in anchor[ch]; phase 2 starts segment g in the exact fresh

@@ -146,6 +146,7 @@ struct mcrx_hip_s {
     // synchronizer bank
     unsigned ch_first = 0, nch = 0;
     uint32_t max_payload = 0, max_enc = 0, max_syms = 0, max_rec = 0;
+    uint32_t max_jobs = 0;                  // job list entries per launch: the frames (max_rec) + the entries the segment waves fill for nothing (two per segment) + void reservations
     uint64_t arena_cap = 0;
     ChanState *d_st = nullptr; uint8_t *d_hbits = nullptr; float2 *d_R = nullptr;
     uint8_t *d_soft = nullptr, *d_tmpa = nullptr, *d_tmpb = nullptr; float2 *d_syms = nullptr;
@@ -164,7 +165,7 @@ struct mcrx_hip_s {
     uint64_t sarena_cap = 0;
     // per-launch slots
     PayloadJob *d_jobs[MCRX_SLOTS] = {}; uint32_t *d_njobs = nullptr; float2 *d_jR[MCRX_SLOTS] = {};
-    uint32_t *d_gen[MCRX_SLOTS] = {}, *d_vit[MCRX_SLOTS] = {}, *d_qam[MCRX_SLOTS] = {}; uint32_t vit_cap = 0;
+    uint32_t *d_gen[MCRX_SLOTS] = {}, *d_vit[MCRX_SLOTS] = {}, *d_qam[MCRX_SLOTS] = {}, *d_live[MCRX_SLOTS] = {}; uint32_t vit_cap = 0;
     uint64_t seq = 0;                       // synchronizer launches so far (slot = seq % nslots)
     unsigned nslots = 5;                    // buffer sets in use: the channelizer and the acquisition chain of up to nslots - 1 pushes run ahead of the payload workers
     uint32_t *d_stats = nullptr;            // speculation statistics (SyncArgs::stats)
@@ -517,25 +518,27 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
         if (hipHostGetDevicePointer((void **)&q->d_hint, q->h_hint, 0) != hipSuccess) q->d_hint = nullptr;
     }
     if (q->scout) {
+        q->max_jobs = 2 * q->max_rec + 4 * q->nch + 1024;
         for (unsigned sl = 0; sl < q->nslots; sl++) {
-            if ((rc = q->alloc(&q->d_jobs[sl], q->max_rec))) return bail(rc);
-            if ((rc = q->alloc(&q->d_gen[sl], (size_t)q->max_rec + 1))) return bail(rc);
-            if ((rc = q->alloc(&q->d_qam[sl], (size_t)q->max_rec + 1))) return bail(rc);
+            if ((rc = q->alloc(&q->d_jobs[sl], q->max_jobs))) return bail(rc);
+            if ((rc = q->alloc(&q->d_gen[sl], (size_t)q->max_jobs + 1))) return bail(rc);
+            if ((rc = q->alloc(&q->d_qam[sl], (size_t)q->max_jobs + 1))) return bail(rc);
+            if ((rc = q->alloc(&q->d_live[sl], (size_t)q->max_jobs + 1))) return bail(rc);
             q->vit_cap = (uint32_t)std::min<uint64_t>((uint64_t)q->max_rec * ((4ull * q->max_enc + 6 + 959) / 960), 1u << 24);      // trellis blocks of every frame of a launch
             if ((rc = q->alloc(&q->d_vit[sl], (size_t)q->vit_cap + 1))) return bail(rc);
-            if ((rc = q->alloc(&q->d_jR[sl], (size_t)q->max_rec * M))) return bail(rc);
-            if ((rc = q->alloc(&q->d_jsoft[sl], (size_t)q->max_rec * 8 * q->max_enc))) return bail(rc);
-            if ((rc = q->alloc(&q->d_jtmp[sl], (size_t)q->max_rec * 2 * (q->max_enc + 16)))) return bail(rc);
+            if ((rc = q->alloc(&q->d_jR[sl], (size_t)q->max_jobs * M))) return bail(rc);
+            if ((rc = q->alloc(&q->d_jsoft[sl], (size_t)q->max_jobs * 8 * q->max_enc))) return bail(rc);
+            if ((rc = q->alloc(&q->d_jtmp[sl], (size_t)q->max_jobs * 2 * (q->max_enc + 16)))) return bail(rc);
         }
         // speculative acquisition (lean path only): slots, their equalisers, the prediction lists
         const bool lean = q->sc.log2M >= 6 && q->sc.M == 64 * q->sc.E && q->sc.M_pilot <= 64;
         q->spec = lean && q->d_hint && getenv("MCRX_NO_SPEC") == nullptr;
-        if (getenv("MCRX_NSEG")) q->nseg_fixed = (uint32_t)std::max(1, std::min(MCRX_SPEC_MAX / 2, atoi(getenv("MCRX_NSEG"))));           // experiments: segments per channel, fixed
+        if (getenv("MCRX_NSEG")) q->nseg_fixed = (uint32_t)std::max(1, std::min(MCRX_SEG_MAX, atoi(getenv("MCRX_NSEG"))));           // experiments: segments per channel, fixed
         if (getenv("MCRX_SEG_FRAMES")) q->seg_frames = (uint32_t)std::max(1, std::min(64, atoi(getenv("MCRX_SEG_FRAMES"))));            // ... or frames per segment aimed at
         if (getenv("MCRX_LEAN_BUILD")) q->lean_build = atoi(getenv("MCRX_LEAN_BUILD"));
         if (q->spec) {
             if ((rc = q->alloc(&q->d_spec, (size_t)q->nch * MCRX_SPEC_MAX))) return bail(rc);
-            if ((rc = q->alloc(&q->d_spec_R, (size_t)q->nch * MCRX_SPEC_MAX * M))) return bail(rc);
+            if ((rc = q->alloc(&q->d_spec_R, (size_t)q->nch * MCRX_SEG_MAX * M))) return bail(rc);
             if ((rc = q->alloc(&q->d_anchor, q->nch))) return bail(rc);
         }
     }
@@ -665,11 +668,15 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     a.payload_lds_pad = q->acq_mode == 2 ? q->walk_lds_pad : q->round_lds_pad;
     a.vit_off = 0;
     a.scout = q->scout ? 1 : 0;
-    a.jobs = q->d_jobs[slot]; a.njobs = q->d_njobs + slot; a.njobs_next = q->d_njobs + next; a.max_jobs = q->max_rec;
+    a.jobs = q->d_jobs[slot]; a.njobs = q->d_njobs + slot; a.njobs_next = q->d_njobs + next; a.max_jobs = q->max_jobs;
     a.gen_list = q->d_gen[slot]; a.dec_lds_soft = 0; a.vit_list = q->d_vit[slot]; a.vit_cap = q->vit_cap;
-    a.qam_list = q->d_qam[slot]; a.list_hint = nullptr;
+    a.qam_list = q->d_qam[slot]; a.qam_next = q->d_qam[next]; a.list_hint = nullptr;
+    a.live = q->d_live[slot]; a.live_next = q->d_live[next];
+    a.live_off = 0;
+    a.frames_hint = (q->h_hint && q->d_hint) ? ((volatile uint32_t *)q->h_hint)[7] : ~0u;
+    if (a.frames_hint == 0) a.frames_hint = ~0u;                 // (a launch without frames says nothing about the next)
     for (int i = 0; i < 3; i++) a.grid_hint[i] = ~0u;
-    if (q->h_hint && q->d_hint && q->pipelined) {        // (sticky for a while: a list that was non-empty within the last 64 launches keeps its full grid)
+    if (q->h_hint && q->d_hint) {                        // (sticky for a while: a list that was non-empty within the last 64 launches keeps its full grid)
         a.list_hint = q->d_hint + 8;
         for (int i = 0; i < 3; i++) {
             const uint32_t v = ((volatile uint32_t *)q->h_hint)[8 + i];
@@ -681,7 +688,7 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     a.stats = q->d_stats;
     a.hint = q->d_hint; a.enc_hint = (q->h_hint && q->d_hint) ? *(volatile uint32_t *)q->h_hint : 0u;
     a.spec = q->d_spec; a.spec_R = q->d_spec_R; a.pred = nullptr; a.pred_n = nullptr; a.spec_cap = 0; a.spec_hint = nullptr; a.walk_hint = nullptr;
-    a.nseg = 0; a.seg_phase = 0; a.anchor = nullptr;
+    a.nseg = 0; a.seg_phase = 0; a.anchor = nullptr; a.seg_jobs = 1;
     hipStream_t sa = st, sw = st;
     // The host never waits for the device on this path (slots are handed over by stream waits), so a free-running caller
     // can be any number of launches ahead -- and the hints the kernels leave for the next launch (widest prediction list,
@@ -726,7 +733,7 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
             if (want > room) want = room;
             nseg = want < 1.0f ? 1u : (want > 32.0f ? 32u : (uint32_t)(want + 0.5f));
         }
-        if (nseg > MCRX_SPEC_MAX / 2) nseg = MCRX_SPEC_MAX / 2;
+        if (nseg > MCRX_SEG_MAX) nseg = MCRX_SEG_MAX;
         // The anchor phase (kernels.h, SyncArgs::seg_phase) is one more launch and one frame's latency in front of everything else: worth it
         // while most frames follow their predecessor at the distance of the pair before (the scouts count both, place_jobs_kernel
         // copies the totals to host-mapped words), useless on traffic without a cadence.  Windows of 8 launches; MCRX_ACQ_MODE=3 / 1 pins it.
@@ -740,14 +747,21 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
         if (q->acq_mode == 3) q->cadenced = true;
         q->last_nsamp = nsamp;
         a.nseg = nseg; a.spec_cap = nseg * (MCRX_SPEC_MAX / nseg);
+        { const float Fq = q->frames_per_push > 0.f ? q->frames_per_push : (float)nsamp / 16384.0f;
+          const float per = Fq / (float)nseg + 2.0f;                     // its share of the channel's frames + the two at the segment's ends
+          a.seg_jobs = per < 2.0f ? 2u : (per > 32.0f ? 32u : (uint32_t)(per + 0.999f));
+          // ... and all the first blocks together leave the scouts' own hand-offs and second blocks half of the list
+          const uint32_t room = q->max_jobs / 2 / (q->nch * nseg);
+          if (a.seg_jobs > room) a.seg_jobs = room ? room : 1u; }
         a.walk_hint = q->d_hint ? q->d_hint + 2 : nullptr;
         if (a.debug & 4) fprintf(stderr, "[host] launch %llu: %u segments per channel, %.1f frames per channel and push expected\n", (unsigned long long)q->seq, nseg, q->frames_per_push);
         a.anchor = q->d_anchor;
         if (q->acq_mode == 2) a.spec_cap = 0;                        // (MCRX_ACQ_MODE=2: no segment waves, the scouts walk everything)
         else if (q->acq_mode == 1 || nseg == 1 || (q->acq_mode == 0 && !q->cadenced)) { a.seg_phase = 0; HIPCHK(sync_launch_spec(a, sa)); }     // one launch, coarse starts
         else {
-            a.seg_phase = 1; HIPCHK(sync_launch_spec(a, sa));        // the first frame of every channel, from its real state: the cadence's anchor
-            a.seg_phase = 2; HIPCHK(sync_launch_spec(a, sa));        // everything behind it, segment-parallel
+            const uint32_t sj = a.seg_jobs;
+            a.seg_phase = 1; a.seg_jobs = 1; HIPCHK(sync_launch_spec(a, sa));        // the first frame of every channel, from its real state: the cadence's anchor
+            a.seg_phase = 2; a.seg_jobs = sj; HIPCHK(sync_launch_spec(a, sa));       // everything behind it, segment-parallel
         }
         a.seg_phase = 0;
         if (q->lean_build == 1) HIPCHK(sync_launch_walk(a, sa)); else HIPCHK(sync_launch_lean(a, sa));
@@ -1124,7 +1138,9 @@ static int collect(mcrx_hip_t q, int g)
           if (want_syms && used[1]) HIPCHK(hipMemcpyAsync(q->sarena_host.p + sbase, q->d_sarena[g], (size_t)used[1], hipMemcpyDeviceToHost, q->s_copy));
           HIPCHK(hipStreamSynchronize(q->s_copy));
           q->t_d2h += now_s() - t1; q->b_d2h += (double)used[0] + (want_syms ? (double)used[1] : 0.0); }
-        for (size_t i = r0; i < r0 + n; i++) {
+        // (record slots of frames that found no room in an arena stay unfilled: Walker::place_owned marks them)
+        q->recs.erase(std::remove_if(q->recs.begin() + r0, q->recs.end(), [](const FrameRec &r) { return r.channel == 0xFFFFFFFFu; }), q->recs.end());
+        for (size_t i = r0; i < q->recs.size(); i++) {
             q->recs[i].payload_off += base;
             if (want_syms) q->recs[i].syms_off += sbase; else q->recs[i].num_framesyms = 0;
         }

@@ -640,9 +640,9 @@ extern __shared__ __attribute__((aligned(16))) float2 sy_lds[];
 #define ldshm (reinterpret_cast<uint16_t *>(ldsps + 256))                      /* header bit map [288]  */
 #define ldshb (ldsps + 256 + 2 * MCRX_HDR_SYMS)                                /* header bits, decoded order [288] */
 #define ldshd (reinterpret_cast<uint16_t *>(ldsps + 256 + 3 * MCRX_HDR_SYMS))   /* Golay-decoded 12-bit words [12] */
-#define ldsad (ldsps + 256 + 3 * MCRX_HDR_SYMS + 32)                            /* adopted speculative slots [MCRX_SPEC_MAX] */
-#define ldsqn (ldsad + MCRX_SPEC_MAX)                                             /* QAM neighbour table of the frame's modem [256] */
-#define SY_LDS_BYTES(M) ((((size_t)(M) * 8 + (size_t)(M) * 12 + 256 + 3 * MCRX_HDR_SYMS + 32 + MCRX_SPEC_MAX + 256) + 15) & ~(size_t)15)
+#define ldsad (reinterpret_cast<uint32_t *>(ldsps + 256 + 3 * MCRX_HDR_SYMS + 32)) /* job list entries of the adopted frames [MCRX_SPEC_MAX] */
+#define ldsqn (ldsps + 256 + 3 * MCRX_HDR_SYMS + 32 + 4 * MCRX_SPEC_MAX)        /* QAM neighbour table of the frame's modem [256] */
+#define SY_LDS_BYTES(M) ((((size_t)(M) * 8 + (size_t)(M) * 12 + 256 + 3 * MCRX_HDR_SYMS + 32 + 4 * MCRX_SPEC_MAX + 256) + 15) & ~(size_t)15)
 
 // One wavefront per workgroup: LDS traffic of a wave is processed in order, so a compiler-level
 // fence is all the hand-off between lanes needs (no s_barrier, and no vmcnt(0) drain of the
@@ -688,6 +688,7 @@ struct Walker {
     unsigned long long pre_soff;    // ... its framesyms in the symbol arena
     uint32_t pre_idx;           // ... and its record slot
     int64_t handoff_last;       // scout: last event index of the frame just handed off
+    uint32_t handoff_job;       // segment wave: its job list entry
     uint32_t jres;              // scout: job slot reserved at frame detection (0xFFFFFFFF: none)
     SpecSlot *slot;             // != nullptr: this wave acquires speculatively into this slot (no side effects elsewhere)
     int64_t pf_t; float2 pf_x[E];   // scout: lookahead window (first sample, raw samples)
@@ -1048,14 +1049,38 @@ struct Walker {
     // scout: hand the payload of the frame whose header was just decoded to a worker wave
     // if every payload symbol is already in the buffer.  Returns false to keep walking serially.
     // speculative wave: park the hand-off in the slot (R already sits in the slot's bR); no atomics, no records
+    // segment wave: the hand-off goes into the job list at once, owner void (kernels.h, SpecSlot); no records, no channel state
     __device__ __forceinline__ bool try_handoff_spec(int64_t t_ev)
     {
         const int64_t nsym = (int64_t)((s.mod_len + (uint32_t)c.M_data - 1) / (uint32_t)c.M_data);
         const int64_t t_last = t_ev + nsym * (int64_t)c.L;
         if (s.enc_len > c.max_enc_len || s.mod_len > c.max_syms || s.payload_len > c.max_payload_len || t_last >= a.end) return false;
-        if (l == 0) { PayloadJob jb; jb.s = s; jb.ch = ch; jb.pad = 0; jb.arena_off = 0; jb.syms_off = 0; slot->job = jb; }
-        handoff_last = t_last;
+        const uint32_t j = park_state();
+        if (j == 0xFFFFFFFFu) return false;
+#pragma unroll
+        for (int e = 0; e < E; e++) if (k[e] >= 0) a.jR[(size_t)j * c.M + k[e]] = R[e];
+        handoff_job = j; handoff_last = t_last;
         return true;
+    }
+    // ... the synchronizer state into a job list entry nobody owns yet (the one reserved at S1, or a new one); ~0: the list is full
+    // Job list entries come in blocks: one atomic on the launch's counter per a.seg_jobs frames of a wave instead of one per frame
+    // (8192 waves queueing on one address cost the acquisition 30 us), requested when the wave starts, so that its round trip is
+    // long over when the first frame is handed off.  What a wave leaves of its last block is voided (run_seg).
+    uint32_t jblk_next = 0, jblk_end = 0;
+    __device__ __forceinline__ void reserve_block()
+    {
+        const uint32_t nb = a.seg_jobs ? a.seg_jobs : 1u;
+        uint32_t b = 0;
+        if (l == 0) b = atomicAdd(a.njobs, nb);
+        jblk_next = (uint32_t)__shfl((int)b, 0, WV); jblk_end = jblk_next + nb;
+    }
+    __device__ __forceinline__ uint32_t park_state()
+    {
+        if (jblk_next == jblk_end) reserve_block();
+        const uint32_t j = jblk_next++;
+        if (j >= a.max_jobs) return 0xFFFFFFFFu;
+        if (l == 0) { PayloadJob jb; jb.s = s; jb.ch = 0xFFFFFFFFu; jb.pad = 0; jb.arena_off = 0; jb.syms_off = 0; a.jobs[j] = jb; }
+        return j;
     }
     __device__ __forceinline__ bool try_handoff(int64_t t_ev)
     {
@@ -1078,9 +1103,11 @@ struct Walker {
         for (int e = 0; e < E; e++) if (k[e] >= 0) a.jR[(size_t)j * c.M + k[e]] = R[e];
         if (l == 0) {
             PayloadJob jb;
-            jb.s = s; jb.ch = ch; jb.pad = 0; jb.arena_off = 0; jb.syms_off = 0;
+            jb.s = s; jb.ch = 0xFFFFFFFFu; jb.pad = 0; jb.arena_off = 0; jb.syms_off = 0;      // (owner and record space: place_owned)
             a.jobs[j] = jb;
         }
+        if (l == 0) ldsad[nown] = j;            // (room for one: run() empties the list before it is full)
+        nown++;
         handoff_last = t_last;
         return true;
     }
@@ -1088,10 +1115,15 @@ struct Walker {
     // under the header symbols; a frame that ends up not handed off gives the slot back as void.
     __device__ __forceinline__ void reserve_job()
     {
-        if (!a.scout || slot || jres != 0xFFFFFFFFu) return;
+        if (!a.scout || slot || jres != 0xFFFFFFFFu) return;       // (segment waves take their entries from blocks: park_state)
         uint32_t j = 0;
         if (l == 0) j = atomicAdd(a.njobs, 1u);
         jres = (uint32_t)__shfl((int)j, 0, WV);
+    }
+    __device__ __forceinline__ void void_block()
+    {
+        for (uint32_t q = jblk_next + (uint32_t)l; q < jblk_end; q += WV) if (q < a.max_jobs) a.jobs[q].ch = 0xFFFFFFFFu;
+        jblk_next = jblk_end;
     }
     __device__ __forceinline__ void void_reservation()
     {
@@ -1765,6 +1797,7 @@ struct Walker {
     // serial chain waits for memory because of an adoption.
     static constexpr int SPH = MCRX_SPEC_MAX / WV;          // slot headers per lane
     int64_t sp_start[SPH]; int32_t sp_tlast[SPH]; uint32_t sp_aux[SPH]; uint32_t nadopted; uint32_t nwalked = 0;
+    uint32_t nown = 0;              // job list entries noted in ldsad: this channel's frames of the launch, not placed yet
     int64_t sk_cur = 0; uint32_t sk_timer = 0;      // lean scout: the SEEK state before the last seek event (where a frame is re-acquired from if deferred)
     __device__ __forceinline__ void load_spec_headers()
     {
@@ -1798,43 +1831,69 @@ struct Walker {
         aux = (uint32_t)__shfl((int)ax, hl, WV);
         kslot = (uint32_t)(hl + WV * hh);
         if ((aux & 0xffu) == 1u) {
-            if (l == 0) ldsad[nadopted] = (uint8_t)(hl + WV * hh);
-            nadopted++;
+            if (l == 0) ldsad[nown] = aux >> 8;
+            nown++; nadopted++;
         }
         return true;
     }
-    __device__ __forceinline__ void publish_adopted()
+    // The channel's frames of this launch become real: their job list entries (written by segment waves, or by this scout's own
+    // hand-offs) get their owner, and record space -- payload bytes, equalised symbols, a record slot -- out of ONE reservation per
+    // channel and launch: a wave-level prefix sum of the frames' sizes, then one atomic per arena.  (Rounds 1-3 placed all frames of a
+    // launch in one workgroup between the scouts and the workers: 45 us on every push's critical chain.)  Frames of a block that
+    // runs past the end of a pool are counted as dropped.
+    __device__ __forceinline__ void place_owned()
     {
-        static_assert(sizeof(PayloadJob) / 4 <= WV, "one job word per lane");
-        if (!nadopted) return;
+        if (!nown) return;
         wave_sync_lds();
-        uint32_t j0 = 0;
-        if (l == 0) j0 = atomicAdd(a.njobs, nadopted);             // one block of job slots for all of them
-        j0 = (uint32_t)__shfl((int)j0, 0, WV);
-        const SpecSlot *sl = a.spec + (size_t)ch * MCRX_SPEC_MAX;
-        uint32_t lost = 0;
-        for (uint32_t i0 = 0; i0 < nadopted; i0 += 4) {            // four frames' loads in flight
-            uint32_t w[4]; float2 r[4][E]; uint32_t jj[4];
+        constexpr int PO = MCRX_SPEC_MAX / WV;
+        uint32_t jj[PO], p16[PO]; unsigned long long sb[PO];
+        unsigned long long mine_s = 0; uint32_t mine_p = 0, mine_n = 0, menc = 0;
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint32_t i = i0 + u < nadopted ? i0 + u : nadopted - 1;
-                const uint32_t k = ldsad[i];
-                jj[u] = i0 + u < nadopted ? j0 + i : 0xFFFFFFFFu;
-                w[u] = ((uint32_t)l < sizeof(PayloadJob) / 4) ? reinterpret_cast<const uint32_t *>(&sl[k].job)[l] : 0u;
-                const float2 *rs = a.spec_R + ((size_t)ch * MCRX_SPEC_MAX + k) * c.M;
-#pragma unroll
-                for (int e = 0; e < E; e++) r[u][e] = (l + WV * e < c.M) ? rs[l + WV * e] : make_float2(0.f, 0.f);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (jj[u] == 0xFFFFFFFFu) continue;
-                if (jj[u] >= a.max_jobs) { lost++; continue; }     // job list (= record pool) full: counted as dropped
-                if ((uint32_t)l < sizeof(PayloadJob) / 4) reinterpret_cast<uint32_t *>(&a.jobs[jj[u]])[l] = w[u];
-#pragma unroll
-                for (int e = 0; e < E; e++) if (l + WV * e < c.M) a.jR[(size_t)jj[u] * c.M + l + WV * e] = r[u][e];
-            }
+        for (int u = 0; u < PO; u++) {                          // lane l takes entries l*PO .. l*PO+PO-1: offsets grow with the list
+            const uint32_t i = (uint32_t)l * PO + u;
+            const bool v = i < nown;
+            jj[u] = v ? ldsad[i] : 0xFFFFFFFFu;
+            const PayloadJob *q = a.jobs + (v ? jj[u] : 0u);
+            const uint32_t ml = q->s.mod_len, pl = q->s.payload_len, el = q->s.enc_len, md = q->s.mod_scheme;
+            sb[u] = v ? 8ull * ml : 0ull; p16[u] = v ? (pl + 15u) >> 4 : 0u;
+            mine_s += sb[u]; mine_p += p16[u]; mine_n += v ? 1u : 0u;
+            if (v && el > menc) menc = el;
+            if (v && a.qam_list && md != 39u && md != 40u) { const uint32_t at = atomicAdd(a.qam_list, 1u); if (at < a.max_jobs) a.qam_list[1u + at] = jj[u]; }
         }
-        if (lost && l == 0) atomicAdd(a.nrec + 1, lost);
+        // exclusive prefix over the lanes
+        unsigned long long ex_s = mine_s; uint32_t ex_p = mine_p, ex_n = mine_n;
+#pragma unroll
+        for (int d = 1; d < WV; d <<= 1) {
+            const unsigned long long ts = (unsigned long long)__shfl_up((long long)ex_s, d, WV); const uint32_t tp = (uint32_t)__shfl_up((int)ex_p, d, WV), tn = (uint32_t)__shfl_up((int)ex_n, d, WV);
+            if (l >= d) { ex_s += ts; ex_p += tp; ex_n += tn; }
+        }
+        const unsigned long long tot_s = (unsigned long long)__shfl((long long)ex_s, WV - 1, WV); const uint32_t tot_p = (uint32_t)__shfl((int)ex_p, WV - 1, WV), tot_n = (uint32_t)__shfl((int)ex_n, WV - 1, WV);
+        ex_s -= mine_s; ex_p -= mine_p; ex_n -= mine_n;
+#pragma unroll
+        for (int h = 32; h >= 1; h >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)menc, h, WV); menc = o > menc ? o : menc; }
+        // (nothing is ever given back: a counter that moves both ways under concurrent reservations hands the same bytes out twice.
+        //  A block that runs past the end of a pool is used as far as it fits; the counters may end up beyond the capacities, which
+        //  the harvest clamps, and the pool stays exhausted until then)
+        unsigned long long b_s = 0, b_p = 0; uint32_t b_r = 0, b_l = 0;
+        if (l == 0) {
+            b_p = atomicAdd(a.arena_used, 16ull * tot_p); b_s = atomicAdd(a.arena_used + 1, tot_s); b_r = atomicAdd(a.nrec, tot_n);
+            b_l = atomicAdd(a.live, tot_n);
+            if (menc && a.stats) atomicMax(a.stats + 7, menc);
+        }
+        b_p = (unsigned long long)__shfl((long long)b_p, 0, WV); b_s = (unsigned long long)__shfl((long long)b_s, 0, WV); b_r = (uint32_t)__shfl((int)b_r, 0, WV); b_l = (uint32_t)__shfl((int)b_l, 0, WV);
+        unsigned long long os = b_s + ex_s, op = b_p + 16ull * ex_p; uint32_t r = b_r + ex_n, lv = b_l + ex_n, lost = 0;
+#pragma unroll
+        for (int u = 0; u < PO; u++) if (jj[u] != 0xFFFFFFFFu) {
+            PayloadJob *q = a.jobs + jj[u];
+            if (op + 16ull * p16[u] <= a.arena_cap && os + sb[u] <= a.sarena_cap && r < a.max_rec) { q->arena_off = op; q->syms_off = os; q->pad = r; }
+            else { q->arena_off = ~0ull; q->syms_off = ~0ull; lost++; if (r < a.max_rec) a.rec[r].channel = 0xFFFFFFFFu; }     // (a record slot nobody fills: the harvest skips it)
+            q->ch = ch;
+            if (lv < a.max_jobs) a.live[1u + lv] = jj[u];
+            op += 16ull * p16[u]; os += sb[u]; r++; lv++;
+        }
+        if (lost) atomicAdd(a.nrec + 1, lost);
+        wave_sync_lds();
+        nown = 0;
     }
 
     // Coarse preamble finder for the segment waves (never part of the synchronizer's decisions: it only chooses where a wave
@@ -1869,7 +1928,7 @@ struct Walker {
     {
         const uint32_t spw = a.spec_cap / a.nseg;                // slots of this wave
         SpecSlot *sl0 = a.spec + (size_t)ch * MCRX_SPEC_MAX + (size_t)g * spw;
-        float2 *R0 = a.spec_R + ((size_t)ch * MCRX_SPEC_MAX + (size_t)g * spw) * c.M;
+        bR = a.spec_R + ((size_t)ch * MCRX_SEG_MAX + (g < MCRX_SEG_MAX ? g : 0u)) * c.M;       // (the S1 fit's memory copy: unused, the hand-off stores R from registers)
         const int M = c.M, M2 = c.M2, L = c.L;
         const int phase = a.seg_phase;
         s = a.st[ch];
@@ -1905,14 +1964,10 @@ struct Walker {
             } else if (g == 0) {
                 // the channel's real state, whatever it is (normally the fresh state behind the last frame of the previous push)
                 key = spec_key(s.cur, s.timer, s.state);
-                init_consts();                                  // (R from the channel's equaliser: an acquisition in progress has it)
+                { float2 *mine = bR; bR = a.R + (size_t)ch * c.M; init_consts(); bR = mine; }      // (R from the channel's equaliser: an acquisition in progress has it)
                 if (fastp && s.state == SY_RX && s.fstate == FX_HEADER && s.header_symbol_index > 0) {
                     for (int i = l; i < MCRX_HDR_SYMS; i += WV) ldshb[i] = bhbits[i];
                     wave_sync_lds();
-                }
-                if (s.state == SY_RX) {
-#pragma unroll
-                    for (int e = 0; e < E; e++) if (k[e] >= 0) R0[k[e]] = R[e];     // the hand-off reads the slot's equaliser
                 }
                 if (phase == 1) jmax = 1;
             } else {
@@ -1933,8 +1988,9 @@ struct Walker {
                 if (preamble_behind(pn)) p_next = pn;
             }
         }
+        if (go) reserve_block();
         while (go && j < jmax) {
-            slot = sl0 + j; bR = R0 + (size_t)j * c.M;
+            slot = sl0 + j;
             int verdict = 0;
             while (true) {
                 if (s.state == SY_SEEK) {
@@ -1960,9 +2016,9 @@ struct Walker {
                 break;
             }
             if (verdict == 2) {                                 // handed off: the job sits in the slot (try_handoff_spec)
-                if (l == 0) { slot->start = key; slot->t_last = handoff_last; slot->status = 1; slot->pad = 0; }
+                if (l == 0) { slot->start = key; slot->t_last = handoff_last; slot->status = 1; slot->pad = handoff_job; }
                 j++;
-                if (phase == 1) { if (l == 0) a.anchor[ch] = handoff_last + 1; return; }
+                if (phase == 1) { if (l == 0) a.anchor[ch] = handoff_last + 1; void_block(); return; }
                 if (handoff_last + 1 == p_next) break;          // exactly the state the next segment's wave started from: linked
                 // ... else the first frame detected at or behind the place the next wave started looking from -- its lattice point if
                 // it took one, else the segment boundary -- is that wave's first frame: acquired from my (real) state it links us
@@ -1972,8 +2028,9 @@ struct Walker {
                 continue;
             }
             if (verdict == 5 && phase != 1) {                   // header decoded, check failed: the record is the scout's to write; liquid resets and seeks on
-                if (l == 0) { PayloadJob jb; jb.s = s; jb.ch = ch; jb.pad = 0; jb.arena_off = 0; jb.syms_off = 0; slot->job = jb;
-                              slot->start = key; slot->t_last = s.cur - 1; slot->status = 3; slot->pad = 0; }
+                const uint32_t jp = park_state();
+                if (jp == 0xFFFFFFFFu) break;
+                if (l == 0) { slot->start = key; slot->t_last = s.cur - 1; slot->status = 3; slot->pad = jp; }
                 j++;
                 reset_framesync(); s.timer = (uint32_t)L;
                 key = spec_key(s.cur, s.timer);
@@ -1985,6 +2042,7 @@ struct Walker {
             }
             break;                                              // anything else (invalid header, end of the buffer, idle) is the scout's
         }
+        void_block();
         if (phase == 1) {                                       // no hand-off: no anchor; segment 0 starts over from the entry state in phase 2
             if (l == 0) { a.anchor[ch] = -1; sl0[0].start = -1; sl0[0].status = 0; }
             return;
@@ -2035,6 +2093,7 @@ struct Walker {
         nadopted = 0;
         if (a.spec_cap) load_spec_headers();
         while (true) {
+            if (nown >= MCRX_SPEC_MAX - 1) place_owned();       // (a channel with hundreds of frames in one push)
             if (a.spec_cap && (entry || (s.state == SY_SEEK && s.timer == (uint32_t)L))) {
                 // a state a segment wave may have started a frame from -- the one this launch starts in (whatever it is: segment 0
                 // cloned it) and the fresh one after every frame: the frame is taken from that wave if it started from exactly this
@@ -2043,13 +2102,13 @@ struct Walker {
                 // adoption leaves it in the same fresh post-frame state, only the position differs).
                 int64_t key = spec_key(s.cur, s.timer, s.state);
                 int64_t pos = s.cur, t_end = 0; uint32_t aux = 0, kslot = 0; bool any = false, deferred = false;
-                while (nadopted < MCRX_SPEC_MAX && adopt_match(key, t_end, aux, kslot)) {
+                while (nown < MCRX_SPEC_MAX && adopt_match(key, t_end, aux, kslot)) {
                     if ((aux & 0xffu) == 2u) { deferred = true; break; }
                     if ((aux & 0xffu) == 3u) {
                         // a frame whose header did not pass its check (noise, a neighbour's leakage): the record the synchronizer
                         // reports for it is written here, from the state the segment wave parked
                         const ChanState keep = s;
-                        s = a.spec[(size_t)ch * MCRX_SPEC_MAX + kslot].job.s;
+                        s = a.jobs[aux >> 8].s;
                         emit(t_end, false, false);
                         s = keep; nwalked++;
                     }
@@ -2126,7 +2185,7 @@ struct Walker {
         if (SY_PROF(a) && l == 0 && ch == 0)
             printf("[prof] ch0 rx phases: load %lld  core %lld  derot+nco %lld  flex %lld (header decode %lld, hand-off %lld)\n", ph[0], ph[1], ph[2], ph[3], ph[4], ph[5]);
         void_reservation();
-        publish_adopted();
+        place_owned();
         if (a.stats && l == 0) {
             if (nwalked) atomicAdd(a.stats, nwalked);
             if (nadopted) atomicAdd(a.stats + 1, nadopted);
@@ -2162,7 +2221,7 @@ __device__ __forceinline__ void launder(SyncArgs &a)
     LAUNDER(c.cod.crc_zadv); LAUNDER(c.cod.qam16_nb); LAUNDER(c.cod.qam64_nb);
     LAUNDER(chan); LAUNDER(st); LAUNDER(hbits); LAUNDER(R); LAUNDER(soft); LAUNDER(tmpa); LAUNDER(tmpb);
     LAUNDER(syms); LAUNDER(rec); LAUNDER(arena); LAUNDER(sarena); LAUNDER(nrec); LAUNDER(arena_used);
-    LAUNDER(jobs); LAUNDER(njobs); LAUNDER(jR); LAUNDER(jsoft); LAUNDER(jtmp); LAUNDER(vit_list); LAUNDER(qam_list);
+    LAUNDER(jobs); LAUNDER(njobs); LAUNDER(jR); LAUNDER(jsoft); LAUNDER(jtmp); LAUNDER(vit_list); LAUNDER(qam_list); LAUNDER(hint); LAUNDER(live);
     LAUNDER(spec); LAUNDER(spec_R); LAUNDER(pred); LAUNDER(pred_n); LAUNDER(stats); LAUNDER(walk_hint); LAUNDER(anchor);
 }
 #undef LAUNDER
@@ -2254,10 +2313,8 @@ template <int E, bool FAST>
 __global__ __launch_bounds__(WV, ((E == 1 && FAST) ? 6 : E <= 4 ? 4 : (E <= 8 ? 2 : 1))) void payload_kernel(SyncArgs a)
 {
     launder(a);
-    const uint32_t j = blockIdx.x;
-    uint32_t nj = *a.njobs;
-    if (nj > a.max_jobs) nj = a.max_jobs;
-    if (j >= nj) return;
+    if (blockIdx.x >= a.live[0]) return;
+    const uint32_t j = a.live[1u + blockIdx.x];
     const uint32_t ch = a.jobs[j].ch;
     if (ch >= a.nch) return;
     Walker<E> w(a, ch);
@@ -2285,15 +2342,16 @@ __global__ __launch_bounds__(WV) void payload_multi_kernel(SyncArgs a)
     __shared__ uint32_t qnb16[16], qnb64[64];                           // the soft demodulator's nearest-neighbour tables: read on every QAM symbol's chain
     const SyncConsts &c = a.c;
     const int l = lane_id(), g = l / G, i = l % G;
-    uint32_t nj = *a.njobs;
-    if (nj > a.max_jobs) nj = a.max_jobs;
-    const uint32_t j0 = (uint32_t)FR * blockIdx.x, j = j0 + (uint32_t)g;
-    if (j0 >= nj) return;
-    bool active = j < nj;
-    const uint32_t jj = active ? j : j0;                                // idle groups shadow the first job, store nothing
+    const uint32_t nj = a.live[0];
+    const uint32_t k0 = (uint32_t)FR * blockIdx.x;
+    if (k0 >= nj) return;
+    bool active = k0 + (uint32_t)g < nj;
+    const uint32_t j = a.live[1u + (active ? k0 + (uint32_t)g : k0)];
+    const uint32_t jj = j;                                              // idle groups shadow the first job, store nothing
     const PayloadJob *job = a.jobs + jj;
-    const uint32_t ch = job->ch;
-    active = active && ch < a.nch && job->arena_off != ~0ull;
+    const uint32_t ch_owner = job->ch;                                  // (~0: an entry nobody owns -- a frame a segment wave acquired for nothing, a void reservation)
+    active = active && ch_owner < a.nch && job->arena_off != ~0ull;
+    const uint32_t ch = ch_owner < a.nch ? ch_owner : 0u;               // idle groups read channel 0's samples and store nothing
     qps[l] = reinterpret_cast<const uint32_t *>(c.pilot_seq)[l];        // 256 bytes, one word per lane
     qnb64[l] = reinterpret_cast<const uint32_t *>(c.cod.qam64_nb)[l];
     if (l < 16) qnb16[l] = reinterpret_cast<const uint32_t *>(c.cod.qam16_nb)[l];
@@ -2578,13 +2636,8 @@ __device__ uint32_t crc32_tree(const CodingDev cod, uint32_t tab_off, uint32_t m
     }
     return ~(uint32_t)__shfl((int)s, 0, WV);
 }
-__global__ __launch_bounds__(DK_T) void decode_kernel(SyncArgs a, uint32_t lds_soft_bytes, uint32_t msg_bytes)
+__device__ __forceinline__ void decode_frame(SyncArgs &a, const uint32_t j, uint32_t lds_soft_bytes, uint32_t msg_bytes)
 {
-    launder(a);
-    const uint32_t j = blockIdx.x;
-    uint32_t nj = *a.njobs;
-    if (nj > a.max_jobs) nj = a.max_jobs;
-    if (j >= nj) return;
     const uint32_t ch = a.jobs[j].ch;
     if (ch >= a.nch || a.jobs[j].arena_off == ~0ull) return;
     const SyncConsts &c = a.c;
@@ -2753,6 +2806,17 @@ __global__ __launch_bounds__(DK_T) void decode_kernel(SyncArgs a, uint32_t lds_s
     if (prof && threadIdx.x == 0) printf("[prof] decode wg7 cycles: stage %lld  passes %lld  h128 %lld  crc %lld  emit %lld\n", tk[1]-tk[0], tk[2]-tk[1], tk[3]-tk[2], tk[4]-tk[3], tk[5]-tk[4]);
 #undef DK_TICK
 }
+// a workgroup per frame of the launch (live list), grid stride: the host sizes the grid from the previous launch's frame count
+__global__ __launch_bounds__(DK_T) void decode_kernel(SyncArgs a, uint32_t lds_soft_bytes, uint32_t msg_bytes)
+{
+    launder(a);
+    uint32_t nl = a.live[0];
+    if (nl > a.max_jobs) nl = a.max_jobs;
+    for (uint32_t k = blockIdx.x; k < nl; k += gridDim.x) {
+        decode_frame(a, a.live[1u + k], lds_soft_bytes, msg_bytes);
+        __syncthreads();                                        // (the next frame reuses the staging area)
+    }
+}
 
 // The frames the LDS path does not take (hard decisions, an inner code, the convolutional code, frames longer than the
 // LDS sized for this launch): one wave per frame decodes in place in HBM with the walker's general decoder -- a separate
@@ -2804,107 +2868,40 @@ __global__ __launch_bounds__(WV) void decode_general_kernel(SyncArgs a)
     }
 }
 
-// Record space for the handed-off frames: an exclusive prefix sum of their sizes in job order
-// (one workgroup, between the scout and the worker launch), so no wave queues on an allocation
-// counter.  Frames that do not fit the arena are counted as dropped.
-#define PJ_T 1024
-#define PJ_CAP 8192
-__global__ __launch_bounds__(PJ_T) void place_jobs_kernel(SyncArgs a)
+// Between the scouts and the workers of a launch: one wave of housekeeping.  (Record space is reserved by the scouts themselves,
+// a block per channel: Walker::place_owned.)  The lists this launch's workers and decoders fill are emptied, the NEXT launch's job
+// counter and QAM list are zeroed, and what the host sizes the next launches by goes to its mapped words.
+__global__ __launch_bounds__(WV) void place_jobs_kernel(SyncArgs a)
 {
-    __shared__ unsigned long long part[PJ_T];       // (valid count << 40) | symbol bytes, scanned together
-    __shared__ uint32_t part2[PJ_T];                // payload bytes in 16-byte units
-    __shared__ uint32_t need_l[PJ_CAP];             // symbol-arena bytes of job j (0 = void slot: a live frame always has symbols)
-    __shared__ uint16_t pay_l[PJ_CAP];              // payload-arena bytes of job j in 16-byte units
-    __shared__ uint32_t maxenc;
-    if (threadIdx.x == 0) { maxenc = 0; if (a.gen_list) as_global(a.gen_list)[0] = 0; if (a.vit_list) as_global(a.vit_list)[0] = 0; }
-    __syncthreads();
     launder(a);
-    a.gen_list = a.gen_list ? as_global(a.gen_list) : nullptr;
+    if (threadIdx.x != 0) return;
+    if (a.gen_list) as_global(a.gen_list)[0] = 0;
+    if (a.vit_list) as_global(a.vit_list)[0] = 0;
     uint32_t nj = *a.njobs;
     if (nj > a.max_jobs) nj = a.max_jobs;
-    if (threadIdx.x == 0 && a.njobs_next) *a.njobs_next = 0;
-    if (threadIdx.x == 0 && a.walk_hint && a.stats) {
-        // frames the scouts acquired themselves / adopted from speculative waves so far: the host reads them without a sync
-        // and sets its acquisition policy by them (mcrx_hip.hip launch_sync)
+    if (a.njobs_next) *a.njobs_next = 0;
+    if (a.qam_next) as_global(a.qam_next)[0] = 0;
+    if (a.live_next) as_global(a.live_next)[0] = 0;
+    { uint32_t nl = a.live[0]; if (nl > a.max_jobs) a.live[0] = a.max_jobs; }
+    if (a.qam_list) {
+        uint32_t nq = a.qam_list[0];
+        if (nq > a.max_jobs) { nq = a.max_jobs; a.qam_list[0] = nq; }
+        if (a.list_hint) a.list_hint[0] = nq;
+    }
+    if (a.stats) {
+        const uint32_t maxenc = a.stats[7];
+        a.stats[7] = 0;
+        if (a.hint && maxenc) *a.hint = maxenc;                 // host-mapped: sizes the next launch's decode LDS
+    }
+    if (a.walk_hint && a.stats) {
+        // frames the scouts acquired themselves / adopted from segment waves so far, frames on a cadence: the host reads them without
+        // a sync (mcrx_hip.hip launch_sync)
         volatile uint32_t *h = a.walk_hint;
         h[0] = a.stats[0]; h[1] = a.stats[1]; h[2] = a.stats[4]; h[3] = a.stats[5];
-        h[4] = a.stats[6]; a.stats[6] = 0;
-        h[5] = nj;                              // hand-offs of THIS launch: frames per channel and push, which sizes the next launches' segments
+        const uint32_t tot = a.stats[0] + a.stats[1], prev = a.stats[6] <= tot ? a.stats[6] : 0u;      // (a statistics reset zeroes them all)
+        a.stats[6] = tot;
+        h[5] = tot - prev;                      // frames of THIS launch: frames per channel and push, which sizes the next launches' segments
         __threadfence_system();
-    }
-    __shared__ uint32_t nqam;
-    if (a.qam_list) {                       // the hand-offs the lean workers' second launch takes (16- / 64-QAM), any order
-        if (threadIdx.x == 0) nqam = 0;
-        __syncthreads();
-        for (uint32_t j = threadIdx.x; j < nj; j += PJ_T) {
-            const uint32_t m = a.jobs[j].s.mod_scheme;
-            if (a.jobs[j].ch < a.nch && m != 39 && m != 40) a.qam_list[1 + atomicAdd(&nqam, 1u)] = j;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) { a.qam_list[0] = nqam; if (a.list_hint) a.list_hint[0] = nqam; }
-    }
-    auto need_of = [&](uint32_t j, uint32_t &pay16) -> uint32_t {
-        pay16 = 0;
-        if (a.jobs[j].ch >= a.nch) return 0u;
-        pay16 = (a.jobs[j].s.payload_len + 15u) >> 4;
-        return 8u * a.jobs[j].s.mod_len;
-    };
-    // chunks of PJ_CAP jobs, each placed in parallel if all of it fits behind what is already placed; from the first
-    // chunk that does not, one thread places the rest exactly, job by job (a full pool: rare, and then speed is moot)
-    unsigned long long base = a.arena_used[0], sbase = a.arena_used[1];
-    uint32_t rbase = a.nrec[0];
-    uint32_t c0 = 0;
-    for (; c0 < nj; c0 += PJ_CAP) {
-        const uint32_t cn = nj - c0 < PJ_CAP ? nj - c0 : PJ_CAP;
-        uint32_t me = 0;
-        for (uint32_t j = threadIdx.x; j < cn; j += PJ_T) {                             // all requests in flight at once
-            uint32_t p16; need_l[j] = need_of(c0 + j, p16); pay_l[j] = (uint16_t)p16;
-            const uint32_t e = a.jobs[c0 + j].ch < a.nch ? a.jobs[c0 + j].s.enc_len : 0u;
-            me = e > me ? e : me;
-
-        }
-        if (me) atomicMax(&maxenc, me);
-        __syncthreads();
-        const uint32_t per = (cn + PJ_T - 1) / PJ_T;
-        const uint32_t j0 = threadIdx.x * per < cn ? threadIdx.x * per : cn, j1 = (j0 + per < cn) ? j0 + per : cn;
-        unsigned long long mine = 0; uint32_t mine2 = 0;
-        for (uint32_t j = j0; j < j1; j++) if (need_l[j]) { mine += (1ull << 40) | need_l[j]; mine2 += pay_l[j]; }
-        part[threadIdx.x] = mine; part2[threadIdx.x] = mine2;
-        __syncthreads();
-        for (int o = 1; o < PJ_T; o <<= 1) {
-            const unsigned long long v = (int)threadIdx.x >= o ? part[threadIdx.x - o] : 0ull;
-            const uint32_t v2 = (int)threadIdx.x >= o ? part2[threadIdx.x - o] : 0u;
-            __syncthreads();
-            part[threadIdx.x] += v; part2[threadIdx.x] += v2;
-            __syncthreads();
-        }
-        const unsigned long long tot = part[PJ_T - 1];
-        const unsigned long long tot_sym = tot & ((1ull << 40) - 1), tot_cnt = tot >> 40, tot_pay = 16ull * part2[PJ_T - 1];
-        if (!(base + tot_pay <= a.arena_cap && sbase + tot_sym <= a.sarena_cap && rbase + tot_cnt <= a.max_rec)) break;
-        const unsigned long long excl = part[threadIdx.x] - mine;
-        unsigned long long soff = sbase + (excl & ((1ull << 40) - 1));
-        unsigned long long off = base + 16ull * (part2[threadIdx.x] - mine2);
-        uint32_t ridx = rbase + (uint32_t)(excl >> 40);
-        for (uint32_t j = j0; j < j1; j++) if (need_l[j]) {
-            a.jobs[c0 + j].arena_off = off; a.jobs[c0 + j].syms_off = soff; a.jobs[c0 + j].pad = ridx++;
-            off += 16ull * pay_l[j]; soff += need_l[j];
-        }
-        base += tot_pay; sbase += tot_sym; rbase += (uint32_t)tot_cnt;
-        __syncthreads();                                                                // the staging is reused by the next chunk
-    }
-    if (threadIdx.x == 0 && a.hint && maxenc) *a.hint = maxenc;                         // host-mapped: sizes the next launch's LDS
-    if (threadIdx.x == 0) {
-        unsigned long long off = base, soff = sbase; uint32_t ridx = rbase, dropped = 0;
-        for (uint32_t j = c0; j < nj; j++) {                                            // (empty when every chunk fitted)
-            uint32_t p16; const uint32_t nd = need_of(j, p16);
-            if (!nd) continue;
-            if (off + 16ull * p16 <= a.arena_cap && soff + nd <= a.sarena_cap && ridx < a.max_rec) {
-                a.jobs[j].arena_off = off; a.jobs[j].syms_off = soff; a.jobs[j].pad = ridx++; off += 16ull * p16; soff += nd;
-            }
-            else { a.jobs[j].arena_off = ~0ull; a.jobs[j].syms_off = ~0ull; dropped++; }
-        }
-        a.arena_used[0] = off; a.arena_used[1] = soff; a.nrec[0] = ridx;
-        if (dropped) atomicAdd(a.nrec + 1, dropped);
     }
 }
 
@@ -3093,18 +3090,22 @@ hipError_t sync_launch_payload(const SyncArgs &a0, int stage, hipStream_t st)
     if (a0.nch == 0 || !a0.scout || a0.max_jobs == 0) return hipSuccess;
     SyncArgs a = a0;
     const unsigned nj = a.max_jobs;
+    // frames of the most recent launch + a quarter: the workers and decoders walk the live list with a grid stride, so a launch that
+    // holds more than expected only takes a second turn
+    unsigned ngrid = a.frames_hint == ~0u ? nj : a.frames_hint + a.frames_hint / 4 + 64;
+    if (ngrid > nj) ngrid = nj;
     const bool fast = a.c.log2M >= 6 && a.c.M == WV * a.c.E && a.c.M_pilot <= WV && !(a.no_fast & 1);
     a.dec_lds_soft = fast ? decode_soft_lds(a) : 0u;
     if (!fast) a.gen_list = nullptr;
     if (stage == 0) {
-        hipLaunchKernelGGL(place_jobs_kernel, dim3(1), dim3(PJ_T), 0, st, a);
+        hipLaunchKernelGGL(place_jobs_kernel, dim3(1), dim3(WV), 0, st, a);
         return hipGetLastError();
     }
     if (stage == 2) {
         if (!fast) return hipSuccess;
         const size_t soft_lds = a.dec_lds_soft;
         const size_t msg_lds = ((size_t)a.c.max_payload_len + 4 + 15) & ~(size_t)15;
-        hipLaunchKernelGGL(decode_kernel, dim3(nj), dim3(DK_T), 2 * soft_lds + msg_lds + 16, st, a, (uint32_t)soft_lds, (uint32_t)msg_lds);      // soft bits as received | de-interleaved | message
+        hipLaunchKernelGGL(decode_kernel, dim3(ngrid), dim3(DK_T), 2 * soft_lds + msg_lds + 16, st, a, (uint32_t)soft_lds, (uint32_t)msg_lds);      // soft bits as received | de-interleaved | message
         return hipGetLastError();
     }
     if (stage == 3) {                       // the frames on the general list (filled by decode_kernel)
@@ -3131,7 +3132,8 @@ hipError_t sync_launch_payload(const SyncArgs &a0, int stage, hipStream_t st)
             else {
                 unsigned nq = a.grid_hint[0] == ~0u ? nj : 2u * a.grid_hint[0];
                 nq = nq < 256u ? 256u : (nq > nj ? nj : nq);
-#define SY_LEAN(XB) do { hipLaunchKernelGGL(payload_lean_kernel<XB>, dim3(nj), dim3(WV), pad, st, a); \
+#define SY_LEAN(XB) do { a.live_off = ngrid; hipLaunchKernelGGL(payload_lean_kernel<XB>, dim3(ngrid), dim3(WV), pad, st, a); \
+                         if (ngrid < nj) hipLaunchKernelGGL(payload_lean_rest_kernel<XB>, dim3(256), dim3(WV), pad, st, a); \
                          hipLaunchKernelGGL(payload_lean_qam_kernel<XB>, dim3(a.qam_list ? nq : nj), dim3(WV), pad, st, a); } while (0)
                 if (xb == 0) SY_LEAN(0);
                 else         SY_LEAN(63);

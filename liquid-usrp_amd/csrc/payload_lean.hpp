@@ -257,7 +257,10 @@ __device__ __forceinline__ uint32_t symbols(const SyncArgs &a, const PayloadJob 
 // list it saw).  Two kernels because the QAM demodulator's registers (12 running minima, the neighbour walk) would otherwise
 // set the budget of the loop every frame of the periodic benchmark runs in: 56 VGPRs / 70 SGPRs = 8 waves per SIMD
 // (amdgpu_num_sgpr: at 86 SGPRs the scalar file admits 7, measured as 8192 waves taking two rounds).
-template <int XB, int CLS>
+// REST: the frames the main launch's grid (sized from the previous launch's frame count: a.live_off waves, one frame each) did not
+// reach -- a small second launch with a grid stride, normally nothing to do.  (The stride loop in the main kernel cost it its eighth
+// wave per SIMD: 59 -> 70 registers.)
+template <int XB, int CLS, bool REST = false>
 __device__ __forceinline__ void payload_lean_body(SyncArgs &a)
 {
     launder(a);
@@ -266,18 +269,18 @@ __device__ __forceinline__ void payload_lean_body(SyncArgs &a)
     __shared__ int qsrc[16];                // the lane that holds pilot r after the transform
     const SyncConsts &c = a.c;
     const int l = lane_id();
-    uint32_t nj = *a.njobs;
-    if (nj > a.max_jobs) nj = a.max_jobs;
-    uint32_t nlist = nj;
-    if (CLS == 1 && a.qam_list) { nlist = a.qam_list[0]; if (nlist > nj) nlist = nj; }
-    if (blockIdx.x >= nlist) return;
+    const uint32_t nj = a.max_jobs;
+    uint32_t nlist = (CLS == 1 && a.qam_list) ? a.qam_list[0] : a.live[0];       // the QAM frames / every frame of the launch
+    if (nlist > nj) nlist = nj;
+    const uint32_t kfirst = REST ? a.live_off + blockIdx.x : blockIdx.x;
+    if (kfirst >= nlist) return;
     for (int k = l; k < 256 + 16; k += WV) qsg[k] = c.pilot_seq[k >= 255 ? k - 255 : k] == 0 ? 0x80000000u : 0u;
     if (l < 16) qsrc[l] = 0;
     wave_sync_lds();
     { const int pr = c.pilot_rank[(int)(__brev((unsigned)l) >> 26)]; if (pr >= 0 && pr < 16) qsrc[pr] = l; }
     wave_sync_lds();
-    for (uint32_t k = blockIdx.x; k < nlist; k += gridDim.x) {
-        const uint32_t j = (CLS == 1 && a.qam_list) ? rfl(a.qam_list[1 + k]) : k;
+    for (uint32_t k = kfirst; k < nlist; k += gridDim.x) {
+        const uint32_t j = (CLS == 1 && a.qam_list) ? rfl(a.qam_list[1 + k]) : rfl(a.live[1 + k]);
         if (j >= nj) continue;
         const PayloadJob *job = a.jobs + j;
         const uint32_t ch = rfl(job->ch);
@@ -297,8 +300,9 @@ __device__ __forceinline__ void payload_lean_body(SyncArgs &a)
             else           dth = lean::symbols<29, XB>(a, job, ch, j, qsg, qnb, qsrc);
         }
         if (l == 0) a.jobs[j].s.nco_dtheta = dth;
-        if (CLS == 0) break;                // (one hand-off per wave: the grid is the job list)
+        if (CLS == 0 && !REST) break;       // (one frame per wave; what the grid does not cover is the REST launch's)
     }
 }
 template <int XB> __global__ __launch_bounds__(WV) __attribute__((amdgpu_num_sgpr(72))) void payload_lean_kernel(SyncArgs a) { payload_lean_body<XB, 0>(a); }
+template <int XB> __global__ __launch_bounds__(WV) void payload_lean_rest_kernel(SyncArgs a) { payload_lean_body<XB, 0, true>(a); }
 template <int XB> __global__ __launch_bounds__(WV) void payload_lean_qam_kernel(SyncArgs a) { payload_lean_body<XB, 1>(a); }
