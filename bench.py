@@ -78,6 +78,10 @@ def parse():
                          "tests drive), 'c' = the C-ABI pipeline (mcrx_hip_pipeline_*: HIP events + grouped ncclSend/ncclRecv).  auto: c on one "
                          "GPU (--pipeline), torch on several -- the C exchange has only ever run at world = 1 (no multi-GPU lease so far)")
     ap.add_argument("--dry-run-launch", action="store_true", help="start the ranks, rendezvous under gloo, print one JSON line and exit (no GPU needed)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="--gpus N > 1 with every rank on device 0 and the exchange staged through host memory under gloo (RCCL refuses two ranks on one "
+                         "device): executes the whole multi-process code path -- sub-slab cut, halos, pipeline, verification -- on a one-GPU lease.  "
+                         "The value it prints is NOT a scaling number")
     return ap.parse_args()
 
 
@@ -105,12 +109,18 @@ def main():
     import torch
     from __graft_entry__ import load_product, load_oracle
     assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP kernels are the only implementation"
+    rehearsal = args.rehearse_on_one_gpu and world > 1
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)      # RCCL over xGMI
+        if rehearsal:
+            dist.init_process_group(backend="gloo")                 # every rank on cuda:0, exchange through host memory
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)  # RCCL over xGMI
 
     prod, ora = load_product(), load_oracle()
     from liquid_usrp_amd import sharding
@@ -202,13 +212,27 @@ def main():
         torch.cuda.empty_cache()
         period_blocks = tot
         rx = prod.multichannelrx(N, M, cp, taper, channel_first=c0, channel_count=cg, **cfg)
-        use_c = args.exchange == "c" or (args.exchange == "auto" and world == 1)
+        # auto: the extern-C pipeline (HIP events + grouped ncclSend / ncclRecv behind the C-ABI: what north_star asks for) whenever
+        # it can run -- one rank, or several with librccl loadable -- else the torch pipeline, with the reason in the line
+        use_c, why_not_c, uid = (args.exchange != "torch"), None, None
+        if rehearsal and use_c:
+            use_c, why_not_c = False, "one-GPU rehearsal: RCCL refuses two ranks on one device, the exchange goes through host memory under gloo"
+            if args.exchange == "c":
+                sys.exit("--exchange c cannot be rehearsed on one GPU")
+        if use_c and world > 1:                         # rank 0's ncclUniqueId to everybody (the C-ABI leaves the transport to the caller)
+            box = [None, None]
+            if rank == 0:
+                try:
+                    box[0] = prod.pipeline.unique_id()
+                except Exception as e:
+                    box[1] = repr(e)
+            dist.broadcast_object_list(box, src=0)
+            uid = box[0]
+            if uid is None:
+                if args.exchange == "c":
+                    sys.exit("--exchange c: " + str(box[1]))
+                use_c, why_not_c = False, "librccl could not be loaded behind the C-ABI (%s)" % box[1]
         if use_c:
-            uid = None
-            if world > 1:                               # rank 0's ncclUniqueId to everybody (the C-ABI leaves the transport to the caller)
-                box = [prod.pipeline.unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                uid = box[0]
             # (five rotating buffer sets = the receiver's own five slots: the channelizer runs as far ahead of the payload workers as in
             #  the direct path -- 144 -> 148 Gsample/s on one GPU; six wait for a slot and halve it.  MCRX_PIPE_NBUF)
             pipe = prod.pipeline(rx, rank, world, Tc, unique_id=uid, nbuf=int(os.environ.get("MCRX_PIPE_NBUF", "5")))
@@ -241,7 +265,7 @@ def main():
         fence()
         rep_s.append(time.perf_counter() - t0)
     if world > 1:                                      # a repetition takes as long as its slowest rank
-        tt = torch.tensor(rep_s, dtype=torch.float64, device=dev)
+        tt = torch.tensor(rep_s, dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         rep_s = [float(v) for v in tt.tolist()]
     elapsed = float(np.median(rep_s))
@@ -327,7 +351,9 @@ def main():
                                    % (args.payload, args.frames, args.slabs),
                        "channels": N, "subcarriers": M, "samples_per_step": samples_per_step,
                        "receiver": "serial (one stream)" if args.serial else "pipelined (3 internal streams, 3 buffer sets)",
-                       "multi_gpu_path": None if pipe is None else ("C-ABI pipeline (mcrx_hip_pipeline_*)" if use_c else "sharding.Pipeline (torch)"),
+                       "multi_gpu_path": None if pipe is None else ("C-ABI pipeline (mcrx_hip_pipeline_*)" if use_c else
+                                                                      "sharding.Pipeline (torch)" + (": " + why_not_c if why_not_c else "")),
+                       "rehearsal_on_one_gpu": bool(rehearsal),
                        "receiver_hints_from_the_benchmark": "none (no MCRX_* environment is set by this script)",
                        "parallelism": ("round-robin time-sharded channelizer -> all-to-all -> %d channels/GPU, %d rounds per step, "
                                        "exchange overlapped" % (cg, args.rounds)) if world > 1 else "single GPU"},

@@ -232,6 +232,7 @@ struct SyncArgs {
                                 //    is oversize, or the job list is full -- and then on to the end of the buffer
     uint32_t *stats;            // [0] frames the scouts acquired themselves, [1] frames adopted from speculative waves (NULL: not counted)
     int no_fast;               // MCRX_NO_FAST=1: payload workers use the general symbol path (A/B experiments)
+    int payload_fr, payload_lean, payload_xb;      // which build of the M = 64 workers (MCRX_PAYLOAD_FR / _LEAN / _XB at creation; defaults 1, 1, 63): the parity tests compare them
     uint32_t vit_off;          // byte offset of the convolutional decoder's 8 KB block scratch in the launch's dynamic LDS (0: none; set by the launchers)
 };
 hipError_t sync_launch(const SyncArgs &a, hipStream_t st);           // full state machine, one wave per channel (general configurations; tail kernel)

@@ -158,6 +158,7 @@ struct mcrx_hip_s {
     uint32_t list_seen[3] = { 0, 0, 0 }, list_age[3] = { 64, 64, 64 };      // launch_sync: grids of the list-driven launches
     uint32_t round_lds_pad = 0;      // the same cap outside walk mode (MCRX_PAYLOAD_LDS_PAD)
     uint32_t walk_lds_pad = 13312;   // walk mode: unused LDS per payload worker = at most three of them per SIMD, the fourth slot is the walking scouts' (95 -> 110 Gsample/s on ragged traffic)
+    int payload_fr = 1, payload_lean = 1, payload_xb = 63;      // MCRX_PAYLOAD_FR / _LEAN / _XB: which build of the M = 64 payload workers (tests)
     int debug = 0, no_fast = 0, seek_burst = 1, acq_mode = 0; bool free_run = false;      // MCRX_DEBUG (trace bits), MCRX_NO_FAST, MCRX_FREE_RUN: read once, at creation
     hipStream_t acq_stream = nullptr;        // the stream the last launch's acquisition / placement kernels ran on (they write the generation's counters)
     uint64_t gen_close_seq[MCRX_GENS] = {}, close_counter = 0;      // order in which generations were closed (= delivery order)
@@ -502,6 +503,9 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     q->debug = getenv("MCRX_DEBUG") ? atoi(getenv("MCRX_DEBUG")) : 0;
     q->no_fast = getenv("MCRX_NO_FAST") ? atoi(getenv("MCRX_NO_FAST")) : 0;
     q->free_run = getenv("MCRX_FREE_RUN") != nullptr;
+    if (getenv("MCRX_PAYLOAD_FR")) q->payload_fr = atoi(getenv("MCRX_PAYLOAD_FR"));
+    if (getenv("MCRX_PAYLOAD_LEAN")) q->payload_lean = atoi(getenv("MCRX_PAYLOAD_LEAN")) != 0;
+    if (getenv("MCRX_PAYLOAD_XB")) q->payload_xb = atoi(getenv("MCRX_PAYLOAD_XB"));
     if (getenv("MCRX_SEEK_BURST")) q->seek_burst = atoi(getenv("MCRX_SEEK_BURST"));
     if (getenv("MCRX_ACQ_MODE")) q->acq_mode = atoi(getenv("MCRX_ACQ_MODE"));
     if (getenv("MCRX_WALK_LDS_PAD")) q->walk_lds_pad = (uint32_t)atoi(getenv("MCRX_WALK_LDS_PAD"));
@@ -665,6 +669,7 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     a.nrec = q->d_nrec[g]; a.arena_used = q->d_arena_used[g];
     a.arena_cap = q->arena_cap; a.sarena_cap = q->sarena_cap; a.max_rec = q->max_rec;
     a.debug = q->debug; a.no_fast = q->no_fast; a.seek_burst = q->seek_burst;
+    a.payload_fr = q->payload_fr; a.payload_lean = q->payload_lean; a.payload_xb = q->payload_xb;
     a.payload_lds_pad = q->acq_mode == 2 ? q->walk_lds_pad : q->round_lds_pad;
     a.vit_off = 0;
     a.scout = q->scout ? 1 : 0;

@@ -3117,18 +3117,16 @@ hipError_t sync_launch_payload(const SyncArgs &a0, int stage, hipStream_t st)
     }
     // M = 64 with the pilots inside one DPP row: payload_multi_kernel, MCRX_PAYLOAD_FR frames per wave (default 1;
     // 0 = the width-generic worker).  Measured on the bench stream: 1 -> 141.7 Gsample/s, 0 -> 138, 2 -> 138, 4 -> 118.
-    const char *fre = getenv("MCRX_PAYLOAD_FR");                         // (read per launch: the tests compare the builds)
-    const int fr = fre ? atoi(fre) : 1;
+    const int fr = a.payload_fr;                                         // (MCRX_PAYLOAD_FR / _LEAN / _XB: read once, when the handle is created)
     if (fast && a.c.M == WV && a.c.M_pilot <= 16 && fr > 0 && !(a.no_fast & 6)) {
         if (fr == 4)      hipLaunchKernelGGL(payload_multi_kernel<4>, dim3((nj + 3) / 4), dim3(WV), 0, st, a);
         else if (fr == 2) hipLaunchKernelGGL(payload_multi_kernel<2>, dim3((nj + 1) / 2), dim3(WV), 0, st, a);
         else {
             // one frame per wave: the lean build (payload_lean.hpp) unless MCRX_PAYLOAD_LEAN=0; MCRX_PAYLOAD_XB picks which
             // butterfly stages exchange through the LDS crossbar (bit H set: the stage with partners H lanes apart)
-            const char *le = getenv("MCRX_PAYLOAD_LEAN"), *xe = getenv("MCRX_PAYLOAD_XB");
-            const int xb = xe ? atoi(xe) : 63;
+            const int xb = a.payload_xb;
             const size_t pad = (size_t)a.payload_lds_pad;
-            if (le && atoi(le) == 0) hipLaunchKernelGGL(payload_multi_kernel<1>, dim3(nj), dim3(WV), pad, st, a);
+            if (!a.payload_lean) hipLaunchKernelGGL(payload_multi_kernel<1>, dim3(nj), dim3(WV), pad, st, a);
             else {
                 unsigned nq = a.grid_hint[0] == ~0u ? nj : 2u * a.grid_hint[0];
                 nq = nq < 256u ? 256u : (nq > nj ? nj : nq);

@@ -38,9 +38,23 @@ def slab_first_sample(rank, slab_blocks, num_channels):
 
 
 def exchange(out, recv, world, dist):
-    """Time shards -> channel shards.  `out`/`recv` are flat tensors of world equal chunks."""
+    """Time shards -> channel shards.  `out`/`recv` are flat tensors of world equal chunks.
+
+    Device tensors under a process group without device collectives (gloo: the one-GPU rehearsal of the multi-rank job,
+    bench.py --rehearse-on-one-gpu, where RCCL refuses two ranks on one device) are staged through host memory -- the same
+    chunks to the same ranks, only the transport differs."""
     if world == 1:
         return out
+    if getattr(out, "is_cuda", False) and dist.get_backend() == "gloo":
+        import torch
+        o = torch.view_as_real(out).reshape(-1).cpu() if out.is_complex() else out.cpu()       # (waits for the producing stream)
+        r = torch.empty_like(o)
+        dist.all_to_all_single(r, o)
+        if recv.is_complex():
+            torch.view_as_real(recv).reshape(-1).copy_(r, non_blocking=False)
+        else:
+            recv.copy_(r, non_blocking=False)
+        return recv
     if out.is_complex():
         # RCCL (like NCCL) has no complex element type: exchange the same bytes as float pairs
         import torch

@@ -1,0 +1,35 @@
+"""The real multi-process path of `bench.py --gpus N`, executed before the day it counts: two ranks started by
+the script's own launcher, both on device 0 (a one-GPU lease is all there is), the all-to-all staged through host memory under gloo
+because RCCL refuses two ranks on one device.  Everything else is the path the 8-GPU job takes: the sub-slab cut, the halos, the
+round-robin pipeline, each rank's receiver over its channel shard, the verification on every rank, one JSON line from rank 0."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def clean_env():
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    return env
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_two_ranks_rehearsed_on_one_gpu(world):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--rehearse-on-one-gpu", "--steps", "2", "--warmup", "1",
+           "--reps", "2", "--no-cpu", "--frames", "4", "--slabs", "2", "--serial-steps", "1"]
+    r = subprocess.run(cmd, env=clean_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])          # (a rank whose verification fails exits non-zero)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                                # one line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["verified"]["ok"] and d["verified"]["frames"] == d["verified"]["expected"] > 0
+    assert d["config"]["rehearsal_on_one_gpu"] is True and "sharding.Pipeline" in d["config"]["multi_gpu_path"]
+    assert d["steps"] == 2 and d["repetitions"] == 2 and d["value"] > 0 and "exchange" in d
+    assert d["config"]["receiver_hints_from_the_benchmark"].startswith("none")

@@ -8,10 +8,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 REL = 1e-5          # the bar: max |gpu - oracle| relative to the largest |oracle| of the frame (full-scale relative)
-REL_ELEM = 4e-5     # reported beside it: element-wise |gpu - oracle| / |oracle| over every element above 1e-3 of full scale.
-                    # The two pipelines differ by float rounding of sums of full-scale terms (an M-point transform), so the
-                    # error of an element does not shrink with the element: inner QAM points (|s| = 0.32 against 1.34 for a
-                    # 16-QAM corner) and weak channelizer bins sit proportionally higher.  DESIGN.md section 4.5 has the numbers.
+REL_ELEM = 1e-5     # ... and element-wise: |gpu - oracle| / |oracle| over every element above 1e-3 of full scale.  north_star's 1e-5 holds
+                    # in this form too (worst measured over every BASELINE shape: 8.0e-6, profiles/r3_gpu_tests_errors.txt), so it is asserted.
 
 
 def _torch():
@@ -73,7 +71,7 @@ def check_frames(gpu_frames, ora_frames, rel=REL, leak_rssi=None):
         #  channel on its neighbours' leakage, it is the magnitude of noise and moves by 0.1 dB with the last bits of the input)
         assert abs(fg.evm - fo.evm) < 0.05 or fo.evm < -60 or not fo.header_valid
     assert worst <= rel, worst
-    assert worst_e <= max(REL_ELEM, 4 * rel), (worst, worst_e)
+    assert worst_e <= max(REL_ELEM, rel), (worst, worst_e)
     WORST["max_norm"] = max(WORST["max_norm"], worst); WORST["element_wise"] = max(WORST["element_wise"], worst_e)
     check_frames.last = (worst, worst_e)
     return worst
