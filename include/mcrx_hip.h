@@ -218,6 +218,9 @@ int      mcrx_hip_pipeline_create(mcrx_hip_pipeline_t *out, mcrx_hip_t rx, int r
  * non-blocking); MCRX_STREAM_READY = the buffers are complete, wait for nothing */
 #define MCRX_STREAM_READY ((void *)(intptr_t)-1)
 int      mcrx_hip_pipeline_push(mcrx_hip_pipeline_t p, const void *d_iq_sub, const void *d_halo, void *after_stream);
+/* the same from host memory: iq_with_halo = the 13 blocks in front of this rank's sub-slab, then the sub-slab ((13 + sub_blocks) * 2N
+ * cf32, contiguous; zeros in front of the stream's first sub-slab).  What the sharded multichannelrx class calls */
+int      mcrx_hip_pipeline_push_host(mcrx_hip_pipeline_t p, const float *iq_with_halo);
 int      mcrx_hip_pipeline_wait(mcrx_hip_pipeline_t p);                              /* host wait for everything pushed */
 int      mcrx_hip_pipeline_time_exchange(mcrx_hip_pipeline_t p, int on);            /* HIP events around every exchange */
 int      mcrx_hip_pipeline_exchange_ms(mcrx_hip_pipeline_t p, double *total_ms, uint64_t *rounds, int reset);

@@ -97,6 +97,7 @@ _EXPORTS = {
     "mcrx_hip_pipeline_unique_id": (C.c_int, [C.c_void_p]),
     "mcrx_hip_pipeline_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_uint]),
     "mcrx_hip_pipeline_push": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mcrx_hip_pipeline_push_host": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mcrx_hip_pipeline_wait": (C.c_int, [C.c_void_p]),
     "mcrx_hip_pipeline_time_exchange": (C.c_int, [C.c_void_p, C.c_int]),
     "mcrx_hip_pipeline_exchange_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),

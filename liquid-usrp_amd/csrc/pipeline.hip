@@ -82,6 +82,7 @@ struct mcrx_hip_pipeline_s {
     hipEvent_t evA[kMaxBuf] = {}, evB[kMaxBuf] = {}, evC[kMaxBuf] = {}, ev_after = nullptr;
     uint64_t ticket[kMaxBuf] = {}; bool has_ticket[kMaxBuf] = {};
     uint64_t rounds = 0;
+    float *din[kMaxBuf] = {};                                   // push_host: this rank's sub-slab with its 13 halo blocks in front, rotating
     ncclComm_t comm = nullptr;
     bool timing = false; std::vector<std::pair<hipEvent_t, hipEvent_t>> xev; size_t xused = 0; double x_ms = 0; uint64_t x_n = 0;
 };
@@ -106,6 +107,7 @@ extern "C" int mcrx_hip_pipeline_destroy(mcrx_hip_pipeline_t p)
     if (p->comm) (void)g_rccl.CommDestroy(p->comm);
     for (unsigned i = 0; i < kMaxBuf; i++) {
         if (p->recv[i]) (void)hipFree(p->recv[i]);
+        if (p->din[i]) (void)hipFree(p->din[i]);
         if (p->world > 1 && p->out[i]) (void)hipFree(p->out[i]);
         hipEvent_t ev[3] = { p->evA[i], p->evB[i], p->evC[i] };
         for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
@@ -246,6 +248,19 @@ extern "C" int mcrx_hip_pipeline_push(mcrx_hip_pipeline_t p, const void *d_iq_su
     p->ticket[i] = mcrx_hip_launches(p->rx) - 1; p->has_ticket[i] = true;
     p->rounds++;
     return MCRX_OK;
+}
+
+// The same round fed from host memory (the reference's Execute takes host buffers: lib/multichannelrx.cc:155): `iq` holds the 13
+// blocks in front of this rank's sub-slab followed by the sub-slab itself, (13 + sub_blocks) * 2N cf32, contiguous.  The copy goes
+// to one of the rotating device buffers on the channelizer's stream (its last reader, the channelizer of nbuf rounds ago, ran there).
+extern "C" int mcrx_hip_pipeline_push_host(mcrx_hip_pipeline_t p, const float *iq_with_halo)
+{
+    if (!p || !iq_with_halo) return pfail(MCRX_EINVAL, "null argument");
+    const unsigned i = (unsigned)(p->rounds % p->nbuf);
+    const size_t n = (size_t)(13 + p->Tc) * p->K;
+    if (!p->din[i]) PCHK(hipMalloc((void **)&p->din[i], n * 2 * sizeof(float)));
+    PCHK(hipMemcpyAsync(p->din[i], iq_with_halo, n * 2 * sizeof(float), hipMemcpyHostToDevice, p->sA));
+    return mcrx_hip_pipeline_push(p, p->din[i] + (size_t)13 * p->K * 2, p->din[i], MCRX_STREAM_READY);
 }
 
 extern "C" int mcrx_hip_pipeline_wait(mcrx_hip_pipeline_t p)

@@ -4,8 +4,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <mutex>
+#include <string>
 #include <vector>
+#include <unistd.h>
 
 #include "multichannelrx.h"
 #include "mcrx_hip.h"
@@ -19,25 +22,90 @@ struct multichannelrx::impl {
     const char *debug_dir;                                          // $MCRX_DEBUG_DIR (NULL: no dump at destruction)
     std::vector<std::vector<std::complex<float> > > debug_syms;    // [channel]: equalised symbols of its last frame
     std::vector<unsigned long> debug_frames;
+    // Sharded over the GPUs of a node (one process per GPU), switched on from outside the unchanged application:
+    //   MCRX_WORLD / MCRX_RANK   ranks of the job and this process's number (a launcher's WORLD_SIZE / RANK are taken as well)
+    //   MCRX_UID_FILE            where rank 0 leaves the 128-byte ncclUniqueId for the others (world > 1)
+    //   MCRX_SUB_BLOCKS          blocks of 2N samples per rank and round (default 8192)
+    // Every rank is handed the whole wideband stream, like every process behind a shared radio would be; of each round of
+    // world x sub_blocks blocks it channelizes sub-slab number `rank`, one exchange turns the time shards into channel shards, and
+    // this object's callbacks fire for its shard of num_channels / world channels only (mcrx_hip_pipeline_*, csrc/pipeline.hip).
+    mcrx_hip_pipeline_t pipe;
+    int rank, world;
+    size_t sub_blocks, K, fill;                                     // fill: samples of the current round in `round` behind the halo
+    std::vector<std::complex<float> > round;                       // [13 halo blocks][world * sub_blocks blocks]
 };
+
+static int env_int(const char *a, const char *b, int dflt)
+{
+    const char *v = getenv(a);
+    if (!v && b) v = getenv(b);
+    return v ? atoi(v) : dflt;
+}
 
 multichannelrx::multichannelrx(unsigned int _num_channels, unsigned int _M, unsigned int _cp_len,
                                unsigned int _taper_len, unsigned char *_p, void **_userdata,
                                framesync_callback *_callback)
     : num_channels(_num_channels), pimpl(new impl)
 {
-    pimpl->h = NULL;
+    pimpl->h = NULL; pimpl->pipe = NULL;
+    pimpl->world = getenv("MCRX_WORLD") ? env_int("MCRX_WORLD", NULL, 1) : 0;       // 0: not sharded (the plain receiver, no pipeline in between)
+    pimpl->rank = env_int("MCRX_RANK", "RANK", 0);
+    pimpl->sub_blocks = (size_t)env_int("MCRX_SUB_BLOCKS", NULL, 8192) / MCRX_TILE * MCRX_TILE;
+    pimpl->K = 2 * (size_t)_num_channels; pimpl->fill = 0;
     pimpl->debug_dir = getenv("MCRX_DEBUG_DIR");
     pimpl->debug_syms.resize(_num_channels); pimpl->debug_frames.assign(_num_channels, 0);
     mcrx_hip_config cfg;
     memset(&cfg, 0, sizeof(cfg));
     cfg.struct_size = sizeof(cfg);
     cfg.payload_soft = 1;
+    const int W = pimpl->world;
+    if (W > 0) {
+        if (pimpl->rank < 0 || pimpl->rank >= W || _num_channels % (unsigned)W || pimpl->sub_blocks == 0) {
+            fprintf(stderr, "error: multichannelrx, MCRX_WORLD = %d must divide the %u channels, MCRX_RANK = %d lie in [0, MCRX_WORLD), MCRX_SUB_BLOCKS be at least %d\n",
+                    W, _num_channels, pimpl->rank, MCRX_TILE);
+            delete pimpl;
+            throw 0;
+        }
+        cfg.channel_count = _num_channels / (unsigned)W; cfg.channel_first = (unsigned)pimpl->rank * cfg.channel_count;
+        cfg.defer_samples = 16384;              // a frame cut by a round boundary is acquired again, whole, by the next round
+    }
     int rc = mcrx_hip_create(&pimpl->h, _num_channels, _M, _cp_len, _taper_len, _p, &cfg);
     if (rc != MCRX_OK) {
         fprintf(stderr, "%s\n", mcrx_hip_last_error());
         delete pimpl;
         throw 0;
+    }
+    if (W > 0) {
+        unsigned char uid[128];
+        memset(uid, 0, sizeof(uid));
+        const char *uf = getenv("MCRX_UID_FILE");
+        bool ok = true;
+        if (W > 1) {
+            ok = uf != NULL;
+            if (ok && pimpl->rank == 0) {           // rank 0 makes the id and leaves it where the others look (written aside, then renamed)
+                ok = mcrx_hip_pipeline_unique_id(uid) == MCRX_OK;
+                std::string tmp = std::string(uf) + ".tmp";
+                FILE *f = ok ? fopen(tmp.c_str(), "wb") : NULL;
+                ok = f && fwrite(uid, 1, 128, f) == 128;
+                if (f) fclose(f);
+                ok = ok && rename(tmp.c_str(), uf) == 0;
+            } else if (ok) {
+                ok = false;
+                for (int t = 0; t < 600 && !ok; t++) {      // up to a minute
+                    FILE *f = fopen(uf, "rb");
+                    if (f) { ok = fread(uid, 1, 128, f) == 128; fclose(f); }
+                    if (!ok) usleep(100000);
+                }
+            }
+        }
+        if (!ok || mcrx_hip_pipeline_create(&pimpl->pipe, pimpl->h, pimpl->rank, W, W > 1 ? uid : NULL, pimpl->sub_blocks, 0) != MCRX_OK) {
+            fprintf(stderr, "error: multichannelrx, sharded receiver (MCRX_WORLD = %d): %s\n", W,
+                    ok ? mcrx_hip_pipeline_last_error() : "no ncclUniqueId (MCRX_UID_FILE: rank 0 writes it, the others read it)");
+            mcrx_hip_destroy(pimpl->h);
+            delete pimpl;
+            throw 0;
+        }
+        pimpl->round.assign((13 + (size_t)W * pimpl->sub_blocks) * pimpl->K, std::complex<float>(0.f, 0.f));
     }
     for (unsigned int i = 0; i < _num_channels; i++) {
         pimpl->userdata.push_back(_userdata ? _userdata[i] : NULL);
@@ -48,8 +116,10 @@ multichannelrx::multichannelrx(unsigned int _num_channels, unsigned int _M, unsi
 multichannelrx::~multichannelrx()
 {
     if (pimpl->h) {
+        if (pimpl->pipe) mcrx_hip_pipeline_wait(pimpl->pipe);
         mcrx_hip_flush(pimpl->h);
         Deliver();
+        if (pimpl->pipe) mcrx_hip_pipeline_destroy(pimpl->pipe);
         mcrx_hip_destroy(pimpl->h);
     }
     if (pimpl->debug_dir) {
@@ -104,6 +174,29 @@ void multichannelrx::Reset()
 void multichannelrx::Execute(std::complex<float> *_x, unsigned int _num_samples)
 {
     std::lock_guard<std::recursive_mutex> lk(pimpl->mu);
+    if (pimpl->pipe) {
+        // sharded: the stream is collected a round at a time; of every full round this rank's sub-slab (the 13 blocks in front of
+        // it included: they sit right there in the stream) goes to the GPU, and the frames of the rounds before come back
+        const size_t K = pimpl->K, halo = 13 * K, cap = (size_t)pimpl->world * pimpl->sub_blocks * K;
+        size_t done = 0;
+        while (done < _num_samples) {
+            const size_t take = std::min<size_t>(_num_samples - done, cap - pimpl->fill);
+            memcpy(pimpl->round.data() + halo + pimpl->fill, _x + done, take * sizeof(std::complex<float>));
+            pimpl->fill += take; done += take;
+            if (pimpl->fill < cap) break;
+            const std::complex<float> *mine = pimpl->round.data() + (size_t)pimpl->rank * pimpl->sub_blocks * K;      // = halo of sub-slab `rank`
+            if (mcrx_hip_pipeline_push_host(pimpl->pipe, reinterpret_cast<const float *>(mine)) != MCRX_OK) {
+                fprintf(stderr, "error: multichannelrx::Execute(), %s\n", mcrx_hip_pipeline_last_error());
+                throw 0;
+            }
+            mcrx_hip_pipeline_wait(pimpl->pipe);                    // (the round buffer is about to be overwritten)
+            memmove(pimpl->round.data(), pimpl->round.data() + cap, halo * sizeof(std::complex<float>));             // the next round's first halo
+            pimpl->fill = 0;
+            mcrx_hip_poll(pimpl->h);
+            if (mcrx_hip_frames_pending(pimpl->h)) Deliver();
+        }
+        return;
+    }
     int rc = mcrx_hip_execute_host(pimpl->h, reinterpret_cast<const float *>(_x), _num_samples);
     if (rc != MCRX_OK && rc != MCRX_EOVERFLOW) { fprintf(stderr, "error: multichannelrx::Execute(), %s\n", mcrx_hip_last_error()); throw 0; }
     if (rc == MCRX_EOVERFLOW)
@@ -122,6 +215,7 @@ void multichannelrx::ExecuteDevice(const void *_d_x, unsigned int _num_samples)
 void multichannelrx::Flush()
 {
     std::lock_guard<std::recursive_mutex> lk(pimpl->mu);
+    if (pimpl->pipe) mcrx_hip_pipeline_wait(pimpl->pipe);       // (samples of an unfinished round stay where they are: every rank needs the whole round)
     mcrx_hip_flush(pimpl->h);
     Deliver();
 }

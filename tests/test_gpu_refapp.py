@@ -35,6 +35,30 @@ def test_unchanged_reference_app_decodes_synthetic_traffic(oracle, tmp_path):
     assert "PAYLOAD INVALID" not in out.stdout.split("usrp data transfer started")[1][:2000]
 
 
+@pytest.mark.skipif(not os.path.exists(EXE), reason="reference app binary not built")
+def test_unchanged_reference_app_through_the_sharded_receiver(oracle, tmp_path):
+    """The same unchanged application with the receiver class switched to its multi-GPU form from outside (MCRX_WORLD / MCRX_RANK /
+    MCRX_SUB_BLOCKS: host/multichannelrx.cc over mcrx_hip_pipeline_*), world = 1 -- the one size a one-GPU lease can run: rounds of
+    512 blocks fed from host memory, frames cut by round boundaries re-acquired by the next round.  Same packets as the plain receiver."""
+    N, M, cp, tp = 4, 64, 8, 4
+    iq, sent = oracle.synth_traffic(N, M, cp, tp, 6, payload_len=120)
+    f = tmp_path / "iq.bin"
+    iq.astype(np.complex64).tofile(f)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "liquid-usrp_amd", "host"), "-s"])
+    got = {}
+    for mode, extra in (("plain", {}), ("sharded", {"MCRX_WORLD": "1", "MCRX_RANK": "0", "MCRX_SUB_BLOCKS": "512"})):
+        env = dict(os.environ, MCRX_IQ_FILE=str(f), MCRX_IQ_PACKET="4096", **extra)
+        out = subprocess.run([EXE, "-n", str(N), "-M", str(M), "-C", str(cp), "-T", str(tp), "-t", "0.5", "-v"],
+                             env=env, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert "INVALID" not in out.stdout.split("usrp data transfer started")[1]
+        got[mode] = set(re.findall(r"channel: (\d+) rx packet id:\s+(\d+)\n", out.stdout))
+    assert len(got["plain"]) >= 6 * N and got["sharded"] == got["plain"]
+    env = dict(os.environ, MCRX_IQ_FILE=str(f), MCRX_WORLD="3", MCRX_RANK="0")          # 3 ranks do not divide 4 channels: the constructor's error path
+    out = subprocess.run([EXE, "-n", str(N), "-M", str(M), "-C", str(cp), "-T", str(tp), "-t", "0.1"], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "MCRX_WORLD" in out.stderr
+
+
 TXEXE = os.path.join(ROOT, "liquid-usrp_amd", "lib", "multichannel_tx_ref")
 
 
