@@ -2813,7 +2813,8 @@ __global__ __launch_bounds__(DK_T) void decode_kernel(SyncArgs a, uint32_t lds_s
     uint32_t nl = a.live[0];
     if (nl > a.max_jobs) nl = a.max_jobs;
     for (uint32_t k = blockIdx.x; k < nl; k += gridDim.x) {
-        decode_frame(a, a.live[1u + k], lds_soft_bytes, msg_bytes);
+        const uint32_t j = a.live[1u + k];
+        decode_frame(a, j, lds_soft_bytes, msg_bytes);
         __syncthreads();                                        // (the next frame reuses the staging area)
     }
 }
@@ -3094,7 +3095,11 @@ hipError_t sync_launch_payload(const SyncArgs &a0, int stage, hipStream_t st)
     // holds more than expected only takes a second turn
     unsigned ngrid = a.frames_hint == ~0u ? nj : a.frames_hint + a.frames_hint / 4 + 64;
     if (ngrid > nj) ngrid = nj;
+    a.live_off = 0;
     const bool fast = a.c.log2M >= 6 && a.c.M == WV * a.c.E && a.c.M_pilot <= WV && !(a.no_fast & 1);
+    // the M = 64 lean workers take one BPSK / QPSK frame per wave out of the first `ngrid` of the live list; the launch behind them
+    // walks the rest of it (live_off tells it where the grid ended)
+    if (fast && a.c.M == WV && a.c.M_pilot <= 16 && a.payload_fr == 1 && a.payload_lean && !(a.no_fast & 6)) a.live_off = ngrid;
     a.dec_lds_soft = fast ? decode_soft_lds(a) : 0u;
     if (!fast) a.gen_list = nullptr;
     if (stage == 0) {
@@ -3110,6 +3115,7 @@ hipError_t sync_launch_payload(const SyncArgs &a0, int stage, hipStream_t st)
     }
     if (stage == 3) {                       // the frames on the general list (filled by decode_kernel)
         if (!fast) return hipSuccess;
+
         // (grids from the lists' most recent sizes: kernels.h, list_hint)
         if (a.vit_list) hipLaunchKernelGGL(viterbi_blocks_kernel, dim3(a.grid_hint[1] ? 8192 : 64), dim3(WV), (size_t)(VIT_B + VIT_W) * 8, st, a);
         hipLaunchKernelGGL(decode_general_kernel, dim3(a.grid_hint[2] ? (nj < 4096 ? nj : 4096) : 64), dim3(WV), (size_t)VIT_B * 8, st, a);
@@ -3128,11 +3134,12 @@ hipError_t sync_launch_payload(const SyncArgs &a0, int stage, hipStream_t st)
             const size_t pad = (size_t)a.payload_lds_pad;
             if (!a.payload_lean) hipLaunchKernelGGL(payload_multi_kernel<1>, dim3(nj), dim3(WV), pad, st, a);
             else {
+                // (... and one list-driven launch for what the main one does not take: frames beyond its grid, QAM payloads; sized by the
+                //  QAM list's most recent length)
                 unsigned nq = a.grid_hint[0] == ~0u ? nj : 2u * a.grid_hint[0];
                 nq = nq < 256u ? 256u : (nq > nj ? nj : nq);
-#define SY_LEAN(XB) do { a.live_off = ngrid; hipLaunchKernelGGL(payload_lean_kernel<XB>, dim3(ngrid), dim3(WV), pad, st, a); \
-                         if (ngrid < nj) hipLaunchKernelGGL(payload_lean_rest_kernel<XB>, dim3(256), dim3(WV), pad, st, a); \
-                         hipLaunchKernelGGL(payload_lean_qam_kernel<XB>, dim3(a.qam_list ? nq : nj), dim3(WV), pad, st, a); } while (0)
+#define SY_LEAN(XB) do { hipLaunchKernelGGL(payload_lean_kernel<XB>, dim3(ngrid), dim3(WV), pad, st, a); \
+                         hipLaunchKernelGGL(payload_lean_rest_kernel<XB>, dim3(a.qam_list ? nq : nj), dim3(WV), pad, st, a); } while (0)
                 if (xb == 0) SY_LEAN(0);
                 else         SY_LEAN(63);
 #undef SY_LEAN

@@ -304,5 +304,7 @@ __device__ __forceinline__ void payload_lean_body(SyncArgs &a)
     }
 }
 template <int XB> __global__ __launch_bounds__(WV) __attribute__((amdgpu_num_sgpr(72))) void payload_lean_kernel(SyncArgs a) { payload_lean_body<XB, 0>(a); }
-template <int XB> __global__ __launch_bounds__(WV) void payload_lean_rest_kernel(SyncArgs a) { payload_lean_body<XB, 0, true>(a); }
-template <int XB> __global__ __launch_bounds__(WV) void payload_lean_qam_kernel(SyncArgs a) { payload_lean_body<XB, 1>(a); }
+// ONE list-driven launch behind the main one for everything it did not take: the BPSK / QPSK frames beyond its grid, then the QAM frames
+// (rounds 2-4 had a launch each, nearly always empty -- and an empty kernel still has to find a free wave slot on a full chip before the
+// decoder behind it may start: 70-85 us of the work stream's time per push and launch, profiles/r4_s1_kernel_stats.csv)
+template <int XB> __global__ __launch_bounds__(WV) void payload_lean_rest_kernel(SyncArgs a) { payload_lean_body<XB, 0, true>(a); payload_lean_body<XB, 1>(a); }
