@@ -6,8 +6,10 @@
 //   * callbacks fire on the calling thread at flush points -- when the internal staging buffer
 //     fills inside Execute(), in Reset(), in Flush() and in the destructor -- in the reference's
 //     order (frame end time, then channel index), not synchronously per sample;
-//   * samples are consumed in whole tiles of 8 channelizer blocks (16*N samples); a shorter
+//   * samples are consumed in whole tiles of 16 channelizer blocks (MCRX_TILE: 32*N samples); a shorter
 //     tail waits for more input;
+//   * MCRX_WORLD / MCRX_RANK / MCRX_UID_FILE / MCRX_SUB_BLOCKS in the environment make the object one rank of a receiver
+//     sharded over the GPUs of a node (host/multichannelrx.cc): callbacks fire for its channel shard;
 //   * the reference's BST_DEBUG file dump at destruction (lib/multichannelrx.cc:118-122) is liquid's internal state; with
 //     $MCRX_DEBUG_DIR set the destructor writes the same file names (framesync_channel%u.m) with each channel's frame count
 //     and the equalised symbols of its last frame.
