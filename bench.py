@@ -71,6 +71,7 @@ def parse():
     ap.add_argument("--aperiodic-steps", type=int, default=20)
     ap.add_argument("--slab-blocks", type=int, default=0)
     ap.add_argument("--chunk-blocks", type=int, default=0, help="split every push into sub-slabs of this many blocks")
+    ap.add_argument("--defer", type=int, default=-1, help="cfg.defer_samples (experiments; default: 16384 on the pipeline paths, 0 on the direct one)")
     ap.add_argument("--serial", action="store_true", help="time the unpipelined receiver (every kernel in order on one stream)")
     ap.add_argument("--pipeline", action="store_true", help="--gpus 1 through the multi-GPU code path (sharding.Pipeline, exchange = local copy)")
     ap.add_argument("--exchange", choices=["auto", "torch", "c"], default="auto",
@@ -153,6 +154,8 @@ def main():
         # rounds cut the stream anywhere: a frame that straddles two rounds is acquired again by the next round (whole, by
         # the parallel path) instead of being walked symbol by symbol -- the history in front of every round covers a frame
         cfg["defer_samples"] = 16384
+    if args.defer >= 0:
+        cfg["defer_samples"] = args.defer
     if args.slab_blocks:
         cfg["slab_blocks"] = args.slab_blocks
     if args.chunk_blocks:
@@ -242,7 +245,10 @@ def main():
 
         def step(harvest_rx=None):
             for c in range(rounds):
-                pipe.push(mine[c], None if first_push[0] else halos[c])
+                if use_c:
+                    pipe.push(mine[c], None if first_push[0] else halos[c], ready=True)      # (resident since the fence behind the generator)
+                else:
+                    pipe.push(mine[c], None if first_push[0] else halos[c])
                 first_push[0] = False
             if harvest_rx is None:
                 rx.Discard()

@@ -114,9 +114,9 @@ int  mcrx_hip_execute_device(mcrx_hip_t q, const void *d_iq, size_t nsamples, vo
 /* wait for all pushed samples, gather decoded frames (ordered by end time, then channel). */
 int  mcrx_hip_flush(mcrx_hip_t q);
 /* Overlapped harvest for a stream that keeps coming (callbacks inside Execute, lib/multichannelrx.cc:193-194, at
- * slab granularity): gathers the frames of everything pushed before the PREVIOUS poll -- waiting only for those
- * launches -- and marks what was pushed since for the next poll.  With one push + one poll per slab, slab k-1's
- * frames cross the host link while the GPU works on slab k. */
+ * slab granularity): gathers the frames of everything pushed before the poll BEFORE THE PREVIOUS one -- waiting only for those
+ * launches -- and marks what was pushed since.  With one push + one poll per slab, slab k-2's frames cross the host link while
+ * the GPU has slabs k-1 and k in flight (two, so that consecutive slabs keep overlapping on the device); flush delivers the rest. */
 int  mcrx_hip_poll(mcrx_hip_t q);
 /* as poll, but the frames are dropped on the device (no host wait, no copy): steady-state benchmarking.  Dropped frames are
  * never delivered by a later poll / flush. */

@@ -484,11 +484,19 @@ class pipeline(object):
         if rc != MCRX_OK:
             raise McrxError("mcrx_hip_pipeline_%s failed (%d): %s" % (what, rc, lib().mcrx_hip_pipeline_last_error().decode()))
 
-    def push(self, iq_sub, halo=None, after=None):
-        """`after`: the torch stream that produced iq_sub / halo (default: the current one)."""
+    def push(self, iq_sub, halo=None, after=None, ready=False):
+        """`after`: the torch stream that produced iq_sub / halo (default: the current one) -- the round starts behind what is enqueued
+        there.  ready=True: the buffers are complete (the caller has synchronized since writing them), wait for nothing
+        (MCRX_STREAM_READY).  Mind that torch's default stream is HIP's legacy NULL stream: an event recorded there is a barrier
+        across every blocking stream of the process, the handle's own included -- a caller that pushes from the default stream
+        every round serializes its rounds (bench.py --pipeline: 170 -> 70 Gsample/s); push from a side stream, or say ready."""
         import torch
-        st = after if after is not None else torch.cuda.current_stream(iq_sub.device)
-        self._chk(lib().mcrx_hip_pipeline_push(self._h, _dptr(iq_sub), _dptr(halo), _stream_ptr(st)), "push")
+        if ready:
+            ptr = C.c_void_p(-1 & 0xFFFFFFFFFFFFFFFF)
+        else:
+            st = after if after is not None else torch.cuda.current_stream(iq_sub.device)
+            ptr = _stream_ptr(st)
+        self._chk(lib().mcrx_hip_pipeline_push(self._h, _dptr(iq_sub), _dptr(halo), ptr), "push")
         self.rounds += 1
 
     def wait(self):

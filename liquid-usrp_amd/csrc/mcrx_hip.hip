@@ -163,6 +163,8 @@ struct mcrx_hip_s {
     hipStream_t acq_stream = nullptr;        // the stream the last launch's acquisition / placement kernels ran on (they write the generation's counters)
     uint64_t gen_close_seq[MCRX_GENS] = {}, close_counter = 0;      // order in which generations were closed (= delivery order)
     hipEvent_t ev_gen[MCRX_GENS] = {};       // recorded behind the last launch that wrote into the generation
+    hipEvent_t ev_clean[MCRX_GENS] = {};     // recorded behind the zeroing of a collected generation's counters: the next launch into it starts behind that
+    bool clean_pending[MCRX_GENS] = {};
     uint64_t sarena_cap = 0;
     // per-launch slots
     PayloadJob *d_jobs[MCRX_SLOTS] = {}; uint32_t *d_njobs = nullptr; float2 *d_jR[MCRX_SLOTS] = {};
@@ -498,6 +500,7 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
         if ((rc = q->alloc(&q->d_nrec[g], 2))) return bail(rc);
         if ((rc = q->alloc(&q->d_arena_used[g], 2))) return bail(rc);
         if (hipEventCreateWithFlags(&q->ev_gen[g], hipEventDisableTiming) != hipSuccess) return bail(fail(MCRX_EHIP, "hipEventCreate failed"));
+        if (hipEventCreateWithFlags(&q->ev_clean[g], hipEventDisableTiming) != hipSuccess) return bail(fail(MCRX_EHIP, "hipEventCreate failed"));
     }
     q->scout = getenv("MCRX_NO_SCOUT") == nullptr;
     q->debug = getenv("MCRX_DEBUG") ? atoi(getenv("MCRX_DEBUG")) : 0;
@@ -604,7 +607,7 @@ extern "C" int mcrx_hip_destroy(mcrx_hip_t q)
     {
         hipEvent_t evs[] = { q->ev_in, q->ev_consumed, q->ev_tmp[0], q->ev_tmp[1], q->ev_tmp[2] };
         for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
-        for (int g = 0; g < MCRX_GENS; g++) if (q->ev_gen[g]) (void)hipEventDestroy(q->ev_gen[g]);
+        for (int g = 0; g < MCRX_GENS; g++) { if (q->ev_gen[g]) (void)hipEventDestroy(q->ev_gen[g]); if (q->ev_clean[g]) (void)hipEventDestroy(q->ev_clean[g]); }
         for (int sl = 0; sl < MCRX_SLOTS; sl++) {
             if (q->ev_ready[sl]) (void)hipEventDestroy(q->ev_ready[sl]);
             if (q->ev_scout[sl]) (void)hipEventDestroy(q->ev_scout[sl]);
@@ -710,6 +713,7 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     }
     if (!q->scout) HIPCHK(hipMemsetAsync(a.njobs, 0, sizeof(uint32_t), sa));     // (with the scout, the previous launch's placement kernel zeroed it)
     q->acq_stream = sa;
+    if (q->clean_pending[g]) { HIPCHK(hipStreamWaitEvent(sa, q->ev_clean[g], 0)); q->clean_pending[g] = false; }
     RC(q->ev_begin(1, sa));
     a.stop_after_walk = 0; a.tail_only = 0; a.defer_limit = (int64_t)q->defer; a.burst_limit = 0; a.round_idx = 0;
     if (q->spec) {
@@ -734,6 +738,9 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
             float want = F / (float)q->seg_frames;                                   // chains of seg_frames (+ 2) frames ...
             const float fill = 1536.0f / (float)q->nch;                              // ... shorter while the chip is not full (1.5 waves per SIMD)
             if (want < fill) want = fill < F / 2.0f ? fill : F / 2.0f;
+            // on a cadence the lattice starts make segments free (no wasted acquisitions), so chains go down to two frames while
+            // all the waves still run at once (2 per SIMD): what a few-channel receiver's push is made of is this chain's latency
+            if (q->cadenced) { const float conc = 2048.0f / (float)q->nch, two = F / 2.0f; const float c2 = conc < two ? conc : two; if (want < c2) want = c2; }
             const float room = ((float)MCRX_SPEC_MAX - 1.25f * F) / 3.0f;            // F / nseg * 1.25 + 3 slots per wave must fit
             if (want > room) want = room;
             nseg = want < 1.0f ? 1u : (want > 32.0f ? 32u : (uint32_t)(want + 0.5f));
@@ -1116,7 +1123,7 @@ static int collect(mcrx_hip_t q, int g)
     if (q->gen_abandoned[g]) {              // dropped by mcrx_hip_discard: never delivered, only cleaned
         HIPCHK(hipMemsetAsync(q->d_nrec[g], 0, 2 * sizeof(uint32_t), q->s_copy));
         HIPCHK(hipMemsetAsync(q->d_arena_used[g], 0, 2 * sizeof(unsigned long long), q->s_copy));
-        HIPCHK(hipStreamSynchronize(q->s_copy));
+        HIPCHK(hipEventRecord(q->ev_clean[g], q->s_copy)); q->clean_pending[g] = true;
         q->gen_closed[g] = false; q->gen_used[g] = false; q->gen_abandoned[g] = false;
         return MCRX_OK;
     }
@@ -1153,9 +1160,11 @@ static int collect(mcrx_hip_t q, int g)
         std::stable_sort(q->recs.begin() + r0, q->recs.end(), [](const FrameRec &a, const FrameRec &b) {
             return a.end_sample != b.end_sample ? a.end_sample < b.end_sample : a.channel < b.channel; });
     }
+    // (the counters are zeroed on the copy stream without waiting for it: a fill is a kernel, and on a full chip a kernel waits
+    //  100-200 us for a wave slot -- with the host waiting for it, every poll.  The next launch into this generation waits instead.)
     HIPCHK(hipMemsetAsync(q->d_nrec[g], 0, 2 * sizeof(uint32_t), q->s_copy));
     HIPCHK(hipMemsetAsync(q->d_arena_used[g], 0, 2 * sizeof(unsigned long long), q->s_copy));
-    HIPCHK(hipStreamSynchronize(q->s_copy));
+    HIPCHK(hipEventRecord(q->ev_clean[g], q->s_copy)); q->clean_pending[g] = true;
     q->gen_closed[g] = false; q->gen_used[g] = false;
     return cnt[1] ? MCRX_EOVERFLOW : MCRX_OK;
 }
@@ -1167,15 +1176,19 @@ static void close_generation(mcrx_hip_t q)
     q->gen_closed[g] = true; q->gen_close_seq[g] = ++q->close_counter;
     q->gen = next;
 }
-// collect every closed generation, oldest first
-static int collect_closed(mcrx_hip_t q)
+// collect every closed generation, oldest first (keep_newest: all but the one closed last -- mcrx_hip_poll)
+static int collect_closed(mcrx_hip_t q, int keep_newest = 0)
 {
     int rc = MCRX_OK;
     while (true) {
-        int best = -1;
-        for (int g = 0; g < MCRX_GENS; g++)
-            if (q->gen_closed[g] && (best < 0 || q->gen_close_seq[g] < q->gen_close_seq[best])) best = g;
-        if (best < 0) break;
+        int best = -1, newest = -1, nclosed = 0;
+        for (int g = 0; g < MCRX_GENS; g++) {
+            if (!q->gen_closed[g]) continue;
+            nclosed++;
+            if (best < 0 || q->gen_close_seq[g] < q->gen_close_seq[best]) best = g;
+            if (newest < 0 || q->gen_close_seq[g] > q->gen_close_seq[newest]) newest = g;
+        }
+        if (best < 0 || nclosed <= keep_newest) break;
         const int r = collect(q, best);
         if (r != MCRX_OK && r != MCRX_EOVERFLOW) return r;
         if (r == MCRX_EOVERFLOW) rc = r;
@@ -1204,8 +1217,12 @@ static int harvest(mcrx_hip_t q)
 extern "C" int mcrx_hip_poll(mcrx_hip_t q)
 {
     if (!q) return fail(MCRX_EINVAL, "null handle");
+    // Two pushes stay in flight: what is collected here was closed by the poll before the previous one, so the wait is for the
+    // launches of two pushes ago while the device has the last two queued.  (Collecting the previous poll's generation left the
+    // device with ONE push in flight while the host waited, copied and sorted: consecutive pushes no longer overlapped, 0.82 x value.)
     const double t0 = now_s();
-    const int rc = collect_closed(q);
+    static const int keep = getenv("MCRX_POLL_KEEP") ? std::max(0, std::min(MCRX_GENS - 2, atoi(getenv("MCRX_POLL_KEEP")))) : 1;
+    const int rc = collect_closed(q, keep);
     if (rc == MCRX_OK || rc == MCRX_EOVERFLOW) close_generation(q);
     q->pending_bound = record_bound(q, 0);
     q->t_harvest += now_s() - t0;
