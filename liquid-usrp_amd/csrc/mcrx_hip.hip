@@ -743,7 +743,7 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
             if (q->cadenced) { const float conc = 2048.0f / (float)q->nch, two = F / 2.0f; const float c2 = conc < two ? conc : two; if (want < c2) want = c2; }
             const float room = ((float)MCRX_SPEC_MAX - 1.25f * F) / 3.0f;            // F / nseg * 1.25 + 3 slots per wave must fit
             if (want > room) want = room;
-            nseg = want < 1.0f ? 1u : (want > 32.0f ? 32u : (uint32_t)(want + 0.5f));
+            nseg = want < 1.0f ? 1u : (want > 64.0f ? 64u : (uint32_t)(want + 0.5f));
         }
         if (nseg > MCRX_SEG_MAX) nseg = MCRX_SEG_MAX;
         // The anchor phase (kernels.h, SyncArgs::seg_phase) is one more launch and one frame's latency in front of everything else: worth it

@@ -1904,15 +1904,30 @@ struct Walker {
     {
         const int M2 = c.M2;
         if (to > a.end - c.M) to = a.end - c.M;                 // windows stay inside the buffer
+        const float2 *chb = a.chan + ((size_t)a.chan_off + ch) * MCRX_TILE_S;
+        const size_t tstride = (size_t)a.chan_stride * MCRX_TILE_S;
+        if (from < a.buf_first) from = a.buf_first;             // (samples in front of the buffer are not there to be looked at)
+        if (from < 0) from = 0;
         for (int64_t p0 = from; p0 < to; p0 += (int64_t)WV * M2) {
             const int64_t d = p0 + (int64_t)l * M2;
             const bool in = d < to;
-            const int64_t dd = in ? d : p0;
+            const uint32_t r0 = (uint32_t)((in ? d : p0) - a.buf_first);       // window [r0, r0 + M) lies inside the buffer: p0 < to <= end - M
             float2 acc = make_float2(0.f, 0.f); float en = 0.f;
-            for (int n = 0; n < M2; n++) {
-                const float2 u = sample(dd + n), v = sample(dd + n + M2);
-                acc = cadd(acc, cmulc(u, v));
-                en += u.x * u.x + u.y * u.y + v.x * v.x + v.y * v.y;
+            // eight products at a time, their sixteen loads in flight together (branch-free addresses: a chain of 2 M2 round trips
+            // per pass was a frame's worth of latency for the two validation scans every segment wave makes)
+            for (int n0 = 0; n0 < M2; n0 += 8) {
+                float2 u[8], v[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const uint32_t ru = r0 + (uint32_t)(n0 + q), rv = ru + (uint32_t)M2;
+                    u[q] = chb[(size_t)(ru >> MCRX_TILE_SH) * tstride + (ru & (uint32_t)(MCRX_TILE_S - 1))];
+                    v[q] = chb[(size_t)(rv >> MCRX_TILE_SH) * tstride + (rv & (uint32_t)(MCRX_TILE_S - 1))];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    acc = cadd(acc, cmulc(u[q], v[q]));
+                    en += u[q].x * u[q].x + u[q].y * u[q].y + v[q].x * v[q].x + v[q].y * v[q].y;
+                }
             }
             const bool hit = in && (acc.x * acc.x + acc.y * acc.y) > 0.09f * en * en;        // |P| / (E / 2) > 0.6
             const unsigned long long b = __ballot(hit);
@@ -2042,6 +2057,7 @@ struct Walker {
             }
             break;                                              // anything else (invalid header, end of the buffer, idle) is the scout's
         }
+        if ((a.debug & 64) && l == 0 && ch == 0) printf("[segw] g %u phase %d: A %lld P %lld seg [%lld, %lld) p_next %lld frames %u last state %d cur %lld\n", g, phase, (long long)A, (long long)P, (long long)seg_start, (long long)(last ? -1 : seg_end), (long long)p_next, j, s.state, (long long)s.cur);
         void_block();
         if (phase == 1) {                                       // no hand-off: no anchor; segment 0 starts over from the entry state in phase 2
             if (l == 0) { a.anchor[ch] = -1; sl0[0].start = -1; sl0[0].status = 0; }

@@ -1,7 +1,7 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4k; mkdir -p $O
-for w in 8ch c3; do
+for w in 8ch; do
   echo "== $w"
   rocprofv3 --kernel-trace --stats --output-format csv -d $O -o $w -- python $R/scratch/cfg_probe.py $w > $O/$w.log 2>&1
   tail -1 $O/$w.log | cut -c1-300
