@@ -32,6 +32,13 @@
 
 namespace mcrx {
 
+#ifndef CH_NT_STORE
+#define CH_NT_STORE 1   /* the half-granule stores are non-temporal: the line's other half arrives a round later and nobody on this CU reads
+                           either -- 0.591 -> 0.577 ms alone, value 170.4 -> 175.0 in alternating runs of one call (scratch/r4u.sh) */
+#endif
+#ifndef CH_NT_LOAD
+#define CH_NT_LOAD 1    /* ... and so are the loads of the IQ blocks, read once (0.578 -> 0.556-0.571 ms in the same kind of run; small) */
+#endif
 #define CH_R 8          // blocks per round == half a (channel, tile) granule
 static_assert(MCRX_TILE_S == 2 * CH_R, "two rounds fill one granule");
 #define CH_P 14         // taps per branch (m = 7)
@@ -163,7 +170,12 @@ __device__ __forceinline__ void channelizer_rounds(const ChanArgs &a, float2 *ti
         } else src = a.x + (size_t)b * K + n0;
         // the value is not touched here (that would wait for it): the mixer zeroes blocks outside the stream
         if constexpr (C == 2) {
+#if CH_NT_LOAD
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(src));
+#else
             const float4 v = *reinterpret_cast<const float4 *>(src);
+#endif
             dst[0] = make_float2(v.x, v.y); dst[1] = make_float2(v.z, v.w);
         } else dst[0] = src[0];
     };
@@ -333,7 +345,13 @@ __device__ __forceinline__ void channelizer_rounds(const ChanArgs &a, float2 *ti
             if (ok) {
                 const float2 *src = tile + ssrc[k];
                 const float2 v0 = src[0], v1 = src[ROWP];
+#if CH_NT_STORE
+                { typedef float v4f __attribute__((ext_vector_type(4)));
+                  v4f nv = { v0.x, v0.y, v1.x, v1.y };
+                  __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(&out4[(size_t)(sdst[k] + ((uint32_t)rd >> 1) * tile_step + ((uint32_t)rd & 1u) * (CH_R / 2))])); }
+#else
                 out4[(size_t)(sdst[k] + ((uint32_t)rd >> 1) * tile_step + ((uint32_t)rd & 1u) * (CH_R / 2))] = make_float4(v0.x, v0.y, v1.x, v1.y);
+#endif
             }
         }
         lds_barrier();

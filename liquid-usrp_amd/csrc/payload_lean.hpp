@@ -18,6 +18,9 @@
 //     is instantiated per modem; stores take a scalar base + constant lane offsets.
 // MCRX_PAYLOAD_LEAN=0 launches payload_multi_kernel<1> instead (A/B and parity tests).
 
+#ifndef PL_NT_STORE
+#define PL_NT_STORE 0       /* measured, not kept: the equalised symbols as non-temporal stores -- workers 0.333 -> 0.354 ms (scratch/r4u.sh) */
+#endif
 namespace lean {
 
 typedef float v2f __attribute__((ext_vector_type(2)));       // a complex sample in an aligned register pair: the packed-f32 VALU takes it whole
@@ -173,7 +176,11 @@ __device__ __forceinline__ uint32_t symbols(const SyncArgs &a, const PayloadJob 
         uint8_t *ssym = syms + (size_t)ps * 8, *ssoft = soft + (size_t)ps * bps;
         if (inner || (ps + (uint32_t)Md <= mod_len && (ps + (uint32_t)Md) * bps <= nbits)) {
             if (isdata) {
+#if PL_NT_STORE
+                __builtin_nontemporal_store(Z, reinterpret_cast<v2f *>(ssym + so_sym));
+#else
                 *reinterpret_cast<v2f *>(ssym + so_sym) = Z;
+#endif
                 uint8_t *dst = ssoft + so_soft;
                 if constexpr (bps == 1) dst[0] = (uint8_t)sw;
                 else if constexpr (bps == 2) *reinterpret_cast<uint16_t *>(dst) = (uint16_t)sw;
