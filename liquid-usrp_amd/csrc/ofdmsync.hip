@@ -2555,6 +2555,9 @@ __global__ __launch_bounds__(WV) void payload_multi_kernel(SyncArgs a)
 // reads LDS.  A cell's rank in liquid's column walk is a closed form (columns are valid from row 0
 // down to a per-column count), so the passes need no ballots or sequential ranking.
 #define DK_T 256
+#ifndef DK_NT_LOAD
+#define DK_NT_LOAD 1        /* the frame's soft bits (read once) as non-temporal loads: 0.153 -> 0.150 ms */
+#endif
 extern __shared__ __attribute__((aligned(16))) unsigned long long dk_soft[];
 // The passes walk the 8-byte groups with strides of ~2 sqrt(n) (one side) and ~sqrt(n)/2 (the other):
 // in a linear layout either lands on 4 of the 32 bank pairs.  XOR-folding index bits 5..9 into bits
@@ -2708,7 +2711,11 @@ __device__ __forceinline__ void decode_frame(SyncArgs &a, const uint32_t j, uint
         for (uint32_t b0 = 0; b0 < e1; b0 += 8 * DK_T) {           // eight requests per thread in flight
             unsigned long long v[8];
 #pragma unroll
+#if DK_NT_LOAD
+            for (int u = 0; u < 8; u++) { const uint32_t i = b0 + u * DK_T + threadIdx.x; v[u] = __builtin_nontemporal_load(g64 + (i < e1 ? i : 0)); }
+#else
             for (int u = 0; u < 8; u++) { const uint32_t i = b0 + u * DK_T + threadIdx.x; v[u] = g64[i < e1 ? i : 0]; }
+#endif
 #pragma unroll
             for (int u = 0; u < 8; u++) { const uint32_t i = b0 + u * DK_T + threadIdx.x; if (i < e1) dk_soft[DKP(i)] = v[u]; }
         }
@@ -2724,13 +2731,23 @@ __device__ __forceinline__ void decode_frame(SyncArgs &a, const uint32_t j, uint
                 const uint4 *mp = reinterpret_cast<const uint4 *>(c.il_map + (size_t)moff * 8);
                 const uint8_t *sb = reinterpret_cast<const uint8_t *>(dk_soft);
                 unsigned long long *dst = dk_soft + lds_soft_bytes / 8;
-                for (uint32_t i = threadIdx.x; i < e1; i += DK_T) {
-                    const uint4 m = mp[i];
-                    const unsigned src[8] = { m.x & 0xffffu, m.x >> 16, m.y & 0xffffu, m.y >> 16, m.z & 0xffffu, m.z >> 16, m.w & 0xffffu, m.w >> 16 };
-                    unsigned long long v = 0;
+                // (eight table entries per thread requested together: one round trip to the L2-resident table instead of one per entry --
+                //  the gather was 10-16 k of the workgroup's ~32 k cycles, most of it these loads' latency)
+                for (uint32_t i0 = threadIdx.x; i0 < e1; i0 += 8 * DK_T) {
+                    uint4 mm[8];
 #pragma unroll
-                    for (int kb = 0; kb < 8; kb++) v |= (unsigned long long)sb[8u * DKP(src[kb]) + (unsigned)kb] << (8 * kb);
-                    dst[DKP(i)] = v;
+                    for (int u = 0; u < 8; u++) { const uint32_t i = i0 + u * DK_T; mm[u] = mp[i < e1 ? i : 0]; }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const uint32_t i = i0 + u * DK_T;
+                        if (i >= e1) break;
+                        const uint4 m = mm[u];
+                        const unsigned src[8] = { m.x & 0xffffu, m.x >> 16, m.y & 0xffffu, m.y >> 16, m.z & 0xffffu, m.z >> 16, m.w & 0xffffu, m.w >> 16 };
+                        unsigned long long v = 0;
+#pragma unroll
+                        for (int kb = 0; kb < 8; kb++) v |= (unsigned long long)sb[8u * DKP(src[kb]) + (unsigned)kb] << (8 * kb);
+                        dst[DKP(i)] = v;
+                    }
                 }
                 cur = dst;
                 __syncthreads();
@@ -2787,9 +2804,16 @@ __device__ __forceinline__ void decode_frame(SyncArgs &a, const uint32_t j, uint
         const bool by_pos = crc_len && c.crc_pos && n_msg >= 4 && n_msg <= c.crc_pos_n;
         if (by_pos) {
             uint32_t acc = 0;
-            for (uint32_t i = threadIdx.x; i < n_msg; i += DK_T) {
-                const uint32_t b = (uint32_t)msg[i] ^ (i < 4 ? 0xffu : 0u);
-                acc ^= c.crc_pos[(size_t)(n_msg - 1 - i) * 256 + b];
+            for (uint32_t i0 = threadIdx.x; i0 < n_msg; i0 += 8 * DK_T) {              // (eight table reads in flight per thread)
+                uint32_t t[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t i = i0 + u * DK_T, ii = i < n_msg ? i : n_msg - 1;
+                    const uint32_t b = (uint32_t)msg[ii] ^ (ii < 4 ? 0xffu : 0u);
+                    t[u] = c.crc_pos[(size_t)(n_msg - 1 - ii) * 256 + b];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) if (i0 + u * DK_T < n_msg) acc ^= t[u];
             }
             acc = wave_xor_u32(acc);
             if ((threadIdx.x & (WV - 1)) == 0) reinterpret_cast<uint32_t *>(dk_soft)[256 + threadIdx.x / WV] = acc;      // (behind the byte table below)

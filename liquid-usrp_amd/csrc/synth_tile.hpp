@@ -18,6 +18,9 @@
 #pragma once
 
 namespace mcrx {
+#ifndef SYN_NT_STORE
+#define SYN_NT_STORE 0      /* experiment: the wideband output as non-temporal stores */
+#endif
 namespace syn {
 
 // development builds only (scratch/syn_ablate.sh: -DSYN_ABLATE=bits): 1 no radix-4 stages, 2 no register stage, 4 one tap instead
@@ -472,8 +475,14 @@ __global__ __launch_bounds__(K / 2) void synth_kernel(TxSynthArgs a, uint32_t sl
                     const float s1 = fmaf(osn, cd1, ocs * sd1), c1 = fmaf(ocs, cd1, -(osn * sd1));            // the second column
                     const float2 y0 = make_float2(fmaf(acc[r][0].x, ocs, -(acc[r][0].y * osn)), fmaf(acc[r][0].y, ocs, acc[r][0].x * osn));
                     const float2 y1 = make_float2(fmaf(acc[r][1].x, c1, -(acc[r][1].y * s1)), fmaf(acc[r][1].y, c1, acc[r][1].x * s1));
+#if SYN_NT_STORE
+                    { typedef float v4f __attribute__((ext_vector_type(4)));
+                      const v4f nv = { y0.x * a.gain, y0.y * a.gain, y1.x * a.gain, y1.y * a.gain };
+                      __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(uniform_ptr(outb + (size_t)(b - (long long)a.out_first) * K * sizeof(float2)) + ooff)); }
+#else
                     *reinterpret_cast<float4 *>(uniform_ptr(outb + (size_t)(b - (long long)a.out_first) * K * sizeof(float2)) + ooff) =
                         make_float4(y0.x * a.gain, y0.y * a.gain, y1.x * a.gain, y1.y * a.gain);
+#endif
                 }
                 { const float s2 = fmaf(osn, ck8, ocs * sk8), c2 = fmaf(ocs, ck8, -(osn * sk8)); osn = s2; ocs = c2; }      // next block
             }
