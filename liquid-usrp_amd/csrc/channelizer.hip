@@ -54,10 +54,16 @@ __device__ __forceinline__ void lds_barrier()
 template <int K> struct Log2 { enum { v = 1 + Log2<K / 2>::v }; };
 template <> struct Log2<1> { enum { v = 0 }; };
 
-// transform plan: S radix-4 LDS stages, then F-point register transforms
+// transform plan: S radix-R LDS stages, then F-point register transforms.  K = 1024 = 8 x 8 x 16 goes through LDS in two
+// radix-8 stages (three radix-4 ones until round 3: a third fewer LDS instructions per round and a barrier less);
+// the other sizes keep radix 4, whose stage count is the same or smaller for them.
+#ifndef CH_RADIX8
+#define CH_RADIX8 1
+#endif
 template <int K> struct Plan {
-    static constexpr int stages() { int L = K, s = 0; while (L > 16) { L /= 4; s++; } return s; }
-    static constexpr int final_size() { int L = K; while (L > 16) L /= 4; return L; }
+    enum { R = (CH_RADIX8 && K == 1024) ? 8 : 4, LR = R == 8 ? 3 : 2 };
+    static constexpr int stages() { int L = K, s = 0; while (L > 16) { L /= R; s++; } return s; }
+    static constexpr int final_size() { int L = K; while (L > 16) L /= R; return L; }
     enum { S = stages(), F = final_size(), RL = K + K / F, ROWP = RL + 1 };
 };
 // element index -> padded LDS index within a row
@@ -68,7 +74,7 @@ __device__ __forceinline__ int dif_pos(int k)
 {
     int L = K, pos = 0;
 #pragma unroll
-    for (int s = 0; s < Plan<K>::S; s++) { pos += (k & 3) * (L >> 2); k >>= 2; L >>= 2; }
+    for (int s = 0; s < Plan<K>::S; s++) { pos += (k & (Plan<K>::R - 1)) * (L >> Plan<K>::LR); k >>= Plan<K>::LR; L >>= Plan<K>::LR; }
     return pos + k;
 }
 
@@ -115,7 +121,7 @@ __device__ __forceinline__ void channelizer_rounds(const ChanArgs &a, float2 *ti
     constexpr int TPS = K / C;              // threads per slab
     constexpr int NS = T / TPS;             // slabs per workgroup
     constexpr int N = K / 2;
-    constexpr int S = Plan<K>::S, F = Plan<K>::F, ROWP = Plan<K>::ROWP;
+    constexpr int S = Plan<K>::S, F = Plan<K>::F, ROWP = Plan<K>::ROWP, R = Plan<K>::R, LR = Plan<K>::LR;
     static_assert(TPS * C == K && NS * TPS == T && NS >= 1, "bad channelizer geometry");
 
     const int tid = threadIdx.x;
@@ -138,15 +144,15 @@ __device__ __forceinline__ void channelizer_rounds(const ChanArgs &a, float2 *ti
         for (int i = 0; i < PER; i++) { const int idx = tid + i * T; if (idx < NT) ltap[idx] = tv[i]; }
     }
     __syncthreads();
-    // radix-4 stage twiddles W_L^{r*pos}, r = 1..3: pos = q % (L/4) does not depend on the
-    // loop trip because L/4 divides the workgroup size
-    float2 tw[S > 0 ? S : 1][3];
+    // radix-R stage twiddles W_L^{r*pos}, r = 1..R-1: pos = q % (L/R) does not depend on the
+    // loop trip because L/R divides the workgroup size
+    float2 tw[S > 0 ? S : 1][R - 1];
 #pragma unroll
     for (int st = 0; st < S; st++) {
-        const int L = K >> (2 * st), q4 = L >> 2;
+        const int L = K >> (LR * st), q4 = L >> LR;
         const int pos = tid % q4;
 #pragma unroll
-        for (int r = 1; r <= 3; r++) {
+        for (int r = 1; r < R; r++) {
             float sn, cs; sincos_u32((uint32_t)(r * pos) * (uint32_t)(4294967296.0 / L), sn, cs);
             tw[st][r - 1] = make_float2(cs, -sn);
         }
@@ -226,18 +232,18 @@ __device__ __forceinline__ void channelizer_rounds(const ChanArgs &a, float2 *ti
     }
 
     // ---- round-invariant addresses
-    constexpr int NBF4 = NS * CH_R * (K / 4);           // radix-4 butterflies per stage
+    constexpr int NBF4 = NS * CH_R * (K / R);           // radix-R butterflies per stage
     constexpr int NG = NS * CH_R * (K / F);             // F-point groups
     constexpr int NOPS = NS * N * (CH_R / 2);           // 16-byte stores per round
-    static_assert(S == 0 || (NBF4 % T == 0 && T % (K / 4) == 0), "a thread's butterflies must differ by whole rows");
+    static_assert(S == 0 || (NBF4 % T == 0 && T % (K / R) == 0), "a thread's butterflies must differ by whole rows");
     static_assert(NG % T == 0 || NG < T, "F-point groups per thread");
     static_assert(NOPS % T == 0, "granule stores per thread");
-    constexpr int BTRIPS = S > 0 ? NBF4 / T : 0, BSTEP = S > 0 ? (T / (K / 4)) * ROWP : 0;
+    constexpr int BTRIPS = S > 0 ? NBF4 / T : 0, BSTEP = S > 0 ? (T / (K / R)) * ROWP : 0;
     int fa[S > 0 ? S : 1];                              // padded LDS index of a butterfly's first element, trip 0
 #pragma unroll
     for (int st = 0; st < S; st++) {
-        const int L = K >> (2 * st), q4 = L >> 2;
-        const int f = tid / (K / 4), j = tid % (K / 4);
+        const int L = K >> (LR * st), q4 = L >> LR;
+        const int f = tid / (K / R), j = tid % (K / R);
         fa[st] = f * ROWP + pad<K>((j / q4) * L + j % q4);
     }
     constexpr int GTRIPS = (NG + T - 1) / T;
@@ -307,11 +313,21 @@ __device__ __forceinline__ void channelizer_rounds(const ChanArgs &a, float2 *ti
         if constexpr (S > 0) {
 #pragma unroll
             for (int st = 0; st < S; st++) {
-                const int L = K >> (2 * st), q4 = L >> 2;
+                const int L = K >> (LR * st), q4 = L >> LR;
                 const int D = q4 + q4 / F;              // padded distance of the butterfly's legs (q4 is a multiple of F)
 #pragma unroll
                 for (int i = 0; i < BTRIPS; i++) {
                     float2 *p = tile + fa[st] + i * BSTEP;
+                    if constexpr (R == 8) {
+                        float2 v[8];
+#pragma unroll
+                        for (int m = 0; m < 8; m++) v[m] = p[m * D];
+                        fft_reg<8>(v);                  // v[m] = X[bitrev(m)]
+                        p[0] = v[0];
+#pragma unroll
+                        for (int r = 1; r < 8; r++) p[r * D] = cmul(v[bitrev_c(r, 3)], tw[st][r - 1]);
+                        continue;
+                    }
                     const float2 x0 = p[0], x1 = p[D], x2 = p[2 * D], x3 = p[3 * D];
                     const float2 a0 = cadd(x0, x2), a1 = csub(x0, x2), a2 = cadd(x1, x3), a3 = cmulnj(csub(x1, x3));
                     p[0] = cadd(a0, a2);
