@@ -2555,6 +2555,9 @@ __global__ __launch_bounds__(WV) void payload_multi_kernel(SyncArgs a)
 // reads LDS.  A cell's rank in liquid's column walk is a closed form (columns are valid from row 0
 // down to a per-column count), so the passes need no ballots or sequential ranking.
 #define DK_T 256
+#ifndef DK_FUSED
+#define DK_FUSED 1
+#endif
 #ifndef DK_NT_LOAD
 #define DK_NT_LOAD 1        /* the frame's soft bits (read once) as non-temporal loads: 0.153 -> 0.150 ms */
 #endif
@@ -2685,11 +2688,9 @@ __device__ __forceinline__ void decode_frame(SyncArgs &a, const uint32_t j, uint
             unsigned long long *o64 = reinterpret_cast<unsigned long long *>(soft);
             for (uint32_t i = threadIdx.x; i < e1; i += DK_T) {
                 const uint4 m = mp[i];
-                const unsigned src[8] = { m.x & 0xffffu, m.x >> 16, m.y & 0xffffu, m.y >> 16, m.z & 0xffffu, m.z >> 16, m.w & 0xffffu, m.w >> 16 };
-                unsigned long long v = 0;
-#pragma unroll
-                for (int kb = 0; kb < 8; kb++) v |= (unsigned long long)sb[8u * DKP(src[kb]) + (unsigned)kb] << (8 * kb);
-                o64[i] = v;
+                const uint32_t lo = (uint32_t)sb[m.x & 0xffffu] | ((uint32_t)sb[m.x >> 16] << 8) | ((uint32_t)sb[m.y & 0xffffu] << 16) | ((uint32_t)sb[m.y >> 16] << 24);
+                const uint32_t hi = (uint32_t)sb[m.z & 0xffffu] | ((uint32_t)sb[m.z >> 16] << 8) | ((uint32_t)sb[m.w & 0xffffu] << 16) | ((uint32_t)sb[m.w >> 16] << 24);
+                o64[i] = (unsigned long long)lo | ((unsigned long long)hi << 32);
             }
         }
         if (threadIdx.x == 0 && a.gen_list) {
@@ -2707,6 +2708,22 @@ __device__ __forceinline__ void decode_frame(SyncArgs &a, const uint32_t j, uint
         return;
     }
     if (lds_path) {
+        // Hamming(12,8) with a gather table: the decoder takes its 12 soft bits straight from where the frame was staged -- table
+        // entries are byte addresses there -- so the de-interleaved copy, its barrier and its re-read never happen, and the first
+        // symbols' table entries are requested before the soft bits, one round trip to memory instead of two in a row
+        const uint32_t moff_h = (fec1 == 6 && c.il_off && e1 < c.il_n) ? c.il_off[e1] : ~0u;
+        const bool fused = DK_FUSED && moff_h != ~0u;
+        constexpr int SU = 4;
+        const uint2 *mp2 = reinterpret_cast<const uint2 *>(c.il_map + (size_t)(fused ? moff_h : 0u) * 8);
+        uint2 pm[SU][3];
+        if (fused) {
+#pragma unroll
+            for (int u = 0; u < SU; u++) {
+                const uint32_t i = threadIdx.x + u * DK_T, ii = i < n0 ? i : 0u;
+#pragma unroll
+                for (int k = 0; k < 3; k++) pm[u][k] = mp2[3u * ii + k];
+            }
+        }
         const unsigned long long *g64 = reinterpret_cast<const unsigned long long *>(soft);
         for (uint32_t b0 = 0; b0 < e1; b0 += 8 * DK_T) {           // eight requests per thread in flight
             unsigned long long v[8];
@@ -2725,7 +2742,32 @@ __device__ __forceinline__ void decode_frame(SyncArgs &a, const uint32_t j, uint
         // codes produce up to the handle's payload limit), one pass builds the de-interleaved groups in the second half of
         // the soft area -- 8 byte reads per coded byte -- instead of four in-place passes of swaps over the first
         unsigned long long *cur = dk_soft;
-        if (fec1 != 1) {
+        uint8_t *msg = reinterpret_cast<uint8_t *>(dk_soft) + 2 * lds_soft_bytes;
+        if (fused) {
+            const uint8_t *sb = reinterpret_cast<const uint8_t *>(dk_soft);
+            for (uint32_t b0 = 0; b0 < n0; b0 += SU * DK_T) {
+                if (b0) {
+#pragma unroll
+                    for (int u = 0; u < SU; u++) {
+                        const uint32_t i = b0 + threadIdx.x + u * DK_T, ii = i < n0 ? i : 0u;
+#pragma unroll
+                        for (int k = 0; k < 3; k++) pm[u][k] = mp2[3u * ii + k];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < SU; u++) {
+                    const uint32_t i = b0 + threadIdx.x + u * DK_T;
+                    if (i >= n0) break;
+                    uint32_t w[3];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        const uint2 m = pm[u][k];
+                        w[k] = (uint32_t)sb[m.x & 0xffffu] | ((uint32_t)sb[m.x >> 16] << 8) | ((uint32_t)sb[m.y & 0xffffu] << 16) | ((uint32_t)sb[m.y >> 16] << 24);
+                    }
+                    msg[i] = (uint8_t)h128_dec_soft_words(w[0], w[1], w[2]);
+                }
+            }
+        } else if (fec1 != 1) {
             const uint32_t moff = (c.il_off && e1 < c.il_n) ? c.il_off[e1] : ~0u;
             if (moff != ~0u) {
                 const uint4 *mp = reinterpret_cast<const uint4 *>(c.il_map + (size_t)moff * 8);
@@ -2742,11 +2784,9 @@ __device__ __forceinline__ void decode_frame(SyncArgs &a, const uint32_t j, uint
                         const uint32_t i = i0 + u * DK_T;
                         if (i >= e1) break;
                         const uint4 m = mm[u];
-                        const unsigned src[8] = { m.x & 0xffffu, m.x >> 16, m.y & 0xffffu, m.y >> 16, m.z & 0xffffu, m.z >> 16, m.w & 0xffffu, m.w >> 16 };
-                        unsigned long long v = 0;
-#pragma unroll
-                        for (int kb = 0; kb < 8; kb++) v |= (unsigned long long)sb[8u * DKP(src[kb]) + (unsigned)kb] << (8 * kb);
-                        dst[DKP(i)] = v;
+                        const uint32_t lo = (uint32_t)sb[m.x & 0xffffu] | ((uint32_t)sb[m.x >> 16] << 8) | ((uint32_t)sb[m.y & 0xffffu] << 16) | ((uint32_t)sb[m.y >> 16] << 24);
+                        const uint32_t hi = (uint32_t)sb[m.z & 0xffffu] | ((uint32_t)sb[m.z >> 16] << 8) | ((uint32_t)sb[m.w & 0xffffu] << 16) | ((uint32_t)sb[m.w >> 16] << 24);
+                        dst[DKP(i)] = (unsigned long long)lo | ((unsigned long long)hi << 32);
                     }
                 }
                 cur = dst;
@@ -2764,7 +2804,6 @@ __device__ __forceinline__ void decode_frame(SyncArgs &a, const uint32_t j, uint
         // decoded bytes (message + CRC key) go to LDS behind the soft bits; the payload leaves for the
         // frame arena from there, coalesced, by the whole workgroup
         const uint32_t *w32 = reinterpret_cast<const uint32_t *>(cur);
-        uint8_t *msg = reinterpret_cast<uint8_t *>(dk_soft) + 2 * lds_soft_bytes;
         auto word = [&](uint32_t w) { return w32[2u * DKP(w >> 1) + (w & 1u)]; };            // 12 soft bits = 3 words, group-swizzled
         // one coded byte = 8 soft bits sliced at 127, MSB first
         auto slice = [&](uint32_t g) -> unsigned {
@@ -2774,7 +2813,8 @@ __device__ __forceinline__ void decode_frame(SyncArgs &a, const uint32_t j, uint
             for (int kb = 0; kb < 8; kb++) b = (b << 1) | ((((unsigned)(v >> (8 * kb)) & 0xffu) > 127u) ? 1u : 0u);
             return b;
         };
-        if (fec1 == 6) {
+        if (fused) {
+        } else if (fec1 == 6) {
             for (uint32_t i = threadIdx.x; i < n0; i += DK_T) msg[i] = (uint8_t)h128_dec_soft_words(word(3 * i), word(3 * i + 1), word(3 * i + 2));
         } else if (fec1 == 7) {
             const uint32_t G = n0 / 3, rr = n0 % 3;                         // 6 coded bytes -> 3 message bytes; tail: 3 -> 1
@@ -2958,7 +2998,8 @@ __global__ __launch_bounds__(WV) void ilmap_build_kernel(const uint32_t *lens, c
     deinterleave<true>(xl, e, 4);
     deinterleave<true>(xh, e, 4);
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < 8 * e; i += WV) map[o + i] = (uint16_t)(xl[i] | ((unsigned)xh[i] << 8));
+    // stored as the soft bit's byte address in decode_kernel's staging area (groups swizzled by DKP): nothing left to compute per read
+    for (uint32_t i = threadIdx.x; i < 8 * e; i += WV) { const unsigned src = xl[i] | ((unsigned)xh[i] << 8); map[o + i] = (uint16_t)(8u * DKP(src) + (i & 7u)); }
 }
 hipError_t ilmap_build_launch(const uint32_t *d_lens, const uint32_t *d_offs, uint32_t nlen, uint8_t *d_lo, uint8_t *d_hi, uint16_t *d_map, hipStream_t st)
 {
