@@ -54,14 +54,14 @@ __device__ __forceinline__ void lds_barrier()
 template <int K> struct Log2 { enum { v = 1 + Log2<K / 2>::v }; };
 template <> struct Log2<1> { enum { v = 0 }; };
 
-// transform plan: S radix-R LDS stages, then F-point register transforms.  K = 1024 = 8 x 8 x 16 goes through LDS in two
+// transform plan: S radix-R LDS stages, then F-point register transforms.  K = 1024 = 8 x 8 x 16 (and 512 = 8 x 8 x 8) goes through LDS in two
 // radix-8 stages (three radix-4 ones until round 3: a third fewer LDS instructions per round and a barrier less);
 // the other sizes keep radix 4, whose stage count is the same or smaller for them.
 #ifndef CH_RADIX8
 #define CH_RADIX8 1
 #endif
 template <int K> struct Plan {
-    enum { R = (CH_RADIX8 && K == 1024) ? 8 : 4, LR = R == 8 ? 3 : 2 };
+    enum { R = (CH_RADIX8 && (K == 1024 || K == 512)) ? 8 : 4, LR = R == 8 ? 3 : 2 };
     static constexpr int stages() { int L = K, s = 0; while (L > 16) { L /= R; s++; } return s; }
     static constexpr int final_size() { int L = K; while (L > 16) L /= R; return L; }
     enum { S = stages(), F = final_size(), RL = K + K / F, ROWP = RL + 1 };

@@ -57,11 +57,16 @@ template <class T> __device__ __forceinline__ T *uniform_ptr(T *p)
     return (T *)reinterpret_cast<GT *>(((unsigned long long)hi << 32) | lo);
 }
 
+// (K = 1024 and 512 cross LDS in radix-8 stages -- a stage fewer than in radix 4 --, like channelizer.hip since round 4)
+#ifndef SYN_RADIX8
+#define SYN_RADIX8 1
+#endif
 template <int K> struct Plan {
-    static constexpr int stages() { int L = K, s = 0; while (L > 16) { L /= 4; s++; } return s; }
-    static constexpr int final_size() { int L = K; while (L > 16) L /= 4; return L; }
+    enum { RR = (SYN_RADIX8 && (K == 1024 || K == 512)) ? 8 : 4, LR = RR == 8 ? 3 : 2 };
+    static constexpr int stages() { int L = K, s = 0; while (L > 16) { L /= RR; s++; } return s; }
+    static constexpr int final_size() { int L = K; while (L > 16) L /= RR; return L; }
     enum { S = stages(), F = final_size(), RL = K + K / F, ROWP = RL + 1 };
-    static constexpr int tw_off(int st) { int o = 0; for (int i = 0; i < st; i++) o += 3 * ((K >> (2 * i)) >> 2); return o; }
+    static constexpr int tw_off(int st) { int o = 0; for (int i = 0; i < st; i++) o += (RR - 1) * ((K >> (LR * i)) >> LR); return o; }
     enum { TW = tw_off(stages()) };
 };
 template <int K> __device__ __forceinline__ int pad(int e) { return e + e / Plan<K>::F; }
@@ -69,7 +74,7 @@ template <int K> __device__ __forceinline__ int dif_pos(int k)
 {
     int L = K, pos = 0;
 #pragma unroll
-    for (int s = 0; s < Plan<K>::S; s++) { pos += (k & 3) * (L >> 2); k >>= 2; L >>= 2; }
+    for (int s = 0; s < Plan<K>::S; s++) { pos += (k & (Plan<K>::RR - 1)) * (L >> Plan<K>::LR); k >>= Plan<K>::LR; L >>= Plan<K>::LR; }
     return pos + k;
 }
 __device__ __forceinline__ float2 w16(int k)
@@ -119,7 +124,7 @@ template <int K, int R, int IN>
 __global__ __launch_bounds__(K / 2) void synth_kernel(TxSynthArgs a, uint32_t slab_blocks)
 {
     constexpr int T = K / 2, N = K / 2, C = 2;
-    constexpr int S = Plan<K>::S, F = Plan<K>::F, ROWP = Plan<K>::ROWP, TAPF = Lds<K, R>::TAPF;
+    constexpr int S = Plan<K>::S, F = Plan<K>::F, ROWP = Plan<K>::ROWP, TAPF = Lds<K, R>::TAPF, RR = Plan<K>::RR, LR = Plan<K>::LR;
     constexpr int LEAD = (SYN_H + R - 1) / R * R;                   // blocks a slab starts early to fill its window
     extern __shared__ __attribute__((aligned(16))) float2 tile[];   // [R][ROWP], taps, twiddles
     const int tid = threadIdx.x;
@@ -136,8 +141,8 @@ __global__ __launch_bounds__(K / 2) void synth_kernel(TxSynthArgs a, uint32_t sl
     float2 *ltw = reinterpret_cast<float2 *>(ltap + TAPF);
 #pragma unroll
     for (int st = 0; st < S; st++) {
-        const int L = K >> (2 * st), q4 = L >> 2;
-        for (int e = tid; e < 3 * q4; e += T) {
+        const int L = K >> (LR * st), q4 = L >> LR;
+        for (int e = tid; e < (RR - 1) * q4; e += T) {
             const int r = e / q4 + 1, pos = e % q4;
             float sn, cs; sincos_u32((uint32_t)(r * pos) * (uint32_t)(4294967296.0 / L), sn, cs);
             ltw[Plan<K>::tw_off(st) + e] = make_float2(cs, -sn);
@@ -156,14 +161,14 @@ __global__ __launch_bounds__(K / 2) void synth_kernel(TxSynthArgs a, uint32_t sl
     const int xrow = opaque(pad<K>(tid));                           // where channel tid's input goes in a row
     const int vsrc0 = opaque(pad<K>(dif_pos<K>(n0))), vsrc1 = opaque(pad<K>(dif_pos<K>(n0 + 1)));
     const float *ltf = reinterpret_cast<const float *>(tile);
-    constexpr int NBF4 = R * (K / 4), NG = R * (K / F);
+    constexpr int NBF4 = R * (K / RR), NG = R * (K / F);
     constexpr bool SPLIT = (2 * NG == T) && F >= 4;
-    static_assert(S == 0 || (NBF4 % T == 0 && T % (K / 4) == 0), "a thread's butterflies differ by whole rows");
+    static_assert(S == 0 || (NBF4 % T == 0 && T % (K / RR) == 0), "a thread's butterflies differ by whole rows");
     static_assert(NG % T == 0 || SPLIT, "F-point groups per thread");
-    constexpr int BTRIPS = S > 0 ? NBF4 / T : 0, BSTEP = S > 0 ? (T / (K / 4)) * ROWP : 0;
+    constexpr int BTRIPS = S > 0 ? NBF4 / T : 0, BSTEP = S > 0 ? (T / (K / RR)) * ROWP : 0;
     auto stage_index = [&](int st, int t) {
-        const int L = K >> (2 * st), q4 = L >> 2;
-        const int f = t / (K / 4), j = t % (K / 4);
+        const int L = K >> (LR * st), q4 = L >> LR;
+        const int f = t / (K / RR), j = t % (K / RR);
         return f * ROWP + pad<K>((j / q4) * L + j % q4);
     };
     auto group_index = [&](int g) { return (g / (K / F)) * ROWP + (g % (K / F)) * (F + 1); };
@@ -340,10 +345,43 @@ __global__ __launch_bounds__(K / 2) void synth_kernel(TxSynthArgs a, uint32_t sl
         if constexpr (S > 0 && (SYN_ABLATE & 1) == 0) {
 #pragma unroll
             for (int st = 0; st < S; st++) {
-                const int L = K >> (2 * st), q4 = L >> 2;
+                const int L = K >> (LR * st), q4 = L >> LR;
                 const int D = q4 + q4 / F;
                 const float2 *twp = tile + R * ROWP + TAPF / 2 + Plan<K>::tw_off(st) + tq % q4;
                 const int fa_st = stage_index(st, tq);
+                if constexpr (RR == 8) {
+                    float2 tw[7];
+#pragma unroll
+                    for (int r = 0; r < 7; r++) tw[r] = twp[r * q4];
+#pragma unroll
+                    for (int i = 0; i < BTRIPS; i++) {
+                        float2 *p = tile + fa_st + i * BSTEP;
+                        float2 v[8];
+                        if (st == 0) {
+                            // legs 4 .. 7 are the zero bins N .. K-1: the first level's sums are the inputs themselves, its
+                            // differences the inputs turned by W_8^m; two 4-point transforms give the even and the odd outputs
+                            float2 e[4], o[4];
+#pragma unroll
+                            for (int m = 0; m < 4; m++) e[m] = p[m * D];
+                            o[0] = e[0]; o[1] = cmul(e[1], w16(2)); o[2] = cmulnj(e[2]); o[3] = cmul(e[3], w16(6));
+                            fft_reg<4>(e); fft_reg<4>(o);           // e[m] = E[bitrev(m)], o likewise
+#pragma unroll
+                            for (int k = 0; k < 4; k++) { v[2 * k] = e[bitrev_c(k, 2)]; v[2 * k + 1] = o[bitrev_c(k, 2)]; }     // v[r] = X[r]
+                            p[0] = v[0];
+#pragma unroll
+                            for (int r = 1; r < 8; r++) p[r * D] = cmul(v[r], tw[r - 1]);
+                        } else {
+#pragma unroll
+                            for (int m = 0; m < 8; m++) v[m] = p[m * D];
+                            fft_reg<8>(v);                          // v[m] = X[bitrev(m)]
+                            p[0] = v[0];
+#pragma unroll
+                            for (int r = 1; r < 8; r++) p[r * D] = cmul(v[bitrev_c(r, 3)], tw[r - 1]);
+                        }
+                    }
+                    lds_barrier();
+                    continue;
+                }
                 const float2 tw1 = twp[0], tw2 = twp[q4], tw3 = twp[2 * q4];
                 if (st == 0) {
                     // legs 2 and 3 are the zero bins N .. K-1: a0 = a1 = x0, a2 = x1, a3 = -j x1 (the values the full butterfly
