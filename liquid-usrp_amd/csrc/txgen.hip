@@ -55,40 +55,62 @@ __device__ __forceinline__ float2 modulate(int mod, unsigned sym)
     return make_float2((float)gi * alpha, (float)gq * alpha);
 }
 
-// one (channel, global symbol index): time-domain symbol body x[M] (no prefix yet); twl = the six lane-stage twiddles of lane l
-template <int E>
-__device__ __forceinline__ void txsym_one(const TxSymArgs &a, const uint32_t gs, const uint32_t ch, const int l, const float2 (&twl)[6])
+// one (channel, global symbol index): time-domain symbol body x[M] (no prefix yet); twl = the six lane-stage twiddles of lane l.
+// Two halves, so that a wave can have the loads of the symbols behind the current one in flight while it transforms it (one symbol
+// after the other, each waiting for its subcarrier map, then its rank, then its byte: 0.59 ms per 1.44 M symbols, two thirds of the
+// wave cycles waiting): txsym_fetch requests what the symbol needs from memory, txsym_emit consumes it.
+struct TxSymWhat { int s; bool table, zero, is_hdr; const uint8_t *bits; };
+__device__ __forceinline__ TxSymWhat txsym_what(const TxSymArgs &a, const uint32_t gs, const uint32_t ch, const unsigned long long d)
 {
-    int f = gs / a.S, s = gs % a.S;
-    float2 *dst = a.xsym + (a.xs_sym ? (size_t)ch * a.xs_ch + (size_t)gs * a.xs_sym : ((size_t)ch * a.frames * a.S + gs) * a.M);
-    bool table = s < 3 || s == a.S - 1, zero = s == a.S - 1, is_hdr = s < 3 + a.S_hdr;
-    const uint8_t *bits = nullptr;
+    TxSymWhat w;
+    const int f = gs / a.S;
+    w.s = gs % a.S;
+    w.table = w.s < 3 || w.s == a.S - 1; w.zero = w.s == a.S - 1; w.is_hdr = w.s < 3 + a.S_hdr;
+    w.bits = a.hdr;                                  // (always mapped: table symbols load nothing from it)
     if (a.symdesc) {
-        const unsigned long long d = a.symdesc[(size_t)ch * a.S + gs];
         const int kind = (int)(d & 0xff);
-        s = (int)((d >> 8) & 0xffff);
-        table = kind != TXK_HDR && kind != TXK_PAY; zero = kind == TXK_IDLE || kind == TXK_TAIL; is_hdr = kind == TXK_HDR;
-        bits = (is_hdr ? a.hdr : a.pay) + (size_t)(d >> 32) * a.M_data;
+        w.s = (int)((d >> 8) & 0xffff);
+        w.table = kind != TXK_HDR && kind != TXK_PAY; w.zero = kind == TXK_IDLE || kind == TXK_TAIL; w.is_hdr = kind == TXK_HDR;
+        if (!w.table) w.bits = (w.is_hdr ? a.hdr : a.pay) + (size_t)(d >> 32) * a.M_data;
+    } else if (!w.table)
+        w.bits = w.is_hdr ? a.hdr + ((size_t)ch * a.frames + f) * a.S_hdr * a.M_data + (size_t)(w.s - 3) * a.M_data
+                          : a.pay + ((size_t)ch * a.frames + f) * a.S_pay * a.M_data + (size_t)(w.s - 3 - a.S_hdr) * a.M_data;
+    return w;
+}
+template <int E> struct TxSymPre { unsigned long long d; uint8_t bit[E], pil[E]; };
+// the lane's subcarriers: type, rank among the data / pilot subcarriers -- the same for every symbol, read once per wave
+template <int E> struct TxSymLane { int t[E], dr[E], pr[E]; };
+template <int E>
+__device__ __forceinline__ TxSymPre<E> txsym_fetch(const TxSymArgs &a, const uint32_t gs, const uint32_t ch, const TxSymLane<E> &ln)
+{
+    TxSymPre<E> p;
+    p.d = a.symdesc ? a.symdesc[(size_t)ch * a.S + gs] : 0ull;
+    const TxSymWhat w = txsym_what(a, gs, ch, p.d);
+    const uint32_t pcount = (uint32_t)(w.s >= 3 ? w.s - 3 : 0) * (uint32_t)a.M_pilot;      // pilot generator resets per frame
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        p.bit[e] = w.bits[(!w.table && ln.t[e] == 2) ? ln.dr[e] : 0];          // (no load under a branch: it would be waited for at the join)
+        p.pil[e] = a.pilot_seq[(pcount + (uint32_t)ln.pr[e]) % 255u];
     }
-    if (table) {                                    // S0a, S0b, S1 bodies come from the tables; tail (and idle symbols) have none
-        const float2 *src = (s == 2) ? a.s1t : a.s0t;
-        for (int i = l; i < a.M; i += TXW) dst[i] = zero ? make_float2(0.f, 0.f) : src[i];
+    return p;
+}
+template <int E>
+__device__ __forceinline__ void txsym_emit(const TxSymArgs &a, const uint32_t gs, const uint32_t ch, const int l, const float2 (&twl)[6],
+                                           const TxSymLane<E> &ln, const TxSymPre<E> &pre)
+{
+    const TxSymWhat w = txsym_what(a, gs, ch, pre.d);
+    float2 *dst = a.xsym + (a.xs_sym ? (size_t)ch * a.xs_ch + (size_t)gs * a.xs_sym : ((size_t)ch * a.frames * a.S + gs) * a.M);
+    if (w.table) {                                  // S0a, S0b, S1 bodies come from the tables; tail (and idle symbols) have none
+        const float2 *src = (w.s == 2) ? a.s1t : a.s0t;
+        for (int i = l; i < a.M; i += TXW) dst[i] = w.zero ? make_float2(0.f, 0.f) : src[i];
         return;
     }
-    if (!a.symdesc)
-        bits = is_hdr ? a.hdr + ((size_t)ch * a.frames + f) * a.S_hdr * a.M_data + (size_t)(s - 3) * a.M_data
-                      : a.pay + ((size_t)ch * a.frames + f) * a.S_pay * a.M_data + (size_t)(s - 3 - a.S_hdr) * a.M_data;
-    const uint32_t pcount = (uint32_t)(s - 3) * (uint32_t)a.M_pilot;      // pilot generator resets per frame
     float2 x[E];
 #pragma unroll
     for (int e = 0; e < E; e++) {
-        const int k = l + TXW * e;
         float2 v = make_float2(0.f, 0.f);
-        if (k < a.M) {
-            const int t = a.sctype[k];
-            if (t == 1) v = make_float2(a.pilot_seq[(pcount + (uint32_t)a.pilot_rank[k]) % 255u] ? a.g_data : -a.g_data, 0.f);
-            else if (t == 2) { v = modulate(is_hdr ? 39 : a.mod, bits[a.data_rank[k]]); v.x *= a.g_data; v.y *= a.g_data; }
-        }
+        if (ln.t[e] == 1) v = make_float2(pre.pil[e] ? a.g_data : -a.g_data, 0.f);
+        else if (ln.t[e] == 2) { v = modulate(w.is_hdr ? 39 : a.mod, pre.bit[e]); v.x *= a.g_data; v.y *= a.g_data; }
         x[e] = make_float2(v.x, -v.y);              // inverse FFT = conj(FFT(conj(X)))
     }
     // forward DIF across position i = l + 64 e (natural subcarrier order in), bit-reversed out
@@ -97,10 +119,10 @@ __device__ __forceinline__ void txsym_one(const TxSymArgs &a, const uint32_t gs,
 #pragma unroll
         for (int e = 0; e < E; e++) if ((e & j) == 0 && e + j < E) {
             const int h = TXW * j;
-            const float2 u = x[e], w = x[e + j];
+            const float2 u = x[e], w2 = x[e + j];
             float sn, cs; sincos_u32((uint32_t)((l + TXW * e) & (h - 1)) * (uint32_t)(0x80000000u / (unsigned)h), sn, cs);
-            x[e] = cadd(u, w);
-            x[e + j] = cmul(csub(u, w), make_float2(cs, -sn));
+            x[e] = cadd(u, w2);
+            x[e + j] = cmul(csub(u, w2), make_float2(cs, -sn));
         }
     }
 #pragma unroll
@@ -125,8 +147,9 @@ __device__ __forceinline__ void txsym_one(const TxSymArgs &a, const uint32_t gs,
         }
     }
 }
-// a wave makes TXSYM_PER consecutive symbols of one channel: the lane twiddles (a sin / cos pair per stage) and the launch's
-// per-wave set-up are paid once for them (one symbol per wave: 403 M VALU + 201 M SALU instructions per 1.44 M symbols)
+// a wave makes TXSYM_PER consecutive symbols of one channel: the lane twiddles (a sin / cos pair per stage), the lane's subcarrier
+// map and the launch's per-wave set-up are paid once for them (one symbol per wave: 403 M VALU + 201 M SALU instructions per
+// 1.44 M symbols); narrow symbols (E <= 2) have all eight symbols' bytes requested before the first transform, wider ones the next one's
 #define TXSYM_PER 8
 template <int E>
 __global__ __launch_bounds__(TXW) void txsym_kernel(TxSymArgs a, uint32_t nsym)
@@ -140,9 +163,25 @@ __global__ __launch_bounds__(TXW) void txsym_kernel(TxSymArgs a, uint32_t nsym)
         float sn, cs; sincos_u32((uint32_t)(l & (h - 1)) * (uint32_t)(0x80000000u / (unsigned)h), sn, cs);
         twl[st] = make_float2(cs, -sn);
     }
-    for (uint32_t k = 0; k < TXSYM_PER; k++) {
-        const uint32_t gs = blockIdx.x * TXSYM_PER + k;
-        if (gs < nsym) txsym_one<E>(a, gs, ch, l, twl);
+    TxSymLane<E> ln;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int k = l + TXW * e, kk = k < a.M ? k : 0;
+        ln.t[e] = k < a.M ? (int)a.sctype[kk] : 0; ln.dr[e] = a.data_rank[kk]; ln.pr[e] = a.pilot_rank[kk];
+        if (ln.t[e] != 2) ln.dr[e] = 0;
+        if (ln.t[e] != 1) ln.pr[e] = 0;
+    }
+    constexpr int D = E <= 2 ? TXSYM_PER : 1;       // symbols requested ahead
+    const uint32_t gs0 = blockIdx.x * TXSYM_PER;
+    TxSymPre<E> pre[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) { const uint32_t gs = gs0 + d; pre[d] = txsym_fetch<E>(a, gs < nsym ? gs : nsym - 1, ch, ln); }
+#pragma unroll
+    for (int k = 0; k < TXSYM_PER; k++) {
+        const uint32_t gs = gs0 + k;
+        const TxSymPre<E> cur = pre[k % D];
+        if (k + D < TXSYM_PER) { const uint32_t gn = gs0 + k + D; pre[k % D] = txsym_fetch<E>(a, gn < nsym ? gn : nsym - 1, ch, ln); }
+        if (gs < nsym) txsym_emit<E>(a, gs, ch, l, twl, ln, cur);
     }
 }
 
