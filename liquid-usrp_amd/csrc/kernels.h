@@ -198,10 +198,12 @@ struct SyncArgs {
     uint32_t payload_lds_pad;  // bytes of unused dynamic LDS per payload worker: caps the workers' occupancy (walk mode, launch_sync)
     int seek_burst;            // idle stretches: SEEK events four at a time, their windows requested together (Walker::seek_burst)
     // speculation (see SpecSlot)
-    SpecSlot *spec; float2 *spec_R;      // [nch][MCRX_SPEC_MAX]; [nch][MCRX_SEG_MAX][M]: a segment wave's equaliser between the S1 fit and the hand-off
+    SpecSlot *spec; float2 *spec_R;      // [nch][spec_stride]; [nch][MCRX_SEG_MAX][M]: a segment wave's equaliser between the S1 fit and the hand-off
 #define MCRX_SEG_MAX 128
     int64_t *pred; uint32_t *pred_n;     // predicted fresh-state positions for the next launch: [nch][MCRX_SPEC_MAX], [nch]
     uint32_t spec_cap;                   // slots per channel the segment waves fill in this launch = nseg * (slots per wave) (0: off)
+    uint32_t spec_stride;                // slots between two channels in `spec` (>= spec_cap; MCRX_SPEC_MAX unless a push holds more frames per
+                                         // channel than that: the scouts then read the slot headers a window of MCRX_SPEC_MAX at a time)
     uint32_t nseg;                       // segment waves per channel
     uint32_t seg_jobs;                   // job list entries a segment wave reserves at a time (the frames it is expected to hand off)
     // The two wasted acquisitions of a segment (its first frame from an arbitrary state, the frame that links it to the next

@@ -180,6 +180,7 @@ struct mcrx_hip_s {
 
     hipEvent_t ev_ready[MCRX_SLOTS] = {}, ev_scout[MCRX_SLOTS] = {}, ev_done[MCRX_SLOTS] = {}, ev_in = nullptr, ev_consumed = nullptr, ev_tmp[3] = {};
     int last_slot = -1; size_t last_ntiles = 0;     // where the synchronizer history (tail of the previous launch) sits
+    uint32_t spec_stride = MCRX_SPEC_MAX;           // slots per channel in d_spec (grows when a push holds more frames per channel: launch_sync)
     SpecSlot *d_spec = nullptr; float2 *d_spec_R = nullptr; int64_t *d_pred = nullptr, *d_anchor = nullptr; uint32_t *d_pred_n = nullptr;
     bool spec = false;
     uint32_t *h_hint = nullptr, *d_hint = nullptr;     // pinned, device-mapped: longest coded frame of the last launch
@@ -695,7 +696,7 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     a.jR = q->d_jR[slot]; a.jsoft = q->d_jsoft[slot]; a.jtmp = q->d_jtmp[slot];
     a.stats = q->d_stats;
     a.hint = q->d_hint; a.enc_hint = (q->h_hint && q->d_hint) ? *(volatile uint32_t *)q->h_hint : 0u;
-    a.spec = q->d_spec; a.spec_R = q->d_spec_R; a.pred = nullptr; a.pred_n = nullptr; a.spec_cap = 0; a.spec_hint = nullptr; a.walk_hint = nullptr;
+    a.spec = q->d_spec; a.spec_stride = q->spec_stride; a.spec_R = q->d_spec_R; a.pred = nullptr; a.pred_n = nullptr; a.spec_cap = 0; a.spec_hint = nullptr; a.walk_hint = nullptr;
     a.nseg = 0; a.seg_phase = 0; a.anchor = nullptr; a.seg_jobs = 1;
     hipStream_t sa = st, sw = st;
     // The host never waits for the device on this path (slots are handed over by stream waits), so a free-running caller
@@ -741,9 +742,11 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
             // on a cadence the lattice starts make segments free (no wasted acquisitions), so chains go down to two frames while
             // all the waves still run at once (2 per SIMD): what a few-channel receiver's push is made of is this chain's latency
             if (q->cadenced) { const float conc = 2048.0f / (float)q->nch, two = F / 2.0f; const float c2 = conc < two ? conc : two; if (want < c2) want = c2; }
-            const float room = ((float)MCRX_SPEC_MAX - 1.25f * F) / 3.0f;            // F / nseg * 1.25 + 3 slots per wave must fit
-            if (want > room) want = room;
-            nseg = want < 1.0f ? 1u : (want > 64.0f ? 64u : (uint32_t)(want + 0.5f));
+            // (a wave's slots: F / nseg * 1.25 + 4, at most half a window of the scouts' slot headers -- see spw below)
+            const float least = 1.25f * F / (float)(MCRX_SPEC_MAX / 2 - 4);
+            if (want < least) want = least;
+            const float most = q->nch * 128u <= 4096u ? 128.0f : 64.0f;               // (few channels: even 128 waves each leave the chip mostly empty)
+            nseg = want < 1.0f ? 1u : (want > most ? (uint32_t)most : (uint32_t)(want + 0.999f));
         }
         if (nseg > MCRX_SEG_MAX) nseg = MCRX_SEG_MAX;
         // The anchor phase (kernels.h, SyncArgs::seg_phase) is one more launch and one frame's latency in front of everything else: worth it
@@ -758,7 +761,23 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
         }
         if (q->acq_mode == 3) q->cadenced = true;
         q->last_nsamp = nsamp;
-        a.nseg = nseg; a.spec_cap = nseg * (MCRX_SPEC_MAX / nseg);
+        // Slots per wave: its share of MCRX_SPEC_MAX while the push's frames fit there (the scouts then hold every slot header in
+        // registers), else what its frames need -- the channel's slots then exceed the window and the scouts move it along
+        // (ofdmsync.hip: adopt_lookup), which takes two neighbouring waves' slots to fit in one window.
+        uint32_t spw = MCRX_SPEC_MAX / nseg;
+        { const float Fs = q->frames_per_push > 0.f ? q->frames_per_push : (float)nsamp / 16384.0f;
+          const uint32_t need = (uint32_t)(1.25f * Fs / (float)nseg) + 4u;
+          if (need > spw) spw = need > MCRX_SPEC_MAX / 2 ? MCRX_SPEC_MAX / 2 : need; }
+        if ((uint64_t)nseg * spw > q->spec_stride) {
+            // (rare: the first long push of a few-channel stream.  Launches in flight use the old slots: wait for them.)
+            uint32_t ns = q->spec_stride; while (ns < nseg * spw) ns *= 2;
+            SpecSlot *nb = nullptr;
+            HIPCHK(hipDeviceSynchronize());
+            RC(q->alloc(&nb, (size_t)q->nch * ns));
+            q->d_spec = nb; q->spec_stride = ns;            // (the old array stays with the handle until it is destroyed)
+            a.spec = q->d_spec; a.spec_stride = q->spec_stride;
+        }
+        a.nseg = nseg; a.spec_cap = nseg * spw;
         { const float Fq = q->frames_per_push > 0.f ? q->frames_per_push : (float)nsamp / 16384.0f;
           const float per = Fq / (float)nseg + 2.0f;                     // its share of the channel's frames + the two at the segment's ends
           a.seg_jobs = per < 2.0f ? 2u : (per > 32.0f ? 32u : (uint32_t)(per + 0.999f));

@@ -1797,22 +1797,57 @@ struct Walker {
     // serial chain waits for memory because of an adoption.
     static constexpr int SPH = MCRX_SPEC_MAX / WV;          // slot headers per lane
     int64_t sp_start[SPH]; int32_t sp_tlast[SPH]; uint32_t sp_aux[SPH]; uint32_t nadopted; uint32_t nwalked = 0;
+    int32_t sp_rel[SPH];            // start position relative to the buffer of the slots acquired from a fresh post-frame state (INT32_MIN: any other)
     uint32_t nown = 0;              // job list entries noted in ldsad: this channel's frames of the launch, not placed yet
     int64_t sk_cur = 0; uint32_t sk_timer = 0;      // lean scout: the SEEK state before the last seek event (where a frame is re-acquired from if deferred)
+    uint32_t win0 = 0;              // first slot of the window of MCRX_SPEC_MAX headers held in registers
+    int64_t seg_base = 0, seg_len_s = 0;            // the launch's segment grid (run_seg's), to tell which wave a position belongs to
     __device__ __forceinline__ void load_spec_headers()
     {
-        const SpecSlot *sl = a.spec + (size_t)ch * MCRX_SPEC_MAX;
+        const SpecSlot *sl = a.spec + (size_t)ch * a.spec_stride;
 #pragma unroll
         for (int h = 0; h < SPH; h++) {
-            const uint32_t k = (uint32_t)l + WV * h;
+            const uint32_t k = win0 + (uint32_t)l + WV * h;
             const bool live = k < a.spec_cap;
             const SpecSlot *q = sl + (live ? k : 0);
             const int32_t stt = q->status;
             sp_start[h] = (live && stt >= 1 && stt <= 3) ? q->start : -1;
             sp_tlast[h] = (int32_t)(q->t_last - a.buf_first);       // (positions inside the buffer: 31 bits are plenty)
             sp_aux[h] = (uint32_t)stt | (q->pad << 8);
+            const bool fresh = sp_start[h] >= 0 && (sp_start[h] >> 48) == (spec_key(0, (uint32_t)c.L) >> 48);
+            sp_rel[h] = fresh ? (int32_t)((sp_start[h] & 0xFFFFFFFFFFFFll) - a.buf_first) : INT32_MIN;
         }
-        nadopted = 0;
+    }
+    // The common hop, tight: from a fresh post-frame state at `pos` to the frame a segment wave handed off from exactly there, to
+    // the fresh state behind it, and so on -- 32-bit compares on buffer-relative positions, the hit read with v_readlane, nothing
+    // but the position carried from hop to hop (through the general lookup below a hop cost ~1500 cycles: 0.09 ms of an 8-channel
+    // push of 100 frames per channel).  Leaves at the first state that is not such a hit; the general lookup takes it from there.
+    __device__ __forceinline__ bool hop_fresh(int64_t &pos, int64_t &fresh_prev, int64_t &fresh_last, uint32_t &nfresh, uint32_t &nsame)
+    {
+        static_assert(SPH == 4, "four rows of slot headers");
+        bool any = false;
+        int32_t rel = (int32_t)(pos - a.buf_first);
+        while (nown < MCRX_SPEC_MAX) {
+            const unsigned long long b0 = __ballot(sp_rel[0] == rel), b1 = __ballot(sp_rel[1] == rel), b2 = __ballot(sp_rel[2] == rel), b3 = __ballot(sp_rel[3] == rel);
+            if (!(b0 | b1 | b2 | b3)) break;
+            const unsigned long long b = b0 ? b0 : (b1 ? b1 : (b2 ? b2 : b3));
+            const int row = b0 ? 0 : (b1 ? 1 : (b2 ? 2 : 3));
+            const int hl = (int)__builtin_ctzll(b);
+            const uint32_t axv = row == 0 ? sp_aux[0] : (row == 1 ? sp_aux[1] : (row == 2 ? sp_aux[2] : sp_aux[3]));
+            const int32_t tlv = row == 0 ? sp_tlast[0] : (row == 1 ? sp_tlast[1] : (row == 2 ? sp_tlast[2] : sp_tlast[3]));
+            const uint32_t ax = (uint32_t)__builtin_amdgcn_readlane((int)axv, hl);
+            if ((ax & 0xffu) != 1u) break;
+            const int32_t tl = __builtin_amdgcn_readlane(tlv, hl);
+            if (l == 0) ldsad[nown] = ax >> 8;
+            nown++; nadopted++;
+            any = true;
+            rel = tl + 1;
+            const int64_t p = a.buf_first + (int64_t)rel;
+            if (fresh_prev >= 0 && p - fresh_last == fresh_last - fresh_prev) nsame++;
+            fresh_prev = fresh_last; fresh_last = p; nfresh++;
+        }
+        if (any) pos = a.buf_first + (int64_t)rel;
+        return any;
     }
     // the slot that started from exactly `key`, if there is one: noted, and the sample its frame ended with returned
     // aux: the slot's status (1: frame handed off, t_end = its last symbol's event; 2: deferred, t_end = the SEEK position to go
@@ -1835,6 +1870,24 @@ struct Walker {
             nown++; nadopted++;
         }
         return true;
+    }
+    // ... looked up where a push holds more slots per channel than the window: the slots a frame acquired from `pos` can sit in are
+    // the ones of the wave whose segment holds `pos` and of the wave before it (its last frame, the one that links the two, is
+    // acquired from a state behind the segment boundary when the frame before it straddles it); if the window does not hold
+    // both, it moves there and the lookup is repeated.  A miss only ever costs speed: the scout then walks that frame itself.
+    __device__ __forceinline__ bool adopt_lookup(int64_t key, int64_t pos, int64_t &t_end, uint32_t &aux, uint32_t &kslot)
+    {
+        if (adopt_match(key, t_end, aux, kslot)) return true;
+        if (a.spec_cap <= (uint32_t)MCRX_SPEC_MAX || seg_len_s <= 0) return false;
+        const uint32_t spw = a.spec_cap / a.nseg;
+        int64_t gq = (pos - seg_base) / seg_len_s;
+        if (gq < 0) gq = 0;
+        const uint32_t g = gq >= (int64_t)a.nseg ? a.nseg - 1u : (uint32_t)gq;
+        const uint32_t want0 = (g ? g - 1u : 0u) * spw;
+        if (want0 >= win0 && (g + 1u) * spw <= win0 + (uint32_t)MCRX_SPEC_MAX) return false;        // both waves' slots were in the window
+        win0 = want0;
+        load_spec_headers();
+        return adopt_match(key, t_end, aux, kslot);
     }
     // The channel's frames of this launch become real: their job list entries (written by segment waves, or by this scout's own
     // hand-offs) get their owner, and record space -- payload bytes, equalised symbols, a record slot -- out of ONE reservation per
@@ -1942,7 +1995,7 @@ struct Walker {
     __device__ __forceinline__ void run_seg(uint32_t g)
     {
         const uint32_t spw = a.spec_cap / a.nseg;                // slots of this wave
-        SpecSlot *sl0 = a.spec + (size_t)ch * MCRX_SPEC_MAX + (size_t)g * spw;
+        SpecSlot *sl0 = a.spec + (size_t)ch * a.spec_stride + (size_t)g * spw;
         bR = a.spec_R + ((size_t)ch * MCRX_SEG_MAX + (g < MCRX_SEG_MAX ? g : 0u)) * c.M;       // (the S1 fit's memory copy: unused, the hand-off stores R from registers)
         const int M = c.M, M2 = c.M2, L = c.L;
         const int phase = a.seg_phase;
@@ -2107,7 +2160,12 @@ struct Walker {
         int64_t fresh_prev = -1, fresh_last = -1;       // the last two fresh post-frame states (behind handed-off frames): the cadence the next push's segment waves try
         uint32_t nfresh = 0, nsame = 0;                 // hand-offs seen, and how many of them followed their predecessor at the distance of the pair before
         nadopted = 0;
-        if (a.spec_cap) load_spec_headers();
+        if (a.spec_cap) {
+            win0 = 0; seg_base = s.cur;
+            const int64_t span = a.end - seg_base;
+            seg_len_s = (span > 0 && a.nseg) ? (span + (int64_t)a.nseg - 1) / (int64_t)a.nseg : 0;
+            load_spec_headers();
+        }
         while (true) {
             if (nown >= MCRX_SPEC_MAX - 1) place_owned();       // (a channel with hundreds of frames in one push)
             if (a.spec_cap && (entry || (s.state == SY_SEEK && s.timer == (uint32_t)L))) {
@@ -2118,7 +2176,8 @@ struct Walker {
                 // adoption leaves it in the same fresh post-frame state, only the position differs).
                 int64_t key = spec_key(s.cur, s.timer, s.state);
                 int64_t pos = s.cur, t_end = 0; uint32_t aux = 0, kslot = 0; bool any = false, deferred = false;
-                while (nown < MCRX_SPEC_MAX && adopt_match(key, t_end, aux, kslot)) {
+                if (s.state == SY_SEEK && s.timer == (uint32_t)L && hop_fresh(pos, fresh_prev, fresh_last, nfresh, nsame)) { any = true; key = spec_key(pos, (uint32_t)L); }
+                while (nown < MCRX_SPEC_MAX && adopt_lookup(key, pos, t_end, aux, kslot)) {
                     if ((aux & 0xffu) == 2u) { deferred = true; break; }
                     if ((aux & 0xffu) == 3u) {
                         // a frame whose header did not pass its check (noise, a neighbour's leakage): the record the synchronizer
@@ -2133,6 +2192,7 @@ struct Walker {
                         if (fresh_prev >= 0 && pos - fresh_last == fresh_last - fresh_prev) nsame++;
                         fresh_prev = fresh_last; fresh_last = pos; nfresh++;
                     }
+                    if (hop_fresh(pos, fresh_prev, fresh_last, nfresh, nsame)) { }     // (on from there in the tight loop)
                     key = spec_key(pos, (uint32_t)L);
                 }
                 if (deferred) {

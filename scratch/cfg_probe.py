@@ -11,5 +11,6 @@ dev = torch.device("cuda", 0)
 which = sys.argv[1] if len(sys.argv) > 1 else "8ch"
 legs = {"8ch": (8, 64, 8, 100, 1200, 40, 6, False), "8ch_v27": (8, 64, 8, 100, 1200, 40, 11, False), "c3": (64, 256, 32, 32, 1200, 27, 7, True)}
 N, M, cp, fr, pl, mod, fec1, rs = legs[which]
+fr = int(os.environ.get("FRAMES", fr))
 r = bench.config_leg(prod, torch, dev, N, M, cp, fr, pl, mod, fec1, rs, steps=int(os.environ.get("STEPS", "6")), reps=3, what=which)
 print(json.dumps(r))
