@@ -482,6 +482,9 @@ def configs_block(prod, torch, dev, args):
     headline, configs[0] a CPU plumbing case covered by tests/test_gpu_baseline_shapes.py)."""
     out = {}
     legs = (("8ch", 8, 64, 8, 100, 1200, 40, 6, False, "configs[1]: 8-ch multichannelrx, M=64 cp=8 QPSK CRC32+Hamming128 1200B payloads, 100 frames/ch/slab"),
+            ("8ch_long_pushes", 8, 64, 8, 400, 1200, 40, 6, False,
+             "configs[1] in pushes four times as long (400 frames/ch/slab, 54 M samples): a push is a chain of latencies -- acquisition, payload workers, decoder, "
+             "0.45 ms at 100 frames per channel whatever the sample count -- that eight channels cannot fill the chip beside; longer pushes amortize it"),
             ("8ch_v27", 8, 64, 8, 100, 1200, 40, 11, False, "configs[1] with the K=7 r=1/2 convolutional code (soft Viterbi) as the outer code"),
             ("64ch_m256_qam16_resamp", 64, 256, 32, 32, 1200, 27, 7, True,
              "configs[2]: 64-ch multichannelrx, M=256 cp=32 QAM16 CRC32+Golay(24,12) 1200B payloads, 32 frames/ch/slab, msresamp(0.5) front end"))

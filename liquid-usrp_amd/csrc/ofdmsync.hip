@@ -1830,14 +1830,16 @@ struct Walker {
         while (nown < MCRX_SPEC_MAX) {
             const unsigned long long b0 = __ballot(sp_rel[0] == rel), b1 = __ballot(sp_rel[1] == rel), b2 = __ballot(sp_rel[2] == rel), b3 = __ballot(sp_rel[3] == rel);
             if (!(b0 | b1 | b2 | b3)) break;
-            const unsigned long long b = b0 ? b0 : (b1 ? b1 : (b2 ? b2 : b3));
-            const int row = b0 ? 0 : (b1 ? 1 : (b2 ? 2 : 3));
-            const int hl = (int)__builtin_ctzll(b);
-            const uint32_t axv = row == 0 ? sp_aux[0] : (row == 1 ? sp_aux[1] : (row == 2 ? sp_aux[2] : sp_aux[3]));
-            const int32_t tlv = row == 0 ? sp_tlast[0] : (row == 1 ? sp_tlast[1] : (row == 2 ? sp_tlast[2] : sp_tlast[3]));
-            const uint32_t ax = (uint32_t)__builtin_amdgcn_readlane((int)axv, hl);
+            // (every row's candidate read with v_readlane, the hit chosen among scalars: choosing the ROW first makes the compiler index
+            //  the header arrays dynamically -- a copy in scratch memory and a load from it per hop)
+            const int l0 = b0 ? (int)__builtin_ctzll(b0) : 0, l1 = b1 ? (int)__builtin_ctzll(b1) : 0, l2 = b2 ? (int)__builtin_ctzll(b2) : 0, l3 = b3 ? (int)__builtin_ctzll(b3) : 0;
+            const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)sp_aux[0], l0), a1 = (uint32_t)__builtin_amdgcn_readlane((int)sp_aux[1], l1),
+                           a2 = (uint32_t)__builtin_amdgcn_readlane((int)sp_aux[2], l2), a3 = (uint32_t)__builtin_amdgcn_readlane((int)sp_aux[3], l3);
+            const int32_t t0 = __builtin_amdgcn_readlane(sp_tlast[0], l0), t1 = __builtin_amdgcn_readlane(sp_tlast[1], l1),
+                          t2 = __builtin_amdgcn_readlane(sp_tlast[2], l2), t3 = __builtin_amdgcn_readlane(sp_tlast[3], l3);
+            const uint32_t ax = b0 ? a0 : (b1 ? a1 : (b2 ? a2 : a3));
             if ((ax & 0xffu) != 1u) break;
-            const int32_t tl = __builtin_amdgcn_readlane(tlv, hl);
+            const int32_t tl = b0 ? t0 : (b1 ? t1 : (b2 ? t2 : t3));
             if (l == 0) ldsad[nown] = ax >> 8;
             nown++; nadopted++;
             any = true;
@@ -2192,7 +2194,7 @@ struct Walker {
                         if (fresh_prev >= 0 && pos - fresh_last == fresh_last - fresh_prev) nsame++;
                         fresh_prev = fresh_last; fresh_last = pos; nfresh++;
                     }
-                    if (hop_fresh(pos, fresh_prev, fresh_last, nfresh, nsame)) { }     // (on from there in the tight loop)
+                    hop_fresh(pos, fresh_prev, fresh_last, nfresh, nsame);         // (on from there in the tight loop)
                     key = spec_key(pos, (uint32_t)L);
                 }
                 if (deferred) {
