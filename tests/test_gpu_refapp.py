@@ -205,6 +205,31 @@ def test_unchanged_multichannel_txrx_app_hears_its_own_bursts(oracle, product, t
             episodes += 1
     assert episodes <= 8 and abs(len(rx.frames) - len(orx.frames)) <= 8, episodes
     rx.close()
+    # ... and exactly, with the leakage masked: a seeded noise floor 40 dB under the bursts (20 dB over a neighbour's leakage)
+    # keeps idle channels from locking onto it, and on the first 12 M samples of that recording the two receivers then report
+    # the same frames -- ids, lengths, flags, order, every payload byte -- with no episode to excuse.  (One is tolerated: the
+    # recording is new in every run, and a detection within 1e-6 of its threshold can always exist.)
+    n2 = min(len(iq), 12_000_000) // (32 * N) * (32 * N)
+    act = np.abs(iq[:n2]) > 0
+    sigma = float(np.sqrt(np.mean(np.abs(iq[:n2][act]) ** 2))) * 10 ** (-40 / 20) / np.sqrt(2.0)
+    rng = np.random.default_rng(20260930)
+    x = (iq[:n2] + sigma * (rng.standard_normal(n2, dtype=np.float32) + 1j * rng.standard_normal(n2, dtype=np.float32))).astype(np.complex64)
+    orx2 = oracle.MultiChannelRx(N, 64, 8, 4)
+    orx2.execute(x)
+    rx2 = product.multichannelrx(N, 64, 8, 4)
+    for i in range(0, len(x), 256 * 64):
+        rx2.Execute(x[i:i + 256 * 64])
+    rx2.Flush()
+    full = lambda f: (f.header, f.payload, int(f.header_valid), int(f.payload_valid))
+    differ = 0
+    for c in range(N):
+        a, b = [full(f) for f in rx2.frames if f.channel == c], [full(f) for f in orx2.frames if f.channel == c]
+        if a != b:
+            ops = [o for o in difflib.SequenceMatcher(None, [k[0] for k in a], [k[0] for k in b], autojunk=False).get_opcodes() if o[0] != "equal"]
+            differ += max(1, len(ops))
+    print("txrx recording, leakage masked: %d frames, %d differing episodes" % (len(orx2.frames), differ))
+    assert len(orx2.frames) >= 500 and differ <= 1, differ
+    rx2.close()
     # the live callbacks: the same list up to what two free-running worker threads and a wall clock do to the stand-in's
     # air (a receive worker that lags is handed the stream with a sample gap; the recording has none)
     sg, sw = set(got), set(want)
