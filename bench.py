@@ -139,6 +139,8 @@ def main():
     slabs, sents = [], []
     for i in range(nslab):
         pad = (0, 80, 32, 144, 48, 112)[i % 6]                       # different idle gaps (blocks; whole tiles)
+        if os.environ.get("BENCH_EQUAL_PADS"):                       # (experiment: rounds of the pipeline paths then cut the stream between frames)
+            pad = 64
         d, s = tx.generate(args.frames, args.payload, seed=0xC0FFEE + 7919 * i, nblocks=base_blocks + pad, device=dev)
         slabs.append(d); sents.append(frame_index(s))
     torch.cuda.synchronize()
