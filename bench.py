@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--payload", type=int, default=1200)
     ap.add_argument("--rounds", type=int, default=3, help="--gpus > 1: exchange rounds per step (a round = one sub-slab per rank)")
     ap.add_argument("--serial-steps", type=int, default=8, help="steps of the unpipelined pass that times each kernel alone")
-    ap.add_argument("--harvest-steps", type=int, default=10)
+    ap.add_argument("--harvest-steps", type=int, default=40, help="steps of the harvested legs (their timed region ends with the flush of the two pushes still in flight: ~2 ms, 6 %% of ten steps)")
     ap.add_argument("--cpu-reps", type=int, default=1, help="passes over the first slab timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-harvest", action="store_true")

@@ -214,7 +214,7 @@ struct mcrx_hip_s {
     uint64_t min_frame = 1;                 // channel-rate samples of the shortest possible frame
     uint64_t pending_bound = 0;             // upper bound of frame records produced since the last harvest
     uint64_t drain_touch = 0;
-    double t_copy = 0, t_harvest = 0, t_run = 0, t_wait = 0, t_d2h = 0, b_d2h = 0, t_grow = 0;   // MCRX_DEBUG=8: host seconds spent per phase of the bulk path
+    double t_copy = 0, t_harvest = 0, t_run = 0, t_wait = 0, t_d2h = 0, b_d2h = 0, t_grow = 0, t_cnt = 0, t_post = 0;   // MCRX_DEBUG=8: host seconds spent per phase of the bulk path
     // per-kernel HIP event rings (MCRX_NKERNELS of them, see mcrx_hip.h); pairs (start, stop)
     std::vector<hipEvent_t> evring[MCRX_NKERNELS];
     size_t ev_used[MCRX_NKERNELS] = {};
@@ -593,7 +593,7 @@ extern "C" int mcrx_hip_destroy(mcrx_hip_t q)
     if (!q) return MCRX_OK;
     (void)hipDeviceSynchronize();
     if (q->debug & 8)
-        fprintf(stderr, "mcrx bulk path: copy %.4f s, launch %.4f s, waiting for the GPU %.4f s, harvest (incl. that wait) %.4f s of which frame D2H %.4f s for %.1f MB, host arena growth %.4f s\n", q->t_copy, q->t_run, q->t_wait, q->t_harvest, q->t_d2h, q->b_d2h / 1e6, q->t_grow);
+        fprintf(stderr, "mcrx bulk path: copy %.4f s, launch %.4f s, waiting for the GPU %.4f s, harvest (incl. that wait) %.4f s of which frame D2H %.4f s for %.1f MB, host arena growth %.4f s, counters D2H %.4f s, filter + sort %.4f s\n", q->t_copy, q->t_run, q->t_wait, q->t_harvest, q->t_d2h, q->b_d2h / 1e6, q->t_grow, q->t_cnt, q->t_post);
     if ((q->debug & 32) && q->d_stats) {
         uint32_t v[4] = {};
         (void)hipMemcpy(v, q->d_stats, sizeof(v), hipMemcpyDeviceToHost);
@@ -1146,9 +1146,11 @@ static int collect(mcrx_hip_t q, int g)
         q->gen_closed[g] = false; q->gen_used[g] = false; q->gen_abandoned[g] = false;
         return MCRX_OK;
     }
+    { const double t1 = now_s();
     HIPCHK(hipMemcpyAsync(cnt, q->d_nrec[g], sizeof(cnt), hipMemcpyDeviceToHost, q->s_copy));
     HIPCHK(hipMemcpyAsync(used, q->d_arena_used[g], sizeof(used), hipMemcpyDeviceToHost, q->s_copy));
     HIPCHK(hipStreamSynchronize(q->s_copy));
+    q->t_cnt += now_s() - t1; }
     q->dropped += cnt[1];
     const uint32_t n = std::min(cnt[0], q->max_rec);
     if (used[0] > q->arena_cap) used[0] = q->arena_cap;
@@ -1169,6 +1171,7 @@ static int collect(mcrx_hip_t q, int g)
           if (want_syms && used[1]) HIPCHK(hipMemcpyAsync(q->sarena_host.p + sbase, q->d_sarena[g], (size_t)used[1], hipMemcpyDeviceToHost, q->s_copy));
           HIPCHK(hipStreamSynchronize(q->s_copy));
           q->t_d2h += now_s() - t1; q->b_d2h += (double)used[0] + (want_syms ? (double)used[1] : 0.0); }
+        const double t2 = now_s();
         // (record slots of frames that found no room in an arena stay unfilled: Walker::place_owned marks them)
         q->recs.erase(std::remove_if(q->recs.begin() + r0, q->recs.end(), [](const FrameRec &r) { return r.channel == 0xFFFFFFFFu; }), q->recs.end());
         for (size_t i = r0; i < q->recs.size(); i++) {
@@ -1178,6 +1181,7 @@ static int collect(mcrx_hip_t q, int g)
         // reference order: by end time, then channel index (lib/multichannelrx.cc:193-194)
         std::stable_sort(q->recs.begin() + r0, q->recs.end(), [](const FrameRec &a, const FrameRec &b) {
             return a.end_sample != b.end_sample ? a.end_sample < b.end_sample : a.channel < b.channel; });
+        q->t_post += now_s() - t2;
     }
     // (the counters are zeroed on the copy stream without waiting for it: a fill is a kernel, and on a full chip a kernel waits
     //  100-200 us for a wave slot -- with the host waiting for it, every poll.  The next launch into this generation waits instead.)
