@@ -4,8 +4,10 @@
 //   A  channelize this rank's sub-slab into per-destination groups            out[g][tile][c][8], channel = g*Cg + c
 //   B  exchange: chunk g of rank r -> chunk r of rank g                         RCCL, grouped ncclSend / ncclRecv over xGMI
 //   C  synchronizer bank of the rank's channel shard over the round             recv[s][tile][c][8] = [tile of the round][c][8]
-// on three HIP streams with `nbuf` rotating buffer sets, linked by events only -- channelize(c+1) || exchange(c) || sync(c-1) --
-// and nothing waits on the host.  This is liquid-usrp_amd/sharding.py's Pipeline (which stays as the mirror the gloo tests
+// with `nbuf` rotating buffer sets, linked by events only -- channelize(c+1) || exchange(c) || sync(c-1) -- and nothing waits on
+// the host.  Two HIP streams of the pipeline's own carry this: one for stage A, one for stage B and the launch of stage C (whose
+// kernels run on the receiver handle's three internal streams anyway).  A third stream for C, as in rounds 2-3, put the process at
+// eight streams and cost the one-GPU run 11 % (154-156 against 172.8 Gsample/s, direct path 178.9: scratch/r4an.sh).  This is liquid-usrp_amd/sharding.py's Pipeline (which stays as the mirror the gloo tests
 // drive on CPU) without Python between the stages.  world == 1 runs the same code with no exchange: the channelizer writes
 // straight into the synchronizers' buffer.
 //
@@ -18,6 +20,7 @@
 #include <dlfcn.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -114,8 +117,9 @@ extern "C" int mcrx_hip_pipeline_destroy(mcrx_hip_pipeline_t p)
     }
     for (auto &pr : p->xev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (p->ev_after) (void)hipEventDestroy(p->ev_after);
-    hipStream_t ss[3] = { p->sA, p->sB, p->sC };
-    for (hipStream_t s : ss) if (s) (void)hipStreamDestroy(s);
+    if (p->sC && p->sC != p->sB && p->sC != p->sA) (void)hipStreamDestroy(p->sC);
+    if (p->sB && p->sB != p->sA) (void)hipStreamDestroy(p->sB);
+    if (p->sA) (void)hipStreamDestroy(p->sA);
     delete p;
     return MCRX_OK;
 }
@@ -146,8 +150,15 @@ extern "C" int mcrx_hip_pipeline_create(mcrx_hip_pipeline_t *out, mcrx_hip_t rx,
             hipEventCreateWithFlags(&p->evC[i], hipEventDisableTiming) != hipSuccess) return bail(pfail(MCRX_EHIP, "hipEventCreate failed"));
     }
     if (hipEventCreateWithFlags(&p->ev_after, hipEventDisableTiming) != hipSuccess) return bail(pfail(MCRX_EHIP, "hipEventCreate failed"));
-    if (hipStreamCreateWithFlags(&p->sA, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&p->sB, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&p->sC, hipStreamNonBlocking) != hipSuccess) return bail(pfail(MCRX_EHIP, "hipStreamCreate failed"));
+    {   const char *ev = getenv("MCRX_PIPE_STREAMS");           // experiments: 1 = one stream for all three stages, 3 = one each (rounds 2-3)
+        const int ns = ev ? atoi(ev) : 2;
+        if (hipStreamCreateWithFlags(&p->sA, hipStreamNonBlocking) != hipSuccess) return bail(pfail(MCRX_EHIP, "hipStreamCreate failed"));
+        if (ns <= 1) p->sB = p->sA;
+        else if (hipStreamCreateWithFlags(&p->sB, hipStreamNonBlocking) != hipSuccess) return bail(pfail(MCRX_EHIP, "hipStreamCreate failed"));
+        if (ns <= 1) p->sC = p->sA;
+        else if (ns == 2) p->sC = p->sB;
+        else if (hipStreamCreateWithFlags(&p->sC, hipStreamNonBlocking) != hipSuccess) return bail(pfail(MCRX_EHIP, "hipStreamCreate failed"));
+    }
     if (hipDeviceSynchronize() != hipSuccess) return bail(pfail(MCRX_EHIP, "device synchronize failed"));      // (the zeroed buffers, before the non-blocking streams use them)
     if (world > 1) {
         if (!g_rccl.load()) return bail(pfail(MCRX_EUNSUPP, "librccl.so.1 not found"));

@@ -10,11 +10,13 @@ that turns the time-sharded channelizer output into channel shards:
     all-to-all:  chunk g of rank r  ->  chunk r of rank g
     sync:        chan[s][tile][c][16] s = source rank  ==  [tile of the round][c][16], contiguous in time
 
-Rounds are pipelined on three streams with rotating buffers:
+Rounds are pipelined with rotating buffers:
 
     channelize(c+1)  ||  all_to_all(c)  ||  synchronizers(c-1)
 
-(the synchronizer stage itself overlaps its acquisition and payload kernels inside the handle).
+on two streams of the pipeline's own -- one for the channelizer, one for the exchange and the launch of the synchronizer stage,
+which overlaps its acquisition and payload kernels on the handle's internal streams (a third stream for that launch, as in
+rounds 2-3, cost the one-GPU run 11 %: scratch/r4an.sh).
 No collective other than this exchange is on the data path.
 The backend object supplies the two compute stages (the HIP library in production; tests
 inject a CPU stand-in so the orchestration runs under gloo without a GPU).
@@ -107,9 +109,10 @@ class Pipeline(object):
         self.time_exchange = False                  # bench.py: HIP events around every exchange (exchange_ms)
         self._xev = []
         if self.cuda:
-            self.sA, self.sB, self.sC = (torch.cuda.Stream(device=device) for _ in range(3))
+            self.sA, self.sB = (torch.cuda.Stream(device=device) for _ in range(2))
+            self.sC = self.sB                       # (module docstring: the synchronizer stage is launched from the exchange's stream)
             # the buffers above were zeroed on the current stream; round 0 relies on those zeros (no history copy yet)
-            for s in (self.sA, self.sB, self.sC):
+            for s in (self.sA, self.sB):
                 s.wait_stream(torch.cuda.current_stream(device))
             self.evA = [torch.cuda.Event() for _ in range(nbuf)]
             self.evB = [torch.cuda.Event() for _ in range(nbuf)]
