@@ -109,10 +109,12 @@ class Pipeline(object):
         self.time_exchange = False                  # bench.py: HIP events around every exchange (exchange_ms)
         self._xev = []
         if self.cuda:
-            self.sA, self.sB = (torch.cuda.Stream(device=device) for _ in range(2))
-            self.sC = self.sB                       # (module docstring: the synchronizer stage is launched from the exchange's stream)
+            nstr = int(__import__("os").environ.get("MCRX_PIPE_STREAMS", "2"))          # (experiments; the C-ABI pipeline reads the same variable)
+            self.sA = torch.cuda.Stream(device=device)
+            self.sB = torch.cuda.Stream(device=device) if nstr >= 2 else self.sA
+            self.sC = torch.cuda.Stream(device=device) if nstr >= 3 else self.sB     # (module docstring: the synchronizer stage is launched from the exchange's stream)
             # the buffers above were zeroed on the current stream; round 0 relies on those zeros (no history copy yet)
-            for s in (self.sA, self.sB):
+            for s in (self.sA, self.sB, self.sC):
                 s.wait_stream(torch.cuda.current_stream(device))
             self.evA = [torch.cuda.Event() for _ in range(nbuf)]
             self.evB = [torch.cuda.Event() for _ in range(nbuf)]
