@@ -60,11 +60,11 @@ __device__ __forceinline__ float2 modulate(int mod, unsigned sym)
 // after the other, each waiting for its subcarrier map, then its rank, then its byte: 0.59 ms per 1.44 M symbols, two thirds of the
 // wave cycles waiting): txsym_fetch requests what the symbol needs from memory, txsym_emit consumes it.
 struct TxSymWhat { int s; bool table, zero, is_hdr; const uint8_t *bits; };
-__device__ __forceinline__ TxSymWhat txsym_what(const TxSymArgs &a, const uint32_t gs, const uint32_t ch, const unsigned long long d)
+__device__ __forceinline__ TxSymWhat txsym_what(const TxSymArgs &a, const uint32_t gs, const uint32_t ch, const unsigned long long d, int f = -1, int sidx = 0)
 {
     TxSymWhat w;
-    const int f = gs / a.S;
-    w.s = gs % a.S;
+    if (f < 0) { f = gs / a.S; sidx = gs % a.S; }       // (callers that walk the symbol axis pass frame and index)
+    w.s = sidx;
     w.table = w.s < 3 || w.s == a.S - 1; w.zero = w.s == a.S - 1; w.is_hdr = w.s < 3 + a.S_hdr;
     w.bits = a.hdr;                                  // (always mapped: table symbols load nothing from it)
     if (a.symdesc) {
@@ -183,6 +183,94 @@ __global__ __launch_bounds__(TXW) void txsym_kernel(TxSymArgs a, uint32_t nsym)
         if (k + D < TXSYM_PER) { const uint32_t gn = gs0 + k + D; pre[k % D] = txsym_fetch<E>(a, gn < nsym ? gn : nsym - 1, ch, ln); }
         if (gs < nsym) txsym_emit<E>(a, gs, ch, l, twl, ln, cur);
     }
+}
+
+// M = 64 (the benchmark's and the applications' symbol): the wave's eight symbols side by side, eight lanes each, a lane holding
+// the eight subcarriers i = j + 8 e of its symbol (j = lane & 7).  The transform's first three stages (partners 32, 16, 8 apart) are
+// register butterflies with the lane's own twiddles, the last three cross lanes inside the group of eight; every lane ends with the
+// eight CONTIGUOUS outputs n = 8 bitrev3(j) + bitrev3(e), written as four 16-byte stores.  One pass of ~350 wave instructions per eight
+// symbols where the one-point-per-lane kernel above runs eight passes of ~125 (0.43 ms per 1.44 M symbols, the VALU its bound).
+__global__ __launch_bounds__(TXW) void txsym64_kernel(TxSymArgs a, uint32_t nsym)
+{
+    const int l = threadIdx.x & 63, j = l & 7;
+    const uint32_t ch = blockIdx.y;
+    const uint32_t gs_raw = blockIdx.x * TXSYM_PER + (uint32_t)(l >> 3);
+    const bool live = gs_raw < nsym;
+    const uint32_t gs = live ? gs_raw : nsym - 1;
+    // what this group's symbol is, and its bytes (requested first: everything below up to the modulator is independent of them)
+    const unsigned long long d = a.symdesc ? a.symdesc[(size_t)ch * a.S + gs] : 0ull;
+    // (frame and index of the wave's first symbol by one scalar division, the lane's own by walking on from there)
+    const uint32_t gs0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * TXSYM_PER));
+    int f = (int)(gs0 / (uint32_t)a.S), sidx = (int)(gs0 % (uint32_t)a.S) + (int)(gs - gs0);
+    while (sidx >= a.S) { sidx -= a.S; f++; }
+    const TxSymWhat w = txsym_what(a, gs, ch, d, f, sidx);
+    int t[8]; int dr[8], pr[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int k = j + 8 * e;
+        t[e] = (int)a.sctype[k]; dr[e] = a.data_rank[k]; pr[e] = a.pilot_rank[k];
+    }
+    const uint32_t pcount = (uint32_t)(w.s >= 3 ? w.s - 3 : 0) * (uint32_t)a.M_pilot;
+    uint8_t bit[8], pil[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        bit[e] = w.bits[(!w.table && t[e] == 2) ? dr[e] : 0];
+        pil[e] = a.pilot_seq[(pcount + (uint32_t)(t[e] == 1 ? pr[e] : 0)) % 255u];
+    }
+    // lane twiddles: W_64^(j + 8 e) (e < 4), W_32^(j + 8 e) (e < 2), W_16^j; across the lanes W_8^(j & 3), W_4^(j & 1)
+    // (on the transcendental unit: nine twiddles per lane and wave are a third of the instructions otherwise; 1.2e-7 absolute)
+    auto tw = [](int k, unsigned h) { float sn, cs; sincos_u32_hw((uint32_t)k * (uint32_t)(0x80000000u / h), sn, cs); return make_float2(cs, -sn); };
+    float2 t32[4], t16[2];
+#pragma unroll
+    for (int e = 0; e < 4; e++) t32[e] = tw(j + 8 * e, 32u);
+#pragma unroll
+    for (int e = 0; e < 2; e++) t16[e] = tw(j + 8 * e, 16u);
+    const float2 t8 = tw(j, 8u), t4 = tw(j & 3, 4u), t2 = tw(j & 1, 2u);
+    const float2 *src = (w.s == 2) ? a.s1t : a.s0t;
+    float2 x[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        float2 v = make_float2(0.f, 0.f);
+        if (t[e] == 1) v = make_float2(pil[e] ? a.g_data : -a.g_data, 0.f);
+        else if (t[e] == 2) { v = modulate(w.is_hdr ? 39 : a.mod, bit[e]); v.x *= a.g_data; v.y *= a.g_data; }
+        x[e] = make_float2(v.x, -v.y);              // inverse FFT = conj(FFT(conj(X)))
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) { const float2 u = x[e], v = x[e + 4]; x[e] = cadd(u, v); x[e + 4] = cmul(csub(u, v), t32[e]); }
+#pragma unroll
+    for (int b = 0; b < 8; b += 4)
+#pragma unroll
+        for (int e = 0; e < 2; e++) { const float2 u = x[b + e], v = x[b + e + 2]; x[b + e] = cadd(u, v); x[b + e + 2] = cmul(csub(u, v), t16[e]); }
+#pragma unroll
+    for (int b = 0; b < 8; b += 2) { const float2 u = x[b], v = x[b + 1]; x[b] = cadd(u, v); x[b + 1] = cmul(csub(u, v), t8); }
+#pragma unroll
+    for (int st = 0; st < 3; st++) {
+        const int h = 4 >> st;
+        const float2 twl = st == 0 ? t4 : (st == 1 ? t2 : make_float2(1.f, 0.f));
+        const bool up = (j & h) != 0;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float2 p = make_float2(__shfl_xor(x[e].x, h, TXW), __shfl_xor(x[e].y, h, TXW));
+            x[e] = up ? (st == 2 ? csub(p, x[e]) : cmul(csub(p, x[e]), twl)) : cadd(x[e], p);
+        }
+    }
+    if (!live) return;
+    // position j + 8 e holds X[8 bitrev3(j) + bitrev3(e)]
+    const int n0 = 8 * (int)(__brev((unsigned)j) >> 29);
+    float2 *dst = a.xsym + (a.xs_sym ? (size_t)ch * a.xs_ch + (size_t)gs * a.xs_sym : ((size_t)ch * a.frames * a.S + gs) * a.M) + n0;
+    float2 o[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        constexpr int br3[8] = { 0, 4, 2, 6, 1, 5, 3, 7 };
+        o[m] = make_float2(x[br3[m]].x, -x[br3[m]].y);
+    }
+    if (w.table) {                                  // S0a, S0b, S1 bodies come from the tables; tail (and idle symbols) have none
+#pragma unroll
+        for (int m = 0; m < 8; m++) o[m] = w.zero ? make_float2(0.f, 0.f) : src[n0 + m];
+    }
+    float4 *d4 = reinterpret_cast<float4 *>(dst);
+#pragma unroll
+    for (int m = 0; m < 4; m++) d4[m] = make_float4(o[2 * m].x, o[2 * m].y, o[2 * m + 1].x, o[2 * m + 1].y);
 }
 
 // the same for a subcarrier count that is not a power of two (the reference applications default to M = 48):
@@ -840,6 +928,12 @@ static int tx_launch_sym(mctx_hip_t q, const TxSymArgs &sa, unsigned nsym, unsig
     const dim3 gsym(nsym, nch), gsym8((nsym + TXSYM_PER - 1) / TXSYM_PER, nch);
     if (q->M & (q->M - 1)) {
         hipLaunchKernelGGL(txsym_dft_kernel, gsym, dim3(TXW), 0, st, sa);
+        TXCHK(hipGetLastError());
+        return MCRX_OK;
+    }
+    static const bool wide = getenv("MCTX_TXSYM64") == nullptr || atoi(getenv("MCTX_TXSYM64")) != 0;      // (0: the one-point-per-lane kernel, comparisons)
+    if (q->M == 64 && wide && (sa.xs_sym % 2) == 0 && (sa.xs_ch % 2) == 0) {
+        hipLaunchKernelGGL(txsym64_kernel, gsym8, dim3(TXW), 0, st, sa, nsym);
         TXCHK(hipGetLastError());
         return MCRX_OK;
     }
