@@ -203,8 +203,9 @@ const char *mcrx_hip_pfb2_last_error(void);
  * `sub_blocks` blocks of the wideband stream go round robin to the ranks (sub-slab u -> rank u % world); per round every
  * rank channelizes its sub-slab into per-destination groups, one grouped ncclSend / ncclRecv exchange over xGMI turns the
  * time shards into channel shards, and the rank's handle -- created with channel_first / channel_count = its shard of
- * N / world channels and defer_samples covering a frame -- synchronizes them; rounds overlap on three streams
- * (channelize(c+1) || exchange(c) || synchronizers(c-1)), events only, nothing waits on the host.  world == 1 is the same
+ * N / world channels and defer_samples covering a frame -- synchronizes them; rounds overlap
+ * (channelize(c+1) || exchange(c) || synchronizers(c-1)) on two streams of the pipeline's own plus the handle's, events only,
+ * nothing waits on the host.  world == 1 is the same
  * code without the exchange.  RCCL is loaded at run time (librccl.so.1); the caller hands rank 0's 128-byte ncclUniqueId to
  * every rank (MPI_Bcast, a file, torch.distributed).  Frames surface through the handle (poll / flush / next_frame) on the
  * rank that owns their channel.  liquid-usrp_amd/sharding.py is the Python mirror of the same schedule. */

@@ -14,6 +14,15 @@ with open(os.path.join(dst, "%s_%s_kernel_stats.csv" % (pre, tag)), "w") as f:
     w = csv.DictWriter(f, fieldnames=rows[0].keys()); w.writeheader()
     for r in rows:
         if any(o in r["Name"] for o in ours): w.writerow(r)
+if os.path.exists(os.path.join(src, "serial_kernel_stats.csv")):        # the serial receiver's table: every kernel alone
+    srows = list(csv.DictReader(open(os.path.join(src, "serial_kernel_stats.csv"))))
+    with open(os.path.join(dst, "%s_%s_kernel_stats_serial.csv" % (pre, tag)), "w") as f:
+        w = csv.DictWriter(f, fieldnames=srows[0].keys()); w.writeheader()
+        for r in srows:
+            if any(o in r["Name"] for o in ours): w.writerow(r)
+for extra in ("bench.json", "bench_pipeline.json", "duplex.json"):
+    if os.path.exists(os.path.join(src, extra)) and os.path.getsize(os.path.join(src, extra)) > 2:
+        open(os.path.join(dst, "%s_%s_%s" % (pre, tag, extra)), "w").write(open(os.path.join(src, extra)).read())
 acc = collections.defaultdict(lambda: [0.0, 0])
 for fn in sorted(os.listdir(src)):
     if not fn.endswith("_counter_collection.csv"): continue
