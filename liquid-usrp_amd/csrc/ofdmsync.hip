@@ -29,6 +29,9 @@ namespace mcrx {
 #ifndef SY_PROFILE
 #define SY_PROFILE 0        /* 1: MCRX_DEBUG=2 cycle counters per event / phase (they cost ~40 registers in the scout) */
 #endif
+#ifndef SY_RANK
+#define SY_RANK 1           /* scouts rank the chain of a window that holds many frames (Walker::rank_window) instead of hopping along it */
+#endif
 #ifndef SY_SEG_BURST
 #define SY_SEG_BURST 1      /* segment waves take idle stretches four SEEK events at a time (Walker::seek_burst) */
 #endif
@@ -1873,6 +1876,144 @@ struct Walker {
         }
         return true;
     }
+    // The same chain by list ranking, for windows that hold many frames (a serial hop is ~95 dependent scalar instructions of one wave
+    // alone on its SIMD, 0.3-0.9 us: a push of 400 frames per channel spent two thirds of its acquisition hopping).
+    //   next:  a slot's successor is the slot whose key is the state behind its frame -- the next slot of the same wave when that wave
+    //          went on from there (chained by construction), else one of the first four slots of the next wave (where two waves link:
+    //          its first slot when that wave started on the lattice, its second when it started from a coarse position);
+    //   rank:  eight rounds of pointer jumping over the window's 256 slots (byte arrays in the wave's event scratch) give every slot
+    //          its distance to the end of its chain; the head is the slot keyed `pos`, a slot's place in the head's chain is the
+    //          difference of the two distances;
+    //   check: the places are filled by whoever claims them and then verified link by link against `next` -- the verified prefix is
+    //          the chain, whatever else the window holds (chains that merge, stale slots);
+    //   adopt: the prefix' job entries go to the owner's list in order, the cadence counters are what the serial hop would have counted.
+    // Anything it cannot take (no head, a link it does not see, a non-frame slot) is left to hop_fresh / the general lookup.
+    __device__ __forceinline__ bool rank_window(int64_t &pos, int64_t &fresh_prev, int64_t &fresh_last, uint32_t &nfresh, uint32_t &nsame)
+    {
+        static_assert(SPH == 4 && MCRX_SPEC_MAX == 256, "byte indices over four rows of slot headers");
+        if (c.M < 64 || a.nseg == 0) return false;
+        const int32_t rel0 = (int32_t)(pos - a.buf_first);
+        bool val[SPH];
+        unsigned long long vb[SPH]; int nvalid = 0;
+#pragma unroll
+        for (int h = 0; h < SPH; h++) { val[h] = sp_rel[h] != INT32_MIN && (sp_aux[h] & 0xffu) == 1u; vb[h] = __ballot(val[h]); nvalid += __popcll(vb[h]); }
+        if (nvalid < 24) return false;                       // (a short chain: the serial hop is cheaper than the ~800 instructions below)
+        // head
+        int head = -1;
+#pragma unroll
+        for (int h = SPH - 1; h >= 0; h--) { const unsigned long long b = __ballot(val[h] && sp_rel[h] == rel0); if (b) head = 64 * h + (int)__builtin_ctzll(b); }
+        if (head < 0) return false;
+        uint8_t *nx = reinterpret_cast<uint8_t *>(sy_w), *rk = nx + 256, *nx0 = nx + 512, *Lp = nx + 768;
+        const uint32_t spw = a.spec_cap / a.nseg;
+        wave_sync_lds();
+        // ---- next
+        int nxt[SPH];
+#pragma unroll
+        for (int h = 0; h < SPH; h++) {
+            const int i = l + 64 * h;
+            const uint32_t gi = win0 + (uint32_t)i;                                 // slot number in the channel
+            // the slot behind me: the lane to my right, or the next row's first lane
+            int32_t rr = __shfl_down(sp_rel[h], 1, WV); bool vr = (__shfl_down(val[h] ? 1 : 0, 1, WV)) != 0;
+            if (h + 1 < SPH) { const int32_t r0 = __builtin_amdgcn_readlane(sp_rel[h + 1], 0); const bool v0 = (vb[h + 1] & 1ull) != 0; if (l == 63) { rr = r0; vr = v0; } }
+            else if (l == 63) vr = false;
+            const int32_t want = sp_tlast[h] + 1;
+            const bool same_wave = (gi + 1u) % spw != 0u;
+            int n = i;                                                              // (nobody: a chain ends here)
+            if (val[h] && same_wave && vr && rr == want) n = i + 1;
+            nxt[h] = n;
+        }
+        // links between waves: the first four slots of the next wave, read from their lanes
+#pragma unroll
+        for (int h = 0; h < SPH; h++) {
+            const int i = l + 64 * h;
+            const uint32_t gi = win0 + (uint32_t)i;
+            const uint32_t c0g = (gi / spw + 1u) * spw;                             // next wave's first slot (channel numbering)
+            const int32_t want = sp_tlast[h] + 1;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t cg = c0g + (uint32_t)k;
+                const bool inw = cg >= win0 && cg < win0 + 256u && cg < a.spec_cap && (uint32_t)k < spw;
+                const int ci = inw ? (int)(cg - win0) : 0;
+                int32_t cr = 0; int cv = 0;
+#pragma unroll
+                for (int r = 0; r < SPH; r++) {                                     // (every lane asks its own candidate: one permute per row of headers)
+                    const int32_t t = __shfl(sp_rel[r], ci & 63, WV); const int tv = __shfl(val[r] ? 1 : 0, ci & 63, WV);
+                    if ((ci >> 6) == r) { cr = t; cv = tv; }
+                }
+                if (val[h] && nxt[h] == i && inw && cv && cr == want) nxt[h] = ci;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < SPH; h++) {
+            const int i = l + 64 * h;
+            nx[i] = (uint8_t)nxt[h]; nx0[i] = (uint8_t)nxt[h]; rk[i] = (uint8_t)(nxt[h] != i ? 1 : 0);
+        }
+        wave_sync_lds();
+        // ---- rank: distance to the end of the chain
+#pragma unroll 1
+        for (int round = 0; round < 8; round++) {
+            int na[SPH], ra[SPH];
+#pragma unroll
+            for (int h = 0; h < SPH; h++) { const int i = l + 64 * h; const int a1 = nx[i]; ra[h] = (int)rk[i] + (int)rk[a1]; na[h] = nx[a1]; if (a1 == i) ra[h] = rk[i]; }
+            wave_sync_lds();
+#pragma unroll
+            for (int h = 0; h < SPH; h++) { const int i = l + 64 * h; nx[i] = (uint8_t)na[h]; rk[i] = (uint8_t)(ra[h] > 255 ? 255 : ra[h]); }
+            wave_sync_lds();
+        }
+        const int R = rk[head];
+        int n = R + 1;
+        const int room = MCRX_SPEC_MAX - (int)nown;
+        if (n > room) n = room;
+        // ---- places, claimed ...
+#pragma unroll
+        for (int h = 0; h < SPH; h++) { const int i = l + 64 * h; const int rki = rk[i]; if (val[h] && rki <= R) Lp[R - rki] = (uint8_t)i; }
+        wave_sync_lds();
+        // ... and verified link by link
+        int mine[SPH]; int nok = n;
+#pragma unroll
+        for (int h = 0; h < SPH; h++) {
+            const int pp = l + 64 * h;
+            mine[h] = Lp[pp];
+            const int prev = Lp[pp > 0 ? pp - 1 : 0];
+            const bool good = pp == 0 ? mine[h] == head : (int)nx0[prev] == mine[h] && prev != mine[h];
+            const unsigned long long bad = __ballot(pp < n && !good);
+            if (bad) { const int first = 64 * h + (int)__builtin_ctzll(bad); if (first < nok) nok = first; }
+        }
+        if (nok <= 0) return false;
+        n = nok;
+        wave_sync_lds();
+        // ---- adopt: job entries in chain order; the frames' ends for the cadence counters (the scratch is free again: positions as words)
+        int32_t *fend = reinterpret_cast<int32_t *>(sy_w);
+        int32_t myend[SPH];
+#pragma unroll
+        for (int h = 0; h < SPH; h++) {
+            const int pp = l + 64 * h, i = mine[h];
+            uint32_t ax = 0; int32_t tl = 0;
+#pragma unroll
+            for (int r = 0; r < SPH; r++) {
+                const uint32_t t = (uint32_t)__shfl((int)sp_aux[r], i & 63, WV); const int32_t u = __shfl(sp_tlast[r], i & 63, WV);
+                if ((i >> 6) == r) { ax = t; tl = u; }
+            }
+            myend[h] = tl + 1;
+            if (pp < n) { ldsad[nown + (uint32_t)pp] = ax >> 8; fend[pp] = tl + 1; }
+        }
+        wave_sync_lds();
+        const int32_t relp1 = fresh_last >= 0 ? (int32_t)(fresh_last - a.buf_first) : INT32_MIN, relp2 = fresh_prev >= 0 ? (int32_t)(fresh_prev - a.buf_first) : INT32_MIN;
+        uint32_t same = 0;
+#pragma unroll
+        for (int h = 0; h < SPH; h++) {
+            const int pp = l + 64 * h;
+            const int32_t f1 = pp >= 1 ? fend[pp - 1] : relp1, f2 = pp >= 2 ? fend[pp - 2] : (pp == 1 ? relp1 : relp2);
+            const bool have = pp >= 2 || (pp == 1 ? relp1 != INT32_MIN : (relp1 != INT32_MIN && relp2 != INT32_MIN));
+            same += (uint32_t)__popcll(__ballot(pp < n && have && myend[h] - f1 == f1 - f2));
+        }
+        const int32_t e1 = fend[n - 1], e2 = n >= 2 ? fend[n - 2] : relp1;
+        wave_sync_lds();
+        nsame += same; nfresh += (uint32_t)n; nown += (uint32_t)n; nadopted += (uint32_t)n;
+        fresh_prev = (n >= 2 || relp1 != INT32_MIN) ? a.buf_first + (int64_t)e2 : -1; fresh_last = a.buf_first + (int64_t)e1;
+        pos = fresh_last;
+        return true;
+    }
     // ... looked up where a push holds more slots per channel than the window: the slots a frame acquired from `pos` can sit in are
     // the ones of the wave whose segment holds `pos` and of the wave before it (its last frame, the one that links the two, is
     // acquired from a state behind the segment boundary when the frame before it straddles it); if the window does not hold
@@ -2178,7 +2319,11 @@ struct Walker {
                 // adoption leaves it in the same fresh post-frame state, only the position differs).
                 int64_t key = spec_key(s.cur, s.timer, s.state);
                 int64_t pos = s.cur, t_end = 0; uint32_t aux = 0, kslot = 0; bool any = false, deferred = false;
-                if (s.state == SY_SEEK && s.timer == (uint32_t)L && hop_fresh(pos, fresh_prev, fresh_last, nfresh, nsame)) { any = true; key = spec_key(pos, (uint32_t)L); }
+                if (s.state == SY_SEEK && s.timer == (uint32_t)L) {
+                    bool got = SY_RANK && rank_window(pos, fresh_prev, fresh_last, nfresh, nsame);
+                    got = hop_fresh(pos, fresh_prev, fresh_last, nfresh, nsame) || got;
+                    if (got) { any = true; key = spec_key(pos, (uint32_t)L); }
+                }
                 while (nown < MCRX_SPEC_MAX && adopt_lookup(key, pos, t_end, aux, kslot)) {
                     if ((aux & 0xffu) == 2u) { deferred = true; break; }
                     if ((aux & 0xffu) == 3u) {
@@ -2194,6 +2339,7 @@ struct Walker {
                         if (fresh_prev >= 0 && pos - fresh_last == fresh_last - fresh_prev) nsame++;
                         fresh_prev = fresh_last; fresh_last = pos; nfresh++;
                     }
+                    if (SY_RANK) rank_window(pos, fresh_prev, fresh_last, nfresh, nsame);
                     hop_fresh(pos, fresh_prev, fresh_last, nfresh, nsame);         // (on from there in the tight loop)
                     key = spec_key(pos, (uint32_t)L);
                 }
@@ -2204,6 +2350,9 @@ struct Walker {
                     break;
                 }
                 if (any) { reset_framesync(); s.timer = (uint32_t)L; s.cur = pos; }
+                // (the owner's list is full: place what it holds and look again from this state -- falling through would take the next
+                //  event here, and a scout that has left the fresh state walks the whole frame: 61 k cycles once per 255 frames)
+                if (any && nown >= MCRX_SPEC_MAX - 1) { entry = false; continue; }
             }
             entry = false;
             if (MODE == SYM_LEAN && s.cur >= a.end) break;      // (a frame jumped over may end beyond this buffer)
