@@ -194,7 +194,7 @@ def main():
                 else:
                     h.Poll()                        # a result generation holds one slab's frames
         samples_per_step = period_blocks * K
-        pipe = None
+        pipe, trial_steps = None, 0
     else:
         # one period of the stream = nslab slabs; cut into rounds * world sub-slabs, sub-slab u -> rank u % world
         rounds = args.rounds
@@ -220,7 +220,7 @@ def main():
         # auto: the extern-C pipeline (HIP events + grouped ncclSend / ncclRecv behind the C-ABI: what north_star asks for) whenever
         # it can run -- one rank, or several with librccl loadable -- else the torch pipeline, with the reason in the line
         use_c, why_not_c, uid = (args.exchange != "torch"), None, None
-        if rehearsal and use_c:
+        if rehearsal and use_c and not os.environ.get("BENCH_REHEARSE_C"):      # (BENCH_REHEARSE_C=1: try it anyway -- RCCL refuses, which exercises the agreed fall-back below)
             use_c, why_not_c = False, "one-GPU rehearsal: RCCL refuses two ranks on one device, the exchange goes through host memory under gloo"
             if args.exchange == "c":
                 sys.exit("--exchange c cannot be rehearsed on one GPU")
@@ -237,13 +237,42 @@ def main():
                 if args.exchange == "c":
                     sys.exit("--exchange c: " + str(box[1]))
                 use_c, why_not_c = False, "librccl could not be loaded behind the C-ABI (%s)" % box[1]
+        nbuf = int(os.environ.get("MCRX_PIPE_NBUF", "5"))
+        first_push = [True]
+        trial_steps = 0
         if use_c:
             # (five rotating buffer sets = the receiver's own five slots: the channelizer runs as far ahead of the payload workers as in
-            #  the direct path -- 144 -> 148 Gsample/s on one GPU; six wait for a slot and halve it.  MCRX_PIPE_NBUF)
-            pipe = prod.pipeline(rx, rank, world, Tc, unique_id=uid, nbuf=int(os.environ.get("MCRX_PIPE_NBUF", "5")))
-        else:
-            pipe = sharding.Pipeline(rx, rank, world, dist, N, Tc, rx.hist_tiles, device=dev, nbuf=int(os.environ.get("MCRX_PIPE_NBUF", "5")))
-        first_push = [True]
+            #  the direct path; six wait for a slot and halve it.  MCRX_PIPE_NBUF)
+            # The grouped ncclSend / ncclRecv exchange behind the C-ABI has never run between two GPUs (no multi-GPU lease so far): it
+            # is created and tried for one round of the stream under a guard, the ranks agree on the outcome, and if any of them
+            # failed all of them take the torch pipeline on a fresh receiver, with the reason in the line.
+            err = None
+            try:
+                pipe = prod.pipeline(rx, rank, world, Tc, unique_id=uid, nbuf=nbuf)
+                if world > 1:                           # one whole step, so that the stream stays a whole number of periods long
+                    for c in range(rounds):
+                        pipe.push(mine[c], None if first_push[0] else halos[c], ready=True)
+                        first_push[0] = False
+                    rx.Discard()
+                    pipe.wait(); torch.cuda.synchronize()
+                    trial_steps = 1
+            except Exception as e:
+                err, pipe = repr(e), None
+            all_ok = err is None
+            if world > 1:
+                flag = torch.tensor([1 if err is None else 0], dtype=torch.int32, device="cpu" if rehearsal else dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                all_ok = bool(int(flag.item()))
+            if not all_ok:
+                if args.exchange == "c":
+                    sys.exit("--exchange c: the C-ABI pipeline failed on a rank (%s)" % err)
+                if pipe is not None:
+                    pipe.close()
+                rx.close()
+                rx = prod.multichannelrx(N, M, cp, taper, channel_first=c0, channel_count=cg, **cfg)
+                use_c, why_not_c, first_push[0], trial_steps = False, "the C-ABI pipeline failed in its trial step on at least one rank (this rank: %s)" % err, True, 0
+        if not use_c:
+            pipe = sharding.Pipeline(rx, rank, world, dist, N, Tc, rx.hist_tiles, device=dev, nbuf=nbuf)
 
         def step(harvest_rx=None):
             for c in range(rounds):
@@ -294,7 +323,7 @@ def main():
     # ---- verification (untimed): one more step of the continuing stream, harvested; every frame of the step
     # decoded, valid and equal to what the transmitter sent
     rx.Flush(); rx.frames.clear()
-    step_first = int(args.warmup + nsteps_timed) * period_blocks         # channel-rate sample index where this step starts
+    step_first = int(args.warmup + nsteps_timed + trial_steps) * period_blocks         # channel-rate sample index where this step starts
     step(harvest_rx=rx)
     rx.Flush()
     nfr, n_ok = len(rx.frames), 0

@@ -33,3 +33,20 @@ def test_bench_two_ranks_rehearsed_on_one_gpu(world):
     assert d["config"]["rehearsal_on_one_gpu"] is True and "sharding.Pipeline" in d["config"]["multi_gpu_path"]
     assert d["steps"] == 2 and d["repetitions"] == 2 and d["value"] > 0 and "exchange" in d
     assert d["config"]["receiver_hints_from_the_benchmark"].startswith("none")
+
+
+def test_c_pipeline_failure_falls_back_on_every_rank():
+    """`--exchange auto` takes the C-ABI pipeline (grouped ncclSend / ncclRecv) for N > 1 -- code that has never run between two GPUs.
+    bench.py therefore creates it and runs one trial step under a guard, lets the ranks agree on the outcome, and takes the torch
+    pipeline on a fresh receiver everywhere if any rank failed.  Two ranks on ONE device make RCCL refuse the communicator
+    (BENCH_REHEARSE_C=1 lets the rehearsal try it): the fall-back has to carry the run, with the reason in the line."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--steps", "2", "--warmup", "1",
+           "--reps", "1", "--no-cpu", "--frames", "4", "--slabs", "2", "--serial-steps", "1"]
+    r = subprocess.run(cmd, env=dict(clean_env(), BENCH_REHEARSE_C="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["verified"]["ok"] and d["verified"]["frames"] == d["verified"]["expected"] > 0
+    path = d["config"]["multi_gpu_path"]
+    assert "sharding.Pipeline" in path and "C-ABI pipeline failed" in path, path
