@@ -21,7 +21,7 @@ for it in range(iters):
         parts.append(x)
     tx.close()
     iq = torch.cat(parts)
-    n = int(iq.numel()) // (16 * N) * (16 * N)
+    n = int(iq.numel()) // (32 * N) * (32 * N)                # (whole tiles: MCRX_TILE = 16 blocks of 2N samples since round 4)
     x = iq[:n].cpu().numpy()
     t = np.arange(n)
     snr = rng.uniform(22, 40)
@@ -29,14 +29,14 @@ for it in range(iters):
     x = (x * np.exp(1j * (rng.uniform(-3e-4, 3e-4) * t + rng.uniform(0, 6.28))) +
          sig * 10 ** (-snr / 20) / np.sqrt(2) * (rng.randn(n) + 1j * rng.randn(n))).astype(np.complex64)
     o = ora.MultiChannelRx(N, M, cp, 4); o.execute(x)
-    rx = prod.multichannelrx(N, M, cp, 4, max_payload_len=640, batch_samples=16 * N * int(rng.randint(8, 200)))
+    rx = prod.multichannelrx(N, M, cp, 4, max_payload_len=640, batch_samples=32 * N * int(rng.randint(4, 100)))
     xd = torch.from_numpy(x).cuda()
     seen = 0
     for rep in range(3):
         if rep: rx.Reset()
         i = 0
         while i < n:
-            step = 16 * N * int(rng.randint(1, 400))
+            step = 32 * N * int(rng.randint(1, 200))
             rx.Execute(xd[i:min(i + step, n)]); i += step
         rx.Flush()
         got = rx.frames[seen:]; seen = len(rx.frames)
