@@ -29,6 +29,9 @@ namespace mcrx {
 #ifndef SY_PROFILE
 #define SY_PROFILE 0        /* 1: MCRX_DEBUG=2 cycle counters per event / phase (they cost ~40 registers in the scout) */
 #endif
+#ifndef H128_EARLY_OUT
+#define H128_EARLY_OUT 1    /* Hamming(12,8) soft decision: no neighbour search in a wave whose hard decisions are all codewords */
+#endif
 #ifndef SY_RANK
 #define SY_RANK 1           /* scouts rank the chain of a window that holds many frames (Walker::rank_window) instead of hopping along it */
 #endif
@@ -208,6 +211,12 @@ __device__ __forceinline__ unsigned h128_dec_soft_words(uint32_t w0, uint32_t w1
         c = (c << 1) | (sb > 127 ? 1u : 0u);
     }
     const unsigned s0 = h128_dec_sym(c);
+    // A neighbour at distance 3 beats the estimate only if flipping its three bits LOWERS the soft distance, which takes a bit where the
+    // estimate's codeword goes against the hard decision -- and there is none when the hard decisions are a codeword already (zero
+    // syndrome: every flip costs |255 - 2 soft| >= 1).  On clean traffic that is every symbol: the seventeen neighbour sums are only
+    // formed when some lane of the wave has a non-zero syndrome (same decisions either way: ties go to the estimate).
+    const unsigned z0 = (par_d(c & 0x01f) << 3) | (par_d(c & 0x1e1) << 2) | (par_d(c & 0x666) << 1) | par_d(c & 0xaaa);
+    if (H128_EARLY_OUT && __ballot(z0 != 0u) == 0ull) return s0;
     const unsigned cw0 = (s0 & 0x0f) | ((s0 & 0x70) << 1) | ((s0 & 0x80) << 2) | (par_d(s0 & 0xda) << 11) | (par_d(s0 & 0xb6) << 10) |
                          (par_d(s0 & 0x71) << 8) | (par_d(s0 & 0x0f) << 4);
     int flip[12];
