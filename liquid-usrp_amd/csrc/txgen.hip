@@ -243,15 +243,20 @@ __global__ __launch_bounds__(TXW) void txsym64_kernel(TxSymArgs a, uint32_t nsym
         for (int e = 0; e < 2; e++) { const float2 u = x[b + e], v = x[b + e + 2]; x[b + e] = cadd(u, v); x[b + e + 2] = cmul(csub(u, v), t16[e]); }
 #pragma unroll
     for (int b = 0; b < 8; b += 2) { const float2 u = x[b], v = x[b + 1]; x[b] = cadd(u, v); x[b + 1] = cmul(csub(u, v), t8); }
+    // (across the lanes: y = (p + sg x) tw with sg = -1, tw = W in the upper lane of a pair and sg = +1, tw = 1 in the lower one --
+    //  one fma per component and one complex multiply instead of both results and a select; the last stage has no twiddle)
 #pragma unroll
     for (int st = 0; st < 3; st++) {
         const int h = 4 >> st;
-        const float2 twl = st == 0 ? t4 : (st == 1 ? t2 : make_float2(1.f, 0.f));
         const bool up = (j & h) != 0;
+        const float sg = up ? -1.f : 1.f;
+        const float2 twl = st == 0 ? t4 : t2;
+        const float2 twu = up ? twl : make_float2(1.f, 0.f);
 #pragma unroll
         for (int e = 0; e < 8; e++) {
             const float2 p = make_float2(__shfl_xor(x[e].x, h, TXW), __shfl_xor(x[e].y, h, TXW));
-            x[e] = up ? (st == 2 ? csub(p, x[e]) : cmul(csub(p, x[e]), twl)) : cadd(x[e], p);
+            const float2 y = make_float2(fmaf(sg, x[e].x, p.x), fmaf(sg, x[e].y, p.y));
+            x[e] = st == 2 ? y : cmul(y, twu);
         }
     }
     if (!live) return;
