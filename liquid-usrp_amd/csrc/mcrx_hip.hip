@@ -498,8 +498,10 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
         if ((rc = q->alloc(&q->d_rec[g], q->max_rec))) return bail(rc);
         if ((rc = q->alloc(&q->d_arena[g], q->arena_cap))) return bail(rc);
         if ((rc = q->alloc(&q->d_sarena[g], q->sarena_cap))) return bail(rc);
-        if ((rc = q->alloc(&q->d_nrec[g], 2))) return bail(rc);
-        if ((rc = q->alloc(&q->d_arena_used[g], 2))) return bail(rc);
+        // (one 32-byte block per generation -- records, dropped | pad | payload bytes, symbol bytes -- so that a poll reads it with one
+        //  small copy and clears it with one fill: each of those waits ~0.1 ms for a slot on the full chip)
+        if ((rc = q->alloc(&q->d_nrec[g], 8))) return bail(rc);
+        q->d_arena_used[g] = reinterpret_cast<unsigned long long *>(q->d_nrec[g] + 4);
         if (hipEventCreateWithFlags(&q->ev_gen[g], hipEventDisableTiming) != hipSuccess) return bail(fail(MCRX_EHIP, "hipEventCreate failed"));
         if (hipEventCreateWithFlags(&q->ev_clean[g], hipEventDisableTiming) != hipSuccess) return bail(fail(MCRX_EHIP, "hipEventCreate failed"));
     }
@@ -1140,16 +1142,16 @@ static int collect(mcrx_hip_t q, int g)
     q->t_wait += now_s() - t0;
     uint32_t cnt[2] = { 0, 0 }; unsigned long long used[2] = { 0, 0 };
     if (q->gen_abandoned[g]) {              // dropped by mcrx_hip_discard: never delivered, only cleaned
-        HIPCHK(hipMemsetAsync(q->d_nrec[g], 0, 2 * sizeof(uint32_t), q->s_copy));
-        HIPCHK(hipMemsetAsync(q->d_arena_used[g], 0, 2 * sizeof(unsigned long long), q->s_copy));
+        HIPCHK(hipMemsetAsync(q->d_nrec[g], 0, 32, q->s_copy));
         HIPCHK(hipEventRecord(q->ev_clean[g], q->s_copy)); q->clean_pending[g] = true;
         q->gen_closed[g] = false; q->gen_used[g] = false; q->gen_abandoned[g] = false;
         return MCRX_OK;
     }
     { const double t1 = now_s();
-    HIPCHK(hipMemcpyAsync(cnt, q->d_nrec[g], sizeof(cnt), hipMemcpyDeviceToHost, q->s_copy));
-    HIPCHK(hipMemcpyAsync(used, q->d_arena_used[g], sizeof(used), hipMemcpyDeviceToHost, q->s_copy));
-    HIPCHK(hipStreamSynchronize(q->s_copy));
+    { unsigned long long blk[4] = { 0, 0, 0, 0 };
+      HIPCHK(hipMemcpyAsync(blk, q->d_nrec[g], sizeof(blk), hipMemcpyDeviceToHost, q->s_copy));
+      HIPCHK(hipStreamSynchronize(q->s_copy));
+      cnt[0] = (uint32_t)blk[0]; cnt[1] = (uint32_t)(blk[0] >> 32); used[0] = blk[2]; used[1] = blk[3]; }
     q->t_cnt += now_s() - t1; }
     q->dropped += cnt[1];
     const uint32_t n = std::min(cnt[0], q->max_rec);
@@ -1185,8 +1187,7 @@ static int collect(mcrx_hip_t q, int g)
     }
     // (the counters are zeroed on the copy stream without waiting for it: a fill is a kernel, and on a full chip a kernel waits
     //  100-200 us for a wave slot -- with the host waiting for it, every poll.  The next launch into this generation waits instead.)
-    HIPCHK(hipMemsetAsync(q->d_nrec[g], 0, 2 * sizeof(uint32_t), q->s_copy));
-    HIPCHK(hipMemsetAsync(q->d_arena_used[g], 0, 2 * sizeof(unsigned long long), q->s_copy));
+    HIPCHK(hipMemsetAsync(q->d_nrec[g], 0, 32, q->s_copy));
     HIPCHK(hipEventRecord(q->ev_clean[g], q->s_copy)); q->clean_pending[g] = true;
     q->gen_closed[g] = false; q->gen_used[g] = false;
     return cnt[1] ? MCRX_EOVERFLOW : MCRX_OK;
@@ -1262,8 +1263,7 @@ extern "C" int mcrx_hip_discard(mcrx_hip_t q)
     if (!q->gen_used[g]) return MCRX_OK;
     if (q->gen_used[next] || q->gen_closed[next]) {
         HIPCHK(hipStreamWaitEvent(q->s_copy, q->ev_gen[next], 0));
-        HIPCHK(hipMemsetAsync(q->d_nrec[next], 0, 2 * sizeof(uint32_t), q->s_copy));
-        HIPCHK(hipMemsetAsync(q->d_arena_used[next], 0, 2 * sizeof(unsigned long long), q->s_copy));
+        HIPCHK(hipMemsetAsync(q->d_nrec[next], 0, 32, q->s_copy));
         HIPCHK(hipEventRecord(q->ev_gen[next], q->s_copy));
         // the next launches into that generation start behind the zeroing: on the stream the acquisition kernels (which
         // place records and advance these counters) were last launched on -- the caller's own stream on a serial handle
