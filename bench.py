@@ -392,6 +392,9 @@ def main():
                                                                       "sharding.Pipeline (torch)" + (": " + why_not_c if why_not_c else "")),
                        "rehearsal_on_one_gpu": bool(rehearsal),
                        "receiver_hints_from_the_benchmark": "none (no MCRX_* environment is set by this script)",
+                       "channel": "noise-free loopback of the GPU transmitter (BASELINE.json's synthetic source).  One stage's cost depends on that: the "
+                                  "Hamming(12,8) soft decision forms its neighbour distances only in waves with a non-zero syndrome (exact; "
+                                  "decode_kernel 0.115 ms here, 0.138 ms when every wave has one: DESIGN.md section 4.2)",
                        "parallelism": ("round-robin time-sharded channelizer -> all-to-all -> %d channels/GPU, %d rounds per step, "
                                        "exchange overlapped" % (cg, args.rounds)) if world > 1 else "single GPU"},
             "spec_hit_rate": round(adopted / total, 4) if total else None,
