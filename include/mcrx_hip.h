@@ -77,6 +77,15 @@ typedef struct {
                                     channel counts) */
     uint32_t skip_framesyms;     /* 1 = harvests leave the equalised symbols in HBM (frames report num_framesyms = 0): 1.2 KB
                                     instead of 59 KB per frame over the host link at the benchmark's frame size */
+    /* Alternate builds of the same stages.  Every one decodes the same frames (the -m gpu tests hold each to the oracle); they
+     * differ in speed only and exist so that a regression in the default can be told from one in the algorithm.  0 = default. */
+    uint32_t worker_build;       /* M = 64 payload workers: 0 = lean workers, butterfly exchanges through the LDS crossbar;
+                                    1 = lean workers with the exchanges on the VALU (DPP / permlane swaps); 2 = the round-2 worker, one
+                                    frame per wave; 3 / 4 = that worker with two / four frames per wave; 5 = the width-generic kernel */
+    uint32_t acquisition;        /* 0 = segment-parallel acquisition, anchor phase while the traffic has a cadence; 1 = one launch of
+                                    segment waves, no anchor phase; 2 = no segment waves (the scouts walk every frame); 3 = anchor phase
+                                    always; 4 = no speculation at all (the round-1 scout: one kernel per push does everything) */
+    uint32_t scout_build;        /* 0 = the scouts' unbudgeted build (two waves per SIMD); 1 = the 168-register build of rounds 2-3 */
 } mcrx_hip_config;
 
 /* One decoded frame = the arguments of the reference's framesync_callback

@@ -24,6 +24,7 @@ TX_TILE = 8       # granules of the transmit side (mctx_hip_traffic_tiles)
 
 LIQUID_CRC_NONE, LIQUID_CRC_32 = 1, 6
 LIQUID_FEC_NONE, LIQUID_FEC_HAMMING128, LIQUID_FEC_GOLAY2412, LIQUID_FEC_CONV_V27 = 1, 6, 7, 11
+LIQUID_FEC_REP3, LIQUID_FEC_REP5, LIQUID_FEC_HAMMING74, LIQUID_FEC_HAMMING84 = 2, 3, 4, 5
 LIQUID_MODEM_QAM16, LIQUID_MODEM_QAM64, LIQUID_MODEM_BPSK, LIQUID_MODEM_QPSK = 27, 29, 39, 40
 
 
@@ -42,7 +43,8 @@ class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("max_payload_len", C.c_uint32), ("max_frames", C.c_uint32),
                 ("payload_soft", C.c_uint32), ("slab_blocks", C.c_uint32), ("channel_first", C.c_uint32),
                 ("channel_count", C.c_uint32), ("batch_samples", C.c_uint32), ("single_channel", C.c_uint32),
-                ("serial", C.c_uint32), ("chunk_blocks", C.c_uint32), ("defer_samples", C.c_uint32), ("front_end", C.c_uint32), ("skip_framesyms", C.c_uint32)]
+                ("serial", C.c_uint32), ("chunk_blocks", C.c_uint32), ("defer_samples", C.c_uint32), ("front_end", C.c_uint32), ("skip_framesyms", C.c_uint32),
+                ("worker_build", C.c_uint32), ("acquisition", C.c_uint32), ("scout_build", C.c_uint32)]
 
 
 class FrameC(C.Structure):

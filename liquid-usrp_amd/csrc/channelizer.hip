@@ -27,6 +27,7 @@
 // xGMI all-to-all needs.  A round of 8 blocks fills one half of every granule; the next round of the same
 // workgroup fills the other (slabs are whole tiles), so the halves meet in that XCD's L2.
 // HBM-bound by design: 8 B read + 4 B written per wideband sample.
+#include "devel.h"
 #include "devmath.h"
 #include "kernels.h"
 
@@ -513,7 +514,7 @@ hipError_t channelizer_launch(unsigned K, const ChanArgs &a, hipStream_t st)
     case 128:  return launch_one<128, 2, 256>(a, st);
     case 256:  return launch_one<256, 2, 256>(a, st);
     case 512:  return launch_one<512, 2, 256>(a, st);
-    case 1024: { static const int c1 = getenv("MCRX_CHAN_C1") ? atoi(getenv("MCRX_CHAN_C1")) : 0;
+    case 1024: { static const int c1 = devel_env("MCRX_CHAN_C1") ? atoi(devel_env("MCRX_CHAN_C1")) : 0;
                  return c1 ? launch_one<1024, 1, 1024>(a, st) : launch_one<1024, 2, 512>(a, st); }
     default:   return hipErrorInvalidValue;
     }

@@ -19,7 +19,10 @@ struct cf { float re, im; };
 
 enum { SC_NULL = 0, SC_PILOT = 1, SC_DATA = 2 };
 enum { CRC_UNKNOWN = 0, CRC_NONE = 1, CRC_32 = 6 };
-enum { FEC_UNKNOWN = 0, FEC_NONE = 1, FEC_HAMMING128 = 6, FEC_GOLAY2412 = 7, FEC_CONV_V27 = 11 };
+enum { FEC_UNKNOWN = 0, FEC_NONE = 1, FEC_REP3 = 2, FEC_REP5 = 3, FEC_HAMMING74 = 4, FEC_HAMMING84 = 5, FEC_HAMMING128 = 6, FEC_GOLAY2412 = 7,
+       FEC_CONV_V27 = 11 };
+// the schemes this path encodes and decodes as themselves; everything else is refused (MCRX_EUNSUPP), never sent under a false id
+inline bool fec_supported(int fs) { return (fs >= FEC_NONE && fs <= FEC_GOLAY2412) || fs == FEC_CONV_V27; }
 enum { MOD_UNKNOWN = 0, MOD_QAM16 = 27, MOD_QAM64 = 29, MOD_BPSK = 39, MOD_QPSK = 40 };
 
 // ---------------------------------------------------------------- Kaiser prototype
@@ -337,8 +340,14 @@ inline unsigned fec_enc_len(int fs, unsigned n)
     if (fs == FEC_HAMMING128) return (n / 2) * 3 + (n % 2) * 2;
     if (fs == FEC_GOLAY2412) return (n / 3) * 6 + (n % 3) * 3;
     if (fs == FEC_CONV_V27) return 2 * n + 2;               // r = 1/2, K = 7: 2 (8 n + 6) bits
+    if (fs == FEC_REP3) return 3 * n;
+    if (fs == FEC_REP5) return 5 * n;
+    if (fs == FEC_HAMMING74) return (14 * n + 7) / 8;        // liquid fec_block_get_enc_msg_len(n, 4, 7)
+    if (fs == FEC_HAMMING84) return 2 * n;
     return n;
 }
+// liquid packetizer.c: every stage but an uncoded one is followed by the four-pass interleaver
+inline unsigned fec_il_depth(int fs) { return (fs == FEC_NONE || fs == FEC_UNKNOWN) ? 0u : 4u; }
 inline unsigned packet_enc_len(unsigned n, int crc, int fec0, int fec1)
 { return fec_enc_len(fec1, fec_enc_len(fec0, n + (crc == CRC_32 ? 4 : 0))); }
 inline unsigned mod_bps(int mod)

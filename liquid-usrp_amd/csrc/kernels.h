@@ -71,7 +71,7 @@ struct SyncConsts {
     uint32_t crc_pos_n;
     // de-interleaver as one gather (decode_kernel): the four passes of liquid's packet interleaver are a fixed permutation of
     // the soft bits for a given coded length e -- soft bit kb of coded byte i comes from bit kb of coded byte il_map[8 (il_off[e] + i) + kb];
-    // il_off[e] = ~0: no map for that length (the passes run in LDS as before).  Built once per handle on the device.
+    // il_off[e] = ~0: no map for that length (the passes run in LDS as before).  One copy per device, shared (mcrx_hip.hip: il_tables_acquire).
     const uint32_t *il_off;     // [il_n]
     const uint16_t *il_map;
     uint32_t il_n;

@@ -3,6 +3,7 @@
 // harvesting.  Host code only; the kernels live in channelizer.hip / ofdmsync.hip.
 #include "../../include/mcrx_hip.h"
 #include "design.hpp"
+#include "devel.h"
 #include "devmath.h"
 #include "kernels.h"
 #include "txcode.hpp"
@@ -185,7 +186,7 @@ struct mcrx_hip_s {
     bool spec = false;
     uint32_t *h_hint = nullptr, *d_hint = nullptr;     // pinned, device-mapped: longest coded frame of the last launch
     uint8_t *d_jsoft[MCRX_SLOTS] = {}, *d_jtmp[MCRX_SLOTS] = {};
-    bool scout = true, scout_tables = true;
+    bool scout = true, scout_tables = true, il_tried = false;
     uint32_t nseg_fixed = 0, seg_frames = 4; float frames_per_push = 0.f; uint64_t last_nsamp = 0;      // segment-parallel acquisition: launch_sync
     bool cadenced = true; uint32_t cad_same = 0, cad_frames = 0; int cad_count = 0;                       // ... its anchor phase
     // scouts of the acquisition rounds: 1 = the lean scout's unbudgeted build (sync_walk_kernel: 256 + 40 registers, no spills), 0 = the
@@ -269,6 +270,76 @@ struct mcrx_hip_s {
 
 static unsigned pow2ceil(unsigned v) { unsigned p = 1; while (p < v) p <<= 1; return p; }
 
+// De-interleaver gather tables (SyncConsts::il_map) for every coded length the LDS decode path can meet: CRC-32 + outer
+// Hamming(12,8), Golay(24,12) or the K = 7 convolutional code, no inner code, payloads up to the handle's limit, coded frames up to
+// the 56 KiB of soft bits a workgroup stages.  16 bytes per coded byte and length (40 MB at 1200-byte payloads, 120 MB at the
+// default 2048), built on the device by pushing indices through the inverse interleaver (ofdmsync.hip: ilmap_build_kernel).
+// They depend on (payload limit, staging cap) only, so there is ONE copy per device and process, shared by every handle with those
+// limits and reference counted (ADVICE r3 / VERDICT r4 #8: every handle -- single-channel ofdmtxrx ones included -- used to build
+// its own at creation behind a hipDeviceSynchronize, and leaked the scratch on a failing call).  Built on a stream of its own.
+struct IlShared { int dev; uint32_t max_payload, cap; uint16_t *d_map; uint32_t *d_off; uint32_t n; int refs; };
+static std::mutex g_il_mu;
+static std::vector<IlShared> g_il;
+
+static int il_tables_acquire(uint32_t max_payload, uint32_t max_enc, const uint16_t **map, const uint32_t **off, uint32_t *n)
+{
+    *map = nullptr; *off = nullptr; *n = 0;
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    const uint32_t cap = std::min<uint32_t>(max_enc, 56u * 1024u / 8u);
+    std::lock_guard<std::mutex> lk(g_il_mu);
+    for (auto &t : g_il)
+        if (t.dev == dev && t.max_payload == max_payload && t.cap == cap) { t.refs++; *map = t.d_map; *off = t.d_off; *n = t.n; return MCRX_OK; }
+    std::vector<uint32_t> offv(cap + 1, ~0u), lens, offs;
+    uint64_t total = 0;
+    static const int outer[3] = { FEC_HAMMING128, FEC_GOLAY2412, FEC_CONV_V27 };
+    for (int oc = 0; oc < 3; oc++)
+        for (uint32_t np = 0; np <= max_payload; np++) {
+            const uint32_t e = packet_enc_len(np, CRC_32, FEC_NONE, outer[oc]);
+            if (e == 0 || e > cap || offv[e] != ~0u || e >= 65536u) continue;
+            offv[e] = (uint32_t)total; lens.push_back(e); offs.push_back((uint32_t)total); total += e;
+        }
+    if (lens.empty() || total * 8 >= (1ull << 32)) return MCRX_OK;           // (no table: the decoder's in-place passes serve every length)
+    uint16_t *d_map = nullptr; uint8_t *d_lo = nullptr, *d_hi = nullptr; uint32_t *d_lens = nullptr, *d_offs = nullptr, *d_off = nullptr;
+    hipStream_t st = nullptr;
+    hipError_t e = hipSuccess;
+    auto step = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
+    if (step(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) &&
+        step(hipMalloc((void **)&d_map, (size_t)total * 8 * sizeof(uint16_t))) &&
+        step(hipMalloc((void **)&d_lo, (size_t)total * 8)) && step(hipMalloc((void **)&d_hi, (size_t)total * 8)) &&
+        step(hipMalloc((void **)&d_lens, lens.size() * sizeof(uint32_t))) && step(hipMalloc((void **)&d_offs, offs.size() * sizeof(uint32_t))) &&
+        step(hipMalloc((void **)&d_off, offv.size() * sizeof(uint32_t))) &&
+        step(hipMemcpyAsync(d_lens, lens.data(), lens.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st)) &&
+        step(hipMemcpyAsync(d_offs, offs.data(), offs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st)) &&
+        step(hipMemcpyAsync(d_off, offv.data(), offv.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st)) &&
+        step(ilmap_build_launch(d_lens, d_offs, (uint32_t)lens.size(), d_lo, d_hi, d_map, st)))
+        step(hipStreamSynchronize(st));
+    // scratch goes whatever happened; the tables stay only on success
+    if (d_lo) (void)hipFree(d_lo);
+    if (d_hi) (void)hipFree(d_hi);
+    if (d_lens) (void)hipFree(d_lens);
+    if (d_offs) (void)hipFree(d_offs);
+    if (st) (void)hipStreamDestroy(st);
+    if (e != hipSuccess) {
+        if (d_map) (void)hipFree(d_map);
+        if (d_off) (void)hipFree(d_off);
+        return fail(MCRX_EHIP, hipGetErrorString(e));
+    }
+    g_il.push_back(IlShared{ dev, max_payload, cap, d_map, d_off, cap + 1, 1 });
+    *map = d_map; *off = d_off; *n = cap + 1;
+    return MCRX_OK;
+}
+static void il_tables_release(const uint16_t *map)
+{
+    if (!map) return;
+    std::lock_guard<std::mutex> lk(g_il_mu);
+    for (size_t i = 0; i < g_il.size(); i++)
+        if (g_il[i].d_map == map) {
+            if (--g_il[i].refs == 0) { (void)hipFree(g_il[i].d_map); (void)hipFree(g_il[i].d_off); g_il.erase(g_il.begin() + (long)i); }
+            return;
+        }
+}
+
 static int build_tables(mcrx_hip_t q)
 {
     const OfdmDesign &od = q->od;
@@ -332,34 +403,9 @@ static int build_tables(mcrx_hip_t q)
         c.crc_pos_n = q->max_payload;
     }
     c.payload_soft = q->cfg.payload_soft ? 1 : 0;
-    // De-interleaver gather tables (SyncConsts::il_map) for every coded length the LDS decode path can meet: CRC-32 + outer
-    // Hamming(12,8) or Golay(24,12), no inner code, payloads up to the handle's limit, coded frames up to the 56 KiB of soft bits
-    // a workgroup stages.  16 bytes per coded byte and length: 40 MB at 1200-byte payloads, 120 MB at the default 2048; built on
-    // the device by pushing indices through the inverse interleaver (ofdmsync.hip: ilmap_build_kernel).  MCRX_NO_ILMAP=1: none.
+    // De-interleaver gather tables (SyncConsts::il_map): shared per device, built when the handle first runs its synchronizers
+    // (il_tables_acquire, launch_sync) -- a handle that is created and never fed pays nothing for them.
     c.il_off = nullptr; c.il_map = nullptr; c.il_n = 0;
-    if (q->scout_tables && getenv("MCRX_NO_ILMAP") == nullptr) {
-        const uint32_t cap = std::min<uint32_t>(q->max_enc, 56u * 1024u / 8u);
-        std::vector<uint32_t> off(cap + 1, ~0u), lens, offs;
-        uint64_t total = 0;
-        static const int outer[3] = { 6, 7, 11 };       // Hamming(12,8), Golay(24,12), r = 1/2 K = 7 convolutional
-        for (int oc = 0; oc < 3; oc++)
-            for (uint32_t n = 0; n <= q->max_payload; n++) {
-                const uint32_t e = packet_enc_len(n, CRC_32, 1, outer[oc]);
-                if (e == 0 || e > cap || off[e] != ~0u || e >= 65536u) continue;
-                off[e] = (uint32_t)total; lens.push_back(e); offs.push_back((uint32_t)total); total += e;
-            }
-        if (!lens.empty() && total * 8 < (1ull << 32)) {
-            uint16_t *d_map = nullptr; uint8_t *d_lo = nullptr, *d_hi = nullptr; const uint32_t *d_lens = nullptr, *d_offs = nullptr;
-            RC(q->alloc(&d_map, (size_t)total * 8));
-            HIPCHK(hipMalloc((void **)&d_lo, (size_t)total * 8)); HIPCHK(hipMalloc((void **)&d_hi, (size_t)total * 8));
-            RC(q->upload(&d_lens, lens.data(), lens.size())); RC(q->upload(&d_offs, offs.data(), offs.size()));
-            HIPCHK(ilmap_build_launch(d_lens, d_offs, (uint32_t)lens.size(), d_lo, d_hi, d_map, nullptr));
-            HIPCHK(hipDeviceSynchronize());
-            (void)hipFree(d_lo); (void)hipFree(d_hi);
-            RC(q->upload(&c.il_off, off.data(), off.size()));
-            c.il_map = d_map; c.il_n = cap + 1;
-        }
-    }
     return MCRX_OK;
 }
 
@@ -461,7 +507,7 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     q->arena_cap = (uint64_t)q->max_rec * (((uint64_t)q->max_payload + 15) & ~15ull);
     q->sarena_cap = (uint64_t)q->max_rec * (8ull * 8ull * (2ull * (q->max_payload + 4) + 8));
     if (q->sarena_cap > (8ull << 30)) q->sarena_cap = 8ull << 30;
-    q->pipelined = !(q->cfg.struct_size >= offsetof(mcrx_hip_config, serial) + sizeof(uint32_t) && q->cfg.serial) && getenv("MCRX_SERIAL") == nullptr;
+    q->pipelined = !(q->cfg.struct_size >= offsetof(mcrx_hip_config, serial) + sizeof(uint32_t) && q->cfg.serial) && devel_env("MCRX_SERIAL") == nullptr;
     q->slab_blocks = q->cfg.slab_blocks ? ((q->cfg.slab_blocks + MCRX_TILE - 1) & ~(uint32_t)(MCRX_TILE - 1)) : 0;      // 0: sized per launch; slabs are whole tiles
     { int dev = 0, n = 0;
       if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
@@ -476,7 +522,7 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     q->hist_tiles = (unsigned)((q->defer + M + cp + 8 + MCRX_TILE - 1) / MCRX_TILE + 1);
 
     auto bail = [&](int rc) { mcrx_hip_destroy(q); return rc; };
-    int rc;
+    int rc; bool no_spec_cfg = false;
     if ((rc = q->upload(&q->d_taps, q->taps.data(), q->taps.size()))) return bail(rc);
     if ((rc = build_tables(q))) return bail(rc);
     if (q->oversampled) {
@@ -505,18 +551,28 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
         if (hipEventCreateWithFlags(&q->ev_gen[g], hipEventDisableTiming) != hipSuccess) return bail(fail(MCRX_EHIP, "hipEventCreate failed"));
         if (hipEventCreateWithFlags(&q->ev_clean[g], hipEventDisableTiming) != hipSuccess) return bail(fail(MCRX_EHIP, "hipEventCreate failed"));
     }
-    q->scout = getenv("MCRX_NO_SCOUT") == nullptr;
+    q->scout = devel_env("MCRX_NO_SCOUT") == nullptr;
     q->debug = getenv("MCRX_DEBUG") ? atoi(getenv("MCRX_DEBUG")) : 0;
-    q->no_fast = getenv("MCRX_NO_FAST") ? atoi(getenv("MCRX_NO_FAST")) : 0;
-    q->free_run = getenv("MCRX_FREE_RUN") != nullptr;
-    if (getenv("MCRX_PAYLOAD_FR")) q->payload_fr = atoi(getenv("MCRX_PAYLOAD_FR"));
-    if (getenv("MCRX_PAYLOAD_LEAN")) q->payload_lean = atoi(getenv("MCRX_PAYLOAD_LEAN")) != 0;
-    if (getenv("MCRX_PAYLOAD_XB")) q->payload_xb = atoi(getenv("MCRX_PAYLOAD_XB"));
-    if (getenv("MCRX_SEEK_BURST")) q->seek_burst = atoi(getenv("MCRX_SEEK_BURST"));
-    if (getenv("MCRX_ACQ_MODE")) q->acq_mode = atoi(getenv("MCRX_ACQ_MODE"));
-    if (getenv("MCRX_WALK_LDS_PAD")) q->walk_lds_pad = (uint32_t)atoi(getenv("MCRX_WALK_LDS_PAD"));
-    if (getenv("MCRX_PAYLOAD_LDS_PAD")) q->round_lds_pad = (uint32_t)atoi(getenv("MCRX_PAYLOAD_LDS_PAD"));
-    if (getenv("MCRX_SLOTS")) q->nslots = (unsigned)std::max(2, std::min(MCRX_SLOTS, atoi(getenv("MCRX_SLOTS"))));
+    q->no_fast = devel_env("MCRX_NO_FAST") ? atoi(devel_env("MCRX_NO_FAST")) : 0;
+    q->free_run = devel_env("MCRX_FREE_RUN") != nullptr;
+    {   // mcrx_hip_config::worker_build / acquisition / scout_build (fields past the caller's struct_size read as 0 = default)
+        auto field = [&](size_t off) { return q->cfg.struct_size >= off + sizeof(uint32_t) ? *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(&q->cfg) + off) : 0u; };
+        const uint32_t wb = field(offsetof(mcrx_hip_config, worker_build)), aq = field(offsetof(mcrx_hip_config, acquisition));
+        if (wb > 5 || aq > 4) return bail(fail(MCRX_EINVAL, "worker_build / acquisition out of range"));
+        if (wb == 1) q->payload_xb = 0;
+        if (wb >= 2) { q->payload_lean = 0; q->payload_fr = wb == 2 ? 1 : wb == 3 ? 2 : wb == 4 ? 4 : 0; }
+        if (aq >= 1 && aq <= 3) q->acq_mode = (int)aq;
+        no_spec_cfg = aq == 4;
+        if (field(offsetof(mcrx_hip_config, scout_build)) == 1) q->lean_build = 0;
+    }
+    if (devel_env("MCRX_PAYLOAD_FR")) q->payload_fr = atoi(devel_env("MCRX_PAYLOAD_FR"));
+    if (devel_env("MCRX_PAYLOAD_LEAN")) q->payload_lean = atoi(devel_env("MCRX_PAYLOAD_LEAN")) != 0;
+    if (devel_env("MCRX_PAYLOAD_XB")) q->payload_xb = atoi(devel_env("MCRX_PAYLOAD_XB"));
+    if (devel_env("MCRX_SEEK_BURST")) q->seek_burst = atoi(devel_env("MCRX_SEEK_BURST"));
+    if (devel_env("MCRX_ACQ_MODE")) q->acq_mode = atoi(devel_env("MCRX_ACQ_MODE"));
+    if (devel_env("MCRX_WALK_LDS_PAD")) q->walk_lds_pad = (uint32_t)atoi(devel_env("MCRX_WALK_LDS_PAD"));
+    if (devel_env("MCRX_PAYLOAD_LDS_PAD")) q->round_lds_pad = (uint32_t)atoi(devel_env("MCRX_PAYLOAD_LDS_PAD"));
+    if (devel_env("MCRX_SLOTS")) q->nslots = (unsigned)std::max(2, std::min(MCRX_SLOTS, atoi(devel_env("MCRX_SLOTS"))));
     if (!q->pipelined) q->nslots = 2;
     if ((rc = q->alloc(&q->d_njobs, MCRX_SLOTS))) return bail(rc);      // one counter per slot: a launch's placement kernel zeroes the next slot's
     if ((rc = q->alloc(&q->d_stats, 8))) return bail(rc);
@@ -542,10 +598,10 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
         }
         // speculative acquisition (lean path only): slots, their equalisers, the prediction lists
         const bool lean = q->sc.log2M >= 6 && q->sc.M == 64 * q->sc.E && q->sc.M_pilot <= 64;
-        q->spec = lean && q->d_hint && getenv("MCRX_NO_SPEC") == nullptr;
-        if (getenv("MCRX_NSEG")) q->nseg_fixed = (uint32_t)std::max(1, std::min(MCRX_SEG_MAX, atoi(getenv("MCRX_NSEG"))));           // experiments: segments per channel, fixed
-        if (getenv("MCRX_SEG_FRAMES")) q->seg_frames = (uint32_t)std::max(1, std::min(64, atoi(getenv("MCRX_SEG_FRAMES"))));            // ... or frames per segment aimed at
-        if (getenv("MCRX_LEAN_BUILD")) q->lean_build = atoi(getenv("MCRX_LEAN_BUILD"));
+        q->spec = lean && q->d_hint && !no_spec_cfg && devel_env("MCRX_NO_SPEC") == nullptr;
+        if (devel_env("MCRX_NSEG")) q->nseg_fixed = (uint32_t)std::max(1, std::min(MCRX_SEG_MAX, atoi(devel_env("MCRX_NSEG"))));           // experiments: segments per channel, fixed
+        if (devel_env("MCRX_SEG_FRAMES")) q->seg_frames = (uint32_t)std::max(1, std::min(64, atoi(devel_env("MCRX_SEG_FRAMES"))));            // ... or frames per segment aimed at
+        if (devel_env("MCRX_LEAN_BUILD")) q->lean_build = atoi(devel_env("MCRX_LEAN_BUILD"));
         if (q->spec) {
             if ((rc = q->alloc(&q->d_spec, (size_t)q->nch * MCRX_SPEC_MAX))) return bail(rc);
             if ((rc = q->alloc(&q->d_spec_R, (size_t)q->nch * MCRX_SEG_MAX * M))) return bail(rc);
@@ -566,7 +622,7 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     if (hipStreamCreate(&q->stream) != hipSuccess) return bail(fail(MCRX_EHIP, "hipStreamCreate failed"));
     {   // the acquisition stream carries the serial per-channel chains every payload launch waits for: highest priority
         int least = 0, greatest = 0;
-        const bool prio = getenv("MCRX_NO_PRIO") == nullptr && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least;
+        const bool prio = devel_env("MCRX_NO_PRIO") == nullptr && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least;
         if ((prio ? hipStreamCreateWithPriority(&q->s_scout, hipStreamDefault, greatest) : hipStreamCreate(&q->s_scout)) != hipSuccess)
             return bail(fail(MCRX_EHIP, "hipStreamCreate failed"));
     }
@@ -602,6 +658,7 @@ extern "C" int mcrx_hip_destroy(mcrx_hip_t q)
         fprintf(stderr, "mcrx stats: walked %u adopted %u last failed crc: key %08x computed %08x\n", v[0], v[1], v[2], v[3]);
     }
     for (void *p : q->owned) (void)hipFree(p);
+    il_tables_release(q->sc.il_map);
     for (int i = 0; i < MCRX_SLOTS; i++) if (q->d_chan[i]) (void)hipFree(q->d_chan[i]);
     for (int i = 0; i < 2; i++) { if (q->d_pfin[i]) (void)hipFree(q->d_pfin[i]); if (q->d_pfout[i]) (void)hipFree(q->d_pfout[i]); }
     if (q->pfb2) (void)mcrx_hip_pfb2_destroy(q->pfb2);
@@ -667,6 +724,11 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
 {
     const unsigned slot = (unsigned)(q->seq % q->nslots), next = (unsigned)((q->seq + 1) % q->nslots);
     const int g = q->gen;
+    if (!q->il_tried) {                    // first synchronizer launch of this handle: the device's shared de-interleaver tables
+        q->il_tried = true;
+        if (q->scout_tables && devel_env("MCRX_NO_ILMAP") == nullptr)
+            RC(il_tables_acquire(q->max_payload, q->max_enc, &q->sc.il_map, &q->sc.il_off, &q->sc.il_n));
+    }
     SyncArgs a;
     a.c = q->sc; a.chan = chan; a.chan_stride = stride; a.chan_off = off;
     a.buf_first = buf_first; a.end = end; a.nch = q->nch; a.ch_first = q->ch_first;
@@ -1245,7 +1307,7 @@ extern "C" int mcrx_hip_poll(mcrx_hip_t q)
     // launches of two pushes ago while the device has the last two queued.  (Collecting the previous poll's generation left the
     // device with ONE push in flight while the host waited, copied and sorted: consecutive pushes no longer overlapped, 0.82 x value.)
     const double t0 = now_s();
-    static const int keep = getenv("MCRX_POLL_KEEP") ? std::max(0, std::min(MCRX_GENS - 2, atoi(getenv("MCRX_POLL_KEEP")))) : 1;
+    static const int keep = devel_env("MCRX_POLL_KEEP") ? std::max(0, std::min(MCRX_GENS - 2, atoi(devel_env("MCRX_POLL_KEEP")))) : 1;
     const int rc = collect_closed(q, keep);
     if (rc == MCRX_OK || rc == MCRX_EOVERFLOW) close_generation(q);
     q->pending_bound = record_bound(q, 0);

@@ -57,8 +57,16 @@ __device__ __forceinline__ unsigned fec_enc_len_d(unsigned fs, unsigned n)
     if (fs == 6) return (n / 2) * 3 + (n % 2) * 2;      // Hamming(12,8)
     if (fs == 7) return (n / 3) * 6 + (n % 3) * 3;      // Golay(24,12)
     if (fs == 11) return 2 * n + 2;                     // r = 1/2, K = 7 convolutional: 2 (8 n + 6) bits
+    if (fs == 2) return 3 * n;                          // rep3
+    if (fs == 3) return 5 * n;                          // rep5
+    if (fs == 4) return (14 * n + 7) / 8;               // Hamming(7,4): two 7-bit symbols per byte, bit-packed
+    if (fs == 5) return 2 * n;                          // Hamming(8,4)
     return n;
 }
+// liquid's fec_scheme ids this receiver decodes: none, rep3, rep5, h74, h84, h128, g2412 (1..7) and v27 (11)
+__device__ __forceinline__ bool fec_known_d(unsigned fs) { return (fs >= 1 && fs <= 7) || fs == 11; }
+// packetizer.c: every coded stage is followed by the four-pass interleaver
+__device__ __forceinline__ unsigned fec_depth_d(unsigned fs) { return fs == 1 ? 0u : 4u; }
 __device__ __forceinline__ unsigned mod_bps_d(unsigned m)
 { return m == 39 ? 1u : m == 40 ? 2u : m == 27 ? 4u : m == 29 ? 6u : 0u; }
 
@@ -475,6 +483,13 @@ __device__ void conv27_decode_block(const VitSym sy, unsigned n_, unsigned b_, u
     }
 }
 
+// Hamming(7,4) codeword p1 p2 d1 p4 d2 d3 d4 (MSB first); Hamming(8,4) = the same with the overall parity as the LSB
+__device__ __forceinline__ unsigned hsmall_enc_d(unsigned s, unsigned nb)
+{
+    const unsigned d1 = (s >> 3) & 1, d2 = (s >> 2) & 1, d3 = (s >> 1) & 1, d4 = s & 1;
+    const unsigned c = ((d1 ^ d2 ^ d4) << 6) | ((d1 ^ d3 ^ d4) << 5) | (d1 << 4) | ((d2 ^ d3 ^ d4) << 3) | (d2 << 2) | (d3 << 1) | d4;
+    return nb == 7 ? c : ((c << 1) | ((unsigned)__popc(c) & 1u));
+}
 // hard decode `enc` -> `dec` (dec_len bytes), lanes in parallel
 __device__ void fec_decode_hard(unsigned fs, unsigned n, const uint8_t *enc, uint8_t *dec)
 {
@@ -500,8 +515,85 @@ __device__ void fec_decode_hard(unsigned fs, unsigned n, const uint8_t *enc, uin
             const uint8_t *e = enc + 6 * G + 3 * l;
             dec[3 * G + l] = (uint8_t)(golay_dec_sym(((unsigned)e[0] << 16) | ((unsigned)e[1] << 8) | e[2]) & 0xff);
         }
+    } else if (fs == 2) {                                   // rep3: bitwise majority of the three copies
+        for (unsigned i = (unsigned)l; i < n; i += WV) {
+            const unsigned s0 = enc[i], s1 = enc[i + n], s2 = enc[i + 2 * n];
+            dec[i] = (uint8_t)((s0 & s1) | (s0 & s2) | (s1 & s2));
+        }
+    } else if (fs == 3) {                                   // rep5: bitwise majority of five (bit-sliced 3-bit counter)
+        for (unsigned i = (unsigned)l; i < n; i += WV) {
+            unsigned c0 = 0, c1 = 0, c2 = 0;
+#pragma unroll
+            for (unsigned r = 0; r < 5; r++) {
+                const unsigned v = enc[i + r * n], k0 = c0 & v;
+                c0 ^= v; const unsigned k1 = c1 & k0; c1 ^= k0; c2 |= k1;
+            }
+            dec[i] = (uint8_t)(c2 | (c1 & c0));                 // count >= 3: 4 or 5 (c2), or 3 (c1 & c0)
+        }
+    } else if (fs == 4 || fs == 5) {                        // Hamming(7,4) / (8,4): nearest codeword, symbols ascending, strict <
+        const unsigned nb = fs == 4 ? 7u : 8u;
+        for (unsigned i = (unsigned)l; i < n; i += WV) {
+            unsigned by = 0;
+#pragma unroll
+            for (unsigned h = 0; h < 2; h++) {
+                const unsigned k = 2 * nb * i + nb * h;             // bit index of the symbol, MSB first
+                const unsigned w16 = ((unsigned)enc[k >> 3] << 8) | ((k >> 3) + 1 < fec_enc_len_d(fs, n) ? (unsigned)enc[(k >> 3) + 1] : 0u);
+                const unsigned w = (w16 >> (16 - nb - (k & 7))) & ((1u << nb) - 1u);
+                unsigned best = 0, dmin = 99;
+#pragma unroll
+                for (unsigned sy = 0; sy < 16; sy++) {
+                    const unsigned d = (unsigned)__popc(w ^ hsmall_enc_d(sy, nb));
+                    if (d < dmin) { dmin = d; best = sy; }
+                }
+                by = (by << 4) | best;
+            }
+            dec[i] = (uint8_t)by;
+        }
     } else {
         for (unsigned i = (unsigned)l; i < n; i += WV) dec[i] = enc[i];
+    }
+    __syncthreads();
+}
+// soft decision for the short block codes (liquid fec_rep3_decode_soft / fec_rep5_decode_soft / fec_hamming74_decode_soft /
+// fec_hamming84_decode_soft): `soft` = 8 soft bits per coded byte, de-interleaved; lanes in parallel over the message bytes
+__device__ void fec_decode_soft_small(unsigned fs, unsigned n, const uint8_t *soft, uint8_t *dec)
+{
+    const int l = lane_id();
+    if (fs == 2 || fs == 3) {                               // mean of the copies (integer division) against the erasure level 127
+        const unsigned R = fs == 2 ? 3u : 5u;
+        for (unsigned i = (unsigned)l; i < n; i += WV) {
+            unsigned b = 0;
+#pragma unroll
+            for (unsigned k = 0; k < 8; k++) {
+                unsigned sum = 0;
+                for (unsigned r = 0; r < R; r++) sum += soft[8 * ((size_t)i + (size_t)r * n) + k];
+                b = (b << 1) | ((sum / R) > 127u ? 1u : 0u);
+            }
+            dec[i] = (uint8_t)b;
+        }
+    } else {                                                // least soft distance over all 16 codewords, ascending, strict <
+        const unsigned nb = fs == 4 ? 7u : 8u;
+        for (unsigned i = (unsigned)l; i < n; i += WV) {
+            unsigned by = 0;
+#pragma unroll
+            for (unsigned h = 0; h < 2; h++) {
+                const uint8_t *sb = soft + 2 * (size_t)nb * i + nb * h;
+                unsigned v[8];
+#pragma unroll
+                for (unsigned k = 0; k < 8; k++) v[k] = k < nb ? (unsigned)sb[k] : 0u;
+                unsigned best = 0, dmin = 0;
+#pragma unroll
+                for (unsigned sy = 0; sy < 16; sy++) {
+                    const unsigned c = hsmall_enc_d(sy, nb);
+                    unsigned d = 0;
+#pragma unroll
+                    for (unsigned k = 0; k < 8; k++) if (k < nb) d += ((c >> (nb - 1 - k)) & 1u) ? 255u - v[k] : v[k];
+                    if (sy == 0 || d < dmin) { dmin = d; best = sy; }
+                }
+                by = (by << 4) | best;
+            }
+            dec[i] = (uint8_t)by;
+        }
     }
     __syncthreads();
 }
@@ -531,7 +623,7 @@ __device__ bool packet_decode(const CodingDev cod, bool soft_mode, bool scramble
     const unsigned crc_len = (crc == 6) ? 4u : 0u;
     const unsigned n0 = n_msg + crc_len;
     const unsigned e0 = fec_enc_len_d(fec0, n0), e1 = fec_enc_len_d(fec1, e0);
-    const unsigned d0 = (fec0 == 6 || fec0 == 7 || fec0 == 11) ? 4u : 0u, d1 = (fec1 == 6 || fec1 == 7 || fec1 == 11) ? 4u : 0u;
+    const unsigned d0 = fec_depth_d(fec0), d1 = fec_depth_d(fec1);
     if ((fec0 == 11 || fec1 == 11) && !vit_lds) return false;      // (every launch that can get here provides the scratch)
     if (soft_mode && fec1 == 6) {
         if (!(ablate & 8)) deinterleave<true>(soft, e1, d1);
@@ -543,6 +635,9 @@ __device__ bool packet_decode(const CodingDev cod, bool soft_mode, bool scramble
         if (!(ablate & 64)) deinterleave<true>(soft, e1, d1);
         if (!(ablate & 128)) conv27_decode_wave(VitSym{ soft, false }, e0, tmpa, reinterpret_cast<uint16_t *>(tmpb), vit_lds);   // checkpoints: 128 * ceil((8 e0 + 6) / 960) bytes <= max_enc_len + 16 (mcrx_hip_create keeps max_enc_len >= 256)
         __syncthreads();
+    } else if (soft_mode && fec1 >= 2 && fec1 <= 5) {
+        deinterleave<true>(soft, e1, d1);
+        fec_decode_soft_small(fec1, e0, soft, tmpa);
     } else {
         if (soft_mode) deinterleave<true>(soft, e1, d1);
         soft_pack(soft, e1, tmpb, scrambled);
@@ -1171,7 +1266,7 @@ struct Walker {
         const unsigned check = (hbyte(12) >> 5) & 7, fec0 = hbyte(12) & 0x1f, fec1 = hbyte(13) & 0x1f;
         const unsigned bps = mod_bps_d(mod);
         if (proto != 104 || bps == 0 || !(check == 1 || check == 6) ||
-            !(fec0 == 1 || fec0 == 6 || fec0 == 7 || fec0 == 11) || !(fec1 == 1 || fec1 == 6 || fec1 == 7 || fec1 == 11)) ok = false;
+            !fec_known_d(fec0) || !fec_known_d(fec1)) ok = false;
         s.header_valid = ok ? 1 : 0;
         if (ok) {
             s.payload_len = plen; s.mod_scheme = mod; s.bps = bps; s.check = check; s.fec0 = fec0; s.fec1 = fec1;
@@ -2899,7 +2994,26 @@ __device__ __forceinline__ void decode_frame(SyncArgs &a, const uint32_t j, uint
         // the decoded bytes waiting
         const uint32_t moff = (c.il_off && e1 < c.il_n) ? c.il_off[e1] : ~0u;
         const bool conv_pre = c.payload_soft && fec1 == 11 && a.vit_list && moff != ~0u && 8u * e1 <= lds_soft_bytes && !(a.no_fast & 8);
+        // The trellis blocks are reserved BEFORE the soft bits are touched (ADVICE r3 / VERDICT r4 #8): the gather below rewrites the
+        // frame's soft bits in place, so a frame that found the block list full must reach the general decoder untouched --
+        // it de-interleaves for itself.  A compare-and-swap loop: the counter only ever moves up, so a range is handed out once.
+        __shared__ uint32_t dk_vit_at;
+        const uint32_t vit_e0 = fec_enc_len_d(fec0, n0), vit_nblk = (8u * vit_e0 + 6u + VIT_B - 1u) / VIT_B;
         if (conv_pre) {
+            if (threadIdx.x == 0) {
+                uint32_t *vl = as_global(a.vit_list);
+                uint32_t seen = __atomic_load_n(vl, __ATOMIC_RELAXED), at = ~0u;
+                while (seen + vit_nblk <= a.vit_cap) {
+                    const uint32_t prev = atomicCAS(vl, seen, seen + vit_nblk);
+                    if (prev == seen) { at = seen; break; }
+                    seen = prev;
+                }
+                dk_vit_at = at;
+            }
+            __syncthreads();
+        }
+        const bool conv_go = conv_pre && dk_vit_at != ~0u;
+        if (conv_go) {
             const unsigned long long *g64 = reinterpret_cast<const unsigned long long *>(soft);
             for (uint32_t i = threadIdx.x; i < e1; i += DK_T) dk_soft[DKP(i)] = g64[i];
             __syncthreads();
@@ -2916,13 +3030,11 @@ __device__ __forceinline__ void decode_frame(SyncArgs &a, const uint32_t j, uint
         if (threadIdx.x == 0 && a.gen_list) {
             uint32_t *gl = as_global(a.gen_list);
             uint32_t tag = j;
-            if (conv_pre) {
-                const uint32_t e0 = fec_enc_len_d(fec0, n0), nblk = (8u * e0 + 6u + VIT_B - 1u) / VIT_B;
+            if (conv_go) {
                 uint32_t *vl = as_global(a.vit_list);
-                const uint32_t at = atomicAdd(vl, nblk);
-                if (at + nblk <= a.vit_cap) { for (uint32_t b = 0; b < nblk; b++) vl[1u + at + b] = (j << 6) | b; tag |= 0x80000000u; }
-                else atomicSub(vl, nblk);             // (list full: this frame's trellis stays with the general decoder's single wave)
-            }
+                for (uint32_t b = 0; b < vit_nblk; b++) vl[1u + dk_vit_at + b] = (j << 6) | b;
+                tag |= 0x80000000u;
+            }                                         // (list full: this frame's trellis stays with the general decoder's single wave)
             gl[1u + atomicAdd(gl, 1u)] = tag;
         }
         return;

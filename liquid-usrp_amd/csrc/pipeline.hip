@@ -15,6 +15,7 @@
 // the library has no link-time dependency on it and single-GPU users never touch it.  The caller distributes the 128-byte
 // ncclUniqueId of rank 0 (mcrx_hip_pipeline_unique_id) by whatever means it has (MPI, a file, torch.distributed).
 #include "../../include/mcrx_hip.h"
+#include "devel.h"
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <dlfcn.h>
@@ -150,7 +151,7 @@ extern "C" int mcrx_hip_pipeline_create(mcrx_hip_pipeline_t *out, mcrx_hip_t rx,
             hipEventCreateWithFlags(&p->evC[i], hipEventDisableTiming) != hipSuccess) return bail(pfail(MCRX_EHIP, "hipEventCreate failed"));
     }
     if (hipEventCreateWithFlags(&p->ev_after, hipEventDisableTiming) != hipSuccess) return bail(pfail(MCRX_EHIP, "hipEventCreate failed"));
-    {   const char *ev = getenv("MCRX_PIPE_STREAMS");           // experiments: 1 = one stream for all three stages, 3 = one each (rounds 2-3)
+    {   const char *ev = devel_env("MCRX_PIPE_STREAMS");           // experiments: 1 = one stream for all three stages, 3 = one each (rounds 2-3)
         const int ns = ev ? atoi(ev) : 2;
         if (hipStreamCreateWithFlags(&p->sA, hipStreamNonBlocking) != hipSuccess) return bail(pfail(MCRX_EHIP, "hipStreamCreate failed"));
         if (ns <= 1) p->sB = p->sA;

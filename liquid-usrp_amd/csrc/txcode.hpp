@@ -32,6 +32,14 @@ inline unsigned golay_encode(unsigned m)
     for (unsigned i = 0; i < 12; i++) if (m & (1u << (11 - i))) par ^= golay_P[i];
     return (par << 12) | m;
 }
+// liquid fec_hamming74.c / fec_hamming84.c: p1 p2 d1 p4 d2 d3 d4 (MSB first) [+ overall parity as the LSB]
+inline unsigned hamming74_encode(unsigned s)
+{
+    const unsigned d1 = (s >> 3) & 1, d2 = (s >> 2) & 1, d3 = (s >> 1) & 1, d4 = s & 1;
+    return ((d1 ^ d2 ^ d4) << 6) | ((d1 ^ d3 ^ d4) << 5) | (d1 << 4) | ((d2 ^ d3 ^ d4) << 3) | (d2 << 2) | (d3 << 1) | d4;
+}
+inline unsigned hamming84_encode(unsigned s)
+{ const unsigned c = hamming74_encode(s); unsigned p = c; p ^= p >> 4; p ^= p >> 2; p ^= p >> 1; return (c << 1) | (p & 1u); }
 inline void fec_encode(int fs, const std::vector<uint8_t> &dec, std::vector<uint8_t> &enc)
 {
     const size_t n = dec.size();
@@ -71,6 +79,15 @@ inline void fec_encode(int fs, const std::vector<uint8_t> &dec, std::vector<uint
             if (nb == 8) { enc[j++] = (uint8_t)acc; acc = 0; nb = 0; }
         }
         if (nb) enc[j++] = (uint8_t)(acc << (8 - nb));
+    } else if (fs == FEC_REP3 || fs == FEC_REP5) {
+        // liquid fec_rep3.c / fec_rep5.c: the whole message, three / five times in a row
+        for (size_t r = 0; r < (fs == FEC_REP3 ? 3u : 5u); r++) std::memcpy(enc.data() + r * n, dec.data(), n);
+    } else if (fs == FEC_HAMMING74) {
+        // two 7-bit symbols per byte (high nibble first), bit-packed back to back
+        auto put = [&](size_t k, unsigned v) { for (unsigned i = 0; i < 7; i++) if ((v >> (6 - i)) & 1u) enc[(k + i) >> 3] |= (uint8_t)(0x80u >> ((k + i) & 7)); };
+        for (size_t i = 0; i < n; i++) { put(14 * i, hamming74_encode(dec[i] >> 4)); put(14 * i + 7, hamming74_encode(dec[i] & 0x0f)); }
+    } else if (fs == FEC_HAMMING84) {
+        for (size_t i = 0; i < n; i++) { enc[2 * i] = (uint8_t)hamming84_encode(dec[i] >> 4); enc[2 * i + 1] = (uint8_t)hamming84_encode(dec[i] & 0x0f); }
     } else enc = dec;
 }
 // liquid's interleaver: pass = swap masked bits of x[2i] and x[2j+1], j(i) from the column walk
@@ -104,8 +121,8 @@ inline void packet_encode(const std::vector<uint8_t> &msg, int crc, int fec0, in
         uint32_t key = crc32_bytes(msg.data(), msg.size());
         b0.push_back((uint8_t)(key >> 24)); b0.push_back((uint8_t)(key >> 16)); b0.push_back((uint8_t)(key >> 8)); b0.push_back((uint8_t)key);
     }
-    fec_encode(fec0, b0, b1); interleave(b1, (fec0 == FEC_HAMMING128 || fec0 == FEC_GOLAY2412 || fec0 == FEC_CONV_V27) ? 4 : 0);
-    fec_encode(fec1, b1, b0); interleave(b0, (fec1 == FEC_HAMMING128 || fec1 == FEC_GOLAY2412 || fec1 == FEC_CONV_V27) ? 4 : 0);
+    fec_encode(fec0, b0, b1); interleave(b1, fec_il_depth(fec0));
+    fec_encode(fec1, b1, b0); interleave(b0, fec_il_depth(fec1));
     pkt.swap(b0);
 }
 

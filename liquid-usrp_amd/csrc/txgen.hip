@@ -15,6 +15,7 @@
 //                     (bK+i)*dtheta, soft gain.
 // Bit-level frame assembly (CRC/FEC/interleaver/scrambler) is host code: txcode.hpp.
 #include "../../include/mcrx_hip.h"
+#include "devel.h"
 #include "devmath.h"
 #include "txcode.hpp"
 #include <random>
@@ -654,7 +655,7 @@ static void frame_geometry(mctx_hip_t q, unsigned payload_len, int mod, int fec0
 
 extern "C" size_t mctx_hip_blocks_for(mctx_hip_t q, unsigned frames_per_channel, unsigned payload_len, int mod, int fec0, int fec1)
 {
-    if (!q || !mod_bps(mod)) return 0;
+    if (!q || !mod_bps(mod) || !fec_supported(fec0) || !fec_supported(fec1)) return 0;
     unsigned Sh, Sp, S; frame_geometry(q, payload_len, mod, fec0, fec1, Sh, Sp, S);
     size_t nb = (size_t)frames_per_channel * S * (q->M + q->cp) + 64;     // + idle tail for the filter to ring out
     return (nb + 15) / 16 * 16;     // whole receiver tiles (MCRX_TILE blocks), so that the stream can be pushed as it is
@@ -665,6 +666,7 @@ extern "C" int mctx_hip_generate(mctx_hip_t q, void *d_iq, size_t nblocks, unsig
                                  uint8_t *hdr_out, uint8_t *pay_out, void *stream)
 {
     if (!q || !d_iq || !mod_bps(mod)) { g_tx_err = "bad argument"; return MCRX_EINVAL; }
+    if (!fec_supported(fec0) || !fec_supported(fec1)) { g_tx_err = "unsupported fec scheme"; return MCRX_EUNSUPP; }
     hipStream_t st = (hipStream_t)stream;
     unsigned Sh, Sp, S; frame_geometry(q, payload_len, mod, fec0, fec1, Sh, Sp, S);
     const unsigned Md = q->od.M_data, N = q->N, M = q->M, K = q->K;
@@ -727,6 +729,7 @@ extern "C" int mctx_hip_generate_ragged(mctx_hip_t q, void *d_iq, size_t nblocks
                                         uint8_t *pay_out, uint64_t *start_out, void *stream)
 {
     if (!q || !d_iq || !mod_bps(mod) || len_hi < len_lo || !max_frames) { g_tx_err = "bad argument"; return MCRX_EINVAL; }
+    if (!fec_supported(fec0) || !fec_supported(fec1)) { g_tx_err = "unsupported fec scheme"; return MCRX_EUNSUPP; }
     if (q->M & (q->M - 1)) { g_tx_err = "ragged traffic needs a power-of-two subcarrier count"; return MCRX_EUNSUPP; }
     hipStream_t st = (hipStream_t)stream;
     const unsigned Md = q->od.M_data, N = q->N, M = q->M, K = q->K, L = M + q->cp;
@@ -821,6 +824,7 @@ extern "C" int mctx_hip_traffic_create(mctx_hip_t q, mctx_hip_traffic_t *out, un
                                        uint8_t *hdr_out, uint8_t *pay_out, void *stream)
 {
     if (!q || !out || !mod_bps(mod)) { g_tx_err = "bad argument"; return MCRX_EINVAL; }
+    if (!fec_supported(fec0) || !fec_supported(fec1)) { g_tx_err = "unsupported fec scheme"; return MCRX_EUNSUPP; }
     *out = nullptr;
     if (!ch_count || ch_first + ch_count > q->N || !frames) { g_tx_err = "channel shard outside the transmitter"; return MCRX_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
@@ -936,7 +940,7 @@ static int tx_launch_sym(mctx_hip_t q, const TxSymArgs &sa, unsigned nsym, unsig
         TXCHK(hipGetLastError());
         return MCRX_OK;
     }
-    static const bool wide = getenv("MCTX_TXSYM64") == nullptr || atoi(getenv("MCTX_TXSYM64")) != 0;      // (0: the one-point-per-lane kernel, comparisons)
+    static const bool wide = devel_env("MCTX_TXSYM64") == nullptr || atoi(devel_env("MCTX_TXSYM64")) != 0;      // (0: the one-point-per-lane kernel, comparisons)
     if (q->M == 64 && wide && (sa.xs_sym % 2) == 0 && (sa.xs_ch % 2) == 0) {
         hipLaunchKernelGGL(txsym64_kernel, gsym8, dim3(TXW), 0, st, sa, nsym);
         TXCHK(hipGetLastError());
@@ -972,7 +976,7 @@ static int tx_launch_ifft(mctx_hip_t q, const TxSynthArgs &ya, unsigned nblocks,
 // sharded forms -- else the two-kernel path through `v` (inverse-FFT outputs in HBM).  MCTX_SYNTH=0 forces the latter.
 static bool tx_fused_ok(mctx_hip_t q, const TxSynthArgs &ya)
 {
-    static const int env = getenv("MCTX_SYNTH") ? atoi(getenv("MCTX_SYNTH")) : 1;
+    static const int env = devel_env("MCTX_SYNTH") ? atoi(devel_env("MCTX_SYNTH")) : 1;
     return env != 0 && q->taps_symmetric && !ya.ft0 && ya.hist == 0 && (q->K == 128 || q->K == 256 || q->K == 512 || q->K == 1024) &&
            (ya.out_first % 8) == 0;
 }
@@ -1000,7 +1004,7 @@ static int tx_launch_fused(mctx_hip_t q, const TxSynthArgs &ya, hipStream_t st)
 {
     if (ya.tiles) return tx_launch_fused_in<KK, R, syn::SYN_TILES>(q, ya, st);
     if constexpr (R == 8) {
-        static const int al = getenv("MCTX_ALIGNED") ? atoi(getenv("MCTX_ALIGNED")) : 1;
+        static const int al = devel_env("MCTX_ALIGNED") ? atoi(devel_env("MCTX_ALIGNED")) : 1;
         if (al && syn::syn_aligned(ya)) return tx_launch_fused_in<KK, 8, syn::SYN_SYMS>(q, ya, st);
     }
     return tx_launch_fused_in<KK, R, syn::SYN_WALK>(q, ya, st);
@@ -1011,8 +1015,8 @@ static int tx_synthesize(mctx_hip_t q, const TxSynthArgs &ya, hipStream_t st)
         switch (q->K) {
         case 128: return tx_launch_fused<128, 4>(q, ya, st);
         case 256: return tx_launch_fused<256, 4>(q, ya, st);
-        case 512: { static const int r8 = getenv("MCTX_R8") ? atoi(getenv("MCTX_R8")) : 1; return r8 ? tx_launch_fused<512, 8>(q, ya, st) : tx_launch_fused<512, 4>(q, ya, st); }
-        default:  { static const int r8 = getenv("MCTX_R8") ? atoi(getenv("MCTX_R8")) : 1; return r8 ? tx_launch_fused<1024, 8>(q, ya, st) : tx_launch_fused<1024, 4>(q, ya, st); }
+        case 512: { static const int r8 = devel_env("MCTX_R8") ? atoi(devel_env("MCTX_R8")) : 1; return r8 ? tx_launch_fused<512, 8>(q, ya, st) : tx_launch_fused<512, 4>(q, ya, st); }
+        default:  { static const int r8 = devel_env("MCTX_R8") ? atoi(devel_env("MCTX_R8")) : 1; return r8 ? tx_launch_fused<1024, 8>(q, ya, st) : tx_launch_fused<1024, 4>(q, ya, st); }
         }
     }
     if (!ya.v) { g_tx_err = "two-kernel synthesis needs its inverse-FFT buffer"; return MCRX_EINVAL; }
@@ -1094,6 +1098,7 @@ extern "C" int mctx_hip_stream_update(mctx_hip_t q, unsigned ch, const uint8_t *
     if (!q || !q->st_on || !header8 || (!payload && payload_len)) { g_tx_err = "bad argument"; return MCRX_EINVAL; }
     if (ch >= q->N) { g_tx_err = "error: multichanneltx::UpdateData(), invalid channel id"; return MCRX_EINVAL; }
     if (!mod_bps(mod)) { g_tx_err = "unsupported modulation scheme"; return MCRX_EUNSUPP; }
+    if (!fec_supported(fec0) || !fec_supported(fec1)) { g_tx_err = "unsupported fec scheme"; return MCRX_EUNSUPP; }
     if (q->assembled[ch]) { g_tx_err = "warning: multichanneltx::UpdateData(), channel busy"; return MCRX_EBUSY; }
     const unsigned M = q->M, Md = q->od.M_data;
     unsigned Sh, Sp, S; frame_geometry(q, payload_len, mod, fec0, fec1, Sh, Sp, S);
@@ -1167,7 +1172,7 @@ extern "C" int mctx_hip_stream_generate(mctx_hip_t q, float *out)
 // 385-388): S0a, S0b, S1, header symbols, payload symbols and the tail symbol, M + cp samples each.
 extern "C" size_t mctx_hip_frame_len(mctx_hip_t q, unsigned payload_len, int mod, int fec0, int fec1)
 {
-    if (!q || !mod_bps(mod)) return 0;
+    if (!q || !mod_bps(mod) || !fec_supported(fec0) || !fec_supported(fec1)) return 0;
     unsigned Sh, Sp, S; frame_geometry(q, payload_len, mod, fec0, fec1, Sh, Sp, S);
     return (size_t)S * (q->M + q->cp);
 }
@@ -1177,6 +1182,7 @@ extern "C" int mctx_hip_frame(mctx_hip_t q, const uint8_t *header8, const uint8_
 {
     if (!q || !header8 || (!payload && payload_len) || !out) { g_tx_err = "bad argument"; return MCRX_EINVAL; }
     if (!mod_bps(mod)) { g_tx_err = "unsupported modulation scheme"; return MCRX_EUNSUPP; }
+    if (!fec_supported(fec0) || !fec_supported(fec1)) { g_tx_err = "unsupported fec scheme"; return MCRX_EUNSUPP; }
     const unsigned M = q->M, Md = q->od.M_data, L = M + q->cp;
     unsigned Sh, Sp, S; frame_geometry(q, payload_len, mod, fec0, fec1, Sh, Sp, S);
     const size_t ns = (size_t)S * L;

@@ -86,7 +86,7 @@ class Pipeline(object):
     Tensors are complex64 on the backend's device (CUDA: three torch streams; CPU/gloo: everything in order).
     """
 
-    def __init__(self, backend, rank, world, dist, num_channels, sub_blocks, hist_tiles, device=None, nbuf=3):
+    def __init__(self, backend, rank, world, dist, num_channels, sub_blocks, hist_tiles, device=None, nbuf=3, streams=2):
         import torch
         assert sub_blocks % TILE == 0 and num_channels % world == 0
         self.be, self.rank, self.world, self.dist = backend, rank, world, dist
@@ -109,7 +109,7 @@ class Pipeline(object):
         self.time_exchange = False                  # bench.py: HIP events around every exchange (exchange_ms)
         self._xev = []
         if self.cuda:
-            nstr = int(__import__("os").environ.get("MCRX_PIPE_STREAMS", "2"))          # (experiments; the C-ABI pipeline reads the same variable)
+            nstr = int(streams)          # 2: channelizer | exchange + launch of the synchronizer stage (3 = a stream per stage, rounds 2-3: slower)
             self.sA = torch.cuda.Stream(device=device)
             self.sB = torch.cuda.Stream(device=device) if nstr >= 2 else self.sA
             self.sC = torch.cuda.Stream(device=device) if nstr >= 3 else self.sB     # (module docstring: the synchronizer stage is launched from the exchange's stream)
@@ -222,7 +222,7 @@ class TxPipeline(object):
     """
 
     def __init__(self, tx, traffic, rank, world, dist, num_channels, sub_blocks, lead_blocks=48, keep_blocks=16,
-                 device=None, nbuf=3, gain=None):
+                 device=None, nbuf=3, gain=None, streams=0):
         import torch
         assert sub_blocks % TX_TILE == 0 and lead_blocks % TX_TILE == 0 and num_channels % world == 0
         assert lead_blocks >= 25 + keep_blocks, "the synthesis filter remembers 25 blocks"
@@ -243,7 +243,7 @@ class TxPipeline(object):
             # (streams are not free: every one past the hardware queues shares a queue with a busy one -- Pipeline above.  Here stage C is
             #  a kernel of its own: several ranks run it beside the exchange, which shares the tile generator's stream; one rank has
             #  no exchange and runs everything in order -- full duplex on one GPU 62.8 / 68.4 / 74.3 Gsample/s with 3 / 2 / 1 streams)
-            nstr = int(__import__("os").environ.get("MCTX_PIPE_STREAMS", "0")) or (1 if self.alias else 2)
+            nstr = int(streams) or (1 if self.alias else 2)
             self.sA = torch.cuda.Stream(device=device)
             self.sB = torch.cuda.Stream(device=device) if nstr >= 3 else self.sA
             self.sC = torch.cuda.Stream(device=device) if nstr >= 2 else self.sA

@@ -100,10 +100,13 @@ const unsigned char *ll_modem_soft_neighbors(ll_modem q, unsigned *p);
 unsigned ll_crc_length(int scheme);
 unsigned ll_crc_generate_key(int scheme, const unsigned char *msg, unsigned n);
 unsigned ll_fec_enc_len(int scheme, unsigned dec_len);
+int      ll_fec_supported(int scheme);      /* the schemes restated here: none, rep3, rep5, h74, h84, h128, g2412, v27 */
 void     ll_fec_encode(int scheme, unsigned dec_len, const unsigned char *dec, unsigned char *enc);
 void     ll_fec_decode(int scheme, unsigned dec_len, const unsigned char *enc, unsigned char *dec);
 void     ll_fec_decode_soft(int scheme, unsigned dec_len, const unsigned char *enc_soft, unsigned char *dec);
 unsigned ll_hamming128_encode_symbol(unsigned s);
+unsigned ll_hamming74_encode_symbol(unsigned s);
+unsigned ll_hamming84_encode_symbol(unsigned s);
 unsigned ll_hamming128_decode_symbol(unsigned c);
 unsigned ll_golay2412_encode_symbol(unsigned s);
 unsigned ll_golay2412_decode_symbol(unsigned r);

@@ -6,8 +6,10 @@
  * interleaver.c, packetizer.c}, src/framing/... scramble.c and src/utility pack_bytes.c.
  * The reference selects these through ofdmflexframegenprops_s {check, fec0, fec1}
  * (/root/reference/lib/multichanneltx.cc:72-75,184; src/multichannel_txrx.cc:131-132):
- * CRC-32, fec0 = none, fec1 = Hamming(12,8) or Golay(24,12).  Only the schemes the
- * reference uses are restated.
+ * CRC-32, fec0 = none, fec1 = Hamming(12,8) or Golay(24,12); the applications' -c / -k options hand any
+ * liquid scheme name to the library (src/multichannel_tx.cc:46-52,92-94), so the short block codes those
+ * options list first -- rep3, rep5, Hamming(7,4), Hamming(8,4): liquid fec_rep3.c, fec_rep5.c, fec_hamming74.c,
+ * fec_hamming84.c -- are restated too.
  *
  *  CRC-32      : reflected 0xEDB88320, init/xorout 0xFFFFFFFF, appended big-endian.
  *  Hamming128  : 12-bit symbol  p1 p2 d1 p4 d2 d3 d4 p8 d5 d6 d7 d8 (MSB first);
@@ -18,6 +20,13 @@
  *                parity = P * m with the Lin/Costello P matrix; arithmetic decoder
  *                (syndrome weight tests), corrects <= 3 errors.  No soft decoder
  *                (soft input is sliced at 127 and hard decoded).
+ *  rep3 / rep5 : the message three / five times in a row; hard decode = bitwise majority; soft decode = mean of
+ *                the copies' soft bits (integer division) against the erasure level 127.
+ *  Hamming74/84: 4-bit symbol -> p1 p2 d1 p4 d2 d3 d4 (MSB first) [+ overall parity as the LSB]; a byte is two
+ *                symbols, high nibble first; (7,4) symbols are bit-packed back to back, (8,4) symbols are bytes.
+ *                Soft decode: the codeword of least soft distance among all 16, ascending, strict <.  Hard decode:
+ *                nearest codeword the same way ((7,4) is perfect: unique; a double error in (8,4) goes to the
+ *                lowest symbol at distance 2 -- liquid's table for that case is not visible from the reference).
  *  interleaver : byte swaps x[2i] <-> x[2j+1] over an M x N column walk, then three
  *                masked passes (N+2,0x0f) (N+4,0x55) (N+8,0x33).
  *  scrambler   : XOR with repeating {0xb4, 0x6a, 0x8b, 0xc5}.
@@ -228,13 +237,59 @@ static void conv27_viterbi(unsigned n, const unsigned char *sym, unsigned char *
     free(d);
 }
 
+/* ------------------------------------------------------------------ rep3 / rep5 / Hamming(7,4) / Hamming(8,4) */
+unsigned ll_hamming74_encode_symbol(unsigned s)
+{
+    unsigned d1 = (s >> 3) & 1, d2 = (s >> 2) & 1, d3 = (s >> 1) & 1, d4 = s & 1;
+    unsigned p1 = d1 ^ d2 ^ d4, p2 = d1 ^ d3 ^ d4, p4 = d2 ^ d3 ^ d4;
+    return (p1 << 6) | (p2 << 5) | (d1 << 4) | (p4 << 3) | (d2 << 2) | (d3 << 1) | d4;
+}
+unsigned ll_hamming84_encode_symbol(unsigned s)
+{
+    unsigned c = ll_hamming74_encode_symbol(s);
+    return (c << 1) | par(c);
+}
+static unsigned hsmall_encode(unsigned s, unsigned nb) { return nb == 7 ? ll_hamming74_encode_symbol(s) : ll_hamming84_encode_symbol(s); }
+/* nearest codeword of an nb-bit word, symbols ascending, strict < */
+static unsigned hsmall_decode(unsigned w, unsigned nb)
+{
+    unsigned best = 0, dmin = 99;
+    for (unsigned s = 0; s < 16; s++) {
+        unsigned d = (unsigned)__builtin_popcount(w ^ hsmall_encode(s, nb));
+        if (d < dmin) { dmin = d; best = s; }
+    }
+    return best;
+}
+static unsigned hsmall_decode_soft(const unsigned char *soft, unsigned nb)
+{
+    unsigned best = 0, dmin = 0;
+    for (unsigned s = 0; s < 16; s++) {
+        unsigned c = hsmall_encode(s, nb), d = 0;
+        for (unsigned k = 0; k < nb; k++) d += ((c >> (nb - 1 - k)) & 1) ? 255u - soft[k] : soft[k];
+        if (s == 0 || d < dmin) { dmin = d; best = s; }
+    }
+    return best;
+}
+static unsigned bits_get(const unsigned char *x, unsigned k, unsigned nb)      /* nb bits from bit index k, MSB first */
+{ unsigned v = 0; for (unsigned i = 0; i < nb; i++) v = (v << 1) | ((x[(k + i) >> 3] >> (7 - ((k + i) & 7))) & 1u); return v; }
+static void bits_put(unsigned char *x, unsigned k, unsigned nb, unsigned v)
+{ for (unsigned i = 0; i < nb; i++) if ((v >> (nb - 1 - i)) & 1u) x[(k + i) >> 3] |= (unsigned char)(0x80u >> ((k + i) & 7)); }
+static unsigned rep_copies(int scheme) { return scheme == LL_FEC_REP3 ? 3u : 5u; }
+
 /* ------------------------------------------------------------------ FEC block codecs */
+int ll_fec_supported(int scheme)
+{ return (scheme >= LL_FEC_NONE && scheme <= LL_FEC_GOLAY2412) || scheme == LL_FEC_CONV_V27; }
+
 unsigned ll_fec_enc_len(int scheme, unsigned n)
 {
     switch (scheme) {
     case LL_FEC_CONV_V27:   return 2 * n + 2;
     case LL_FEC_HAMMING128: return (n / 2) * 3 + (n % 2) * 2;
     case LL_FEC_GOLAY2412:  return (n / 3) * 6 + (n % 3) * 3;
+    case LL_FEC_REP3:       return 3 * n;
+    case LL_FEC_REP5:       return 5 * n;
+    case LL_FEC_HAMMING74:  return (14 * n + 7) / 8;        /* liquid fec_block_get_enc_msg_len(n, 4, 7) */
+    case LL_FEC_HAMMING84:  return 2 * n;
     default: return n;
     }
 }
@@ -276,6 +331,22 @@ void ll_fec_encode(int scheme, unsigned n, const unsigned char *dec, unsigned ch
         }
     } break;
     case LL_FEC_CONV_V27: conv27_encode(n, dec, enc); break;
+    case LL_FEC_REP3: case LL_FEC_REP5:
+        for (i = 0; i < rep_copies(scheme); i++) memmove(enc + i * n, dec, n);
+        break;
+    case LL_FEC_HAMMING74:
+        memset(enc, 0, ll_fec_enc_len(scheme, n));
+        for (i = 0; i < n; i++) {
+            bits_put(enc, 14 * i,     7, ll_hamming74_encode_symbol(dec[i] >> 4));
+            bits_put(enc, 14 * i + 7, 7, ll_hamming74_encode_symbol(dec[i] & 0x0f));
+        }
+        break;
+    case LL_FEC_HAMMING84:
+        for (i = 0; i < n; i++) {
+            enc[2 * i]     = (unsigned char)ll_hamming84_encode_symbol(dec[i] >> 4);
+            enc[2 * i + 1] = (unsigned char)ll_hamming84_encode_symbol(dec[i] & 0x0f);
+        }
+        break;
     default: memmove(enc, dec, n);
     }
 }
@@ -322,6 +393,31 @@ void ll_fec_decode(int scheme, unsigned n, const unsigned char *enc, unsigned ch
             j += 3;
         }
     } break;
+    case LL_FEC_REP3:
+        for (i = 0; i < n; i++) {
+            unsigned s0 = enc[i], s1 = enc[i + n], s2 = enc[i + 2 * n];
+            dec[i] = (unsigned char)((s0 & s1) | (s0 & s2) | (s1 & s2));
+        }
+        break;
+    case LL_FEC_REP5:
+        for (i = 0; i < n; i++) {
+            unsigned b = 0;
+            for (unsigned k = 0; k < 8; k++) {
+                unsigned cnt = 0;
+                for (unsigned r = 0; r < 5; r++) cnt += (enc[i + r * n] >> k) & 1u;
+                b |= (cnt >= 3 ? 1u : 0u) << k;
+            }
+            dec[i] = (unsigned char)b;
+        }
+        break;
+    case LL_FEC_HAMMING74:
+        for (i = 0; i < n; i++)
+            dec[i] = (unsigned char)((hsmall_decode(bits_get(enc, 14 * i, 7), 7) << 4) | hsmall_decode(bits_get(enc, 14 * i + 7, 7), 7));
+        break;
+    case LL_FEC_HAMMING84:
+        for (i = 0; i < n; i++)
+            dec[i] = (unsigned char)((hsmall_decode(enc[2 * i], 8) << 4) | hsmall_decode(enc[2 * i + 1], 8));
+        break;
     default: memmove(dec, enc, n);
     }
 }
@@ -339,6 +435,25 @@ void ll_fec_decode_soft(int scheme, unsigned n, const unsigned char *soft, unsig
         return;
     }
     if (scheme == LL_FEC_CONV_V27) { conv27_viterbi(n, soft, dec); return; }
+    if (scheme == LL_FEC_REP3 || scheme == LL_FEC_REP5) {
+        const unsigned R = rep_copies(scheme);
+        for (unsigned i = 0; i < n; i++) {
+            unsigned b = 0;
+            for (unsigned k = 0; k < 8; k++) {
+                unsigned sum = 0;
+                for (unsigned r = 0; r < R; r++) sum += soft[8 * (i + r * n) + k];
+                b = (b << 1) | ((sum / R) > 127 ? 1u : 0u);
+            }
+            dec[i] = (unsigned char)b;
+        }
+        return;
+    }
+    if (scheme == LL_FEC_HAMMING74 || scheme == LL_FEC_HAMMING84) {
+        const unsigned nb = scheme == LL_FEC_HAMMING74 ? 7u : 8u;
+        for (unsigned i = 0; i < n; i++)
+            dec[i] = (unsigned char)((hsmall_decode_soft(soft + 2 * nb * i, nb) << 4) | hsmall_decode_soft(soft + 2 * nb * i + nb, nb));
+        return;
+    }
     /* no soft decoder: slice at 127, pack MSB first, hard decode */
     unsigned enc_len = ll_fec_enc_len(scheme, n);
     unsigned char *hard = (unsigned char *)malloc(enc_len ? enc_len : 1);

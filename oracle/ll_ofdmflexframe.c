@@ -285,8 +285,7 @@ static void fs_decode_header(ll_ofdmflexframesync q)
     ll_modem m = ll_modem_create((int)mod_scheme);
     if (!m) { q->header_valid = 0; return; }
     if (check == LL_CRC_UNKNOWN || check > LL_CRC_32 ||
-        !(fec0 == LL_FEC_NONE || fec0 == LL_FEC_HAMMING128 || fec0 == LL_FEC_GOLAY2412 || fec0 == LL_FEC_CONV_V27) ||
-        !(fec1 == LL_FEC_NONE || fec1 == LL_FEC_HAMMING128 || fec1 == LL_FEC_GOLAY2412 || fec1 == LL_FEC_CONV_V27)) {
+        !ll_fec_supported((int)fec0) || !ll_fec_supported((int)fec1)) {
         ll_modem_destroy(m); q->header_valid = 0; return;
     }
     ll_modem_destroy(q->mod_payload); q->mod_payload = m;

@@ -13,6 +13,7 @@ _LIB = os.path.join(_HERE, "liboracle.so")
 
 CRC_NONE, CRC_32 = 1, 6
 FEC_NONE, FEC_HAMMING128, FEC_GOLAY2412, FEC_CONV_V27 = 1, 6, 7, 11
+FEC_REP3, FEC_REP5, FEC_HAMMING74, FEC_HAMMING84 = 2, 3, 4, 5
 MODEM_QAM16, MODEM_QAM64, MODEM_BPSK, MODEM_QPSK = 27, 29, 39, 40
 ANALYZER, SYNTHESIZER = 0, 1
 
@@ -89,6 +90,9 @@ def lib():
     sig("ll_fec_decode_soft", None, i, u, vp, vp)
     sig("ll_hamming128_encode_symbol", u, u)
     sig("ll_hamming128_decode_symbol", u, u)
+    sig("ll_hamming74_encode_symbol", u, u)
+    sig("ll_hamming84_encode_symbol", u, u)
+    sig("ll_fec_supported", i, i)
     sig("ll_golay2412_encode_symbol", u, u)
     sig("ll_golay2412_decode_symbol", u, u)
     sig("ll_interleaver_encode", None, u, u, vp, vp)

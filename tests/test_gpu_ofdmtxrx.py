@@ -33,6 +33,10 @@ def traffic(oracle, M, cp, taper, nframes, plen, mod, fec0, fec1, seed, gain=0.2
     (64, 8, 40, 1, 6, 0),
     (48, 6, 40, 1, 7, 1200),         # the reference applications' default numerology: direct inverse DFT
     (80, 10, 27, 1, 6, 100),
+    (64, 8, 40, 1, 2, 300),          # the short block codes the applications' -c / -k options name first: rep3 ...
+    (64, 8, 27, 3, 4, 77),           # ... rep5 inside Hamming(7,4) (bit-packed 7-bit symbols) ...
+    (128, 16, 40, 5, 1, 200),        # ... Hamming(8,4) as the inner code alone
+    (64, 8, 39, 4, 5, 51),
 ])
 def test_frame_generator_matches_oracle(oracle, product, M, cp, mod, fec0, fec1, plen):
     rng = np.random.RandomState(M + plen)
@@ -70,7 +74,10 @@ def test_config1_loopback_1e6_samples_matches_oracle(oracle, product):
     rx.close()
 
 
-@pytest.mark.parametrize("M,cp,mod,fec0,fec1,plen", [(256, 32, 27, 1, 7, (1, 900)), (64, 16, 39, 7, 7, (0, 60)), (48, 6, 40, 1, 6, (10, 200))])
+@pytest.mark.parametrize("M,cp,mod,fec0,fec1,plen", [(256, 32, 27, 1, 7, (1, 900)), (64, 16, 39, 7, 7, (0, 60)), (48, 6, 40, 1, 6, (10, 200)),
+                                                     (64, 8, 40, 1, 2, (1, 400)), (64, 8, 27, 1, 3, (1, 300)), (64, 8, 40, 1, 4, (0, 500)),
+                                                     (128, 16, 29, 1, 5, (1, 500)), (64, 8, 40, 2, 5, (1, 200)), (48, 6, 39, 4, 3, (1, 100)),
+                                                     (64, 8, 40, 5, 4, (1, 300)), (64, 8, 27, 3, 6, (1, 200))])
 def test_single_synchronizer_other_schemes(oracle, product, M, cp, mod, fec0, fec1, plen):
     import torch
     iq, sent = traffic(oracle, M, cp, 4, 9, plen, mod, fec0, fec1, seed=M)
@@ -84,6 +91,23 @@ def test_single_synchronizer_other_schemes(oracle, product, M, cp, mod, fec0, fe
     check_frames(rx.frames, ora.frames, rel=2e-5 if M >= 1024 else 1e-5)
     assert [(f.header, f.payload) for f in rx.frames] == sent
     rx.close()
+
+
+def test_schemes_the_path_does_not_carry_are_refused_not_sent_uncoded(product):
+    """a scheme id may only ever be transmitted if the bits behind it are that scheme's.  liquid's SEC-DED codes
+    (8 .. 10), the other convolutional / punctured / Reed-Solomon ids and 'unknown' are refused by every transmit entry point."""
+    fg = product.ofdmflexframegen(64, 8, 4)
+    h = bytes(8)
+    for bad in (0, 8, 9, 10, 12, 27, 31):
+        with pytest.raises((RuntimeError, ValueError)):
+            fg.frame(h, b"abc", 40, 1, bad)
+        with pytest.raises((RuntimeError, ValueError)):
+            fg.frame(h, b"abc", 40, bad, 6)
+    fg.close()
+    tx = product.multichanneltx(2, 64, 8, 4)
+    with pytest.raises((RuntimeError, ValueError)):
+        tx.generate(1, 20, fec1=9)
+    tx.close()
 
 
 def test_gpu_generator_to_gpu_synchronizer_and_reset(oracle, product):

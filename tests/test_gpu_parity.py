@@ -430,6 +430,39 @@ def test_convolutional_k7_rate_half_viterbi(oracle, product, mod, fec0, fec1, so
     rx.close()
 
 
+@pytest.mark.parametrize("mod,fec0,fec1,soft,snr_db", [(40, 1, 2, 1, 4.0), (40, 1, 3, 1, 2.0), (27, 1, 4, 1, 17.0), (40, 1, 5, 1, 9.0),
+                                                       (40, 1, 2, 0, 6.0), (40, 3, 4, 0, 6.0), (27, 5, 2, 1, 12.0), (40, 4, 6, 1, None), (39, 2, 5, 0, 3.0)])
+def test_short_block_codes_same_decisions_as_oracle(oracle, product, mod, fec0, fec1, soft, snr_db):
+    """liquid's rep3 / rep5 / Hamming(7,4) / Hamming(8,4) (fec ids 2 .. 5; src/multichannel_tx.cc:46-52,92-94 hands any scheme name
+    to the library): as outer code with soft decisions, as inner code (hard), in hard-decision mode, at SNRs where every frame
+    carries hundreds of channel bit errors -- the GPU transmitter encodes what the oracle decodes, and the GPU receiver makes the
+    oracle's decisions frame for frame (wrong ones included)."""
+    N, M, cp, plen = 4, 64, 8, 260
+    tx = product.multichanneltx(N, M, cp, 4)
+    iq, sent = tx.generate(3, plen, mod=mod, fec0=fec0, fec1=fec1, seed=7)
+    tx.close()
+    x = iq.cpu().numpy()
+    if snr_db is not None:
+        rng = np.random.RandomState(3)
+        nstd = np.sqrt(np.mean(np.abs(x) ** 2)) * 10.0 ** (-snr_db / 20.0) / np.sqrt(2.0)
+        x = (x + nstd * (rng.randn(len(x)) + 1j * rng.randn(len(x)))).astype(np.complex64)
+    x = x[:len(x) // (32 * N) * (32 * N)]
+    ora = oracle.MultiChannelRx(N, M, cp, 4, soft=bool(soft))
+    ora.execute(x)
+    assert len(ora.frames) >= 3 * N - 1
+    nvalid = sum(1 for f in ora.frames if f.payload_valid)
+    assert nvalid >= len(ora.frames) // 2, nvalid
+    if snr_db is None:
+        for f in ora.frames:
+            assert sent[f.channel][(f.header[0] << 8) | f.header[1]] == (f.header, f.payload)
+    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=plen, payload_soft=soft)
+    rx.Execute(x); rx.Flush()
+    w = check_frames(rx.frames, ora.frames, rel=1.0)
+    assert w <= REL, w
+    assert all((f.fec0, f.fec1) == (fec0, fec1) for f in rx.frames if f.header_valid)
+    rx.close()
+
+
 @pytest.mark.parametrize("M,cp,step_blocks", [(64, 8, 40), (48, 6, 0)])
 def test_convolutional_code_on_the_serial_paths(oracle, product, M, cp, step_blocks):
     """The same code where a whole frame is decoded by one wave of a walker kernel: pushes that cut every frame (the tail
@@ -500,14 +533,13 @@ def test_speculation_survives_wrong_predictions(oracle, product):
     rx.close(); tx.close()
 
 
-@pytest.mark.parametrize("build", ["0", "1"])
-def test_both_builds_of_the_rounds_scout_equal_the_oracle(oracle, product, monkeypatch, build):
-    """The acquisition rounds launch the lean scout's unbudgeted build by default (MCRX_LEAN_BUILD=1: sync_walk_kernel) and
-    the 168-register build on request (0: sync_lean_kernel); a periodic stream long enough for cadence speculation -- every
+@pytest.mark.parametrize("scout_build", [1, 0])
+def test_both_builds_of_the_rounds_scout_equal_the_oracle(oracle, product, scout_build):
+    """The acquisition rounds launch the lean scout's unbudgeted build by default (sync_walk_kernel) and the 168-register
+    build on request (mcrx_hip_config::scout_build = 1: sync_lean_kernel); a periodic stream long enough for cadence speculation -- every
     frame but the first adopted, a dozen per channel chased in one go -- pushed in pieces must give the oracle's frames
     through either."""
     import torch
-    monkeypatch.setenv("MCRX_LEAN_BUILD", build)          # (read once, when the handle is created)
     N, M, cp = 8, 64, 8
     tx = product.multichanneltx(N, M, cp, 4)
     iq, _ = tx.generate(14, 200, seed=77)
@@ -516,7 +548,7 @@ def test_both_builds_of_the_rounds_scout_equal_the_oracle(oracle, product, monke
     ora = oracle.MultiChannelRx(N, M, cp, 4)
     ora.execute(x)
     assert len(ora.frames) == 14 * N
-    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=200)
+    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=200, scout_build=scout_build)
     step = n // 3 // (32 * N) * (32 * N)
     for rep in range(2):                                    # the second pass runs on the first one's cadence
         for i in range(0, n, step):

@@ -201,18 +201,17 @@ def test_chunked_push_with_deferral_overlaps_without_serial_walks(product):
     ref.close(); rx.close()
 
 
-@pytest.mark.parametrize("fr", [0, 2, 4])
-def test_payload_worker_builds_agree(oracle, product, fr, monkeypatch):
+@pytest.mark.parametrize("worker_build", [5, 3, 4])
+def test_payload_worker_builds_agree(oracle, product, worker_build):
     """The M = 64 payload worker exists as one frame per wave (default), two and four frames per wave (groups of 32 / 16
-    lanes, in-register transform stages) and as the width-generic kernel (0): same frames as the oracle, symbols <= 1e-5."""
+    lanes, in-register transform stages: worker_build 3 / 4) and as the width-generic kernel (5): same frames as the oracle, symbols <= 1e-5."""
     N, M, cp, nf, plen = 8, 64, 8, 5, 333
     slabs = _slabs(product, N, M, cp, 2, nf, plen, (0, 48))
     x = np.concatenate([iq.cpu().numpy() for iq, _ in slabs])
     ora = oracle.MultiChannelRx(N, M, cp, 4)
     ora.execute(x)
     assert len(ora.frames) == 2 * nf * N
-    monkeypatch.setenv("MCRX_PAYLOAD_FR", str(fr))
-    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=plen)
+    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=plen, worker_build=worker_build)      # mcrx_hip_config::worker_build
     for iq, _ in slabs:
         rx.Execute(iq)
     rx.Flush()
@@ -229,13 +228,13 @@ def test_payload_worker_builds_agree(oracle, product, fr, monkeypatch):
     rx.close()
 
 
-@pytest.mark.parametrize("env", [{}, {"MCRX_PAYLOAD_XB": "0"}, {"MCRX_PAYLOAD_LEAN": "0"}])
-def test_lean_payload_workers_every_modem_in_one_slab(oracle, product, env, monkeypatch):
+@pytest.mark.parametrize("worker_build", [0, 1, 2])
+def test_lean_payload_workers_every_modem_in_one_slab(oracle, product, worker_build):
     """The 64-subcarrier payload workers (payload_lean.hpp) are two launches: BPSK / QPSK frames a wave each, 16- / 64-QAM frames
     from the list place_jobs_kernel writes.  A stream whose channels change modem, code and length from frame to frame puts both
     classes (and the partly filled last symbol of every length) into every launch: frames, bytes and order are the oracle's,
-    symbols <= 1e-5, in the default build, with the butterflies' exchanges on the VALU (MCRX_PAYLOAD_XB=0) and with the
-    round-2 worker (MCRX_PAYLOAD_LEAN=0)."""
+    symbols <= 1e-5, in the default build, with the butterflies' exchanges on the VALU (worker_build 1) and with the
+    round-2 worker (worker_build 2)."""
     from test_gpu_parity import check_frames
     N, M, cp, nf = 8, 64, 8, 8
     kinds = [(40, 6, 333), (27, 7, 150), (39, 1, 33), (29, 6, 257), (40, 1, 64), (27, 6, 1), (29, 1, 90), (39, 6, 500)]
@@ -259,9 +258,7 @@ def test_lean_payload_workers_every_modem_in_one_slab(oracle, product, env, monk
     ora.execute(x)
     assert len(ora.frames) == nf * N and all(f.payload_valid for f in ora.frames)
     assert {f.mod_scheme for f in ora.frames} == {27, 29, 39, 40}
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=512)
+    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=512, worker_build=worker_build)
     half = len(x) // 2 // (32 * N) * (32 * N)
     rx.Execute(x[:half]); rx.Execute(x[half:]); rx.Flush()       # (two pushes: frames of both classes straddle the cut)
     check_frames(rx.frames, ora.frames)

@@ -47,13 +47,77 @@ def test_golay2412_is_extended_golay(oracle):
         assert L.ll_golay2412_decode_symbol(int(words[s]) ^ e) == s
 
 
-@pytest.mark.parametrize("scheme,n", [(6, 1), (6, 2), (6, 7), (6, 1204), (7, 1), (7, 2), (7, 3), (7, 18), (7, 1204), (1, 5)])
+def test_small_hamming_codes_are_the_published_tables_and_correct_single_errors(oracle):
+    """liquid fec_hamming74.c / fec_hamming84.c generator tables (hamming74_enc_gentab / hamming84_enc_gentab) as
+    published; (7,4) is perfect (every 7-bit word within distance 1 of exactly one codeword), (8,4) is its extension."""
+    L = oracle.lib()
+    h74 = [L.ll_hamming74_encode_symbol(s) for s in range(16)]
+    h84 = [L.ll_hamming84_encode_symbol(s) for s in range(16)]
+    assert h74 == [0x00, 0x69, 0x2a, 0x43, 0x4c, 0x25, 0x66, 0x0f, 0x70, 0x19, 0x5a, 0x33, 0x3c, 0x55, 0x16, 0x7f]
+    assert h84 == [0x00, 0xd2, 0x55, 0x87, 0x99, 0x4b, 0xcc, 0x1e, 0xe1, 0x33, 0xb4, 0x66, 0x78, 0xaa, 0x2d, 0xff]
+    assert min(bin(h74[a] ^ h74[b]).count("1") for a in range(16) for b in range(a)) == 3
+    assert min(bin(h84[a] ^ h84[b]).count("1") for a in range(16) for b in range(a)) == 4
+    for scheme, words, nb in ((oracle.FEC_HAMMING74, h74, 7), (oracle.FEC_HAMMING84, h84, 8)):
+        for hi in range(16):
+            for lo in range(16):
+                msg = np.array([(hi << 4) | lo], np.uint8)
+                enc = np.zeros(2, np.uint8)
+                L.ll_fec_encode(scheme, 1, msg.ctypes.data, enc.ctypes.data)
+                word = (int(enc[0]) << 8) | int(enc[1])
+                assert word == ((words[hi] << (16 - nb)) | (words[lo] << (16 - 2 * nb)))     # high nibble first, bit-packed
+                for bit in range(16 - 2 * nb, 16):                                       # every single error in either symbol
+                    bad = word ^ (1 << bit)
+                    e = np.array([bad >> 8, bad & 0xff], np.uint8)
+                    dec = np.zeros(1, np.uint8)
+                    L.ll_fec_decode(scheme, 1, e.ctypes.data, dec.ctypes.data)
+                    assert dec[0] == msg[0]
+    # soft decision: an erased bit plus a weak wrong bit in one (8,4) symbol -- two hard errors, which the hard decoder cannot
+    # resolve -- decodes by soft distance
+    for s in range(16):
+        c = h84[s]
+        soft = np.array([255 if (c >> (7 - k)) & 1 else 0 for k in range(8)] * 2, np.uint8)
+        soft[0] = 127 + (1 if soft[0] == 0 else -1) * 8          # weakly wrong
+        soft[3] = 127 + (1 if soft[3] == 0 else 0)               # (nearly) erased, wrong side
+        dec = np.zeros(1, np.uint8)
+        L.ll_fec_decode_soft(oracle.FEC_HAMMING84, 1, soft.ctypes.data, dec.ctypes.data)
+        assert dec[0] == ((s << 4) | s)
+
+
+@pytest.mark.parametrize("scheme,R", [(2, 3), (3, 5)])
+def test_repeat_codes_majority_vote(oracle, scheme, R):
+    """liquid fec_rep3.c / fec_rep5.c: R copies in a row, bitwise majority; soft = mean of the copies against 127."""
+    L = oracle.lib()
+    rng = np.random.RandomState(R)
+    n = 37
+    msg = rng.randint(0, 256, n).astype(np.uint8)
+    enc = np.zeros(R * n, np.uint8)
+    assert L.ll_fec_enc_len(scheme, n) == R * n
+    L.ll_fec_encode(scheme, n, msg.ctypes.data, enc.ctypes.data)
+    assert np.array_equal(enc, np.tile(msg, R))
+    # any (R - 1) / 2 copies may be arbitrarily wrong
+    bad = enc.copy().reshape(R, n)
+    for col in range(n):
+        for r in rng.choice(R, (R - 1) // 2, replace=False):
+            bad[r, col] = rng.randint(0, 256)
+    dec = np.zeros(n, np.uint8)
+    L.ll_fec_decode(scheme, n, bad.ctypes.data, dec.ctypes.data)
+    assert np.array_equal(dec, msg)
+    # soft: the floor of the mean of the copies' soft bits, strictly above 127
+    soft = rng.randint(0, 256, (R, n, 8)).astype(np.uint8)
+    want = np.packbits((soft.astype(np.int64).sum(0) // R > 127).astype(np.uint8), axis=1)[:, 0]
+    L.ll_fec_decode_soft(scheme, n, soft.ctypes.data, dec.ctypes.data)
+    assert np.array_equal(dec, want)
+
+
+@pytest.mark.parametrize("scheme,n", [(6, 1), (6, 2), (6, 7), (6, 1204), (7, 1), (7, 2), (7, 3), (7, 18), (7, 1204), (1, 5),
+                                      (2, 1), (2, 1204), (3, 9), (3, 1204), (4, 1), (4, 3), (4, 4), (4, 1204), (5, 1), (5, 1204)])
 def test_fec_block_roundtrip_and_lengths(oracle, scheme, n):
     L = oracle.lib()
     rng = np.random.RandomState(n)
     msg = rng.randint(0, 256, n).astype(np.uint8)
     k = L.ll_fec_enc_len(scheme, n)
-    bits_in, m_bits, k_bits = 8 * n, {6: 8, 7: 12, 1: 8}[scheme], {6: 12, 7: 24, 1: 8}[scheme]
+    bits_in = 8 * n
+    m_bits, k_bits = {6: (8, 12), 7: (12, 24), 1: (8, 8), 2: (8, 24), 3: (8, 40), 4: (4, 7), 5: (4, 8)}[scheme]
     blocks = -(-bits_in // m_bits)
     assert k == -(-(blocks * k_bits) // 8)                 # liquid fec_block_get_enc_msg_len
     enc = np.zeros(k, np.uint8)
@@ -155,7 +219,9 @@ def test_conv_v27_is_the_k7_rate_half_code(oracle):
 
 @pytest.mark.parametrize("n,fec0,fec1,enc", [(14, 7, 1, 36), (1200, 1, 6, 1806), (1200, 1, 7, 2409),
                                              (1200, 1, 1, 1204), (0, 1, 6, 6), (5, 6, 7, 30),
-                                             (1200, 1, 11, 2410), (100, 11, 6, 315), (0, 1, 11, 10)])
+                                             (1200, 1, 11, 2410), (100, 11, 6, 315), (0, 1, 11, 10),
+                                             (1200, 1, 2, 3612), (1200, 1, 3, 6020), (1200, 1, 4, 2107), (1200, 1, 5, 2408),
+                                             (33, 4, 2, 195), (33, 5, 3, 370), (21, 2, 4, 132), (7, 3, 5, 110)])
 def test_packetizer_lengths_roundtrip_and_error_correction(oracle, n, fec0, fec1, enc):
     p = oracle.Packetizer(n, oracle.CRC_32, fec0, fec1)
     assert p.enc_len == enc
