@@ -33,6 +33,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -73,6 +74,9 @@ def parse():
     ap.add_argument("--chunk-blocks", type=int, default=0, help="split every push into sub-slabs of this many blocks")
     ap.add_argument("--defer", type=int, default=-1, help="cfg.defer_samples (experiments; default: 16384 on the pipeline paths, 0 on the direct one)")
     ap.add_argument("--serial", action="store_true", help="time the unpipelined receiver (every kernel in order on one stream)")
+    ap.add_argument("--contact-timeout", type=float, default=600.0,
+                    help="--gpus > 1: seconds the rendezvous, the first collective and the first exchange round may each take before rank 0 "
+                         "prints a line with value 0 and the stage that hung")
     ap.add_argument("--pipeline", action="store_true", help="--gpus 1 through the multi-GPU code path (sharding.Pipeline, exchange = local copy)")
     ap.add_argument("--exchange", choices=["auto", "torch", "c"], default="auto",
                     help="multi-GPU path: 'torch' = sharding.Pipeline (torch streams + torch.distributed all_to_all_single: the path the gloo "
@@ -84,6 +88,37 @@ def parse():
                          "device): executes the whole multi-process code path -- sub-slab cut, halos, pipeline, verification -- on a one-GPU lease.  "
                          "The value it prints is NOT a scaling number")
     return ap.parse_args()
+
+
+class Watchdog(object):
+    """with Watchdog(stage, seconds, rank, args): ...   -- if the block does not finish in time, rank 0 prints the benchmark's JSON line
+    with value 0 and the reason, and the process exits with code 3 (a hang inside a collective cannot be interrupted from Python)."""
+
+    def __init__(self, stage, seconds, rank, args):
+        self.stage, self.seconds, self.rank, self.args = stage, seconds, rank, args
+        self.done = threading.Event()
+
+    def _run(self):
+        if self.done.wait(self.seconds):
+            return
+        if self.rank == 0:
+            print(json.dumps({"metric": "complex Msamples/s through multichannelrx", "value": 0.0, "unit": "Msamples/s",
+                              "n_gpus": self.args.gpus, "steps": self.args.steps, "warmup": self.args.warmup, "ms_per_step": None,
+                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                              "config": {"workload": "512-ch multichannelrx", "parallelism": "%d ranks" % self.args.gpus},
+                              "error": "timed out after %.0f s in: %s" % (self.seconds, self.stage)}), flush=True)
+        sys.stderr.write("bench.py rank %d: timed out after %.0f s in: %s\n" % (self.rank, self.seconds, self.stage))
+        sys.stderr.flush()
+        os._exit(3)
+
+    def __enter__(self):
+        self.t = threading.Thread(target=self._run, daemon=True)
+        self.t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.done.set()
+        return False
 
 
 def launcher():
@@ -116,12 +151,26 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
+    ranks_seen = None
     if world > 1:
+        # First contact with a multi-GPU node (no SCALE record exists yet): the rendezvous and the first collective run under a
+        # watchdog.  If either hangs, rank 0 still prints a JSON line -- value 0, the stage that hung -- and every rank exits non-zero,
+        # instead of the driver's clock running out on a silent process.
+        import datetime
         import torch.distributed as dist
-        if rehearsal:
-            dist.init_process_group(backend="gloo")                 # every rank on cuda:0, exchange through host memory
-        else:
-            dist.init_process_group(backend="nccl", device_id=dev)  # RCCL over xGMI
+        limit = float(args.contact_timeout)                          # (the process group's own timeout is a minute longer, so that the watchdog speaks first)
+        with Watchdog("rendezvous (init_process_group, %s)" % ("gloo" if rehearsal else "nccl"), limit, rank, args):
+            if rehearsal:
+                dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=limit + 60))   # every rank on cuda:0, exchange through host memory
+            else:
+                dist.init_process_group(backend="nccl", device_id=dev, timeout=datetime.timedelta(seconds=limit + 60))  # RCCL over xGMI
+        with Watchdog("first collective (all_reduce of one int32 per rank)", limit, rank, args):
+            one = torch.ones(1, dtype=torch.int32, device="cpu" if rehearsal else dev)
+            dist.all_reduce(one)                                    # sum of ones = the ranks that really took part
+            if not rehearsal:
+                torch.cuda.synchronize()
+            ranks_seen = int(one.item())
+        assert ranks_seen == world, "all_reduce saw %d of %d ranks" % (ranks_seen, world)
 
     prod, ora = load_product(), load_oracle()
     from liquid_usrp_amd import sharding
@@ -248,14 +297,15 @@ def main():
             # failed all of them take the torch pipeline on a fresh receiver, with the reason in the line.
             err = None
             try:
-                pipe = prod.pipeline(rx, rank, world, Tc, unique_id=uid, nbuf=nbuf)
-                if world > 1:                           # one whole step, so that the stream stays a whole number of periods long
-                    for c in range(rounds):
-                        pipe.push(mine[c], None if first_push[0] else halos[c], ready=True)
-                        first_push[0] = False
-                    rx.Discard()
-                    pipe.wait(); torch.cuda.synchronize()
-                    trial_steps = 1
+                with Watchdog("ncclCommInitRank + the first grouped ncclSend / ncclRecv exchange (C-ABI pipeline)", float(args.contact_timeout), rank, args):
+                    pipe = prod.pipeline(rx, rank, world, Tc, unique_id=uid, nbuf=nbuf)
+                    if world > 1:                           # one whole step, so that the stream stays a whole number of periods long
+                        for c in range(rounds):
+                            pipe.push(mine[c], None if first_push[0] else halos[c], ready=True)
+                            first_push[0] = False
+                        rx.Discard()
+                        pipe.wait(); torch.cuda.synchronize()
+                        trial_steps = 1
             except Exception as e:
                 err, pipe = repr(e), None
             all_ok = err is None
@@ -313,7 +363,19 @@ def main():
         xms, xn = pipe.exchange_ms()
         if xn:
             sent = pipe.bytes_sent_per_round()
-            xchg = {"ms_per_round": round(xms / xn, 4), "rounds_timed": xn, "bytes_sent_per_rank_and_round": sent,
+            # which exchange ran, and how many ranks the transport itself counts (the record must be able to answer "did RCCL see N ranks"):
+            # the C pipeline asks its communicator (ncclCommCount); the torch pipeline reports the process group's backend and size, and
+            # `ranks_seen_by_all_reduce` is the sum of ones a real all_reduce over that group produced at start-up
+            if world == 1:
+                xpath, rccl_ranks = "none: one rank, the channelizer writes into the synchronizers' buffer", None
+            elif use_c:
+                xpath, rccl_ranks = "c-abi: grouped ncclSend/ncclRecv on the pipeline's exchange stream (csrc/pipeline.hip)", pipe.comm_count()
+            elif rehearsal:
+                xpath, rccl_ranks = "rehearsal: all_to_all staged through host memory under gloo (every rank on one GPU) -- NOT RCCL", None
+            else:
+                xpath, rccl_ranks = "torch: torch.distributed.all_to_all_single on the %s backend (sharding.Pipeline)" % dist.get_backend(), dist.get_world_size()
+            xchg = {"path": xpath, "rccl_ranks": rccl_ranks, "ranks_seen_by_all_reduce": ranks_seen,
+                    "ms_per_round": round(xms / xn, 4), "rounds_timed": xn, "bytes_sent_per_rank_and_round": sent,
                     "GBps_out_of_each_rank": round(sent / (xms / xn * 1e-3) / 1e9, 2) if world > 1 else None,
                     "what": ("RCCL, HIP events on the exchange stream of rank 0 (%s)" % ("grouped ncclSend/ncclRecv behind the C-ABI" if use_c else "torch.distributed all_to_all_single")) if world > 1
                             else "local copy standing in for the exchange (one GPU)"}

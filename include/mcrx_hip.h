@@ -48,7 +48,9 @@ typedef struct mcrx_hip_s *mcrx_hip_t;
 
 typedef struct {
     uint32_t struct_size;        /* sizeof(mcrx_hip_config) */
-    uint32_t max_payload_len;    /* largest decodable payload [bytes]; 0 -> 2048 */
+    uint32_t max_payload_len;    /* largest decodable payload [bytes]; 0 -> 2048.  The per-frame buffers hold coded frames of up to
+                                    4 (max_payload_len + 4) + 16 bytes (two rate-1/2 codes); a frame that codes to more -- rep5 expands
+                                    five-fold -- or carries a longer payload is reported with payload_valid = 0 */
     uint32_t max_frames;         /* frame records kept between flushes; 0 -> auto (covers one host batch of
                                     the shortest possible frames on every channel) */
     uint32_t payload_soft;       /* 1 = soft-decision payload decoding (default), 0 = hard */
@@ -109,6 +111,9 @@ int  mcrx_hip_create(mcrx_hip_t *out, unsigned num_channels, unsigned M, unsigne
                      unsigned taper_len, const unsigned char *p, const mcrx_hip_config *cfg);
 int  mcrx_hip_destroy(mcrx_hip_t q);
 int  mcrx_hip_reset(mcrx_hip_t q);
+/* the same for a handle driven through the stage-level calls (mcrx_hip_sync: it never learns the stream position by itself):
+ * the synchronizers restart in SEEK at channel-rate sample `chan_position`.  What mcrx_hip_pipeline_reset calls. */
+int  mcrx_hip_reset_at(mcrx_hip_t q, uint64_t chan_position);
 unsigned mcrx_hip_num_channels(mcrx_hip_t q);
 
 /* push wideband cf32 samples (interleaved re,im).  Any n; partial blocks are buffered.  MCRX_EOVERFLOW: the
@@ -231,6 +236,20 @@ int      mcrx_hip_pipeline_push(mcrx_hip_pipeline_t p, const void *d_iq_sub, con
 /* the same from host memory: iq_with_halo = the 13 blocks in front of this rank's sub-slab, then the sub-slab ((13 + sub_blocks) * 2N
  * cf32, contiguous; zeros in front of the stream's first sub-slab).  What the sharded multichannelrx class calls */
 int      mcrx_hip_pipeline_push_host(mcrx_hip_pipeline_t p, const float *iq_with_halo);
+/* Lifetime: iq_with_halo may be reused as soon as push_host returns -- it is copied to a pinned staging buffer before the call comes
+ * back.  To skip that host copy, fill the buffer this call hands out ((13 + sub_blocks) * 2N cf32 = *nsamples; pinned; `nbuf` of them
+ * rotate) and pass it to the next push_host.  Neither call waits for a round's kernels, only for the host-to-device copy of the push
+ * `nbuf` rounds back. */
+int      mcrx_hip_pipeline_host_buffer(mcrx_hip_pipeline_t p, float **buf, size_t *nsamples);
+/* multichannelrx::Reset() for the sharded receiver (lib/multichannelrx.cc:135-153): called by every rank at the same point of the
+ * stream.  The oscillator is not reset (:144) and runs on the samples of the stream, so the caller says how the samples it pushed
+ * differ from the samples it was handed: extra_samples > 0 = handed but not pushed (a discarded partial round), < 0 = pushed but
+ * never in the stream (zero padding that completed the last round so that everything before the Reset got synchronized).
+ * Waits for everything pushed; decoded frames stay deliverable (poll / flush on the handle). */
+int      mcrx_hip_pipeline_reset(mcrx_hip_pipeline_t p, int64_t extra_samples);
+/* ranks of the RCCL communicator behind the exchange as RCCL counts them (ncclCommCount); 1 when world == 1 (no communicator);
+ * -1 when the loaded RCCL does not export the call */
+int      mcrx_hip_pipeline_comm_count(mcrx_hip_pipeline_t p);
 int      mcrx_hip_pipeline_wait(mcrx_hip_pipeline_t p);                              /* host wait for everything pushed */
 int      mcrx_hip_pipeline_time_exchange(mcrx_hip_pipeline_t p, int on);            /* HIP events around every exchange */
 int      mcrx_hip_pipeline_exchange_ms(mcrx_hip_pipeline_t p, double *total_ms, uint64_t *rounds, int reset);

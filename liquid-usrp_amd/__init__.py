@@ -60,6 +60,7 @@ _EXPORTS = {
     "mcrx_hip_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p]),
     "mcrx_hip_destroy": (C.c_int, [C.c_void_p]),
     "mcrx_hip_reset": (C.c_int, [C.c_void_p]),
+    "mcrx_hip_reset_at": (C.c_int, [C.c_void_p, C.c_uint64]),
     "mcrx_hip_num_channels": (C.c_uint, [C.c_void_p]),
     "mcrx_hip_execute_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "mcrx_hip_execute_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -101,6 +102,9 @@ _EXPORTS = {
     "mcrx_hip_pipeline_push": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mcrx_hip_pipeline_push_host": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mcrx_hip_pipeline_wait": (C.c_int, [C.c_void_p]),
+    "mcrx_hip_pipeline_host_buffer": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "mcrx_hip_pipeline_reset": (C.c_int, [C.c_void_p, C.c_int64]),
+    "mcrx_hip_pipeline_comm_count": (C.c_int, [C.c_void_p]),
     "mcrx_hip_pipeline_time_exchange": (C.c_int, [C.c_void_p, C.c_int]),
     "mcrx_hip_pipeline_exchange_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
     "mcrx_hip_pipeline_bytes_sent_per_round": (C.c_uint64, [C.c_void_p]),
@@ -514,6 +518,15 @@ class pipeline(object):
 
     def bytes_sent_per_round(self):
         return int(lib().mcrx_hip_pipeline_bytes_sent_per_round(self._h))
+
+    def comm_count(self):
+        """Ranks of the RCCL communicator behind the exchange, as ncclCommCount reports them (1 at world 1; -1: call missing)."""
+        return int(lib().mcrx_hip_pipeline_comm_count(self._h))
+
+    def reset(self, extra_samples=0):
+        """multichannelrx::Reset() for the sharded receiver (every rank, same point of the stream): mcrx_hip_pipeline_reset."""
+        self._chk(lib().mcrx_hip_pipeline_reset(self._h, int(extra_samples)), "reset")
+        self.rounds = 0
 
     def close(self):
         if self._h:

@@ -1408,3 +1408,14 @@ extern "C" int mcrx_hip_reset(mcrx_hip_t q)
     HIPCHK(hipDeviceSynchronize());
     return MCRX_OK;
 }
+extern "C" int mcrx_hip_reset_at(mcrx_hip_t q, uint64_t chan_position)
+{
+    if (!q) return fail(MCRX_EINVAL, "null handle");
+    HIPCHK(hipDeviceSynchronize());                      // stage-level launches run on the caller's and the handle's streams
+    int rc = harvest(q);
+    if (rc != MCRX_OK && rc != MCRX_EOVERFLOW) return rc;
+    q->chan_samples = (int64_t)chan_position;
+    RC(restart_async(q, q->stream, false));
+    HIPCHK(hipDeviceSynchronize());
+    return MCRX_OK;
+}

@@ -1,9 +1,9 @@
 // pipeline.hip -- the multi-GPU receive pipeline behind the C-ABI (include/mcrx_hip.h: mcrx_hip_pipeline_*).
 //
 // One process per GPU.  Sub-slabs of the wideband stream go round robin to the ranks (sub-slab u -> rank u % G); a round is
-//   A  channelize this rank's sub-slab into per-destination groups            out[g][tile][c][8], channel = g*Cg + c
+//   A  channelize this rank's sub-slab into per-destination groups            out[g][tile][c][16], channel = g*Cg + c (MCRX_TILE = 16)
 //   B  exchange: chunk g of rank r -> chunk r of rank g                         RCCL, grouped ncclSend / ncclRecv over xGMI
-//   C  synchronizer bank of the rank's channel shard over the round             recv[s][tile][c][8] = [tile of the round][c][8]
+//   C  synchronizer bank of the rank's channel shard over the round             recv[s][tile][c][16] = [tile of the round][c][16]
 // with `nbuf` rotating buffer sets, linked by events only -- channelize(c+1) || exchange(c) || sync(c-1) -- and nothing waits on
 // the host.  Two HIP streams of the pipeline's own carry this: one for stage A, one for stage B and the launch of stage C (whose
 // kernels run on the receiver handle's three internal streams anyway).  A third stream for C, as in rounds 2-3, put the process at
@@ -45,6 +45,7 @@ struct Rccl {
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;       // optional (reporting only)
     // every symbol is resolved into a candidate first and the table committed only when all of them were found (a partly filled
     // table behind a non-null `lib` would crash the next caller); once per process, thread safe
     std::once_flag once; bool ok = false;
@@ -64,6 +65,7 @@ struct Rccl {
             if (!all) { dlclose(h); return; }
             lib = h; GetUniqueId = t.GetUniqueId; CommInitRank = t.CommInitRank; CommDestroy = t.CommDestroy; GroupStart = t.GroupStart;
             GroupEnd = t.GroupEnd; Send = t.Send; Recv = t.Recv; GetErrorString = t.GetErrorString;
+            CommCount = reinterpret_cast<decltype(CommCount)>(dlsym(h, "ncclCommCount"));
             ok = true;
         });
         return ok;
@@ -86,7 +88,13 @@ struct mcrx_hip_pipeline_s {
     hipEvent_t evA[kMaxBuf] = {}, evB[kMaxBuf] = {}, evC[kMaxBuf] = {}, ev_after = nullptr;
     uint64_t ticket[kMaxBuf] = {}; bool has_ticket[kMaxBuf] = {};
     uint64_t rounds = 0;
+    uint64_t nco_base = 0;                                      // wideband samples in front of round 0 (the oscillator is never reset: lib/multichannelrx.cc:144)
+    uint64_t chan_base = 0;                                     // channel-rate position of round 0's first block (moves at a reset)
+    bool fresh_zeroed = true;                                   // recv[0]'s history tiles are zero already (creation); false after a reset: the first round zeroes them
     float *din[kMaxBuf] = {};                                   // push_host: this rank's sub-slab with its 13 halo blocks in front, rotating
+    float *hin[kMaxBuf] = {};                                   // ... and the pinned host buffers they are copied from (mcrx_hip_pipeline_host_buffer)
+    hipEvent_t evH[kMaxBuf] = {}; bool hin_busy[kMaxBuf] = {};  // recorded behind the copy out of hin[i]
+    uint64_t host_pushes = 0;
     ncclComm_t comm = nullptr;
     bool timing = false; std::vector<std::pair<hipEvent_t, hipEvent_t>> xev; size_t xused = 0; double x_ms = 0; uint64_t x_n = 0;
 };
@@ -112,6 +120,8 @@ extern "C" int mcrx_hip_pipeline_destroy(mcrx_hip_pipeline_t p)
     for (unsigned i = 0; i < kMaxBuf; i++) {
         if (p->recv[i]) (void)hipFree(p->recv[i]);
         if (p->din[i]) (void)hipFree(p->din[i]);
+        if (p->hin[i]) (void)hipHostFree(p->hin[i]);
+        if (p->evH[i]) (void)hipEventDestroy(p->evH[i]);
         if (p->world > 1 && p->out[i]) (void)hipFree(p->out[i]);
         hipEvent_t ev[3] = { p->evA[i], p->evB[i], p->evC[i] };
         for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
@@ -218,7 +228,7 @@ extern "C" int mcrx_hip_pipeline_push(mcrx_hip_pipeline_t p, const void *d_iq_su
             PCHK(hipStreamWaitEvent(p->sA, p->evC[(i + 1) % nb], 0));
         }
     }
-    const uint64_t first = (c * (uint64_t)p->world + (uint64_t)p->rank) * (uint64_t)p->Tc * (uint64_t)p->K;
+    const uint64_t first = p->nco_base + (c * (uint64_t)p->world + (uint64_t)p->rank) * (uint64_t)p->Tc * (uint64_t)p->K;
     PRC(mcrx_hip_channelize(p->rx, d_iq_sub, p->Tc, first, d_halo, out, (unsigned)p->world, p->sA));
     PCHK(hipEventRecord(p->evA[i], p->sA));
     // ---- B: time shards -> channel shards
@@ -252,9 +262,12 @@ extern "C" int mcrx_hip_pipeline_push(mcrx_hip_pipeline_t p, const void *d_iq_su
         const float *prev = p->recv[(c - 1) % nb];
         const size_t total = p->hist_elems + (size_t)p->world * p->per;
         PCHK(hipMemcpyAsync(recv, prev + 2 * (total - p->hist_elems), p->hist_elems * 2 * sizeof(float), hipMemcpyDeviceToDevice, p->sC));
+    } else if (!p->fresh_zeroed) {          // first round after a reset: what sits in front of it belongs to the stream before the reset
+        PCHK(hipMemsetAsync(recv, 0, p->hist_elems * 2 * sizeof(float), p->sC));
     }
+    p->fresh_zeroed = false;
     PCHK(hipEventRecord(p->evC[i], p->sC));
-    const int64_t first_chan = (int64_t)(c * (uint64_t)p->world * (uint64_t)p->Tc) - (int64_t)p->hist * MCRX_TILE;
+    const int64_t first_chan = (int64_t)(p->chan_base + c * (uint64_t)p->world * (uint64_t)p->Tc) - (int64_t)p->hist * MCRX_TILE;
     const size_t nsamp = (size_t)p->hist * MCRX_TILE + (size_t)p->world * p->Tc;
     PRC(mcrx_hip_sync(p->rx, recv, (uint64_t)first_chan, nsamp, p->sC));
     p->ticket[i] = mcrx_hip_launches(p->rx) - 1; p->has_ticket[i] = true;
@@ -263,16 +276,78 @@ extern "C" int mcrx_hip_pipeline_push(mcrx_hip_pipeline_t p, const void *d_iq_su
 }
 
 // The same round fed from host memory (the reference's Execute takes host buffers: lib/multichannelrx.cc:155): `iq` holds the 13
-// blocks in front of this rank's sub-slab followed by the sub-slab itself, (13 + sub_blocks) * 2N cf32, contiguous.  The copy goes
-// to one of the rotating device buffers on the channelizer's stream (its last reader, the channelizer of nbuf rounds ago, ran there).
+// blocks in front of this rank's sub-slab followed by the sub-slab itself, (13 + sub_blocks) * 2N cf32, contiguous.  The samples are
+// staged through `nbuf` rotating PINNED host buffers: a caller that fills the buffer mcrx_hip_pipeline_host_buffer() hands out pays no
+// copy; any other pointer is copied into that buffer first, so the caller's memory is free again when the call returns either way
+// (the call used to run hipMemcpyAsync from the caller's pageable buffer and say nothing about its lifetime).  The host
+// waits only for the copy out of the pinned buffer it is about to refill -- the push of nbuf rounds ago -- never for a round's kernels.
+static int host_slot(mcrx_hip_pipeline_t p, unsigned *slot)
+{
+    const unsigned i = (unsigned)(p->host_pushes % p->nbuf);
+    const size_t bytes = (size_t)(13 + p->Tc) * p->K * 2 * sizeof(float);
+    if (!p->hin[i]) {
+        PCHK(hipHostMalloc((void **)&p->hin[i], bytes, hipHostMallocDefault));
+        PCHK(hipMalloc((void **)&p->din[i], bytes));
+        PCHK(hipEventCreateWithFlags(&p->evH[i], hipEventDisableTiming));
+    }
+    if (p->hin_busy[i]) { PCHK(hipEventSynchronize(p->evH[i])); p->hin_busy[i] = false; }
+    *slot = i;
+    return MCRX_OK;
+}
+extern "C" int mcrx_hip_pipeline_host_buffer(mcrx_hip_pipeline_t p, float **buf, size_t *nsamples)
+{
+    if (!p || !buf) return pfail(MCRX_EINVAL, "null argument");
+    unsigned i = 0;
+    int rc = host_slot(p, &i);
+    if (rc != MCRX_OK) return rc;
+    *buf = p->hin[i];
+    if (nsamples) *nsamples = (size_t)(13 + p->Tc) * p->K;
+    return MCRX_OK;
+}
 extern "C" int mcrx_hip_pipeline_push_host(mcrx_hip_pipeline_t p, const float *iq_with_halo)
 {
     if (!p || !iq_with_halo) return pfail(MCRX_EINVAL, "null argument");
-    const unsigned i = (unsigned)(p->rounds % p->nbuf);
+    unsigned i = 0;
+    int rc = host_slot(p, &i);
+    if (rc != MCRX_OK) return rc;
     const size_t n = (size_t)(13 + p->Tc) * p->K;
-    if (!p->din[i]) PCHK(hipMalloc((void **)&p->din[i], n * 2 * sizeof(float)));
-    PCHK(hipMemcpyAsync(p->din[i], iq_with_halo, n * 2 * sizeof(float), hipMemcpyHostToDevice, p->sA));
+    if (iq_with_halo != p->hin[i]) memcpy(p->hin[i], iq_with_halo, n * 2 * sizeof(float));
+    // din[i]'s last reader, the channelizer of nbuf host pushes ago, ran on sA: the copy is ordered behind it there
+    PCHK(hipMemcpyAsync(p->din[i], p->hin[i], n * 2 * sizeof(float), hipMemcpyHostToDevice, p->sA));
+    PCHK(hipEventRecord(p->evH[i], p->sA));
+    p->hin_busy[i] = true; p->host_pushes++;
     return mcrx_hip_pipeline_push(p, p->din[i] + (size_t)13 * p->K * 2, p->din[i], MCRX_STREAM_READY);
+}
+
+// multichannelrx::Reset() on a sharded receiver (lib/multichannelrx.cc:135-153 -- legal mid-stream, lib/multichanneltxrx.cc:333 calls it):
+// synchronizers back to SEEK, channelizer windows empty (the caller's next halo is zeros), block alignment restarts with the next
+// sample; the oscillator runs on (:144), so the `dropped_samples` of the unfinished round the caller discards still count for its
+// phase: extra_samples = samples the caller was handed and did not push (> 0), or minus the samples it pushed that were never in the
+// stream (< 0: zero padding behind the last real sample of a round it completed itself so that everything before the Reset is
+// synchronized, as the reference has it).  Every rank calls this at the same point of the stream (they are all handed the same
+// calls); no exchange is needed.  Frames decoded so far stay deliverable through the handle.
+extern "C" int mcrx_hip_pipeline_reset(mcrx_hip_pipeline_t p, int64_t extra_samples)
+{
+    if (!p) return pfail(MCRX_EINVAL, "null handle");
+    PCHK(hipStreamSynchronize(p->sA)); PCHK(hipStreamSynchronize(p->sB)); PCHK(hipStreamSynchronize(p->sC));
+    const uint64_t blocks = p->rounds * (uint64_t)p->world * (uint64_t)p->Tc;
+    p->nco_base += blocks * (uint64_t)p->K + (uint64_t)extra_samples;          // (two's complement: a negative adjustment subtracts)
+    p->chan_base += blocks;
+    p->rounds = 0; p->fresh_zeroed = false;
+    for (unsigned i = 0; i < kMaxBuf; i++) p->has_ticket[i] = false;
+    PRC(mcrx_hip_reset_at(p->rx, p->chan_base));          // (waits for the device: nothing of the old stream is in flight after this)
+    return MCRX_OK;
+}
+
+// ranks of the RCCL communicator the exchange runs on, as RCCL itself counts them (1 without a communicator: world == 1); what a
+// benchmark line quotes to prove that N ranks took part.  -1: this RCCL has no ncclCommCount.
+extern "C" int mcrx_hip_pipeline_comm_count(mcrx_hip_pipeline_t p)
+{
+    if (!p) return -1;
+    if (!p->comm) return 1;
+    if (!g_rccl.CommCount) return -1;
+    int n = -1;
+    return g_rccl.CommCount(p->comm, &n) == ncclSuccess ? n : -1;
 }
 
 extern "C" int mcrx_hip_pipeline_wait(mcrx_hip_pipeline_t p)

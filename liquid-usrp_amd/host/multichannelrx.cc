@@ -24,15 +24,27 @@ struct multichannelrx::impl {
     std::vector<unsigned long> debug_frames;
     // Sharded over the GPUs of a node (one process per GPU), switched on from outside the unchanged application:
     //   MCRX_WORLD / MCRX_RANK   ranks of the job and this process's number (a launcher's WORLD_SIZE / RANK are taken as well)
-    //   MCRX_UID_FILE            where rank 0 leaves the 128-byte ncclUniqueId for the others (world > 1)
+    //   MCRX_UID_FILE            where rank 0 leaves the 128-byte ncclUniqueId for the others (world > 1); rank 0 removes what it finds
+    //                            there first and removes its own file again when the object goes
+    //   MCRX_JOB_ID              (optional) a string unique to this job, the same on every rank: it is appended to the file name and
+    //                            stored in the file, so that a rank can never pick up the id an earlier job left behind
     //   MCRX_SUB_BLOCKS          blocks of 2N samples per rank and round (default 8192)
     // Every rank is handed the whole wideband stream, like every process behind a shared radio would be; of each round of
     // world x sub_blocks blocks it channelizes sub-slab number `rank`, one exchange turns the time shards into channel shards, and
     // this object's callbacks fire for its shard of num_channels / world channels only (mcrx_hip_pipeline_*, csrc/pipeline.hip).
     mcrx_hip_pipeline_t pipe;
     int rank, world;
-    size_t sub_blocks, K, fill;                                     // fill: samples of the current round in `round` behind the halo
-    std::vector<std::complex<float> > round;                       // [13 halo blocks][world * sub_blocks blocks]
+    size_t sub_blocks, K, fill;                                     // fill: samples of the current round seen so far
+    // Of every round only this rank's part is kept: the 13 blocks in front of its sub-slab and the sub-slab, copied as they arrive
+    // into the pinned staging buffer the pipeline hands out (mcrx_hip_pipeline_host_buffer) -- (13 + sub_blocks) x 2N samples, not
+    // the round's world x sub_blocks x 2N (0.5 GB per process at 512 channels and 8 ranks until round 5).  Rank 0's halo is the tail
+    // of the previous round: the last 13 blocks of every round are remembered in `tail`.
+    float *mine;                                                    // pinned buffer of the round being collected (NULL: not asked for yet)
+    std::vector<std::complex<float> > tail;                         // [13 blocks]: the end of the round being collected = rank 0's next halo
+    std::string uid_path;                                           // rank 0: the file it wrote (removed at destruction)
+    void take(const std::complex<float> *x, size_t n);              // sharded Execute: n samples at position `fill` of the round
+    void push_round(multichannelrx *self);
+    size_t finish_round(multichannelrx *self);                      // zero the trailing partial block, pad the round with zeros, push it
 };
 
 static int env_int(const char *a, const char *b, int dflt)
@@ -47,7 +59,7 @@ multichannelrx::multichannelrx(unsigned int _num_channels, unsigned int _M, unsi
                                framesync_callback *_callback)
     : num_channels(_num_channels), pimpl(new impl)
 {
-    pimpl->h = NULL; pimpl->pipe = NULL;
+    pimpl->h = NULL; pimpl->pipe = NULL; pimpl->mine = NULL;
     pimpl->world = getenv("MCRX_WORLD") ? env_int("MCRX_WORLD", NULL, 1) : 0;       // 0: not sharded (the plain receiver, no pipeline in between)
     pimpl->rank = env_int("MCRX_RANK", "RANK", 0);
     pimpl->sub_blocks = (size_t)env_int("MCRX_SUB_BLOCKS", NULL, 8192) / MCRX_TILE * MCRX_TILE;
@@ -78,22 +90,36 @@ multichannelrx::multichannelrx(unsigned int _num_channels, unsigned int _M, unsi
     if (W > 0) {
         unsigned char uid[128];
         memset(uid, 0, sizeof(uid));
-        const char *uf = getenv("MCRX_UID_FILE");
+        const char *uf = getenv("MCRX_UID_FILE"), *job = getenv("MCRX_JOB_ID");
         bool ok = true;
         if (W > 1) {
+            // file = 128 bytes of ncclUniqueId + the job string (may be empty).  ADVICE r4: a second job on the same path used to read the
+            // first job's id before rank 0 had replaced it.  Now rank 0 removes whatever is there BEFORE it makes its id and removes its own
+            // file when the object goes; with MCRX_JOB_ID the name and the content are per job, which closes the window in which a reader
+            // that starts before rank 0 could still see the old file.
             ok = uf != NULL;
+            std::string path = ok ? std::string(uf) : std::string(), tag = job ? std::string(job) : std::string();
+            if (job) path += "." + tag;
             if (ok && pimpl->rank == 0) {           // rank 0 makes the id and leaves it where the others look (written aside, then renamed)
+                unlink(path.c_str());
                 ok = mcrx_hip_pipeline_unique_id(uid) == MCRX_OK;
-                std::string tmp = std::string(uf) + ".tmp";
+                std::string tmp = path + ".tmp";
                 FILE *f = ok ? fopen(tmp.c_str(), "wb") : NULL;
-                ok = f && fwrite(uid, 1, 128, f) == 128;
+                ok = f && fwrite(uid, 1, 128, f) == 128 && fwrite(tag.data(), 1, tag.size(), f) == tag.size();
                 if (f) fclose(f);
-                ok = ok && rename(tmp.c_str(), uf) == 0;
+                ok = ok && rename(tmp.c_str(), path.c_str()) == 0;
+                if (ok) pimpl->uid_path = path;
             } else if (ok) {
                 ok = false;
                 for (int t = 0; t < 600 && !ok; t++) {      // up to a minute
-                    FILE *f = fopen(uf, "rb");
-                    if (f) { ok = fread(uid, 1, 128, f) == 128; fclose(f); }
+                    FILE *f = fopen(path.c_str(), "rb");
+                    if (f) {
+                        char got[256]; memset(got, 0, sizeof(got));
+                        ok = fread(uid, 1, 128, f) == 128;
+                        const size_t nt = ok ? fread(got, 1, sizeof(got) - 1, f) : 0;
+                        ok = ok && std::string(got, nt) == tag;
+                        fclose(f);
+                    }
                     if (!ok) usleep(100000);
                 }
             }
@@ -105,7 +131,7 @@ multichannelrx::multichannelrx(unsigned int _num_channels, unsigned int _M, unsi
             delete pimpl;
             throw 0;
         }
-        pimpl->round.assign((13 + (size_t)W * pimpl->sub_blocks) * pimpl->K, std::complex<float>(0.f, 0.f));
+        pimpl->tail.assign(13 * pimpl->K, std::complex<float>(0.f, 0.f));
     }
     for (unsigned int i = 0; i < _num_channels; i++) {
         pimpl->userdata.push_back(_userdata ? _userdata[i] : NULL);
@@ -116,12 +142,20 @@ multichannelrx::multichannelrx(unsigned int _num_channels, unsigned int _M, unsi
 multichannelrx::~multichannelrx()
 {
     if (pimpl->h) {
-        if (pimpl->pipe) mcrx_hip_pipeline_wait(pimpl->pipe);
+        if (pimpl->pipe) {
+            // The stream ends here.  The reference has synchronized every sample it was given (lib/multichannelrx.cc:185-195); a sharded
+            // round needs every rank's part, so the unfinished round is padded with zeros and pushed -- by every rank: they all reach
+            // their destructor at the same point of the stream -- and what it held is delivered below.  (Flush() cannot do this: padding
+            // in the middle of a stream would move the block alignment of everything behind it.)
+            try { pimpl->finish_round(this); } catch (...) { }
+            mcrx_hip_pipeline_wait(pimpl->pipe);
+        }
         mcrx_hip_flush(pimpl->h);
         Deliver();
         if (pimpl->pipe) mcrx_hip_pipeline_destroy(pimpl->pipe);
         mcrx_hip_destroy(pimpl->h);
     }
+    if (!pimpl->uid_path.empty()) unlink(pimpl->uid_path.c_str());
     if (pimpl->debug_dir) {
         // the reference, built with BST_DEBUG, leaves liquid's internal dump of every synchronizer behind
         // (ofdmflexframesync_debug_print, lib/multichannelrx.cc:118-122: "framesync_channel%u.m"); here, with MCRX_DEBUG_DIR
@@ -167,33 +201,96 @@ void multichannelrx::Deliver()
 void multichannelrx::Reset()
 {
     std::lock_guard<std::recursive_mutex> lk(pimpl->mu);
+    if (pimpl->pipe) {
+        // sharded: the pipeline's round counter and the halo are part of the state a Reset clears.  The reference has
+        // synchronized every whole block pushed before the Reset and drops the partial one (lib/multichannelrx.cc:152,167-174); here the
+        // unfinished round is completed with zeros and pushed first -- block alignment restarts behind a Reset anyway, so the padding is
+        // invisible -- and the oscillator is told that the padding was never in the stream (it is not reset, :144, and the samples of the
+        // dropped partial block still count for it).  Every rank gets the same call at the same point of the stream.
+        const size_t real = pimpl->fill, pushed = pimpl->finish_round(this);         // pushed: 0 (nothing but a partial block) or a whole round
+        if (mcrx_hip_pipeline_reset(pimpl->pipe, (long long)real - (long long)pushed) != MCRX_OK) {
+            fprintf(stderr, "error: multichannelrx::Reset(), %s\n", mcrx_hip_pipeline_last_error());
+            throw 0;
+        }
+        pimpl->fill = 0;
+        std::fill(pimpl->tail.begin(), pimpl->tail.end(), std::complex<float>(0.f, 0.f));
+        if (pimpl->mine && pimpl->rank == 0) memset(pimpl->mine, 0, 13 * pimpl->K * sizeof(std::complex<float>));      // (a buffer taken but not pushed: its halo is the old tail)
+        Deliver();
+        return;
+    }
     mcrx_hip_reset(pimpl->h);
     Deliver();
+}
+
+// n samples at position `fill` of the round: keep what falls into this rank's part, [rank * T - 13 blocks, (rank + 1) * T) with
+// T = sub_blocks * 2N (rank 0: the 13 blocks come from the previous round's tail), and into the round's last 13 blocks
+void multichannelrx::impl::take(const std::complex<float> *x, size_t n)
+{
+    const size_t halo = 13 * K, T = sub_blocks * K, cap = (size_t)world * T;
+    if (!mine) {
+        size_t ns = 0;
+        if (mcrx_hip_pipeline_host_buffer(pipe, &mine, &ns) != MCRX_OK || ns != halo + T) {
+            fprintf(stderr, "error: multichannelrx::Execute(), %s\n", mcrx_hip_pipeline_last_error());
+            throw 0;
+        }
+        if (rank == 0) memcpy(mine, tail.data(), halo * sizeof(std::complex<float>));
+    }
+    std::complex<float> *dst = reinterpret_cast<std::complex<float> *>(mine);
+    const size_t a = fill, b = fill + n;                                    // [a, b) of the round
+    {   // this rank's part: round positions [lo, hi) -> dst[pos - lo + off]
+        const size_t lo = rank == 0 ? 0 : (size_t)rank * T - halo, hi = ((size_t)rank + 1) * T, off = rank == 0 ? halo : 0;
+        const size_t s = std::max(a, lo), e = std::min(b, hi);
+        if (s < e) memcpy(dst + (s - lo) + off, x + (s - a), (e - s) * sizeof(std::complex<float>));
+    }
+    {   // the round's tail
+        const size_t lo = cap - halo, s = std::max(a, lo), e = std::min(b, cap);
+        if (s < e) memcpy(tail.data() + (s - lo), x + (s - a), (e - s) * sizeof(std::complex<float>));
+    }
+    fill = b;
+}
+
+// The stream stops here (Reset, destruction): whole blocks collected so far are synchronized like the reference's, the partial block
+// behind them is dropped (zeroed), the rest of the round is zeros.  Returns the samples pushed (0: the round was empty).
+size_t multichannelrx::impl::finish_round(multichannelrx *self)
+{
+    if (!fill) return 0;
+    const size_t cap = (size_t)world * sub_blocks * K;
+    fill -= fill % K;                                                       // re-taking from here overwrites the partial block
+    if (!fill) return 0;
+    std::vector<std::complex<float> > zeros(std::min<size_t>(cap - fill, (size_t)1 << 20), std::complex<float>(0.f, 0.f));
+    while (fill < cap) take(zeros.data(), std::min(zeros.size(), cap - fill));
+    push_round(self);
+    return cap;
+}
+
+void multichannelrx::impl::push_round(multichannelrx *self)
+{
+    if (mcrx_hip_pipeline_push_host(pipe, mine) != MCRX_OK) {               // returns once the round is enqueued: nothing waits for its kernels
+        fprintf(stderr, "error: multichannelrx::Execute(), %s\n", mcrx_hip_pipeline_last_error());
+        throw 0;
+    }
+    mine = NULL; fill = 0;
+    const int rc = mcrx_hip_poll(h);                                        // the frames of the rounds before
+    if (rc == MCRX_EOVERFLOW)
+        fprintf(stderr, "warning: multichannelrx::Execute(), frame pool exhausted, %llu frames dropped so far\n",
+                (unsigned long long)mcrx_hip_frames_dropped(h));
+    if (mcrx_hip_frames_pending(h)) self->Deliver();
 }
 
 void multichannelrx::Execute(std::complex<float> *_x, unsigned int _num_samples)
 {
     std::lock_guard<std::recursive_mutex> lk(pimpl->mu);
     if (pimpl->pipe) {
-        // sharded: the stream is collected a round at a time; of every full round this rank's sub-slab (the 13 blocks in front of
-        // it included: they sit right there in the stream) goes to the GPU, and the frames of the rounds before come back
-        const size_t K = pimpl->K, halo = 13 * K, cap = (size_t)pimpl->world * pimpl->sub_blocks * K;
+        // sharded: of every round of world x sub_blocks blocks this rank keeps its own sub-slab and the 13 blocks in front of it, in a
+        // pinned buffer of the pipeline; a full round is pushed without waiting for the one before (the buffers rotate) and the frames
+        // of the rounds before come back through the poll
+        const size_t cap = (size_t)pimpl->world * pimpl->sub_blocks * pimpl->K;
         size_t done = 0;
         while (done < _num_samples) {
-            const size_t take = std::min<size_t>(_num_samples - done, cap - pimpl->fill);
-            memcpy(pimpl->round.data() + halo + pimpl->fill, _x + done, take * sizeof(std::complex<float>));
-            pimpl->fill += take; done += take;
-            if (pimpl->fill < cap) break;
-            const std::complex<float> *mine = pimpl->round.data() + (size_t)pimpl->rank * pimpl->sub_blocks * K;      // = halo of sub-slab `rank`
-            if (mcrx_hip_pipeline_push_host(pimpl->pipe, reinterpret_cast<const float *>(mine)) != MCRX_OK) {
-                fprintf(stderr, "error: multichannelrx::Execute(), %s\n", mcrx_hip_pipeline_last_error());
-                throw 0;
-            }
-            mcrx_hip_pipeline_wait(pimpl->pipe);                    // (the round buffer is about to be overwritten)
-            memmove(pimpl->round.data(), pimpl->round.data() + cap, halo * sizeof(std::complex<float>));             // the next round's first halo
-            pimpl->fill = 0;
-            mcrx_hip_poll(pimpl->h);
-            if (mcrx_hip_frames_pending(pimpl->h)) Deliver();
+            const size_t n = std::min<size_t>(_num_samples - done, cap - pimpl->fill);
+            pimpl->take(_x + done, n);
+            done += n;
+            if (pimpl->fill == cap) pimpl->push_round(this);
         }
         return;
     }

@@ -33,6 +33,26 @@ def test_bench_two_ranks_rehearsed_on_one_gpu(world):
     assert d["config"]["rehearsal_on_one_gpu"] is True and "sharding.Pipeline" in d["config"]["multi_gpu_path"]
     assert d["steps"] == 2 and d["repetitions"] == 2 and d["value"] > 0 and "exchange" in d
     assert d["config"]["receiver_hints_from_the_benchmark"].startswith("none")
+    # the fields the first real SCALE record will be read by: which exchange ran, how many ranks the transport counted,
+    # how many ranks a real all_reduce summed over -- in the rehearsal the exchange is NOT RCCL and the line has to say so
+    x = d["exchange"]
+    assert x["ranks_seen_by_all_reduce"] == world and x["path"].startswith("rehearsal") and "NOT RCCL" in x["path"] and x["rccl_ranks"] is None
+
+
+def test_a_hung_rendezvous_still_prints_a_line():
+    """Two ranks are announced and one is started: the rendezvous can never complete.  bench.py's watchdog makes rank 0 print a line with
+    value 0 and the stage that hung, and exit non-zero, instead of sitting there until the driver's clock runs out."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(clean_env(), RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--steps", "1", "--warmup", "0", "--no-cpu",
+           "--contact-timeout", "8"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
+    d = json.loads(lines[0])
+    assert d["value"] == 0.0 and "timed out" in d["error"] and "rendezvous" in d["error"] and d["n_gpus"] == 2
 
 
 def test_c_pipeline_failure_falls_back_on_every_rank():

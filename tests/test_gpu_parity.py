@@ -455,7 +455,9 @@ def test_short_block_codes_same_decisions_as_oracle(oracle, product, mod, fec0, 
     if snr_db is None:
         for f in ora.frames:
             assert sent[f.channel][(f.header[0] << 8) | f.header[1]] == (f.header, f.payload)
-    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=plen, payload_soft=soft)
+    # (a handle's buffers hold coded frames of up to 4 (max_payload_len + 4) + 16 bytes -- a double rate-1/2 code; rep5 expands five-fold,
+    #  so the limit is set with that in mind, as a caller expecting such frames would: include/mcrx_hip.h max_payload_len)
+    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=4 * plen, payload_soft=soft)
     rx.Execute(x); rx.Flush()
     w = check_frames(rx.frames, ora.frames, rel=1.0)
     assert w <= REL, w

@@ -59,6 +59,43 @@ def test_unchanged_reference_app_through_the_sharded_receiver(oracle, tmp_path):
     assert out.returncode != 0 and "MCRX_WORLD" in out.stderr
 
 
+def test_sharded_class_reset_in_mid_stream_and_end_of_stream(oracle, tmp_path):
+    """Reset() on the sharded class (it used to reset the handle only and leave the pipeline's round counter, halo and
+    partial round behind) and the samples of an unfinished round at destruction (they used to be lost).  host/shard_test.cc feeds the
+    class bulk pieces of uneven size, calls Reset() in the middle of a frame, and destroys the object right behind the last frame --
+    a point that is not a round boundary.  Plain class and sharded class (world = 1, rounds of 256 and of 4096 blocks: the second is
+    longer than the whole stream, so every frame is delivered by the reset's / the destructor's completion of the round) print the
+    same frames, and they are the frames the oracle receiver gets from the same calls."""
+    N, M, cp, tp = 4, 64, 8, 4
+    iq, sent = oracle.synth_traffic(N, M, cp, tp, 8, payload_len=150, seed=3)
+    iq = iq.astype(np.complex64)
+    f = tmp_path / "iq.bin"
+    iq.tofile(f)
+    host = os.path.join(ROOT, "liquid-usrp_amd", "host")
+    subprocess.check_call(["make", "-C", host, "-s"])
+    subprocess.check_call(["make", "-C", host, "-s", "shard_test"])
+    K = 2 * N
+    frame = len(iq) // 8                                      # roughly one frame period of wideband samples
+    reset_at = (3 * frame + frame // 2) // K * K + 3          # in the middle of the fourth frame, not on a block boundary
+    ora = oracle.MultiChannelRx(N, M, cp, tp)
+    ora.execute(iq[:reset_at]); ora.reset(); ora.execute(iq[reset_at:])
+    want = sorted((f_.channel, (f_.header[0] << 8) | f_.header[1], f_.payload_valid, len(f_.payload)) for f_ in ora.frames)
+    assert len(want) >= 6 * N and all(w[2] for w in want)
+    got = {}
+    for mode, extra in (("plain", {}), ("sharded256", {"MCRX_WORLD": "1", "MCRX_RANK": "0", "MCRX_SUB_BLOCKS": "256"}),
+                        ("sharded4096", {"MCRX_WORLD": "1", "MCRX_RANK": "0", "MCRX_SUB_BLOCKS": "4096"})):
+        out = subprocess.run([os.path.join(ROOT, "liquid-usrp_amd", "lib", "shard_test"), str(f), str(N), str(M), str(cp), str(tp), "10007", str(reset_at)],
+                             env=dict(os.environ, **extra), capture_output=True, text=True, timeout=180)
+        assert out.returncode == 0 and "done" in out.stdout, out.stderr[-2000:]
+        got[mode] = sorted((int(a), int(b), int(d), int(e)) for a, b, c, d, e in
+                           re.findall(r"frame ch (\d+) pid (\d+) hv (\d+) pv (\d+) len (\d+)", out.stdout))
+        sums = sorted(re.findall(r"frame (ch \d+ pid \d+) .* sum (\d+)", out.stdout))
+        got[mode + "_sums"] = sums
+    assert got["plain"] == want, (got["plain"], want)
+    assert got["sharded256"] == want and got["sharded4096"] == want
+    assert got["sharded256_sums"] == got["plain_sums"] == got["sharded4096_sums"]
+
+
 TXEXE = os.path.join(ROOT, "liquid-usrp_amd", "lib", "multichannel_tx_ref")
 
 
