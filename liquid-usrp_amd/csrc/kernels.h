@@ -214,6 +214,9 @@ struct SyncArgs {
     // missing prediction costs nothing but the two acquisitions again (the coarse start); the results never depend on it.
     int seg_phase;                       // 1: first frame from the entry state only (grid = channels); 2: the rest; 0: one launch, no cadence
     int64_t *anchor;                     // [nch] where phase 1's frame ended + 1 (-1: it did not hand a frame off)
+    int64_t *seekst;                     // [nch][2] the SEEK state (cur, timer) the acquisition a channel's push ENDED in was detected from: where that
+                                         // frame is re-acquired from if the next push defers it (a frame detected at the end of one push and deferred
+                                         // in the next used to go back to position 0 -- pushes shorter than a frame re-delivered the whole history)
     uint32_t *spec_hint;                 // host-mapped word: largest prediction count, sizes the next launch's grid
     uint32_t *walk_hint;                 // host-mapped word: frames the scouts had to acquire themselves so far (the host adds a full-width round while it moves)
     uint32_t *hint;             // host-mapped word: longest coded frame (bytes) among this launch's jobs

@@ -182,7 +182,7 @@ struct mcrx_hip_s {
     hipEvent_t ev_ready[MCRX_SLOTS] = {}, ev_scout[MCRX_SLOTS] = {}, ev_done[MCRX_SLOTS] = {}, ev_in = nullptr, ev_consumed = nullptr, ev_tmp[3] = {};
     int last_slot = -1; size_t last_ntiles = 0;     // where the synchronizer history (tail of the previous launch) sits
     uint32_t spec_stride = MCRX_SPEC_MAX;           // slots per channel in d_spec (grows when a push holds more frames per channel: launch_sync)
-    SpecSlot *d_spec = nullptr; float2 *d_spec_R = nullptr; int64_t *d_pred = nullptr, *d_anchor = nullptr; uint32_t *d_pred_n = nullptr;
+    SpecSlot *d_spec = nullptr; float2 *d_spec_R = nullptr; int64_t *d_pred = nullptr, *d_anchor = nullptr, *d_seekst = nullptr; uint32_t *d_pred_n = nullptr;
     bool spec = false;
     uint32_t *h_hint = nullptr, *d_hint = nullptr;     // pinned, device-mapped: longest coded frame of the last launch
     uint8_t *d_jsoft[MCRX_SLOTS] = {}, *d_jtmp[MCRX_SLOTS] = {};
@@ -447,6 +447,7 @@ static int restart_async(mcrx_hip_t q, hipStream_t st, bool from_zero)
                                  (from_zero && g == 0) ? q->d_pred_n : nullptr, st));
         q->gen_used[g] = false; q->gen_closed[g] = false; q->gen_abandoned[g] = false;
     }
+    if (q->d_seekst) HIPCHK(hipMemsetAsync(q->d_seekst, 0, (size_t)q->nch * 2 * sizeof(int64_t), st));     // (the synchronizers restart in SEEK: it is set before it is used)
     q->gen = 0;
     RC(fork_from(q, st));
     return MCRX_OK;
@@ -534,6 +535,7 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
         if ((rc = q->upload(&q->d_h1, h1.data(), h1.size()))) return bail(rc);
     }
     if ((rc = q->alloc(&q->d_st, q->nch))) return bail(rc);
+    if ((rc = q->alloc(&q->d_seekst, (size_t)q->nch * 2))) return bail(rc);
     if ((rc = q->alloc(&q->d_hbits, (size_t)q->nch * MCRX_HDR_SYMS))) return bail(rc);
     if ((rc = q->alloc(&q->d_R, (size_t)q->nch * M))) return bail(rc);
     if ((rc = q->alloc(&q->d_soft, (size_t)q->nch * 8 * q->max_enc))) return bail(rc);
@@ -761,7 +763,7 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     a.stats = q->d_stats;
     a.hint = q->d_hint; a.enc_hint = (q->h_hint && q->d_hint) ? *(volatile uint32_t *)q->h_hint : 0u;
     a.spec = q->d_spec; a.spec_stride = q->spec_stride; a.spec_R = q->d_spec_R; a.pred = nullptr; a.pred_n = nullptr; a.spec_cap = 0; a.spec_hint = nullptr; a.walk_hint = nullptr;
-    a.nseg = 0; a.seg_phase = 0; a.anchor = nullptr; a.seg_jobs = 1;
+    a.nseg = 0; a.seg_phase = 0; a.anchor = nullptr; a.seg_jobs = 1; a.seekst = q->d_seekst;
     hipStream_t sa = st, sw = st;
     // The host never waits for the device on this path (slots are handed over by stream waits), so a free-running caller
     // can be any number of launches ahead -- and the hints the kernels leave for the next launch (widest prediction list,

@@ -2247,6 +2247,7 @@ struct Walker {
         const int M = c.M, M2 = c.M2, L = c.L;
         const int phase = a.seg_phase;
         s = a.st[ch];
+        if (a.seekst) { sk_cur = a.seekst[2 * (size_t)ch]; sk_timer = (uint32_t)a.seekst[2 * (size_t)ch + 1]; }               // (segment 0 may start in the middle of an acquisition the previous push began)
         const bool mid_payload = s.state == SY_RX && s.fstate == FX_PAYLOAD;      // (a payload that runs through this whole push: the tail kernel's)
         const int64_t base = s.cur, span = a.end - base;
         const int64_t seg_len = span > 0 ? (span + (int64_t)a.nseg - 1) / (int64_t)a.nseg : 0;
@@ -2393,6 +2394,7 @@ struct Walker {
     __device__ __forceinline__ void run()
     {
         s = a.st[ch];
+        if (a.seekst) { sk_cur = a.seekst[2 * (size_t)ch]; sk_timer = (uint32_t)a.seekst[2 * (size_t)ch + 1]; }
         const bool mid_payload = s.state == SY_RX && s.fstate == FX_PAYLOAD;
         if constexpr (MODE == SYM_LEAN) { if (mid_payload) return; }
         else if (a.tail_only && !mid_payload) return;
@@ -2531,6 +2533,7 @@ struct Walker {
         // a header in progress continues in the next launch: its bits move from LDS to the channel's HBM slot
         if (fastp && s.state == SY_RX && s.fstate == FX_HEADER && s.header_symbol_index > 0)
             for (int i = l; i < MCRX_HDR_SYMS; i += WV) bhbits[i] = ldshb[i];
+        if (l == 0 && a.seekst) { a.seekst[2 * (size_t)ch] = sk_cur; a.seekst[2 * (size_t)ch + 1] = (int64_t)sk_timer; }
         if (l == 0) a.st[ch] = s;
     }
 };
@@ -2553,7 +2556,7 @@ __device__ __forceinline__ void launder(SyncArgs &a)
     LAUNDER(chan); LAUNDER(st); LAUNDER(hbits); LAUNDER(R); LAUNDER(soft); LAUNDER(tmpa); LAUNDER(tmpb);
     LAUNDER(syms); LAUNDER(rec); LAUNDER(arena); LAUNDER(sarena); LAUNDER(nrec); LAUNDER(arena_used);
     LAUNDER(jobs); LAUNDER(njobs); LAUNDER(jR); LAUNDER(jsoft); LAUNDER(jtmp); LAUNDER(vit_list); LAUNDER(qam_list); LAUNDER(hint); LAUNDER(live);
-    LAUNDER(spec); LAUNDER(spec_R); LAUNDER(pred); LAUNDER(pred_n); LAUNDER(stats); LAUNDER(walk_hint); LAUNDER(anchor);
+    LAUNDER(spec); LAUNDER(spec_R); LAUNDER(pred); LAUNDER(pred_n); LAUNDER(stats); LAUNDER(walk_hint); LAUNDER(anchor); LAUNDER(seekst);
 }
 #undef LAUNDER
 
