@@ -212,6 +212,7 @@ struct SyncArgs {
     // state at the first point of anchor + n * period_hint inside it -- if the half-symbol autocorrelation finds a preamble right
     // behind that point -- and a wave whose chain arrives exactly at the next segment's validated start stops there.  A wrong or
     // missing prediction costs nothing but the two acquisitions again (the coarse start); the results never depend on it.
+    int seg_walker;                      // 1: the Walker's build of the segment waves (sync_spec_kernel) where the lean one (acq_lean.hpp) would run
     int seg_phase;                       // 1: first frame from the entry state only (grid = channels); 2: the rest; 0: one launch, no cadence
     int64_t *anchor;                     // [nch] where phase 1's frame ended + 1 (-1: it did not hand a frame off)
     int64_t *seekst;                     // [nch][2] the SEEK state (cur, timer) the acquisition a channel's push ENDED in was detected from: where that
@@ -246,6 +247,7 @@ hipError_t sync_launch_tail(const SyncArgs &a, hipStream_t st);      // lean con
 hipError_t ilmap_build_launch(const uint32_t *d_lens, const uint32_t *d_offs, uint32_t nlen, uint8_t *d_lo, uint8_t *d_hi, uint16_t *d_map, hipStream_t st);
 hipError_t sync_launch_walk(const SyncArgs &a, hipStream_t st);      // the lean scout built without a register budget: for streams it has to walk by itself
 hipError_t sync_launch_lean(const SyncArgs &a, hipStream_t st);      // lean scout: acquisition + header + hand-off, one wave per channel
+int acq_lean_waves(const SyncConsts &c);
 hipError_t sync_launch_spec(const SyncArgs &a, hipStream_t st);      // segment-parallel acquisition: one wave per (channel, segment)
 // stage 0: record placement (one workgroup), 1: payload workers (one wave per handed-off frame),
 // 2: packet decode (one workgroup per frame; only after the lean workers -- the general ones decode in place)

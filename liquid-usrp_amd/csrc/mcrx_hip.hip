@@ -194,6 +194,7 @@ struct mcrx_hip_s {
     // workers per SIMD neither fits beside them any more, and a scout that adopts 100 frames of a channel pays for every spill:
     // 8 channels 54.7 -> 64.8 Gsample/s, 512 channels 166.4 -> 169.9 (same box, same run; MCRX_LEAN_BUILD)
     int lean_build = 1;
+    int seg_walker = 0;                     // mcrx_hip_config::scout_build = 2: the segment waves as the Walker's kernel, not acq_lean.hpp's
     // streaming state
     uint64_t total_samples = 0;             // wideband samples accepted since creation (NCO phase)
     uint64_t stage_first = 0;               // absolute index of h_stage[0]
@@ -565,7 +566,10 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
         if (wb >= 2) { q->payload_lean = 0; q->payload_fr = wb == 2 ? 1 : wb == 3 ? 2 : wb == 4 ? 4 : 0; }
         if (aq >= 1 && aq <= 3) q->acq_mode = (int)aq;
         no_spec_cfg = aq == 4;
-        if (field(offsetof(mcrx_hip_config, scout_build)) == 1) q->lean_build = 0;
+        const uint32_t sb = field(offsetof(mcrx_hip_config, scout_build));
+        if (sb > 2) return bail(fail(MCRX_EINVAL, "scout_build out of range"));
+        if (sb == 1) q->lean_build = 0;
+        if (sb == 2) q->seg_walker = 1;
     }
     if (devel_env("MCRX_PAYLOAD_FR")) q->payload_fr = atoi(devel_env("MCRX_PAYLOAD_FR"));
     if (devel_env("MCRX_PAYLOAD_LEAN")) q->payload_lean = atoi(devel_env("MCRX_PAYLOAD_LEAN")) != 0;
@@ -763,7 +767,7 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     a.stats = q->d_stats;
     a.hint = q->d_hint; a.enc_hint = (q->h_hint && q->d_hint) ? *(volatile uint32_t *)q->h_hint : 0u;
     a.spec = q->d_spec; a.spec_stride = q->spec_stride; a.spec_R = q->d_spec_R; a.pred = nullptr; a.pred_n = nullptr; a.spec_cap = 0; a.spec_hint = nullptr; a.walk_hint = nullptr;
-    a.nseg = 0; a.seg_phase = 0; a.anchor = nullptr; a.seg_jobs = 1; a.seekst = q->d_seekst;
+    a.nseg = 0; a.seg_phase = 0; a.anchor = nullptr; a.seg_jobs = 1; a.seekst = q->d_seekst; a.seg_walker = q->seg_walker;
     hipStream_t sa = st, sw = st;
     // The host never waits for the device on this path (slots are handed over by stream waits), so a free-running caller
     // can be any number of launches ahead -- and the hints the kernels leave for the next launch (widest prediction list,
@@ -807,7 +811,14 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
             if (want < fill) want = fill < F / 2.0f ? fill : F / 2.0f;
             // on a cadence the lattice starts make segments free (no wasted acquisitions), so chains go down to two frames while
             // all the waves still run at once (2 per SIMD): what a few-channel receiver's push is made of is this chain's latency
-            if (q->cadenced) { const float conc = 2048.0f / (float)q->nch, two = F / 2.0f; const float c2 = conc < two ? conc : two; if (want < c2) want = c2; }
+            // (the lean segment waves of the 64-subcarrier designs run acq_lean_waves() to a SIMD, and a frame there is a chain of ~15 us:
+            //  chains of ONE frame while every wave is resident at once)
+            if (q->cadenced) {
+                const int lw = q->seg_walker ? 0 : acq_lean_waves(q->sc);
+                const float conc = (lw ? 1024.0f * (float)lw : 2048.0f) / (float)q->nch, shortest = lw ? F : F / 2.0f;
+                const float c2 = conc < shortest ? conc : shortest;
+                if (want < c2) want = c2;
+            }
             // (a wave's slots: F / nseg * 1.25 + 4, at most half a window of the scouts' slot headers -- see spw below)
             const float least = 1.25f * F / (float)(MCRX_SPEC_MAX / 2 - 4);
             if (want < least) want = least;

@@ -3437,6 +3437,19 @@ hipError_t sy_launch_acq_e1(int what, const SyncArgs &a, unsigned grid, size_t l
 hipError_t sy_launch_acq_e2(int what, const SyncArgs &a, unsigned grid, size_t lds, hipStream_t st) { return sy_launch_acq_width<2>(what, a, grid, lds, st); }
 #endif
 
+// part 4 = the lean segment waves of the 64-subcarrier configurations (acq_lean.hpp)
+hipError_t acq_lean_launch(const SyncArgs &a, unsigned grid, hipStream_t st);
+int acq_lean_waves(const SyncConsts &c);        // waves per SIMD of the lean segment-wave kernel if this design takes it, else 0
+#if SY_PART < 0 || SY_PART == 4
+#include "acq_lean.hpp"
+int acq_lean_waves(const SyncConsts &c) { return (c.M == 64 && c.E == 1 && c.M_pilot <= 16 && c.M_pilot >= 1 && c.Nen <= 64) ? ACQ_LEAN_WAVES : 0; }
+hipError_t acq_lean_launch(const SyncArgs &a, unsigned grid, hipStream_t st)
+{
+    hipLaunchKernelGGL((acq_lean_kernel<63>), dim3(grid), dim3(WV), 0, st, a);
+    return hipGetLastError();
+}
+#endif
+
 #if SY_PART <= 0
 static hipError_t sy_launch(int what, const SyncArgs &a0, unsigned grid, size_t lds, hipStream_t st)
 {
@@ -3487,7 +3500,10 @@ hipError_t sync_launch_tail(const SyncArgs &a, hipStream_t st)
 hipError_t sync_launch_spec(const SyncArgs &a, hipStream_t st)
 {
     if (a.nch == 0 || a.spec_cap == 0 || a.nseg == 0) return hipSuccess;
-    return sy_launch(SYK_SPEC, a, a.seg_phase == 1 ? a.nch : a.nch * a.nseg, SY_LDS_BYTES(a.c.M), st);
+    const unsigned grid = a.seg_phase == 1 ? a.nch : a.nch * a.nseg;
+    // 64 subcarriers, the pilots inside one DPP row: the lean segment waves (acq_lean.hpp); everything else, and scout_build = 2: the Walker's
+    if (acq_lean_waves(a.c) && !a.seg_walker) return acq_lean_launch(a, grid, st);
+    return sy_launch(SYK_SPEC, a, grid, SY_LDS_BYTES(a.c.M), st);
 }
 
 // bytes of LDS a frame's soft bits get in this push's decode launch: 8 per coded byte, at most 56 KiB (longer frames
