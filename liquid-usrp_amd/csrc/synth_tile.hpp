@@ -235,6 +235,13 @@ __global__ __launch_bounds__(K / 2) void synth_kernel(TxSynthArgs a, uint32_t sl
     uint32_t gq = (uint32_t)(bstart < 0 ? 0 : bstart) / (uint32_t)a.L, iq = (uint32_t)(bstart < 0 ? 0 : bstart) % (uint32_t)a.L;
     gq = (uint32_t)uniform_i((int)gq); iq = (uint32_t)uniform_i((int)iq);
     uint32_t gf = 0, if_ = 0; bool okf = false;                         // ... of the round whose samples are in xq
+    // The overlap needs the PREVIOUS body's first `taper` samples.  They went through this thread's registers when that symbol's round
+    // with read offset 0 was consumed (i = cp; S0a: 2 cp), so they are kept from there -- 8 registers -- instead of being fetched again
+    // at every symbol start: 32 bytes used of a line that had been evicted by then, a ninth of the kernel's fetches (round 5).  Only a
+    // slab's first symbol start, whose predecessor's round belonged to the slab before, still asks memory (req_keep_g != gq - 1).
+    float4 keep[2] = { make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f) };
+    uint32_t req_keep_g = ~0u;                                          // symbol whose offset-0 round this workgroup has requested
+    bool keep_f = false, pq_f = false;                                  // the round in xq: is the offset-0 round of its symbol / its overlap comes from pq
     auto step = [&](long long &bb, uint32_t &g, uint32_t &i) {
         if (bb >= 0) { i += R; if (i >= (uint32_t)a.L) { i -= (uint32_t)a.L; g++; } }
         bb += R;
@@ -252,13 +259,17 @@ __global__ __launch_bounds__(K / 2) void synth_kernel(TxSynthArgs a, uint32_t sl
             if (a.symkind) { s0a = kq == TXK_S0A; s0b_q = kq == TXK_S0B; }
             else { const int sidx = (int)(gq % (uint32_t)a.S); s0a = sidx == 0; s0b_q = sidx == 1; }
             gf = gq; if_ = iq; okf = ok;
+            keep_f = ok && iq == (s0a ? 2u : 1u) * (uint32_t)a.cp;
+            const bool have_prev = iq == 0 && gq > 0 && req_keep_g == gq - 1u;
+            if (keep_f) req_keep_g = gq;
             const uint32_t gsc = ok ? gq : 0u;
             const float2 *x = xch + (size_t)gsc * xstep;
             const uint32_t base1 = (iq + (uint32_t)a.M - (uint32_t)a.cp) % (uint32_t)a.M, base2 = (iq + (uint32_t)a.M - 2u * (uint32_t)a.cp) % (uint32_t)a.M;
-            const float4 *xp = reinterpret_cast<const float4 *>(x + (s0a ? base2 : base1));
+            const float4 *xp = reinterpret_cast<const float4 *>(x + xs_at(a.xs_grp, s0a ? base2 : base1));      // (8 | base: one group of 8 samples)
 #pragma unroll
             for (int q = 0; q < 4; q++) xq[q] = xp[q];
-            if (iq == 0) {                                              // (uniform) the previous body's first samples: the overlap
+            pq_f = iq == 0 && !have_prev;
+            if (pq_f) {                                                 // (uniform) the previous body's first samples: the overlap
                 const float4 *pp = reinterpret_cast<const float4 *>(gsc > 0 ? x - xstep : x);
                 pq[0] = pp[0]; pq[1] = pp[1];
             }
@@ -273,10 +284,11 @@ __global__ __launch_bounds__(K / 2) void synth_kernel(TxSynthArgs a, uint32_t sl
 #pragma unroll
                 for (int r = 0; r < 8; r++) xin[r] = make_float2(0.f, 0.f);
             } else if (if_ == 0) {
+                const float4 o0 = pq_f ? pq[0] : keep[0], o1 = pq_f ? pq[1] : keep[1];
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     if (r < a.taper) {
-                        const float2 p = (r & 1) ? make_float2(pq[r / 2].z, pq[r / 2].w) : make_float2(pq[r / 2].x, pq[r / 2].y);
+                        const float2 p = r == 0 ? make_float2(o0.x, o0.y) : (r == 1 ? make_float2(o0.z, o0.w) : (r == 2 ? make_float2(o1.x, o1.y) : make_float2(o1.z, o1.w)));
                         const int kb = a.taper - 1 - r;
                         const float wa = twin[r], wb = gf > 0 ? (kb == 0 ? twin[0] : (kb == 1 ? twin[1] : (kb == 2 ? twin[2] : twin[3]))) : 0.f;
                         const float2 bl = taper_blend(xin[r], wa, p, wb);
@@ -284,6 +296,7 @@ __global__ __launch_bounds__(K / 2) void synth_kernel(TxSynthArgs a, uint32_t sl
                     }
                 }
             }
+            if (keep_f) { keep[0] = xq[0]; keep[1] = xq[1]; }          // (this body's first samples, as loaded: the next symbol's overlap)
             if (b0 + R > (long long)a.nblocks) {                        // (the stream's last, partly filled round)
 #pragma unroll
                 for (int r = 0; r < 8; r++) if (b0 + r >= (long long)a.nblocks) xin[r] = make_float2(0.f, 0.f);

@@ -36,12 +36,14 @@ struct TxSymArgs {
     const uint8_t *pay;         // [ch][frame][S_pay*M_data]
     float2 *xsym;               // [ch][frames*S][M], or symbol gs of channel ch at ch xs_ch + gs xs_sym when xs_sym != 0
     size_t xs_ch = 0, xs_sym = 0;
+    size_t xs_grp = 0;          // != 0: sample n of a body sits (n >> 3) xs_grp + (n & 7) behind its start (TxSynthArgs::xs_grp)
     uint32_t nch;
     // ragged traffic (mctx_hip_generate_ragged): frames of different lengths anywhere on the channel's symbol axis.
     // frames = 1, S = symbols of the whole axis; symdesc[ch][S] says what symbol gs is: kind | s << 8 | row << 32
     // (kind: TXK_* below; s: index inside its frame; row: its M_data bytes in hdr / pay)
     const unsigned long long *symdesc = nullptr;
 };
+__device__ __forceinline__ size_t xs_at(size_t xs_grp, uint32_t n);
 enum { TXK_IDLE = 0, TXK_S0A = 1, TXK_S0B = 2, TXK_S1 = 3, TXK_HDR = 4, TXK_PAY = 5, TXK_TAIL = 6 };
 
 __device__ __forceinline__ unsigned gray_dec_t(unsigned x) { unsigned y = x; while (x >>= 1) y ^= x; return y; }
@@ -103,7 +105,7 @@ __device__ __forceinline__ void txsym_emit(const TxSymArgs &a, const uint32_t gs
     float2 *dst = a.xsym + (a.xs_sym ? (size_t)ch * a.xs_ch + (size_t)gs * a.xs_sym : ((size_t)ch * a.frames * a.S + gs) * a.M);
     if (w.table) {                                  // S0a, S0b, S1 bodies come from the tables; tail (and idle symbols) have none
         const float2 *src = (w.s == 2) ? a.s1t : a.s0t;
-        for (int i = l; i < a.M; i += TXW) dst[i] = w.zero ? make_float2(0.f, 0.f) : src[i];
+        for (int i = l; i < a.M; i += TXW) dst[xs_at(a.xs_grp, (uint32_t)i)] = w.zero ? make_float2(0.f, 0.f) : src[i];
         return;
     }
     float2 x[E];
@@ -144,7 +146,7 @@ __device__ __forceinline__ void txsym_emit(const TxSymArgs &a, const uint32_t gs
         const int i = l + TXW * e;
         if (i < a.M) {
             const int n = (int)(__brev((unsigned)i) >> (32 - a.log2M));
-            dst[n] = make_float2(x[e].x, -x[e].y);
+            dst[xs_at(a.xs_grp, (uint32_t)n)] = make_float2(x[e].x, -x[e].y);
         }
     }
 }
@@ -194,14 +196,18 @@ __global__ __launch_bounds__(TXW) void txsym_kernel(TxSymArgs a, uint32_t nsym)
 __global__ __launch_bounds__(TXW) void txsym64_kernel(TxSymArgs a, uint32_t nsym)
 {
     const int l = threadIdx.x & 63, j = l & 7;
-    const uint32_t ch = blockIdx.y;
-    const uint32_t gs_raw = blockIdx.x * TXSYM_PER + (uint32_t)(l >> 3);
+    // (bodies in channel-interleaved groups, TxSynthArgs::xs_grp: a lane's 64 bytes are half a cache line whose other half is the
+    //  neighbouring CHANNEL's -- the wave then takes four symbols of two channels, so that its stores are whole lines)
+    const bool pair = a.xs_grp != 0 && (a.nch & 1u) == 0;
+    const uint32_t per = pair ? TXSYM_PER / 2 : TXSYM_PER;
+    const uint32_t ch = pair ? 2u * blockIdx.y + (uint32_t)((l >> 3) & 1) : blockIdx.y;
+    const uint32_t gs_raw = blockIdx.x * per + (uint32_t)(pair ? (l >> 4) : (l >> 3));
     const bool live = gs_raw < nsym;
     const uint32_t gs = live ? gs_raw : nsym - 1;
     // what this group's symbol is, and its bytes (requested first: everything below up to the modulator is independent of them)
     const unsigned long long d = a.symdesc ? a.symdesc[(size_t)ch * a.S + gs] : 0ull;
     // (frame and index of the wave's first symbol by one scalar division, the lane's own by walking on from there)
-    const uint32_t gs0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * TXSYM_PER));
+    const uint32_t gs0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * per));
     int f = (int)(gs0 / (uint32_t)a.S), sidx = (int)(gs0 % (uint32_t)a.S) + (int)(gs - gs0);
     while (sidx >= a.S) { sidx -= a.S; f++; }
     const TxSymWhat w = txsym_what(a, gs, ch, d, f, sidx);
@@ -263,7 +269,7 @@ __global__ __launch_bounds__(TXW) void txsym64_kernel(TxSymArgs a, uint32_t nsym
     if (!live) return;
     // position j + 8 e holds X[8 bitrev3(j) + bitrev3(e)]
     const int n0 = 8 * (int)(__brev((unsigned)j) >> 29);
-    float2 *dst = a.xsym + (a.xs_sym ? (size_t)ch * a.xs_ch + (size_t)gs * a.xs_sym : ((size_t)ch * a.frames * a.S + gs) * a.M) + n0;
+    float2 *dst = a.xsym + (a.xs_sym ? (size_t)ch * a.xs_ch + (size_t)gs * a.xs_sym : ((size_t)ch * a.frames * a.S + gs) * a.M) + xs_at(a.xs_grp, (uint32_t)n0);      // (n0 is a multiple of 8: one group)
     float2 o[8];
 #pragma unroll
     for (int m = 0; m < 8; m++) {
@@ -290,7 +296,7 @@ __global__ __launch_bounds__(TXW) void txsym_dft_kernel(TxSymArgs a)
     float2 *dst = a.xsym + (a.xs_sym ? (size_t)ch * a.xs_ch + (size_t)gs * a.xs_sym : ((size_t)ch * a.frames * a.S + gs) * a.M);
     if (s < 3 || s == a.S - 1) {
         const float2 *src = (s == 2) ? a.s1t : a.s0t;
-        for (int i = l; i < a.M; i += TXW) dst[i] = (s == a.S - 1) ? make_float2(0.f, 0.f) : src[i];
+        for (int i = l; i < a.M; i += TXW) dst[xs_at(a.xs_grp, (uint32_t)i)] = (s == a.S - 1) ? make_float2(0.f, 0.f) : src[i];
         return;
     }
     const bool is_hdr = s < 3 + a.S_hdr;
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(TXW) void txsym_dft_kernel(TxSymArgs a)
             acc.y += X[k].x * sn + X[k].y * cs;
             kn += (uint32_t)n; if (kn >= (uint32_t)a.M) kn -= (uint32_t)a.M;
         }
-        dst[n] = acc;
+        dst[xs_at(a.xs_grp, (uint32_t)n)] = acc;
     }
 }
 
@@ -326,6 +332,14 @@ struct TxSynthArgs {
     // (the fused synthesis kernel reads 64 B of every channel per round: with the channel as the slow axis those are 512
     // pages a round, with the symbol as the slow axis one 32 KB span)
     size_t xs_ch = 0, xs_sym = 0;   // elements between channels / between a channel's consecutive symbols (0: the legacy layout)
+    // Round 5: bodies in groups of 8 samples with the CHANNEL between the groups -- [symbol][M / 8][channel][8]: xs_ch = 8, xs_grp = 8 N,
+    // xs_sym = N M; sample n of a body sits (n >> 3) xs_grp + (n & 7) behind its start.  A round of the fused synthesis kernel reads 64 B
+    // = one group of every channel: with the channel's M samples contiguous (rounds 3-4) that was HALF of a 128-byte line per thread,
+    // the other half being the same thread's next round -- and a line fetched for one half is fetched again for the other (FETCH_SIZE
+    // 1.86 x the bytes used, profiles/r4_t5_traffic.json; profiles/r4_fetchcal.txt: a half-line read moves the line).  With the channel
+    // between the groups the two halves of a line are two neighbouring threads' requests of the SAME round: whole lines, once.
+    // 0 = the samples of a body are contiguous.
+    size_t xs_grp = 0;
     size_t ks_ch = 0, ks_sym = 0;   // the same for symkind
     const float *taps;          // 26*K synthesis prototype
     float2 *v;                  // [nblocks][K] inverse-FFT outputs
@@ -356,6 +370,8 @@ __device__ __forceinline__ float2 taper_blend(float2 v, float wa, float2 p, floa
 }
 // batch / ragged layout only (no streaming slots): the caller walks (gs, i) itself
 __device__ __forceinline__ size_t xs_sym_of(const TxSynthArgs &a) { return a.xs_sym ? a.xs_sym : (size_t)a.M; }
+// where sample n of a symbol body sits behind the body's start (TxSynthArgs::xs_grp)
+__device__ __forceinline__ size_t xs_at(size_t xs_grp, uint32_t n) { return xs_grp ? (size_t)(n >> 3) * xs_grp + (size_t)(n & 7u) : (size_t)n; }
 __device__ __forceinline__ const float2 *xs_channel(const TxSynthArgs &a, uint32_t ch)
 {
     return a.xsym + (a.xs_sym ? (size_t)ch * a.xs_ch : (size_t)ch * a.frames * a.S * a.M);
@@ -394,19 +410,19 @@ __device__ __forceinline__ float2 frame_sample_sym(const TxSynthArgs &a, uint32_
     const float2 *x = xb + (size_t)gs * xs;
     const int M = a.M, cp = a.cp;
     if (s == 0) {                                   // S0a: shifted copy, ramp up only
-        float2 v = x[(i + M - 2 * cp) % M];
+        float2 v = x[xs_at(a.xs_grp, (i + M - 2 * cp) % M)];
         if ((int)i < a.taper) { v.x *= a.taperwin[i]; v.y *= a.taperwin[i]; }
         return v;
     }
-    if (s == 1) return x[(i + M - cp) % M];         // S0b: plain cyclic extension
+    if (s == 1) return x[xs_at(a.xs_grp, (i + M - cp) % M)];         // S0b: plain cyclic extension
     if (s == S - 1) {                               // tail: previous symbol's postfix ramping down
         if ((int)i >= a.taper) return make_float2(0.f, 0.f);
-        const float2 p = (x - xs)[i]; const float b = a.taperwin[a.taper - 1 - i];
+        const float2 p = (x - xs)[xs_at(a.xs_grp, i)]; const float b = a.taperwin[a.taper - 1 - i];
         return make_float2(p.x * b, p.y * b);
     }
-    float2 v = x[(i + M - cp) % M];
+    float2 v = x[xs_at(a.xs_grp, (i + M - cp) % M)];
     if ((int)i < a.taper) {
-        const float2 p = (x - xs)[i];                // first samples of the previous symbol body (S0b: s0)
+        const float2 p = (x - xs)[xs_at(a.xs_grp, i)];                // first samples of the previous symbol body (S0b: s0)
         const float wa = a.taperwin[i], wb = a.taperwin[a.taper - 1 - i];
         v = taper_blend(v, wa, p, wb);
     }
@@ -516,7 +532,7 @@ __global__ void txtiles_kernel(TxSynthArgs a, long long first_block, uint32_t nt
         const size_t xs = xs_sym_of(a);
         const float2 *x = xs_channel(a, c) + (size_t)gs * xs;
         const uint32_t base = (i + (uint32_t)a.M - (sidx == 0 ? 2u : 1u) * (uint32_t)a.cp) % (uint32_t)a.M;
-        const float4 *xp = reinterpret_cast<const float4 *>(x + base);
+        const float4 *xp = reinterpret_cast<const float4 *>(x + xs_at(a.xs_grp, base));      // (base is a multiple of 8: one group, 64 contiguous bytes in either layout)
         float4 q4[4];
 #pragma unroll
         for (int t = 0; t < 4; t++) q4[t] = xp[t];
@@ -702,10 +718,12 @@ extern "C" int mctx_hip_generate(mctx_hip_t q, void *d_iq, size_t nblocks, unsig
     sa.g_data = 1.0f / sqrtf((float)(q->od.M_pilot + q->od.M_data));
     sa.sctype = q->d_sctype; sa.data_rank = q->d_drank; sa.pilot_rank = q->d_prank; sa.pilot_seq = q->d_pseq;
     sa.s0t = q->d_s0t; sa.s1t = q->d_s1t; sa.hdr = d_hdr; sa.pay = d_pay; sa.xsym = d_xsym; sa.nch = N; sa.xs_ch = M; sa.xs_sym = (size_t)N * M;   // symbol-major: see TxSynthArgs
+    if (M % 8 == 0) { sa.xs_ch = 8; sa.xs_grp = (size_t)8 * N; }                                   // ... in groups of 8 samples with the channel between them
     { int rc = tx_launch_sym(q, sa, (unsigned)nsym, N, st); if (rc) return rc; }
     TxSynthArgs ya;
     ya.M = (int)M; ya.cp = (int)q->cp; ya.taper = (int)q->taper; ya.L = (int)(M + q->cp); ya.S = (int)S; ya.frames = (int)frames;
     ya.taperwin = q->d_taper; ya.xsym = d_xsym; ya.xs_ch = M; ya.xs_sym = (size_t)N * M; ya.taps = q->d_taps; ya.v = d_v; ya.out = (float2 *)d_iq;
+    ya.xs_ch = sa.xs_ch; ya.xs_grp = sa.xs_grp;
     ya.nblocks = (uint32_t)nblocks; ya.N = N; ya.dtheta = q->dtheta; ya.first_sample_lo = 0; ya.gain = gain;
     ya.ft0 = nullptr; ya.fS = nullptr; ya.xstride = 0; ya.b_first = 0; ya.hist = 0;
     { int rc = tx_synthesize(q, ya, st); if (rc) return rc; }
@@ -791,10 +809,12 @@ extern "C" int mctx_hip_generate_ragged(mctx_hip_t q, void *d_iq, size_t nblocks
     sa.g_data = 1.0f / sqrtf((float)(q->od.M_pilot + q->od.M_data));
     sa.sctype = q->d_sctype; sa.data_rank = q->d_drank; sa.pilot_rank = q->d_prank; sa.pilot_seq = q->d_pseq;
     sa.s0t = q->d_s0t; sa.s1t = q->d_s1t; sa.hdr = d_hdr; sa.pay = d_pay; sa.xsym = d_xsym; sa.nch = N; sa.symdesc = d_desc; sa.xs_ch = M; sa.xs_sym = (size_t)N * M;
+    if (M % 8 == 0) { sa.xs_ch = 8; sa.xs_grp = (size_t)8 * N; }
     { int rc = tx_launch_sym(q, sa, (unsigned)T, N, st); if (rc) return rc; }
     TxSynthArgs ya;
     ya.M = (int)M; ya.cp = (int)q->cp; ya.taper = (int)q->taper; ya.L = (int)L; ya.S = (int)T; ya.frames = 1;
     ya.taperwin = q->d_taper; ya.xsym = d_xsym; ya.xs_ch = M; ya.xs_sym = (size_t)N * M; ya.ks_ch = 1; ya.ks_sym = N; ya.taps = q->d_taps; ya.v = d_v; ya.out = (float2 *)d_iq;
+    ya.xs_ch = sa.xs_ch; ya.xs_grp = sa.xs_grp;
     ya.nblocks = (uint32_t)nblocks; ya.N = N; ya.dtheta = q->dtheta; ya.first_sample_lo = 0; ya.gain = gain;
     ya.ft0 = nullptr; ya.fS = nullptr; ya.xstride = 0; ya.b_first = 0; ya.hist = 0; ya.symkind = d_kind;
     { int rc = tx_synthesize(q, ya, st); if (rc) return rc; }
@@ -860,6 +880,7 @@ extern "C" int mctx_hip_traffic_create(mctx_hip_t q, mctx_hip_traffic_t *out, un
     sa.g_data = 1.0f / sqrtf((float)(q->od.M_pilot + q->od.M_data));
     sa.sctype = q->d_sctype; sa.data_rank = q->d_drank; sa.pilot_rank = q->d_prank; sa.pilot_seq = q->d_pseq;
     sa.s0t = q->d_s0t; sa.s1t = q->d_s1t; sa.hdr = d_hdr; sa.pay = d_pay; sa.xsym = d_xsym; sa.nch = ch_count; sa.xs_ch = M; sa.xs_sym = (size_t)ch_count * M;      // symbol-major, like the generators
+    if (M % 8 == 0) { sa.xs_ch = 8; sa.xs_grp = (size_t)8 * ch_count; }
     { int rc = tx_launch_sym(q, sa, (unsigned)nsym, ch_count, st); if (rc) return rc; }
     TXCHK(hipStreamSynchronize(st));
     (void)hipFree(d_hdr); (void)hipFree(d_pay);
@@ -887,6 +908,7 @@ extern "C" int mctx_hip_traffic_tiles(mctx_hip_traffic_t t, long long first_bloc
     ya.M = (int)q->M; ya.cp = (int)q->cp; ya.taper = (int)q->taper; ya.L = (int)(q->M + q->cp); ya.S = (int)t->S; ya.frames = (int)t->frames;
     ya.taperwin = q->d_taper; ya.xsym = t->d_xsym; ya.taps = q->d_taps; ya.v = nullptr; ya.out = nullptr;
     ya.xs_ch = q->M; ya.xs_sym = (size_t)t->ch_count * q->M;
+    if (q->M % 8 == 0) { ya.xs_ch = 8; ya.xs_grp = (size_t)8 * t->ch_count; }
     ya.nblocks = (uint32_t)nblocks; ya.N = t->ch_count; ya.dtheta = 0; ya.first_sample_lo = 0; ya.gain = 1.0f;
     ya.ft0 = nullptr; ya.fS = nullptr; ya.xstride = 0; ya.b_first = 0; ya.hist = 0;
     const uint32_t ntiles = (uint32_t)(nblocks / 8), n = ntiles * t->ch_count;
@@ -942,7 +964,9 @@ static int tx_launch_sym(mctx_hip_t q, const TxSymArgs &sa, unsigned nsym, unsig
     }
     static const bool wide = devel_env("MCTX_TXSYM64") == nullptr || atoi(devel_env("MCTX_TXSYM64")) != 0;      // (0: the one-point-per-lane kernel, comparisons)
     if (q->M == 64 && wide && (sa.xs_sym % 2) == 0 && (sa.xs_ch % 2) == 0) {
-        hipLaunchKernelGGL(txsym64_kernel, gsym8, dim3(TXW), 0, st, sa, nsym);
+        const bool pair = sa.xs_grp != 0 && (sa.nch & 1u) == 0 && sa.nch == nch;          // (txsym64_kernel: four symbols of two channels per wave)
+        const dim3 g64 = pair ? dim3((nsym + TXSYM_PER / 2 - 1) / (TXSYM_PER / 2), nch / 2) : gsym8;
+        hipLaunchKernelGGL(txsym64_kernel, g64, dim3(TXW), 0, st, sa, nsym);
         TXCHK(hipGetLastError());
         return MCRX_OK;
     }
