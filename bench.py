@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-harvest", action="store_true")
     ap.add_argument("--no-aperiodic", action="store_true", help="skip the ragged-traffic leg (value_aperiodic)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the headline's variants (30 dB AWGN on the wideband samples; equalised symbols not stored)")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE.json configurations (the `configs` block)")
     ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed region of --steps steps: value = median, value_min / value_max beside it")
     ap.add_argument("--aperiodic-steps", type=int, default=20)
@@ -406,6 +407,9 @@ def main():
     aper = None
     if world == 1 and not args.no_aperiodic and not args.pipeline:
         aper = aperiodic_leg(prod, N, M, cp, taper, slab_blocks[:args.slabs], K, args, torch, dev)
+    variants = None
+    if world == 1 and not args.no_variants and not args.pipeline and not args.serial:
+        variants = variant_legs(prod, N, M, cp, taper, cfg, slabs, sents, args, torch, dev)
     cfgs = None
     if world == 1 and not args.no_configs and not args.pipeline:
         cfgs = configs_block(prod, torch, dev, args)
@@ -489,6 +493,8 @@ def main():
         if aper:
             out.update(aper)
             out["value_aperiodic_over_value"] = round(aper["value_aperiodic"] / value, 4)
+        if variants:
+            out.update(variants)
         if cfgs:
             out["configs"] = cfgs
         if not args.no_cpu and world == 1:                     # the CPU leg is reported at N = 1 only
@@ -679,6 +685,56 @@ def aperiodic_leg(prod, N, M, cp, taper, slab_blocks, K, args, torch, dev):
                                                             "starts underneath (reference behaviour, same in the oracle): ok = nothing valid differs "
                                                             "from what was sent and >= 99.5 % of the sent frames arrive",
                                                     "ok": wrong == 0 and ok >= 0.995 * sum(nfr_slab)}}}
+
+
+def variant_legs(prod, N, M, cp, taper, cfg, slabs, sent_idx, args, torch, dev):
+    """The headline's loop -- the same slabs through one un-restarted receiver, frames dropped on the device -- under two changed
+    conditions, each verified on one more harvested step:
+    value_awgn30: white noise 30 dB below the wideband signal on every sample (BASELINE.md section 2 / SURVEY 8d: "optional seeded
+      AWGN at 30 dB SNR (seed 1)"): the clean channel is the one place where a stage's cost depends on the data (decode_kernel forms
+      its Hamming neighbour distances only in waves with a non-zero syndrome), so the driver's line carries the noisy figure too;
+    value_without_framesyms: mcrx_hip_config::skip_framesyms = 2 -- the payload workers do not store the equalised symbols (8 B per
+      data symbol, a third of what that stage moves): what materialising stats.framesyms for callbacks that never read it costs."""
+    res = {}
+    samples = sum(int(d.numel()) for d in slabs)
+    steps = max(4, args.steps // 2)
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    noisy = []
+    for d in slabs:
+        v = torch.view_as_real(d)
+        rms = float(torch.sqrt(torch.mean(v * v) * 2.0))                   # rms of the complex samples
+        nstd = rms * 10.0 ** (-30.0 / 20.0) / np.sqrt(2.0)
+        noisy.append(torch.view_as_complex(v + nstd * torch.randn(v.shape, generator=g, device=dev, dtype=v.dtype)))
+    for name, inputs, extra in (("value_awgn30", noisy, {}), ("value_without_framesyms", slabs, {"skip_framesyms": 2})):
+        rx = prod.multichannelrx(N, M, cp, taper, **dict(cfg, **extra))
+
+        def step(keep=False):
+            for d in inputs:
+                rx.Execute(d)
+                rx.Poll() if keep else rx.Discard()
+        for _ in range(max(2, args.warmup)):
+            step()
+        torch.cuda.synchronize()
+        rx.kernel_stats(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ovl = {k: round(v[0] / max(v[1], 1), 4) for k, v in rx.kernel_stats().items()}
+        rx.Flush(); rx.frames.clear()
+        step(keep=True); rx.Flush()
+        nfr = len(rx.frames)
+        ok = sum(1 for f in rx.frames if f.header_valid and f.payload_valid and
+                 any(sn[f.channel].get((f.header[0] << 8) | f.header[1]) == (f.header, f.payload) for sn in sent_idx))
+        rx.close()
+        res[name] = round(samples * steps / dt / 1e6, 3)
+        res[name + "_detail"] = {"steps": steps, "kernels_ms_overlapped": ovl,
+                                 "verified": {"frames": nfr, "expected": N * args.frames * len(slabs), "bit_exact_payloads": ok,
+                                              "ok": nfr == N * args.frames * len(slabs) and ok == nfr}}
+    del noisy
+    torch.cuda.empty_cache()
+    return res
 
 
 def harvest_legs(prod, N, M, cp, taper, cfg, slabs, K, args, torch):

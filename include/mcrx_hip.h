@@ -78,7 +78,9 @@ typedef struct {
                                     24 + 12 instead of 12 algorithmic bytes per sample; execute_host / execute_device only (power-of-two
                                     channel counts) */
     uint32_t skip_framesyms;     /* 1 = harvests leave the equalised symbols in HBM (frames report num_framesyms = 0): 1.2 KB
-                                    instead of 59 KB per frame over the host link at the benchmark's frame size */
+                                    instead of 59 KB per frame over the host link at the benchmark's frame size; 2 = the payload workers
+                                    of 64-subcarrier symbols do not even store them (a third of the bytes that stage moves): for callers
+                                    whose callback never reads stats.framesyms (the reference's src/multichannel_rx.cc:37-66 does not) */
     /* Alternate builds of the same stages.  Every one decodes the same frames (the -m gpu tests hold each to the oracle); they
      * differ in speed only and exist so that a regression in the default can be told from one in the algorithm.  0 = default. */
     uint32_t worker_build;       /* M = 64 payload workers: 0 = lean workers, butterfly exchanges through the LDS crossbar;

@@ -768,6 +768,7 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     a.hint = q->d_hint; a.enc_hint = (q->h_hint && q->d_hint) ? *(volatile uint32_t *)q->h_hint : 0u;
     a.spec = q->d_spec; a.spec_stride = q->spec_stride; a.spec_R = q->d_spec_R; a.pred = nullptr; a.pred_n = nullptr; a.spec_cap = 0; a.spec_hint = nullptr; a.walk_hint = nullptr;
     a.nseg = 0; a.seg_phase = 0; a.anchor = nullptr; a.seg_jobs = 1; a.seekst = q->d_seekst; a.seg_walker = q->seg_walker;
+    a.no_syms = (q->cfg.struct_size >= offsetof(mcrx_hip_config, skip_framesyms) + sizeof(uint32_t) && q->cfg.skip_framesyms == 2) ? 1 : 0;
     hipStream_t sa = st, sw = st;
     // The host never waits for the device on this path (slots are handed over by stream waits), so a free-running caller
     // can be any number of launches ahead -- and the hints the kernels leave for the next launch (widest prediction list,

@@ -94,6 +94,7 @@ __device__ __forceinline__ uint32_t symbols(const SyncArgs &a, const PayloadJob 
     const uint32_t tstride = a.chan_stride * (uint32_t)MCRX_TILE_S;      // elements between a channel's consecutive tiles
     const int32_t r_max = (int32_t)(a.end - a.buf_first) - 1;
     const bool soft_mode = c.payload_soft != 0;
+    const bool keep_syms = a.no_syms == 0;                              // (skip_framesyms = 2: the caller never reads stats.framesyms -- not even stored)
     uint8_t *soft = a.jsoft + (size_t)j * 8 * c.max_enc_len;
     const uint64_t syms_off = job->syms_off;
     uint8_t *syms = a.sarena + (((uint64_t)rfl((uint32_t)(syms_off >> 32)) << 32) | rfl((uint32_t)syms_off));
@@ -128,9 +129,9 @@ __device__ __forceinline__ uint32_t symbols(const SyncArgs &a, const PayloadJob 
         if (inner || (ps + (uint32_t)Md <= mod_len && (ps + (uint32_t)Md) * bps <= nbits)) {
             if (isdata) {
 #if PL_NT_STORE
-                __builtin_nontemporal_store(Z, reinterpret_cast<v2f *>(ssym + so_sym));
+                if (keep_syms) __builtin_nontemporal_store(Z, reinterpret_cast<v2f *>(ssym + so_sym));
 #else
-                *reinterpret_cast<v2f *>(ssym + so_sym) = Z;
+                if (keep_syms) *reinterpret_cast<v2f *>(ssym + so_sym) = Z;
 #endif
                 uint8_t *dst = ssoft + so_soft;
                 if constexpr (bps == 1) dst[0] = (uint8_t)sw;
@@ -142,7 +143,7 @@ __device__ __forceinline__ uint32_t symbols(const SyncArgs &a, const PayloadJob 
                 }
             }
         } else if (isdata && ps + (uint32_t)dr < mod_len) {              // the frame's last symbol: part of the subcarriers, part of their bits
-            *reinterpret_cast<v2f *>(ssym + so_sym) = Z;
+            if (keep_syms) *reinterpret_cast<v2f *>(ssym + so_sym) = Z;
             const uint32_t b0 = (ps + (uint32_t)dr) * bps;
 #pragma unroll
             for (unsigned kb = 0; kb < bps; kb++) if (b0 + kb < nbits) ssoft[so_soft + kb] = (uint8_t)(sw >> (8 * kb));
