@@ -598,6 +598,10 @@ def configs_block(prod, torch, dev, args):
              "configs[1] in pushes four times as long (400 frames/ch/slab, 54 M samples): a push is a chain of latencies -- acquisition, payload workers, decoder, "
              "0.45 ms at 100 frames per channel whatever the sample count -- that eight channels cannot fill the chip beside; longer pushes amortize it"),
             ("8ch_v27", 8, 64, 8, 100, 1200, 40, 11, False, "configs[1] with the K=7 r=1/2 convolutional code (soft Viterbi) as the outer code"),
+            ("512ch_m48_reference_app_defaults", 512, 48, 6, 16, 1200, 40, 6, False,
+             "the reference applications' own default numerology (src/multichannel_rx.cc:93-95, src/multichannel_tx.cc: M=48 cp=6 taper=4) at 512 channels, "
+             "QPSK CRC32+Hamming128 1200B payloads, 16 frames/ch/slab: 48 = 3 x 16 on the lean path (segment waves, one-frame-per-wave workers) since round 5; "
+             "rounds 1-4: direct DFTs, every frame walked, 20.4 Gsample/s"),
             ("64ch_m256_qam16_resamp", 64, 256, 32, 32, 1200, 27, 7, True,
              "configs[2]: 64-ch multichannelrx, M=256 cp=32 QAM16 CRC32+Golay(24,12) 1200B payloads, 32 frames/ch/slab, msresamp(0.5) front end"))
     for name, N, M, cp, fr, pl, mod, fec1, rsmp, what in legs:

@@ -40,16 +40,17 @@ __device__ __forceinline__ int64_t rfl64(int64_t v)
 { return (int64_t)(((uint64_t)rfl((uint32_t)((uint64_t)v >> 32)) << 32) | (uint64_t)rfl((uint32_t)v)); }
 __device__ __forceinline__ float gather(int addr, float v) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v))); }
 
-template <int XB>
+template <int XB, int MM>
 struct Acq {
-    static constexpr int M = 64, M2 = 32;
+    static constexpr int M = MM, M2 = MM / 2;
     SyncArgs &a;
     const SyncConsts &c;
     const int l;
     const uint32_t ch;
     // ---- lane constants
-    int bp32, kk, dr, er, src1, src2, psrc, esrc;
-    bool sct;
+    int bp32, kk, dr, er, src1, src2, psrc, esrc, half;
+    bool sct, lane_on;
+    Radix3 r3;                  // (MM = 48 only)
     float S0v, S1v, fxr, pf0, pf1;
     v2f tw[6], sgp[3], R;
     // ---- LDS (one wave per workgroup)
@@ -85,14 +86,17 @@ struct Acq {
     {
         L = c.L; cp = c.cp; backoff = c.backoff; cb = cp - backoff; Mp = c.M_pilot; Md = c.M_data; Nen = c.Nen;
         bp32 = (l ^ 32) << 2;
-        kk = (int)(__brev((unsigned)l) >> 26);
-        dr = c.data_rank[kk]; er = c.en_rank[kk];
-        const int pr = c.pilot_rank[kk];
-        sct = c.sctype[kk] != 0;
-        S0v = c.S0[kk]; S1v = c.S1[kk];
+        const int kq = lane_k<MM>(l);
+        lane_on = kq >= 0; kk = lane_on ? kq : 0;                  // (a lane behind a 48-sample symbol holds zeros and owns no subcarrier)
+        dr = lane_on ? c.data_rank[kk] : -1; er = lane_on ? c.en_rank[kk] : -1;
+        const int pr = lane_on ? c.pilot_rank[kk] : -1;
+        sct = lane_on && c.sctype[kk] != 0;
+        S0v = lane_on ? c.S0[kk] : 0.f; S1v = lane_on ? c.S1[kk] : 0.f;
         fxr = ((kk > M2) ? (float)kk - (float)M : (float)kk) * 0.15915494309189535f;
-        src1 = (int)(__brev((unsigned)((kk + 1) & 63)) >> 26) << 2;
-        src2 = (int)(__brev((unsigned)((kk + 2) & 63)) >> 26) << 2;
+        src1 = k_lane<MM>((kk + 1) % M) << 2;
+        src2 = k_lane<MM>((kk + 2) % M) << 2;
+        half = ((l + M2) & 63) << 2;                                 // the lane M / 2 samples on (the CFO estimate's second half)
+        if constexpr (MM == 48) r3 = radix3_consts(l);
 #pragma unroll
         for (int s = 0; s < 6; s++) {
             const int h = 32 >> s;
@@ -185,17 +189,14 @@ struct Acq {
             w0 = r0;
             ACQ_T1(8);
         }
-        return wbuf[r0 - w0 + l];
+        v2f v = wbuf[r0 - w0 + l];
+        if constexpr (MM < WV) { if (l >= MM) { v.x = 0.f; v.y = 0.f; } }          // (a window is MM samples)
+        return v;
     }
-    __device__ __forceinline__ v2f fft64(v2f x) const
+    __device__ __forceinline__ v2f fft64(v2f x) const             // (the MM-point transform; the name is round 5's first build's)
     {
-        x = stage<32, XB, 0>(x, sgp[0], tw[0], bp32);
-        x = stage<16, XB, 1>(x, sgp[0], tw[1], bp32);
-        x = stage<8, XB, 0>(x, sgp[1], tw[2], bp32);
-        x = stage<4, XB, 1>(x, sgp[1], tw[3], bp32);
-        x = stage<2, XB, 0>(x, sgp[2], tw[4], bp32);
-        x = stage<1, XB, 1>(x, sgp[2], tw[5], bp32);
-        return x;
+        if constexpr (MM == 64) return lean::fft64<XB>(x, tw, sgp, bp32);
+        else return lean::fft48<XB>(x, tw, sgp, r3, bp32, l);
     }
     // S0 metric of a window (Walker::s0_metric_of): its power, and sum over the even subcarriers of X[k + 2] conj X[k], / M_S0
     __device__ __forceinline__ float2 s0_metric(v2f x, float &power) const
@@ -206,7 +207,7 @@ struct Acq {
         const float xr = x.x * sc, xi = x.y * sc;
         const float pr_ = gather(src2, xr), pi_ = gather(src2, xi);
         float2 t = cmulc(make_float2(pr_, pi_), make_float2(xr, xi));
-        if (kk & 1) t = make_float2(0.f, 0.f);
+        if ((kk & 1) || !lane_on) t = make_float2(0.f, 0.f);
         const float inv = 1.0f / (float)c.M_S0;
         return make_float2(wave_total_dpp(t.x) * inv, wave_total_dpp(t.y) * inv);
     }
@@ -256,8 +257,8 @@ struct Acq {
             timer = rfl((uint32_t)(M + cp - backoff) - (uint32_t)(int)roundf(tau));
             // CFO: time-domain ML estimate over the two halves of the oldest M window samples (lanes 0..31: sample i and i + M/2)
             const v2f y = window(t_ev - L + 1);
-            const float2 s0 = c.s0t[l];
-            const float r1x = xch<32>(y.x, bp32), r1y = xch<32>(y.y, bp32), sbx = xch<32>(s0.x, bp32), sby = xch<32>(s0.y, bp32);
+            const float2 s0 = c.s0t[l < M ? l : 0];
+            const float r1x = gather(half, y.x), r1y = gather(half, y.y), sbx = gather(half, s0.x), sby = gather(half, s0.y);
             float2 t = cmul(cmulc(s0, make_float2(y.x, y.y)), cmulc(make_float2(r1x, r1y), make_float2(sbx, sby)));
             if (l >= M2) t = make_float2(0.f, 0.f);
             const float ax = wave_total_dpp(t.x), ay = wave_total_dpp(t.y);
@@ -275,7 +276,8 @@ struct Acq {
             x = fft64(x);
             const float sc = S1v * gain1;
             const float xr = x.x * sc, xi = x.y * sc;
-            const float2 t = cmulc(make_float2(gather(src1, xr), gather(src1, xi)), make_float2(xr, xi));
+            float2 t = cmulc(make_float2(gather(src1, xr), gather(src1, xi)), make_float2(xr, xi));
+            if (!lane_on) t = make_float2(0.f, 0.f);
             const float2 acc = make_float2(wave_total_dpp(t.x), wave_total_dpp(t.y));
 #if MCRX_S1_METRIC_G0_NORMALISED
             float2 gh = cscale(acc, g0 / (float)c.M_S1);
@@ -474,7 +476,7 @@ struct Acq {
         if (!oversize() && t_last < a.end) {
             const uint32_t j = park_state();
             if (j != 0xFFFFFFFFu) {
-                a.jR[(size_t)j * M + kk] = make_float2(R.x, R.y);
+                if (lane_on) a.jR[(size_t)j * M + kk] = make_float2(R.x, R.y);
                 handoff_job = j; handoff_last = t_last;
                 return 2;
             }
@@ -560,7 +562,7 @@ struct Acq {
                 reset_framesync(); timer = (uint32_t)L; cur = A; key = spec_key(A, (uint32_t)L);
             } else if (g == 0) {
                 key = spec_key(cur, timer, st);
-                { const float2 r = (a.R + (size_t)ch * M)[kk]; R.x = r.x; R.y = r.y; }       // (an acquisition in progress has its equaliser there)
+                { const float2 r = (a.R + (size_t)ch * M)[kk]; R.x = lane_on ? r.x : 0.f; R.y = lane_on ? r.y : 0.f; }       // (an acquisition in progress has its equaliser there)
                 if (st == SY_RX && fstate == FX_HEADER && hsi > 0) {
                     const uint8_t *hb = a.hbits + (size_t)ch * MCRX_HDR_SYMS;
                     for (int i = l; i < MCRX_HDR_SYMS; i += WV) hbits[i] = hb[i];
@@ -662,7 +664,7 @@ struct Acq {
 }  // namespace lean
 
 // one wave per (channel, segment of the push): sync_spec_kernel<1>'s grid and protocol
-template <int XB>
+template <int XB, int MM>
 __global__ __launch_bounds__(WV, ACQ_LEAN_WAVES) void acq_lean_kernel(SyncArgs a)
 {
     __builtin_amdgcn_s_setprio(3);
@@ -676,6 +678,6 @@ __global__ __launch_bounds__(WV, ACQ_LEAN_WAVES) void acq_lean_kernel(SyncArgs a
     __shared__ lean::v2f wbuf[ACQ_WIN];
     const uint32_t ch = a.seg_phase == 1 ? blockIdx.x : blockIdx.x / a.nseg, g = a.seg_phase == 1 ? 0u : blockIdx.x % a.nseg;
     if (ch >= a.nch) return;
-    lean::Acq<XB> w(a, rfl(ch), qsg, hmap, hbits, hd, wbuf);
+    lean::Acq<XB, MM> w(a, rfl(ch), qsg, hmap, hbits, hd, wbuf);
     w.run_seg(rfl(g), qsrc, qesrc);
 }

@@ -603,7 +603,8 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
             if ((rc = q->alloc(&q->d_jtmp[sl], (size_t)q->max_jobs * 2 * (q->max_enc + 16)))) return bail(rc);
         }
         // speculative acquisition (lean path only): slots, their equalisers, the prediction lists
-        const bool lean = q->sc.log2M >= 6 && q->sc.M == 64 * q->sc.E && q->sc.M_pilot <= 64;
+        const bool lean = (q->sc.log2M >= 6 && q->sc.M == 64 * q->sc.E && q->sc.M_pilot <= 64) ||
+                          (q->sc.M == 48 && q->sc.E == 1 && q->sc.M_pilot <= 64);        // (48 = 3 x 16: the reference applications' default, round 5)
         q->spec = lean && q->d_hint && !no_spec_cfg && devel_env("MCRX_NO_SPEC") == nullptr;
         if (devel_env("MCRX_NSEG")) q->nseg_fixed = (uint32_t)std::max(1, std::min(MCRX_SEG_MAX, atoi(devel_env("MCRX_NSEG"))));           // experiments: segments per channel, fixed
         if (devel_env("MCRX_SEG_FRAMES")) q->seg_frames = (uint32_t)std::max(1, std::min(64, atoi(devel_env("MCRX_SEG_FRAMES"))));            // ... or frames per segment aimed at

@@ -51,6 +51,7 @@ namespace mcrx {
 
 // ------------------------------------------------------------------ small utilities
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+#include "lean_prims.hpp"       // packed-f32 / LDS-crossbar building blocks, the lane <-> subcarrier maps of the lean transforms
 
 __device__ __forceinline__ unsigned fec_enc_len_d(unsigned fs, unsigned n)
 {
@@ -851,7 +852,7 @@ struct Walker {
         for (int e = 0; e < E; e++) {
             const int i = l + WV * e;
             int kk = -1;
-            if (i < c.M) kk = c.log2M ? (int)(__brev((unsigned)i) >> (32 - c.log2M)) : i;
+            if (i < c.M) kk = (E == 1 && c.M == 48 && c.M_pilot <= WV) ? lean::lane_k<48>(i) : (c.log2M ? (int)(__brev((unsigned)i) >> (32 - c.log2M)) : i);
             k[e] = kk;
             const int kq = kk < 0 ? 0 : kk;
             sct[e] = kk < 0 ? (uint8_t)0 : c.sctype[kq];
@@ -904,13 +905,12 @@ struct Walker {
             sg[st] = up ? -1.f : 1.f;
         }
         bp32 = (l ^ 32) << 2;
-        const int lg = c.log2M;
 #pragma unroll
         for (int e = 0; e < E; e++) {
-            const int kk = (int)(__brev((unsigned)(l + WV * e)) >> (32 - lg));
-            k[e] = kk;
-            sct[e] = c.sctype[kk];
-            dr[e] = c.data_rank[kk]; pr[e] = c.pilot_rank[kk];
+            const int kq = fast_k(l + WV * e), kk = kq < 0 ? 0 : kq;        // (kq < 0: a lane behind a 48-sample symbol -- holds zeros, owns nothing)
+            k[e] = kq;
+            sct[e] = kq < 0 ? (uint8_t)0 : c.sctype[kk];
+            dr[e] = kq < 0 ? -1 : c.data_rank[kk]; pr[e] = kq < 0 ? -1 : c.pilot_rank[kk];
             fxr[e] = ((kk > c.M2) ? (float)kk - (float)c.M : (float)kk) * 0.15915494309189535f;   // revolutions per rad of slope
         }
         const int Mp = c.M_pilot;
@@ -1446,10 +1446,42 @@ struct Walker {
     // registers, DPP / LDS-crossbar lane exchanges, the pilot phase unwrap as a prefix sum of
     // 2 pi jumps (liquid's sequential `while` unwrap only ever adds -rint(d / 2 pi) turns per
     // step), and v_sin / v_cos for the two rotations per sample.
-    __device__ __forceinline__ bool fast_ok() const { return c.log2M >= 6 && c.M == WV * E && c.M_pilot <= WV; }
+    // (round 5: and 48 subcarriers -- the reference applications' default -- as 3 x 16: lean_prims.hpp, fast_fft48 below)
+    __device__ __forceinline__ bool fast_ok() const { return (c.log2M >= 6 && c.M == WV * E && c.M_pilot <= WV) || (E == 1 && c.M == 48 && c.M_pilot <= WV); }
+    // lane -> subcarrier of the lean transforms: bit reversal for the power-of-two widths, lean::lane_k<48> (-1: idle lane) for 48
+    __device__ __forceinline__ int fast_k(int i) const
+    {
+        if (c.M == 48) return lean::lane_k<48>(i);
+        return (int)(__brev((unsigned)i) >> (32 - c.log2M));
+    }
 
+    // 48 = 3 x 16 (lean_prims.hpp): the radix-3 stage's three inputs through the LDS crossbar, then the last four stages of the 64-point
+    // transform inside every DPP row.  (The lane constants are formed here, per call: these are the scouts' and the tail kernel's
+    // rare paths -- the segment waves and the payload workers of 48-subcarrier symbols hold them in registers.)
+    __device__ __forceinline__ void fast_fft48(float2 &x)
+    {
+        const lean::Radix3 r3 = lean::radix3_consts(l);
+        const float xr = x.x, xi = x.y;
+        float2 x0, x1, x2;
+        x0.x = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(r3.a0, __builtin_bit_cast(int, xr)));
+        x0.y = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(r3.a0, __builtin_bit_cast(int, xi)));
+        x1.x = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(r3.a1, __builtin_bit_cast(int, xr)));
+        x1.y = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(r3.a1, __builtin_bit_cast(int, xi)));
+        x2.x = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(r3.a2, __builtin_bit_cast(int, xr)));
+        x2.y = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(r3.a2, __builtin_bit_cast(int, xi)));
+        const float2 p1 = cmul(x1, make_float2(r3.w1.x, r3.w1.y)), p2 = cmul(x2, make_float2(r3.w2.x, r3.w2.y));
+        float2 y = make_float2((x0.x + p1.x) + p2.x, (x0.y + p1.y) + p2.y);
+        y = cmul(y, make_float2(r3.t.x, r3.t.y));
+        if (l >= 48) y = make_float2(0.f, 0.f);
+#define SY_XSTAGE1(ST, H) { const float sx = bfly_leg<H>(y.x, sg[ST]), sy = bfly_leg<H>(y.y, sg[ST]);   \
+            if (H == 1) y = make_float2(sx, sy); else y = make_float2(sx * tw[ST].x - sy * tw[ST].y, sx * tw[ST].y + sy * tw[ST].x); }
+        SY_XSTAGE1(2, 8) SY_XSTAGE1(3, 4) SY_XSTAGE1(4, 2) SY_XSTAGE1(5, 1)
+#undef SY_XSTAGE1
+        x = y;
+    }
     __device__ __forceinline__ void fast_fft(float2 (&x)[E])
     {
+        if constexpr (E == 1) { if (c.M == 48) { fast_fft48(x[0]); return; } }
         // in-lane stages (span 64 J), twiddle W_{128 J}^{i mod 64 J}
 #pragma unroll
         for (int J = E / 2; J >= 1; J >>= 1) {
@@ -1550,11 +1582,14 @@ struct Walker {
         for (int e = 0; e < E; e++) nxt[e] = make_float2(0.f, 0.f);
 #pragma unroll
         for (int e = 0; e < E; e++) { const int r = r_ws + l + WV * e; cur[e] = chb[(size_t)(r >> MCRX_TILE_SH) * tstride + (size_t)(r & (MCRX_TILE_S - 1))]; }
+        const bool short_sym = c.M < WV * E;                                // (48 subcarriers: the lanes behind the window hold zeros)
+        if (short_sym) { for (int e = 0; e < E; e++) if (l + WV * e >= c.M) cur[e] = make_float2(0.f, 0.f); }
         uint32_t psi = 0;
         for (uint32_t n = 0; n < ((a.no_fast & 4) ? 1u : nsym); n++) {
             if (n + 1 < nsym) {
 #pragma unroll
                 for (int e = 0; e < E; e++) { const int r = r_ws + L + l + WV * e; nxt[e] = chb[(size_t)(r >> MCRX_TILE_SH) * tstride + (size_t)(r & (MCRX_TILE_S - 1))]; }
+                if (short_sym) { for (int e = 0; e < E; e++) if (l + WV * e >= c.M) nxt[e] = make_float2(0.f, 0.f); }
             }
             float p0, p1;
             fast_core(cur, th_ws, dth, pc, p1_prime, p0, p1);
@@ -3442,10 +3477,11 @@ hipError_t acq_lean_launch(const SyncArgs &a, unsigned grid, hipStream_t st);
 int acq_lean_waves(const SyncConsts &c);        // waves per SIMD of the lean segment-wave kernel if this design takes it, else 0
 #if SY_PART < 0 || SY_PART == 4
 #include "acq_lean.hpp"
-int acq_lean_waves(const SyncConsts &c) { return (c.M == 64 && c.E == 1 && c.M_pilot <= 16 && c.M_pilot >= 1 && c.Nen <= 64) ? ACQ_LEAN_WAVES : 0; }
+int acq_lean_waves(const SyncConsts &c) { return ((c.M == 64 || c.M == 48) && c.E == 1 && c.M_pilot <= 16 && c.M_pilot >= 1 && c.Nen <= 64) ? ACQ_LEAN_WAVES : 0; }
 hipError_t acq_lean_launch(const SyncArgs &a, unsigned grid, hipStream_t st)
 {
-    hipLaunchKernelGGL((acq_lean_kernel<63>), dim3(grid), dim3(WV), 0, st, a);
+    if (a.c.M == 48) hipLaunchKernelGGL((acq_lean_kernel<63, 48>), dim3(grid), dim3(WV), 0, st, a);
+    else hipLaunchKernelGGL((acq_lean_kernel<63, 64>), dim3(grid), dim3(WV), 0, st, a);
     return hipGetLastError();
 }
 #endif
@@ -3528,10 +3564,11 @@ hipError_t sync_launch_payload(const SyncArgs &a0, int stage, hipStream_t st)
     unsigned ngrid = a.frames_hint == ~0u ? nj : a.frames_hint + a.frames_hint / 4 + 64;
     if (ngrid > nj) ngrid = nj;
     a.live_off = 0;
-    const bool fast = a.c.log2M >= 6 && a.c.M == WV * a.c.E && a.c.M_pilot <= WV && !(a.no_fast & 1);
+    const bool fast = ((a.c.log2M >= 6 && a.c.M == WV * a.c.E) || (a.c.M == 48 && a.c.E == 1)) && a.c.M_pilot <= WV && !(a.no_fast & 1);
+    const bool m64or48 = a.c.M == WV || a.c.M == 48;                        // the symbol widths of the lean one-frame-per-wave workers (payload_lean.hpp)
     // the M = 64 lean workers take one BPSK / QPSK frame per wave out of the first `ngrid` of the live list; the launch behind them
     // walks the rest of it (live_off tells it where the grid ended)
-    if (fast && a.c.M == WV && a.c.M_pilot <= 16 && a.payload_fr == 1 && a.payload_lean && !(a.no_fast & 6)) a.live_off = ngrid;
+    if (fast && m64or48 && a.c.M_pilot <= 16 && a.payload_fr == 1 && a.payload_lean && !(a.no_fast & 6)) a.live_off = ngrid;
     a.dec_lds_soft = fast ? decode_soft_lds(a) : 0u;
     if (!fast) a.gen_list = nullptr;
     if (stage == 0) {
@@ -3556,6 +3593,15 @@ hipError_t sync_launch_payload(const SyncArgs &a0, int stage, hipStream_t st)
     // M = 64 with the pilots inside one DPP row: payload_multi_kernel, MCRX_PAYLOAD_FR frames per wave (default 1;
     // 0 = the width-generic worker).  Measured on the bench stream: 1 -> 141.7 Gsample/s, 0 -> 138, 2 -> 138, 4 -> 118.
     const int fr = a.payload_fr;                                         // (MCRX_PAYLOAD_FR / _LEAN / _XB: read once, when the handle is created)
+    if (fast && a.c.M == 48 && a.c.M_pilot <= 16 && fr == 1 && a.payload_lean && !(a.no_fast & 6)) {
+        // 48 subcarriers: the lean workers' 3 x 16 build (the packed-frame and round-2 workers are 64-subcarrier kernels)
+        unsigned nq = a.grid_hint[0] == ~0u ? nj : 2u * a.grid_hint[0];
+        nq = nq < 256u ? 256u : (nq > nj ? nj : nq);
+        const size_t pad = (size_t)a.payload_lds_pad;
+        hipLaunchKernelGGL((payload_lean_kernel<63, 48>), dim3(ngrid), dim3(WV), pad, st, a);
+        hipLaunchKernelGGL((payload_lean_rest_kernel<63, 48>), dim3(a.qam_list ? nq : nj), dim3(WV), pad, st, a);
+        return hipGetLastError();
+    }
     if (fast && a.c.M == WV && a.c.M_pilot <= 16 && fr > 0 && !(a.no_fast & 6)) {
         if (fr == 4)      hipLaunchKernelGGL(payload_multi_kernel<4>, dim3((nj + 3) / 4), dim3(WV), 0, st, a);
         else if (fr == 2) hipLaunchKernelGGL(payload_multi_kernel<2>, dim3((nj + 1) / 2), dim3(WV), 0, st, a);

@@ -48,7 +48,7 @@ __device__ __forceinline__ uint64_t demod_pk(const uint8_t *nbt, v2f r, bool sof
 template <int MOD> struct bits_per_symbol { static constexpr unsigned v = MOD == 39 ? 1u : MOD == 40 ? 2u : MOD == 27 ? 4u : 6u; };
 
 // the symbols of one frame.  Everything passed by value is wave-uniform unless it says "lane"
-template <int MOD, int XB>
+template <int MOD, int XB, int MM = 64>
 __device__ __forceinline__ uint32_t symbols(const SyncArgs &a, const PayloadJob *job, const uint32_t ch, const uint32_t j,
                                             const uint32_t *qsg, const uint32_t *qnb, const int *qsrc)
 {
@@ -56,13 +56,16 @@ __device__ __forceinline__ uint32_t symbols(const SyncArgs &a, const PayloadJob 
     const SyncConsts &c = a.c;
     const int l = lane_id();
     const int bp32 = (l ^ 32) << 2;
-    // ---- lane constants: after the transform lane l holds subcarrier bitrev6(l)
-    const int kk = (int)(__brev((unsigned)l) >> 26);
-    const int dr = c.data_rank[kk];
+    // ---- lane constants: after the transform lane l holds subcarrier lane_k<MM>(l) (64: bitrev6(l); 48: lean_prims.hpp; idle lanes: none)
+    const int kq = lane_k<MM>(l);
+    const bool lane_on = kq >= 0;
+    const int kk = lane_on ? kq : 0;
+    const int dr = lane_on ? c.data_rank[kk] : -1;
     const bool isdata = dr >= 0;
+    Radix3 r3; if constexpr (MM == 48) r3 = radix3_consts(l);
     const float fxr = ((kk > c.M2) ? (float)kk - (float)c.M : (float)kk) * 0.15915494309189535f;
     v2f R = {0.f, 0.f};
-    if (c.sctype[kk]) { const float2 g = (a.jR + (size_t)j * c.M)[kk]; R.x = g.x; R.y = g.y; }
+    if (lane_on && c.sctype[kk]) { const float2 g = (a.jR + (size_t)j * c.M)[kk]; R.x = g.x; R.y = g.y; }
     v2f tw[6], sgp[3];                                                  // stage twiddles (1 in the lower lanes); butterfly signs, two stages to a pair
 #pragma unroll
     for (int st = 0; st < 6; st++) {
@@ -111,11 +114,15 @@ __device__ __forceinline__ uint32_t symbols(const SyncArgs &a, const PayloadJob 
                 if (ph != q0) { q0 = ph; const uint32_t q = (uint32_t)ph + (uint32_t)l; offl = ((q >> MCRX_TILE_SH) * tstride + (q & (uint32_t)(MCRX_TILE_S - 1))) * 8u; }
             }
             const char *base = reinterpret_cast<const char *>(chb + (size_t)(uint32_t)(rw >> MCRX_TILE_SH) * tstride);
-            return *reinterpret_cast<const v2f *>(base + offl);
+            v2f v = *reinterpret_cast<const v2f *>(base + offl);
+            if constexpr (MM < WV) { if (l >= MM) { v.x = 0.f; v.y = 0.f; } }      // (a window is MM samples: the lanes behind it hold zeros)
+            return v;
         }
         int32_t r = rw + l;
         r = r < 0 ? 0 : (r > r_max ? r_max : r);
-        return *reinterpret_cast<const v2f *>(chb + ((size_t)(r >> MCRX_TILE_SH) * tstride + (size_t)(r & (MCRX_TILE_S - 1))));
+        v2f v = *reinterpret_cast<const v2f *>(chb + ((size_t)(r >> MCRX_TILE_SH) * tstride + (size_t)(r & (MCRX_TILE_S - 1))));
+        if constexpr (MM < WV) { if (l >= MM) { v.x = 0.f; v.y = 0.f; } }
+        return v;
     };
 
     // Stores run one symbol late.  Loads and stores share one counter (vmcnt) and return out of order against each other, so
@@ -158,13 +165,9 @@ __device__ __forceinline__ uint32_t symbols(const SyncArgs &a, const PayloadJob 
         v2f x = rot_down_pk(cur, u32rev(th_ws + (uint32_t)l * dth));
         if (n + 1 < nsym) cur = load_win(r_ws + L);
         if (n > 0) store_symbol(psi - (uint32_t)Md, Zp, swp, true);
-        // ---- 64-point DIF transform, equaliser
-        x = stage<32, XB, 0>(x, sgp[0], tw[0], bp32);
-        x = stage<16, XB, 1>(x, sgp[0], tw[1], bp32);
-        x = stage<8, XB, 0>(x, sgp[1], tw[2], bp32);
-        x = stage<4, XB, 1>(x, sgp[1], tw[3], bp32);
-        x = stage<2, XB, 0>(x, sgp[2], tw[4], bp32);
-        x = stage<1, XB, 1>(x, sgp[2], tw[5], bp32);
+        // ---- MM-point DIF transform, equaliser
+        if constexpr (MM == 64) x = fft64<XB>(x, tw, sgp, bp32);
+        else x = fft48<XB>(x, tw, sgp, r3, bp32, l);
         x = cmul_pk(x, R);
         // ---- pilots to the first lanes, polarity, phase, unwrap, the two projections of the line fit
         const float xr = x.x, xi = x.y;                                  // (copies: __builtin_bit_cast of a vector element reads element 0)
@@ -219,7 +222,7 @@ __device__ __forceinline__ uint32_t symbols(const SyncArgs &a, const PayloadJob 
 // REST: the frames the main launch's grid (sized from the previous launch's frame count: a.live_off waves, one frame each) did not
 // reach -- a small second launch with a grid stride, normally nothing to do.  (The stride loop in the main kernel cost it its eighth
 // wave per SIMD: 59 -> 70 registers.)
-template <int XB, int CLS, bool REST = false>
+template <int XB, int CLS, bool REST = false, int MM = 64>
 __device__ __forceinline__ void payload_lean_body(SyncArgs &a)
 {
     launder(a);
@@ -236,7 +239,7 @@ __device__ __forceinline__ void payload_lean_body(SyncArgs &a)
     for (int k = l; k < 256 + 16; k += WV) qsg[k] = c.pilot_seq[k >= 255 ? k - 255 : k] == 0 ? 0x80000000u : 0u;
     if (l < 16) qsrc[l] = 0;
     wave_sync_lds();
-    { const int pr = c.pilot_rank[(int)(__brev((unsigned)l) >> 26)]; if (pr >= 0 && pr < 16) qsrc[pr] = l; }
+    { const int kq = lean::lane_k<MM>(l); const int pr = kq >= 0 ? c.pilot_rank[kq] : -1; if (pr >= 0 && pr < 16) qsrc[pr] = l; }
     wave_sync_lds();
     for (uint32_t k = kfirst; k < nlist; k += gridDim.x) {
         const uint32_t j = (CLS == 1 && a.qam_list) ? rfl(a.qam_list[1 + k]) : rfl(a.live[1 + k]);
@@ -248,22 +251,22 @@ __device__ __forceinline__ void payload_lean_body(SyncArgs &a)
         if (((mod == 39 || mod == 40) ? 0 : 1) != CLS) continue;
         uint32_t dth;
         if constexpr (CLS == 0) {
-            if (mod == 39) dth = lean::symbols<39, XB>(a, job, ch, j, qsg, qnb, qsrc);
-            else           dth = lean::symbols<40, XB>(a, job, ch, j, qsg, qnb, qsrc);
+            if (mod == 39) dth = lean::symbols<39, XB, MM>(a, job, ch, j, qsg, qnb, qsrc);
+            else           dth = lean::symbols<40, XB, MM>(a, job, ch, j, qsg, qnb, qsrc);
         } else {
             wave_sync_lds();
             if (mod == 27) { if (l < 16) qnb[l] = reinterpret_cast<const uint32_t *>(c.cod.qam16_nb)[l]; }
             else qnb[l] = reinterpret_cast<const uint32_t *>(c.cod.qam64_nb)[l];
             wave_sync_lds();
-            if (mod == 27) dth = lean::symbols<27, XB>(a, job, ch, j, qsg, qnb, qsrc);
-            else           dth = lean::symbols<29, XB>(a, job, ch, j, qsg, qnb, qsrc);
+            if (mod == 27) dth = lean::symbols<27, XB, MM>(a, job, ch, j, qsg, qnb, qsrc);
+            else           dth = lean::symbols<29, XB, MM>(a, job, ch, j, qsg, qnb, qsrc);
         }
         if (l == 0) a.jobs[j].s.nco_dtheta = dth;
         if (CLS == 0 && !REST) break;       // (one frame per wave; what the grid does not cover is the REST launch's)
     }
 }
-template <int XB> __global__ __launch_bounds__(WV) __attribute__((amdgpu_num_sgpr(72))) void payload_lean_kernel(SyncArgs a) { payload_lean_body<XB, 0>(a); }
+template <int XB, int MM = 64> __global__ __launch_bounds__(WV) __attribute__((amdgpu_num_sgpr(72))) void payload_lean_kernel(SyncArgs a) { payload_lean_body<XB, 0, false, MM>(a); }
 // ONE list-driven launch behind the main one for everything it did not take: the BPSK / QPSK frames beyond its grid, then the QAM frames
 // (rounds 2-4 had a launch each, nearly always empty -- and an empty kernel still has to find a free wave slot on a full chip before the
 // decoder behind it may start: 70-85 us of the work stream's time per push and launch, profiles/r4_s1_kernel_stats.csv)
-template <int XB> __global__ __launch_bounds__(WV) void payload_lean_rest_kernel(SyncArgs a) { payload_lean_body<XB, 0, true>(a); payload_lean_body<XB, 1>(a); }
+template <int XB, int MM = 64> __global__ __launch_bounds__(WV) void payload_lean_rest_kernel(SyncArgs a) { payload_lean_body<XB, 0, true, MM>(a); payload_lean_body<XB, 1, false, MM>(a); }

@@ -402,3 +402,33 @@ def test_pushes_with_hundreds_of_frames_per_channel(product):
         assert ends == sorted(ends)
     assert adopted >= 0.95 * (walked + adopted) and adopted >= 2 * N * frames, (walked, adopted)
     rx.close()
+
+
+@pytest.mark.parametrize("mod,fec1,plen", [(40, 6, 300), (27, 7, 200)])
+def test_reference_app_default_numerology_takes_the_lean_path(oracle, product, mod, fec1, plen):
+    """M = 48, cp = 6, taper = 4 -- what src/multichannel_rx.cc:93-95 and src/multichannel_tx.cc run with when given no options -- was a
+    correctness-only path through round 4 (direct DFTs, every frame walked by one wave per channel: VERDICT r4, missing #2).  48 = 3 x 16
+    now runs on the lean kernels (lean_prims.hpp: radix-3 stage + the 16-point row transform): a continuous stream in several pushes
+    gives the oracle's frames and symbols, and once the stream runs every frame is acquired by the segment waves -- none walked."""
+    N, M, cp, nf = 16, 48, 6, 6
+    tx = product.multichanneltx(N, M, cp, 4)
+    slabs = [tx.generate(nf, plen, mod=mod, fec1=fec1, seed=900 + i)[0] for i in range(3)]
+    tx.close()
+    x = np.concatenate([d.cpu().numpy() for d in slabs])
+    ora = oracle.MultiChannelRx(N, M, cp, 4)
+    ora.execute(x)
+    assert len(ora.frames) == 3 * nf * N and all(f.payload_valid for f in ora.frames)
+    from test_gpu_parity import check_frames
+    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=plen)
+    for d in slabs:
+        rx.Execute(d)
+    rx.Flush()
+    check_frames(rx.frames, ora.frames)
+    rx.spec_stats(reset=True)
+    for d in slabs:                                          # the stream goes on: acquisition is the segment waves' now
+        rx.Execute(d)
+    rx.Flush()
+    walked, adopted = rx.spec_stats()
+    assert walked == 0 and adopted == 3 * nf * N, (walked, adopted)
+    assert len(rx.frames) == 2 * len(ora.frames)
+    rx.close()
