@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-harvest", action="store_true")
     ap.add_argument("--no-aperiodic", action="store_true", help="skip the ragged-traffic leg (value_aperiodic)")
+    ap.add_argument("--scout-build", type=int, default=0, help="mcrx_hip_config::scout_build for the headline receiver (A/B runs: 2 = the general state machine's segment waves)")
     ap.add_argument("--no-variants", action="store_true", help="skip the headline's variants (30 dB AWGN on the wideband samples; equalised symbols not stored)")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE.json configurations (the `configs` block)")
     ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed region of --steps steps: value = median, value_min / value_max beside it")
@@ -202,6 +203,8 @@ def main():
 
     max_frames = N * args.frames + 64 if (world == 1 and not args.pipeline) else cg * args.frames * nslab + 64
     cfg = dict(max_payload_len=max(args.payload, 64), max_frames=max_frames)
+    if args.scout_build:
+        cfg["scout_build"] = args.scout_build
     if world > 1 or args.pipeline:
         # rounds cut the stream anywhere: a frame that straddles two rounds is acquired again by the next round (whole, by
         # the parallel path) instead of being walked symbol by symbol -- the history in front of every round covers a frame
@@ -640,6 +643,8 @@ def aperiodic_leg(prod, N, M, cp, taper, slab_blocks, K, args, torch, dev):
     tx.close()
     nfr_slab = [sum(len(c) for c in s) for s in sents]
     cfg = dict(max_payload_len=max(args.payload, 64), max_frames=max(nfr_slab) + 64)
+    if args.scout_build:
+        cfg["scout_build"] = args.scout_build
     rx = prod.multichannelrx(N, M, cp, taper, **cfg)
 
     def step(keep=False):

@@ -89,9 +89,9 @@ typedef struct {
     uint32_t acquisition;        /* 0 = segment-parallel acquisition, anchor phase while the traffic has a cadence; 1 = one launch of
                                     segment waves, no anchor phase; 2 = no segment waves (the scouts walk every frame); 3 = anchor phase
                                     always; 4 = no speculation at all (the round-1 scout: one kernel per push does everything) */
-    uint32_t scout_build;        /* 0 = default: lean segment waves for 64-subcarrier symbols (csrc/acq_lean.hpp), the scouts' unbudgeted build;
-                                    1 = the scouts' 168-register build of rounds 2-3; 2 = the segment waves as the general state machine's
-                                    kernel (the only one until round 5) */
+    uint32_t scout_build;        /* 0 = default: the general state machine's segment waves, the scouts' unbudgeted build; 1 = the scouts'
+                                    168-register build of rounds 2-3; 2 = the lean segment waves of 48- / 64-subcarrier symbols
+                                    (csrc/acq_lean.hpp: half the instructions, the same time on periodic traffic, 10 % behind on ragged) */
 } mcrx_hip_config;
 
 /* One decoded frame = the arguments of the reference's framesync_callback

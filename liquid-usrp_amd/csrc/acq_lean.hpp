@@ -7,7 +7,7 @@
 // push, frame after frame, every hand-off parked in a job list entry and a slot keyed by the state the frame was acquired from.  The
 // Walker's build of it (sync_spec_kernel<1>) holds the whole state machine's registers: 248 VGPRs, two waves per SIMD, one dependent
 // chain each -- 2 x 0.10 ms per 8192-frame slab on a chip it fills with 2048 waves, while a frame's acquisition is seventeen events of
-// the kind the lean payload workers run 165 of per frame at eight waves per SIMD (payload_lean.hpp).  Same treatment here:
+// the kind the lean payload workers run 165 of per frame at eight waves per SIMD (payload_lean.hpp).  The same treatment, tried here:
 //   * the synchronizer state lives in scalars (every wave-uniform result goes through v_readfirstlane), positions inside the kernel
 //     are 32-bit offsets into the buffer;
 //   * one transform: the payload workers' six packed-f32 stages with the partner through the LDS crossbar (lean_prims.hpp);
@@ -16,14 +16,24 @@
 //   * the S1 fit's factors (5 + 5 floats per lane) are fetched when a frame is detected, not held across the walk.
 // The arithmetic per event is the Walker's (same sums in the same lane order, same thresholds, atan2f / roundf where it decides a
 // timer); the transform's twiddle products are fused differently (one packed mul + one packed fma), as in the payload workers.
-// Every configuration with M = 64 and at most 16 pilots takes this kernel; mcrx_hip_config::scout_build = 2 keeps the Walker's.
+// MEASURED, AND NOT THE DEFAULT (round 5; scratch/r5/acq_ab.sh, acq_ab2.sh, m48_ab.py; profiles/r5_acq_*): the kernel issues half the
+// Walker's instructions (42 M against 84 M VALU per 8192-frame slab) and takes the same time -- 2 x 0.10 ms alone, 181-183 Gsample/s
+// either way at 512 channels, M = 64 and M = 48 -- because a segment wave is a CHAIN: ~250 dependent instructions per event, ~6 k
+// cycles whoever issues them (LDS-crossbar round trips, DPP scans, v_readfirstlane -> scalar -> vector turnarounds), and with every wave
+// of the launch resident at once the launch lasts as long as its longest chain.  On ragged traffic the chain is a sixth longer here
+// (the LDS staging's round trip in front of every ~700 samples; 37 against 32 us for one frame alone) and the receiver 10 % slower
+// (127 against 142 Gsample/s).  It needs ~165 registers -- at 128 (four waves per SIMD) forty of them spill onto every event's chain,
+// 136 against 110 us per launch.  mcrx_hip_config::scout_build = 2 selects it (designs with 48 or 64 subcarriers and at most 16
+// pilots); the tests hold it to the oracle like the default (tests/test_gpu_parity.py, test_gpu_alloc.py).
 
 #include "lean_prims.hpp"
 #ifndef ACQ_LEAN_WAVES
-#define ACQ_LEAN_WAVES 4        /* waves per SIMD the kernel is built for (mcrx_hip.hip sizes the segments by it: acq_lean_waves()) */
+#define ACQ_LEAN_WAVES 3        /* waves per SIMD the kernel is built for (mcrx_hip.hip sizes the segments by it: acq_lean_waves()).  Three = 168
+                                   registers: the kernel's real pressure is ~165, and at four (128) the 40 spilled registers sit on every event's
+                                   chain -- 136 against 110 us per launch, scratch/r5/acq_ab.sh */
 #endif
 #ifndef ACQ_WIN
-#define ACQ_WIN 640             /* samples of the channel staged in LDS at a time: 5 KB per wave */
+#define ACQ_WIN 768             /* samples of the channel staged in LDS at a time: 6 KB per wave (a 64-subcarrier frame's acquisition spans ~720) */
 #endif
 // -DACQ_PROF (development builds): cycles per kind of event of one wave (channel 0, segment 0), printed when it leaves
 #ifdef ACQ_PROF
@@ -107,8 +117,18 @@ struct Acq {
         }
         pf0 = (l < Mp) ? c.Pfit[l] : 0.f; pf1 = (l < Mp) ? c.Pfit[Mp + l] : 0.f;
         gain0 = sqrtf((float)c.M_S0) / (float)M; gain1 = sqrtf((float)c.M_S1) / (float)M;
-        for (int k = l; k < 256 + 16; k += WV) qsg[k] = c.pilot_seq[k >= 255 ? k - 255 : k] == 0 ? 0x80000000u : 0u;
-        for (int k = l; k < MCRX_HDR_SYMS / 2; k += WV) reinterpret_cast<uint32_t *>(hmap)[k] = reinterpret_cast<const uint32_t *>(c.hdr_map)[k];
+        {   // the two tables: every request issued before the first LDS store (one round trip to memory, not one per chunk -- the
+            // set-up was 22 k cycles of a wave's ~110 k per frame)
+            uint8_t ps[5]; uint32_t hm[3];
+#pragma unroll
+            for (int u = 0; u < 5; u++) { const int k = l + WV * u, kc = k < 256 + 16 ? k : 0; ps[u] = c.pilot_seq[kc >= 255 ? kc - 255 : kc]; }
+#pragma unroll
+            for (int u = 0; u < 3; u++) { const int k = l + WV * u; hm[u] = reinterpret_cast<const uint32_t *>(c.hdr_map)[k < MCRX_HDR_SYMS / 2 ? k : 0]; }
+#pragma unroll
+            for (int u = 0; u < 5; u++) { const int k = l + WV * u; if (k < 256 + 16) qsg[k] = ps[u] == 0 ? 0x80000000u : 0u; }
+#pragma unroll
+            for (int u = 0; u < 3; u++) { const int k = l + WV * u; if (k < MCRX_HDR_SYMS / 2) reinterpret_cast<uint32_t *>(hmap)[k] = hm[u]; }
+        }
         if (l < 16) qsrc[l] = 0;
         qesrc[l] = 0;
         wave_sync_lds();
@@ -123,7 +143,7 @@ struct Acq {
         rlen = (int32_t)(a.end - a.buf_first);
         rmin = a.buf_first < 0 ? (int32_t)(-a.buf_first) : 0;         // (samples of negative absolute index are zeros: Walker::sample)
         R.x = 0.f; R.y = 0.f;
-        jblk_next = 0; jblk_end = 0; handoff_job = 0; handoff_last = 0;
+        handoff_job = 0; handoff_last = 0;
     }
     __device__ __forceinline__ void reset_framesync()
     {
@@ -174,24 +194,30 @@ struct Acq {
     __device__ __forceinline__ v2f window(int64_t t0)
     {
         const int32_t r0 = (int32_t)(t0 - a.buf_first);
-        if (!(w0 != INT32_MIN && r0 >= w0 && r0 + WV <= w0 + ACQ_WIN)) {
+        stage_from(r0, WV);
+        v2f v = wbuf[r0 - w0 + l];
+        if constexpr (MM < WV) { if (l >= MM) { v.x = 0.f; v.y = 0.f; } }          // (a window is MM samples)
+        return v;
+    }
+    // make [r0, r0 + n) available in wbuf (n <= ACQ_WIN); staged from r0 on when it is not
+    __device__ __forceinline__ void stage_from(int32_t r0, int32_t n)
+    {
+        if (!(w0 != INT32_MIN && r0 >= w0 && r0 + n <= w0 + ACQ_WIN)) {
             ACQ_T0();
             wave_sync_lds();
+            static_assert((ACQ_WIN / WV) % 6 == 0, "the staging loop takes six requests per lane at a time");
 #pragma unroll 1
-            for (int h = 0; h < ACQ_WIN / WV; h += 5) {                  // five requests per lane in flight at a time (registers)
-                v2f t[5];
+            for (int h = 0; h < ACQ_WIN / WV; h += 6) {                  // six requests per lane in flight at a time (registers)
+                v2f t[6];
 #pragma unroll
-                for (int i = 0; i < 5; i++) t[i] = sample_at(r0 + WV * (h + i) + l);
+                for (int i = 0; i < 6; i++) t[i] = sample_at(r0 + WV * (h + i) + l);
 #pragma unroll
-                for (int i = 0; i < 5; i++) wbuf[WV * (h + i) + l] = t[i];
+                for (int i = 0; i < 6; i++) wbuf[WV * (h + i) + l] = t[i];
             }
             wave_sync_lds();
             w0 = r0;
             ACQ_T1(8);
         }
-        v2f v = wbuf[r0 - w0 + l];
-        if constexpr (MM < WV) { if (l >= MM) { v.x = 0.f; v.y = 0.f; } }          // (a window is MM samples)
-        return v;
     }
     __device__ __forceinline__ v2f fft64(v2f x) const             // (the MM-point transform; the name is round 5's first build's)
     {
@@ -257,7 +283,9 @@ struct Acq {
             timer = rfl((uint32_t)(M + cp - backoff) - (uint32_t)(int)roundf(tau));
             // CFO: time-domain ML estimate over the two halves of the oldest M window samples (lanes 0..31: sample i and i + M/2)
             const v2f y = window(t_ev - L + 1);
-            const float2 s0 = c.s0t[l < M ? l : 0];
+            int i_s = l < M ? l : 0;
+            asm volatile("" : "+v"(i_s));
+            const float2 s0 = c.s0t[i_s];
             const float r1x = gather(half, y.x), r1y = gather(half, y.y), sbx = gather(half, s0.x), sby = gather(half, s0.y);
             float2 t = cmul(cmulc(s0, make_float2(y.x, y.y)), cmulc(make_float2(r1x, r1y), make_float2(sbx, sby)));
             if (l >= M2) t = make_float2(0.f, 0.f);
@@ -298,8 +326,11 @@ struct Acq {
 #endif
                 const float gab = sqrtf(G.x * G.x + G.y * G.y), gar = atan2f(G.y, G.x);
                 float smn[5], smk[5];
+                int i_n = l * 5, i_k = kk * 5;
+                asm volatile("" : "+v"(i_n), "+v"(i_k));           // (opaque: the ten loads stay here, in the one event per frame that needs them -- hoisted
+                                                                    //  out of the event loop they were ten registers held for the whole walk)
 #pragma unroll
-                for (int d = 0; d < 5; d++) { smn[d] = (l < Nen) ? c.smn[l * 5 + d] : 0.f; smk[d] = c.smk[kk * 5 + d]; }
+                for (int d = 0; d < 5; d++) { smn[d] = (l < Nen) ? c.smn[i_n + d] : 0.f; smk[d] = c.smk[i_k + d]; }
                 // rank order: lane n takes the enabled bin of rank n
                 // (both gathers outside any lane condition: ds_bpermute returns zero for a source lane that is masked off)
                 const float gva = gather(esrc, gab);
@@ -384,16 +415,26 @@ struct Acq {
     }
 
     // job list entries come in blocks (Walker::reserve_block / park_state / void_block)
+    // (the counter's answer is only looked at when the first entry is needed -- jblk_wait -- so the atomic's round trip runs under
+    //  whatever the wave does in between: the first block is asked for before the set-up)
+    uint32_t jblk_v; bool jblk_pending = false;
     __device__ __forceinline__ void reserve_block()
     {
         const uint32_t nb = a.seg_jobs ? a.seg_jobs : 1u;
-        uint32_t b = 0;
-        if (l == 0) b = atomicAdd(a.njobs, nb);
-        jblk_next = rfl(b); jblk_end = jblk_next + nb;
+        jblk_v = 0;
+        if (l == 0) jblk_v = atomicAdd(a.njobs, nb);
+        jblk_pending = true;
+    }
+    __device__ __forceinline__ void jblk_wait()
+    {
+        if (!jblk_pending) return;
+        const uint32_t nb = a.seg_jobs ? a.seg_jobs : 1u;
+        jblk_next = rfl(jblk_v); jblk_end = jblk_next + nb; jblk_pending = false;
     }
     __device__ __forceinline__ uint32_t park_state()
     {
-        if (jblk_next == jblk_end) reserve_block();
+        jblk_wait();
+        if (jblk_next == jblk_end) { reserve_block(); jblk_wait(); }
         const uint32_t j = jblk_next++;
         if (j >= a.max_jobs) return 0xFFFFFFFFu;
         if (l == 0) { PayloadJob jb; jb.s = make_state(); jb.ch = 0xFFFFFFFFu; jb.pad = 0; jb.arena_off = 0; jb.syms_off = 0; a.jobs[j] = jb; }
@@ -401,6 +442,7 @@ struct Acq {
     }
     __device__ __forceinline__ void void_block()
     {
+        jblk_wait();
         for (uint32_t q = jblk_next + (uint32_t)l; q < jblk_end; q += WV) if (q < a.max_jobs) a.jobs[q].ch = 0xFFFFFFFFu;
         jblk_next = jblk_end;
     }
@@ -493,27 +535,47 @@ struct Acq {
         ACQ_T1(6);
         return r_;
     }
-    __device__ __forceinline__ int64_t coarse_scan_(int64_t from, int64_t to) const
+    __device__ __forceinline__ int64_t coarse_scan_(int64_t from, int64_t to)
     {
         if (to > a.end - M) to = a.end - M;
         if (from < a.buf_first) from = a.buf_first;
         if (from < 0) from = 0;
+        // A range that fits the staging buffer (the validation scans behind a lattice point: four symbols) is read from LDS: one round
+        // trip to memory for the wave instead of one per eight products, and -- staged from M samples in front of `from` -- the buffer
+        // then already holds the windows of the frame the wave goes on to acquire from that point.
+        if (to > from && (to - from) + M + M2 + M <= (int64_t)ACQ_WIN && from - M >= a.buf_first && from - M >= 0) {
+            const int32_t rb = (int32_t)(from - M - a.buf_first);
+            stage_from(rb, (int32_t)((to - from) + 2 * M + M2));
+            const int64_t d = from + (int64_t)l * M2;
+            const bool in = d < to;
+            const v2f *w = wbuf + (rb - w0) + M + (in ? l * M2 : 0);
+            float2 acc = make_float2(0.f, 0.f); float en = 0.f;
+#pragma unroll 4
+            for (int n = 0; n < M2; n++) {
+                const v2f u = w[n], v = w[n + M2];
+                acc = cadd(acc, cmulc(make_float2(u.x, u.y), make_float2(v.x, v.y)));
+                en += u.x * u.x + u.y * u.y + v.x * v.x + v.y * v.y;
+            }
+            const bool hit = in && (acc.x * acc.x + acc.y * acc.y) > 0.09f * en * en;
+            const unsigned long long b = __ballot(hit);
+            return b ? from + (int64_t)__builtin_ctzll(b) * M2 : -1;
+        }
         for (int64_t p0 = from; p0 < to; p0 += (int64_t)WV * M2) {
             const int64_t d = p0 + (int64_t)l * M2;
             const bool in = d < to;
             const uint32_t r0 = (uint32_t)((in ? d : p0) - a.buf_first);
             float2 acc = make_float2(0.f, 0.f); float en = 0.f;
 #pragma unroll 1
-            for (int n0 = 0; n0 < M2; n0 += 4) {
-                float2 u[4], v[4];
+            for (int n0 = 0; n0 < M2; n0 += 8) {                        // eight products at a time, their sixteen loads in flight together
+                float2 u[8], v[8];
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 0; q < 8; q++) {
                     const uint32_t ru = r0 + (uint32_t)(n0 + q), rv = ru + (uint32_t)M2;
                     u[q] = chb[(size_t)(ru >> MCRX_TILE_SH) * tstride + (ru & (uint32_t)(MCRX_TILE_S - 1))];
                     v[q] = chb[(size_t)(rv >> MCRX_TILE_SH) * tstride + (rv & (uint32_t)(MCRX_TILE_S - 1))];
                 }
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 0; q < 8; q++) {
                     acc = cadd(acc, cmulc(u[q], v[q]));
                     en += u[q].x * u[q].x + u[q].y * u[q].y + v[q].x * v[q].x + v[q].y * v[q].y;
                 }
@@ -531,8 +593,10 @@ struct Acq {
         const uint32_t spw = a.spec_cap / a.nseg;
         SpecSlot *sl0 = a.spec + (size_t)ch * a.spec_stride + (size_t)g * spw;
         const int phase = a.seg_phase;
-        { ACQ_T0(); init(qsrc, qesrc);
-        load_state(a.st[ch]); ACQ_T1(7); }
+        load_state(a.st[ch]);
+        jblk_next = 0; jblk_end = 0;
+        if (!(st == SY_RX && fstate == FX_PAYLOAD)) reserve_block();       // (its answer is waited for at the first hand-off)
+        { ACQ_T0(); init(qsrc, qesrc); ACQ_T1(7); }
         sk_cur = 0; sk_timer = 0;
         if (a.seekst) { sk_cur = rfl64(a.seekst[2 * (size_t)ch]); sk_timer = rfl((uint32_t)a.seekst[2 * (size_t)ch + 1]); }
         const bool mid_payload = st == SY_RX && fstate == FX_PAYLOAD;
@@ -556,6 +620,11 @@ struct Acq {
             return coarse_scan(p, p + 4 * (int64_t)L + M2) >= 0;
         };
         int64_t p_next = -1;
+        if (go && !last && phase != 1) {                        // (the next wave's own rule, on its own segment -- looked at FIRST: the samples
+            int64_t pn = lattice(seg_end);                       //  staged for this wave's own start are then the ones left in LDS)
+            if (pn >= 0 && g + 2 != a.nseg && pn >= seg_end + seg_len) pn = -1;
+            if (preamble_behind(pn)) p_next = pn;
+        }
         if (go) {
             if (g == 0 && phase == 2 && A >= 0) {
                 j = 1;
@@ -580,13 +649,7 @@ struct Acq {
                     else { const int64_t p = hit - M; cur = p > seg_start ? p : seg_start; }
                 }
             }
-            if (go && !last && phase != 1) {
-                int64_t pn = lattice(seg_end);
-                if (pn >= 0 && g + 2 != a.nseg && pn >= seg_end + seg_len) pn = -1;
-                if (preamble_behind(pn)) p_next = pn;
-            }
         }
-        if (go) reserve_block();
         while (go && j < jmax) {
             SpecSlot *slot = sl0 + j;
             int verdict = 0;

@@ -213,7 +213,7 @@ struct SyncArgs {
     // behind that point -- and a wave whose chain arrives exactly at the next segment's validated start stops there.  A wrong or
     // missing prediction costs nothing but the two acquisitions again (the coarse start); the results never depend on it.
     int no_syms;                         // 1 (mcrx_hip_config::skip_framesyms = 2): the lean payload workers do not store the equalised symbols at all
-    int seg_walker;                      // 1: the Walker's build of the segment waves (sync_spec_kernel) where the lean one (acq_lean.hpp) would run
+    int seg_walker;                      // 1 (default): the segment waves are the Walker's kernel (sync_spec_kernel); 0 (scout_build = 2): acq_lean.hpp's where the design allows
     int seg_phase;                       // 1: first frame from the entry state only (grid = channels); 2: the rest; 0: one launch, no cadence
     int64_t *anchor;                     // [nch] where phase 1's frame ended + 1 (-1: it did not hand a frame off)
     int64_t *seekst;                     // [nch][2] the SEEK state (cur, timer) the acquisition a channel's push ENDED in was detected from: where that

@@ -194,7 +194,7 @@ struct mcrx_hip_s {
     // workers per SIMD neither fits beside them any more, and a scout that adopts 100 frames of a channel pays for every spill:
     // 8 channels 54.7 -> 64.8 Gsample/s, 512 channels 166.4 -> 169.9 (same box, same run; MCRX_LEAN_BUILD)
     int lean_build = 1;
-    int seg_walker = 0;                     // mcrx_hip_config::scout_build = 2: the segment waves as the Walker's kernel, not acq_lean.hpp's
+    int seg_walker = 1;                     // 1: the segment waves are the general state machine's kernel (default); mcrx_hip_config::scout_build = 2: acq_lean.hpp's
     // streaming state
     uint64_t total_samples = 0;             // wideband samples accepted since creation (NCO phase)
     uint64_t stage_first = 0;               // absolute index of h_stage[0]
@@ -569,7 +569,7 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
         const uint32_t sb = field(offsetof(mcrx_hip_config, scout_build));
         if (sb > 2) return bail(fail(MCRX_EINVAL, "scout_build out of range"));
         if (sb == 1) q->lean_build = 0;
-        if (sb == 2) q->seg_walker = 1;
+        if (sb == 2) q->seg_walker = 0;
     }
     if (devel_env("MCRX_PAYLOAD_FR")) q->payload_fr = atoi(devel_env("MCRX_PAYLOAD_FR"));
     if (devel_env("MCRX_PAYLOAD_LEAN")) q->payload_lean = atoi(devel_env("MCRX_PAYLOAD_LEAN")) != 0;

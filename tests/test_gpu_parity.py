@@ -537,9 +537,9 @@ def test_speculation_survives_wrong_predictions(oracle, product):
 
 @pytest.mark.parametrize("scout_build", [1, 0, 2])
 def test_both_builds_of_the_rounds_scout_equal_the_oracle(oracle, product, scout_build):
-    """The acquisition launches the lean segment waves (csrc/acq_lean.hpp) and the scouts' unbudgeted build by default, the scouts'
-    168-register build on request (mcrx_hip_config::scout_build = 1: sync_lean_kernel) and the general state machine's segment waves
-    (scout_build = 2: sync_spec_kernel, the only ones until round 5); a periodic stream long enough for cadence speculation -- every
+    """The acquisition launches the general state machine's segment waves and the scouts' unbudgeted build by default, the scouts'
+    168-register build on request (mcrx_hip_config::scout_build = 1: sync_lean_kernel) and the lean segment waves of 48- / 64-subcarrier
+    symbols (scout_build = 2: csrc/acq_lean.hpp); a periodic stream long enough for cadence speculation -- every
     frame but the first adopted, a dozen per channel chased in one go -- pushed in pieces must give the oracle's frames
     through either."""
     import torch
