@@ -76,7 +76,7 @@ def parse():
     ap.add_argument("--chunk-blocks", type=int, default=0, help="split every push into sub-slabs of this many blocks")
     ap.add_argument("--defer", type=int, default=-1, help="cfg.defer_samples (experiments; default: 16384 on the pipeline paths, 0 on the direct one)")
     ap.add_argument("--serial", action="store_true", help="time the unpipelined receiver (every kernel in order on one stream)")
-    ap.add_argument("--contact-timeout", type=float, default=600.0,
+    ap.add_argument("--contact-timeout", type=float, default=240.0,
                     help="--gpus > 1: seconds the rendezvous, the first collective and the first exchange round may each take before rank 0 "
                          "prints a line with value 0 and the stage that hung")
     ap.add_argument("--pipeline", action="store_true", help="--gpus 1 through the multi-GPU code path (sharding.Pipeline, exchange = local copy)")

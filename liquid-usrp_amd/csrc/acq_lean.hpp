@@ -598,7 +598,7 @@ struct Acq {
         if (!(st == SY_RX && fstate == FX_PAYLOAD)) reserve_block();       // (its answer is waited for at the first hand-off)
         { ACQ_T0(); init(qsrc, qesrc); ACQ_T1(7); }
         sk_cur = 0; sk_timer = 0;
-        if (a.seekst) { sk_cur = rfl64(a.seekst[2 * (size_t)ch]); sk_timer = rfl((uint32_t)a.seekst[2 * (size_t)ch + 1]); }
+        if (a.seekst && g == 0 && st != SY_SEEK) { sk_cur = rfl64(a.seekst[2 * (size_t)ch]); sk_timer = rfl((uint32_t)a.seekst[2 * (size_t)ch + 1]); }
         const bool mid_payload = st == SY_RX && fstate == FX_PAYLOAD;
         const int64_t base = cur, span = a.end - base;
         const int64_t seg_len = span > 0 ? (span + (int64_t)a.nseg - 1) / (int64_t)a.nseg : 0;

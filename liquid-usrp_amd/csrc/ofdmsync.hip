@@ -2282,7 +2282,8 @@ struct Walker {
         const int M = c.M, M2 = c.M2, L = c.L;
         const int phase = a.seg_phase;
         s = a.st[ch];
-        if (a.seekst) { sk_cur = a.seekst[2 * (size_t)ch]; sk_timer = (uint32_t)a.seekst[2 * (size_t)ch + 1]; }               // (segment 0 may start in the middle of an acquisition the previous push began)
+        // (segment 0 may start in the middle of an acquisition the previous push began: only then does the detection lie in another push)
+        if (a.seekst && g == 0 && s.state != SY_SEEK) { sk_cur = a.seekst[2 * (size_t)ch]; sk_timer = (uint32_t)a.seekst[2 * (size_t)ch + 1]; }
         const bool mid_payload = s.state == SY_RX && s.fstate == FX_PAYLOAD;      // (a payload that runs through this whole push: the tail kernel's)
         const int64_t base = s.cur, span = a.end - base;
         const int64_t seg_len = span > 0 ? (span + (int64_t)a.nseg - 1) / (int64_t)a.nseg : 0;
@@ -2429,7 +2430,7 @@ struct Walker {
     __device__ __forceinline__ void run()
     {
         s = a.st[ch];
-        if (a.seekst) { sk_cur = a.seekst[2 * (size_t)ch]; sk_timer = (uint32_t)a.seekst[2 * (size_t)ch + 1]; }
+        if (a.seekst && s.state != SY_SEEK) { sk_cur = a.seekst[2 * (size_t)ch]; sk_timer = (uint32_t)a.seekst[2 * (size_t)ch + 1]; }
         const bool mid_payload = s.state == SY_RX && s.fstate == FX_PAYLOAD;
         if constexpr (MODE == SYM_LEAN) { if (mid_payload) return; }
         else if (a.tail_only && !mid_payload) return;
@@ -2568,7 +2569,7 @@ struct Walker {
         // a header in progress continues in the next launch: its bits move from LDS to the channel's HBM slot
         if (fastp && s.state == SY_RX && s.fstate == FX_HEADER && s.header_symbol_index > 0)
             for (int i = l; i < MCRX_HDR_SYMS; i += WV) bhbits[i] = ldshb[i];
-        if (l == 0 && a.seekst) { a.seekst[2 * (size_t)ch] = sk_cur; a.seekst[2 * (size_t)ch + 1] = (int64_t)sk_timer; }
+        if (l == 0 && a.seekst && s.state != SY_SEEK) { a.seekst[2 * (size_t)ch] = sk_cur; a.seekst[2 * (size_t)ch + 1] = (int64_t)sk_timer; }      // (a push that ends in SEEK carries nothing over)
         if (l == 0) a.st[ch] = s;
     }
 };
