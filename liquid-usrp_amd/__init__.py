@@ -72,6 +72,7 @@ _EXPORTS = {
     "mcrx_hip_history_tiles": (C.c_uint, [C.c_void_p]),
     "mcrx_hip_stream_wait_launch": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
     "mcrx_hip_spec_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]),
+    "mcrx_hip_viterbi_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]),
     "mcrx_hip_frames_pending": (C.c_size_t, [C.c_void_p]),
     "mcrx_hip_next_frame": (C.c_int, [C.c_void_p, C.POINTER(FrameC)]),
     "mcrx_hip_drain_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
@@ -294,6 +295,12 @@ class multichannelrx(object):
         a, b = C.c_uint64(0), C.c_uint64(0)
         _check(lib().mcrx_hip_spec_stats(self._h, C.byref(a), C.byref(b), 1 if reset else 0))
         return int(a.value), int(b.value)
+
+    def viterbi_stats(self, reset=False):
+        """(frames through the K = 7 decoder's own kernel, forward passes repeated, traceback passes repeated)"""
+        a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        _check(lib().mcrx_hip_viterbi_stats(self._h, C.byref(a), C.byref(b), C.byref(c), 1 if reset else 0))
+        return int(a.value), int(b.value), int(c.value)
 
     def _deliver(self, flush):
         f = FrameC()

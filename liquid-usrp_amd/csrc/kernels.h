@@ -178,7 +178,10 @@ struct SyncArgs {
     uint8_t *jsoft;             // [max_jobs][8*max_enc_len]
     uint8_t *jtmp;              // [max_jobs][2*(max_enc_len+16)]
     int debug;                 // MCRX_DEBUG=1: trace state-machine events of channel 0
-    uint32_t *vit_list; uint32_t vit_cap;   // trellis blocks for viterbi_blocks_kernel: [0] = count, then (job << 6 | block); filled by decode_kernel
+    uint32_t *vit_list; uint32_t vit_cap;   // frames for viterbi_frames_kernel: [0] = count, then job indices; filled by decode_kernel
+    uint2 *vit_scratch;         // the K = 7 decoder's decision rows: [vit_waves][vit_rows][64] (one region per workgroup of viterbi_frames_kernel; csrc/viterbi_frames.hpp)
+    uint32_t vit_rows, vit_waves;
+    uint32_t *vit_passes;       // [0] forward passes repeated, [1] traceback passes repeated (blocks whose survivors had not merged inside the overlap), [2] frames; NULL: not counted
     // list-driven launches that are nearly always empty (QAM payload workers, trellis blocks, general decoder): a launch of
     // 8192 do-nothing workgroups still has to find 8192 wave slots, behind the channelizer's whole-CU workgroups -- measured
     // 0.15-0.27 ms on the work stream.  The kernels walk their lists with a grid stride, so any grid is correct; the host
@@ -193,7 +196,7 @@ struct SyncArgs {
     uint32_t *live, *live_next;
     uint32_t frames_hint;       // ~0: unknown
     uint32_t live_off;          // lean workers: the main launch's grid (payload_lean.hpp, REST)
-    uint32_t *list_hint;        // [0] QAM hand-offs, [1] trellis blocks, [2] frames on the general list, of the most recent launch
+    uint32_t *list_hint;        // [0] QAM hand-offs, [1] frames of the K = 7 decoder, [2] frames on the general list, of the most recent launch
     uint32_t grid_hint[3];      // what the host last read there (~0: no hint, full grids)
     uint32_t payload_lds_pad;  // bytes of unused dynamic LDS per payload worker: caps the workers' occupancy (walk mode, launch_sync)
     int seek_burst;            // idle stretches: SEEK events four at a time, their windows requested together (Walker::seek_burst)
@@ -242,6 +245,13 @@ struct SyncArgs {
     int payload_fr, payload_lean, payload_xb;      // which build of the M = 64 workers (MCRX_PAYLOAD_FR / _LEAN / _XB at creation; defaults 1, 1, 63): the parity tests compare them
     uint32_t vit_off;          // byte offset of the convolutional decoder's 8 KB block scratch in the launch's dynamic LDS (0: none; set by the launchers)
 };
+// the K = 7 decoder's geometry (csrc/viterbi_frames.hpp): T trellis steps in at most 64 blocks of a multiple of 24 steps, each run W steps
+// early and W steps long; a wave keeps B + 2 W decision rows of 512 bytes
+namespace vf {
+constexpr unsigned W = 48;
+__host__ __device__ constexpr unsigned block_steps(unsigned T) { return 24u * ((T + 1535u) / 1536u); }
+__host__ __device__ constexpr unsigned rows_for(unsigned T) { return block_steps(T) + 2u * W; }
+}
 hipError_t sync_launch(const SyncArgs &a, hipStream_t st);           // full state machine, one wave per channel (general configurations; tail kernel)
 hipError_t sync_launch_tail(const SyncArgs &a, hipStream_t st);      // lean configurations: payloads in progress, to the frame's end (a.tail_only = 1)
 // fill `map` for the `nlen` coded lengths lens[k] at coded-byte offsets offs[k]; lo / hi: scratch of the map's size in bytes / 2 each

@@ -170,6 +170,7 @@ struct mcrx_hip_s {
     // per-launch slots
     PayloadJob *d_jobs[MCRX_SLOTS] = {}; uint32_t *d_njobs = nullptr; float2 *d_jR[MCRX_SLOTS] = {};
     uint32_t *d_gen[MCRX_SLOTS] = {}, *d_vit[MCRX_SLOTS] = {}, *d_qam[MCRX_SLOTS] = {}, *d_live[MCRX_SLOTS] = {}; uint32_t vit_cap = 0;
+    uint2 *d_vit_scratch = nullptr; uint32_t vit_rows = 0, vit_waves = 0; uint32_t *d_vit_passes = nullptr;      // the K = 7 decoder's decision rows (kernels.h: vit_scratch)
     uint64_t seq = 0;                       // synchronizer launches so far (slot = seq % nslots)
     unsigned nslots = 5;                    // buffer sets in use: the channelizer and the acquisition chain of up to nslots - 1 pushes run ahead of the payload workers
     uint32_t *d_stats = nullptr;            // speculation statistics (SyncArgs::stats)
@@ -258,6 +259,12 @@ struct mcrx_hip_s {
         T *p = nullptr;
         RC(upload_raw(&p, src, n));
         owned.push_back(p); *dst = p;
+        return MCRX_OK;
+    }
+    template <class T> int alloc_raw(T **dst, size_t n)           // (scratch that is written before it is read: not cleared)
+    {
+        HIPCHK(hipMalloc((void **)dst, std::max<size_t>(n, 1) * sizeof(T)));
+        owned.push_back(*dst);
         return MCRX_OK;
     }
     template <class T> int alloc(T **dst, size_t n)
@@ -596,11 +603,21 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
             if ((rc = q->alloc(&q->d_gen[sl], (size_t)q->max_jobs + 1))) return bail(rc);
             if ((rc = q->alloc(&q->d_qam[sl], (size_t)q->max_jobs + 1))) return bail(rc);
             if ((rc = q->alloc(&q->d_live[sl], (size_t)q->max_jobs + 1))) return bail(rc);
-            q->vit_cap = (uint32_t)std::min<uint64_t>((uint64_t)q->max_rec * ((4ull * q->max_enc + 6 + 959) / 960), 1u << 24);      // trellis blocks of every frame of a launch
+            q->vit_cap = q->max_jobs;                                   // frames of a launch for the K = 7 decoder's own kernel
             if ((rc = q->alloc(&q->d_vit[sl], (size_t)q->vit_cap + 1))) return bail(rc);
             if ((rc = q->alloc(&q->d_jR[sl], (size_t)q->max_jobs * M))) return bail(rc);
             if ((rc = q->alloc(&q->d_jsoft[sl], (size_t)q->max_jobs * 8 * q->max_enc))) return bail(rc);
             if ((rc = q->alloc(&q->d_jtmp[sl], (size_t)q->max_jobs * 2 * (q->max_enc + 16)))) return bail(rc);
+        }
+        if (q->sc.payload_soft) {
+            // The K = 7 decoder's own kernel takes a frame per wave and keeps 512 bytes of decisions per trellis step of a block in HBM:
+            // one region per workgroup, as many workgroups as a launch can have frames (at most 2 per SIMD: the kernel is arithmetic).
+            // Its launches follow each other on the work stream, so one set serves every slot.  (~200 KB per workgroup at 1200-byte
+            // payloads; a handle never asked for a convolutional frame pays the allocation and nothing else.)
+            q->vit_rows = vf::rows_for(4u * q->max_enc + 6u);
+            q->vit_waves = (uint32_t)std::max<uint64_t>(64, std::min<uint64_t>(q->max_rec, 2048));
+            if ((rc = q->alloc_raw(&q->d_vit_scratch, (size_t)q->vit_waves * q->vit_rows * 64))) return bail(rc);
+            if ((rc = q->alloc(&q->d_vit_passes, 8))) return bail(rc);
         }
         // speculative acquisition (lean path only): slots, their equalisers, the prediction lists
         const bool lean = (q->sc.log2M >= 6 && q->sc.M == 64 * q->sc.E && q->sc.M_pilot <= 64) ||
@@ -750,6 +767,7 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     a.scout = q->scout ? 1 : 0;
     a.jobs = q->d_jobs[slot]; a.njobs = q->d_njobs + slot; a.njobs_next = q->d_njobs + next; a.max_jobs = q->max_jobs;
     a.gen_list = q->d_gen[slot]; a.dec_lds_soft = 0; a.vit_list = q->d_vit[slot]; a.vit_cap = q->vit_cap;
+    a.vit_scratch = q->d_vit_scratch; a.vit_rows = q->vit_rows; a.vit_waves = q->vit_waves; a.vit_passes = q->d_vit_passes;
     a.qam_list = q->d_qam[slot]; a.qam_next = q->d_qam[next]; a.list_hint = nullptr;
     a.live = q->d_live[slot]; a.live_next = q->d_live[next];
     a.live_off = 0;
@@ -1366,6 +1384,24 @@ extern "C" int mcrx_hip_spec_stats(mcrx_hip_t q, uint64_t *walked, uint64_t *ado
     if (walked) *walked = v[0];
     if (adopted) *adopted = v[1];
     if (reset) HIPCHK(hipMemset(q->d_stats, 0, 8 * sizeof(uint32_t)));
+    return MCRX_OK;
+}
+
+extern "C" int mcrx_hip_viterbi_stats(mcrx_hip_t q, uint64_t *frames, uint64_t *forward_repeats, uint64_t *traceback_repeats, int reset)
+{
+    if (!q) return fail(MCRX_EINVAL, "null handle");
+    uint32_t v[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    if (q->d_vit_passes) {
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpy(v, q->d_vit_passes, sizeof(v), hipMemcpyDeviceToHost));
+        if (reset) HIPCHK(hipMemset(q->d_vit_passes, 0, sizeof(v)));
+    }
+    if (frames) *frames = v[2];
+#ifdef VF_PROF                  // (make S1FLAGS=-DVF_PROF: the kernel then leaves its clock readings in words 4..7)
+    if (q->debug && v[2]) fprintf(stderr, "[viterbi] frames %u, per frame: forward %.1f us, traceback %.1f us ; first to last wave start %.1f us (builds with -DVF_PROF)\n", v[2], v[4] / 100.0 / v[2], v[5] / 100.0 / v[2], (v[7] - ~v[6]) / 100.0);
+#endif
+    if (forward_repeats) *forward_repeats = v[0];
+    if (traceback_repeats) *traceback_repeats = v[1];
     return MCRX_OK;
 }
 

@@ -52,6 +52,7 @@ namespace mcrx {
 // ------------------------------------------------------------------ small utilities
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 #include "lean_prims.hpp"       // packed-f32 / LDS-crossbar building blocks, the lane <-> subcarrier maps of the lean transforms
+#include "viterbi_frames.hpp"   // the K = 7 soft decoder of viterbi_frames_kernel: a frame per wave, a trellis block per lane
 
 __device__ __forceinline__ unsigned fec_enc_len_d(unsigned fs, unsigned n)
 {
@@ -424,66 +425,6 @@ __device__ void conv27_decode_wave(const VitSym sy, unsigned n_, uint8_t *dec, u
     }
 }
 
-// The same decoder, one BLOCK of VIT_B steps per wave, so that a frame's trellis is worked on by all its blocks at once
-// (viterbi_blocks_kernel) instead of three serial passes of one wave.  A block does not know the path metrics at its first
-// step nor the survivor's state at its last: it starts VIT_W steps early from equal metrics and runs VIT_W steps past its
-// end, tracing back from the best state there.  After a few constraint lengths every survivor has merged into the one the
-// full decoder keeps (K = 7: ~35 steps; VIT_W = 192 is 27 K), from there on the metric DIFFERENCES, hence every decision
-// and every tie, are the full decoder's -- the first block starts from the true metrics and the last one ends in the true
-// state 0.  Byte-equal to oracle/ll_fec.c's full traceback in tests/test_gpu_parity.py::test_convolutional_* and the soak.
-#define VIT_W 192u
-__device__ void conv27_decode_block(const VitSym sy, unsigned n_, unsigned b_, uint8_t *dec, unsigned long long *lds)
-{
-    const int s = lane_id();
-    const unsigned n = (unsigned)__builtin_amdgcn_readfirstlane((int)n_), b = (unsigned)__builtin_amdgcn_readfirstlane((int)b_);
-    const unsigned T = 8 * n + 6;
-    const unsigned t0 = b * VIT_B;
-    if (t0 >= T) return;
-    const unsigned t1 = t0 + VIT_B < T ? t0 + VIT_B : T;
-    const unsigned tw = t0 >= VIT_W ? t0 - VIT_W : 0u, te = t1 + VIT_W < T ? t1 + VIT_W : T;
-    int pm = (tw == 0u && s) ? (1 << 20) : 0;               // stream start: the encoder's state 0; elsewhere: nothing known
-    if (tw < t0) pm = vit_forward<false>(sy, tw, t0, T, pm, nullptr);
-    pm = vit_forward<true>(sy, t0, te, T, pm, lds);         // decision words of steps t0 .. te-1
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    unsigned state = 0;                                     // te == T: the tail bits return the encoder to state 0
-    if (te < T) {
-        int mn = pm;
-#pragma unroll
-        for (int h = 32; h >= 1; h >>= 1) { const int o = __shfl_xor(mn, h, WV); mn = o < mn ? o : mn; }
-        const unsigned lane = (unsigned)__builtin_ctzll(__ballot(pm == mn));
-        state = rotl6(lane, te % 6u);                       // the lane layout of vit_forward at time te
-    }
-    for (unsigned c1 = te; c1 > t0;) {
-        const unsigned c0 = (c1 - 1) & ~63u, cn = c1 - c0;
-        const unsigned long long w = (unsigned)s < cn ? lds[c0 - t0 + s] : 0ull;
-        unsigned r1 = (c0 + cn) % 6;
-        const unsigned wlo = (unsigned)w, whi = (unsigned)(w >> 32);
-#define VIT_BACK(K)                                                                                            \
-        {                                                                                                  \
-            const unsigned long long wk = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)whi, (int)(K)) << 32) | \
-                                          (unsigned)__builtin_amdgcn_readlane((int)wlo, (int)(K));          \
-            const unsigned ln = ((state * 65u) >> r1) & 63u;                                                \
-            state = (state >> 1) | ((unsigned)((wk >> ln) & 1ull) << 5);                                   \
-            r1 = r1 ? r1 - 1u : 5u;                                                                        \
-        }
-        unsigned k = cn;
-        while (k & 7u) { k--; VIT_BACK(k) }
-        unsigned long long bytes = 0;
-        while (k) {
-            k -= 8;
-            const unsigned s1 = state;
-            VIT_BACK(k + 7) VIT_BACK(k + 6) VIT_BACK(k + 5) VIT_BACK(k + 4) VIT_BACK(k + 3) VIT_BACK(k + 2)
-            const unsigned s2 = state;
-            VIT_BACK(k + 1) VIT_BACK(k)
-            bytes |= (unsigned long long)(((s2 & 3u) << 6) | (s1 & 63u)) << k;
-        }
-#undef VIT_BACK
-        const unsigned by = (c0 >> 3) + (unsigned)s;
-        if (c0 < t1 && s < 8 && by < n) dec[by] = (uint8_t)(bytes >> (8 * (unsigned)s));      // (chunks past t1 only steer the traceback)
-        c1 = c0;
-    }
-}
-
 // Hamming(7,4) codeword p1 p2 d1 p4 d2 d3 d4 (MSB first); Hamming(8,4) = the same with the overall parity as the LSB
 __device__ __forceinline__ unsigned hsmall_enc_d(unsigned s, unsigned nb)
 {
@@ -618,7 +559,7 @@ __device__ void soft_pack(const uint8_t *soft, unsigned nbytes, uint8_t *out, bo
 __device__ bool packet_decode(const CodingDev cod, bool soft_mode, bool scrambled, unsigned n_msg,
                               unsigned crc, unsigned fec0, unsigned fec1,
                               uint8_t *soft, uint8_t *tmpa, uint8_t *tmpb, unsigned long long *vit_lds = nullptr, unsigned ablate = 0,
-                              bool pre_done = false)      // pre_done: soft de-interleaved and Viterbi-decoded into tmpa already (decode_kernel + viterbi_blocks_kernel)
+                              bool pre_done = false)      // pre_done: soft de-interleaved and Viterbi-decoded into tmpa already (decode_kernel + viterbi_frames_kernel)
 {
     const int l = lane_id();
     const unsigned crc_len = (crc == 6) ? 4u : 0u;
@@ -2591,7 +2532,7 @@ __device__ __forceinline__ void launder(SyncArgs &a)
     LAUNDER(c.cod.crc_zadv); LAUNDER(c.cod.qam16_nb); LAUNDER(c.cod.qam64_nb);
     LAUNDER(chan); LAUNDER(st); LAUNDER(hbits); LAUNDER(R); LAUNDER(soft); LAUNDER(tmpa); LAUNDER(tmpb);
     LAUNDER(syms); LAUNDER(rec); LAUNDER(arena); LAUNDER(sarena); LAUNDER(nrec); LAUNDER(arena_used);
-    LAUNDER(jobs); LAUNDER(njobs); LAUNDER(jR); LAUNDER(jsoft); LAUNDER(jtmp); LAUNDER(vit_list); LAUNDER(qam_list); LAUNDER(hint); LAUNDER(live);
+    LAUNDER(jobs); LAUNDER(njobs); LAUNDER(jR); LAUNDER(jsoft); LAUNDER(jtmp); LAUNDER(vit_list); LAUNDER(vit_scratch); LAUNDER(vit_passes); LAUNDER(qam_list); LAUNDER(hint); LAUNDER(live);
     LAUNDER(spec); LAUNDER(spec_R); LAUNDER(pred); LAUNDER(pred_n); LAUNDER(stats); LAUNDER(walk_hint); LAUNDER(anchor); LAUNDER(seekst);
 }
 #undef LAUNDER
@@ -3029,27 +2970,20 @@ __device__ __forceinline__ void decode_frame(SyncArgs &a, const uint32_t j, uint
     const bool lds_path = c.payload_soft && fec0 == 1 && (fec1 == 6 || fec1 == 7 || fec1 == 1) && 8u * e1 <= lds_soft_bytes && !(a.no_fast & 8);
     if (!lds_path) {                        // everything else: onto the list of decode_general_kernel (one wave per frame, in place in HBM)
         // ... the K = 7 convolutional code as the outer code first gets its soft bits de-interleaved here (the same gather as below,
-        // written back in place) and its trellis blocks onto the list of viterbi_blocks_kernel: the general decoder then finds
+        // written back in place) and the frame onto the list of viterbi_frames_kernel: the general decoder then finds
         // the decoded bytes waiting
         const uint32_t moff = (c.il_off && e1 < c.il_n) ? c.il_off[e1] : ~0u;
-        const bool conv_pre = c.payload_soft && fec1 == 11 && a.vit_list && moff != ~0u && 8u * e1 <= lds_soft_bytes && !(a.no_fast & 8);
-        // The trellis blocks are reserved BEFORE the soft bits are touched (ADVICE r3 / VERDICT r4 #8): the gather below rewrites the
-        // frame's soft bits in place, so a frame that found the block list full must reach the general decoder untouched --
-        // it de-interleaves for itself.  One atomic add per frame; the counter only ever moves up (a counter that moves both ways under
-        // concurrent reservations hands entries out twice), so a reservation that does not fit leaves a hole up to the list's end,
-        // which it fills with void entries (~0: viterbi_blocks_kernel skips them).  (A compare-and-swap loop was tried first: 800
-        // workgroups retrying against each other took 1.4 ms where the add takes microseconds.)
+        const bool conv_pre = c.payload_soft && fec1 == 11 && a.vit_list && a.vit_scratch && moff != ~0u && 8u * e1 <= lds_soft_bytes && !(a.no_fast & 8) &&
+                              vf::rows_for(8u * fec_enc_len_d(fec0, n0) + 6u) <= a.vit_rows;
+        // The list entry is reserved BEFORE the soft bits are touched (ADVICE r3 / VERDICT r4 #8): the gather below rewrites the frame's
+        // soft bits in place, so a frame that found the list full must reach the general decoder untouched -- it de-interleaves for
+        // itself.  One atomic add per frame; the counter only ever moves up and viterbi_frames_kernel clips it to the capacity.
         __shared__ uint32_t dk_vit_at;
-        const uint32_t vit_e0 = fec_enc_len_d(fec0, n0), vit_nblk = (8u * vit_e0 + 6u + VIT_B - 1u) / VIT_B;
+        const uint32_t vit_e0 = fec_enc_len_d(fec0, n0);
         if (conv_pre) {
             if (threadIdx.x == 0) {
-                uint32_t *vl = as_global(a.vit_list);
-                const uint32_t at = atomicAdd(vl, vit_nblk);
-                if (at + vit_nblk <= a.vit_cap) dk_vit_at = at;
-                else {
-                    for (uint32_t b = at; b < a.vit_cap; b++) vl[1u + b] = 0xFFFFFFFFu;
-                    dk_vit_at = ~0u;
-                }
+                const uint32_t at = atomicAdd(as_global(a.vit_list), 1u);
+                dk_vit_at = at < a.vit_cap ? at : ~0u;
             }
             __syncthreads();
         }
@@ -3072,8 +3006,7 @@ __device__ __forceinline__ void decode_frame(SyncArgs &a, const uint32_t j, uint
             uint32_t *gl = as_global(a.gen_list);
             uint32_t tag = j;
             if (conv_go) {
-                uint32_t *vl = as_global(a.vit_list);
-                for (uint32_t b = 0; b < vit_nblk; b++) vl[1u + dk_vit_at + b] = (j << 6) | b;
+                as_global(a.vit_list)[1u + dk_vit_at] = j;
                 tag |= 0x80000000u;
             }                                         // (list full: this frame's trellis stays with the general decoder's single wave)
             gl[1u + atomicAdd(gl, 1u)] = tag;
@@ -3275,23 +3208,27 @@ __global__ __launch_bounds__(DK_T) void decode_kernel(SyncArgs a, uint32_t lds_s
 // The frames the LDS path does not take (hard decisions, an inner code, the convolutional code, frames longer than the
 // LDS sized for this launch): one wave per frame decodes in place in HBM with the walker's general decoder -- a separate
 // kernel so that its registers (the Viterbi decoder's among them) do not set the occupancy of the one above.
-// the trellis blocks decode_kernel listed: one wave each (conv27_decode_block)
-__global__ __launch_bounds__(WV) void viterbi_blocks_kernel(SyncArgs a)
+// the frames decode_kernel listed for the K = 7 decoder: one wave each (viterbi_frames.hpp), decision rows in the workgroup's region of
+// a.vit_scratch, decoded bytes where the general decoder expects them
+__global__ __launch_bounds__(WV) void viterbi_frames_kernel(SyncArgs a)
 {
     launder(a);
-    if (!a.vit_list) return;
+    if (!a.vit_list || !a.vit_scratch) return;
+    __shared__ uint16_t vf_ck[2 * 64 * 64];
     const uint32_t *vl = as_global(a.vit_list);
-    uint32_t nb = vl[0];
-    if (blockIdx.x == 0 && threadIdx.x == 0 && a.list_hint) a.list_hint[1] = nb;
-    if (nb > a.vit_cap) nb = a.vit_cap;
+    uint32_t nf = vl[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.list_hint) a.list_hint[1] = nf;
+    if (nf > a.vit_cap) nf = a.vit_cap;
+    if (blockIdx.x >= a.vit_waves) return;
+    const uint32_t stride = gridDim.x < a.vit_waves ? gridDim.x : a.vit_waves;
     const SyncConsts &c = a.c;
-    for (uint32_t k = blockIdx.x; k < nb; k += gridDim.x) {
-        const uint32_t ent = vl[1 + k], j = ent >> 6, b = ent & 63u;
-        if (ent == 0xFFFFFFFFu) continue;                       // (a reservation that did not fit: decode_kernel)
+    uint2 *rows = a.vit_scratch + (size_t)blockIdx.x * a.vit_rows * 64u;
+    for (uint32_t k = blockIdx.x; k < nf; k += stride) {
+        const uint32_t j = vl[1 + k];
         const uint32_t n_msg = a.jobs[j].s.payload_len, crc = a.jobs[j].s.check, fec0 = a.jobs[j].s.fec0;
         const uint32_t n0 = n_msg + ((crc == 6) ? 4u : 0u), e0 = fec_enc_len_d(fec0, n0);
         const size_t tstride = (size_t)c.max_enc_len + 16;
-        conv27_decode_block(VitSym{ a.jsoft + (size_t)j * 8 * c.max_enc_len, false }, e0, b, a.jtmp + (size_t)j * 2 * tstride, dk_soft);
+        vf::decode_frame(a.jsoft + (size_t)j * 8 * c.max_enc_len, e0, a.jtmp + (size_t)j * 2 * tstride, rows, vf_ck, a.vit_passes);
         __syncthreads();
     }
 }
@@ -3590,7 +3527,17 @@ hipError_t sync_launch_payload(const SyncArgs &a0, int stage, hipStream_t st)
         if (!fast) return hipSuccess;
 
         // (grids from the lists' most recent sizes: kernels.h, list_hint)
-        if (a.vit_list) hipLaunchKernelGGL(viterbi_blocks_kernel, dim3(a.grid_hint[1] ? 8192 : 64), dim3(WV), (size_t)(VIT_B + VIT_W) * 8, st, a);
+        if (a.vit_list && a.vit_scratch) {
+            // (Grid: one workgroup per region of the scratch once the list has been seen non-empty; before that a floor -- a cold start's
+            //  frames then take frames / floor rounds of ~0.25 ms.  Capping the workgroups per CU with unused dynamic LDS -- 4 = one wave
+            //  per SIMD, 8, 2 -- changes nothing or costs: the kernel is bound by vector issue at any occupancy, ~0.25 us per 1200-byte
+            //  frame with the chip full, ~0.22 ms for a wave from start to end: scratch/r5/v27_pad.sh.)
+            size_t pad = 0;
+#ifdef VF_PROF
+            if (getenv("VF_PAD")) pad = (size_t)atoi(getenv("VF_PAD"));
+#endif
+            hipLaunchKernelGGL(viterbi_frames_kernel, dim3(a.grid_hint[1] ? a.vit_waves : (a.vit_waves < 128u ? a.vit_waves : 128u)), dim3(WV), pad, st, a);
+        }
         hipLaunchKernelGGL(decode_general_kernel, dim3(a.grid_hint[2] ? (nj < 4096 ? nj : 4096) : 64), dim3(WV), (size_t)VIT_B * 8, st, a);
         return hipGetLastError();
     }

@@ -427,6 +427,39 @@ def test_convolutional_k7_rate_half_viterbi(oracle, product, mod, fec0, fec1, so
     w = check_frames(rx.frames, ora.frames, rel=1.0)
     assert w <= REL, w
     assert all((f.fec0, f.fec1) == (fec0, fec1) for f in rx.frames if f.header_valid)
+    if snr_db is None and soft and fec1 == 11:
+        frames, fwd, tb = rx.viterbi_stats()                         # (clean signal: the overlaps always hold, nothing is repeated)
+        assert frames == len(rx.frames) and fwd == 0 and tb == 0, (frames, fwd, tb)
+    rx.close()
+
+
+@pytest.mark.parametrize("snr_db", [0.0, -1.0])
+def test_convolutional_decoder_is_exact_where_survivors_do_not_merge(oracle, product, snr_db):
+    """The K = 7 decoder's own kernel (csrc/viterbi_frames.hpp) runs every trellis block from a 48-step overlap and CHECKS the overlap
+    against the neighbouring blocks, repeating a block's pass where the survivors had not merged.  On a decodable signal that never
+    happens; here the headers (BPSK) survive and the QPSK payloads do not -- frames the oracle delivers with payload_valid = 0 and
+    bytes that are noise.  The GPU must deliver the same noise, byte for byte, and must have needed its repair passes to do so
+    (profiles/r5_viterbi_merge_depth.txt: one boundary in a hundred is open after 48 steps at 0 dB per coded bit; the decoder of
+    rounds 3-4, blocks with a fixed 192-step overlap and no check, was exact only where survivors merge)."""
+    N, M, cp, plen = 4, 64, 8, 700
+    tx = product.multichanneltx(N, M, cp, 4)
+    iq, sent = tx.generate(4, plen, mod=40, fec0=1, fec1=11, seed=5)
+    tx.close()
+    x = iq.cpu().numpy()
+    rng = np.random.RandomState(2)
+    nstd = np.sqrt(np.mean(np.abs(x) ** 2)) * 10.0 ** (-snr_db / 20.0) / np.sqrt(2.0)
+    x = (x + nstd * (rng.randn(len(x)) + 1j * rng.randn(len(x)))).astype(np.complex64)
+    x = x[:len(x) // (32 * N) * (32 * N)]
+    ora = oracle.MultiChannelRx(N, M, cp, 4, soft=True)
+    ora.execute(x)
+    broken = [f for f in ora.frames if f.header_valid and not f.payload_valid and (f.fec0, f.fec1) == (1, 11)]
+    assert len(broken) >= 6, (len(ora.frames), len(broken))
+    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=plen, payload_soft=1)
+    rx.Execute(x); rx.Flush()
+    check_frames(rx.frames, ora.frames, rel=1.0)                     # (payload bytes compared whether valid or not)
+    frames, fwd, tb = rx.viterbi_stats()
+    print("snr %.1f: %d frames through the kernel, %d forward / %d traceback passes repeated" % (snr_db, frames, fwd, tb))
+    assert frames >= len(broken) and fwd + tb >= 1, (frames, fwd, tb)
     rx.close()
 
 
