@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-harvest", action="store_true")
     ap.add_argument("--no-aperiodic", action="store_true", help="skip the ragged-traffic leg (value_aperiodic)")
+    ap.add_argument("--acquisition", type=int, default=0, help="mcrx_hip_config::acquisition for every receiver of the run (A/B runs: 3 = an anchor phase in front of the segment waves, the default of rounds 4-5)")
     ap.add_argument("--scout-build", type=int, default=0, help="mcrx_hip_config::scout_build for the headline receiver (A/B runs: 2 = the general state machine's segment waves)")
     ap.add_argument("--no-variants", action="store_true", help="skip the headline's variants (30 dB AWGN on the wideband samples; equalised symbols not stored)")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE.json configurations (the `configs` block)")
@@ -90,6 +91,9 @@ def parse():
                          "device): executes the whole multi-process code path -- sub-slab cut, halos, pipeline, verification -- on a one-GPU lease.  "
                          "The value it prints is NOT a scaling number")
     return ap.parse_args()
+
+
+LEG_CFG = {}           # receiver configuration the command line adds to every leg (--acquisition)
 
 
 class Watchdog(object):
@@ -139,6 +143,8 @@ def frame_index(sent):
 
 def main():
     args = parse()
+    if args.acquisition:
+        LEG_CFG["acquisition"] = args.acquisition
     # `python bench.py --gpus N` is the whole command: without a launcher around it the ranks are started here
     # (torch.distributed.run on 127.0.0.1); under torch.distributed.run (the driver's form for N > 1) this returns the ranks
     if args.dry_run_launch:
@@ -205,6 +211,8 @@ def main():
     cfg = dict(max_payload_len=max(args.payload, 64), max_frames=max_frames)
     if args.scout_build:
         cfg["scout_build"] = args.scout_build
+    if args.acquisition:
+        cfg["acquisition"] = args.acquisition
     if world > 1 or args.pipeline:
         # rounds cut the stream anywhere: a frame that straddles two rounds is acquired again by the next round (whole, by
         # the parallel path) instead of being walked symbol by symbol -- the history in front of every round covers a frame
@@ -538,7 +546,7 @@ def config_leg(prod, torch, dev, N, M, cp, frames, plen, mod, fec1, resamp, step
             inputs.append(torch.view_as_complex(re.reshape(2, -1).T.contiguous()))
         del up, re
         rs = prod.msresamp(0.5, 60.0)
-    rx = prod.multichannelrx(N, M, cp, taper, max_payload_len=plen, max_frames=N * frames + 64)
+    rx = prod.multichannelrx(N, M, cp, taper, max_payload_len=plen, max_frames=N * frames + 64, **LEG_CFG)
     tile = prod.TILE * K
 
     # resampler and receiver on ONE caller stream that is not the legacy default stream (work on the NULL stream is a
@@ -645,6 +653,8 @@ def aperiodic_leg(prod, N, M, cp, taper, slab_blocks, K, args, torch, dev):
     cfg = dict(max_payload_len=max(args.payload, 64), max_frames=max(nfr_slab) + 64)
     if args.scout_build:
         cfg["scout_build"] = args.scout_build
+    if args.acquisition:
+        cfg["acquisition"] = args.acquisition
     rx = prod.multichannelrx(N, M, cp, taper, **cfg)
 
     def step(keep=False):

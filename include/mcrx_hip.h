@@ -86,9 +86,11 @@ typedef struct {
     uint32_t worker_build;       /* M = 64 payload workers: 0 = lean workers, butterfly exchanges through the LDS crossbar;
                                     1 = lean workers with the exchanges on the VALU (DPP / permlane swaps); 2 = the round-2 worker, one
                                     frame per wave; 3 / 4 = that worker with two / four frames per wave; 5 = the width-generic kernel */
-    uint32_t acquisition;        /* 0 = segment-parallel acquisition, anchor phase while the traffic has a cadence; 1 = one launch of
-                                    segment waves, no anchor phase; 2 = no segment waves (the scouts walk every frame); 3 = anchor phase
-                                    always; 4 = no speculation at all (the round-1 scout: one kernel per push does everything) */
+    uint32_t acquisition;        /* 0 = segment-parallel acquisition, anchored on the state a push begins in while the traffic has a cadence;
+                                    1 = one launch of segment waves, no anchor; 2 = no segment waves (the scouts walk every frame); 3 = an
+                                    anchor phase in front of the segment waves, always (rounds 4-5: a launch that acquires every channel's first
+                                    frame); 4 = no speculation at all (the round-1 scout: one kernel per push does everything); 5 = as 0 with
+                                    the cadence taken for granted */
     uint32_t scout_build;        /* 0 = default: the general state machine's segment waves, the scouts' unbudgeted build; 1 = the scouts'
                                     168-register build of rounds 2-3; 2 = the lean segment waves of 48- / 64-subcarrier symbols
                                     (csrc/acq_lean.hpp: half the instructions, the same time on periodic traffic, 10 % behind on ragged) */

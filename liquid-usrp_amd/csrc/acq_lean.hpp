@@ -609,11 +609,14 @@ struct Acq {
         int64_t key = -1;
         bool go = !mid_payload && seg_len > 0 && seg_start < a.end;
         uint32_t j = 0, jmax = spw;
-        const int64_t A = (phase == 2 && a.anchor) ? rfl64(a.anchor[ch]) : -1, P = (int64_t)period_hint;
+        const int64_t P = (int64_t)period_hint;                 // (phases 3 and 4: ofdmsync.hip, run_seg)
+        const int64_t A = (phase == 2 && a.anchor) ? rfl64(a.anchor[ch])
+                        : (phase == 3 && P > 0 && last_fresh > 0) ? last_fresh
+                        : (phase == 4 && P > 0 && a.anchor) ? (rfl64(a.anchor[ch]) >= 0 ? base + rfl64(a.anchor[ch]) : -1) : -1;
         auto lattice = [&](int64_t from) -> int64_t {
             if (A < 0 || P <= 0) return -1;
-            const int64_t f = from > A + 1 ? from : A + 1;
-            return A + (f - A + P - 1) / P * P;
+            const int64_t d = from - A, pt = A + (d >= 0 ? (d + P - 1) / P : -((-d) / P)) * P;
+            return (phase == 2 && pt <= A) ? A + P : pt;
         };
         auto preamble_behind = [&](int64_t p) -> bool {
             if (p < 0 || p + 6 * (int64_t)L >= a.end) return false;
@@ -680,7 +683,7 @@ struct Acq {
                 if (l == 0) { slot->start = key; slot->t_last = handoff_last; slot->status = 1; slot->pad = handoff_job; }
                 j++;
                 if (phase == 1) {
-                    if (l == 0) a.anchor[ch] = handoff_last + 1;
+                    if (l == 0) { a.anchor[ch] = handoff_last + 1; if (a.stats) atomicAdd(a.stats + 2, 1u); }
                     void_block();
 #ifdef ACQ_PROF
                     if (l == 0 && ch == 0)
@@ -710,6 +713,7 @@ struct Acq {
             }
             break;
         }
+        if (l == 0 && a.stats && j > ((g == 0 && phase == 2 && A >= 0) ? 1u : 0u)) atomicAdd(a.stats + 2, j - ((g == 0 && phase == 2 && A >= 0) ? 1u : 0u));
         void_block();
 #ifdef ACQ_PROF
         if (l == 0 && ch == 0 && g == (a.nseg > 1 ? 1u : 0u))

@@ -217,7 +217,8 @@ struct SyncArgs {
     // missing prediction costs nothing but the two acquisitions again (the coarse start); the results never depend on it.
     int no_syms;                         // 1 (mcrx_hip_config::skip_framesyms = 2): the lean payload workers do not store the equalised symbols at all
     int seg_walker;                      // 1 (default): the segment waves are the Walker's kernel (sync_spec_kernel); 0 (scout_build = 2): acq_lean.hpp's where the design allows
-    int seg_phase;                       // 1: first frame from the entry state only (grid = channels); 2: the rest; 0: one launch, no cadence
+    int seg_phase;                       // 1: first frame from the entry state only (grid = channels); 2: the rest; 0: one launch, no cadence;
+                                         // 3 / 4 (round 5): one launch, the lattice carried over from the previous push -- absolute / relative to the push's beginning
     int64_t *anchor;                     // [nch] where phase 1's frame ended + 1 (-1: it did not hand a frame off)
     int64_t *seekst;                     // [nch][2] the SEEK state (cur, timer) the acquisition a channel's push ENDED in was detected from: where that
                                          // frame is re-acquired from if the next push defers it (a frame detected at the end of one push and deferred
@@ -240,7 +241,8 @@ struct SyncArgs {
                                 //    1 (before the acquisition rounds): the frame a previous push left unfinished, to its end;
                                 //    2 (after them): a frame the lean scout could not hand off -- it straddles the end of the buffer,
                                 //    is oversize, or the job list is full -- and then on to the end of the buffer
-    uint32_t *stats;            // [0] frames the scouts acquired themselves, [1] frames adopted from speculative waves (NULL: not counted)
+    uint32_t *stats;            // [0] frames the scouts acquired themselves, [1] frames adopted from speculative waves (NULL: not counted);
+                                // [2] slots the segment waves filled (the frames among them that nobody adopts are the host's measure of a wrong anchor)
     int no_fast;               // MCRX_NO_FAST=1: payload workers use the general symbol path (A/B experiments)
     int payload_fr, payload_lean, payload_xb;      // which build of the M = 64 workers (MCRX_PAYLOAD_FR / _LEAN / _XB at creation; defaults 1, 1, 63): the parity tests compare them
     uint32_t vit_off;          // byte offset of the convolutional decoder's 8 KB block scratch in the launch's dynamic LDS (0: none; set by the launchers)

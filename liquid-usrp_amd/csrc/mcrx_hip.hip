@@ -188,6 +188,7 @@ struct mcrx_hip_s {
     uint32_t *h_hint = nullptr, *d_hint = nullptr;     // pinned, device-mapped: longest coded frame of the last launch
     uint8_t *d_jsoft[MCRX_SLOTS] = {}, *d_jtmp[MCRX_SLOTS] = {};
     bool scout = true, scout_tables = true, il_tried = false;
+    int anchor_kind = 0; uint32_t anchor_retry = 0, anc_filled = 0, anc_adopted = 0;      // cadenced traffic: 0 / 1 = the lattice carried over from the previous push (absolute / from the push's beginning), 2 = an anchor phase (launch_sync)
     uint32_t nseg_fixed = 0, seg_frames = 4; float frames_per_push = 0.f; uint64_t last_nsamp = 0;      // segment-parallel acquisition: launch_sync
     bool cadenced = true; uint32_t cad_same = 0, cad_frames = 0; int cad_count = 0;                       // ... its anchor phase
     // scouts of the acquisition rounds: 1 = the lean scout's unbudgeted build (sync_walk_kernel: 256 + 40 registers, no spills), 0 = the
@@ -568,10 +569,10 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     {   // mcrx_hip_config::worker_build / acquisition / scout_build (fields past the caller's struct_size read as 0 = default)
         auto field = [&](size_t off) { return q->cfg.struct_size >= off + sizeof(uint32_t) ? *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(&q->cfg) + off) : 0u; };
         const uint32_t wb = field(offsetof(mcrx_hip_config, worker_build)), aq = field(offsetof(mcrx_hip_config, acquisition));
-        if (wb > 5 || aq > 4) return bail(fail(MCRX_EINVAL, "worker_build / acquisition out of range"));
+        if (wb > 5 || aq > 5) return bail(fail(MCRX_EINVAL, "worker_build / acquisition out of range"));
         if (wb == 1) q->payload_xb = 0;
         if (wb >= 2) { q->payload_lean = 0; q->payload_fr = wb == 2 ? 1 : wb == 3 ? 2 : wb == 4 ? 4 : 0; }
-        if (aq >= 1 && aq <= 3) q->acq_mode = (int)aq;
+        if ((aq >= 1 && aq <= 3) || aq == 5) q->acq_mode = (int)aq;
         no_spec_cfg = aq == 4;
         const uint32_t sb = field(offsetof(mcrx_hip_config, scout_build));
         if (sb > 2) return bail(fail(MCRX_EINVAL, "scout_build out of range"));
@@ -855,8 +856,18 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
             const uint32_t ds = sm >= q->cad_same ? sm - q->cad_same : 0u, df = fr >= q->cad_frames ? fr - q->cad_frames : 0u;     // (mcrx_hip_spec_stats may have reset them)
             if (df > q->nch) q->cadenced = 2ull * ds > df;
             q->cad_same = sm; q->cad_frames = fr; q->cad_count = 0;
+            // ... and which anchor.  The lattice carried over from the previous push needs no launch in front of the segment waves: as it
+            // stood in the stream (a continuous stream), or as it stood from the push's beginning (pushes that are bursts of their own, a
+            // replayed slab with a gap at its end).  A wrong one shows: every segment hands off two frames nobody adopts.  So: one
+            // after the other while more than an eighth of the slots filled go to waste, the anchor phase (which finds the lattice inside
+            // every push) when neither holds, and from the start again after 256 launches.
+            const uint32_t sf = h[6], ad = h[3];
+            const uint32_t dsf = sf >= q->anc_filled ? sf - q->anc_filled : 0u, dad = ad >= q->anc_adopted ? ad - q->anc_adopted : 0u;
+            if (q->anchor_kind < 2 && dad > q->nch && dsf > dad + dad / 8) { if (++q->anchor_kind == 2) q->anchor_retry = 256; }
+            q->anc_filled = sf; q->anc_adopted = ad;
         }
-        if (q->acq_mode == 3) q->cadenced = true;
+        if (q->anchor_kind == 2 && q->anchor_retry && --q->anchor_retry == 0) q->anchor_kind = 0;
+        if (q->acq_mode == 3 || q->acq_mode == 5) q->cadenced = true;
         q->last_nsamp = nsamp;
         // Slots per wave: its share of MCRX_SPEC_MAX while the push's frames fit there (the scouts then hold every slot header in
         // registers), else what its frames need -- the channel's slots then exceed the window and the scouts move it along
@@ -886,6 +897,7 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
         a.anchor = q->d_anchor;
         if (q->acq_mode == 2) a.spec_cap = 0;                        // (MCRX_ACQ_MODE=2: no segment waves, the scouts walk everything)
         else if (q->acq_mode == 1 || nseg == 1 || (q->acq_mode == 0 && !q->cadenced)) { a.seg_phase = 0; HIPCHK(sync_launch_spec(a, sa)); }     // one launch, coarse starts
+        else if (q->acq_mode != 3 && q->anchor_kind < 2) { a.seg_phase = 3 + q->anchor_kind; HIPCHK(sync_launch_spec(a, sa)); }       // one launch, anchored on the entry state (a channel that does not stand behind a frame: coarse starts)
         else {
             const uint32_t sj = a.seg_jobs;
             a.seg_phase = 1; a.seg_jobs = 1; HIPCHK(sync_launch_spec(a, sa));        // the first frame of every channel, from its real state: the cadence's anchor
@@ -907,6 +919,9 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
             HIPCHK(hipEventRecord(q->ev_scout[slot], sa));
             HIPCHK(hipStreamWaitEvent(sw, q->ev_scout[slot], 0));
         }
+        // (Round 5: the K = 7 decoder's kernel + the general decoder on a stream of their own while convolutional frames arrive, so that the
+        //  next push's workers need not queue behind 0.3 ms of trellis: 8 channels x 100 frames 41.4 -> 35.9 Gsample/s, x 50 frames 25.9 -> 19.8.
+        //  Not kept: streams are not free, scratch/README.md.)
         // payload workers; the LDS-path packet decoder; the general decoder (nearly always an empty launch: ~12 us.
         // Giving it a stream of its own was tried: a fifth stream makes the harvest's copy stream share a hardware
         // queue with a busy one, and every poll then waits a slab's time for its 16-byte copies -- harvest 123 -> 98 Gsample/s)

@@ -2238,11 +2238,19 @@ struct Walker {
         bool go = !mid_payload && seg_len > 0 && seg_start < a.end;
         uint32_t j = 0, jmax = spw;
         // cadence: the lattice anchor + n P of fresh post-frame states the frames of a periodic stream are acquired from
-        const int64_t A = (phase == 2 && a.anchor) ? a.anchor[ch] : -1, P = (int64_t)s.period_hint;
-        auto lattice = [&](int64_t from) -> int64_t {           // its first point at or behind `from`, strictly behind the anchor
+        // No launch in front of the segment waves where the lattice can be carried over from the previous push: phase 3 -- from the last
+        // fresh state behind a frame that the channel's scout saw (ChanState::last_fresh): a continuous stream; phase 4 -- from where that
+        // state stood RELATIVE TO THE PUSH'S BEGINNING (the scout leaves the offset in anchor[ch]): pushes that are bursts of their own, a
+        // capture window per burst, a replayed slab with a gap at its end.  A wrong guess costs the two acquisitions per segment again;
+        // the host tells by the frames the waves hand off for nothing (stats[2] against stats[1]) and moves on to the next one.
+        const int64_t P = (int64_t)s.period_hint;
+        const int64_t A = (phase == 2 && a.anchor) ? a.anchor[ch]
+                        : (phase == 3 && P > 0 && s.last_fresh > 0) ? s.last_fresh
+                        : (phase == 4 && P > 0 && a.anchor && a.anchor[ch] >= 0) ? base + a.anchor[ch] : -1;
+        auto lattice = [&](int64_t from) -> int64_t {           // its first point at or behind `from` (phase 2: strictly behind the anchor)
             if (A < 0 || P <= 0) return -1;
-            const int64_t f = from > A + 1 ? from : A + 1;
-            return A + (f - A + P - 1) / P * P;
+            const int64_t d = from - A, pt = A + (d >= 0 ? (d + P - 1) / P : -((-d) / P)) * P;
+            return (phase == 2 && pt <= A) ? A + P : pt;
         };
         auto preamble_behind = [&](int64_t p) -> bool {        // a frame does begin within a few symbols of p
             if (p < 0 || p + 6 * (int64_t)L >= a.end) return false;
@@ -2311,7 +2319,7 @@ struct Walker {
             if (verdict == 2) {                                 // handed off: the job sits in the slot (try_handoff_spec)
                 if (l == 0) { slot->start = key; slot->t_last = handoff_last; slot->status = 1; slot->pad = handoff_job; }
                 j++;
-                if (phase == 1) { if (l == 0) a.anchor[ch] = handoff_last + 1; void_block(); return; }
+                if (phase == 1) { if (l == 0) { a.anchor[ch] = handoff_last + 1; if (a.stats) atomicAdd(a.stats + 2, 1u); } void_block(); return; }
                 if (handoff_last + 1 == p_next) break;          // exactly the state the next segment's wave started from: linked
                 // ... else the first frame detected at or behind the place the next wave started looking from -- its lattice point if
                 // it took one, else the segment boundary -- is that wave's first frame: acquired from my (real) state it links us
@@ -2336,6 +2344,7 @@ struct Walker {
             break;                                              // anything else (invalid header, end of the buffer, idle) is the scout's
         }
         if ((a.debug & 64) && l == 0 && ch == 0) printf("[segw] g %u phase %d: A %lld P %lld seg [%lld, %lld) p_next %lld frames %u last state %d cur %lld\n", g, phase, (long long)A, (long long)P, (long long)seg_start, (long long)(last ? -1 : seg_end), (long long)p_next, j, s.state, (long long)s.cur);
+        if (l == 0 && a.stats && j > ((g == 0 && phase == 2 && A >= 0) ? 1u : 0u)) atomicAdd(a.stats + 2, j - ((g == 0 && phase == 2 && A >= 0) ? 1u : 0u));      // (slots this wave filled: the host's waste count)
         void_block();
         if (phase == 1) {                                       // no hand-off: no anchor; segment 0 starts over from the entry state in phase 2
             if (l == 0) { a.anchor[ch] = -1; sl0[0].start = -1; sl0[0].status = 0; }
@@ -2506,6 +2515,7 @@ struct Walker {
             if (fresh_prev >= 0 && fresh_last - fresh_prev < (int64_t)0x7fffffff) s.period_hint = (uint32_t)(fresh_last - fresh_prev);
             s.last_fresh = fresh_last;
         }
+        if (l == 0 && a.anchor && a.spec_cap) a.anchor[ch] = fresh_last >= 0 ? fresh_last - seg_base : -1;       // (where the lattice stood in THIS push, from its beginning: run_seg, phase 3)
         if ((a.debug & 4) && l == 0) printf("[seg] ch %u adopted %u walked %u (slots %u in %u segments)\n", ch, nadopted, nwalked, a.spec_cap, a.nseg);
         // a header in progress continues in the next launch: its bits move from LDS to the channel's HBM slot
         if (fastp && s.state == SY_RX && s.fstate == FX_HEADER && s.header_symbol_index > 0)
@@ -3289,7 +3299,7 @@ __global__ __launch_bounds__(WV) void place_jobs_kernel(SyncArgs a)
         // frames the scouts acquired themselves / adopted from segment waves so far, frames on a cadence: the host reads them without
         // a sync (mcrx_hip.hip launch_sync)
         volatile uint32_t *h = a.walk_hint;
-        h[0] = a.stats[0]; h[1] = a.stats[1]; h[2] = a.stats[4]; h[3] = a.stats[5];
+        h[0] = a.stats[0]; h[1] = a.stats[1]; h[2] = a.stats[4]; h[3] = a.stats[5]; h[4] = a.stats[2];
         const uint32_t tot = a.stats[0] + a.stats[1], prev = a.stats[6] <= tot ? a.stats[6] : 0u;      // (a statistics reset zeroes them all)
         a.stats[6] = tot;
         h[5] = tot - prev;                      // frames of THIS launch: frames per channel and push, which sizes the next launches' segments

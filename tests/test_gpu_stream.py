@@ -346,7 +346,15 @@ def test_acquisition_policy_switches_with_the_traffic(oracle, product):
     x = iq[:n].cpu().numpy()
     ora = oracle.MultiChannelRx(N, M, cp, 4)
     ora.execute(x)
-    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=200)
+    # acquisition = 0: the host's choice (round 5: the lattice carried over from the previous push -- as it stood in the stream, then as it
+    # stood from the push's beginning -- before the anchor phase); 3: the anchor phase always (rounds 4-5); 5: a cadence taken for
+    # granted, on the ragged stretch too
+    for acq in (0, 3, 5):
+        _policy_case(product, iq, n, N, M, cp, ora, acq)
+
+
+def _policy_case(product, iq, n, N, M, cp, ora, acq):
+    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=200, acquisition=acq)
     step = 32 * N * 260                                  # 4160 blocks, ~ 3 frames per channel and push: 75 pushes
     for i in range(0, n, step):
         rx.Execute(iq[i:min(i + step, n)])
@@ -366,7 +374,7 @@ def test_acquisition_policy_switches_with_the_traffic(oracle, product):
             assert e <= 1e-3, e
             loose += e > 1e-5
     assert loose <= 4, loose
-    assert len(rx.frames) >= 80 * N and walked > 0 and adopted > 0, (len(rx.frames), walked, adopted)
+    assert len(rx.frames) >= 80 * N and walked > 0 and adopted > 0, (acq, len(rx.frames), walked, adopted)
     rx.close()
 
 
