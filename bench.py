@@ -488,6 +488,7 @@ def main():
                          "kernels_frac_of_peak": {k: round(v, 5) for k, v in fracs.items()},
                          "kernels_ms_overlapped": {k: round(v, 4) for k, v in ovl.items()},
                          "serial_sum_ms_per_slab": round(sum(per.values()), 4),
+                         "vector_issue": vector_issue(value, world, N, args.frames, args.payload, samples_per_step / max(1, args.slabs) / world),
                          "pipeline_frac_of_16B_roofline": round(value * 1e6 * 16.0 / (world * HBM_PEAK_GBS * 1e9), 5),
                          "per_gpu": {"Msamples_per_s": round(value / world, 3), "GBps_at_16B_per_sample": round(value / world * 16e-3, 2),
                                      "peak_GBps": HBM_PEAK_GBS},
@@ -785,9 +786,22 @@ def harvest_legs(prod, N, M, cp, taper, cfg, slabs, K, args, torch):
     return res
 
 
-def traffic_source():
+def traffic_files():
+    """the committed counter summaries of the receiver's benchmark command, oldest first (profiles/r*_traffic.json with a `workload`
+    line: the transmit side's summaries, profiles/r*_tx_traffic.json, have none)"""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    out = []
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))):
+        try:
+            if "multichannelrx" in json.load(open(f)).get("workload", ""):
+                out.append(f)
+        except (OSError, ValueError):
+            pass
+    return out
+
+
+def traffic_source():
+    files = traffic_files()
     return ("profiles/" + os.path.basename(files[-1]) + " (rocprofv3 --pmc passes of this command on this workload, 2 x FETCH_SIZE + "
             "WRITE_SIZE per launch; counters cannot be read from inside the timed run)") if files else None
 
@@ -796,8 +810,8 @@ def measured_traffic(kernel, N, frames, payload):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r*_traffic.json:
     2 x FETCH_SIZE + WRITE_SIZE, collected on this workload by scratch/prof.sh); None when the run's
     configuration is not the profiled one.  Counters cannot be read from inside the timed run."""
-    import glob, re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    import re
+    files = traffic_files()
     if not files:
         return None
     prof = json.load(open(files[-1]))
@@ -810,6 +824,36 @@ def measured_traffic(kernel, N, frames, payload):
             if want in name:
                 return round(t["hbm_bytes_per_launch"], 0)
     return None
+
+
+def vector_issue(value, world, N, frames, payload, slab_samples):
+    """The other ceiling of this path: wave64 vector instructions per slab (SQ_INSTS_VALU of the receiver's kernels, from the committed
+    rocprofv3 --pmc passes of this command: profiles/r*_pmc.csv beside the traffic summary) and the rate the timed run issued them at,
+    against 1024 SIMDs x 2.4 GHz / 4 cycles.  DESIGN.md section 4: a kernel of nothing but register arithmetic sustains 330-410 G/s here."""
+    import csv
+    files = traffic_files()
+    if not files or measured_traffic("channelizer_kernel", N, frames, payload) is None:
+        return None                                     # (the committed counters are of another workload)
+    pmc, stats = files[-1].replace("_traffic.json", "_pmc.csv"), files[-1].replace("_traffic.json", "_kernel_stats.csv")
+    if not (os.path.exists(pmc) and os.path.exists(stats)):
+        return None
+    not_rx = ("syn::", "txsym", "txifft", "txfir", "ilmap", "reset")
+    per = {r["kernel"]: float(r["mean_per_dispatch"]) for r in csv.DictReader(open(pmc))
+           if r["counter"] == "SQ_INSTS_VALU" and r["kernel"].startswith("mcrx::") and not any(t in r["kernel"] for t in not_rx)}
+    calls = {r["Name"]: int(r["Calls"]) for r in csv.DictReader(open(stats))}
+    chan = max([c for n, c in calls.items() if "channelizer_kernel" in n] or [0])
+    if not per or not chan:
+        return None
+    table, total = {}, 0.0
+    for k, n in per.items():
+        c = max([c for nm, c in calls.items() if nm.startswith(k) or nm.startswith("void " + k)] or [chan])
+        table[k.replace("mcrx::", "")] = round(n * c / chan / 1e6, 2)          # dispatches per slab = calls relative to the channelizer's
+        total += n * c / chan
+    rate = total * (value * 1e6 / world) / slab_samples / 1e9
+    return {"unit": "wave64 vector instructions", "per_slab_millions": table, "per_slab_total_millions": round(total / 1e6, 1),
+            "rate_G_per_s": round(rate, 1), "peak_G_per_s": 614.4, "frac": round(rate / 614.4, 4),
+            "peak": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction; a kernel of nothing but register arithmetic sustains 330-410 G/s on this chip (DESIGN.md section 4)",
+            "source": "profiles/" + os.path.basename(pmc) + " (SQ_INSTS_VALU per dispatch x dispatches per slab) and this run's rate"}
 
 
 def usable_cores():
