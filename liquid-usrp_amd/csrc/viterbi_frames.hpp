@@ -5,9 +5,8 @@
 // selects, four adds, a compare, a select and two lane writes for the decision word -- 14 vector and 5 scalar instructions per
 // step for 64 states -- followed by a traceback that is a scalar chain of ~12 instructions per step; 1.5 ms per 800 frames of 1200
 // bytes (profiles/r5_v27_before_kernel_stats.csv).  With the states in registers the butterfly (states j, j + 32 -> 2j, 2j + 1) has
-// compile-time operands, needs no exchange at all, and its decision bits shift into two accumulators through the carry flag: 10
-// instructions per butterfly = 5 per state and step FOR 64 BLOCKS AT ONCE, and the traceback is 8 vector instructions per step for
-// 64 blocks at once.
+// compile-time operands and needs no exchange at all: 3 instructions per state and step FOR 64 BLOCKS AT ONCE (16-bit metrics, two
+// states to a register: see bfly below), and the traceback is 8 vector instructions per step for 64 blocks at once.
 //
 // Exactness.  A lane does not know the path metrics at its block's first step, nor the survivor's state at its last.  It starts W
 // steps early from equal metrics and runs W steps past its end -- and then both assumptions are CHECKED against the neighbours, and
@@ -26,10 +25,6 @@
 // noise -- where 7 % of the block boundaries of the old kernel's 192-step overlap had not merged, i.e. the old kernel was not exact --
 // a frame takes a few extra passes.  (Merge-depth statistics: profiles/r5_viterbi_merge_depth.txt.)
 //
-// Register layout of the forward pass: after i steps register r holds state rotl6(r, i mod 6) -- a new state 2j (2j + 1) goes where
-// its predecessor j (j + 32) was, so the butterfly works in place -- and everything that looks at the registers (start, checkpoints,
-// best state) does so at multiples of 6 steps, where the layout is the identity.  Decision words of a step: state n -> word n & 1,
-// bit 31 - (n >> 1).
 #pragma once
 // (included inside namespace mcrx, after lane_id(): ofdmsync.hip; needs <utility>)
 namespace vf {
@@ -37,47 +32,74 @@ namespace vf {
 // (W, block_steps(T), rows_for(T): kernels.h -- the host sizes the scratch with them)
 static_assert(W % 24u == 0u && W >= 48u, "warm-up: whole register-layout periods, whole bytes, and the traceback's prefetch reaches back 48 rows");
 
-__device__ __forceinline__ constexpr unsigned rr6(unsigned v, unsigned r) { return r == 0 ? v : (((v >> r) | (v << (6u - r))) & 63u); }
 __device__ __forceinline__ constexpr unsigned par(unsigned v) { unsigned p = 0; while (v) { p ^= v & 1u; v >>= 1; } return p; }
 // expected outputs of the transition (predecessor j, input 0): index into the step's four branch metrics (first output << 1 | second)
 __device__ __forceinline__ constexpr unsigned bm_idx(unsigned j) { return (par((2u * j) & 0x6du) << 1) | par((2u * j) & 0x4fu); }
 
-// butterfly j of a step whose index is PH mod 6: the transitions j -> 2j and j + 32 -> 2j + 1 expect the outputs c, the other two
-// the complement (both generators tap the oldest and the newest bit)
-template <unsigned PH, unsigned J>
-__device__ __forceinline__ void bfly(unsigned (&R)[64], const unsigned (&BM)[4], unsigned &w0, unsigned &w1)
+// Path metrics: 16 bits, two states to a register -- register k holds states 2k (low half) and 2k + 1 (high half).  The butterfly
+// (states j, j + 32 -> 2j, 2j + 1) fills ONE new register from one half each of two old ones, and the packed instructions' operand
+// selects broadcast that half for free: with c = the outputs the transition j -> 2j expects and c' their complement (both generators
+// tap the oldest and the newest bit, so j -> 2j + 1 and j + 32 -> 2j expect c', j + 32 -> 2j + 1 expects c),
+//     m0 = (old[j],      old[j])      + (BM[c],  BM[c'])      m1 = (old[j + 32], old[j + 32]) + (BM[c'], BM[c])
+//     new = min(m0, m1)    decisions = the sign bits of m1 - m0 (16-bit wrap-around: differences stay below 6 x 510 + 510)
+// = 6 instructions for two states (adds, minimum, difference, and the two that shift the sign bits into the step's decision word),
+// where 32-bit metrics with one state to a register took 10.  A register file of 32 old + 32 new, no layout that rotates.  Metrics
+// grow by at most 510 a step and never differ by more than 6 x 510, so the minimum is subtracted every 96 steps.
+// Decision words of a step: state n = 2j + h -> word j >> 4, bit (j & 15) + 16 h.
+template <unsigned J>
+__device__ __forceinline__ void bfly(const unsigned (&P)[32], unsigned (&Q)[32], const unsigned (&PB)[4], unsigned &acc, unsigned k80008000)
 {
-    constexpr unsigned ra = rr6(J, PH), rb = rr6(J + 32u, PH), ix = bm_idx(J);
-    unsigned t0, t1, t2, t3;
-    asm("v_add_u32_e32 %4, %0, %8\n\t"
-        "v_add_u32_e32 %5, %1, %9\n\t"
-        "v_add_u32_e32 %6, %0, %9\n\t"
-        "v_add_u32_e32 %7, %1, %8\n\t"
-        "v_cmp_lt_u32_e32 vcc, %5, %4\n\t"
-        "v_cndmask_b32_e32 %0, %4, %5, vcc\n\t"
-        "v_addc_co_u32_e32 %2, vcc, %2, %2, vcc\n\t"
-        "v_cmp_lt_u32_e32 vcc, %7, %6\n\t"
-        "v_cndmask_b32_e32 %1, %6, %7, vcc\n\t"
-        "v_addc_co_u32_e32 %3, vcc, %3, %3, vcc"
-        : "+v"(R[ra]), "+v"(R[rb]), "+v"(w0), "+v"(w1), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
-        : "v"(BM[ix]), "v"(BM[3u - ix])
-        : "vcc");
+    constexpr unsigned lo = J >> 1, hi = 16u + (J >> 1), ix = bm_idx(J);
+    unsigned m0, m1, t;
+#define VF_BFLY(SEL)                                                                                                       \
+    asm("v_pk_add_u16 %1, %5, %7 " SEL "\n\t"                                                                               \
+        "v_pk_add_u16 %2, %6, %8 " SEL "\n\t"                                                                               \
+        "v_pk_min_u16 %0, %1, %2\n\t"                                                                                       \
+        "v_pk_sub_u16 %3, %2, %1\n\t"                                                                                       \
+        "v_pk_lshrrev_b16 %4, 1, %4 op_sel_hi:[0,1]\n\t"                                                                    \
+        "v_and_or_b32 %4, %3, %9, %4"                                                                                        \
+        : "=v"(Q[J]), "=&v"(m0), "=&v"(m1), "=&v"(t), "+v"(acc)                                                             \
+        : "v"(P[lo]), "v"(P[hi]), "v"(PB[ix]), "v"(PB[3u - ix]), "s"(k80008000))
+    if constexpr ((J & 1u) == 0u) VF_BFLY("op_sel:[0,0] op_sel_hi:[0,1]");
+    else                          VF_BFLY("op_sel:[1,0] op_sel_hi:[1,1]");
+#undef VF_BFLY
 }
-// (Two butterflies interleaved, their compares in scalar register pairs of their own so that four are in flight, change nothing: a
-//  wave alone on its SIMD issues a vector instruction every ~4.8 cycles either way, and waves that share a SIMD share that rate.)
-template <unsigned PH, unsigned... J>
-__device__ __forceinline__ void step_impl(unsigned (&R)[64], const unsigned (&BM)[4], unsigned &w0, unsigned &w1, std::integer_sequence<unsigned, J...>)
+template <unsigned... J>
+__device__ __forceinline__ void half_step(const unsigned (&P)[32], unsigned (&Q)[32], const unsigned (&PB)[4], unsigned &acc, unsigned k, std::integer_sequence<unsigned, J...>)
 {
-    (bfly<PH, J>(R, BM, w0, w1), ...);
+    (bfly<J>(P, Q, PB, acc, k), ...);
 }
-// one step: sy = first soft symbol | second << 8 (low 16 bits)
-template <unsigned PH>
-__device__ __forceinline__ void step(unsigned (&R)[64], unsigned sy, unsigned &w0, unsigned &w1)
+template <unsigned... J>
+__device__ __forceinline__ void half_step_hi(const unsigned (&P)[32], unsigned (&Q)[32], const unsigned (&PB)[4], unsigned &acc, unsigned k, std::integer_sequence<unsigned, J...>)
+{
+    (bfly<16u + J>(P, Q, PB, acc, k), ...);
+}
+// one step, P -> Q: sy = first soft symbol | second << 8 (low 16 bits); w0 / w1: the decision words
+__device__ __forceinline__ void step(const unsigned (&P)[32], unsigned (&Q)[32], unsigned sy, unsigned &w0, unsigned &w1, unsigned k80008000)
 {
     const unsigned sa = sy & 255u, sb = (sy >> 8) & 255u;
-    unsigned BM[4];
+    unsigned BM[4], PB[4];
     BM[0] = sa + sb; BM[1] = sa + 255u - sb; BM[2] = 255u - sa + sb; BM[3] = 510u - sa - sb;
-    step_impl<PH>(R, BM, w0, w1, std::make_integer_sequence<unsigned, 32>{});
+#pragma unroll
+    for (int i = 0; i < 4; i++) PB[i] = BM[i] | (BM[3 - i] << 16);
+    w0 = 0u; w1 = 0u;
+    half_step(P, Q, PB, w0, k80008000, std::make_integer_sequence<unsigned, 16>{});
+    half_step_hi(P, Q, PB, w1, k80008000, std::make_integer_sequence<unsigned, 16>{});
+}
+// the minimum of the 64 metrics in both halves
+__device__ __forceinline__ unsigned min_all(const unsigned (&P)[32])
+{
+    unsigned m = P[0];
+#pragma unroll
+    for (int k = 1; k < 32; k++) asm("v_pk_min_u16 %0, %0, %1" : "+v"(m) : "v"(P[k]));
+    asm("v_pk_min_u16 %0, %0, %0 op_sel:[0,1] op_sel_hi:[1,0]" : "+v"(m));
+    return m;
+}
+__device__ __forceinline__ void normalise(unsigned (&P)[32])
+{
+    const unsigned m = min_all(P);
+#pragma unroll
+    for (int k = 0; k < 32; k++) asm("v_pk_sub_u16 %0, %0, %1" : "+v"(P[k]) : "v"(m));
 }
 
 struct Frame {
@@ -101,15 +123,15 @@ __device__ __forceinline__ void load_syms(const Frame &f, int t, unsigned (&d)[3
 }
 
 // metrics with the minimum subtracted -> ck[which][state][lane]
-__device__ __forceinline__ void checkpoint(const Frame &f, const unsigned (&R)[64], unsigned which, unsigned lane)
+__device__ __forceinline__ void checkpoint(const Frame &f, const unsigned (&P)[32], unsigned which, unsigned lane)
 {
-    unsigned mn = R[0];
+    const unsigned m = min_all(P);
 #pragma unroll
-    for (int s = 1; s < 64; s++) mn = R[s] < mn ? R[s] : mn;
-#pragma unroll
-    for (int s = 0; s < 64; s++) {
-        const unsigned v = R[s] - mn;
-        f.ck[(which * 64u + (unsigned)s) * 64u + lane] = (uint16_t)(v > 65535u ? 65535u : v);
+    for (int k = 0; k < 32; k++) {
+        unsigned v;
+        asm("v_pk_sub_u16 %0, %1, %2" : "=v"(v) : "v"(P[k]), "v"(m));
+        f.ck[(which * 64u + 2u * (unsigned)k) * 64u + lane] = (uint16_t)v;
+        f.ck[(which * 64u + 2u * (unsigned)k + 1u) * 64u + lane] = (uint16_t)(v >> 16);
     }
 }
 
@@ -118,41 +140,49 @@ __device__ __forceinline__ void checkpoint(const Frame &f, const unsigned (&R)[6
 // Lanes outside `commit` run along and leave nothing behind.  Returns the best state at the lane's last step.
 __device__ __forceinline__ unsigned forward(const Frame &f, bool first, bool commit, unsigned lane, int tw)
 {
-    unsigned R[64];
+    unsigned P[32], Q[32];
     const unsigned rowsN = f.B + 2u * W, i0 = first ? 0u : W;
+    const unsigned k8 = 0x80008000u;
     if (first) {
 #pragma unroll
-        for (int s = 0; s < 64; s++) R[s] = 0u;
+        for (int k = 0; k < 32; k++) P[k] = 0u;
     } else {
         const unsigned pl = lane ? lane - 1u : 0u;
 #pragma unroll
-        for (int s = 0; s < 64; s++) R[s] = f.ck[(64u + (unsigned)s) * 64u + pl];
+        for (int k = 0; k < 32; k++) P[k] = (unsigned)f.ck[(64u + 2u * (unsigned)k) * 64u + pl] | ((unsigned)f.ck[(64u + 2u * (unsigned)k + 1u) * 64u + pl] << 16);
         if (commit) {
 #pragma unroll
-            for (int s = 0; s < 64; s++) f.ck[(unsigned)s * 64u + lane] = (uint16_t)R[s];        // C0 := what this run starts from
+            for (int k = 0; k < 32; k++) {                  // C0 := what this run starts from
+                f.ck[(2u * (unsigned)k) * 64u + lane] = (uint16_t)P[k];
+                f.ck[(2u * (unsigned)k + 1u) * 64u + lane] = (uint16_t)(P[k] >> 16);
+            }
         }
     }
     unsigned d[3], dn[3];
     load_syms(f, tw + (int)i0, d);
+    unsigned since = 0u;                                    // steps since the minimum was last subtracted
     for (unsigned i = i0; i < rowsN; i += 6u) {
         load_syms(f, tw + (int)i + 6, dn);
         if (first && i == W) {
+            // the encoder starts in state 0: every other state far enough behind never to win against a path from state 0 (6 x 510 would
+            // do; oracle/ll_fec.c has 1 << 20), near enough not to overflow before the next subtraction
             if (lane == 0u) {
+                P[0] = 0x2000u << 16;
 #pragma unroll
-                for (int s = 0; s < 64; s++) R[s] = s ? (1u << 20) : 0u;
+                for (int k = 1; k < 32; k++) P[k] = 0x20002000u;
             }
-            if (commit) checkpoint(f, R, 0u, lane);
+            if (commit) checkpoint(f, P, 0u, lane);
         }
-        if (i == W + f.B && commit) checkpoint(f, R, 1u, lane);
+        if (i == W + f.B && commit) checkpoint(f, P, 1u, lane);
+        if (since >= 90u) { normalise(P); since = 0u; }
+        since += 6u;
         unsigned w[12];
-#pragma unroll
-        for (int k = 0; k < 12; k++) w[k] = 0u;
-        step<0>(R, d[0], w[0], w[1]);
-        step<1>(R, d[0] >> 16, w[2], w[3]);
-        step<2>(R, d[1], w[4], w[5]);
-        step<3>(R, d[1] >> 16, w[6], w[7]);
-        step<4>(R, d[2], w[8], w[9]);
-        step<5>(R, d[2] >> 16, w[10], w[11]);
+        step(P, Q, d[0], w[0], w[1], k8);
+        step(Q, P, d[0] >> 16, w[2], w[3], k8);
+        step(P, Q, d[1], w[4], w[5], k8);
+        step(Q, P, d[1] >> 16, w[6], w[7], k8);
+        step(P, Q, d[2], w[8], w[9], k8);
+        step(Q, P, d[2] >> 16, w[10], w[11], k8);
         if (commit) {
             uint2 *row = f.rows + (size_t)i * 64u + lane;
 #pragma unroll
@@ -161,9 +191,12 @@ __device__ __forceinline__ unsigned forward(const Frame &f, bool first, bool com
 #pragma unroll
         for (int k = 0; k < 3; k++) d[k] = dn[k];
     }
-    unsigned best = 0u, bm = R[0];
+    unsigned best = 0u, bm = P[0] & 0xffffu;
 #pragma unroll
-    for (int s = 1; s < 64; s++) { const bool lt = R[s] < bm; bm = lt ? R[s] : bm; best = lt ? (unsigned)s : best; }
+    for (int s = 1; s < 64; s++) {
+        const unsigned v = (s & 1) ? (P[s >> 1] >> 16) : (P[s >> 1] & 0xffffu);
+        const bool lt = v < bm; bm = lt ? v : bm; best = lt ? (unsigned)s : best;
+    }
     return best;
 }
 
@@ -184,9 +217,9 @@ __device__ __forceinline__ unsigned traceback(const Frame &f, unsigned hi, unsig
 #pragma unroll
         for (int r = 23; r >= 0; r--) {
             const unsigned k = k1 - 24u + (unsigned)r;
-            const unsigned odd = 0u - (n & 1u), wsel = (cur[r].x & ~odd) | (cur[r].y & odd);      // (a select of the two would make the rows an indexed array: scratch)
+            const unsigned up = 0u - (n >> 5), wsel = (cur[r].x & ~up) | (cur[r].y & up);         // (a select of the two would make the rows an indexed array: scratch)
             const unsigned h = n >> 1;
-            const unsigned dbit = (wsel << h) >> 31;
+            const unsigned dbit = (wsel >> ((h & 15u) + ((n & 1u) << 4))) & 1u;                  // (state 2j + h: word j >> 4, bit (j & 15) + 16 h)
             bytes |= (n & 1u) << ((unsigned)(r >> 3) * 8u + 7u - (unsigned)(r & 7));       // (step t -> byte t / 8, bit 7 - t % 8)
             const unsigned nn = h | (dbit << 5);
             n = k < iend ? nn : n;
