@@ -68,6 +68,7 @@ def parse():
     ap.add_argument("--no-harvest", action="store_true")
     ap.add_argument("--no-aperiodic", action="store_true", help="skip the ragged-traffic leg (value_aperiodic)")
     ap.add_argument("--acquisition", type=int, default=0, help="mcrx_hip_config::acquisition for every receiver of the run (A/B runs: 3 = an anchor phase in front of the segment waves, the default of rounds 4-5)")
+    ap.add_argument("--worker-build", type=int, default=0, help="mcrx_hip_config::worker_build for every receiver of the run (A/B runs: 1 = the lean workers with their butterfly exchanges on the VALU)")
     ap.add_argument("--scout-build", type=int, default=0, help="mcrx_hip_config::scout_build for the headline receiver (A/B runs: 2 = the general state machine's segment waves)")
     ap.add_argument("--no-variants", action="store_true", help="skip the headline's variants (30 dB AWGN on the wideband samples; equalised symbols not stored)")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE.json configurations (the `configs` block)")
@@ -145,6 +146,8 @@ def main():
     args = parse()
     if args.acquisition:
         LEG_CFG["acquisition"] = args.acquisition
+    if args.worker_build:
+        LEG_CFG["worker_build"] = args.worker_build
     # `python bench.py --gpus N` is the whole command: without a launcher around it the ranks are started here
     # (torch.distributed.run on 127.0.0.1); under torch.distributed.run (the driver's form for N > 1) this returns the ranks
     if args.dry_run_launch:
@@ -213,6 +216,8 @@ def main():
         cfg["scout_build"] = args.scout_build
     if args.acquisition:
         cfg["acquisition"] = args.acquisition
+    if args.worker_build:
+        cfg["worker_build"] = args.worker_build
     if world > 1 or args.pipeline:
         # rounds cut the stream anywhere: a frame that straddles two rounds is acquired again by the next round (whole, by
         # the parallel path) instead of being walked symbol by symbol -- the history in front of every round covers a frame
@@ -656,6 +661,8 @@ def aperiodic_leg(prod, N, M, cp, taper, slab_blocks, K, args, torch, dev):
         cfg["scout_build"] = args.scout_build
     if args.acquisition:
         cfg["acquisition"] = args.acquisition
+    if args.worker_build:
+        cfg["worker_build"] = args.worker_build
     rx = prod.multichannelrx(N, M, cp, taper, **cfg)
 
     def step(keep=False):

@@ -433,6 +433,32 @@ def test_convolutional_k7_rate_half_viterbi(oracle, product, mod, fec0, fec1, so
     rx.close()
 
 
+@pytest.mark.parametrize("plen", [1, 20, 187, 188, 379, 380, 1147, 1148, 2040])
+def test_convolutional_decoder_block_geometry(oracle, product, plen):
+    """The K = 7 decoder's kernel cuts a frame's T = 8 (payload + 4) + 6 trellis steps into at most 64 blocks of a multiple of 24 steps
+    (csrc/kernels.h: vf::block_steps): payload lengths on either side of the points where the block length changes (T = 1534 / 1542:
+    24 -> 48 steps; 3070 / 3078; 9214 / 9222), a one-byte payload (one block: the trellis' first and last block at once), one near
+    the handle's limit -- at an SNR where the decoder has thousands of errors to correct per frame.  Bytes equal to the oracle's."""
+    N, M, cp = 2, 64, 8
+    tx = product.multichanneltx(N, M, cp, 4)
+    iq, sent = tx.generate(3, plen, mod=40, fec0=1, fec1=11, seed=100 + plen)
+    tx.close()
+    x = iq.cpu().numpy()
+    rng = np.random.RandomState(plen)
+    nstd = np.sqrt(np.mean(np.abs(x) ** 2)) * 10.0 ** (-5.0 / 20.0) / np.sqrt(2.0)
+    x = (x + nstd * (rng.randn(len(x)) + 1j * rng.randn(len(x)))).astype(np.complex64)
+    x = x[:len(x) // (32 * N) * (32 * N)]
+    ora = oracle.MultiChannelRx(N, M, cp, 4, soft=True)
+    ora.execute(x)
+    assert len(ora.frames) >= 3 * N - 1 and sum(f.payload_valid for f in ora.frames) >= len(ora.frames) - 1
+    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=2048, payload_soft=1)
+    rx.Execute(x); rx.Flush()
+    check_frames(rx.frames, ora.frames, rel=1.0)
+    frames, fwd, tb = rx.viterbi_stats()
+    assert frames == sum(1 for f in rx.frames if f.header_valid), (frames, len(rx.frames))        # (every frame went through the kernel, none to the fallback)
+    rx.close()
+
+
 @pytest.mark.parametrize("snr_db", [0.0, -1.0])
 def test_convolutional_decoder_is_exact_where_survivors_do_not_merge(oracle, product, snr_db):
     """The K = 7 decoder's own kernel (csrc/viterbi_frames.hpp) runs every trellis block from a 48-step overlap and CHECKS the overlap
