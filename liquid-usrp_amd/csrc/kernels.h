@@ -178,8 +178,7 @@ struct SyncArgs {
     uint8_t *jsoft;             // [max_jobs][8*max_enc_len]
     uint8_t *jtmp;              // [max_jobs][2*(max_enc_len+16)]
     int debug;                 // MCRX_DEBUG=1: trace state-machine events of channel 0
-    uint32_t *vit_list; uint32_t vit_cap;   // frames for viterbi_frames_kernel: [0] = count, then job indices; filled by decode_kernel
-    uint2 *vit_scratch;         // the K = 7 decoder's decision rows: [vit_waves][vit_rows][64] (one region per workgroup of viterbi_frames_kernel; csrc/viterbi_frames.hpp)
+    uint2 *vit_scratch;         // the K = 7 decoder's decision rows: [vit_waves][vit_rows][64] (one region per workgroup of decode_general_kernel; csrc/viterbi_frames.hpp)
     uint32_t vit_rows, vit_waves;
     uint32_t *vit_passes;       // [0] forward passes repeated, [1] traceback passes repeated (blocks whose survivors had not merged inside the overlap), [2] frames; NULL: not counted
     // list-driven launches that are nearly always empty (QAM payload workers, trellis blocks, general decoder): a launch of
@@ -196,7 +195,7 @@ struct SyncArgs {
     uint32_t *live, *live_next;
     uint32_t frames_hint;       // ~0: unknown
     uint32_t live_off;          // lean workers: the main launch's grid (payload_lean.hpp, REST)
-    uint32_t *list_hint;        // [0] QAM hand-offs, [1] frames of the K = 7 decoder, [2] frames on the general list, of the most recent launch
+    uint32_t *list_hint;        // [0] QAM hand-offs, [1] unused, [2] frames on the general list, of the most recent launch
     uint32_t grid_hint[3];      // what the host last read there (~0: no hint, full grids)
     uint32_t payload_lds_pad;  // bytes of unused dynamic LDS per payload worker: caps the workers' occupancy (walk mode, launch_sync)
     int seek_burst;            // idle stretches: SEEK events four at a time, their windows requested together (Walker::seek_burst)

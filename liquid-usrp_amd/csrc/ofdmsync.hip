@@ -52,7 +52,7 @@ namespace mcrx {
 // ------------------------------------------------------------------ small utilities
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 #include "lean_prims.hpp"       // packed-f32 / LDS-crossbar building blocks, the lane <-> subcarrier maps of the lean transforms
-#include "viterbi_frames.hpp"   // the K = 7 soft decoder of viterbi_frames_kernel: a frame per wave, a trellis block per lane
+#include "viterbi_frames.hpp"   // the K = 7 soft decoder of decode_general_kernel: a frame per wave, a trellis block per lane
 
 __device__ __forceinline__ unsigned fec_enc_len_d(unsigned fs, unsigned n)
 {
@@ -2542,7 +2542,7 @@ __device__ __forceinline__ void launder(SyncArgs &a)
     LAUNDER(c.cod.crc_zadv); LAUNDER(c.cod.qam16_nb); LAUNDER(c.cod.qam64_nb);
     LAUNDER(chan); LAUNDER(st); LAUNDER(hbits); LAUNDER(R); LAUNDER(soft); LAUNDER(tmpa); LAUNDER(tmpb);
     LAUNDER(syms); LAUNDER(rec); LAUNDER(arena); LAUNDER(sarena); LAUNDER(nrec); LAUNDER(arena_used);
-    LAUNDER(jobs); LAUNDER(njobs); LAUNDER(jR); LAUNDER(jsoft); LAUNDER(jtmp); LAUNDER(vit_list); LAUNDER(vit_scratch); LAUNDER(vit_passes); LAUNDER(qam_list); LAUNDER(hint); LAUNDER(live);
+    LAUNDER(jobs); LAUNDER(njobs); LAUNDER(jR); LAUNDER(jsoft); LAUNDER(jtmp); LAUNDER(vit_scratch); LAUNDER(vit_passes); LAUNDER(qam_list); LAUNDER(hint); LAUNDER(live);
     LAUNDER(spec); LAUNDER(spec_R); LAUNDER(pred); LAUNDER(pred_n); LAUNDER(stats); LAUNDER(walk_hint); LAUNDER(anchor); LAUNDER(seekst);
 }
 #undef LAUNDER
@@ -2564,8 +2564,16 @@ __global__ __launch_bounds__(WV) void sync_kernel(SyncArgs a)
     w.template run<SYM_FULL>();
 }
 
+// (the tail kernel is launched twice per push and normally finds nothing to do -- but its waves have to find room first, on SIMDs full of
+//  channelizer and worker waves: held to four waves per SIMD (126 registers) where the acquisition kernels get two.  Round 5's first library let it
+//  grow from 131 to 212 registers with the 48-point transform in the Walker's fast path: `bench.py --pipeline` 177 -> 168 Gsample/s.)
+#if SY_PART == 3 && !defined(SY_TAIL_WAVES)
+#define SY_TAIL_WAVES 4
+#elif !defined(SY_TAIL_WAVES)
+#define SY_TAIL_WAVES SY_ACQ_WAVES
+#endif
 template <int E>
-__global__ __launch_bounds__(WV, SY_ACQ_WAVES) void sync_tail_kernel(SyncArgs a)
+__global__ __launch_bounds__(WV, SY_TAIL_WAVES) void sync_tail_kernel(SyncArgs a)
 {
     __builtin_amdgcn_s_setprio(3);      // a chain of dependent events every payload launch waits for: win the issue arbitration against the workers sharing the SIMD
     launder(a);
@@ -2980,24 +2988,16 @@ __device__ __forceinline__ void decode_frame(SyncArgs &a, const uint32_t j, uint
     const bool lds_path = c.payload_soft && fec0 == 1 && (fec1 == 6 || fec1 == 7 || fec1 == 1) && 8u * e1 <= lds_soft_bytes && !(a.no_fast & 8);
     if (!lds_path) {                        // everything else: onto the list of decode_general_kernel (one wave per frame, in place in HBM)
         // ... the K = 7 convolutional code as the outer code first gets its soft bits de-interleaved here (the same gather as below,
-        // written back in place) and the frame onto the list of viterbi_frames_kernel: the general decoder then finds
-        // the decoded bytes waiting
+        // written back in place): the general decoder's wave then runs the trellis with the frame-per-wave decoder (viterbi_frames.hpp)
+        // instead of the one-state-per-lane one
         const uint32_t moff = (c.il_off && e1 < c.il_n) ? c.il_off[e1] : ~0u;
-        const bool conv_pre = c.payload_soft && fec1 == 11 && a.vit_list && a.vit_scratch && moff != ~0u && 8u * e1 <= lds_soft_bytes && !(a.no_fast & 8) &&
+        const bool conv_pre = c.payload_soft && fec1 == 11 && a.vit_scratch && moff != ~0u && 8u * e1 <= lds_soft_bytes && !(a.no_fast & 8) &&
                               vf::rows_for(8u * fec_enc_len_d(fec0, n0) + 6u) <= a.vit_rows;
-        // The list entry is reserved BEFORE the soft bits are touched (ADVICE r3 / VERDICT r4 #8): the gather below rewrites the frame's
-        // soft bits in place, so a frame that found the list full must reach the general decoder untouched -- it de-interleaves for
-        // itself.  One atomic add per frame; the counter only ever moves up and viterbi_frames_kernel clips it to the capacity.
-        __shared__ uint32_t dk_vit_at;
-        const uint32_t vit_e0 = fec_enc_len_d(fec0, n0);
-        if (conv_pre) {
-            if (threadIdx.x == 0) {
-                const uint32_t at = atomicAdd(as_global(a.vit_list), 1u);
-                dk_vit_at = at < a.vit_cap ? at : ~0u;
-            }
-            __syncthreads();
-        }
-        const bool conv_go = conv_pre && dk_vit_at != ~0u;
+        // (Every frame has an entry of the general list to itself, so nothing has to be reserved before the gather below rewrites the frame's
+        //  soft bits in place: the tag on that entry says they are de-interleaved.  Rounds 3-5 kept a second list, of trellis blocks and
+        //  then of frames, for a kernel of the decoder's own between this one and the general decoder -- ADVICE r3 / VERDICT r4 #8 were about
+        //  a frame that found it full.)
+        const bool conv_go = conv_pre;
         if (conv_go) {
             const unsigned long long *g64 = reinterpret_cast<const unsigned long long *>(soft);
             for (uint32_t i = threadIdx.x; i < e1; i += DK_T) dk_soft[DKP(i)] = g64[i];
@@ -3016,7 +3016,6 @@ __device__ __forceinline__ void decode_frame(SyncArgs &a, const uint32_t j, uint
             uint32_t *gl = as_global(a.gen_list);
             uint32_t tag = j;
             if (conv_go) {
-                as_global(a.vit_list)[1u + dk_vit_at] = j;
                 tag |= 0x80000000u;
             }                                         // (list full: this frame's trellis stays with the general decoder's single wave)
             gl[1u + atomicAdd(gl, 1u)] = tag;
@@ -3218,41 +3217,27 @@ __global__ __launch_bounds__(DK_T) void decode_kernel(SyncArgs a, uint32_t lds_s
 // The frames the LDS path does not take (hard decisions, an inner code, the convolutional code, frames longer than the
 // LDS sized for this launch): one wave per frame decodes in place in HBM with the walker's general decoder -- a separate
 // kernel so that its registers (the Viterbi decoder's among them) do not set the occupancy of the one above.
-// the frames decode_kernel listed for the K = 7 decoder: one wave each (viterbi_frames.hpp), decision rows in the workgroup's region of
-// a.vit_scratch, decoded bytes where the general decoder expects them
-__global__ __launch_bounds__(WV) void viterbi_frames_kernel(SyncArgs a)
+// One launch for everything decode_kernel did not finish (round 5; rounds 3-5 had a kernel of the K = 7 decoder's own in front of it):
+//   tagged entries  frames with the K = 7 code as the outer code, soft bits de-interleaved already: the frame-per-wave decoder
+//                   (viterbi_frames.hpp; decision rows in the workgroup's region of a.vit_scratch), then inner code, CRC, delivery;
+//   the rest        hard decisions, an inner code, the short block codes, frames longer than the LDS sized for the launch.
+// It is launched for every push and normally finds its list empty -- but an empty launch still has to find room for its waves on SIMDs
+// full of channelizer and worker waves, and the work stream waits for it: held to four waves per SIMD (128 registers: the K = 7 decoder
+// fits, the general decoder's rare paths spill).  With 212 registers (the Walker it builds for the delivery grew with the 48-point
+// transform) and the K = 7 kernel's launch in front, `bench.py --pipeline` had lost 5 %: 177 -> 168 Gsample/s.
+__global__ __launch_bounds__(WV) __attribute__((amdgpu_num_vgpr(128))) void decode_general_kernel(SyncArgs a)
 {
     launder(a);
-    if (!a.vit_list || !a.vit_scratch) return;
     __shared__ uint16_t vf_ck[2 * 64 * 64];
-    const uint32_t *vl = as_global(a.vit_list);
-    uint32_t nf = vl[0];
-    if (blockIdx.x == 0 && threadIdx.x == 0 && a.list_hint) a.list_hint[1] = nf;
-    if (nf > a.vit_cap) nf = a.vit_cap;
-    if (blockIdx.x >= a.vit_waves) return;
-    const uint32_t stride = gridDim.x < a.vit_waves ? gridDim.x : a.vit_waves;
-    const SyncConsts &c = a.c;
-    uint2 *rows = a.vit_scratch + (size_t)blockIdx.x * a.vit_rows * 64u;
-    for (uint32_t k = blockIdx.x; k < nf; k += stride) {
-        const uint32_t j = vl[1 + k];
-        const uint32_t n_msg = a.jobs[j].s.payload_len, crc = a.jobs[j].s.check, fec0 = a.jobs[j].s.fec0;
-        const uint32_t n0 = n_msg + ((crc == 6) ? 4u : 0u), e0 = fec_enc_len_d(fec0, n0);
-        const size_t tstride = (size_t)c.max_enc_len + 16;
-        vf::decode_frame(a.jsoft + (size_t)j * 8 * c.max_enc_len, e0, a.jtmp + (size_t)j * 2 * tstride, rows, vf_ck, a.vit_passes);
-        __syncthreads();
-    }
-}
-
-__global__ __launch_bounds__(WV) void decode_general_kernel(SyncArgs a)
-{
-    launder(a);
     const uint32_t *gl = as_global(a.gen_list);
     uint32_t ng = gl[0];
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.list_hint) a.list_hint[2] = ng;
     if (ng > a.max_jobs) ng = a.max_jobs;
     const SyncConsts &c = a.c;
+    const bool have_rows = a.vit_scratch && blockIdx.x < a.vit_waves;       // (the launcher keeps the grid inside the scratch: every workgroup has a region)
+    uint2 *rows = a.vit_scratch + (have_rows ? (size_t)blockIdx.x * a.vit_rows * 64u : 0u);
     for (uint32_t k = blockIdx.x; k < ng; k += gridDim.x) {        // (a handful of workgroups; the list is normally empty)
-        const bool pre_done = (gl[1 + k] & 0x80000000u) != 0;      // de-interleaved and Viterbi-decoded already
+        const bool pre_done = (gl[1 + k] & 0x80000000u) != 0;      // de-interleaved already, the K = 7 code outermost
         const uint32_t j = gl[1 + k] & 0x7fffffffu;
         const uint32_t ch = a.jobs[j].ch;
         if (ch >= a.nch || a.jobs[j].arena_off == ~0ull) continue;
@@ -3260,7 +3245,13 @@ __global__ __launch_bounds__(WV) void decode_general_kernel(SyncArgs a)
         const size_t tstride = (size_t)c.max_enc_len + 16;
         uint8_t *soft = a.jsoft + (size_t)j * 8 * c.max_enc_len;
         uint8_t *tmpa = a.jtmp + (size_t)j * 2 * tstride, *tmpb = tmpa + tstride;
-        const bool valid = packet_decode(c.cod, c.payload_soft != 0, false, n_msg, crc, fec0, fec1, soft, tmpa, tmpb, dk_soft, MCRX_DEVEL_ABLATE(a), pre_done);   // 8 KB of LDS: the Viterbi block scratch
+        if (pre_done) {
+            const uint32_t e0 = fec_enc_len_d(fec0, n_msg + ((crc == 6) ? 4u : 0u));
+            if (have_rows) vf::decode_frame(soft, e0, tmpa, rows, vf_ck, a.vit_passes);
+            else conv27_decode_wave(VitSym{ soft, false }, e0, tmpa, reinterpret_cast<uint16_t *>(tmpb), dk_soft);
+            __syncthreads();
+        }
+        const bool valid = packet_decode(c.cod, c.payload_soft != 0, false, n_msg, crc, fec0, fec1, soft, tmpa, tmpb, dk_soft, MCRX_DEVEL_ABLATE(a), pre_done);   // 8 KB of LDS: the one-wave Viterbi decoder's block scratch
         Walker<1> w(a, ch);
         const PayloadJob job = a.jobs[j];
         if (!w.bind_job(j, job)) continue;
@@ -3278,7 +3269,6 @@ __global__ __launch_bounds__(WV) void place_jobs_kernel(SyncArgs a)
     launder(a);
     if (threadIdx.x != 0) return;
     if (a.gen_list) as_global(a.gen_list)[0] = 0;
-    if (a.vit_list) as_global(a.vit_list)[0] = 0;
     uint32_t nj = *a.njobs;
     if (nj > a.max_jobs) nj = a.max_jobs;
     if (a.njobs_next) *a.njobs_next = 0;
@@ -3505,6 +3495,12 @@ static uint32_t decode_soft_lds(const SyncArgs &a)
     return (uint32_t)soft_lds;
 }
 
+#ifndef SY_REST_FLOOR
+#define SY_REST_FLOOR 256u
+#endif
+#ifndef SY_GEN_FLOOR
+#define SY_GEN_FLOOR 128u
+#endif
 hipError_t sync_launch_payload(const SyncArgs &a0, int stage, hipStream_t st)
 {
     if (a0.nch == 0 || !a0.scout || a0.max_jobs == 0) return hipSuccess;
@@ -3537,18 +3533,13 @@ hipError_t sync_launch_payload(const SyncArgs &a0, int stage, hipStream_t st)
         if (!fast) return hipSuccess;
 
         // (grids from the lists' most recent sizes: kernels.h, list_hint)
-        if (a.vit_list && a.vit_scratch) {
-            // (Grid: one workgroup per region of the scratch once the list has been seen non-empty; before that a floor -- a cold start's
-            //  frames then take frames / floor rounds of ~0.25 ms.  Capping the workgroups per CU with unused dynamic LDS -- 4 = one wave
-            //  per SIMD, 8, 2 -- changes nothing or costs: the kernel is bound by vector issue at any occupancy, ~0.25 us per 1200-byte
-            //  frame with the chip full, ~0.22 ms for a wave from start to end: scratch/r5/v27_pad.sh.)
-            size_t pad = 0;
-#ifdef VF_PROF
-            if (getenv("VF_PAD")) pad = (size_t)atoi(getenv("VF_PAD"));
-#endif
-            hipLaunchKernelGGL(viterbi_frames_kernel, dim3(a.grid_hint[1] ? a.vit_waves : (a.vit_waves < 128u ? a.vit_waves : 128u)), dim3(WV), pad, st, a);
-        }
-        hipLaunchKernelGGL(decode_general_kernel, dim3(a.grid_hint[2] ? (nj < 4096 ? nj : 4096) : 64), dim3(WV), (size_t)VIT_B * 8, st, a);
+        // (Grid from the list's most recent size -- kernels.h, list_hint -- inside the K = 7 decoder's scratch, a region per workgroup.
+        //  Capping the workgroups per CU with unused dynamic LDS -- 4 = one wave per SIMD, 8, 2 -- changed nothing or cost, when the
+        //  decoder had a kernel of its own: it is bound by vector issue at any occupancy, ~0.17 us per 1200-byte frame with the chip
+        //  full, ~0.15 ms for a wave from start to end: scratch/r5/v27_pad.sh.)
+        unsigned ggrid = a.grid_hint[2] ? (nj < 4096 ? nj : 4096) : SY_GEN_FLOOR;
+        if (a.vit_scratch && ggrid > a.vit_waves) ggrid = a.vit_waves;
+        hipLaunchKernelGGL(decode_general_kernel, dim3(ggrid), dim3(WV), (size_t)VIT_B * 8, st, a);
         return hipGetLastError();
     }
     // M = 64 with the pilots inside one DPP row: payload_multi_kernel, MCRX_PAYLOAD_FR frames per wave (default 1;
@@ -3557,7 +3548,7 @@ hipError_t sync_launch_payload(const SyncArgs &a0, int stage, hipStream_t st)
     if (fast && a.c.M == 48 && a.c.M_pilot <= 16 && fr == 1 && a.payload_lean && !(a.no_fast & 6)) {
         // 48 subcarriers: the lean workers' 3 x 16 build (the packed-frame and round-2 workers are 64-subcarrier kernels)
         unsigned nq = a.grid_hint[0] == ~0u ? nj : 2u * a.grid_hint[0];
-        nq = nq < 256u ? 256u : (nq > nj ? nj : nq);
+        nq = nq < SY_REST_FLOOR ? SY_REST_FLOOR : (nq > nj ? nj : nq);
         const size_t pad = (size_t)a.payload_lds_pad;
         hipLaunchKernelGGL((payload_lean_kernel<63, 48>), dim3(ngrid), dim3(WV), pad, st, a);
         hipLaunchKernelGGL((payload_lean_rest_kernel<63, 48>), dim3(a.qam_list ? nq : nj), dim3(WV), pad, st, a);
@@ -3576,7 +3567,7 @@ hipError_t sync_launch_payload(const SyncArgs &a0, int stage, hipStream_t st)
                 // (... and one list-driven launch for what the main one does not take: frames beyond its grid, QAM payloads; sized by the
                 //  QAM list's most recent length)
                 unsigned nq = a.grid_hint[0] == ~0u ? nj : 2u * a.grid_hint[0];
-                nq = nq < 256u ? 256u : (nq > nj ? nj : nq);
+                nq = nq < SY_REST_FLOOR ? SY_REST_FLOOR : (nq > nj ? nj : nq);
 #define SY_LEAN(XB) do { hipLaunchKernelGGL(payload_lean_kernel<XB>, dim3(ngrid), dim3(WV), pad, st, a); \
                          hipLaunchKernelGGL(payload_lean_rest_kernel<XB>, dim3(a.qam_list ? nq : nj), dim3(WV), pad, st, a); } while (0)
                 if (xb == 0) SY_LEAN(0);
