@@ -151,7 +151,7 @@ int  mcrx_hip_stream_wait_launch(mcrx_hip_t q, uint64_t launch, void *stream);
 /* frames the per-channel scouts acquired themselves / took over from speculative waves since the last reset of
  * the statistics (synchronises the device) */
 int  mcrx_hip_spec_stats(mcrx_hip_t q, uint64_t *walked, uint64_t *adopted, int reset);
-/* the K = 7 convolutional decoder's own kernel (csrc/viterbi_frames.hpp: a frame per wave, a trellis block per lane, each block run from
+/* the K = 7 convolutional decoder (csrc/viterbi_frames.hpp: a frame per wave, a trellis block per lane, each block run from
  * an overlap and CHECKED against its neighbours): frames it decoded, forward passes and traceback passes it had to repeat because a
  * block's survivors had not merged inside the overlap (0 on any decodable signal; noise costs passes, never exactness).  Synchronises
  * the device. */

@@ -559,7 +559,7 @@ __device__ void soft_pack(const uint8_t *soft, unsigned nbytes, uint8_t *out, bo
 __device__ bool packet_decode(const CodingDev cod, bool soft_mode, bool scrambled, unsigned n_msg,
                               unsigned crc, unsigned fec0, unsigned fec1,
                               uint8_t *soft, uint8_t *tmpa, uint8_t *tmpb, unsigned long long *vit_lds = nullptr, unsigned ablate = 0,
-                              bool pre_done = false)      // pre_done: soft de-interleaved and Viterbi-decoded into tmpa already (decode_kernel + viterbi_frames_kernel)
+                              bool pre_done = false)      // pre_done: soft de-interleaved and Viterbi-decoded into tmpa already (decode_kernel; decode_general_kernel's frame-per-wave decoder)
 {
     const int l = lane_id();
     const unsigned crc_len = (crc == 6) ? 4u : 0u;
