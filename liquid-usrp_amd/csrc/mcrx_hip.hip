@@ -285,12 +285,12 @@ static unsigned pow2ceil(unsigned v) { unsigned p = 1; while (p < v) p <<= 1; re
 // default 2048), built on the device by pushing indices through the inverse interleaver (ofdmsync.hip: ilmap_build_kernel).
 // They depend on (payload limit, staging cap) only, so there is ONE copy per device and process, shared by every handle with those
 // limits and reference counted (ADVICE r3 / VERDICT r4 #8: every handle -- single-channel ofdmtxrx ones included -- used to build
-// its own at creation behind a hipDeviceSynchronize, and leaked the scratch on a failing call).  Built on a stream of its own.
+// its own at creation behind a hipDeviceSynchronize, and leaked the scratch on a failing call).
 struct IlShared { int dev; uint32_t max_payload, cap; uint16_t *d_map; uint32_t *d_off; uint32_t n; int refs; };
 static std::mutex g_il_mu;
 static std::vector<IlShared> g_il;
 
-static int il_tables_acquire(uint32_t max_payload, uint32_t max_enc, const uint16_t **map, const uint32_t **off, uint32_t *n)
+static int il_tables_acquire(uint32_t max_payload, uint32_t max_enc, const uint16_t **map, const uint32_t **off, uint32_t *n, hipStream_t st)
 {
     *map = nullptr; *off = nullptr; *n = 0;
     int dev = 0;
@@ -310,11 +310,12 @@ static int il_tables_acquire(uint32_t max_payload, uint32_t max_enc, const uint1
         }
     if (lens.empty() || total * 8 >= (1ull << 32)) return MCRX_OK;           // (no table: the decoder's in-place passes serve every length)
     uint16_t *d_map = nullptr; uint8_t *d_lo = nullptr, *d_hi = nullptr; uint32_t *d_lens = nullptr, *d_offs = nullptr, *d_off = nullptr;
-    hipStream_t st = nullptr;
+    // (On the handle's own stream.  Round 5's first library created a stream for this and destroyed it again: streams are mapped onto the
+    //  hardware queues in turn, and in a process with more streams than queues -- a handle behind a pipeline: nine -- the one that came
+    //  and went moved two busy ones onto the same queue: `bench.py --pipeline` 177 -> 168 Gsample/s.)
     hipError_t e = hipSuccess;
     auto step = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
-    if (step(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) &&
-        step(hipMalloc((void **)&d_map, (size_t)total * 8 * sizeof(uint16_t))) &&
+    if (step(hipMalloc((void **)&d_map, (size_t)total * 8 * sizeof(uint16_t))) &&
         step(hipMalloc((void **)&d_lo, (size_t)total * 8)) && step(hipMalloc((void **)&d_hi, (size_t)total * 8)) &&
         step(hipMalloc((void **)&d_lens, lens.size() * sizeof(uint32_t))) && step(hipMalloc((void **)&d_offs, offs.size() * sizeof(uint32_t))) &&
         step(hipMalloc((void **)&d_off, offv.size() * sizeof(uint32_t))) &&
@@ -328,7 +329,6 @@ static int il_tables_acquire(uint32_t max_payload, uint32_t max_enc, const uint1
     if (d_hi) (void)hipFree(d_hi);
     if (d_lens) (void)hipFree(d_lens);
     if (d_offs) (void)hipFree(d_offs);
-    if (st) (void)hipStreamDestroy(st);
     if (e != hipSuccess) {
         if (d_map) (void)hipFree(d_map);
         if (d_off) (void)hipFree(d_off);
@@ -750,7 +750,7 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     if (!q->il_tried) {                    // first synchronizer launch of this handle: the device's shared de-interleaver tables
         q->il_tried = true;
         if (q->scout_tables && devel_env("MCRX_NO_ILMAP") == nullptr)
-            RC(il_tables_acquire(q->max_payload, q->max_enc, &q->sc.il_map, &q->sc.il_off, &q->sc.il_n));
+            RC(il_tables_acquire(q->max_payload, q->max_enc, &q->sc.il_map, &q->sc.il_off, &q->sc.il_n, q->stream));
     }
     SyncArgs a;
     a.c = q->sc; a.chan = chan; a.chan_stride = stride; a.chan_off = off;
