@@ -417,6 +417,10 @@ def main():
 
     value = samples_per_step * args.steps / elapsed / 1e6
     out = None
+    if world == 1 and pipe is None:
+        # (the legs below make their own receivers: this one's four streams go first, so that theirs do not share hardware queues with
+        #  them -- HIP maps a process's streams onto GPU_MAX_HW_QUEUES queues in turn)
+        rx.close(); rx = None
     harvest = None
     if world == 1 and not args.no_harvest and not args.pipeline:
         harvest = harvest_legs(prod, N, M, cp, taper, cfg, slabs, K, args, torch)
@@ -516,7 +520,8 @@ def main():
             out["configs"] = cfgs
         if not args.no_cpu and world == 1:                     # the CPU leg is reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(ora, prod, slabs[0] if slabs is not None else slabs_keep0, N, M, cp, taper, args.cpu_reps, cfg)
-    rx.close()
+    if rx is not None:
+        rx.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
