@@ -608,7 +608,7 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
             if ((rc = q->alloc(&q->d_jsoft[sl], (size_t)q->max_jobs * 8 * q->max_enc))) return bail(rc);
             if ((rc = q->alloc(&q->d_jtmp[sl], (size_t)q->max_jobs * 2 * (q->max_enc + 16)))) return bail(rc);
         }
-        if (q->sc.payload_soft && devel_env("MCRX_NO_VITALLOC") == nullptr) {
+        if (q->sc.payload_soft) {
             // The K = 7 decoder (decode_general_kernel, viterbi_frames.hpp) takes a frame per wave and keeps 512 bytes of decisions per trellis
             // step of a block in HBM: one region per workgroup, as many workgroups as a launch can have frames (at most 2 per SIMD: it is
             // arithmetic).  Its launches follow each other on the work stream, so one set serves every slot.  (~200 KB per workgroup at 1200-byte
@@ -766,7 +766,7 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     a.scout = q->scout ? 1 : 0;
     a.jobs = q->d_jobs[slot]; a.njobs = q->d_njobs + slot; a.njobs_next = q->d_njobs + next; a.max_jobs = q->max_jobs;
     a.gen_list = q->d_gen[slot]; a.dec_lds_soft = 0;
-    a.vit_scratch = devel_env("MCRX_NO_VITSCRATCH") ? nullptr : q->d_vit_scratch; a.vit_rows = q->vit_rows; a.vit_waves = q->vit_waves; a.vit_passes = q->d_vit_passes;
+    a.vit_scratch = q->d_vit_scratch; a.vit_rows = q->vit_rows; a.vit_waves = q->vit_waves; a.vit_passes = q->d_vit_passes;
     a.qam_list = q->d_qam[slot]; a.qam_next = q->d_qam[next]; a.list_hint = nullptr;
     a.live = q->d_live[slot]; a.live_next = q->d_live[next];
     a.live_off = 0;
@@ -785,7 +785,7 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     a.stats = q->d_stats;
     a.hint = q->d_hint; a.enc_hint = (q->h_hint && q->d_hint) ? *(volatile uint32_t *)q->h_hint : 0u;
     a.spec = q->d_spec; a.spec_stride = q->spec_stride; a.spec_R = q->d_spec_R; a.pred = nullptr; a.pred_n = nullptr; a.spec_cap = 0; a.spec_hint = nullptr; a.walk_hint = nullptr;
-    a.nseg = 0; a.seg_phase = 0; a.anchor = nullptr; a.seg_jobs = 1; a.seekst = devel_env("MCRX_NO_SEEKST") ? nullptr : q->d_seekst; a.seg_walker = q->seg_walker;
+    a.nseg = 0; a.seg_phase = 0; a.anchor = nullptr; a.seg_jobs = 1; a.seekst = q->d_seekst; a.seg_walker = q->seg_walker;
     a.no_syms = (q->cfg.struct_size >= offsetof(mcrx_hip_config, skip_framesyms) + sizeof(uint32_t) && q->cfg.skip_framesyms == 2) ? 1 : 0;
     hipStream_t sa = st, sw = st;
     // The host never waits for the device on this path (slots are handed over by stream waits), so a free-running caller
