@@ -24,7 +24,7 @@ for it in range(iters):
     n = int(iq.numel()) // (32 * N) * (32 * N)                # (whole tiles: MCRX_TILE = 16 blocks of 2N samples since round 4)
     x = iq[:n].cpu().numpy()
     t = np.arange(n)
-    snr = rng.uniform(22, 40)
+    snr = rng.uniform(float(os.environ.get("SOAK_SNR_LO", "22")), float(os.environ.get("SOAK_SNR_HI", "40")))
     sig = np.sqrt(np.mean(np.abs(x) ** 2))
     x = (x * np.exp(1j * (rng.uniform(-3e-4, 3e-4) * t + rng.uniform(0, 6.28))) +
          sig * 10 ** (-snr / 20) / np.sqrt(2) * (rng.randn(n) + 1j * rng.randn(n))).astype(np.complex64)
@@ -51,7 +51,10 @@ for it in range(iters):
             for fg, fo in zip(gy.get(ch, []), by[ch]):
                 nframes += 1
                 if (fg.header_valid, fg.payload_valid, fg.header, fg.payload) != (fo.header_valid, fo.payload_valid, fo.header, fo.payload):
-                    nbad += 1; print("iter", it, "rep", rep, "ch", ch, "mismatch", fg, fo)
+                    nbad += 1
+                    nd = sum(1 for a_, b_ in zip(fg.payload, fo.payload) if a_ != b_)
+                    print("iter", it, "rep", rep, "ch", ch, "mismatch", fg, fo, "| N M cp", N, M, cp, "mod", fg.mod_scheme, "fec0/1", fg.fec0, fg.fec1, "flags", (fg.header_valid, fg.payload_valid), (fo.header_valid, fo.payload_valid),
+                          "header equal", fg.header == fo.header, "payload bytes differing", nd, "of", len(fo.payload), "first at", next((i_ for i_, (a_, b_) in enumerate(zip(fg.payload, fo.payload)) if a_ != b_), -1))
                 elif len(fo.framesyms):
                     e = float(np.max(np.abs(fg.framesyms - fo.framesyms)) / np.max(np.abs(fo.framesyms)))
                     worst = max(worst, e)
