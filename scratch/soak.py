@@ -52,6 +52,16 @@ for it in range(iters):
                 nframes += 1
                 if (fg.header_valid, fg.payload_valid, fg.header, fg.payload) != (fo.header_valid, fo.payload_valid, fo.header, fo.payload):
                     nbad += 1
+                    if os.environ.get("SOAK_PERTURB") and rep == 0:
+                        # is this frame's payload stable under the oracle's OWN float rounding?  the same input with 3e-7 relative noise
+                        # (one float32 ulp or so per sample) through the oracle again
+                        changed = 0
+                        for trial in range(4):
+                            xp = (x * (1.0 + 3e-7 * (rng.randn(n) + 1j * rng.randn(n)))).astype(np.complex64)
+                            o2 = ora.MultiChannelRx(N, M, cp, 4); o2.execute(xp)
+                            f2 = [f_ for f_ in o2.frames if f_.channel == ch and f_.header == fo.header]
+                            changed += 1 if (f2 and f2[0].payload != fo.payload) else 0
+                        print("   oracle on the same input + 3e-7 relative noise: this frame's payload changed in", changed, "of 4 trials")
                     nd = sum(1 for a_, b_ in zip(fg.payload, fo.payload) if a_ != b_)
                     print("iter", it, "rep", rep, "ch", ch, "mismatch", fg, fo, "| N M cp", N, M, cp, "mod", fg.mod_scheme, "fec0/1", fg.fec0, fg.fec1, "flags", (fg.header_valid, fg.payload_valid), (fo.header_valid, fo.payload_valid),
                           "header equal", fg.header == fo.header, "payload bytes differing", nd, "of", len(fo.payload), "first at", next((i_ for i_, (a_, b_) in enumerate(zip(fg.payload, fo.payload)) if a_ != b_), -1))
