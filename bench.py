@@ -497,7 +497,7 @@ def main():
                          "kernels_frac_of_peak": {k: round(v, 5) for k, v in fracs.items()},
                          "kernels_ms_overlapped": {k: round(v, 4) for k, v in ovl.items()},
                          "serial_sum_ms_per_slab": round(sum(per.values()), 4),
-                         "vector_issue": vector_issue(value, world, N, args.frames, args.payload, samples_per_step / max(1, args.slabs) / world),
+                         "vector_issue": safely(vector_issue, value, world, N, args.frames, args.payload, samples_per_step / max(1, args.slabs) / world),
                          "pipeline_frac_of_16B_roofline": round(value * 1e6 * 16.0 / (world * HBM_PEAK_GBS * 1e9), 5),
                          "per_gpu": {"Msamples_per_s": round(value / world, 3), "GBps_at_16B_per_sample": round(value / world * 16e-3, 2),
                                      "peak_GBps": HBM_PEAK_GBS},
@@ -836,6 +836,14 @@ def measured_traffic(kernel, N, frames, payload):
             if want in name:
                 return round(t["hbm_bytes_per_launch"], 0)
     return None
+
+
+def safely(fn, *a):
+    """(an informational block must never cost the benchmark its line)"""
+    try:
+        return fn(*a)
+    except Exception as e:                                   # noqa: BLE001
+        return {"error": repr(e)}
 
 
 def vector_issue(value, world, N, frames, payload, slab_samples):
