@@ -215,6 +215,12 @@ struct SyncArgs {
     // behind that point -- and a wave whose chain arrives exactly at the next segment's validated start stops there.  A wrong or
     // missing prediction costs nothing but the two acquisitions again (the coarse start); the results never depend on it.
     int no_syms;                         // 1 (mcrx_hip_config::skip_framesyms = 2): the lean payload workers do not store the equalised symbols at all
+    // The launch behind the lean workers (QAM payloads, frames beyond their grid) and the general decoder normally find nothing to do,
+    // but an empty launch still waits for a wave slot on a chip full of channelizer and worker waves -- 0.15 + 0.08 ms of the work
+    // stream's 0.98 ms per push (profiles/r5_t3_kernel_stats.csv).  While their lists have been empty the host puts them on a stream
+    // of their own, with a decoder launch for their frames only, so that the next push's workers do not queue behind them:
+    int split_rest;                      // 1: stage 1 launches the main workers only, stage 4 the launch behind them
+    int dec_phase;                       // decode_kernel: 0 = every live frame, 1 = the main workers' frames only, 2 = the others
     int seg_walker;                      // 1 (default): the segment waves are the Walker's kernel (sync_spec_kernel); 0 (scout_build = 2): acq_lean.hpp's where the design allows
     int seg_phase;                       // 1: first frame from the entry state only (grid = channels); 2: the rest; 0: one launch, no cadence;
                                          // 3 / 4 (round 5): one launch, the lattice carried over from the previous push -- absolute / relative to the push's beginning
@@ -264,6 +270,7 @@ hipError_t sync_launch_spec(const SyncArgs &a, hipStream_t st);      // segment-
 // stage 0: record placement (one workgroup), 1: payload workers (one wave per handed-off frame),
 // 2: packet decode (one workgroup per frame; only after the lean workers -- the general ones decode in place)
 hipError_t sync_launch_payload(const SyncArgs &a, int stage, hipStream_t st);
+bool sync_payload_splits(const SyncArgs &a);                         // the payload stage has a launch behind the main workers (SyncArgs::split_rest)
 // synchronizers back to SEEK at sample `cur`; optionally also zero two history buffers of hist_n cf32 each (hist_n even)
 // and the result counters -- a whole restart in one launch
 hipError_t sync_reset_launch(ChanState *st, uint32_t nch, int64_t cur, float2 *hist0, float2 *hist1, size_t hist_n,

@@ -179,8 +179,10 @@ struct mcrx_hip_s {
     // k's payload/decode kernels, and launch k+1's channelizer as soon as CUs free up.
     bool pipelined = true;
     hipStream_t s_scout = nullptr, s_work = nullptr, s_copy = nullptr;
+    // the launches that normally find nothing to do (kernels.h, split_rest), while that is what they have been finding
+    hipStream_t s_side = nullptr; hipEvent_t ev_side[MCRX_SLOTS] = {}, ev_side_last = nullptr; bool side_last = false;
 
-    hipEvent_t ev_ready[MCRX_SLOTS] = {}, ev_scout[MCRX_SLOTS] = {}, ev_done[MCRX_SLOTS] = {}, ev_in = nullptr, ev_consumed = nullptr, ev_tmp[3] = {};
+    hipEvent_t ev_ready[MCRX_SLOTS] = {}, ev_scout[MCRX_SLOTS] = {}, ev_done[MCRX_SLOTS] = {}, ev_in = nullptr, ev_consumed = nullptr, ev_tmp[4] = {};
     int last_slot = -1; size_t last_ntiles = 0;     // where the synchronizer history (tail of the previous launch) sits
     uint32_t spec_stride = MCRX_SPEC_MAX;           // slots per channel in d_spec (grows when a push holds more frames per channel: launch_sync)
     SpecSlot *d_spec = nullptr; float2 *d_spec_R = nullptr; int64_t *d_pred = nullptr, *d_anchor = nullptr, *d_seekst = nullptr; uint32_t *d_pred_n = nullptr;
@@ -422,9 +424,9 @@ static int build_tables(mcrx_hip_t q)
 static int join_into(mcrx_hip_t q, hipStream_t st)
 {
     if (!q->pipelined) return MCRX_OK;
-    hipStream_t in[3] = { q->stream, q->s_scout, q->s_work };
-    for (int i = 0; i < 3; i++) {
-        if (in[i] == st) continue;
+    hipStream_t in[4] = { q->stream, q->s_scout, q->s_work, q->s_side };
+    for (int i = 0; i < 4; i++) {
+        if (in[i] == st || !in[i]) continue;
         HIPCHK(hipEventRecord(q->ev_tmp[i], in[i]));
         HIPCHK(hipStreamWaitEvent(st, q->ev_tmp[i], 0));
     }
@@ -435,8 +437,8 @@ static int fork_from(mcrx_hip_t q, hipStream_t st)
 {
     if (!q->pipelined) return MCRX_OK;
     HIPCHK(hipEventRecord(q->ev_tmp[0], st));
-    hipStream_t out[3] = { q->stream, q->s_scout, q->s_work };
-    for (int i = 0; i < 3; i++) if (out[i] != st) HIPCHK(hipStreamWaitEvent(out[i], q->ev_tmp[0], 0));
+    hipStream_t out[4] = { q->stream, q->s_scout, q->s_work, q->s_side };
+    for (int i = 0; i < 4; i++) if (out[i] && out[i] != st) HIPCHK(hipStreamWaitEvent(out[i], q->ev_tmp[0], 0));
     return MCRX_OK;
 }
 
@@ -650,12 +652,18 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
             return bail(fail(MCRX_EHIP, "hipStreamCreate failed"));
     }
     if (hipStreamCreate(&q->s_work) != hipSuccess) return bail(fail(MCRX_EHIP, "hipStreamCreate failed"));
+    // (With the others: a stream created in mid-stream shifts the queue mapping.  Only for receivers of few channels: their pushes are
+    //  chains of launch gaps, and three launches less in the work stream's chain are worth 15-18 % (8 channels: 65 -> 77 Gsample/s, with
+    //  the K = 7 code 41 -> 47); a receiver that fills the chip gains nothing from it, and the stream's mere existence cost 1 % of the
+    //  headline and 10 % of the pipeline leg in alternating runs -- scratch/r5/split_ab.sh.)
+    if (q->pipelined && q->nch <= 64 && q->cfg.channel_count == 0 && hipStreamCreate(&q->s_side) != hipSuccess)      // (not a rank's shard behind a pipeline: streams enough there)
+        return bail(fail(MCRX_EHIP, "hipStreamCreate failed"));
     if (hipStreamCreateWithFlags(&q->s_copy, hipStreamNonBlocking) != hipSuccess) return bail(fail(MCRX_EHIP, "hipStreamCreate failed"));
     {
-        hipEvent_t *evs[] = { &q->ev_in, &q->ev_consumed, &q->ev_tmp[0], &q->ev_tmp[1], &q->ev_tmp[2] };
+        hipEvent_t *evs[] = { &q->ev_in, &q->ev_consumed, &q->ev_tmp[0], &q->ev_tmp[1], &q->ev_tmp[2], &q->ev_tmp[3], &q->ev_side_last };
         for (hipEvent_t *e : evs) if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return bail(fail(MCRX_EHIP, "hipEventCreate failed"));
         for (int sl = 0; sl < MCRX_SLOTS; sl++) {
-            hipEvent_t *ev3[] = { &q->ev_ready[sl], &q->ev_scout[sl], &q->ev_done[sl] };
+            hipEvent_t *ev3[] = { &q->ev_ready[sl], &q->ev_scout[sl], &q->ev_done[sl], &q->ev_side[sl] };
             for (hipEvent_t *e : ev3) if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return bail(fail(MCRX_EHIP, "hipEventCreate failed"));
         }
     }
@@ -688,15 +696,16 @@ extern "C" int mcrx_hip_destroy(mcrx_hip_t q)
     if (q->h_stage) (void)hipHostFree(q->h_stage);
     q->arena_host.release(); q->sarena_host.release();
     {
-        hipEvent_t evs[] = { q->ev_in, q->ev_consumed, q->ev_tmp[0], q->ev_tmp[1], q->ev_tmp[2] };
+        hipEvent_t evs[] = { q->ev_in, q->ev_consumed, q->ev_tmp[0], q->ev_tmp[1], q->ev_tmp[2], q->ev_tmp[3], q->ev_side_last };
         for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
         for (int g = 0; g < MCRX_GENS; g++) { if (q->ev_gen[g]) (void)hipEventDestroy(q->ev_gen[g]); if (q->ev_clean[g]) (void)hipEventDestroy(q->ev_clean[g]); }
         for (int sl = 0; sl < MCRX_SLOTS; sl++) {
             if (q->ev_ready[sl]) (void)hipEventDestroy(q->ev_ready[sl]);
             if (q->ev_scout[sl]) (void)hipEventDestroy(q->ev_scout[sl]);
             if (q->ev_done[sl]) (void)hipEventDestroy(q->ev_done[sl]);
+            if (q->ev_side[sl]) (void)hipEventDestroy(q->ev_side[sl]);
         }
-        hipStream_t sts[] = { q->s_scout, q->s_work, q->s_copy };
+        hipStream_t sts[] = { q->s_scout, q->s_work, q->s_copy, q->s_side };
         for (hipStream_t t : sts) if (t) (void)hipStreamDestroy(t);
     }
     for (int i = 0; i < 2; i++) {
@@ -769,7 +778,7 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     a.vit_scratch = q->d_vit_scratch; a.vit_rows = q->vit_rows; a.vit_waves = q->vit_waves; a.vit_passes = q->d_vit_passes;
     a.qam_list = q->d_qam[slot]; a.qam_next = q->d_qam[next]; a.list_hint = nullptr;
     a.live = q->d_live[slot]; a.live_next = q->d_live[next];
-    a.live_off = 0;
+    a.live_off = 0; a.split_rest = 0; a.dec_phase = 0;
     a.frames_hint = (q->h_hint && q->d_hint) ? ((volatile uint32_t *)q->h_hint)[7] : ~0u;
     if (a.frames_hint == 0) a.frames_hint = ~0u;                 // (a launch without frames says nothing about the next)
     for (int i = 0; i < 3; i++) a.grid_hint[i] = ~0u;
@@ -923,13 +932,32 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
         // payload workers; the LDS-path packet decoder; the general decoder (nearly always an empty launch: ~12 us.
         // Giving it a stream of its own was tried: a fifth stream makes the harvest's copy stream share a hardware
         // queue with a busy one, and every poll then waits a slab's time for its 16-byte copies -- harvest 123 -> 98 Gsample/s)
+        // While the lists of the launch behind the workers (QAM payloads, frames beyond the grid) and of the general decoder have been
+        // empty for 64 launches, those two go to a stream of their own behind this push's decoder, with a decoder launch for their frames
+        // only -- whatever they find is still done, in this push, it just no longer stands between this push's decoder and the next push's
+        // workers (kernels.h, split_rest).  Everything of the push is finished when THAT stream is; a change of mode orders the two.
+        const bool split = sw == q->s_work && q->s_side && q->h_hint && q->d_hint && q->list_seen[0] == 0 && q->list_seen[2] == 0 &&
+                           q->seq >= 8 && a.frames_hint != ~0u && a.frames_hint < 2048u && sync_payload_splits(a);
+        hipStream_t sd = sw;
+        if (split) { a.split_rest = 1; a.dec_phase = 1; sd = q->s_side; }
+        else if (q->side_last) HIPCHK(hipStreamWaitEvent(sw, q->ev_side_last, 0));       // (back in one line: behind what the other stream still holds)
         RC(q->ev_begin(3, sw));
         HIPCHK(sync_launch_payload(a, 1, sw));
         RC(q->ev_end(3, sw));
         RC(q->ev_begin(4, sw));
         HIPCHK(sync_launch_payload(a, 2, sw));
-        HIPCHK(sync_launch_payload(a, 3, sw));
-        RC(q->ev_end(4, sw));
+        if (split) {
+            HIPCHK(hipEventRecord(q->ev_side[slot], sw));
+            HIPCHK(hipStreamWaitEvent(sd, q->ev_side[slot], 0));
+            HIPCHK(sync_launch_payload(a, 4, sd));
+            a.dec_phase = 2;
+            HIPCHK(sync_launch_payload(a, 2, sd));
+        }
+        HIPCHK(sync_launch_payload(a, 3, sd));
+        RC(q->ev_end(4, sd));
+        if (split) HIPCHK(hipEventRecord(q->ev_side_last, sd));
+        q->side_last = split;
+        sw = sd;
     }
     HIPCHK(hipEventRecord(q->ev_done[slot], sw));
     HIPCHK(hipEventRecord(q->ev_gen[g], sw));

@@ -3209,6 +3209,11 @@ __global__ __launch_bounds__(DK_T) void decode_kernel(SyncArgs a, uint32_t lds_s
     if (nl > a.max_jobs) nl = a.max_jobs;
     for (uint32_t k = blockIdx.x; k < nl; k += gridDim.x) {
         const uint32_t j = a.live[1u + k];
+        if (a.dec_phase && j < a.max_jobs) {                    // (kernels.h, split_rest: whose frame is this -- the main workers' or the launch's behind them?)
+            const uint32_t mod = a.jobs[j].s.mod_scheme;
+            const bool main_frame = k < a.live_off && (mod == 39 || mod == 40);
+            if (main_frame != (a.dec_phase == 1)) continue;
+        }
         decode_frame(a, j, lds_soft_bytes, msg_bytes);
         __syncthreads();                                        // (the next frame reuses the staging area)
     }
@@ -3501,6 +3506,12 @@ static uint32_t decode_soft_lds(const SyncArgs &a)
 #ifndef SY_GEN_FLOOR
 #define SY_GEN_FLOOR 128u
 #endif
+// does this design's payload stage consist of the lean one-frame-per-wave workers and a launch behind them (kernels.h, split_rest)?
+bool sync_payload_splits(const SyncArgs &a)
+{
+    const bool fast = ((a.c.log2M >= 6 && a.c.M == WV * a.c.E) || (a.c.M == 48 && a.c.E == 1)) && a.c.M_pilot <= WV && !(a.no_fast & 1);
+    return a.scout && fast && (a.c.M == WV || a.c.M == 48) && a.c.M_pilot <= 16 && a.payload_fr == 1 && a.payload_lean && !(a.no_fast & 6);
+}
 hipError_t sync_launch_payload(const SyncArgs &a0, int stage, hipStream_t st)
 {
     if (a0.nch == 0 || !a0.scout || a0.max_jobs == 0) return hipSuccess;
@@ -3516,6 +3527,8 @@ hipError_t sync_launch_payload(const SyncArgs &a0, int stage, hipStream_t st)
     // the M = 64 lean workers take one BPSK / QPSK frame per wave out of the first `ngrid` of the live list; the launch behind them
     // walks the rest of it (live_off tells it where the grid ended)
     if (fast && m64or48 && a.c.M_pilot <= 16 && a.payload_fr == 1 && a.payload_lean && !(a.no_fast & 6)) a.live_off = ngrid;
+    if (stage == 4 && !a.live_off) return hipSuccess;                    // (only the lean workers have a launch behind them)
+    if (!a.live_off) { a.split_rest = 0; a.dec_phase = 0; }
     a.dec_lds_soft = fast ? decode_soft_lds(a) : 0u;
     if (!fast) a.gen_list = nullptr;
     if (stage == 0) {
@@ -3550,8 +3563,8 @@ hipError_t sync_launch_payload(const SyncArgs &a0, int stage, hipStream_t st)
         unsigned nq = a.grid_hint[0] == ~0u ? nj : 2u * a.grid_hint[0];
         nq = nq < SY_REST_FLOOR ? SY_REST_FLOOR : (nq > nj ? nj : nq);
         const size_t pad = (size_t)a.payload_lds_pad;
-        hipLaunchKernelGGL((payload_lean_kernel<63, 48>), dim3(ngrid), dim3(WV), pad, st, a);
-        hipLaunchKernelGGL((payload_lean_rest_kernel<63, 48>), dim3(a.qam_list ? nq : nj), dim3(WV), pad, st, a);
+        if (stage != 4) hipLaunchKernelGGL((payload_lean_kernel<63, 48>), dim3(ngrid), dim3(WV), pad, st, a);
+        if (stage == 4 || !a.split_rest) hipLaunchKernelGGL((payload_lean_rest_kernel<63, 48>), dim3(a.qam_list ? nq : nj), dim3(WV), pad, st, a);
         return hipGetLastError();
     }
     if (fast && a.c.M == WV && a.c.M_pilot <= 16 && fr > 0 && !(a.no_fast & 6)) {
@@ -3568,8 +3581,8 @@ hipError_t sync_launch_payload(const SyncArgs &a0, int stage, hipStream_t st)
                 //  QAM list's most recent length)
                 unsigned nq = a.grid_hint[0] == ~0u ? nj : 2u * a.grid_hint[0];
                 nq = nq < SY_REST_FLOOR ? SY_REST_FLOOR : (nq > nj ? nj : nq);
-#define SY_LEAN(XB) do { hipLaunchKernelGGL(payload_lean_kernel<XB>, dim3(ngrid), dim3(WV), pad, st, a); \
-                         hipLaunchKernelGGL(payload_lean_rest_kernel<XB>, dim3(a.qam_list ? nq : nj), dim3(WV), pad, st, a); } while (0)
+#define SY_LEAN(XB) do { if (stage != 4) hipLaunchKernelGGL(payload_lean_kernel<XB>, dim3(ngrid), dim3(WV), pad, st, a); \
+                         if (stage == 4 || !a.split_rest) hipLaunchKernelGGL(payload_lean_rest_kernel<XB>, dim3(a.qam_list ? nq : nj), dim3(WV), pad, st, a); } while (0)
                 if (xb == 0) SY_LEAN(0);
                 else         SY_LEAN(63);
 #undef SY_LEAN

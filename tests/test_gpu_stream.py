@@ -440,3 +440,39 @@ def test_reference_app_default_numerology_takes_the_lean_path(oracle, product, m
     assert walked == 0 and adopted == 3 * nf * N, (walked, adopted)
     assert len(rx.frames) == 2 * len(ora.frames)
     rx.close()
+
+
+def test_surprises_while_the_empty_launches_are_on_their_own_stream(oracle, product):
+    """A receiver of few channels puts the launches that normally find nothing to do -- the one behind the lean workers (QAM payloads,
+    frames beyond their grid) and the general decoder -- on a stream of their own once their lists have been empty for 64 launches, with a
+    decoder launch for their frames only (csrc/kernels.h: split_rest).  What they then DO find must still be done, in its push: 90
+    pushes of QPSK frames, then pushes with 16-QAM payloads, the K = 7 code, hard-to-reach short frames four times as many as the
+    grid expects, then QPSK again; every frame the oracle's, in the oracle's order."""
+    import torch
+    from test_gpu_parity import check_frames
+    N, M, cp = 4, 64, 8
+    tx = product.multichanneltx(N, M, cp, 4)
+    parts = []
+    a, _ = tx.generate(2, 300, mod=40, fec1=6, seed=11)
+    quiet = [a] * 90                                            # (the same slab again and again: a periodic stream of 90 pushes)
+    b, _ = tx.generate(2, 300, mod=27, fec1=7, seed=12)         # 16-QAM + Golay: the launch behind the workers
+    c, _ = tx.generate(2, 300, mod=40, fec1=11, seed=13)        # K = 7: the general decoder
+    d, _ = tx.generate(9, 40, mod=40, fec1=6, seed=14)          # many short frames: more than the grid of the last launches
+    e, _ = tx.generate(2, 300, mod=29, fec1=6, seed=15)         # 64-QAM + Hamming
+    tx.close()
+    seq = quiet + [b, a, c, a, d, e, a, a]
+    iq = torch.cat(seq)
+    n = int(iq.numel()) // (32 * N) * (32 * N)
+    x = iq[:n].cpu().numpy()
+    ora = oracle.MultiChannelRx(N, M, cp, 4)
+    ora.execute(x)
+    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=300)
+    pos = 0
+    for s_ in seq:                                               # one push per slab (tile-aligned cuts: a slab's tail rides with the next)
+        end = min(n, (pos + int(s_.numel())) // (32 * N) * (32 * N)) if s_ is not seq[-1] else n
+        if end > pos:
+            rx.Execute(iq[pos:end]); pos = end
+    rx.Flush()
+    assert len(ora.frames) >= 2 * N * (len(seq) - 1)
+    check_frames(rx.frames, ora.frames)
+    rx.close()
