@@ -531,7 +531,7 @@ def main():
         sys.exit("rank %d: verification failed (%d/%d frames, %d ok)" % (rank, nfr, expect, n_ok))
 
 
-def config_leg(prod, torch, dev, N, M, cp, frames, plen, mod, fec1, resamp, steps, reps, what):
+def config_leg(prod, torch, dev, N, M, cp, frames, plen, mod, fec1, resamp, steps, reps, what, front_end=0):
     """One of the other BASELINE.json configurations as a continuous stream through ONE un-restarted receiver, like `value`:
     two different slabs (seeds, idle tails) pushed alternately, frames dropped on the device, then one more step harvested and
     every frame checked against what was sent.  resamp: the slabs are 2x oversampled (zero stuffing + half-band low-pass, made
@@ -557,7 +557,8 @@ def config_leg(prod, torch, dev, N, M, cp, frames, plen, mod, fec1, resamp, step
             inputs.append(torch.view_as_complex(re.reshape(2, -1).T.contiguous()))
         del up, re
         rs = prod.msresamp(0.5, 60.0)
-    rx = prod.multichannelrx(N, M, cp, taper, max_payload_len=plen, max_frames=N * frames + 64, **LEG_CFG)
+    leg_cfg = dict(LEG_CFG, front_end=front_end) if front_end else LEG_CFG
+    rx = prod.multichannelrx(N, M, cp, taper, max_payload_len=plen, max_frames=N * frames + 64, **leg_cfg)
     tile = prod.TILE * K
 
     # resampler and receiver on ONE caller stream that is not the legacy default stream (work on the NULL stream is a
@@ -598,6 +599,31 @@ def config_leg(prod, torch, dev, N, M, cp, frames, plen, mod, fec1, resamp, step
     if rs is not None:
         rs.close()
     n_in = sum(int(x.numel()) for x in inputs)
+    roof = None
+    if front_end:
+        # the front-end kernel alone (a serial receiver: every kernel of a push in order on one stream, HIP events on that stream),
+        # against the same 12 algorithmic bytes per wideband sample as the reference's bank: 8 read + 4 written
+        ser = prod.multichannelrx(N, M, cp, taper, max_payload_len=plen, max_frames=N * frames + 64, serial=1, **leg_cfg)
+        for k in range(5):
+            if k == 2:
+                torch.cuda.synchronize(); ser.kernel_stats(reset=True)
+            for x in inputs:
+                ser.Execute(x); ser.Discard()
+        torch.cuda.synchronize()
+        cms, cn = ser.kernel_stats()["channelizer_kernel"]
+        ser.close()
+        per_launch = n_in / len(inputs)
+        ms1 = cms / max(cn, 1)
+        ach = B_CHANNELIZER * per_launch / (ms1 * 1e-3) / 1e9
+        traffic = front_end_traffic(N)
+        roof = {"kernel": "channelizer_kernel<%d,2,%d,28,shift> (oscillator + firpfbch2 analysis + half-band decimator per kept channel, folded into one bank)" % (K, 512 if K >= 512 else 256),
+                "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                "kernel_ms_alone": round(ms1, 4), "launches_timed": int(cn), "samples_per_launch": int(per_launch),
+                "algorithmic_bytes_per_sample": B_CHANNELIZER,
+                "traffic": traffic, "traffic_over_algorithmic": round(traffic / (B_CHANNELIZER * per_launch), 3) if traffic else None,
+                "traffic_source": "profiles/r6_pfb2_traffic.json (rocprofv3 --pmc passes of scratch/r6/prof_pfb2.sh: 2 x FETCH_SIZE + WRITE_SIZE per launch)" if traffic else None,
+                "unfused_chain_bytes_per_sample": 52.0,
+                "note": "front_end = 2 runs the same chain as three kernels (oscillator pass 8 + 8, bank at twice the rate 8 + 16, adapter 8 + 4 bytes per sample)"}
     bytes_per = 20.0 if resamp else 16.0
     med = float(np.median(rep_s))
     val = n_in * steps / med / 1e6
@@ -607,8 +633,18 @@ def config_leg(prod, torch, dev, N, M, cp, frames, plen, mod, fec1, resamp, step
             "repetitions": reps, "steps": steps, "samples_per_step": n_in, "ms_per_step": round(med / steps * 1e3, 4),
             "algorithmic_bytes_per_sample": bytes_per, "frac_of_roofline": round(val * 1e6 * bytes_per / (HBM_PEAK_GBS * 1e9), 5),
             "frames_acquired": {"by_scout_walk": walked, "adopted_from_segment_waves": adopted, "walked_share": round(walked / tot, 5) if tot else None},
-            "kernels_ms_overlapped": ovl,
+            "kernels_ms_overlapped": ovl, **({"roofline": roof} if roof else {}),
             "verified": {"frames": nfr, "expected": 2 * N * frames, "bit_exact_payloads": ok, "ok": nfr == 2 * N * frames and ok == nfr}}
+
+
+def front_end_traffic(N):
+    """HBM bytes per launch of the folded front-end kernel from the committed counter passes (profiles/r6_pfb2_traffic.json), None if absent
+    or of another channel count"""
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r6_pfb2_traffic.json")))
+        return round(prof["hbm_bytes_per_launch"], 0) if int(prof.get("channels", 0)) == N else None
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def configs_block(prod, torch, dev, args):
@@ -626,9 +662,14 @@ def configs_block(prod, torch, dev, args):
              "rounds 1-4: direct DFTs, every frame walked, 20.4 Gsample/s"),
             ("64ch_m256_qam16_resamp", 64, 256, 32, 32, 1200, 27, 7, True,
              "configs[2]: 64-ch multichannelrx, M=256 cp=32 QAM16 CRC32+Golay(24,12) 1200B payloads, 32 frames/ch/slab, msresamp(0.5) front end"))
-    for name, N, M, cp, fr, pl, mod, fec1, rsmp, what in legs:
+    legs = tuple(l + (0,) for l in legs) + (
+            ("512ch_pfb2_front_end", 512, 64, 8, 16, 1200, 40, 6, False,
+             "the channelizer BASELINE.json's north_star names in front of the headline's receiver: 512-ch multichannelrx with cfg.front_end = 1 -- oscillator, "
+             "firpfbch2 analysis bank (1024 channels at twice the channel rate) and the half-band decimator of every kept channel as ONE kernel "
+             "(a 28-tap composite bank, csrc/channelizer.hip) -- M=64 cp=8 QPSK CRC32+Hamming128 1200B payloads, 16 frames/ch/slab", 1),)
+    for name, N, M, cp, fr, pl, mod, fec1, rsmp, what, fe in legs:
         try:
-            out[name] = config_leg(prod, torch, dev, N, M, cp, fr, pl, mod, fec1, rsmp, steps=6, reps=3, what=what)
+            out[name] = config_leg(prod, torch, dev, N, M, cp, fr, pl, mod, fec1, rsmp, steps=6, reps=3, what=what, front_end=fe)
         except Exception as e:                                   # a leg that fails says so in the line; the headline stands
             out[name] = {"workload": what, "error": repr(e), "verified": {"ok": False}}
         torch.cuda.empty_cache()

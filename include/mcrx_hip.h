@@ -74,9 +74,13 @@ typedef struct {
     uint32_t front_end;          /* 0 = the reference's analysis bank: critically sampled firpfbch, 2N channels, lower N kept
                                     (lib/multichannelrx.cc:89-91).  1 = the oversampled bank BASELINE.json names: firpfbch2 with 2N
                                     channels (twice the channel rate, prototype cut off at the neighbour's centre) followed per kept
-                                    channel by a half-band decimator back to the channel rate -- less aliasing at the channel edges,
-                                    24 + 12 instead of 12 algorithmic bytes per sample; execute_host / execute_device only (power-of-two
-                                    channel counts) */
+                                    channel by a half-band decimator back to the channel rate -- less aliasing at the channel edges.
+                                    Oscillator, bank and decimator run as ONE kernel (the chain is a critically sampled bank with a
+                                    28-tap composite prototype per column: csrc/channelizer.hip): 12 algorithmic bytes per sample like
+                                    front_end = 0, 27 blocks of filter history instead of 13 (mcrx_hip_history_blocks).
+                                    2 = the same chain stage by stage (oscillator pass, bank at twice the rate, adapter: three kernels,
+                                    52 bytes per sample) -- the form the oracle computes, kept as the cross-check of 1; execute_host /
+                                    execute_device only.  Power-of-two channel counts for 1 and 2 */
     uint32_t skip_framesyms;     /* 1 = harvests leave the equalised symbols in HBM (frames report num_framesyms = 0): 1.2 KB
                                     instead of 59 KB per frame over the host link at the benchmark's frame size; 2 = the payload workers
                                     of 64-subcarrier symbols do not even store them (a third of the bytes that stage moves): for callers
@@ -165,7 +169,8 @@ uint64_t mcrx_hip_frames_dropped(mcrx_hip_t q);
 
 /* ---- stage level (multi-GPU split, parity tests, benchmarks) ------------------------- */
 /* NCO + analysis bank on `nblocks` blocks of 2N samples.  `first_sample` is the absolute
- * index of d_iq[0] (NCO phase); d_halo holds the (2m-1)=13 blocks preceding d_iq (NULL = zeros).
+ * index of d_iq[0] (NCO phase); d_halo holds the mcrx_hip_history_blocks() blocks preceding d_iq -- 13 = 2m - 1 for the
+ * reference's bank, 27 for front_end = 1 -- (NULL = zeros).
  * Output layout: out[g][tile][c][MCRX_TILE] cf32 with channel = g*(N/groups)+c,
  * tile = block / MCRX_TILE; nblocks must be a multiple of MCRX_TILE. */
 int  mcrx_hip_channelize(mcrx_hip_t q, const void *d_iq, size_t nblocks, uint64_t first_sample,
@@ -182,6 +187,7 @@ int  mcrx_hip_restart(mcrx_hip_t q, void *stream);
 /* design data, for parity tests against the oracle */
 int  mcrx_hip_get_taps(mcrx_hip_t q, float *h, size_t n);             /* p*K prototype taps */
 uint32_t mcrx_hip_nco_step(mcrx_hip_t q);                             /* 32-bit phase increment */
+unsigned mcrx_hip_history_blocks(mcrx_hip_t q);                       /* blocks of 2N samples of filter history in front of a push: 13 (27: front_end = 1) */
 int  mcrx_hip_kernel_time_ms(mcrx_hip_t q, float *channelizer_ms, float *sync_ms); /* last launches */
 /* summed HIP-event durations [ms] and launch counts since the last reset of the statistics, per
  * kernel: [0] channelizer_kernel, [1] sync_kernel (per-channel scout), [2] place_jobs_kernel,

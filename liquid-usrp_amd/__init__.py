@@ -82,6 +82,7 @@ _EXPORTS = {
     "mcrx_hip_restart": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mcrx_hip_get_taps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "mcrx_hip_nco_step": (C.c_uint32, [C.c_void_p]),
+    "mcrx_hip_history_blocks": (C.c_uint, [C.c_void_p]),
     "mcrx_hip_kernel_time_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "mcrx_hip_kernel_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
     "mcrx_hip_last_error": (C.c_char_p, []),
@@ -333,6 +334,10 @@ class multichannelrx(object):
 
     def nco_step(self):
         return int(lib().mcrx_hip_nco_step(self._h))
+
+    def history_blocks(self):
+        """Blocks of 2N samples of filter history the analysis bank needs in front of a push (13; 27 with front_end = 1)."""
+        return int(lib().mcrx_hip_history_blocks(self._h))
 
     def channelize(self, d_iq, nblocks, first_sample, d_out, groups=1, d_halo=None, stream=None):
         _check(lib().mcrx_hip_channelize(self._h, _dptr(d_iq), nblocks, first_sample, _dptr(d_halo),

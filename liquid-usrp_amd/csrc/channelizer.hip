@@ -27,9 +27,23 @@
 // xGMI all-to-all needs.  A round of 8 blocks fills one half of every granule; the next round of the same
 // workgroup fills the other (slabs are whole tiles), so the halves meet in that XCD's L2.
 // HBM-bound by design: 8 B read + 4 B written per wideband sample.
+//
+// Round 6: the kernel is a template of the taps per column P, and the oversampled front end (cfg.front_end = 1: liquid's
+// firpfbch2 analysis bank, 2N channels at twice the channel rate, + a half-band decimator per kept channel) runs through it
+// too.  That chain is linear and, per kept channel, time invariant at the block rate, so it IS a critically sampled
+// polyphase bank: out_k[c] = FFT_K( V_k[(n - s) mod K] )[c],  V_k[n] = sum_{d < 28} G[n][d] u[(k - d) K + n],  s = K/2 + 1,
+// with the composite taps G = (both phases of the firpfbch2 prototype, the even steps convolved with the half-band branch
+// filter, the odd step delayed by seven blocks; design.hpp: pfb2_composite_taps) -- ONE transform per block instead of
+// two, no rate-2 intermediate in HBM, the same 12 algorithmic bytes per wideband sample as the reference's bank instead of
+// 8 + 8 (oscillator pass) + 8 + 16 (bank at rate 2) + 8 + 4 (adapter) = 52 over three kernels.  The rotation by s is where a
+// column's FIR output lands in the LDS tile; the taps of 1024 columns x 28 do not fit LDS beside the tile (112 + 68 KB), so
+// the newest TL = 22 of every column live in LDS and the oldest six come from a table in L2 at the start of every round.
 #include "devel.h"
 #include "devmath.h"
 #include "kernels.h"
+
+#include <atomic>
+#include <mutex>
 
 namespace mcrx {
 
@@ -42,8 +56,11 @@ namespace mcrx {
 #endif
 #define CH_R 8          // blocks per round == half a (channel, tile) granule
 static_assert(MCRX_TILE_S == 2 * CH_R, "two rounds fill one granule");
-#define CH_P 14         // taps per branch (m = 7)
-#define CH_H (CH_P - 1) // history blocks
+#define CH_P_REF 14     // taps per column of the reference's bank (m = 7)
+#ifndef CH_RH
+#define CH_RH 4         // outputs of a round the many-tap FIR forms per pass over the taps
+#endif
+#define CH_P_OVS 28     // ... of the composite bank of the oversampled front end (14 + 14 - 1 through the half-band branch, one more for the half-block offset)
 
 // Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain
 // vmcnt, so the prefetched IQ loads and the granule stores stay in flight across it.
@@ -106,24 +123,38 @@ __device__ __forceinline__ void fft_reg(float2 (&v)[F])
                 const int tk = (i & (h - 1)) * (8 / h);       // W_{2h}^{i mod h} as a power of W_16
                 if (tk == 0) v[i + h] = d;
                 else if (tk == 4) v[i + h] = cmulnj(d);
-                else v[i + h] = cmul(d, w16(tk));
+                else v[i + h] = cmul_fx(d, w16(tk));
             }
         }
     }
 }   // result: v[i] holds X[bitrev(i)]; callers store v[i] at index bitrev_c(i, log2 F)
 
+// Geometry of one instantiation: slabs per workgroup, the LDS tile, and how many of a column's P taps live in LDS (the newest
+// TL; the older ones are fetched from the tap table -- L2 -- when a round starts).  160 KB of LDS per workgroup.
+template <int K, int C, int T, int P> struct Geo {
+    enum { TPS = K / C, NS = T / TPS, TILE_F2 = NS * CH_R * Plan<K>::ROWP };
+    static constexpr int taps_in_lds() { const long room = (160l * 1024 - (long)TILE_F2 * 8) / (4l * K); return room >= P ? P : (int)room; }
+    enum { TL = taps_in_lds() };
+    static constexpr size_t lds_bytes() { return (size_t)TILE_F2 * sizeof(float2) + (size_t)TL * K * sizeof(float); }
+};
+
 // EDGE = false: every block the workgroup touches (history, the slabs, the prefetch past the last round) lies inside
 // the stream, so loads need no clamping, the oscillator no zeroing and the stores no guard -- all but the first and the
 // last workgroup of a launch.  Addresses that do not change from round to round (the butterflies' LDS positions, the
 // granule stores' LDS sources and HBM destinations) are computed once per launch, not once per use.
-template <int K, int C, int T, bool EDGE>
+// P = taps per column: a.taps is the column tap table tap[j][n], j = 0 the newest block's tap, P * K floats.
+// SHIFT: column n's FIR output goes to tile column (n + a.col_shift) mod K (the oversampled front end's rotation).
+template <int K, int C, int T, int P, bool SHIFT, bool EDGE>
 __device__ __forceinline__ void channelizer_rounds(const ChanArgs &a, float2 *tile)
 {
     constexpr int TPS = K / C;              // threads per slab
     constexpr int NS = T / TPS;             // slabs per workgroup
     constexpr int N = K / 2;
+    constexpr int H = P - 1;                // history blocks
+    constexpr int TL = Geo<K, C, T, P>::TL, TG = P - TL;     // taps per column in LDS / fetched per round
     constexpr int S = Plan<K>::S, F = Plan<K>::F, ROWP = Plan<K>::ROWP, R = Plan<K>::R, LR = Plan<K>::LR;
     static_assert(TPS * C == K && NS * TPS == T && NS >= 1, "bad channelizer geometry");
+    static_assert(TL >= 1 && TG >= 0 && TG <= 8, "tap split");
 
     const int tid = threadIdx.x;
     const int sl = tid / TPS, cg = tid % TPS;
@@ -131,12 +162,12 @@ __device__ __forceinline__ void channelizer_rounds(const ChanArgs &a, float2 *ti
     const long long slab = (long long)blockIdx.x * NS + sl;
     const long long bs = slab * (long long)a.slab_blocks;        // first block of my slab
 
-    // taps: tap[j][c] = h[K-1-n + j*K].  They live in LDS (p*K floats behind the tile) and are
+    // taps: tap[j][c] = column n0+c's tap on the block j back.  They live in LDS (TL*K floats behind the tile) and are
     // fetched into registers for the FIR of each round only: across the FFT stages the registers
     // hold the sliding window plus the next round's blocks that are already in flight.
     float *ltap = reinterpret_cast<float *>(tile + NS * CH_R * ROWP);
     {
-        constexpr int NT = CH_P * K;                 // all requests first, then the LDS writes: one round trip
+        constexpr int NT = TL * K;                  // all requests first, then the LDS writes: one round trip
         constexpr int PER = (NT + T - 1) / T;
         float tv[PER];
 #pragma unroll
@@ -173,7 +204,7 @@ __device__ __forceinline__ void channelizer_rounds(const ChanArgs &a, float2 *ti
             const bool inx = b >= 0 && b < (long long)a.nblocks;
             const bool inh = b < 0 && a.halo != nullptr;
             if (inx) src = a.x + (size_t)b * K + n0;
-            if (inh) src = a.halo + (size_t)(b + CH_H) * K + n0;
+            if (inh) src = a.halo + (size_t)(b + H) * K + n0;
         } else src = a.x + (size_t)b * K + n0;
         // the value is not touched here (that would wait for it): the mixer zeroes blocks outside the stream
         if constexpr (C == 2) {
@@ -212,24 +243,28 @@ __device__ __forceinline__ void channelizer_rounds(const ChanArgs &a, float2 *ti
         }
     };
 
-    // s[0..12] history (oldest first), s[13..20] the round's new blocks.  The new blocks of
-    // round r+1 are requested into s[13..20] right after round r's FIR has consumed them, so
+    // s[0..H-1] history (oldest first), s[H..H+7] the round's new blocks.  The new blocks of
+    // round r+1 are requested into s[H..H+7] right after round r's FIR has consumed them, so
     // the HBM latency hides under the FFT stages; they are mixed in place when the round starts.
-    float2 s[CH_H + CH_R][C];
+    float2 s[H + CH_R][C];
     // (slabs past the end of the stream run on clamped addresses and zeros; their stores are masked.
     //  Keeping this straight-line matters: a load under a branch is waited for at the join.)
 #pragma unroll
-    for (int i = 0; i < CH_H + CH_R; i++) load_raw(bs - CH_H + i, s[i]);
-    {   // the history blocks bs-13 .. bs-1 sit in the groups starting at bs-16 (positions 3..7) and bs-8 (0..7)
-        static_assert(CH_H == 13 && CH_R == 8, "history walk below assumes 13 history blocks and groups of 8");
-        float sn, cs;
-        osc_start(bs - 16, sn, cs);
-        osc_next_block(sn, cs); osc_next_block(sn, cs); osc_next_block(sn, cs);
+    for (int i = 0; i < H + CH_R; i++) load_raw(bs - H + i, s[i]);
+    {   // the history blocks bs-H .. bs-1 sit in the groups of 8 starting at bs - 8 HG, ..., bs - 8 (the first one from position HSKIP on)
+        constexpr int HG = (H + CH_R - 1) / CH_R, HSKIP = HG * CH_R - H;
+        static_assert(CH_R == 8, "groups of 8");
+        int i = 0;
 #pragma unroll
-        for (int i = 0; i < 5; i++) { mix_with(bs - 13 + i, sn, cs, s[i]); osc_next_block(sn, cs); }
-        osc_start(bs - 8, sn, cs);
+        for (int g = 0; g < HG; g++) {
+            float sn, cs;
+            osc_start(bs - (long long)CH_R * (HG - g), sn, cs);
 #pragma unroll
-        for (int i = 5; i < 13; i++) { mix_with(bs - 13 + i, sn, cs, s[i]); osc_next_block(sn, cs); }
+            for (int k = 0; k < CH_R; k++) {
+                if (g > 0 || k >= HSKIP) { mix_with(bs - H + i, sn, cs, s[i]); i++; }
+                osc_next_block(sn, cs);
+            }
+        }
     }
 
     // ---- round-invariant addresses
@@ -241,11 +276,13 @@ __device__ __forceinline__ void channelizer_rounds(const ChanArgs &a, float2 *ti
     static_assert(NOPS % T == 0, "granule stores per thread");
     constexpr int BTRIPS = S > 0 ? NBF4 / T : 0, BSTEP = S > 0 ? (T / (K / R)) * ROWP : 0;
     int fa[S > 0 ? S : 1];                              // padded LDS index of a butterfly's first element, trip 0
+    if constexpr (S > 0) {
 #pragma unroll
-    for (int st = 0; st < S; st++) {
-        const int L = K >> (LR * st), q4 = L >> LR;
-        const int f = tid / (K / R), j = tid % (K / R);
-        fa[st] = f * ROWP + pad<K>((j / q4) * L + j % q4);
+        for (int st = 0; st < S; st++) {
+            const int L = K >> (LR * st), q4 = L >> LR;
+            const int f = tid / (K / R), j = tid % (K / R);
+            fa[st] = f * ROWP + pad<K>((j / q4) * L + j % q4);
+        }
     }
     constexpr int GTRIPS = (NG + T - 1) / T;
     int fg[GTRIPS];
@@ -269,45 +306,104 @@ __device__ __forceinline__ void channelizer_rounds(const ChanArgs &a, float2 *ti
     }
     const uint32_t tile_step = a.cg * (MCRX_TILE_S / 2);     // 16-byte units between consecutive tiles of a channel group
     float4 *out4 = reinterpret_cast<float4 *>(a.out);
+    int wcol[C];                                        // where my columns' FIR outputs go in a tile row (padded index)
+#pragma unroll
+    for (int c = 0; c < C; c++) wcol[c] = pad<K>(SHIFT ? (int)((n0 + c + a.col_shift) & (K - 1)) : n0 + c);
 
     const int rounds = a.slab_blocks / CH_R;
     for (int rd = 0; rd < rounds; rd++) {
         const long long b0 = bs + (long long)rd * CH_R;
-        float tap[CH_P][C];
+        float tg[TG > 0 ? TG : 1][C];                   // the column's oldest taps, from the table (L2): requested before the mixer, used first
 #pragma unroll
-        for (int j = 0; j < CH_P; j++)
+        for (int j = 0; j < TG; j++)
 #pragma unroll
-            for (int c = 0; c < C; c++) tap[j][c] = ltap[(K - 1 - (n0 + c)) + j * K];
-        {
-            float sn, cs;
-            osc_start(b0, sn, cs);
+            for (int c = 0; c < C; c++) tg[j][c] = a.taps[(size_t)(TL + j) * K + n0 + c];
+        if constexpr (P <= CH_P_REF) {
+            float tap[P][C];
 #pragma unroll
-            for (int r = 0; r < CH_R; r++) { mix_with(b0 + r, sn, cs, s[CH_H + r]); osc_next_block(sn, cs); }
-        }
+            for (int j = 0; j < P; j++)
 #pragma unroll
-        for (int r = 0; r < CH_R; r++) {
-            float2 v[C];
+                for (int c = 0; c < C; c++) tap[j][c] = ltap[j * K + n0 + c];
+            {
+                float sn, cs;
+                osc_start(b0, sn, cs);
 #pragma unroll
-            for (int c = 0; c < C; c++) v[c] = make_float2(0.f, 0.f);
+                for (int r = 0; r < CH_R; r++) { mix_with(b0 + r, sn, cs, s[H + r]); osc_next_block(sn, cs); }
+            }
 #pragma unroll
-            for (int j = CH_P - 1; j >= 0; j--) {           // oldest tap first, like a window dot product
+            for (int r = 0; r < CH_R; r++) {
+                float2 v[C];
 #pragma unroll
-                for (int c = 0; c < C; c++) {
-                    v[c].x += tap[j][c] * s[CH_H + r - j][c].x;
-                    v[c].y += tap[j][c] * s[CH_H + r - j][c].y;
+                for (int c = 0; c < C; c++) v[c] = make_float2(0.f, 0.f);
+#pragma unroll
+                for (int j = P - 1; j >= 0; j--) {              // oldest tap first, like a window dot product
+#pragma unroll
+                    for (int c = 0; c < C; c++) {
+                        v[c].x += tap[j][c] * s[H + r - j][c].x;
+                        v[c].y += tap[j][c] * s[H + r - j][c].y;
+                    }
+                }
+                float2 *row = tile + (sl * CH_R + r) * ROWP;
+                if constexpr (SHIFT) {
+#pragma unroll
+                    for (int c = 0; c < C; c++) row[wcol[c]] = v[c];
+                } else {
+                    float2 *rw = row + pad<K>(n0);              // n0, n0+1 share a pad group
+#pragma unroll
+                    for (int c = 0; c < C; c++) rw[c] = v[c];
                 }
             }
-            float2 *row = tile + (sl * CH_R + r) * ROWP + pad<K>(n0);    // n0, n0+1 share a pad group
+        } else {
+            // many taps: the eight outputs of the round accumulate side by side, one tap (from LDS, or of the fetched ones) at a time,
+            // oldest first -- the taps never sit in registers all at once
+            {
+                float sn, cs;
+                osc_start(b0, sn, cs);
 #pragma unroll
-            for (int c = 0; c < C; c++) row[c] = v[c];
+                for (int r = 0; r < CH_R; r++) { mix_with(b0 + r, sn, cs, s[H + r]); osc_next_block(sn, cs); }
+            }
+            // (CH_RH outputs per pass: the accumulators of all eight at once cost 16 more registers than the kernel has)
+#pragma unroll
+            for (int rh = 0; rh < CH_R; rh += CH_RH) {
+                float2 v[CH_RH][C];
+#pragma unroll
+                for (int r = 0; r < CH_RH; r++)
+#pragma unroll
+                    for (int c = 0; c < C; c++) v[r][c] = make_float2(0.f, 0.f);
+#pragma unroll
+                for (int j = P - 1; j >= 0; j--) {
+                    float tj[C];
+#pragma unroll
+                    for (int c = 0; c < C; c++) tj[c] = j >= TL ? tg[j - TL][c] : ltap[j * K + n0 + c];
+#pragma unroll
+                    for (int r = 0; r < CH_RH; r++)
+#pragma unroll
+                        for (int c = 0; c < C; c++) {
+                            v[r][c].x += tj[c] * s[H + rh + r - j][c].x;
+                            v[r][c].y += tj[c] * s[H + rh + r - j][c].y;
+                        }
+                }
+#pragma unroll
+                for (int r = 0; r < CH_RH; r++) {
+                    float2 *row = tile + (sl * CH_R + rh + r) * ROWP;
+                    if constexpr (SHIFT) {
+#pragma unroll
+                        for (int c = 0; c < C; c++) row[wcol[c]] = v[r][c];
+                    } else {
+                        float2 *rw = row + pad<K>(n0);
+#pragma unroll
+                        for (int c = 0; c < C; c++) rw[c] = v[r][c];
+                    }
+                }
+            }
         }
 #pragma unroll
-        for (int i = 0; i < CH_H; i++)
+        for (int i = 0; i < H; i++)
 #pragma unroll
             for (int c = 0; c < C; c++) s[i][c] = s[i + CH_R][c];
         // next round's blocks (past the slab's last round: clamped, never used)
 #pragma unroll
-        for (int r = 0; r < CH_R; r++) load_raw(b0 + CH_R + r, s[CH_H + r]);
+        for (int r = 0; r < CH_R; r++) load_raw(b0 + CH_R + r, s[H + r]);
         lds_barrier();
 
         // ---- NS*CH_R independent K-point FFTs, in place
@@ -326,15 +422,15 @@ __device__ __forceinline__ void channelizer_rounds(const ChanArgs &a, float2 *ti
                         fft_reg<8>(v);                  // v[m] = X[bitrev(m)]
                         p[0] = v[0];
 #pragma unroll
-                        for (int r = 1; r < 8; r++) p[r * D] = cmul(v[bitrev_c(r, 3)], tw[st][r - 1]);
+                        for (int r = 1; r < 8; r++) p[r * D] = cmul_fx(v[bitrev_c(r, 3)], tw[st][r - 1]);
                         continue;
                     }
                     const float2 x0 = p[0], x1 = p[D], x2 = p[2 * D], x3 = p[3 * D];
                     const float2 a0 = cadd(x0, x2), a1 = csub(x0, x2), a2 = cadd(x1, x3), a3 = cmulnj(csub(x1, x3));
                     p[0] = cadd(a0, a2);
-                    p[D] = cmul(cadd(a1, a3), tw[st][0]);
-                    p[2 * D] = cmul(csub(a0, a2), tw[st][1]);
-                    p[3 * D] = cmul(csub(a1, a3), tw[st][2]);
+                    p[D] = cmul_fx(cadd(a1, a3), tw[st][0]);
+                    p[2 * D] = cmul_fx(csub(a0, a2), tw[st][1]);
+                    p[3 * D] = cmul_fx(csub(a1, a3), tw[st][2]);
                 }
                 lds_barrier();
             }
@@ -375,35 +471,50 @@ __device__ __forceinline__ void channelizer_rounds(const ChanArgs &a, float2 *ti
     }
 }
 
-template <int K, int C, int T>
+template <int K, int C, int T, int P, bool SHIFT>
 __global__ __launch_bounds__(T) void channelizer_kernel(ChanArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) float2 tile[];     // [NS][CH_R][ROWP]
-    constexpr int NS = T / (K / C);
+    extern __shared__ __attribute__((aligned(16))) float2 tile[];     // [NS][CH_R][ROWP], then the taps in LDS
+    constexpr int NS = T / (K / C), H = P - 1;
     const long long s0 = (long long)blockIdx.x * NS;
-    const long long first = s0 * (long long)a.slab_blocks - CH_H, last = (s0 + NS) * (long long)a.slab_blocks + CH_R;
-    if (first >= 0 && last <= (long long)a.nblocks) channelizer_rounds<K, C, T, false>(a, tile);
-    else channelizer_rounds<K, C, T, true>(a, tile);
+    const long long first = s0 * (long long)a.slab_blocks - H, last = (s0 + NS) * (long long)a.slab_blocks + CH_R;
+    if (first >= 0 && last <= (long long)a.nblocks) channelizer_rounds<K, C, T, P, SHIFT, false>(a, tile);
+    else channelizer_rounds<K, C, T, P, SHIFT, true>(a, tile);
 }
-template <int K, int C, int T>
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: done once per (kernel, device), under a lock -- a host that opens
+// handles on several GPUs from one process must not skip it on devices 1..7
+static hipError_t raise_lds_limit(const void *fn, size_t lds, std::atomic<uint64_t> &done_mask)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done_mask.load(std::memory_order_acquire) & bit) return hipSuccess;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (done_mask.load(std::memory_order_relaxed) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    done_mask.fetch_or(bit, std::memory_order_release);
+    return hipSuccess;
+}
+
+template <int K, int C, int T, int P, bool SHIFT>
 static hipError_t launch_one(const ChanArgs &a, hipStream_t st)
 {
     constexpr int NS = T / (K / C);
-    size_t lds = (size_t)(NS * CH_R * Plan<K>::ROWP) * sizeof(float2) + (size_t)CH_P * K * sizeof(float);
+    const size_t lds = Geo<K, C, T, P>::lds_bytes();
     long long nslabs = ((long long)a.nblocks + a.slab_blocks - 1) / a.slab_blocks;
     unsigned grid = (unsigned)((nslabs + NS - 1) / NS);
     if (grid == 0) return hipSuccess;
     // granule stores are addressed by 32-bit offsets in 16-byte units: 64 GB of output per launch
     if ((unsigned long long)(K / 2) * ((unsigned long long)a.ntiles + (unsigned long long)NS * a.slab_blocks / MCRX_TILE_S + 1ull) * (MCRX_TILE_S / 2) >= (1ull << 32))
         return hipErrorInvalidValue;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)channelizer_kernel<K, C, T>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((channelizer_kernel<K, C, T>), dim3(grid), dim3(T), lds, st, a);
+    static std::atomic<uint64_t> attr_done{0};
+    hipError_t e = raise_lds_limit((const void *)channelizer_kernel<K, C, T, P, SHIFT>, lds, attr_done);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((channelizer_kernel<K, C, T, P, SHIFT>), dim3(grid), dim3(T), lds, st, a);
     return hipGetLastError();
 }
 
@@ -414,6 +525,8 @@ static hipError_t launch_one(const ChanArgs &a, hipStream_t st)
 // direct DFT of the kept bins with an exact integer twiddle index.  A fallback for odd sizes, O(K N) per block:
 // the power-of-two kernel above is the product's fast path.
 #define CG_T 256
+#define CH_P CH_P_REF
+#define CH_H (CH_P_REF - 1)
 __global__ __launch_bounds__(CG_T) void channelizer_generic_kernel(ChanArgs a, uint32_t K)
 {
     extern __shared__ __attribute__((aligned(16))) float2 gl[];        // V[CH_R][K], then W[K]
@@ -443,7 +556,7 @@ __global__ __launch_bounds__(CG_T) void channelizer_generic_kernel(ChanArgs a, u
             for (int r = 0; r < CH_R; r++) {
                 const int j = CH_H + r - i;                             // tap branch this block is for row r
                 if (j >= 0 && j < CH_P) {
-                    const float h = a.taps[(K - 1 - n) + (uint32_t)j * K];
+                    const float h = a.taps[(uint32_t)j * K + n];                // column tap table
                     acc[r].x += h * u.x; acc[r].y += h * u.y;
                 }
             }
@@ -494,8 +607,24 @@ uint32_t channelizer_auto_slab(unsigned K, size_t nblocks, unsigned ncu)
     return (uint32_t)slab;
 }
 
-hipError_t channelizer_launch(unsigned K, const ChanArgs &a, hipStream_t st)
+hipError_t channelizer_launch(unsigned K, unsigned P, const ChanArgs &a, hipStream_t st)
 {
+    if (P == CH_P_OVS) {                    // the composite bank of the oversampled front end: power-of-two channel counts only
+        switch (K) {
+        case 2:    return launch_one<2, 1, 256, CH_P_OVS, true>(a, st);
+        case 4:    return launch_one<4, 2, 256, CH_P_OVS, true>(a, st);
+        case 8:    return launch_one<8, 2, 256, CH_P_OVS, true>(a, st);
+        case 16:   return launch_one<16, 2, 256, CH_P_OVS, true>(a, st);
+        case 32:   return launch_one<32, 2, 256, CH_P_OVS, true>(a, st);
+        case 64:   return launch_one<64, 2, 256, CH_P_OVS, true>(a, st);
+        case 128:  return launch_one<128, 2, 256, CH_P_OVS, true>(a, st);
+        case 256:  return launch_one<256, 2, 256, CH_P_OVS, true>(a, st);
+        case 512:  return launch_one<512, 2, 512, CH_P_OVS, true>(a, st);     // (two slabs per workgroup: with 256 threads the taps + tile would leave one wave per SIMD)
+        case 1024: return launch_one<1024, 2, 512, CH_P_OVS, true>(a, st);
+        default:   return hipErrorInvalidValue;
+        }
+    }
+    if (P != CH_P_REF) return hipErrorInvalidValue;
     if (!pow2_fast(K)) {
         if (a.nblocks == 0) return hipSuccess;
         const size_t lds = (size_t)(CH_R + 1) * K * sizeof(float2);
@@ -505,17 +634,17 @@ hipError_t channelizer_launch(unsigned K, const ChanArgs &a, hipStream_t st)
         return hipGetLastError();
     }
     switch (K) {
-    case 2:    return launch_one<2, 1, 256>(a, st);
-    case 4:    return launch_one<4, 2, 256>(a, st);
-    case 8:    return launch_one<8, 2, 256>(a, st);
-    case 16:   return launch_one<16, 2, 256>(a, st);
-    case 32:   return launch_one<32, 2, 256>(a, st);
-    case 64:   return launch_one<64, 2, 256>(a, st);
-    case 128:  return launch_one<128, 2, 256>(a, st);
-    case 256:  return launch_one<256, 2, 256>(a, st);
-    case 512:  return launch_one<512, 2, 256>(a, st);
+    case 2:    return launch_one<2, 1, 256, CH_P_REF, false>(a, st);
+    case 4:    return launch_one<4, 2, 256, CH_P_REF, false>(a, st);
+    case 8:    return launch_one<8, 2, 256, CH_P_REF, false>(a, st);
+    case 16:   return launch_one<16, 2, 256, CH_P_REF, false>(a, st);
+    case 32:   return launch_one<32, 2, 256, CH_P_REF, false>(a, st);
+    case 64:   return launch_one<64, 2, 256, CH_P_REF, false>(a, st);
+    case 128:  return launch_one<128, 2, 256, CH_P_REF, false>(a, st);
+    case 256:  return launch_one<256, 2, 256, CH_P_REF, false>(a, st);
+    case 512:  return launch_one<512, 2, 256, CH_P_REF, false>(a, st);
     case 1024: { static const int c1 = devel_env("MCRX_CHAN_C1") ? atoi(devel_env("MCRX_CHAN_C1")) : 0;
-                 return c1 ? launch_one<1024, 1, 1024>(a, st) : launch_one<1024, 2, 512>(a, st); }
+                 return c1 ? launch_one<1024, 1, 1024, CH_P_REF, false>(a, st) : launch_one<1024, 2, 512, CH_P_REF, false>(a, st); }
     default:   return hipErrorInvalidValue;
     }
 }

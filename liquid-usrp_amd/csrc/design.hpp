@@ -73,6 +73,53 @@ inline std::vector<float> pfb2_prototype(unsigned M, unsigned m, float As)
     return h;
 }
 
+// ---- column tap tables of channelizer.hip: tap[j][n] = column n's tap on the block j back (j = 0: the newest block)
+// the reference's bank (firpfbch analyzer, lib/multichannelrx.cc:89-91): V_b[n] = sum_j h[K-1-n + j K] u[(b-j) K + n]
+inline std::vector<float> pfb_column_taps(const std::vector<float> &h, unsigned K)
+{
+    const unsigned P = (unsigned)(h.size() / K);
+    std::vector<float> t((size_t)P * K);
+    for (unsigned j = 0; j < P; j++)
+        for (unsigned n = 0; n < K; n++) t[(size_t)j * K + n] = h[(size_t)(K - 1 - n) + (size_t)j * K];
+    return t;
+}
+// half-band branch filter of liquid's resamp2_crcf (m = 7): the odd taps of a 29-tap Kaiser design, reversed
+inline std::vector<float> halfband_branch_taps(unsigned m, float As)
+{
+    const unsigned n = 4 * m + 1;
+    std::vector<float> hh = firdes_kaiser(n, 0.25f, As), h1(2 * m);
+    unsigned j = 0;
+    for (unsigned i = 1; i < n; i += 2) h1[j++] = hh[n - i - 1];
+    return h1;
+}
+// The oversampled front end as ONE critically sampled bank (cfg.front_end = 1; channelizer.hip's header).  With M = 2N channels,
+// h = the firpfbch2 prototype (14 M taps), h1 = the half-band branch filter, the chain
+//     Z_s[r] = sum_{j<14} h[r + j M] u[(s+1) M/2 - 1 - r - j M],   Y_s[c] = (-1)^(c s) / M  sum_r Z_s[r] e^{+j 2 pi r c / M}
+//     out_k[c] = 0.5 ( Y_{2k-13}[c] + sum_{i<14} h1[i] Y_{2(k-13+i)}[c] )                                   (c < N)
+// is, because the half-band filter acts along time and the transform along r and (-1)^c e^{j 2 pi r c / M} = e^{j 2 pi (r + M/2) c / M},
+//     out_k[c] = sum_r W_k[r] e^{+j 2 pi r c / M},   W_k[r] = 0.5 / M ( sum_i h1[i] Z_{2(k-13+i)}[r] + Z_{2k-13}[(r - M/2) mod M] ).
+// Both terms of W_k[r] read column n = (M/2 - 1 - r) mod M of the blocks k, k-1, ..., k-27:  W_k[r] = sum_{d<28} G[n][d] u[(k-d) M + n],
+// and e^{+j 2 pi r c / M} = e^{-j 2 pi (n + M/2 + 1) c / M}: a forward transform of the columns rotated by M/2 + 1.
+// Taps are formed in double from the float prototypes the stage-by-stage chain uses and rounded once; 0.5 / M is a power of two.
+// Returns tap[d][n], 28 * M floats.  (scratch/r6/composite_check.py holds the same algebra against the oracle's chain.)
+inline std::vector<float> pfb2_composite_taps(const std::vector<float> &h, const std::vector<float> &h1, unsigned M)
+{
+    const unsigned P = 14, PC = 28;
+    std::vector<double> G((size_t)PC * M, 0.0);
+    for (unsigned r = 0; r < M; r++) {
+        const unsigned n = (M / 2 - 1 - r + M) % M, up = r >= M / 2 ? 1u : 0u;
+        for (unsigned i = 0; i < P; i++)
+            for (unsigned j = 0; j < P; j++)
+                G[(size_t)(13 - i + j + up) * M + n] += (double)h1[i] * (double)h[r + (size_t)j * M];
+        const unsigned rp = (r + M - M / 2) % M;
+        for (unsigned j = 0; j < P; j++) G[(size_t)(7 + j) * M + n] += (double)h[rp + (size_t)j * M];
+    }
+    std::vector<float> t((size_t)PC * M);
+    const double g = 0.5 / (double)M;
+    for (size_t i = 0; i < t.size(); i++) t[i] = (float)(G[i] * g);
+    return t;
+}
+
 // ---------------------------------------------------------------- NCO
 inline uint32_t rad2u32(float rad)
 {

@@ -13,6 +13,11 @@ __device__ __forceinline__ cfd cadd(cfd a, cfd b) { return make_float2(a.x + b.x
 __device__ __forceinline__ cfd csub(cfd a, cfd b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ cfd cmul(cfd a, cfd b)
 { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// the same with the roundings pinned (explicit fma shape): the compiler contracts cmul's a.x b.x - a.y b.y either way round, per inlined copy --
+// two unrolled copies of one butterfly can differ in the last bit.  Where a value must not depend on WHICH copy computed it (the
+// channelizer's transform: a block lands in different tile rows when a stream is cut differently) use this one.
+__device__ __forceinline__ cfd cmul_fx(cfd a, cfd b)
+{ return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x)); }
 __device__ __forceinline__ cfd cmulc(cfd a, cfd b)      // a * conj(b)
 { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
 __device__ __forceinline__ cfd cscale(cfd a, float g) { return make_float2(a.x * g, a.y * g); }

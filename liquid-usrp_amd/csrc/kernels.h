@@ -14,8 +14,8 @@ namespace mcrx {
 // ---------------------------------------------------------------- channelizer.hip
 struct ChanArgs {
     const float2 *x;            // new wideband samples, nblocks * K
-    const float2 *halo;         // 13 blocks preceding x (NULL = zeros: cold start)
-    const float *taps;          // p*K prototype taps
+    const float2 *halo;         // the P - 1 blocks preceding x (NULL = zeros: cold start)
+    const float *taps;          // column tap table tap[j][n]: column n's tap on the block j back (j = 0: the newest), P * K floats
     float2 *out;                // out[g][tile][c][16]
     uint32_t nblocks;           // blocks in x (multiple of 16)
     uint32_t slab_blocks;       // blocks per slab (multiple of 16)
@@ -23,11 +23,13 @@ struct ChanArgs {
     uint32_t dtheta;            // NCO phase increment per sample
     uint32_t ntiles;            // tiles per group in `out`
     uint32_t cg;                // channels per group
+    uint32_t col_shift;         // P = 28 (oversampled front end): column n's FIR output is transform input (n + col_shift) mod K
 };
 int channelizer_supported(unsigned K);
 // blocks per workgroup slab such that the grid is a whole number of waves over `ncu` compute units
 uint32_t channelizer_auto_slab(unsigned K, size_t nblocks, unsigned ncu);
-hipError_t channelizer_launch(unsigned K, const ChanArgs &a, hipStream_t st);
+// P = taps per column: 14 = the reference's bank (any even K <= 2048), 28 = the oversampled front end's composite bank (power-of-two K <= 1024)
+hipError_t channelizer_launch(unsigned K, unsigned P, const ChanArgs &a, hipStream_t st);
 
 // ---------------------------------------------------------------- ofdmsync.hip
 // The two named deviations from liquid-dsp's ofdmframesync in the S1 stage -- the same

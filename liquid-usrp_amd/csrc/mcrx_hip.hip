@@ -19,7 +19,6 @@
 
 using namespace mcrx;
 
-#define HIST_BLOCKS 13      /* 2m - 1 blocks of FIR history (m = 7) */
 #define MCRX_SLOTS 8        /* most per-launch buffer sets (channel tiles, job list, per-job scratch); launch k uses slot k % nslots */
 #define MCRX_GENS 4         /* result generations (records + arenas), a ring: one fills while older ones are harvested or dropped */
 
@@ -76,7 +75,8 @@ __global__ void hist_update_kernel(const float2 *old_hist, const float2 *x, uint
     new_hist[i] = (pos < nh) ? old_hist[pos] : x[pos - nh];
 }
 
-// oversampled front end (cfg.front_end = 1): the oscillator as its own pass (the oversampled bank takes plain samples) ...
+// oversampled front end, stage by stage (cfg.front_end = 2; front_end = 1 is the same chain folded into channelizer_kernel): the
+// oscillator as its own pass (the oversampled bank takes plain samples) ...
 __global__ void nco_mix_kernel(const float2 *x, float2 *y, uint64_t n, uint32_t first_lo, uint32_t dtheta)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -208,7 +208,10 @@ struct mcrx_hip_s {
     float2 *h_stage = nullptr; size_t stage_cap = 0, stage_fill = 0;   // pinned host staging (samples)
     float2 *d_chan[MCRX_SLOTS] = {}; size_t chan_cap_tiles = 0;
     unsigned hist_tiles = 0; uint64_t defer = 0;
-    // oversampled front end (cfg.front_end = 1): the bank, its input (28 N samples of history in front) and output (32
+    // taps per column of the bank channelizer_kernel runs and the blocks of FIR history it needs in front of every push: 14 / 13 = the
+    // reference's firpfbch (m = 7), 28 / 27 = the oversampled front end folded into one bank (cfg.front_end = 1; channelizer.hip)
+    unsigned chan_P = 14, hist_blocks = 13, col_shift = 0;
+    // oversampled front end stage by stage (cfg.front_end = 2, the form the oracle runs; kept as the cross-check of front_end = 1): the bank, its input (28 N samples of history in front) and output (32
     // steps of history in front), both double buffered so that a push's history comes from the other buffer
     bool oversampled = false; mcrx_hip_pfb2_t pfb2 = nullptr; const float *d_h1 = nullptr;
     float2 *d_pfin[2] = { nullptr, nullptr }, *d_pfout[2] = { nullptr, nullptr }; size_t pf_cap_blocks = 0; int pf_cur = 0;
@@ -454,7 +457,7 @@ static int restart_async(mcrx_hip_t q, hipStream_t st, bool from_zero)
     // (both result generations: counters zeroed; the prediction lists only survive a Reset(), not a restart from zero)
     for (int g = 0; g < MCRX_GENS; g++) {
         HIPCHK(sync_reset_launch(q->d_st, q->nch, q->chan_samples, g == 0 ? q->d_hist[0] : nullptr, g == 0 ? q->d_hist[1] : nullptr,
-                                 (size_t)HIST_BLOCKS * q->K, q->d_nrec[g], q->d_arena_used[g],
+                                 (size_t)q->hist_blocks * q->K, q->d_nrec[g], q->d_arena_used[g],
                                  (from_zero && g == 0) ? q->d_pred_n : nullptr, st));
         q->gen_used[g] = false; q->gen_closed[g] = false; q->gen_abandoned[g] = false;
     }
@@ -524,8 +527,11 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     { int dev = 0, n = 0;
       if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
           q->ncu = (uint32_t)n; }
-    q->oversampled = !bypass && q->cfg.struct_size >= offsetof(mcrx_hip_config, front_end) + sizeof(uint32_t) && q->cfg.front_end == 1;
-    if (q->oversampled && ((q->K & (q->K - 1)) || q->K > 1024 || q->K < 2)) { delete q; return fail(MCRX_EUNSUPP, "the oversampled front end needs a power-of-two channel count <= 512"); }
+    const uint32_t front_end = (!bypass && q->cfg.struct_size >= offsetof(mcrx_hip_config, front_end) + sizeof(uint32_t)) ? q->cfg.front_end : 0;
+    if (front_end > 2) { delete q; return fail(MCRX_EINVAL, "front_end must be 0, 1 or 2"); }
+    q->oversampled = front_end == 2;
+    if (front_end && ((q->K & (q->K - 1)) || q->K > 1024 || q->K < 2)) { delete q; return fail(MCRX_EUNSUPP, "the oversampled front end needs a power-of-two channel count <= 512"); }
+    if (front_end == 1) { q->chan_P = 28; q->hist_blocks = 27; q->col_shift = q->K / 2 + 1; }
     q->taps = bypass ? std::vector<float>(14, 0.f) : pfb_prototype(q->K, 7, 60.0f);
     q->dtheta = bypass ? 0u : channel_center_step(N);
     // channel-rate history in front of every push's tiles: a symbol window, plus -- if frames straddling two pushes are
@@ -535,14 +541,15 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
 
     auto bail = [&](int rc) { mcrx_hip_destroy(q); return rc; };
     int rc; bool no_spec_cfg = false;
-    if ((rc = q->upload(&q->d_taps, q->taps.data(), q->taps.size()))) return bail(rc);
+    {   // the channelizer's column tap table (kernels.h: ChanArgs::taps)
+        std::vector<float> ct = q->chan_P == 28 ? pfb2_composite_taps(pfb2_prototype(q->K, 7, 60.0f), halfband_branch_taps(7, 60.0f), q->K)
+                              : bypass ? q->taps : pfb_column_taps(q->taps, q->K);
+        if ((rc = q->upload(&q->d_taps, ct.data(), ct.size()))) return bail(rc);
+    }
     if ((rc = build_tables(q))) return bail(rc);
     if (q->oversampled) {
         if (mcrx_hip_pfb2_create(&q->pfb2, q->K, 7, 60.0f) != MCRX_OK) return bail(fail(MCRX_EHIP, mcrx_hip_pfb2_last_error()));
-        // half-band branch filter of liquid's resamp2 (as in msresamp.hip): odd taps of a 29-tap Kaiser design, reversed
-        std::vector<float> hh = firdes_kaiser(29, 0.25f, 60.0f), h1(14);
-        unsigned j = 0;
-        for (unsigned i = 1; i < 29; i += 2) h1[j++] = hh[29 - i - 1];
+        std::vector<float> h1 = halfband_branch_taps(7, 60.0f);
         if ((rc = q->upload(&q->d_h1, h1.data(), h1.size()))) return bail(rc);
     }
     if ((rc = q->alloc(&q->d_st, q->nch))) return bail(rc);
@@ -633,8 +640,8 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
             if ((rc = q->alloc(&q->d_anchor, q->nch))) return bail(rc);
         }
     }
-    if ((rc = q->alloc(&q->d_hist[0], (size_t)HIST_BLOCKS * q->K))) return bail(rc);
-    if ((rc = q->alloc(&q->d_hist[1], (size_t)HIST_BLOCKS * q->K))) return bail(rc);
+    if ((rc = q->alloc(&q->d_hist[0], (size_t)q->hist_blocks * q->K))) return bail(rc);
+    if ((rc = q->alloc(&q->d_hist[1], (size_t)q->hist_blocks * q->K))) return bail(rc);
     // host staging for Execute(): whole tiles of MCRX_TILE blocks
     size_t tile_samples = (size_t)MCRX_TILE * q->K;
     size_t want = q->cfg.batch_samples ? q->cfg.batch_samples : ((size_t)1 << 20);
@@ -723,6 +730,7 @@ extern "C" int mcrx_hip_destroy(mcrx_hip_t q)
 
 extern "C" unsigned mcrx_hip_num_channels(mcrx_hip_t q) { return q ? q->N : 0; }
 extern "C" uint32_t mcrx_hip_nco_step(mcrx_hip_t q) { return q ? q->dtheta : 0; }
+extern "C" unsigned mcrx_hip_history_blocks(mcrx_hip_t q) { return q ? q->hist_blocks : 0; }
 extern "C" int mcrx_hip_get_taps(mcrx_hip_t q, float *h, size_t n)
 {
     if (!q || !h || n < q->taps.size()) return fail(MCRX_EINVAL, "taps buffer too small");
@@ -742,9 +750,9 @@ static int launch_channelizer(mcrx_hip_t q, const float2 *x, size_t nblocks, uin
     a.nblocks = (uint32_t)nblocks;
     a.slab_blocks = q->slab_blocks ? q->slab_blocks : channelizer_auto_slab(q->K, nblocks, q->ncu);
     a.first_sample_lo = (uint32_t)first_sample; a.dtheta = q->dtheta;
-    a.ntiles = (uint32_t)ntiles_stride; a.cg = q->N / groups;
+    a.ntiles = (uint32_t)ntiles_stride; a.cg = q->N / groups; a.col_shift = q->col_shift;
     RC(q->ev_begin(0, st));
-    HIPCHK(channelizer_launch(q->K, a, st));
+    HIPCHK(channelizer_launch(q->K, q->chan_P, a, st));
     RC(q->ev_end(0, st));
     return MCRX_OK;
 }
@@ -970,7 +978,7 @@ extern "C" int mcrx_hip_channelize(mcrx_hip_t q, const void *d_iq, size_t nblock
                                    const void *d_halo, void *d_out, unsigned groups, void *stream)
 {
     if (q && q->bypass) return fail(MCRX_EUNSUPP, "single_channel handle has no channelizer");
-    if (q && q->oversampled) return fail(MCRX_EUNSUPP, "the oversampled front end runs inside execute_host / execute_device only");
+    if (q && q->oversampled) return fail(MCRX_EUNSUPP, "front_end = 2 (the oversampled front end stage by stage) runs inside execute_host / execute_device only");
     if (!q || !d_iq || !d_out) return fail(MCRX_EINVAL, "null argument");
     hipStream_t st = stream ? (hipStream_t)stream : q->stream;
     return launch_channelizer(q, (const float2 *)d_iq, nblocks, first_sample, (const float2 *)d_halo,
@@ -1028,7 +1036,7 @@ static int ensure_chan(mcrx_hip_t q, size_t tiles)
     return MCRX_OK;
 }
 
-// cfg.front_end = 1: oscillator -> 2N-channel oversampled bank (two steps per block) -> half-band decimator per kept
+// cfg.front_end = 2: oscillator -> 2N-channel oversampled bank (two steps per block) -> half-band decimator per kept
 // channel -> the synchronizers' tiles.  Input and bank output are double buffered with their filter history in front.
 static int run_oversampled(mcrx_hip_t q, const float2 *x, size_t nblocks, uint64_t first_abs, float2 *tiles, hipStream_t sc)
 {
@@ -1104,9 +1112,9 @@ static int run_blocks(mcrx_hip_t q, const float2 *x, size_t nblocks, uint64_t fi
         RC(run_oversampled(q, x, nblocks, first_abs, buf + q->hist_tiles * tile_elems, sc));
     else
         RC(launch_channelizer(q, x, nblocks, first_abs, q->d_hist[q->hist_cur], buf + q->hist_tiles * tile_elems, 1, ntiles, sc));
-    // FIR history: last 13 blocks of (history, x)
+    // FIR history: the last 13 (27) blocks of (history, x)
     if (!q->bypass && !q->oversampled) {
-        const uint64_t nh = (uint64_t)HIST_BLOCKS * q->K;
+        const uint64_t nh = (uint64_t)q->hist_blocks * q->K;
         hipLaunchKernelGGL(hist_update_kernel, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, sc,
                            q->d_hist[q->hist_cur], x, (uint64_t)nblocks * q->K, q->d_hist[1 - q->hist_cur], nh);
         HIPCHK(hipGetLastError());

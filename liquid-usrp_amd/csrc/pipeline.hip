@@ -80,6 +80,7 @@ constexpr unsigned kMaxBuf = 8;
 
 struct mcrx_hip_pipeline_s {
     mcrx_hip_t rx = nullptr;
+    size_t halo = 13;                                           // blocks of filter history in front of a sub-slab: mcrx_hip_history_blocks (13; 27 with front_end = 1)
     int rank = 0, world = 1;
     unsigned N = 0, K = 0, cg = 0, hist = 0, nbuf = 3;
     size_t Tc = 0, tiles = 0, per = 0, hist_elems = 0;         // per: cf32 elements of one (source rank) chunk of a round
@@ -148,7 +149,7 @@ extern "C" int mcrx_hip_pipeline_create(mcrx_hip_pipeline_t *out, mcrx_hip_t rx,
     mcrx_hip_pipeline_t p = new mcrx_hip_pipeline_s();
     auto bail = [&](int rc) { mcrx_hip_pipeline_destroy(p); return rc; };
     p->rx = rx; p->rank = rank; p->world = world; p->N = N; p->K = 2 * N; p->cg = N / (unsigned)world; p->nbuf = nbuf;
-    p->Tc = sub_blocks; p->tiles = sub_blocks / MCRX_TILE; p->hist = mcrx_hip_history_tiles(rx);
+    p->Tc = sub_blocks; p->tiles = sub_blocks / MCRX_TILE; p->hist = mcrx_hip_history_tiles(rx); p->halo = mcrx_hip_history_blocks(rx);
     p->per = p->tiles * p->cg * MCRX_TILE; p->hist_elems = (size_t)p->hist * p->cg * MCRX_TILE;
     const size_t recv_elems = p->hist_elems + (size_t)world * p->per;
     for (unsigned i = 0; i < nbuf; i++) {
@@ -284,7 +285,7 @@ extern "C" int mcrx_hip_pipeline_push(mcrx_hip_pipeline_t p, const void *d_iq_su
 static int host_slot(mcrx_hip_pipeline_t p, unsigned *slot)
 {
     const unsigned i = (unsigned)(p->host_pushes % p->nbuf);
-    const size_t bytes = (size_t)(13 + p->Tc) * p->K * 2 * sizeof(float);
+    const size_t bytes = (size_t)(p->halo + p->Tc) * p->K * 2 * sizeof(float);
     if (!p->hin[i]) {
         PCHK(hipHostMalloc((void **)&p->hin[i], bytes, hipHostMallocDefault));
         PCHK(hipMalloc((void **)&p->din[i], bytes));
@@ -301,7 +302,7 @@ extern "C" int mcrx_hip_pipeline_host_buffer(mcrx_hip_pipeline_t p, float **buf,
     int rc = host_slot(p, &i);
     if (rc != MCRX_OK) return rc;
     *buf = p->hin[i];
-    if (nsamples) *nsamples = (size_t)(13 + p->Tc) * p->K;
+    if (nsamples) *nsamples = (size_t)(p->halo + p->Tc) * p->K;
     return MCRX_OK;
 }
 extern "C" int mcrx_hip_pipeline_push_host(mcrx_hip_pipeline_t p, const float *iq_with_halo)
@@ -310,13 +311,13 @@ extern "C" int mcrx_hip_pipeline_push_host(mcrx_hip_pipeline_t p, const float *i
     unsigned i = 0;
     int rc = host_slot(p, &i);
     if (rc != MCRX_OK) return rc;
-    const size_t n = (size_t)(13 + p->Tc) * p->K;
+    const size_t n = (size_t)(p->halo + p->Tc) * p->K;
     if (iq_with_halo != p->hin[i]) memcpy(p->hin[i], iq_with_halo, n * 2 * sizeof(float));
     // din[i]'s last reader, the channelizer of nbuf host pushes ago, ran on sA: the copy is ordered behind it there
     PCHK(hipMemcpyAsync(p->din[i], p->hin[i], n * 2 * sizeof(float), hipMemcpyHostToDevice, p->sA));
     PCHK(hipEventRecord(p->evH[i], p->sA));
     p->hin_busy[i] = true; p->host_pushes++;
-    return mcrx_hip_pipeline_push(p, p->din[i] + (size_t)13 * p->K * 2, p->din[i], MCRX_STREAM_READY);
+    return mcrx_hip_pipeline_push(p, p->din[i] + p->halo * p->K * 2, p->din[i], MCRX_STREAM_READY);
 }
 
 // multichannelrx::Reset() on a sharded receiver (lib/multichannelrx.cc:135-153 -- legal mid-stream, lib/multichanneltxrx.cc:333 calls it):

@@ -81,7 +81,8 @@ def check_frames(gpu_frames, ora_frames, rel=REL, leak_rssi=None):
 def test_channelizer_matches_oracle(oracle, product, N):
     torch = _torch()
     K = 2 * N
-    nblocks = 64 if N >= 64 else 256
+    nblocks = 96 if N >= 64 else 256        # (96: three slabs of 32 -- a block is then transformed in a different row of the workgroup's tile
+                                            #  when the stream is cut; round 6: the twiddle multiplies round the same way in every row)
     rng = np.random.RandomState(N)
     x = (rng.randn(nblocks * K) + 1j * rng.randn(nblocks * K)).astype(np.complex64)
     ora = oracle.MultiChannelRx(N, 64, 8, 4)
@@ -95,14 +96,14 @@ def test_channelizer_matches_oracle(oracle, product, N):
     got = product.tiles_to_channels(d_out, N).T                 # [block][N]
     assert relerr(got, ref) <= REL
     # split into two calls with halo and a non-zero first sample: identical to one call
-    h = nblocks // 2
-    d_a = torch.zeros(h // 8 * N * 8, dtype=torch.complex64, device="cuda")
-    d_b = torch.zeros_like(d_a)
-    rx.channelize(d_x[:h * K], h, 0, d_a)
-    rx.channelize(d_x[h * K:], h, h * K, d_b, d_halo=d_x[(h - 13) * K:h * K])
-    torch.cuda.synchronize()
-    got2 = np.concatenate([product.tiles_to_channels(d_a, N).T, product.tiles_to_channels(d_b, N).T])
-    assert np.array_equal(got2, got)
+    for h in (nblocks // 2, 16, nblocks - 16):
+        d_a = torch.zeros(h * N, dtype=torch.complex64, device="cuda")
+        d_b = torch.zeros((nblocks - h) * N, dtype=torch.complex64, device="cuda")
+        rx.channelize(d_x[:h * K], h, 0, d_a)
+        rx.channelize(d_x[h * K:], nblocks - h, h * K, d_b, d_halo=d_x[(h - 13) * K:h * K])
+        torch.cuda.synchronize()
+        got2 = np.concatenate([product.tiles_to_channels(d_a, N).T, product.tiles_to_channels(d_b, N).T])
+        assert np.array_equal(got2, got), h
     # grouped layout = per-destination chunks of the same values
     if N >= 2:
         d_g = torch.zeros_like(d_out)
@@ -684,11 +685,56 @@ def test_oversampled_bank_argument_errors(product):
             product.firpfbch2(M, m)
 
 
+@pytest.mark.parametrize("N", [1, 2, 4, 16, 64, 256, 512])
+def test_oversampled_front_end_is_one_bank(oracle, product, N):
+    """front_end = 1, stage level: oscillator + firpfbch2 (2N channels, twice the channel rate) + half-band decimator per kept
+    channel computed as ONE critically sampled bank with the 28-tap composite prototype (csrc/channelizer.hip, design.hpp:
+    pfb2_composite_taps) against the oracle's stage-by-stage chain: <= 1e-5 of full scale (the two differ by float rounding
+    only: ~2e-7); a stream cut in two with 27 blocks of history is bit-identical to one call; grouped layout."""
+    torch = _torch()
+    K = 2 * N
+    nblocks = 96 if N >= 64 else 256
+    rng = np.random.RandomState(100 + N)
+    x = (rng.randn(nblocks * K) + 1j * rng.randn(nblocks * K)).astype(np.complex64)
+    ref = oracle.MultiChannelRx(N, 64, 8, 4).channelize_oversampled(x)         # [block][N]
+    rx = product.multichannelrx(N, 64, 8, 4, front_end=1)
+    assert rx.history_blocks() == 27
+    d_x = torch.from_numpy(x).cuda()
+    d_out = torch.zeros(nblocks * N, dtype=torch.complex64, device="cuda")
+    rx.channelize(d_x, nblocks, 0, d_out)
+    torch.cuda.synchronize()
+    got = product.tiles_to_channels(d_out, N).T
+    err = relerr(got, ref)
+    assert err <= REL, err
+    assert err <= 2e-6, err                                         # (what the identity actually leaves: float rounding)
+    for h in (nblocks // 2 - (nblocks // 2) % 16, 32, nblocks - 16):
+        d_a = torch.zeros(h * N, dtype=torch.complex64, device="cuda")
+        d_b = torch.zeros((nblocks - h) * N, dtype=torch.complex64, device="cuda")
+        rx.channelize(d_x[:h * K], h, 0, d_a)
+        rx.channelize(d_x[h * K:], nblocks - h, h * K, d_b, d_halo=d_x[(h - 27) * K:h * K])
+        torch.cuda.synchronize()
+        assert np.array_equal(np.concatenate([product.tiles_to_channels(d_a, N).T, product.tiles_to_channels(d_b, N).T]), got), h
+    if N >= 2:
+        d_g = torch.zeros_like(d_out)
+        rx.channelize(d_x, nblocks, 0, d_g, groups=2)
+        torch.cuda.synchronize()
+        T_ = product.TILE
+        g = d_g.cpu().numpy().reshape(2, nblocks // T_, N // 2, T_)
+        full = got.T.reshape(N, nblocks // T_, T_)
+        for gi in range(2):
+            assert np.array_equal(g[gi].transpose(1, 0, 2), full[gi * (N // 2):(gi + 1) * (N // 2)])
+    rx.close()
+    assert product.multichannelrx(N, 64, 8, 4).history_blocks() == 13
+    print("composite bank N=%d: %.3g of full scale from the oracle's stage-by-stage chain" % (N, err))
+
+
 @pytest.mark.parametrize("N,M,cp,mod,fec1,plen", [(8, 64, 8, 40, 6, 400), (4, 256, 32, 27, 7, 300), (64, 64, 8, 40, 6, 120), (512, 64, 8, 40, 6, 64)])
-def test_oversampled_front_end_full_chain(oracle, product, N, M, cp, mod, fec1, plen):
-    """front_end = 1: the 2x-oversampled bank BASELINE.json names (firpfbch2, 2N channels) with its rate 2 -> 1
-    half-band adapter in front of the synchronizers, against the same chain in the oracle: every frame, bit for bit,
-    equalised symbols within 1e-5 -- in one push and in uneven pieces -- and what the transmitter sent."""
+@pytest.mark.parametrize("front_end", [1, 2])
+def test_oversampled_front_end_full_chain(oracle, product, N, M, cp, mod, fec1, plen, front_end):
+    """The 2x-oversampled bank BASELINE.json names (firpfbch2, 2N channels) with its rate 2 -> 1 half-band adapter in front of
+    the synchronizers -- front_end = 1: folded into one kernel; 2: stage by stage, three kernels -- against the same chain in
+    the oracle: every frame, bit for bit, equalised symbols within 1e-5 -- in one push and in uneven pieces -- and what the
+    transmitter sent."""
     torch = _torch()
     tx = product.multichanneltx(N, M, cp, 4)
     iq, sent = tx.generate(2, plen, mod=mod, fec1=fec1, seed=N + M)
@@ -700,13 +746,13 @@ def test_oversampled_front_end_full_chain(oracle, product, N, M, cp, mod, fec1, 
     for i in range(0, n, 1 << 22):
         ora.execute(x[i:i + (1 << 22)])
     assert len(ora.frames) == 2 * N and all(f.payload_valid for f in ora.frames)
-    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=max(plen, 64), front_end=1)
+    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=max(plen, 64), front_end=front_end)
     rx.Execute(iq[:n]); rx.Flush()
     worst = check_frames(rx.frames, ora.frames)
     for f in rx.frames:
         assert sent[f.channel][(f.header[0] << 8) | f.header[1]] == (f.header, f.payload)
     rx.close()
-    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=max(plen, 64), front_end=1)
+    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=max(plen, 64), front_end=front_end)
     rng = np.random.RandomState(5)
     i = 0
     while i < n:
@@ -716,5 +762,5 @@ def test_oversampled_front_end_full_chain(oracle, product, N, M, cp, mod, fec1, 
     check_frames(rx.frames, ora.frames)
     rx.close()
     with pytest.raises(Exception):
-        product.multichannelrx(3, 64, 8, 4, front_end=1)
-    print("oversampled front end N=%d M=%d worst framesyms rel err %.3g" % (N, M, worst))
+        product.multichannelrx(3, 64, 8, 4, front_end=front_end)
+    print("oversampled front end (%d) N=%d M=%d worst framesyms rel err %.3g" % (front_end, N, M, worst))
