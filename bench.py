@@ -548,14 +548,12 @@ def config_leg(prod, torch, dev, N, M, cp, frames, plen, mod, fec1, resamp, step
     tx.close()
     inputs, rs = slabs, None
     if resamp:
-        from scipy.signal import firwin
-        h = torch.tensor(2.0 * firwin(63, 0.5), dtype=torch.float32, device=dev)
-        inputs = []
-        for d in slabs:
-            up = torch.zeros(2 * d.numel(), dtype=torch.complex64, device=dev); up[::2] = d
-            re = torch.nn.functional.conv1d(torch.view_as_real(up).T.reshape(2, 1, -1), h.view(1, 1, -1), padding=31)
-            inputs.append(torch.view_as_complex(re.reshape(2, -1).T.contiguous()))
-        del up, re
+        # the antenna stream at twice the rate, made once (untimed) by the transmit applications' own interpolator,
+        # msresamp_crcf_create(2.0, 60) (src/flexframe_tx.cc:170) -- the product's GPU build of it, one continuous stream over the slabs
+        up = prod.msresamp(2.0, 60.0)
+        inputs = [up.execute(d).clone() for d in slabs]
+        torch.cuda.synchronize()
+        up.close()
         rs = prod.msresamp(0.5, 60.0)
     leg_cfg = dict(LEG_CFG, front_end=front_end) if front_end else LEG_CFG
     rx = prod.multichannelrx(N, M, cp, taper, max_payload_len=plen, max_frames=N * frames + 64, **leg_cfg)
@@ -565,13 +563,23 @@ def config_leg(prod, torch, dev, N, M, cp, frames, plen, mod, fec1, resamp, step
     # barrier across the handle's blocking streams -- consecutive pushes then run one after the other, 50 instead of 80+ Gsample/s
     # here); its output buffer is allocated under that stream, so the next push's resampler is ordered behind the channelizer that
     # reads it (mcrx_hip_execute_device lets the caller's stream wait until the input has been read)
-    side = torch.cuda.Stream(device=dev) if rs is not None else None
+    # Two such streams, taken in turn (round 6): Execute(y, stream) makes the caller's stream wait until the channelizer has read y, so with
+    # ONE stream push p + 1's resampler could not start before push p's channelizer had finished -- resampler and channelizer alternated,
+    # 0.83 of every 0.94 ms (profiles/r6_c2_timeline_before.txt); with two, the resampler of the next push runs beside the receiver's
+    # work on this one (each stream's output buffer comes from its own pool of the caching allocator)
+    nside = int(os.environ.get("BENCH_RESAMP_STREAMS", "2"))
+    sides = [torch.cuda.Stream(device=dev) for _ in range(nside)] if rs is not None else []
+    turn, rs_done = [0], [None]
 
     def step(keep=False):
         for x in inputs:
             if rs is not None:
+                side = sides[turn[0] % nside]; turn[0] += 1
                 with torch.cuda.stream(side):
+                    if rs_done[0] is not None:
+                        side.wait_event(rs_done[0])             # the resampler is one stream of samples: its filter state passes from call to call
                     y = rs.execute(x, stream=side)
+                    rs_done[0] = torch.cuda.Event(); rs_done[0].record(side)
                     assert int(y.numel()) % tile == 0, "the decimated slab is not whole tiles (%d samples)" % int(y.numel())
                     rx.Execute(y, stream=side)
             else:

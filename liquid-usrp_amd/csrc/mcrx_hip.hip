@@ -663,7 +663,7 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     //  chains of launch gaps, and three launches less in the work stream's chain are worth 15-18 % (8 channels: 65 -> 77 Gsample/s, with
     //  the K = 7 code 41 -> 47); a receiver that fills the chip gains nothing from it, and the stream's mere existence cost 1 % of the
     //  headline and 10 % of the pipeline leg in alternating runs -- scratch/r5/split_ab.sh.)
-    if (q->pipelined && q->nch <= 64 && q->cfg.channel_count == 0 && hipStreamCreate(&q->s_side) != hipSuccess)      // (not a rank's shard behind a pipeline: streams enough there)
+    if (q->pipelined && q->nch <= 32 && q->cfg.channel_count == 0 && hipStreamCreate(&q->s_side) != hipSuccess)      // (not a rank's shard behind a pipeline: streams enough there)
         return bail(fail(MCRX_EHIP, "hipStreamCreate failed"));
     if (hipStreamCreateWithFlags(&q->s_copy, hipStreamNonBlocking) != hipSuccess) return bail(fail(MCRX_EHIP, "hipStreamCreate failed"));
     {

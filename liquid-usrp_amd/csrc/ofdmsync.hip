@@ -3432,6 +3432,19 @@ hipError_t acq_lean_launch(const SyncArgs &a, unsigned grid, hipStream_t st)
 }
 #endif
 
+// part 1 also holds the lean payload workers of the 128- / 256-subcarrier configurations (payload_wide.hpp)
+hipError_t payload_wide_launch(const SyncArgs &a, unsigned grid, hipStream_t st);
+static inline bool payload_wide_takes(const SyncConsts &c) { return (c.E == 2 || c.E == 4) && c.log2M >= 7 && c.M == WV * c.E && c.M_pilot >= 1 && c.M_pilot <= WV; }
+#if SY_PART < 0 || SY_PART == 1
+#include "payload_wide.hpp"
+hipError_t payload_wide_launch(const SyncArgs &a, unsigned grid, hipStream_t st)
+{
+    if (a.c.E == 2) hipLaunchKernelGGL((payload_wide_kernel<63, 2>), dim3(grid), dim3(WV), 0, st, a);
+    else hipLaunchKernelGGL((payload_wide_kernel<63, 4>), dim3(grid), dim3(WV), 0, st, a);
+    return hipGetLastError();
+}
+#endif
+
 #if SY_PART <= 0
 static hipError_t sy_launch(int what, const SyncArgs &a0, unsigned grid, size_t lds, hipStream_t st)
 {
@@ -3590,6 +3603,10 @@ hipError_t sync_launch_payload(const SyncArgs &a0, int stage, hipStream_t st)
         }
         return hipGetLastError();
     }
+    // 128 / 256 subcarriers: the lean one-frame-per-wave workers of payload_wide.hpp (round 6) unless the handle asks for the width-generic
+    // kernel (worker_build = 5, or payload_lean off: A/B and parity tests)
+    if (fast && payload_wide_takes(a.c) && a.payload_lean && a.payload_fr == 1 && !(a.no_fast & 6))
+        return payload_wide_launch(a, ngrid, st);
     return sy_launch(fast ? SYK_PAYLOAD_FAST : SYK_PAYLOAD_GENERAL, a, nj, SY_LDS_BYTES(a.c.M), st);
 }
 #endif  // SY_PART <= 0

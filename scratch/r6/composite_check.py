@@ -57,3 +57,16 @@ def run(N, nblocks=96, seed=1):
 if __name__ == "__main__":
     for N in (1, 2, 4, 8, 32, 64):
         assert run(N) < 3e-6
+
+
+def tap_profile(N=512):
+    G = composite_taps(N)
+    a = np.abs(G)
+    tot = a.sum(axis=1).max()
+    print("N=%d: per-d max |G| relative to the largest tap, and the worst-case column sum of the taps beyond d (relative to the column's tap sum)" % N)
+    gmax = a.max()
+    for d in range(28):
+        print("  d=%2d  max %.3e   sum over columns' worst |tap| share %.3e" % (d, a[:, d].max() / gmax, (a[:, d] / a.sum(axis=1)).max()))
+    for lo, hi in ((1, 26), (2, 25), (3, 24), (4, 23)):
+        drop = np.concatenate([a[:, :lo], a[:, hi + 1:]], axis=1).sum(axis=1)
+        print("  keep d in [%d, %d] (%d taps): dropped tap mass / kept, worst column %.3e" % (lo, hi, hi - lo + 1, (drop / a.sum(axis=1)).max()))

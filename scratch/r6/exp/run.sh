@@ -1,0 +1,5 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+python scratch/r6/exp/time_chan.py 1 2>&1 | grep -v amdgpu.ids
+python scratch/r6/exp/time_chan.py 0 2>&1 | grep -v amdgpu.ids
+for t in "$@"; do MCRX_LIB=$GRAFT_REPO_ROOT/scratch/r6/exp/libs/libexp_$t.so python scratch/r6/exp/time_chan.py 1 2>&1 | grep -v amdgpu.ids; done

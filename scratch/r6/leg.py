@@ -20,5 +20,8 @@ name = sys.argv[1]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 N, M, cp, fr, pl, mod, fec1, rsmp, fe = LEGS[name]
+for kv in os.environ.get('LEG_CFG', '').split(','):
+    if '=' in kv:
+        k, v = kv.split('='); bench.LEG_CFG[k] = int(v)
 out = bench.config_leg(prod, torch, dev, N, M, cp, fr, pl, mod, fec1, rsmp, steps=steps, reps=reps, what=name, front_end=fe)
 print(json.dumps({name: out}))

@@ -337,6 +337,33 @@ def test_wide_symbols_take_the_lean_path(oracle, product, M, cp, mod, fec1):
     rx.close(); tx.close()
 
 
+@pytest.mark.parametrize("M,cp", [(128, 16), (256, 32)])
+@pytest.mark.parametrize("mod,fec1,plen", [(39, 1, 45), (40, 6, 333), (27, 7, 1200), (29, 6, 257), (27, 11, 90)])
+def test_wide_payload_workers(oracle, product, M, cp, mod, fec1, plen):
+    """payload_wide.hpp (round 6): the lean one-frame-per-wave workers of 128- / 256-subcarrier frames -- every modem, soft and hard
+    decisions, a last symbol that is partly filled, three frames per channel with noise -- against the oracle, and against the
+    width-generic worker they replace (worker_build = 5): same bytes, same flags."""
+    N, nf = 2, 3
+    iq, sent = oracle.synth_traffic(N, M, cp, 4, nf, payload_len=plen, mod=mod, fec1=fec1, seed=M + mod)
+    rng = np.random.RandomState(M + plen)
+    iq = (iq + 0.004 / N * (rng.randn(len(iq)) + 1j * rng.randn(len(iq)))).astype(np.complex64)
+    for soft in (True, False):
+        ora = oracle.MultiChannelRx(N, M, cp, 4, soft=soft)
+        ora.execute(iq)
+        assert len(ora.frames) == N * nf and all(f.payload_valid for f in ora.frames)
+        got = {}
+        for wb in (0, 5):
+            rx = product.multichannelrx(N, M, cp, 4, max_payload_len=max(plen, 64), payload_soft=1 if soft else 0, worker_build=wb)
+            rx.Execute(iq); rx.Flush()
+            check_frames(rx.frames, ora.frames)
+            got[wb] = [(f.channel, f.header, f.payload, f.payload_valid, f.end_sample) for f in rx.frames]
+            seen = len(rx.frames)
+            rx.Reset(); rx.Execute(iq); rx.Flush()                  # (replay: frames now come from the segment waves' hand-offs)
+            check_frames(rx.frames[seen:], ora.frames)
+            rx.close()
+        assert got[0] == got[5]
+
+
 def test_two_rank_sharding_emulated_on_one_gpu(product):
     """The multi-GPU data path (bench.py --gpus 2) with both ranks' HIP handles in one process: rank r
     channelizes time slab r (halo from the slab before, absolute NCO phase) into per-destination groups,
