@@ -98,6 +98,12 @@ typedef struct {
     uint32_t scout_build;        /* 0 = default: the general state machine's segment waves, the scouts' unbudgeted build; 1 = the scouts'
                                     168-register build of rounds 2-3; 2 = the lean segment waves of 48- / 64-subcarrier symbols
                                     (csrc/acq_lean.hpp: half the instructions, the same time on periodic traffic, 10 % behind on ragged) */
+    uint32_t conv_scratch;       /* the K = 7 rate-1/2 decoder's scratch in HBM (512 bytes per trellis step and decoder wave: min(max_frames, 2048) waves x
+                                    (32 max_payload_len + ~100) steps = 0.4 GB at 1200-byte payloads, 0.65 GB at the default 2048).  0 = allocated when
+                                    the first frame with that code has been seen (the launch after the device reports it; until then such frames go
+                                    through the block decoder of rounds 3-4: the same bytes on every frame that decodes, a fixed 192-step overlap
+                                    instead of an exact one on frames that do not); 1 = with the handle (callers that know they will receive the code);
+                                    2 = never.  An allocation that fails is not an error: the block decoder stays */
 } mcrx_hip_config;
 
 /* One decoded frame = the arguments of the reference's framesync_callback
@@ -197,6 +203,13 @@ int  mcrx_hip_kernel_time_ms(mcrx_hip_t q, float *channelizer_ms, float *sync_ms
 int  mcrx_hip_kernel_stats(mcrx_hip_t q, double ms_total[MCRX_NKERNELS], uint64_t launches[MCRX_NKERNELS], int reset);
 
 const char *mcrx_hip_last_error(void);
+
+/* Devices.  A handle (receiver, resampler, bank, generator, pipeline) belongs to the HIP device that was current when it was created:
+ * every entry point that touches the device makes that device current for the call and restores the caller's, and per-kernel device
+ * settings (dynamic LDS limits) are made once per device, not once per process -- a host may open handles on several GPUs of one
+ * process (the design and the benchmark use one process per GPU).  Device buffers and streams passed in must belong to the handle's device. */
+int  mcrx_hip_device(mcrx_hip_t q);                    /* the handle's device index, -1 for a null handle */
+int  mcrx_hip_selftest_device_table(void);             /* the once-per-device bookkeeping driven with made-up device ids: 0 = ok (no GPU needed) */
 
 /* ---- multi-stage resampler: decimating front end (0 < rate <= 1) and the transmit side's interpolator
  *      (rate > 1: msresamp_crcf_create(2.0, 60), src/flexframe_tx.cc:170) -------------

@@ -44,7 +44,7 @@ class Config(C.Structure):
                 ("payload_soft", C.c_uint32), ("slab_blocks", C.c_uint32), ("channel_first", C.c_uint32),
                 ("channel_count", C.c_uint32), ("batch_samples", C.c_uint32), ("single_channel", C.c_uint32),
                 ("serial", C.c_uint32), ("chunk_blocks", C.c_uint32), ("defer_samples", C.c_uint32), ("front_end", C.c_uint32), ("skip_framesyms", C.c_uint32),
-                ("worker_build", C.c_uint32), ("acquisition", C.c_uint32), ("scout_build", C.c_uint32)]
+                ("worker_build", C.c_uint32), ("acquisition", C.c_uint32), ("scout_build", C.c_uint32), ("conv_scratch", C.c_uint32)]
 
 
 class FrameC(C.Structure):
@@ -83,6 +83,8 @@ _EXPORTS = {
     "mcrx_hip_get_taps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "mcrx_hip_nco_step": (C.c_uint32, [C.c_void_p]),
     "mcrx_hip_history_blocks": (C.c_uint, [C.c_void_p]),
+    "mcrx_hip_device": (C.c_int, [C.c_void_p]),
+    "mcrx_hip_selftest_device_table": (C.c_int, []),
     "mcrx_hip_kernel_time_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "mcrx_hip_kernel_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
     "mcrx_hip_last_error": (C.c_char_p, []),

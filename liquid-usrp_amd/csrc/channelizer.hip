@@ -41,9 +41,7 @@
 #include "devel.h"
 #include "devmath.h"
 #include "kernels.h"
-
-#include <atomic>
-#include <mutex>
+#include "devscope.hpp"
 
 namespace mcrx {
 
@@ -482,24 +480,6 @@ __global__ __launch_bounds__(T) void channelizer_kernel(ChanArgs a)
     else channelizer_rounds<K, C, T, P, SHIFT, true>(a, tile);
 }
 
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: done once per (kernel, device), under a lock -- a host that opens
-// handles on several GPUs from one process must not skip it on devices 1..7
-static hipError_t raise_lds_limit(const void *fn, size_t lds, std::atomic<uint64_t> &done_mask)
-{
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    const uint64_t bit = 1ull << (dev & 63);
-    if (done_mask.load(std::memory_order_acquire) & bit) return hipSuccess;
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lk(mu);
-    if (done_mask.load(std::memory_order_relaxed) & bit) return hipSuccess;
-    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    done_mask.fetch_or(bit, std::memory_order_release);
-    return hipSuccess;
-}
-
 template <int K, int C, int T, int P, bool SHIFT>
 static hipError_t launch_one(const ChanArgs &a, hipStream_t st)
 {
@@ -511,7 +491,7 @@ static hipError_t launch_one(const ChanArgs &a, hipStream_t st)
     // granule stores are addressed by 32-bit offsets in 16-byte units: 64 GB of output per launch
     if ((unsigned long long)(K / 2) * ((unsigned long long)a.ntiles + (unsigned long long)NS * a.slab_blocks / MCRX_TILE_S + 1ull) * (MCRX_TILE_S / 2) >= (1ull << 32))
         return hipErrorInvalidValue;
-    static std::atomic<uint64_t> attr_done{0};
+    static PerDeviceOnce attr_done;          // (per instantiation; devscope.hpp)
     hipError_t e = raise_lds_limit((const void *)channelizer_kernel<K, C, T, P, SHIFT>, lds, attr_done);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((channelizer_kernel<K, C, T, P, SHIFT>), dim3(grid), dim3(T), lds, st, a);
@@ -628,7 +608,8 @@ hipError_t channelizer_launch(unsigned K, unsigned P, const ChanArgs &a, hipStre
     if (!pow2_fast(K)) {
         if (a.nblocks == 0) return hipSuccess;
         const size_t lds = (size_t)(CH_R + 1) * K * sizeof(float2);
-        hipError_t e = hipFuncSetAttribute((const void *)channelizer_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        static PerDeviceOnce gen_done;
+        hipError_t e = raise_lds_limit((const void *)channelizer_generic_kernel, 160 * 1024, gen_done);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(channelizer_generic_kernel, dim3(a.nblocks / CH_R), dim3(CG_T), lds, st, a, (uint32_t)K);
         return hipGetLastError();

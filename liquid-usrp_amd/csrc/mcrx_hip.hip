@@ -5,6 +5,7 @@
 #include "design.hpp"
 #include "devel.h"
 #include "devmath.h"
+#include "devscope.hpp"
 #include "kernels.h"
 #include "txcode.hpp"
 
@@ -135,6 +136,7 @@ struct HostArena {
 };
 
 struct mcrx_hip_s {
+    int device = -1;            // the HIP device the handle was created on: every entry point runs with it current (devscope.hpp)
     unsigned N = 0, K = 0, M = 0, cp = 0, taper = 0;
     bool bypass = false;                    // one synchronizer fed channel-rate samples, no channelizer (ofdmtxrx)
     OfdmDesign od;
@@ -170,7 +172,7 @@ struct mcrx_hip_s {
     // per-launch slots
     PayloadJob *d_jobs[MCRX_SLOTS] = {}; uint32_t *d_njobs = nullptr; float2 *d_jR[MCRX_SLOTS] = {};
     uint32_t *d_gen[MCRX_SLOTS] = {}, *d_qam[MCRX_SLOTS] = {}, *d_live[MCRX_SLOTS] = {};
-    uint2 *d_vit_scratch = nullptr; uint32_t vit_rows = 0, vit_waves = 0; uint32_t *d_vit_passes = nullptr;      // the K = 7 decoder's decision rows (kernels.h: vit_scratch)
+    uint2 *d_vit_scratch = nullptr; uint32_t vit_rows = 0, vit_waves = 0, vit_mode = 0; uint32_t *d_vit_passes = nullptr;      // the K = 7 decoder's decision rows (kernels.h: vit_scratch)
     uint64_t seq = 0;                       // synchronizer launches so far (slot = seq % nslots)
     unsigned nslots = 5;                    // buffer sets in use: the channelizer and the acquisition chain of up to nslots - 1 pushes run ahead of the payload workers
     uint32_t *d_stats = nullptr;            // speculation statistics (SyncArgs::stats)
@@ -301,9 +303,14 @@ static int il_tables_acquire(uint32_t max_payload, uint32_t max_enc, const uint1
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));
     const uint32_t cap = std::min<uint32_t>(max_enc, 56u * 1024u / 8u);
-    std::lock_guard<std::mutex> lk(g_il_mu);
-    for (auto &t : g_il)
-        if (t.dev == dev && t.max_payload == max_payload && t.cap == cap) { t.refs++; *map = t.d_map; *off = t.d_off; *n = t.n; return MCRX_OK; }
+    // (round 6, ADVICE r5: the table is built OUTSIDE the lock -- 40-120 MB of allocations and a stream synchronize used to stall the first
+    //  push of every other handle and thread behind it -- and published under it with a second look: whoever lost a race frees its copy)
+    auto find_shared = [&]() -> bool {
+        for (auto &t : g_il)
+            if (t.dev == dev && t.max_payload == max_payload && t.cap == cap) { t.refs++; *map = t.d_map; *off = t.d_off; *n = t.n; return true; }
+        return false;
+    };
+    { std::lock_guard<std::mutex> lk(g_il_mu); if (find_shared()) return MCRX_OK; }
     std::vector<uint32_t> offv(cap + 1, ~0u), lens, offs;
     uint64_t total = 0;
     static const int outer[3] = { FEC_HAMMING128, FEC_GOLAY2412, FEC_CONV_V27 };
@@ -339,6 +346,8 @@ static int il_tables_acquire(uint32_t max_payload, uint32_t max_enc, const uint1
         if (d_off) (void)hipFree(d_off);
         return fail(MCRX_EHIP, hipGetErrorString(e));
     }
+    std::lock_guard<std::mutex> lk(g_il_mu);
+    if (find_shared()) { (void)hipFree(d_map); (void)hipFree(d_off); return MCRX_OK; }       // another handle published the same table meanwhile
     g_il.push_back(IlShared{ dev, max_payload, cap, d_map, d_off, cap + 1, 1 });
     *map = d_map; *off = d_off; *n = cap + 1;
     return MCRX_OK;
@@ -486,6 +495,7 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
         return fail(MCRX_EHIP, "no HIP device: the MI355X kernels are the only implementation (no CPU fallback)");
 
     mcrx_hip_t q = new mcrx_hip_s();
+    q->device = current_device();
     q->N = N; q->K = bypass ? 1 : 2 * N; q->M = M; q->cp = cp; q->taper = taper; q->bypass = bypass;
     if (q->od.init(M, cp, taper, p) != 0) { delete q; return fail(MCRX_EINVAL, "invalid subcarrier allocation"); }
     if (cfg) memcpy(&q->cfg, cfg, std::min<size_t>(cfg->struct_size ? cfg->struct_size : sizeof(*cfg), sizeof(q->cfg)));
@@ -602,7 +612,7 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     // (coherent: with hipHostMallocMapped alone the allocation is non-coherent and a free-running host -- one that never
     //  synchronizes with the device -- does not see the kernels' updates at all)
     if (hipHostMalloc((void **)&q->h_hint, 12 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
-        for (int i = 0; i < 12; i++) q->h_hint[i] = 0;    // [0] longest coded frame, [1] widest prediction list, [2] walked, [3] adopted, [4] frames on a cadence, [5] frames seen,
+        for (int i = 0; i < 12; i++) q->h_hint[i] = 0;    // [0] longest coded frame, [1] widest prediction list, [2] walked, [3] adopted, [4] frames on a cadence, [5] frames seen, [11] a frame with the K = 7 code was decoded,
                                                           // [8] QAM hand-offs, [9] trellis blocks, [10] general-list frames of the most recent launch (kernels.h: list_hint)
         if (hipHostGetDevicePointer((void **)&q->d_hint, q->h_hint, 0) != hipSuccess) q->d_hint = nullptr;
     }
@@ -620,12 +630,14 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
         if (q->sc.payload_soft) {
             // The K = 7 decoder (decode_general_kernel, viterbi_frames.hpp) takes a frame per wave and keeps 512 bytes of decisions per trellis
             // step of a block in HBM: one region per workgroup, as many workgroups as a launch can have frames (at most 2 per SIMD: it is
-            // arithmetic).  Its launches follow each other on the work stream, so one set serves every slot.  (~200 KB per workgroup at 1200-byte
-            // payloads; a handle never asked for a convolutional frame pays the allocation and nothing else.)
+            // arithmetic).  Its launches follow each other on the work stream, so one set serves every slot.  ~200 KB per workgroup at 1200-byte
+            // payloads = 0.4 GB: allocated when the first frame with the code has been seen (cfg.conv_scratch), launch_sync.
             q->vit_rows = vf::rows_for(4u * q->max_enc + 6u);
             q->vit_waves = (uint32_t)std::max<uint64_t>(64, std::min<uint64_t>(q->max_rec, 2048));
-            if ((rc = q->alloc_raw(&q->d_vit_scratch, (size_t)q->vit_waves * q->vit_rows * 64))) return bail(rc);
+            q->vit_mode = q->cfg.struct_size >= offsetof(mcrx_hip_config, conv_scratch) + sizeof(uint32_t) ? q->cfg.conv_scratch : 0u;
+            if (q->vit_mode > 2) return bail(fail(MCRX_EINVAL, "conv_scratch must be 0, 1 or 2"));
             if ((rc = q->alloc(&q->d_vit_passes, 8))) return bail(rc);
+            if (q->vit_mode == 1 && (rc = q->alloc_raw(&q->d_vit_scratch, (size_t)q->vit_waves * q->vit_rows * 64))) return bail(rc);
         }
         // speculative acquisition (lean path only): slots, their equalisers, the prediction lists
         const bool lean = (q->sc.log2M >= 6 && q->sc.M == 64 * q->sc.E && q->sc.M_pilot <= 64) ||
@@ -686,6 +698,7 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
 
 extern "C" int mcrx_hip_destroy(mcrx_hip_t q)
 {
+    DevScope dev_scope_(q ? q->device : -1);
     if (!q) return MCRX_OK;
     (void)hipDeviceSynchronize();
     if (q->debug & 8)
@@ -766,8 +779,14 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     const int g = q->gen;
     if (!q->il_tried) {                    // first synchronizer launch of this handle: the device's shared de-interleaver tables
         q->il_tried = true;
-        if (q->scout_tables && devel_env("MCRX_NO_ILMAP") == nullptr)
-            RC(il_tables_acquire(q->max_payload, q->max_enc, &q->sc.il_map, &q->sc.il_off, &q->sc.il_n, q->stream));
+        // (a table that cannot be built -- 40-120 MB plus twice that in scratch -- is no table, not an error: the decoder's in-place passes
+        //  serve every length)
+        if (q->scout_tables && devel_env("MCRX_NO_ILMAP") == nullptr &&
+            il_tables_acquire(q->max_payload, q->max_enc, &q->sc.il_map, &q->sc.il_off, &q->sc.il_n, q->stream) != MCRX_OK) {
+            (void)hipGetLastError();
+            q->sc.il_map = nullptr; q->sc.il_off = nullptr; q->sc.il_n = 0;
+            if (q->debug) fprintf(stderr, "[mcrx] de-interleaver gather tables not built (%s): decoding without them\n", mcrx_hip_last_error());
+        }
     }
     SyncArgs a;
     a.c = q->sc; a.chan = chan; a.chan_stride = stride; a.chan_off = off;
@@ -783,6 +802,13 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     a.scout = q->scout ? 1 : 0;
     a.jobs = q->d_jobs[slot]; a.njobs = q->d_njobs + slot; a.njobs_next = q->d_njobs + next; a.max_jobs = q->max_jobs;
     a.gen_list = q->d_gen[slot]; a.dec_lds_soft = 0;
+    if (!q->d_vit_scratch && q->vit_mode == 0 && q->vit_rows && q->h_hint && ((volatile uint32_t *)q->h_hint)[11]) {
+        // a frame with the K = 7 code has been decoded: its decoder's scratch from here on (a failure is not an error: the block decoder stays)
+        if (hipMalloc((void **)&q->d_vit_scratch, (size_t)q->vit_waves * q->vit_rows * 64) != hipSuccess) {
+            (void)hipGetLastError(); q->d_vit_scratch = nullptr; q->vit_mode = 2;
+            if (q->debug) fprintf(stderr, "[mcrx] the K = 7 decoder's scratch (%zu MB) could not be allocated: the block decoder stays\n", ((size_t)q->vit_waves * q->vit_rows * 64) >> 20);
+        } else q->owned.push_back(q->d_vit_scratch);
+    }
     a.vit_scratch = q->d_vit_scratch; a.vit_rows = q->vit_rows; a.vit_waves = q->vit_waves; a.vit_passes = q->d_vit_passes;
     a.qam_list = q->d_qam[slot]; a.qam_next = q->d_qam[next]; a.list_hint = nullptr;
     a.live = q->d_live[slot]; a.live_next = q->d_live[next];
@@ -977,6 +1003,7 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
 extern "C" int mcrx_hip_channelize(mcrx_hip_t q, const void *d_iq, size_t nblocks, uint64_t first_sample,
                                    const void *d_halo, void *d_out, unsigned groups, void *stream)
 {
+    DevScope dev_scope_(q ? q->device : -1);
     if (q && q->bypass) return fail(MCRX_EUNSUPP, "single_channel handle has no channelizer");
     if (q && q->oversampled) return fail(MCRX_EUNSUPP, "front_end = 2 (the oversampled front end stage by stage) runs inside execute_host / execute_device only");
     if (!q || !d_iq || !d_out) return fail(MCRX_EINVAL, "null argument");
@@ -986,17 +1013,20 @@ extern "C" int mcrx_hip_channelize(mcrx_hip_t q, const void *d_iq, size_t nblock
 }
 extern "C" int mcrx_hip_sync(mcrx_hip_t q, const void *d_chan, uint64_t first_sample, size_t nsamples, void *stream)
 {
+    DevScope dev_scope_(q ? q->device : -1);
     if (!q || !d_chan) return fail(MCRX_EINVAL, "null argument");
     hipStream_t st = stream ? (hipStream_t)stream : q->stream;
     return launch_sync(q, (const float2 *)d_chan, q->nch, 0, (int64_t)first_sample, (int64_t)(first_sample + nsamples), st);
 }
 extern "C" int mcrx_hip_restart(mcrx_hip_t q, void *stream)
 {
+    DevScope dev_scope_(q ? q->device : -1);
     if (!q) return fail(MCRX_EINVAL, "null handle");
     return restart_async(q, stream ? (hipStream_t)stream : q->stream, true);
 }
 extern "C" int mcrx_hip_kernel_time_ms(mcrx_hip_t q, float *ch_ms, float *sy_ms)
 {
+    DevScope dev_scope_(q ? q->device : -1);
     if (!q) return fail(MCRX_EINVAL, "null handle");
     for (int w = 0; w < MCRX_NKERNELS; w++) RC(q->ev_resolve(w));
     if (ch_ms) *ch_ms = q->ev_last[0];
@@ -1005,6 +1035,7 @@ extern "C" int mcrx_hip_kernel_time_ms(mcrx_hip_t q, float *ch_ms, float *sy_ms)
 }
 extern "C" int mcrx_hip_kernel_stats(mcrx_hip_t q, double ms_total[MCRX_NKERNELS], uint64_t launches[MCRX_NKERNELS], int reset)
 {
+    DevScope dev_scope_(q ? q->device : -1);
     // HIP-event durations of every launch since the last reset, recorded on the stream the
     // kernels were launched on (order: mcrx_hip.h)
     if (!q) return fail(MCRX_EINVAL, "null handle");
@@ -1209,6 +1240,7 @@ static int execute_direct(mcrx_hip_t q, const float2 *&src, size_t &nsamples, bo
 
 extern "C" int mcrx_hip_execute_host(mcrx_hip_t q, const float *iq, size_t nsamples)
 {
+    DevScope dev_scope_(q ? q->device : -1);
     if (!q || (!iq && nsamples)) return fail(MCRX_EINVAL, "null argument");
     const float2 *src = reinterpret_cast<const float2 *>(iq);
     bool overflow = false;
@@ -1238,6 +1270,7 @@ extern "C" int mcrx_hip_execute_host(mcrx_hip_t q, const float *iq, size_t nsamp
 
 extern "C" int mcrx_hip_execute_device(mcrx_hip_t q, const void *d_iq, size_t nsamples, void *stream)
 {
+    DevScope dev_scope_(q ? q->device : -1);
     if (!q || (!d_iq && nsamples)) return fail(MCRX_EINVAL, "null argument");
     if (q->stage_fill) return fail(MCRX_EINVAL, "host samples are still staged: flush before pushing device buffers");
     if (nsamples % ((size_t)MCRX_TILE * q->K)) return fail(MCRX_EINVAL, "device pushes must be whole tiles of MCRX_TILE = 16 blocks (32*N samples)");
@@ -1260,6 +1293,7 @@ extern "C" int mcrx_hip_execute_device(mcrx_hip_t q, const void *d_iq, size_t ns
 
 extern "C" int mcrx_hip_stream_wait(mcrx_hip_t q, void *stream)
 {
+    DevScope dev_scope_(q ? q->device : -1);
     if (!q) return fail(MCRX_EINVAL, "null handle");
     return join_into(q, stream ? (hipStream_t)stream : q->stream);
 }
@@ -1267,6 +1301,7 @@ extern "C" uint64_t mcrx_hip_launches(mcrx_hip_t q) { return q ? q->seq : 0; }
 extern "C" unsigned mcrx_hip_history_tiles(mcrx_hip_t q) { return q ? q->hist_tiles : 0; }
 extern "C" int mcrx_hip_stream_wait_launch(mcrx_hip_t q, uint64_t launch, void *stream)
 {
+    DevScope dev_scope_(q ? q->device : -1);
     // the event ring holds the last MCRX_SLOTS launches; an older launch shares its slot with a later one that
     // finishes after it (payload workers and decoders run in launch order), so waiting for the slot is enough
     if (!q) return fail(MCRX_EINVAL, "null handle");
@@ -1384,6 +1419,7 @@ static int harvest(mcrx_hip_t q)
 // execute_device + one poll per slab, slab k-1's frames cross the host link while slab k is being processed.
 extern "C" int mcrx_hip_poll(mcrx_hip_t q)
 {
+    DevScope dev_scope_(q ? q->device : -1);
     if (!q) return fail(MCRX_EINVAL, "null handle");
     // Two pushes stay in flight: what is collected here was closed by the poll before the previous one, so the wait is for the
     // launches of two pushes ago while the device has the last two queued.  (Collecting the previous poll's generation left the
@@ -1402,6 +1438,7 @@ extern "C" int mcrx_hip_poll(mcrx_hip_t q)
 // device once its launches -- MCRX_GENS - 1 discards ago -- have finished.  Nothing is waited for on the host.
 extern "C" int mcrx_hip_discard(mcrx_hip_t q)
 {
+    DevScope dev_scope_(q ? q->device : -1);
     if (!q) return fail(MCRX_EINVAL, "null handle");
     const int g = q->gen, next = (g + 1) % MCRX_GENS;
     if (!q->gen_used[g]) return MCRX_OK;
@@ -1426,6 +1463,7 @@ extern "C" int mcrx_hip_discard(mcrx_hip_t q)
 
 extern "C" int mcrx_hip_spec_stats(mcrx_hip_t q, uint64_t *walked, uint64_t *adopted, int reset)
 {
+    DevScope dev_scope_(q ? q->device : -1);
     if (!q) return fail(MCRX_EINVAL, "null handle");
     HIPCHK(hipDeviceSynchronize());
     uint32_t v[4] = { 0, 0, 0, 0 };
@@ -1438,6 +1476,7 @@ extern "C" int mcrx_hip_spec_stats(mcrx_hip_t q, uint64_t *walked, uint64_t *ado
 
 extern "C" int mcrx_hip_viterbi_stats(mcrx_hip_t q, uint64_t *frames, uint64_t *forward_repeats, uint64_t *traceback_repeats, int reset)
 {
+    DevScope dev_scope_(q ? q->device : -1);
     if (!q) return fail(MCRX_EINVAL, "null handle");
     uint32_t v[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     if (q->d_vit_passes) {
@@ -1456,6 +1495,7 @@ extern "C" int mcrx_hip_viterbi_stats(mcrx_hip_t q, uint64_t *frames, uint64_t *
 
 extern "C" int mcrx_hip_flush(mcrx_hip_t q)
 {
+    DevScope dev_scope_(q ? q->device : -1);
     if (!q) return fail(MCRX_EINVAL, "null handle");
     RC(process_staged(q));
     return harvest(q);
@@ -1495,6 +1535,7 @@ extern "C" int mcrx_hip_drain_count(mcrx_hip_t q, uint64_t *frames, uint64_t *va
 
 extern "C" int mcrx_hip_reset(mcrx_hip_t q)
 {
+    DevScope dev_scope_(q ? q->device : -1);
     // multichannelrx::Reset (lib/multichannelrx.cc:135-153): synchronizers and channelizer windows
     // reset, partial block dropped, NCO keeps running.  Everything pushed before the Reset has been
     // synchronized by the reference at this point, so the whole tiles still in the staging buffer are processed
@@ -1510,6 +1551,7 @@ extern "C" int mcrx_hip_reset(mcrx_hip_t q)
 }
 extern "C" int mcrx_hip_reset_at(mcrx_hip_t q, uint64_t chan_position)
 {
+    DevScope dev_scope_(q ? q->device : -1);
     if (!q) return fail(MCRX_EINVAL, "null handle");
     HIPCHK(hipDeviceSynchronize());                      // stage-level launches run on the caller's and the handle's streams
     int rc = harvest(q);
@@ -1518,4 +1560,27 @@ extern "C" int mcrx_hip_reset_at(mcrx_hip_t q, uint64_t chan_position)
     RC(restart_async(q, q->stream, false));
     HIPCHK(hipDeviceSynchronize());
     return MCRX_OK;
+}
+
+// ---------------------------------------------------------------- device bookkeeping, testable without a second GPU
+extern "C" int mcrx_hip_device(mcrx_hip_t q) { return q ? q->device : -1; }
+// the per-device "done once" table of devscope.hpp driven with device ids that need not exist: 0 = every check passed
+extern "C" int mcrx_hip_selftest_device_table(void)
+{
+    PerDeviceOnce t;
+    int calls = 0;
+    auto work = [&]() { calls++; return hipSuccess; };
+    auto fail_once = [&]() { calls++; return hipErrorInvalidValue; };
+    for (int dev : { 0, 1, 7, 63, 64, 255 }) {
+        if (t.is_done(dev)) return 1;
+        if (t.run(dev, work) != hipSuccess || !t.is_done(dev)) return 2;
+        const int before = calls;
+        if (t.run(dev, work) != hipSuccess || calls != before) return 3;          // second time on the same device: not done again
+    }
+    if (t.is_done(2) || t.is_done(65)) return 4;                                   // other devices are untouched
+    if (t.run(3, fail_once) == hipSuccess || t.is_done(3)) return 5;               // a failure is not remembered as done
+    if (t.run(3, work) != hipSuccess || !t.is_done(3)) return 6;
+    const int before = calls;
+    if (t.run(-1, work) != hipSuccess || t.run(300, work) != hipSuccess || calls != before + 2) return 7;     // outside the table: every time
+    return 0;
 }

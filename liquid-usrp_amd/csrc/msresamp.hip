@@ -17,6 +17,7 @@
 // Streaming state = absolute sample counters on the host + retained tails of each stage buffer.
 #include "../../include/mcrx_hip.h"
 #include "design.hpp"
+#include "devscope.hpp"
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstring>
@@ -151,6 +152,7 @@ struct StageBuf {                   // device buffer holding samples [base, end)
 };
 
 struct msresamp_hip_s {
+    int device = -1;            // the HIP device the handle was created on: every entry point runs with it current (devscope.hpp)
     float rate = 1, As = 60;
     bool interp = false;
     unsigned num_stages = 0;
@@ -198,6 +200,7 @@ extern "C" int msresamp_hip_create(msresamp_hip_t *out, float rate, float As)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_rs_err = "no HIP device (no CPU fallback)"; return MCRX_EHIP; }
     msresamp_hip_t q = new msresamp_hip_s();
+    q->device = current_device();
     q->rate = rate; q->As = As; q->rate_arb = rate;
     q->interp = rate > 1.0f;
     if (q->interp) while (q->rate_arb > 2.0) { q->num_stages++; q->rate_arb *= 0.5; }
@@ -228,6 +231,7 @@ extern "C" int msresamp_hip_create(msresamp_hip_t *out, float rate, float As)
 
 extern "C" int msresamp_hip_destroy(msresamp_hip_t q)
 {
+    DevScope dev_scope_(q ? q->device : -1);
     if (!q) return MCRX_OK;
     (void)hipDeviceSynchronize();
     for (auto &b : q->in) if (b.d) (void)hipFree(b.d);
@@ -239,6 +243,7 @@ extern "C" int msresamp_hip_destroy(msresamp_hip_t q)
 
 extern "C" int msresamp_hip_reset(msresamp_hip_t q)
 {
+    DevScope dev_scope_(q ? q->device : -1);
     if (!q) return MCRX_EINVAL;
     for (auto &b : q->in) { b.base = 0; b.end = 0; }
     q->out_count = 0;
@@ -260,6 +265,7 @@ extern "C" size_t msresamp_hip_max_output(msresamp_hip_t q, size_t nin)
 extern "C" int msresamp_hip_execute_device(msresamp_hip_t q, const void *d_in, size_t nin, void *d_out,
                                            size_t out_cap, size_t *nout, void *stream)
 {
+    DevScope dev_scope_(q ? q->device : -1);
     if (!q || !nout || (!d_in && nin) || !d_out) { g_rs_err = "null argument"; return MCRX_EINVAL; }
     // NULL = the legacy default stream, like the other stage operators: what a caller enqueues next -- on that stream or on a
     // receiver handle's own (blocking) streams -- is ordered behind the resampler's kernels.  (A private stream here left

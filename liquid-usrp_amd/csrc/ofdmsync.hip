@@ -2998,6 +2998,8 @@ __device__ __forceinline__ void decode_frame(SyncArgs &a, const uint32_t j, uint
         //  then of frames, for a kernel of the decoder's own between this one and the general decoder -- ADVICE r3 / VERDICT r4 #8 were about
         //  a frame that found it full.)
         const bool conv_go = conv_pre;
+        // (tell the host that frames with the code arrive: it allocates the frame-per-wave decoder's scratch then -- cfg.conv_scratch = 0)
+        if (c.payload_soft && fec1 == 11 && !a.vit_scratch && a.hint && threadIdx.x == 0) a.hint[11] = 1u;
         if (conv_go) {
             const unsigned long long *g64 = reinterpret_cast<const unsigned long long *>(soft);
             for (uint32_t i = threadIdx.x; i < e1; i += DK_T) dk_soft[DKP(i)] = g64[i];

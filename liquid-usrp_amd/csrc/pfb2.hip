@@ -15,6 +15,7 @@
 #include "../../include/mcrx_hip.h"
 #include "design.hpp"
 #include "devmath.h"
+#include "devscope.hpp"
 
 #include <hip/hip_runtime.h>
 #include <type_traits>
@@ -269,6 +270,7 @@ static thread_local std::string g_pfb2_err;
 #define P2CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_pfb2_err = std::string(#x) + ": " + hipGetErrorString(e_); return MCRX_EHIP; } } while (0)
 
 struct mcrx_hip_pfb2_s {
+    int device = -1;            // the HIP device the handle was created on: every entry point runs with it current (devscope.hpp)
     unsigned M, m;
     std::vector<float> taps;
     float *d_taps = nullptr;
@@ -287,6 +289,7 @@ extern "C" int mcrx_hip_pfb2_create(mcrx_hip_pfb2_t *out, unsigned M, unsigned m
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_pfb2_err = "no HIP device (no CPU fallback)"; return MCRX_EHIP; }
     mcrx_hip_pfb2_t q = new mcrx_hip_pfb2_s();
+    q->device = current_device();
     q->M = M; q->m = m;
     q->taps = pfb2_prototype(M, m, As);
     if (hipMalloc((void **)&q->d_taps, q->taps.size() * sizeof(float)) != hipSuccess ||
@@ -300,6 +303,7 @@ extern "C" int mcrx_hip_pfb2_create(mcrx_hip_pfb2_t *out, unsigned M, unsigned m
 
 extern "C" int mcrx_hip_pfb2_destroy(mcrx_hip_pfb2_t q)
 {
+    DevScope dev_scope_(q ? q->device : -1);
     if (!q) return MCRX_OK;
     (void)hipDeviceSynchronize();
     (void)hipFree(q->d_taps);
@@ -317,6 +321,7 @@ extern "C" int mcrx_hip_pfb2_get_taps(mcrx_hip_pfb2_t q, float *h, size_t n)
 extern "C" int mcrx_hip_pfb2_analyze(mcrx_hip_pfb2_t q, const void *d_x, size_t lead_samples, size_t nsteps,
                                      uint64_t first_step, void *d_out, void *stream)
 {
+    DevScope dev_scope_(q ? q->device : -1);
     if (!q || !d_x || !d_out) { g_pfb2_err = "bad argument"; return MCRX_EINVAL; }
     if (nsteps == 0) return MCRX_OK;
     if (nsteps > 0x7fffffffu) { g_pfb2_err = "too many steps in one call"; return MCRX_EINVAL; }
@@ -327,7 +332,7 @@ extern "C" int mcrx_hip_pfb2_analyze(mcrx_hip_pfb2_t q, const void *d_x, size_t 
     if (a.p == PF_P && q->M >= 64) {
         const unsigned nwg = ((unsigned)((nsteps + PF_TS - 1) / PF_TS) + 7u) & ~7u;     // whole rounds over the 8 XCDs
         const size_t lds = (size_t)(2 * PF_TB + 1) * q->M * sizeof(float2);
-#define P2T(MM) do { static bool attr_ = false; if (!attr_) { P2CHK(hipFuncSetAttribute((const void *)pfb2_tile_kernel<MM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_ = true; } \
+#define P2T(MM) do { static PerDeviceOnce attr_; P2CHK(raise_lds_limit((const void *)pfb2_tile_kernel<MM>, lds, attr_)); \
                      hipLaunchKernelGGL((pfb2_tile_kernel<MM>), dim3(nwg), dim3(Pfb2Tile<MM>::NT), lds, st, a); } while (0)
         switch (q->M) {
         case 64: P2T(64); break;   case 128: P2T(128); break; case 256: P2T(256); break;

@@ -16,6 +16,7 @@
 // ncclUniqueId of rank 0 (mcrx_hip_pipeline_unique_id) by whatever means it has (MPI, a file, torch.distributed).
 #include "../../include/mcrx_hip.h"
 #include "devel.h"
+#include "devscope.hpp"
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <dlfcn.h>
@@ -79,6 +80,7 @@ constexpr unsigned kMaxBuf = 8;
 }  // namespace
 
 struct mcrx_hip_pipeline_s {
+    int device = -1;            // the HIP device the handle was created on: every entry point runs with it current (devscope.hpp)
     mcrx_hip_t rx = nullptr;
     size_t halo = 13;                                           // blocks of filter history in front of a sub-slab: mcrx_hip_history_blocks (13; 27 with front_end = 1)
     int rank = 0, world = 1;
@@ -115,6 +117,7 @@ extern "C" int mcrx_hip_pipeline_unique_id(void *id128)
 
 extern "C" int mcrx_hip_pipeline_destroy(mcrx_hip_pipeline_t p)
 {
+    mcrx::DevScope dev_scope_(p ? p->device : -1);
     if (!p) return MCRX_OK;
     (void)hipDeviceSynchronize();
     if (p->comm) (void)g_rccl.CommDestroy(p->comm);
@@ -147,6 +150,7 @@ extern "C" int mcrx_hip_pipeline_create(mcrx_hip_pipeline_t *out, mcrx_hip_t rx,
     if (nbuf < 2 || nbuf > kMaxBuf) nbuf = 3;
     if (world > 1 && !unique_id128) return pfail(MCRX_EINVAL, "world > 1 needs rank 0's ncclUniqueId (mcrx_hip_pipeline_unique_id)");
     mcrx_hip_pipeline_t p = new mcrx_hip_pipeline_s();
+    p->device = mcrx::current_device();
     auto bail = [&](int rc) { mcrx_hip_pipeline_destroy(p); return rc; };
     p->rx = rx; p->rank = rank; p->world = world; p->N = N; p->K = 2 * N; p->cg = N / (unsigned)world; p->nbuf = nbuf;
     p->Tc = sub_blocks; p->tiles = sub_blocks / MCRX_TILE; p->hist = mcrx_hip_history_tiles(rx); p->halo = mcrx_hip_history_blocks(rx);
@@ -191,6 +195,7 @@ extern "C" int mcrx_hip_pipeline_time_exchange(mcrx_hip_pipeline_t p, int on)
 
 extern "C" int mcrx_hip_pipeline_exchange_ms(mcrx_hip_pipeline_t p, double *total_ms, uint64_t *rounds, int reset)
 {
+    mcrx::DevScope dev_scope_(p ? p->device : -1);
     if (!p) return pfail(MCRX_EINVAL, "null handle");
     for (size_t i = 0; i < p->xused; i++) {
         float ms = 0;
@@ -215,6 +220,7 @@ extern "C" uint64_t mcrx_hip_pipeline_bytes_sent_per_round(mcrx_hip_pipeline_t p
 // produced d_iq_sub (NULL: the legacy default stream; MCRX_STREAM_READY: nothing to wait for).  Returns after enqueuing.
 extern "C" int mcrx_hip_pipeline_push(mcrx_hip_pipeline_t p, const void *d_iq_sub, const void *d_halo, void *after_stream)
 {
+    mcrx::DevScope dev_scope_(p ? p->device : -1);
     if (!p || !d_iq_sub) return pfail(MCRX_EINVAL, "null argument");
     const uint64_t c = p->rounds; const unsigned nb = p->nbuf, i = (unsigned)(c % nb);
     float *out = p->out[i], *recv = p->recv[i], *fresh = recv + 2 * p->hist_elems;
@@ -297,6 +303,7 @@ static int host_slot(mcrx_hip_pipeline_t p, unsigned *slot)
 }
 extern "C" int mcrx_hip_pipeline_host_buffer(mcrx_hip_pipeline_t p, float **buf, size_t *nsamples)
 {
+    mcrx::DevScope dev_scope_(p ? p->device : -1);
     if (!p || !buf) return pfail(MCRX_EINVAL, "null argument");
     unsigned i = 0;
     int rc = host_slot(p, &i);
@@ -307,6 +314,7 @@ extern "C" int mcrx_hip_pipeline_host_buffer(mcrx_hip_pipeline_t p, float **buf,
 }
 extern "C" int mcrx_hip_pipeline_push_host(mcrx_hip_pipeline_t p, const float *iq_with_halo)
 {
+    mcrx::DevScope dev_scope_(p ? p->device : -1);
     if (!p || !iq_with_halo) return pfail(MCRX_EINVAL, "null argument");
     unsigned i = 0;
     int rc = host_slot(p, &i);
@@ -329,6 +337,7 @@ extern "C" int mcrx_hip_pipeline_push_host(mcrx_hip_pipeline_t p, const float *i
 // calls); no exchange is needed.  Frames decoded so far stay deliverable through the handle.
 extern "C" int mcrx_hip_pipeline_reset(mcrx_hip_pipeline_t p, int64_t extra_samples)
 {
+    mcrx::DevScope dev_scope_(p ? p->device : -1);
     if (!p) return pfail(MCRX_EINVAL, "null handle");
     PCHK(hipStreamSynchronize(p->sA)); PCHK(hipStreamSynchronize(p->sB)); PCHK(hipStreamSynchronize(p->sC));
     const uint64_t blocks = p->rounds * (uint64_t)p->world * (uint64_t)p->Tc;
@@ -344,6 +353,7 @@ extern "C" int mcrx_hip_pipeline_reset(mcrx_hip_pipeline_t p, int64_t extra_samp
 // benchmark line quotes to prove that N ranks took part.  -1: this RCCL has no ncclCommCount.
 extern "C" int mcrx_hip_pipeline_comm_count(mcrx_hip_pipeline_t p)
 {
+    mcrx::DevScope dev_scope_(p ? p->device : -1);
     if (!p) return -1;
     if (!p->comm) return 1;
     if (!g_rccl.CommCount) return -1;
@@ -353,6 +363,7 @@ extern "C" int mcrx_hip_pipeline_comm_count(mcrx_hip_pipeline_t p)
 
 extern "C" int mcrx_hip_pipeline_wait(mcrx_hip_pipeline_t p)
 {
+    mcrx::DevScope dev_scope_(p ? p->device : -1);
     if (!p) return pfail(MCRX_EINVAL, "null handle");
     PCHK(hipStreamSynchronize(p->sA)); PCHK(hipStreamSynchronize(p->sB)); PCHK(hipStreamSynchronize(p->sC));
     return MCRX_OK;

@@ -18,6 +18,7 @@
 #include "devel.h"
 #include "devmath.h"
 #include "txcode.hpp"
+#include "devscope.hpp"
 #include <random>
 #include <string>
 #include <vector>
@@ -569,6 +570,7 @@ static thread_local std::string g_tx_err;
 #define TXCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_tx_err = std::string(#x) + ": " + hipGetErrorString(e_); return MCRX_EHIP; } } while (0)
 
 struct mctx_hip_s {
+    int device = -1;            // the HIP device the handle was created on: every entry point runs with it current (devscope.hpp)
     unsigned N, K, M, cp, taper, ncu = 256;
     bool taps_symmetric = false;                        // h[i] == h[pK - i] bit for bit (the fused synthesis kernel keeps half of it)
     OfdmDesign od;
@@ -617,6 +619,7 @@ extern "C" int mctx_hip_create(mctx_hip_t *out, unsigned N, unsigned M, unsigned
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_tx_err = "no HIP device (no CPU fallback)"; return MCRX_EHIP; }
     mctx_hip_t q = new mctx_hip_s();
+    q->device = current_device();
     q->N = N; q->K = K; q->M = M; q->cp = cp; q->taper = taper;
     if (q->od.init(M, cp, taper, p) != 0) { delete q; g_tx_err = "invalid subcarrier allocation"; return MCRX_EINVAL; }
     q->taps = pfb_prototype(K, 13, 60.0f);
@@ -644,6 +647,7 @@ extern "C" int mctx_hip_create(mctx_hip_t *out, unsigned N, unsigned M, unsigned
 
 extern "C" int mctx_hip_destroy(mctx_hip_t q)
 {
+    DevScope dev_scope_(q ? q->device : -1);
     if (!q) return MCRX_OK;
     (void)hipDeviceSynchronize();
     for (void *p : q->owned) (void)hipFree(p);
@@ -681,6 +685,7 @@ extern "C" int mctx_hip_generate(mctx_hip_t q, void *d_iq, size_t nblocks, unsig
                                  int mod, int fec0, int fec1, float gain, uint32_t seed,
                                  uint8_t *hdr_out, uint8_t *pay_out, void *stream)
 {
+    DevScope dev_scope_(q ? q->device : -1);
     if (!q || !d_iq || !mod_bps(mod)) { g_tx_err = "bad argument"; return MCRX_EINVAL; }
     if (!fec_supported(fec0) || !fec_supported(fec1)) { g_tx_err = "unsupported fec scheme"; return MCRX_EUNSUPP; }
     hipStream_t st = (hipStream_t)stream;
@@ -746,6 +751,7 @@ extern "C" int mctx_hip_generate_ragged(mctx_hip_t q, void *d_iq, size_t nblocks
                                         float gain, uint32_t seed, uint32_t *count_out, uint8_t *hdr_out, uint32_t *len_out,
                                         uint8_t *pay_out, uint64_t *start_out, void *stream)
 {
+    DevScope dev_scope_(q ? q->device : -1);
     if (!q || !d_iq || !mod_bps(mod) || len_hi < len_lo || !max_frames) { g_tx_err = "bad argument"; return MCRX_EINVAL; }
     if (!fec_supported(fec0) || !fec_supported(fec1)) { g_tx_err = "unsupported fec scheme"; return MCRX_EUNSUPP; }
     if (q->M & (q->M - 1)) { g_tx_err = "ragged traffic needs a power-of-two subcarrier count"; return MCRX_EUNSUPP; }
@@ -834,6 +840,7 @@ extern "C" int mctx_hip_generate_ragged(mctx_hip_t q, void *d_iq, size_t nblocks
 //   3. synthesize_tiles runs the 2N-point inverse FFT, synthesis FIR and NCO over ITS time slab from the
 //                       received granules [source rank][tile][c][8]; `lead` blocks in front only fill the filter.
 struct mctx_hip_traffic_s {
+    int device = -1;
     mctx_hip_t q;
     unsigned ch_first, ch_count, frames, S;
     float2 *d_xsym;
@@ -843,6 +850,7 @@ extern "C" int mctx_hip_traffic_create(mctx_hip_t q, mctx_hip_traffic_t *out, un
                                        unsigned frames, unsigned payload_len, int mod, int fec0, int fec1, uint32_t seed,
                                        uint8_t *hdr_out, uint8_t *pay_out, void *stream)
 {
+    DevScope dev_scope_(q ? q->device : -1);
     if (!q || !out || !mod_bps(mod)) { g_tx_err = "bad argument"; return MCRX_EINVAL; }
     if (!fec_supported(fec0) || !fec_supported(fec1)) { g_tx_err = "unsupported fec scheme"; return MCRX_EUNSUPP; }
     *out = nullptr;
@@ -885,6 +893,7 @@ extern "C" int mctx_hip_traffic_create(mctx_hip_t q, mctx_hip_traffic_t *out, un
     TXCHK(hipStreamSynchronize(st));
     (void)hipFree(d_hdr); (void)hipFree(d_pay);
     mctx_hip_traffic_t t = new mctx_hip_traffic_s();
+    t->device = q->device;
     t->q = q; t->ch_first = ch_first; t->ch_count = ch_count; t->frames = frames; t->S = S; t->d_xsym = d_xsym;
     *out = t;
     return MCRX_OK;
@@ -892,6 +901,7 @@ extern "C" int mctx_hip_traffic_create(mctx_hip_t q, mctx_hip_traffic_t *out, un
 
 extern "C" int mctx_hip_traffic_destroy(mctx_hip_traffic_t t)
 {
+    DevScope dev_scope_(t ? t->device : -1);
     if (!t) return MCRX_OK;
     (void)hipDeviceSynchronize();
     if (t->d_xsym) (void)hipFree(t->d_xsym);
@@ -901,6 +911,7 @@ extern "C" int mctx_hip_traffic_destroy(mctx_hip_traffic_t t)
 
 extern "C" int mctx_hip_traffic_tiles(mctx_hip_traffic_t t, long long first_block, size_t nblocks, void *d_tiles, void *stream)
 {
+    DevScope dev_scope_(t ? t->device : -1);
     if (!t || !d_tiles || (nblocks % 8)) { g_tx_err = "bad argument (blocks come in granules of 8)"; return MCRX_EINVAL; }
     if (!nblocks) return MCRX_OK;
     mctx_hip_t q = t->q;
@@ -923,6 +934,7 @@ static int tx_launch_ifft(mctx_hip_t q, const TxSynthArgs &ya, unsigned nblocks,
 extern "C" int mctx_hip_synthesize_tiles(mctx_hip_t q, const void *d_tiles, unsigned groups, long long first_block, size_t nblocks,
                                          size_t lead_blocks, size_t keep_blocks, float gain, void *d_iq, void *stream)
 {
+    DevScope dev_scope_(q ? q->device : -1);
     if (!q || !d_tiles || !d_iq || !groups || (q->N % groups) || (nblocks % 8) || (lead_blocks % 8) || keep_blocks > lead_blocks) {
         g_tx_err = "bad argument (granules of 8 blocks, groups dividing the channel count, keep <= lead)"; return MCRX_EINVAL;
     }
@@ -1008,8 +1020,8 @@ template <int KK, int R, int IN>
 static int tx_launch_fused_in(mctx_hip_t q, const TxSynthArgs &ya, hipStream_t st)
 {
     const size_t lds = syn::Lds<KK, R>::bytes();
-    static bool attr = false;
-    if (!attr) { TXCHK(hipFuncSetAttribute((const void *)syn::synth_kernel<KK, R, IN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    static PerDeviceOnce attr;               // (per instantiation and device: devscope.hpp)
+    TXCHK(raise_lds_limit((const void *)syn::synth_kernel<KK, R, IN>, lds, attr));
     const size_t nout = ya.nblocks - ya.out_first;
     // slab per workgroup: a whole number of workgroup waves over the CUs, at most 512 blocks (28 blocks of lead-in each)
     const size_t cap = (size_t)q->ncu * (KK >= 1024 ? 1 : 2);
@@ -1071,6 +1083,7 @@ static int tx_stream_slots(mctx_hip_t q, unsigned Sp)
 
 extern "C" int mctx_hip_stream_begin(mctx_hip_t q, unsigned max_payload_len)
 {
+    DevScope dev_scope_(q ? q->device : -1);
     if (!q) { g_tx_err = "null handle"; return MCRX_EINVAL; }
     const unsigned N = q->N, M = q->M, K = q->K, L = M + q->cp, Md = q->od.M_data;
     // slots for the longest frame a payload of this size can make: BPSK behind two rate-1/2 codes
@@ -1100,6 +1113,7 @@ extern "C" int mctx_hip_stream_begin(mctx_hip_t q, unsigned max_payload_len)
 
 extern "C" int mctx_hip_stream_reset(mctx_hip_t q)
 {
+    DevScope dev_scope_(q ? q->device : -1);
     if (!q || !q->st_on) { g_tx_err = "stream not started"; return MCRX_EINVAL; }
     const unsigned L = q->M + q->cp;
     TXCHK(hipStreamSynchronize(q->sst));
@@ -1119,6 +1133,7 @@ extern "C" int mctx_hip_stream_ready(mctx_hip_t q, unsigned ch)
 extern "C" int mctx_hip_stream_update(mctx_hip_t q, unsigned ch, const uint8_t *header8, const uint8_t *payload, unsigned payload_len,
                                       int mod, int fec0, int fec1)
 {
+    DevScope dev_scope_(q ? q->device : -1);
     if (!q || !q->st_on || !header8 || (!payload && payload_len)) { g_tx_err = "bad argument"; return MCRX_EINVAL; }
     if (ch >= q->N) { g_tx_err = "error: multichanneltx::UpdateData(), invalid channel id"; return MCRX_EINVAL; }
     if (!mod_bps(mod)) { g_tx_err = "unsupported modulation scheme"; return MCRX_EUNSUPP; }
@@ -1181,6 +1196,7 @@ static int tx_stream_period(mctx_hip_t q)
 
 extern "C" int mctx_hip_stream_generate(mctx_hip_t q, float *out)
 {
+    DevScope dev_scope_(q ? q->device : -1);
     if (!q || !q->st_on || !out) { g_tx_err = "bad argument"; return MCRX_EINVAL; }
     const unsigned L = q->M + q->cp;
     if (q->out_pos >= L) { int rc = tx_stream_period(q); if (rc) return rc; }
@@ -1204,6 +1220,7 @@ extern "C" size_t mctx_hip_frame_len(mctx_hip_t q, unsigned payload_len, int mod
 extern "C" int mctx_hip_frame(mctx_hip_t q, const uint8_t *header8, const uint8_t *payload, unsigned payload_len,
                               int mod, int fec0, int fec1, float gain, float *out, size_t out_cap)
 {
+    DevScope dev_scope_(q ? q->device : -1);
     if (!q || !header8 || (!payload && payload_len) || !out) { g_tx_err = "bad argument"; return MCRX_EINVAL; }
     if (!mod_bps(mod)) { g_tx_err = "unsupported modulation scheme"; return MCRX_EUNSUPP; }
     if (!fec_supported(fec0) || !fec_supported(fec1)) { g_tx_err = "unsupported fec scheme"; return MCRX_EUNSUPP; }

@@ -11,6 +11,9 @@ LEGS = {
     "8ch": (8, 64, 8, 100, 1200, 40, 6, False, 0),
     "8ch_v27": (8, 64, 8, 100, 1200, 40, 11, False, 0),
     "64ch_m256_qam16_resamp": (64, 256, 32, 32, 1200, 27, 7, True, 0),
+    "64ch_m256_qpsk": (64, 256, 32, 32, 1200, 40, 7, False, 0),
+    "64ch_m256_qam16": (64, 256, 32, 32, 1200, 27, 7, False, 0),
+    "64ch_m256_qam64": (64, 256, 32, 32, 1200, 29, 7, False, 0),
     "512ch": (512, 64, 8, 16, 1200, 40, 6, False, 0),
     "512ch_pfb2_front_end": (512, 64, 8, 16, 1200, 40, 6, False, 1),
     "512ch_pfb2_chain": (512, 64, 8, 16, 1200, 40, 6, False, 2),

@@ -35,6 +35,13 @@ def test_library_exports_every_declared_symbol(product):
         getattr(L, s)
 
 
+def test_per_device_bookkeeping_with_made_up_device_ids(product):
+    """Handles belong to a device, not to the process (round 6): the once-per-device table behind
+    hipFuncSetAttribute(MaxDynamicSharedMemorySize) -- csrc/devscope.hpp -- driven with device ids that need not exist."""
+    assert product.lib().mcrx_hip_selftest_device_table() == 0
+    assert product.lib().mcrx_hip_device(None) == -1
+
+
 def test_create_fails_loudly_without_gpu(product):
     import torch
     if torch.cuda.is_available():

@@ -450,7 +450,7 @@ def test_convolutional_k7_rate_half_viterbi(oracle, product, mod, fec0, fec1, so
     if snr_db is None:
         for f in ora.frames:
             assert sent[f.channel][(f.header[0] << 8) | f.header[1]] == (f.header, f.payload)
-    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=plen, payload_soft=soft)
+    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=plen, payload_soft=soft, conv_scratch=1)
     rx.Execute(x); rx.Flush()
     w = check_frames(rx.frames, ora.frames, rel=1.0)
     assert w <= REL, w
@@ -479,7 +479,7 @@ def test_convolutional_decoder_block_geometry(oracle, product, plen):
     ora = oracle.MultiChannelRx(N, M, cp, 4, soft=True)
     ora.execute(x)
     assert len(ora.frames) >= 3 * N - 1 and sum(f.payload_valid for f in ora.frames) >= len(ora.frames) - 1
-    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=2048, payload_soft=1)
+    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=2048, payload_soft=1, conv_scratch=1)
     rx.Execute(x); rx.Flush()
     check_frames(rx.frames, ora.frames, rel=1.0)
     frames, fwd, tb = rx.viterbi_stats()
@@ -508,13 +508,46 @@ def test_convolutional_decoder_is_exact_where_survivors_do_not_merge(oracle, pro
     ora.execute(x)
     broken = [f for f in ora.frames if f.header_valid and not f.payload_valid and (f.fec0, f.fec1) == (1, 11)]
     assert len(broken) >= 6, (len(ora.frames), len(broken))
-    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=plen, payload_soft=1)
+    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=plen, payload_soft=1, conv_scratch=1)
     rx.Execute(x); rx.Flush()
     check_frames(rx.frames, ora.frames, rel=1.0)                     # (payload bytes compared whether valid or not)
     frames, fwd, tb = rx.viterbi_stats()
     print("snr %.1f: %d frames through the kernel, %d forward / %d traceback passes repeated" % (snr_db, frames, fwd, tb))
     assert frames >= len(broken) and fwd + tb >= 1, (frames, fwd, tb)
     rx.close()
+
+
+def test_convolutional_decoder_scratch_is_allocated_when_the_code_is_seen(oracle, product):
+    """cfg.conv_scratch (round 6): the frame-per-wave K = 7 decoder keeps 512 bytes per trellis step and wave in HBM -- 0.4-0.65 GB per
+    handle -- which a receiver that never sees the code should not pay.  Default 0: the first pushes that carry the code go through the block
+    decoder (same frames as the oracle), the device reports the code, the host allocates, and from then on the frames go through the
+    frame-per-wave kernel (mcrx_hip_viterbi_stats counts them).  1 = with the handle, from the first frame; 2 = never."""
+    N, M, cp, plen = 4, 64, 8, 300
+    tx = product.multichanneltx(N, M, cp, 4)
+    iq, sent = tx.generate(3, plen, mod=40, fec0=1, fec1=11, seed=11)
+    tx.close()
+    x = iq.cpu().numpy()
+    x = x[:len(x) // (32 * N) * (32 * N)]
+    ora = oracle.MultiChannelRx(N, M, cp, 4, soft=True)
+    ora.execute(x)
+    assert len(ora.frames) == 3 * N and all(f.payload_valid for f in ora.frames)
+    counts = {}
+    for mode in (0, 1, 2):
+        rx = product.multichannelrx(N, M, cp, 4, max_payload_len=plen, payload_soft=1, conv_scratch=mode)
+        per_push = []
+        for rep in range(4):
+            seen = len(rx.frames)
+            rx.Execute(x); rx.Flush()
+            check_frames(rx.frames[seen:], ora.frames)
+            per_push.append(rx.viterbi_stats()[0])
+            rx.Reset()
+        counts[mode] = per_push
+        rx.close()
+    assert counts[1][0] == 3 * N and counts[1][3] == 4 * 3 * N, counts        # with the handle: every frame, from the first push
+    assert counts[2] == [0, 0, 0, 0], counts                                   # never
+    assert counts[0][0] == 0 and counts[0][3] >= 2 * 3 * N, counts             # lazily: not the first push, every push from the third on at the latest
+    with pytest.raises(Exception):
+        product.multichannelrx(N, M, cp, 4, conv_scratch=3)
 
 
 @pytest.mark.parametrize("mod,fec0,fec1,soft,snr_db", [(40, 1, 2, 1, 4.0), (40, 1, 3, 1, 2.0), (27, 1, 4, 1, 17.0), (40, 1, 5, 1, 9.0),
