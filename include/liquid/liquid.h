@@ -49,6 +49,9 @@ modulation_scheme liquid_getopt_str2mod(const char *_str);
 fec_scheme        liquid_getopt_str2fec(const char *_str);
 void              liquid_print_modulation_schemes(void);
 void              liquid_print_fec_schemes(void);
+/* (liquid-dsp's own reports its version here; this shim says what it is, so that a log or a fixture cannot be mistaken for liquid-dsp's:
+ *  tests/golden/ref_harness.cc writes it into every fixture's .meta) */
+const char *      liquid_libversion(void);
 
 /* frame generator properties (lib/multichanneltx.cc:70-75,184) */
 typedef struct { unsigned int check, fec0, fec1, mod_scheme; } ofdmflexframegenprops_s;
