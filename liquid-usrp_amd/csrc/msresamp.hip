@@ -103,35 +103,105 @@ __global__ __launch_bounds__(256) void halfband_interp_kernel(RsIn in, float2 *o
 }
 
 // Arbitrary stage, outputs j in [j0, j1): input index and branch are closed forms of j (64-bit phase).  The input span
-// of a workgroup's 1024 outputs (<= 2048 + 14 samples: step <= 2 samples per output) is staged in LDS once; the 14 taps
-// of a branch come as four 16-byte loads from the padded table (16 KB, cache resident).
+// of 1024 outputs (<= 2048 + 14 samples: step <= 2 samples per output) is staged in LDS; so is the branch table, TRANSPOSED
+// (round 6): lane l's branch is b_0 + l * db mod 256 -- at any rate but 1/2, 1 and 2 every lane has a row of its own, and the
+// four 16-byte loads per output that fetched it from the (cache-resident) table were 64 different lines per instruction: the
+// stage ran at 28-32 % of HBM for r = 0.37, 0.8, 2.0 against 54 % at r = 0.5, where all lanes share a row
+// (profiles/r2_resamp_roofline.csv).  With tap k of all 256 branches side by side in LDS (a pad word per 32 branches, so that
+// the strides rational rates produce -- r = 0.8: branches 0, 64, 128, 192 -- do not pile onto one bank) a lane's 14 taps are 14
+// four-byte LDS reads at lane-dependent addresses, conflict-free or nearly, and equal addresses broadcast.  A workgroup stages
+// the table once and works through RS_CHUNKS chunks of 1024 outputs.
+// FIXED (round 6): rates whose 24-bit step has no low 16 bits -- 1/2, 1, 2, 0.8, 1.25, 0.64 ...: every rate k / 2^8 samples per output --
+// walk the branches with a period that divides 256, so a thread's outputs (1024 n + tid + 256 r) all use ONE branch: its 14 taps sit in
+// registers for the whole workgroup and the table is not staged at all.
+// Both builds request the next chunk's input span (global loads into registers) before they work on the current one.
+#define RS_CHUNKS 8
+#define RS_HT_ROW (RS_NPFB + RS_NPFB / 32)
+#define RS_SPAN (2 * RS_OB + RS_TAPS + 2)
+#define RS_PER ((RS_SPAN + 255) / 256)
+template <bool FIXED>
 __global__ __launch_bounds__(256) void arbitrary_kernel(RsIn in, float2 *out, long long j0, long long j1,
                                                         unsigned long long step, const float *hpfb)
 {
-    __shared__ float2 x[2 * RS_OB + RS_TAPS + 2];
-    const long long jb = j0 + (long long)blockIdx.x * RS_OB;
-    const long long je = min(jb + (long long)RS_OB, j1);
+    __shared__ float2 x[RS_SPAN];
+    __shared__ float2 ht[FIXED ? 1 : (RS_TAPS / 2) * RS_HT_ROW];      // taps (2 k, 2 k + 1) of branch b at ht[k][b + b / 32]
     const int tid = threadIdx.x;
-    const long long nf = (long long)(((unsigned long long)jb * step) >> RS_PHASE_BITS);
-    const long long nl = (long long)(((unsigned long long)(je - 1) * step) >> RS_PHASE_BITS);
-    const int np = (int)(nl - nf) + RS_TAPS;
-    for (int p = tid; p < np; p += 256) x[p] = rs_fetch(in, nf - (RS_TAPS - 1) + p);
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < RS_OB / 256; r++) {
-        const long long j = jb + tid + 256 * r;
-        if (j >= je) break;
-        const unsigned long long P = (unsigned long long)j * step;
-        const int o = (int)((long long)(P >> RS_PHASE_BITS) - nf);
-        const unsigned b = (unsigned)((P & ((1ull << RS_PHASE_BITS) - 1)) >> (RS_PHASE_BITS - 8));
-        const float4 *hp = reinterpret_cast<const float4 *>(hpfb + (size_t)b * RS_HROW);
+    float hfix[RS_TAPS];
+    if constexpr (FIXED) {
+        const unsigned long long P = (unsigned long long)(j0 + tid) * step;
+        const unsigned bq = (unsigned)((P & ((1ull << RS_PHASE_BITS) - 1)) >> (RS_PHASE_BITS - 8));
+        const float4 *hp = reinterpret_cast<const float4 *>(hpfb + (size_t)bq * RS_HROW);
         const float4 ha = hp[0], hb = hp[1], hc = hp[2], hd = hp[3];
         const float h[RS_HROW] = { ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w, hc.x, hc.y, hc.z, hc.w, hd.x, hd.y, hd.z, hd.w };
-        float2 acc = make_float2(0.f, 0.f);
 #pragma unroll
-        for (int k = 0; k < RS_TAPS; k++) { const float2 v = x[o + k]; acc.x += h[k] * v.x; acc.y += h[k] * v.y; }
-        out[j - j0] = acc;
+        for (int k = 0; k < RS_TAPS; k++) hfix[k] = h[k];
+    } else {   // branch tid's row (16 floats, 14 used) -> column tid of the transposed table
+        const float4 *hp = reinterpret_cast<const float4 *>(hpfb + (size_t)tid * RS_HROW);
+        const float4 ha = hp[0], hb = hp[1], hc = hp[2], hd = hp[3];
+        const float h[RS_HROW] = { ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w, hc.x, hc.y, hc.z, hc.w, hd.x, hd.y, hd.z, hd.w };
+        const int bp = tid + (tid >> 5);
+#pragma unroll
+        for (int k = 0; k < RS_TAPS / 2; k++) ht[k * RS_HT_ROW + bp] = make_float2(h[2 * k], h[2 * k + 1]);
     }
+    // chunk geometry: first input sample and span length of chunk c
+    auto geom = [&](int c, long long &jb, long long &je, long long &nf, int &np) -> bool {
+        jb = j0 + ((long long)blockIdx.x * RS_CHUNKS + c) * RS_OB;
+        if (c >= RS_CHUNKS || jb >= j1) return false;
+        je = min(jb + (long long)RS_OB, j1);
+        nf = (long long)(((unsigned long long)jb * step) >> RS_PHASE_BITS);
+        const long long nl = (long long)(((unsigned long long)(je - 1) * step) >> RS_PHASE_BITS);
+        np = (int)(nl - nf) + RS_TAPS;
+        return true;
+    };
+    float2 pre[RS_PER];
+    auto fetch = [&](long long nf, int np) {
+#pragma unroll
+        for (int i = 0; i < RS_PER; i++) { const int p = tid + 256 * i; pre[i] = p < np ? rs_fetch(in, nf - (RS_TAPS - 1) + p) : make_float2(0.f, 0.f); }
+    };
+    long long jb, je, nf; int np;
+    if (!geom(0, jb, je, nf, np)) return;
+    fetch(nf, np);
+    for (int c = 0; c < RS_CHUNKS; c++) {
+        __syncthreads();                                     // (the previous chunk's reads of x; the table's writes)
+#pragma unroll
+        for (int i = 0; i < RS_PER; i++) { const int p = tid + 256 * i; if (p < np) x[p] = pre[i]; }
+        __syncthreads();
+        const long long cjb = jb, cje = je, cnf = nf;
+        const bool more = geom(c + 1, jb, je, nf, np);
+        if (more) fetch(nf, np);                             // in flight while this chunk is worked on
+#pragma unroll
+        for (int r = 0; r < RS_OB / 256; r++) {
+            const long long j = cjb + tid + 256 * r;
+            if (j >= cje) break;
+            const unsigned long long P = (unsigned long long)j * step;
+            const int o = (int)((long long)(P >> RS_PHASE_BITS) - cnf);
+            float2 acc = make_float2(0.f, 0.f);
+            if constexpr (FIXED) {
+#pragma unroll
+                for (int k = 0; k < RS_TAPS; k++) { const float2 v = x[o + k]; acc.x += hfix[k] * v.x; acc.y += hfix[k] * v.y; }
+            } else {
+                const unsigned bq = (unsigned)((P & ((1ull << RS_PHASE_BITS) - 1)) >> (RS_PHASE_BITS - 8));
+                const float2 *hcol = ht + bq + (bq >> 5);
+#pragma unroll
+                for (int k = 0; k < RS_TAPS / 2; k++) {
+                    const float2 h = hcol[k * RS_HT_ROW];
+                    const float2 v0 = x[o + 2 * k], v1 = x[o + 2 * k + 1];
+                    acc.x += h.x * v0.x; acc.y += h.x * v0.y;
+                    acc.x += h.y * v1.x; acc.y += h.y * v1.y;
+                }
+            }
+            out[j - j0] = acc;
+        }
+        if (!more) break;
+    }
+}
+// (FIXED needs the branch of output j to depend on j mod 256 only, and a thread's outputs to share it: the step's low 16 bits clear)
+static inline bool rs_fixed_rate(unsigned long long step) { return (step & 0xFFFFull) == 0; }
+static inline void rs_launch_arbitrary(const RsIn &in, float2 *out, long long j0, long long j1, unsigned long long step, const float *hpfb, hipStream_t st)
+{
+    const unsigned n = (unsigned)(j1 - j0), grid = (n + RS_OB * RS_CHUNKS - 1) / (RS_OB * RS_CHUNKS);
+    if (rs_fixed_rate(step)) hipLaunchKernelGGL(arbitrary_kernel<true>, dim3(grid), dim3(256), 0, st, in, out, j0, j1, step, hpfb);
+    else hipLaunchKernelGGL(arbitrary_kernel<false>, dim3(grid), dim3(256), 0, st, in, out, j0, j1, step, hpfb);
 }
 
 // the last RS_KEEP samples of a two-segment input become the next call's tail (one workgroup, staged through registers
@@ -304,8 +374,7 @@ extern "C" int msresamp_hip_execute_device(msresamp_hip_t q, const void *d_in, s
             b1.end += j1 - j0;
         }
         if (j1 > j0) {
-            const unsigned n = (unsigned)(j1 - j0);
-            hipLaunchKernelGGL(arbitrary_kernel, dim3((n + OB - 1) / OB), dim3(256), 0, st, src0, dst, j0, j1, q->step, q->d_hpfb);
+            rs_launch_arbitrary(src0, dst, j0, j1, q->step, q->d_hpfb, st);
             RSCHK(hipGetLastError());
         }
         q->out_count = j1;
@@ -355,9 +424,7 @@ extern "C" int msresamp_hip_execute_device(msresamp_hip_t q, const void *d_in, s
     if (j1 < j0) j1 = j0;
     if ((size_t)(j1 - j0) > out_cap) { g_rs_err = "output buffer too small"; return MCRX_EINVAL; }
     if (j1 > j0) {
-        const unsigned n = (unsigned)(j1 - j0);
-        hipLaunchKernelGGL(arbitrary_kernel, dim3((n + OB - 1) / OB), dim3(256), 0, st,
-                           q->num_stages ? stage_in(q->in[q->num_stages]) : src0, (float2 *)d_out, j0, j1, q->step, q->d_hpfb);
+        rs_launch_arbitrary(q->num_stages ? stage_in(q->in[q->num_stages]) : src0, (float2 *)d_out, j0, j1, q->step, q->d_hpfb, st);
         RSCHK(hipGetLastError());
     }
     q->out_count = j1;
