@@ -804,9 +804,10 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
     a.gen_list = q->d_gen[slot]; a.dec_lds_soft = 0;
     if (!q->d_vit_scratch && q->vit_mode == 0 && q->vit_rows && q->h_hint && ((volatile uint32_t *)q->h_hint)[11]) {
         // a frame with the K = 7 code has been decoded: its decoder's scratch from here on (a failure is not an error: the block decoder stays)
-        if (hipMalloc((void **)&q->d_vit_scratch, (size_t)q->vit_waves * q->vit_rows * 64) != hipSuccess) {
+        const size_t vit_bytes = (size_t)q->vit_waves * q->vit_rows * 64 * sizeof(uint2);       // [waves][rows][64 lanes] of 8 bytes
+        if (hipMalloc((void **)&q->d_vit_scratch, vit_bytes) != hipSuccess) {
             (void)hipGetLastError(); q->d_vit_scratch = nullptr; q->vit_mode = 2;
-            if (q->debug) fprintf(stderr, "[mcrx] the K = 7 decoder's scratch (%zu MB) could not be allocated: the block decoder stays\n", ((size_t)q->vit_waves * q->vit_rows * 64) >> 20);
+            if (q->debug) fprintf(stderr, "[mcrx] the K = 7 decoder's scratch (%zu MB) could not be allocated: the block decoder stays\n", vit_bytes >> 20);
         } else q->owned.push_back(q->d_vit_scratch);
     }
     a.vit_scratch = q->d_vit_scratch; a.vit_rows = q->vit_rows; a.vit_waves = q->vit_waves; a.vit_passes = q->d_vit_passes;

@@ -14,6 +14,8 @@ LEGS = {
     "64ch_m256_qpsk": (64, 256, 32, 32, 1200, 40, 7, False, 0),
     "64ch_m256_qam16": (64, 256, 32, 32, 1200, 27, 7, False, 0),
     "64ch_m256_qam64": (64, 256, 32, 32, 1200, 29, 7, False, 0),
+    "8ch_long_pushes": (8, 64, 8, 400, 1200, 40, 6, False, 0),
+    "512ch_m48": (512, 48, 6, 16, 1200, 40, 6, False, 0),
     "512ch": (512, 64, 8, 16, 1200, 40, 6, False, 0),
     "512ch_pfb2_front_end": (512, 64, 8, 16, 1200, 40, 6, False, 1),
     "512ch_pfb2_chain": (512, 64, 8, 16, 1200, 40, 6, False, 2),

@@ -522,7 +522,8 @@ def test_convolutional_decoder_scratch_is_allocated_when_the_code_is_seen(oracle
     handle -- which a receiver that never sees the code should not pay.  Default 0: the first pushes that carry the code go through the block
     decoder (same frames as the oracle), the device reports the code, the host allocates, and from then on the frames go through the
     frame-per-wave kernel (mcrx_hip_viterbi_stats counts them).  1 = with the handle, from the first frame; 2 = never."""
-    N, M, cp, plen = 4, 64, 8, 300
+    N, M, cp, plen = 8, 64, 8, 1200         # (frames as long as the handle allows: every decoder wave uses its whole region of the scratch -- an
+                                            #  allocation eight times too small passed this test's first, 300-byte form and faulted in bench.py)
     tx = product.multichanneltx(N, M, cp, 4)
     iq, sent = tx.generate(3, plen, mod=40, fec0=1, fec1=11, seed=11)
     tx.close()
