@@ -71,7 +71,7 @@ def parse():
     ap.add_argument("--no-aperiodic", action="store_true", help="skip the ragged-traffic leg (value_aperiodic)")
     ap.add_argument("--acquisition", type=int, default=0, help="mcrx_hip_config::acquisition for every receiver of the run (A/B runs: 3 = an anchor phase in front of the segment waves, the default of rounds 4-5)")
     ap.add_argument("--worker-build", type=int, default=0, help="mcrx_hip_config::worker_build for every receiver of the run (A/B runs: 1 = the lean workers with their butterfly exchanges on the VALU)")
-    ap.add_argument("--scout-build", type=int, default=0, help="mcrx_hip_config::scout_build for the headline receiver (A/B runs: 2 = the general state machine's segment waves)")
+    ap.add_argument("--scout-build", type=int, default=0, help="mcrx_hip_config::scout_build for the headline receiver (A/B runs: 2 = the lean segment waves of csrc/acq_lean.hpp; 0 = the general state machine's, the default)")
     ap.add_argument("--no-variants", action="store_true", help="skip the headline's variants (30 dB AWGN on the wideband samples; equalised symbols not stored)")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE.json configurations (the `configs` block)")
     ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed region of --steps steps: value = median, value_min / value_max beside it")

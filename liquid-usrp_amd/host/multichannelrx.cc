@@ -9,6 +9,8 @@
 #include <string>
 #include <vector>
 #include <unistd.h>
+#include <sys/stat.h>
+#include <time.h>
 
 #include "multichannelrx.h"
 #include "mcrx_hip.h"
@@ -111,8 +113,14 @@ multichannelrx::multichannelrx(unsigned int _num_channels, unsigned int _M, unsi
                 if (ok) pimpl->uid_path = path;
             } else if (ok) {
                 ok = false;
+                // (without MCRX_JOB_ID the tag comparison below is '' == '', and a rank that starts before rank 0 could still
+                //  read a dead job's id before rank 0 unlinks it -- and hang in ncclCommInitRank.  A file written more than two minutes
+                //  before this rank started is not this job's: ranks of one job start together; jobs that cannot promise that set MCRX_JOB_ID.)
+                const time_t t_start = time(NULL);
                 for (int t = 0; t < 600 && !ok; t++) {      // up to a minute
-                    FILE *f = fopen(path.c_str(), "rb");
+                    struct stat sb;
+                    const bool fresh = job != NULL || (stat(path.c_str(), &sb) == 0 && sb.st_mtime + 120 >= t_start);
+                    FILE *f = fresh ? fopen(path.c_str(), "rb") : NULL;
                     if (f) {
                         char got[256]; memset(got, 0, sizeof(got));
                         ok = fread(uid, 1, 128, f) == 128;
