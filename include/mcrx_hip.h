@@ -53,7 +53,10 @@ typedef struct {
                                     five-fold -- or carries a longer payload is reported with payload_valid = 0 */
     uint32_t max_frames;         /* frame records kept between flushes; 0 -> auto (covers one host batch of
                                     the shortest possible frames on every channel) */
-    uint32_t payload_soft;       /* 1 = soft-decision payload decoding (default), 0 = hard */
+    uint32_t payload_soft;       /* 1 = soft-decision payload decoding (default), 0 = hard.  (Hard decisions of the Hamming(8,4) code: a double
+                                    error -- a word at distance 2 from several codewords -- decodes to the lowest symbol at that distance; liquid-dsp's
+                                    own table for that case is not visible from the reference, so such frames, which fail their CRC either way, may
+                                    carry other bytes than upstream's: DESIGN.md section 2, D8) */
     uint32_t slab_blocks;        /* channelizer blocks per workgroup slab; 0 -> auto */
     uint32_t channel_first;      /* synchronizer shard: first channel ...          */
     uint32_t channel_count;      /* ... and count handled by this handle; 0 -> all  */
@@ -89,7 +92,9 @@ typedef struct {
      * differ in speed only and exist so that a regression in the default can be told from one in the algorithm.  0 = default. */
     uint32_t worker_build;       /* M = 64 payload workers: 0 = lean workers, butterfly exchanges through the LDS crossbar;
                                     1 = lean workers with the exchanges on the VALU (DPP / permlane swaps); 2 = the round-2 worker, one
-                                    frame per wave; 3 / 4 = that worker with two / four frames per wave; 5 = the width-generic kernel */
+                                    frame per wave; 3 / 4 = that worker with two / four frames per wave; 5 = the width-generic kernel.
+                                    M = 128 / 256: 0 = the lean one-frame-per-wave workers of csrc/payload_wide.hpp (round 6), 2 .. 5 = the
+                                    width-generic kernel they replace */
     uint32_t acquisition;        /* 0 = segment-parallel acquisition, anchored on the state a push begins in while the traffic has a cadence;
                                     1 = one launch of segment waves, no anchor; 2 = no segment waves (the scouts walk every frame); 3 = an
                                     anchor phase in front of the segment waves, always (rounds 4-5: a launch that acquires every channel's first

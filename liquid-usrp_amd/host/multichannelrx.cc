@@ -72,7 +72,13 @@ multichannelrx::multichannelrx(unsigned int _num_channels, unsigned int _M, unsi
     memset(&cfg, 0, sizeof(cfg));
     cfg.struct_size = sizeof(cfg);
     cfg.payload_soft = 1;
+    // MCRX_FRONT_END=1 (round 6): the oversampled analysis bank BASELINE.json's north_star names (liquid's firpfbch2, 2N channels, + a half-band
+    // decimator per kept channel, folded into one kernel: include/mcrx_hip.h, front_end) in place of the reference's critically sampled
+    // firpfbch (lib/multichannelrx.cc:89-91) -- the class interface has no argument for it, so the unchanged applications reach it
+    // through the environment; not with MCRX_WORLD (the sharded class keeps 13 blocks of history per round)
+    cfg.front_end = (uint32_t)env_int("MCRX_FRONT_END", NULL, 0);
     const int W = pimpl->world;
+    if (W > 0 && cfg.front_end) { fprintf(stderr, "error: multichannelrx, MCRX_FRONT_END and MCRX_WORLD cannot be combined\n"); delete pimpl; throw 0; }
     if (W > 0) {
         if (pimpl->rank < 0 || pimpl->rank >= W || _num_channels % (unsigned)W || pimpl->sub_blocks == 0) {
             fprintf(stderr, "error: multichannelrx, MCRX_WORLD = %d must divide the %u channels, MCRX_RANK = %d lie in [0, MCRX_WORLD), MCRX_SUB_BLOCKS be at least %d\n",

@@ -36,6 +36,30 @@ def test_unchanged_reference_app_decodes_synthetic_traffic(oracle, tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(EXE), reason="reference app binary not built")
+def test_unchanged_reference_app_on_the_oversampled_front_end(oracle, tmp_path):
+    """The unchanged src/multichannel_rx.cc with the channelizer BASELINE.json's north_star names in front of the synchronizers:
+    MCRX_FRONT_END=1 switches the receiver class to the firpfbch2 bank + half-band decimators (one folded kernel, include/mcrx_hip.h:
+    front_end) from outside -- the class interface has no argument for it.  Same packets as with the reference's own bank."""
+    N, M, cp, tp = 4, 64, 8, 4
+    iq, sent = oracle.synth_traffic(N, M, cp, tp, 4, payload_len=120)
+    f = tmp_path / "iq.bin"
+    iq.astype(np.complex64).tofile(f)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "liquid-usrp_amd", "host"), "-s"])
+    got = {}
+    for mode, extra in (("firpfbch", {}), ("firpfbch2", {"MCRX_FRONT_END": "1"})):
+        env = dict(os.environ, MCRX_IQ_FILE=str(f), MCRX_IQ_PACKET="4096", **extra)
+        out = subprocess.run([EXE, "-n", str(N), "-M", str(M), "-C", str(cp), "-T", str(tp), "-t", "0.5", "-v"],
+                             env=env, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert "INVALID" not in out.stdout.split("usrp data transfer started")[1]
+        got[mode] = set(re.findall(r"channel: (\d+) rx packet id:\s+(\d+)\n", out.stdout))
+    assert len(got["firpfbch"]) >= 4 * N and got["firpfbch2"] == got["firpfbch"]
+    env = dict(os.environ, MCRX_IQ_FILE=str(f), MCRX_FRONT_END="1", MCRX_WORLD="1", MCRX_RANK="0")     # not with the sharded class
+    out = subprocess.run([EXE, "-n", str(N), "-M", str(M), "-C", str(cp), "-T", str(tp), "-t", "0.1"], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "MCRX_FRONT_END" in out.stderr
+
+
+@pytest.mark.skipif(not os.path.exists(EXE), reason="reference app binary not built")
 def test_unchanged_reference_app_through_the_sharded_receiver(oracle, tmp_path):
     """The same unchanged application with the receiver class switched to its multi-GPU form from outside (MCRX_WORLD / MCRX_RANK /
     MCRX_SUB_BLOCKS: host/multichannelrx.cc over mcrx_hip_pipeline_*), world = 1 -- the one size a one-GPU lease can run: rounds of
