@@ -545,7 +545,10 @@ static void rxsymbol(ll_ofdmframesync q)
         p0 += q->Pfit[i] * y_phase[i];
         p1 += q->Pfit[q->M_pilot + i] * y_phase[i];
     }
-    const float alpha = 0.3f;
+#ifndef LL_P1_ALPHA
+#define LL_P1_ALPHA 0.3f     /* slope smoothing of the pilot fit (experiments only: scratch/r6/d6_probe.py) */
+#endif
+    const float alpha = LL_P1_ALPHA;
     p1 = alpha * p1 + (1.0f - alpha) * q->p1_prime;
     q->p1_prime = p1;
     for (unsigned i = 0; i < M; i++) {
