@@ -526,7 +526,8 @@ def main():
         if cfgs:
             out["configs"] = cfgs
         if world == 1 and not args.no_variants and not args.pipeline and not args.serial and not os.environ.get("BENCH_DEFAULT_HW_QUEUES") and QUEUES_BEFORE is None:
-            out.update(safely(default_queues_leg, args))
+            dq = safely(default_queues_leg, args)
+            out.update(dq if "error" not in dq else {"value_default_hw_queues": None, "value_default_hw_queues_note": dq["error"]})
         if not args.no_cpu and world == 1:                     # the CPU leg is reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(ora, prod, slabs[0] if slabs is not None else slabs_keep0, N, M, cp, taper, args.cpu_reps, cfg)
     if rx is not None:
