@@ -740,6 +740,27 @@ def test_oversampled_bank_matches_oracle(oracle, product, M, m):
     pfb.close()
 
 
+@pytest.mark.parametrize("front_end", [1, 2])
+def test_oversampled_front_end_reset_in_mid_stream(oracle, product, front_end):
+    """Reset() behind the oversampled front end: the bank's 27 blocks of history (front_end = 1: one folded kernel) / the three stages'
+    states (front_end = 2) are cleared, the oscillator is not (lib/multichannelrx.cc:135-153), block alignment restarts -- against
+    the oracle's chain given the same junk, Reset and traffic, in pieces."""
+    N, M, cp = 4, 64, 8
+    iq, _ = oracle.synth_traffic(N, M, cp, 4, 2, payload_len=90, seed=31)
+    rng = np.random.RandomState(9)
+    junk = (0.05 * (rng.randn(32 * N * 37 + 11) + 1j * rng.randn(32 * N * 37 + 11))).astype(np.complex64)
+    ora = oracle.MultiChannelRx(N, M, cp, 4, front_end=1)
+    ora.execute(junk); ora.reset(); ora.execute(iq)
+    assert len(ora.frames) == 2 * N and all(f.payload_valid for f in ora.frames)
+    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=128, front_end=front_end)
+    rx.Execute(junk); rx.Reset()
+    for i in range(0, len(iq), 32 * N * 9 + 5):
+        rx.Execute(iq[i:i + 32 * N * 9 + 5])
+    rx.Flush()
+    check_frames(rx.frames, ora.frames)
+    rx.close()
+
+
 def test_oversampled_bank_argument_errors(product):
     for M, m in [(0, 4), (7, 4), (8, 0)]:                                # firpfbch2_crcf_create: even M, m >= 1
         with pytest.raises(ValueError):
