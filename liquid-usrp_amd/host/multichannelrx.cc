@@ -44,6 +44,11 @@ struct multichannelrx::impl {
     float *mine;                                                    // pinned buffer of the round being collected (NULL: not asked for yet)
     std::vector<std::complex<float> > tail;                         // [13 blocks]: the end of the round being collected = rank 0's next halo
     std::string uid_path;                                           // rank 0: the file it wrote (removed at destruction)
+    // Where the stream stops (Reset, destruction) the unfinished round is completed with zeros: a frame whose last sample would lie
+    // in that padding never ended in the reference's stream (ofdmflexframesync_reset drops it, lib/multichannelrx.cc:139-140; its
+    // destructor synchronizes nothing further) and is not delivered here either.  chan_pos: channel-rate samples
+    // (= blocks) pushed since the object was made -- what mcrx_frame::end_sample counts; drop_from: the first padded one.
+    uint64_t chan_pos = 0, drop_from = ~0ull;
     void take(const std::complex<float> *x, size_t n);              // sharded Execute: n samples at position `fill` of the round
     void push_round(multichannelrx *self);
     size_t finish_round(multichannelrx *self);                      // zero the trailing partial block, pad the round with zeros, push it
@@ -161,11 +166,13 @@ multichannelrx::~multichannelrx()
             // round needs every rank's part, so the unfinished round is padded with zeros and pushed -- by every rank: they all reach
             // their destructor at the same point of the stream -- and what it held is delivered below.  (Flush() cannot do this: padding
             // in the middle of a stream would move the block alignment of everything behind it.)
+            pimpl->drop_from = pimpl->chan_pos + pimpl->fill / pimpl->K;
             try { pimpl->finish_round(this); } catch (...) { }
             mcrx_hip_pipeline_wait(pimpl->pipe);
         }
         mcrx_hip_flush(pimpl->h);
         Deliver();
+        pimpl->drop_from = ~0ull;
         if (pimpl->pipe) mcrx_hip_pipeline_destroy(pimpl->pipe);
         mcrx_hip_destroy(pimpl->h);
     }
@@ -193,6 +200,7 @@ void multichannelrx::Deliver()
 {
     mcrx_frame f;
     while (mcrx_hip_next_frame(pimpl->h, &f) == 1) {
+        if (f.end_sample >= pimpl->drop_from) continue;            // completed on the zeros behind the end of the stream
         if (pimpl->debug_dir && f.channel < num_channels && f.num_framesyms) {      // keep the last frame of every channel for the dump
             const std::complex<float> *p = reinterpret_cast<const std::complex<float> *>(f.framesyms);
             pimpl->debug_syms[f.channel].assign(p, p + f.num_framesyms);
@@ -221,6 +229,7 @@ void multichannelrx::Reset()
         // unfinished round is completed with zeros and pushed first -- block alignment restarts behind a Reset anyway, so the padding is
         // invisible -- and the oscillator is told that the padding was never in the stream (it is not reset, :144, and the samples of the
         // dropped partial block still count for it).  Every rank gets the same call at the same point of the stream.
+        pimpl->drop_from = pimpl->chan_pos + pimpl->fill / pimpl->K;                 // (frames that end in the padding are not delivered)
         const size_t real = pimpl->fill, pushed = pimpl->finish_round(this);         // pushed: 0 (nothing but a partial block) or a whole round
         if (mcrx_hip_pipeline_reset(pimpl->pipe, (long long)real - (long long)pushed) != MCRX_OK) {
             fprintf(stderr, "error: multichannelrx::Reset(), %s\n", mcrx_hip_pipeline_last_error());
@@ -230,6 +239,7 @@ void multichannelrx::Reset()
         std::fill(pimpl->tail.begin(), pimpl->tail.end(), std::complex<float>(0.f, 0.f));
         if (pimpl->mine && pimpl->rank == 0) memset(pimpl->mine, 0, 13 * pimpl->K * sizeof(std::complex<float>));      // (a buffer taken but not pushed: its halo is the old tail)
         Deliver();
+        pimpl->drop_from = ~0ull;
         return;
     }
     mcrx_hip_reset(pimpl->h);
@@ -284,6 +294,7 @@ void multichannelrx::impl::push_round(multichannelrx *self)
         throw 0;
     }
     mine = NULL; fill = 0;
+    chan_pos += (uint64_t)world * sub_blocks;
     const int rc = mcrx_hip_poll(h);                                        // the frames of the rounds before
     if (rc == MCRX_EOVERFLOW)
         fprintf(stderr, "warning: multichannelrx::Execute(), frame pool exhausted, %llu frames dropped so far\n",

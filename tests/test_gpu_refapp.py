@@ -120,6 +120,45 @@ def test_sharded_class_reset_in_mid_stream_and_end_of_stream(oracle, tmp_path):
     assert got["sharded256_sums"] == got["plain_sums"] == got["sharded4096_sums"]
 
 
+def test_sharded_class_reset_inside_a_payload_delivers_nothing_from_the_padding(oracle, product, tmp_path):
+    """the sharded class completes the unfinished round with zeros when the stream stops (Reset, destruction).  A frame whose
+    payload is in progress at that point used to be finished on the zeros and handed to the callback as an invalid frame; the reference
+    drops it silently (ofdmflexframesync_reset, lib/multichannelrx.cc:139-140) and its destructor synchronizes nothing further.  Here the
+    Reset() comes 40 channel samples before the end of every channel's fourth frame (the position is taken from the GPU receiver's own
+    end_sample of a run without reset) and the stream is cut the same way inside the last frame; rounds of 4096 blocks hold the whole
+    stream, so all the padding behind both points is synchronized.  Plain class, sharded class and oracle deliver the same frames."""
+    import torch
+    N, M, cp, tp = 4, 64, 8, 4
+    iq, sent = oracle.synth_traffic(N, M, cp, tp, 8, payload_len=150, seed=5)
+    iq = iq.astype(np.complex64)
+    K = 2 * N
+    rx = product.multichannelrx(N, M, cp, tp, max_payload_len=256)
+    rx.Execute(torch.from_numpy(iq[:len(iq) // K * K]).cuda()); rx.Flush()
+    ends = sorted(f.end_sample for f in rx.frames if f.channel == 0 and f.payload_valid)
+    rx.close()
+    assert len(ends) >= 6
+    reset_at = (ends[3] - 40) * K + 3                        # 40 channel samples short of the fourth frame's last one, not on a block boundary
+    stop_at = (ends[-1] - 40) * K + 5                        # ... and the stream ends inside the last frame
+    cut = iq[:stop_at]
+    f = tmp_path / "iq.bin"
+    cut.tofile(f)
+    ora = oracle.MultiChannelRx(N, M, cp, tp)
+    ora.execute(cut[:reset_at]); ora.reset(); ora.execute(cut[reset_at:])
+    want = sorted((f_.channel, (f_.header[0] << 8) | f_.header[1], f_.payload_valid, len(f_.payload)) for f_ in ora.frames)
+    assert len(want) >= 4 * N and all(w[2] for w in want)
+    host = os.path.join(ROOT, "liquid-usrp_amd", "host")
+    subprocess.check_call(["make", "-C", host, "-s"])
+    subprocess.check_call(["make", "-C", host, "-s", "shard_test"])
+    for mode, extra in (("plain", {}), ("sharded256", {"MCRX_WORLD": "1", "MCRX_RANK": "0", "MCRX_SUB_BLOCKS": "256"}),
+                        ("sharded4096", {"MCRX_WORLD": "1", "MCRX_RANK": "0", "MCRX_SUB_BLOCKS": "4096"})):
+        out = subprocess.run([os.path.join(ROOT, "liquid-usrp_amd", "lib", "shard_test"), str(f), str(N), str(M), str(cp), str(tp), "10007", str(reset_at)],
+                             env=dict(os.environ, **extra), capture_output=True, text=True, timeout=180)
+        assert out.returncode == 0 and "done" in out.stdout, out.stderr[-2000:]
+        got = sorted((int(a), int(b), int(d), int(e)) for a, b, c, d, e in
+                     re.findall(r"frame ch (\d+) pid (\d+) hv (\d+) pv (\d+) len (\d+)", out.stdout))
+        assert got == want, (mode, [g for g in got if g not in want], [w for w in want if w not in got])
+
+
 TXEXE = os.path.join(ROOT, "liquid-usrp_amd", "lib", "multichannel_tx_ref")
 
 
