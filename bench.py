@@ -240,6 +240,7 @@ def main():
     # ---- every kernel alone (serial handle, HIP events on the launch stream): the roofline block's durations.
     # Runs first, so it also brings the clocks up before the timed region.
     ser = prod.multichannelrx(N, M, cp, taper, serial=1, channel_first=c0, channel_count=cg, **cfg)
+    ser.kernel_timing(True)                             # (HIP-event pairs around every kernel: off in a new receiver, include/mcrx_hip.h)
     for k in range(args.serial_steps + 2):
         if k == 2:
             torch.cuda.synchronize(); ser.kernel_stats(reset=True)
@@ -357,7 +358,6 @@ def main():
     for k in range(args.warmup):
         step()
     fence()
-    rx.kernel_stats(reset=True)
     rx.spec_stats(reset=True)
     if pipe is not None:
         pipe.time_exchange(True) if callable(getattr(pipe, "time_exchange", None)) else setattr(pipe, "time_exchange", True)
@@ -399,12 +399,20 @@ def main():
                     "what": ("RCCL, HIP events on the exchange stream of rank 0 (%s)" % ("grouped ncclSend/ncclRecv behind the C-ABI" if use_c else "torch.distributed all_to_all_single")) if world > 1
                             else "local copy standing in for the exchange (one GPU)"}
     walked, adopted = rx.spec_stats()
+    # the kernels' durations while they overlap: a few more steps of the same loop with the receiver's event timing switched on,
+    # outside the timed region (the event pairs are ten more packets per push; the timed region runs the receiver as it is made)
+    stat_steps = 4
+    rx.kernel_timing(True); rx.kernel_stats(reset=True)
+    for k in range(stat_steps):
+        step()
+    fence()
     ovl_stats = rx.kernel_stats()
+    rx.kernel_timing(False)
 
     # ---- verification (untimed): one more step of the continuing stream, harvested; every frame of the step
     # decoded, valid and equal to what the transmitter sent
     rx.Flush(); rx.frames.clear()
-    step_first = int(args.warmup + nsteps_timed + trial_steps) * period_blocks         # channel-rate sample index where this step starts
+    step_first = int(args.warmup + nsteps_timed + trial_steps + stat_steps) * period_blocks         # channel-rate sample index where this step starts
     step(harvest_rx=rx)
     rx.Flush()
     nfr, n_ok = len(rx.frames), 0
@@ -612,7 +620,7 @@ def config_leg(prod, torch, dev, N, M, cp, frames, plen, mod, fec1, resamp, step
     for _ in range(3):
         step()
     torch.cuda.synchronize()
-    rx.kernel_stats(reset=True); rx.spec_stats(reset=True)
+    rx.spec_stats(reset=True)
     rep_s = []
     for _ in range(reps):
         t0 = time.perf_counter()
@@ -621,7 +629,12 @@ def config_leg(prod, torch, dev, N, M, cp, frames, plen, mod, fec1, resamp, step
         torch.cuda.synchronize()
         rep_s.append(time.perf_counter() - t0)
     walked, adopted = rx.spec_stats()
+    rx.kernel_timing(True); rx.kernel_stats(reset=True)         # (outside the timed region: a few more steps with the event pairs switched on)
+    for _ in range(max(2, steps // 2)):
+        step()
+    torch.cuda.synchronize()
     ovl = {k: round(v[0] / max(v[1], 1), 4) for k, v in rx.kernel_stats().items()}
+    rx.kernel_timing(False)
     rx.Flush(); rx.frames.clear()
     step(keep=True); rx.Flush()
     nfr = len(rx.frames)
@@ -636,6 +649,7 @@ def config_leg(prod, torch, dev, N, M, cp, frames, plen, mod, fec1, resamp, step
         # the front-end kernel alone (a serial receiver: every kernel of a push in order on one stream, HIP events on that stream),
         # against the same 12 algorithmic bytes per wideband sample as the reference's bank: 8 read + 4 written
         ser = prod.multichannelrx(N, M, cp, taper, max_payload_len=plen, max_frames=N * frames + 64, serial=1, **leg_cfg)
+        ser.kernel_timing(True)
         for k in range(5):
             if k == 2:
                 torch.cuda.synchronize(); ser.kernel_stats(reset=True)
@@ -751,6 +765,7 @@ def aperiodic_leg(prod, N, M, cp, taper, slab_blocks, K, args, torch, dev):
     for _ in range(nwarm):
         step()
     torch.cuda.synchronize()
+    rx.kernel_timing(True)               # (this leg reports the overlapped kernel durations of its own timed steps: ten event packets per 1.4 ms push)
     rx.kernel_stats(reset=True); rx.spec_stats(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.aperiodic_steps):
@@ -820,6 +835,7 @@ def variant_legs(prod, N, M, cp, taper, cfg, slabs, sent_idx, args, torch, dev):
         for _ in range(max(2, args.warmup)):
             step()
         torch.cuda.synchronize()
+        rx.kernel_timing(True)           # (as in the ragged-traffic leg)
         rx.kernel_stats(reset=True)
         t0 = time.perf_counter()
         for _ in range(steps):

@@ -203,9 +203,12 @@ int  mcrx_hip_kernel_time_ms(mcrx_hip_t q, float *channelizer_ms, float *sync_ms
 /* summed HIP-event durations [ms] and launch counts since the last reset of the statistics, per
  * kernel: [0] channelizer_kernel, [1] sync_kernel (per-channel scout), [2] place_jobs_kernel,
  * [3] payload_kernel (per-frame symbol loop), [4] decode_kernel (per-frame packet decode).
- * Events are recorded on the launch stream; no host sync per launch. */
+ * Events are recorded on the launch stream; no host sync per launch -- and only while timing is switched on
+ * (mcrx_hip_kernel_timing; off in a new handle: the five event pairs per push are ten more packets on the handle's
+ * streams, 9 % of an 8-channel receiver's 0.25 ms push). */
 #define MCRX_NKERNELS 5
 int  mcrx_hip_kernel_stats(mcrx_hip_t q, double ms_total[MCRX_NKERNELS], uint64_t launches[MCRX_NKERNELS], int reset);
+int  mcrx_hip_kernel_timing(mcrx_hip_t q, int on);                    /* returns the previous setting (-1: null handle) */
 
 const char *mcrx_hip_last_error(void);
 

@@ -87,6 +87,7 @@ _EXPORTS = {
     "mcrx_hip_selftest_device_table": (C.c_int, []),
     "mcrx_hip_kernel_time_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "mcrx_hip_kernel_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
+    "mcrx_hip_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "mcrx_hip_last_error": (C.c_char_p, []),
     "msresamp_hip_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_float, C.c_float]),
     "msresamp_hip_destroy": (C.c_int, [C.c_void_p]),
@@ -363,8 +364,12 @@ class multichannelrx(object):
         _check(lib().mcrx_hip_kernel_time_ms(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def kernel_timing(self, on=True):
+        """per-kernel HIP-event timing on / off (off in a new receiver); returns the previous setting"""
+        return bool(lib().mcrx_hip_kernel_timing(self._h, 1 if on else 0))
+
     def kernel_stats(self, reset=False):
-        """{kernel: (total_ms, launches)} from HIP events recorded on the launch stream."""
+        """{kernel: (total_ms, launches)} from HIP events recorded on the launch stream while kernel_timing() was on."""
         names = ("channelizer_kernel", "sync_kernel", "place_jobs_kernel", "payload_kernel", "decode_kernel")
         ms, cnt = (C.c_double * len(names))(), (C.c_uint64 * len(names))()
         _check(lib().mcrx_hip_kernel_stats(self._h, ms, cnt, 1 if reset else 0))

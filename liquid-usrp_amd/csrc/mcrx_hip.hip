@@ -232,8 +232,11 @@ struct mcrx_hip_s {
     double ev_ms_total[MCRX_NKERNELS] = {}; uint64_t ev_count[MCRX_NKERNELS] = {};
     float ev_last[MCRX_NKERNELS] = {};
 
+    bool ev_on = false;                     // mcrx_hip_kernel_timing(): the pairs are recorded on request only -- ten more packets per push on the handle's
+                                            // streams cost an 8-channel receiver of 0.25 ms pushes 9 % (scratch/r6/t23.sh: 267 -> 244 us per push)
     int ev_begin(int which, hipStream_t st)
     {
+        if (!ev_on) return MCRX_OK;
         // ring full: fold the older half (long finished in a running stream, so the host does not stall on it)
         if (ev_used[which] + 2 > evring[which].size()) RC(ev_resolve(which, evring[which].size() / 2));
         HIPCHK(hipEventRecord(evring[which][ev_used[which]], st));
@@ -241,6 +244,7 @@ struct mcrx_hip_s {
     }
     int ev_end(int which, hipStream_t st)
     {
+        if (!ev_on) return MCRX_OK;
         HIPCHK(hipEventRecord(evring[which][ev_used[which] + 1], st));
         ev_used[which] += 2;
         return MCRX_OK;
@@ -605,6 +609,7 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     if (devel_env("MCRX_ACQ_MODE")) q->acq_mode = atoi(devel_env("MCRX_ACQ_MODE"));
     if (devel_env("MCRX_WALK_LDS_PAD")) q->walk_lds_pad = (uint32_t)atoi(devel_env("MCRX_WALK_LDS_PAD"));
     if (devel_env("MCRX_PAYLOAD_LDS_PAD")) q->round_lds_pad = (uint32_t)atoi(devel_env("MCRX_PAYLOAD_LDS_PAD"));
+    if (devel_env("MCRX_EVT")) q->ev_on = true;
     if (devel_env("MCRX_SLOTS")) q->nslots = (unsigned)std::max(2, std::min(MCRX_SLOTS, atoi(devel_env("MCRX_SLOTS"))));
     if (!q->pipelined) q->nslots = 2;
     if ((rc = q->alloc(&q->d_njobs, MCRX_SLOTS))) return bail(rc);      // one counter per slot: a launch's placement kernel zeroes the next slot's
@@ -1047,6 +1052,16 @@ extern "C" int mcrx_hip_kernel_stats(mcrx_hip_t q, double ms_total[MCRX_NKERNELS
         if (reset) { q->ev_ms_total[w] = 0; q->ev_count[w] = 0; }
     }
     return MCRX_OK;
+}
+
+// per-kernel HIP-event timing on / off (off when the handle is made): returns the previous setting, -1 for a null handle.
+// Launches enqueued while it is off are not in mcrx_hip_kernel_stats / mcrx_hip_kernel_time_ms.
+extern "C" int mcrx_hip_kernel_timing(mcrx_hip_t q, int on)
+{
+    if (!q) return -1;
+    const int was = q->ev_on ? 1 : 0;
+    q->ev_on = on != 0;
+    return was;
 }
 
 // ---------------------------------------------------------------- streaming Execute()
