@@ -30,7 +30,7 @@ using namespace mcrx;
 #define RS_TAPS (2 * RS_M)          // taps per polyphase branch / half-band filter branch
 #define RS_NPFB 256
 #define RS_PHASE_BITS 24
-#define RS_KEEP 32                  // samples of history retained per stage (>= 27)
+#define RS_KEEP 64                  // samples of history retained per stage (>= 27; >= 54 where the last half-band stage is folded into the arbitrary one)
 
 #define RS_OB 1024                  // outputs per workgroup (256 threads x 4)
 #define RS_HROW 16                  // floats per row of the padded branch table (14 taps + 2): one row = 4 x 16-B loads
@@ -115,17 +115,30 @@ __global__ __launch_bounds__(256) void halfband_interp_kernel(RsIn in, float2 *o
 // walk the branches with a period that divides 256, so a thread's outputs (1024 n + tid + 256 r) all use ONE branch: its 14 taps sit in
 // registers for the whole workgroup and the table is not staged at all.
 // Both builds request the next chunk's input span (global loads into registers) before they work on the current one.
+// HB (round 6, rates below 1/2): the LAST half-band decimator is folded in -- `in` is THAT stage's input, and the samples the arbitrary
+// stage reads, y[k] = 0.5 (u[2k-13] + sum_i h1[i] u[2(k-13+i)]), are formed in LDS from the staged raw span (even and odd samples apart,
+// as in halfband_kernel) instead of travelling through HBM: at r = 0.37 the two kernels moved 8 + 4 + 4 + 3 = 19 bytes per input sample
+// for 11 algorithmic ones.  Chunks of 512 outputs there (the raw span is twice the half-band span), 40 KB of LDS.
 #define RS_CHUNKS 8
 #define RS_HT_ROW (RS_NPFB + RS_NPFB / 32)
-#define RS_SPAN (2 * RS_OB + RS_TAPS + 2)
-#define RS_PER ((RS_SPAN + 255) / 256)
-template <bool FIXED>
+template <bool FIXED, bool HB>
 __global__ __launch_bounds__(256) void arbitrary_kernel(RsIn in, float2 *out, long long j0, long long j1,
-                                                        unsigned long long step, const float *hpfb)
+                                                        unsigned long long step, const float *hpfb, const float *h1)
 {
+    constexpr int RS_OBK = HB ? RS_OB / 2 : RS_OB;          // outputs per chunk
+    constexpr int RS_SPAN = 2 * RS_OBK + RS_TAPS + 2;       // samples of the arbitrary stage's input behind a chunk (step <= 2 per output)
+    constexpr int RS_SPANR = RS_SPAN + RS_TAPS;             // HB: (even, odd) pairs of raw samples behind those
+    constexpr int RS_PER = ((HB ? RS_SPANR : RS_SPAN) + 255) / 256;
+    constexpr int RS_PERY = (RS_SPAN + 255) / 256;
     __shared__ float2 x[RS_SPAN];
+    __shared__ float2 ev[HB ? RS_SPANR : 1], od[HB ? RS_SPANR : 1];
     __shared__ float2 ht[FIXED ? 1 : (RS_TAPS / 2) * RS_HT_ROW];      // taps (2 k, 2 k + 1) of branch b at ht[k][b + b / 32]
     const int tid = threadIdx.x;
+    float hh[HB ? RS_TAPS : 1];
+    if constexpr (HB) {
+#pragma unroll
+        for (int i = 0; i < RS_TAPS; i++) hh[i] = h1[i];
+    }
     float hfix[RS_TAPS];
     if constexpr (FIXED) {
         const unsigned long long P = (unsigned long long)(j0 + tid) * step;
@@ -145,32 +158,77 @@ __global__ __launch_bounds__(256) void arbitrary_kernel(RsIn in, float2 *out, lo
     }
     // chunk geometry: first input sample and span length of chunk c
     auto geom = [&](int c, long long &jb, long long &je, long long &nf, int &np) -> bool {
-        jb = j0 + ((long long)blockIdx.x * RS_CHUNKS + c) * RS_OB;
+        jb = j0 + ((long long)blockIdx.x * RS_CHUNKS + c) * RS_OBK;
         if (c >= RS_CHUNKS || jb >= j1) return false;
-        je = min(jb + (long long)RS_OB, j1);
+        je = min(jb + (long long)RS_OBK, j1);
         nf = (long long)(((unsigned long long)jb * step) >> RS_PHASE_BITS);
         const long long nl = (long long)(((unsigned long long)(je - 1) * step) >> RS_PHASE_BITS);
         np = (int)(nl - nf) + RS_TAPS;
         return true;
     };
-    float2 pre[RS_PER];
+    float2 pre[RS_PER], pro[HB ? RS_PER : 1];
     auto fetch = [&](long long nf, int np) {
+        if constexpr (HB) {     // y[nf - 13 + p], p < np, read raw pairs q < np + 13 from sample tb = 2 (nf - 26) on
+            const long long tb = 2 * (nf - 2 * (RS_TAPS - 1));
+            const int nq = np + RS_TAPS - 1;
+            // inside the new samples, on a 16-byte boundary (all chunks but a call's first and last, while calls are even-sized): one
+            // 16-byte load per (even, odd) pair, whole lines per instruction
+            const bool whole = tb >= in.cur_base && tb + 2 * (long long)nq <= in.end && (((tb - in.cur_base) & 1) == 0) && ((reinterpret_cast<size_t>(in.cur) & 15) == 0);
+            if (whole) {
+                const float4 *src = reinterpret_cast<const float4 *>(in.cur + (tb - in.cur_base));
 #pragma unroll
-        for (int i = 0; i < RS_PER; i++) { const int p = tid + 256 * i; pre[i] = p < np ? rs_fetch(in, nf - (RS_TAPS - 1) + p) : make_float2(0.f, 0.f); }
+                for (int i = 0; i < RS_PER; i++) {
+                    const int q = tid + 256 * i;
+                    const float4 v = src[q < nq ? q : 0];
+                    pre[i] = make_float2(v.x, v.y); pro[i] = make_float2(v.z, v.w);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < RS_PER; i++) {
+                    const int q = tid + 256 * i;
+                    const bool on = q < nq;
+                    pre[i] = on ? rs_fetch(in, tb + 2 * q) : make_float2(0.f, 0.f);
+                    pro[i] = on ? rs_fetch(in, tb + 2 * q + 1) : make_float2(0.f, 0.f);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < RS_PER; i++) { const int p = tid + 256 * i; pre[i] = p < np ? rs_fetch(in, nf - (RS_TAPS - 1) + p) : make_float2(0.f, 0.f); }
+        }
     };
     long long jb, je, nf; int np;
     if (!geom(0, jb, je, nf, np)) return;
     fetch(nf, np);
     for (int c = 0; c < RS_CHUNKS; c++) {
         __syncthreads();                                     // (the previous chunk's reads of x; the table's writes)
+        if constexpr (HB) {
 #pragma unroll
-        for (int i = 0; i < RS_PER; i++) { const int p = tid + 256 * i; if (p < np) x[p] = pre[i]; }
+            for (int i = 0; i < RS_PER; i++) { const int q = tid + 256 * i; if (q < np + RS_TAPS - 1) { ev[q] = pre[i]; od[q] = pro[i]; } }
+        } else {
+#pragma unroll
+            for (int i = 0; i < RS_PER; i++) { const int p = tid + 256 * i; if (p < np) x[p] = pre[i]; }
+        }
         __syncthreads();
         const long long cjb = jb, cje = je, cnf = nf;
+        const int cnp = np;
         const bool more = geom(c + 1, jb, je, nf, np);
         if (more) fetch(nf, np);                             // in flight while this chunk is worked on
+        if constexpr (HB) {     // the half-band stage's outputs behind this chunk (same arithmetic as halfband_kernel)
 #pragma unroll
-        for (int r = 0; r < RS_OB / 256; r++) {
+            for (int r = 0; r < RS_PERY; r++) {
+                const int p = tid + 256 * r;
+                if (p < cnp) {
+                    float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+                    for (int i = 0; i < RS_TAPS; i++) { const float2 v = ev[p + i]; acc.x += hh[i] * v.x; acc.y += hh[i] * v.y; }
+                    const float2 d = od[p + RS_M - 1];
+                    x[p] = make_float2(0.5f * (d.x + acc.x), 0.5f * (d.y + acc.y));
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int r = 0; r < RS_OBK / 256; r++) {
             const long long j = cjb + tid + 256 * r;
             if (j >= cje) break;
             const unsigned long long P = (unsigned long long)j * step;
@@ -197,11 +255,18 @@ __global__ __launch_bounds__(256) void arbitrary_kernel(RsIn in, float2 *out, lo
 }
 // (FIXED needs the branch of output j to depend on j mod 256 only, and a thread's outputs to share it: the step's low 16 bits clear)
 static inline bool rs_fixed_rate(unsigned long long step) { return (step & 0xFFFFull) == 0; }
-static inline void rs_launch_arbitrary(const RsIn &in, float2 *out, long long j0, long long j1, unsigned long long step, const float *hpfb, hipStream_t st)
+// h1 != nullptr: `in` is the input of the last half-band decimator, folded into the launch (arbitrary_kernel, HB)
+static inline void rs_launch_arbitrary(const RsIn &in, float2 *out, long long j0, long long j1, unsigned long long step, const float *hpfb, hipStream_t st,
+                                       const float *h1 = nullptr)
 {
-    const unsigned n = (unsigned)(j1 - j0), grid = (n + RS_OB * RS_CHUNKS - 1) / (RS_OB * RS_CHUNKS);
-    if (rs_fixed_rate(step)) hipLaunchKernelGGL(arbitrary_kernel<true>, dim3(grid), dim3(256), 0, st, in, out, j0, j1, step, hpfb);
-    else hipLaunchKernelGGL(arbitrary_kernel<false>, dim3(grid), dim3(256), 0, st, in, out, j0, j1, step, hpfb);
+    const unsigned n = (unsigned)(j1 - j0), ob = h1 ? RS_OB / 2 : RS_OB, grid = (n + ob * RS_CHUNKS - 1) / (ob * RS_CHUNKS);
+    if (h1) {
+        if (rs_fixed_rate(step)) hipLaunchKernelGGL((arbitrary_kernel<true, true>), dim3(grid), dim3(256), 0, st, in, out, j0, j1, step, hpfb, h1);
+        else hipLaunchKernelGGL((arbitrary_kernel<false, true>), dim3(grid), dim3(256), 0, st, in, out, j0, j1, step, hpfb, h1);
+    } else {
+        if (rs_fixed_rate(step)) hipLaunchKernelGGL((arbitrary_kernel<true, false>), dim3(grid), dim3(256), 0, st, in, out, j0, j1, step, hpfb, h1);
+        else hipLaunchKernelGGL((arbitrary_kernel<false, false>), dim3(grid), dim3(256), 0, st, in, out, j0, j1, step, hpfb, h1);
+    }
 }
 
 // the last RS_KEEP samples of a two-segment input become the next call's tail (one workgroup, staged through registers
@@ -406,6 +471,10 @@ extern "C" int msresamp_hip_execute_device(msresamp_hip_t q, const void *d_in, s
         StageBuf &bo = q->in[s + 1];
         const long long iend = s ? q->in[s].end : end0;
         const long long k0 = bo.end, k1 = iend / 2;         // output k exists once x[2k+1] has arrived
+        if (s + 1 == q->num_stages) {                       // the last one runs inside the arbitrary stage's kernel: its samples are counted, not stored
+            if (k1 > k0) bo.end = k1;
+            break;
+        }
         if (k1 > k0) {
             if ((rc = stage_reserve(q, bo, (size_t)(k1 - k0), st))) return rc;
             const unsigned n = (unsigned)(k1 - k0);
@@ -424,7 +493,9 @@ extern "C" int msresamp_hip_execute_device(msresamp_hip_t q, const void *d_in, s
     if (j1 < j0) j1 = j0;
     if ((size_t)(j1 - j0) > out_cap) { g_rs_err = "output buffer too small"; return MCRX_EINVAL; }
     if (j1 > j0) {
-        rs_launch_arbitrary(q->num_stages ? stage_in(q->in[q->num_stages]) : src0, (float2 *)d_out, j0, j1, q->step, q->d_hpfb, st);
+        const unsigned ns = q->num_stages;
+        if (ns) rs_launch_arbitrary(ns > 1 ? stage_in(q->in[ns - 1]) : src0, (float2 *)d_out, j0, j1, q->step, q->d_hpfb, st, q->d_h1);
+        else rs_launch_arbitrary(src0, (float2 *)d_out, j0, j1, q->step, q->d_hpfb, st);
         RSCHK(hipGetLastError());
     }
     q->out_count = j1;
