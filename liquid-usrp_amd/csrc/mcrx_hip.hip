@@ -234,9 +234,11 @@ struct mcrx_hip_s {
 
     bool ev_on = false;                     // mcrx_hip_kernel_timing(): the pairs are recorded on request only -- ten more packets per push on the handle's
                                             // streams cost an 8-channel receiver of 0.25 ms pushes 9 % (scratch/r6/t23.sh: 267 -> 244 us per push)
+    hipEvent_t ev_base = nullptr; bool ev_dump = false;      // (development builds, MCRX_EVT_DUMP: every pair's times from the first event on, on stderr -- scratch/r6/evt_timeline.py)
     int ev_begin(int which, hipStream_t st)
     {
         if (!ev_on) return MCRX_OK;
+        if (ev_dump && !ev_base) { HIPCHK(hipEventCreate(&ev_base)); HIPCHK(hipEventRecord(ev_base, st)); }
         // ring full: fold the older half (long finished in a running stream, so the host does not stall on it)
         if (ev_used[which] + 2 > evring[which].size()) RC(ev_resolve(which, evring[which].size() / 2));
         HIPCHK(hipEventRecord(evring[which][ev_used[which]], st));
@@ -256,6 +258,11 @@ struct mcrx_hip_s {
             float ms = 0;
             HIPCHK(hipEventSynchronize(evring[which][i + 1]));
             HIPCHK(hipEventElapsedTime(&ms, evring[which][i], evring[which][i + 1]));
+            if (ev_dump && ev_base) {
+                float t0 = 0;
+                if (hipEventElapsedTime(&t0, ev_base, evring[which][i]) == hipSuccess) fprintf(stderr, "[evt] %d %.1f %.1f\n", which, t0 * 1e3f, (t0 + ms) * 1e3f);
+                else (void)hipGetLastError();
+            }
             ev_ms_total[which] += ms; ev_count[which]++; ev_last[which] = ms;
         }
         std::rotate(evring[which].begin(), evring[which].begin() + n, evring[which].end());
@@ -610,6 +617,7 @@ extern "C" int mcrx_hip_create(mcrx_hip_t *out, unsigned N, unsigned M, unsigned
     if (devel_env("MCRX_WALK_LDS_PAD")) q->walk_lds_pad = (uint32_t)atoi(devel_env("MCRX_WALK_LDS_PAD"));
     if (devel_env("MCRX_PAYLOAD_LDS_PAD")) q->round_lds_pad = (uint32_t)atoi(devel_env("MCRX_PAYLOAD_LDS_PAD"));
     if (devel_env("MCRX_EVT")) q->ev_on = true;
+    if (devel_env("MCRX_EVT_DUMP")) { q->ev_on = true; q->ev_dump = true; }
     if (devel_env("MCRX_SLOTS")) q->nslots = (unsigned)std::max(2, std::min(MCRX_SLOTS, atoi(devel_env("MCRX_SLOTS"))));
     if (!q->pipelined) q->nslots = 2;
     if ((rc = q->alloc(&q->d_njobs, MCRX_SLOTS))) return bail(rc);      // one counter per slot: a launch's placement kernel zeroes the next slot's
@@ -721,7 +729,7 @@ extern "C" int mcrx_hip_destroy(mcrx_hip_t q)
     if (q->h_stage) (void)hipHostFree(q->h_stage);
     q->arena_host.release(); q->sarena_host.release();
     {
-        hipEvent_t evs[] = { q->ev_in, q->ev_consumed, q->ev_tmp[0], q->ev_tmp[1], q->ev_tmp[2], q->ev_tmp[3], q->ev_side_last };
+        hipEvent_t evs[] = { q->ev_in, q->ev_consumed, q->ev_tmp[0], q->ev_tmp[1], q->ev_tmp[2], q->ev_tmp[3], q->ev_side_last, q->ev_base };
         for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
         for (int g = 0; g < MCRX_GENS; g++) { if (q->ev_gen[g]) (void)hipEventDestroy(q->ev_gen[g]); if (q->ev_clean[g]) (void)hipEventDestroy(q->ev_clean[g]); }
         for (int sl = 0; sl < MCRX_SLOTS; sl++) {

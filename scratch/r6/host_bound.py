@@ -28,6 +28,8 @@ for pushes in (12, 60):
     t2 = time.perf_counter()
     print("%d ch x %d frames, fec1 %d: %d pushes: host enqueue %.1f us per push, with the device %.1f us per push (%.1f Gsample/s)" %
           (N, frames, fec1, pushes, (t1 - t0) / pushes * 1e6, (t2 - t0) / pushes * 1e6, sum(int(s.numel()) for s in slabs) / 2 / ((t2 - t0) / pushes) / 1e9), flush=True)
+if os.environ.get("MCRX_EVT_DUMP"):
+    rx.kernel_stats()          # (development build: folds the event pairs, which prints them)
 t0 = time.perf_counter()
 for i in range(60):
     rx.Execute(slabs[i & 1])

@@ -1,12 +1,10 @@
 #!/bin/bash
-# configs[1] latency: what bounds the device period?  devel build
+# configs[1]: the lean segment waves (cfg.scout_build = 2: chains of one frame) against the default
 cd $GRAFT_REPO_ROOT
-export MCRX_LIB=$GRAFT_REPO_ROOT/liquid-usrp_amd/lib/libmcrx_hip_devel.so
-run() { echo "== $*"; env "$@" python scratch/r6/host_bound.py 2>&1 | grep -v amdgpu.ids | grep "60 pushes"; }
-run X=1
-run MCRX_NO_EVT=1
-run MCRX_NO_EVT=1 MCRX_FREE_RUN=1
-run GPU_MAX_HW_QUEUES=12
-run GPU_MAX_HW_QUEUES=16
-run GPU_MAX_HW_QUEUES=16 MCRX_NO_EVT=1
-run MCRX_NO_PRIO=1
+for i in 1 2; do
+  for cfg in "" "scout_build=2"; do
+    for leg in 8ch 8ch_v27 8ch_long_pushes; do
+      LEG_CFG=$cfg python scratch/r6/leg.py $leg 6 3 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); k=list(d)[0]; v=d[k]; print('$cfg', k, v['value'], v['value_min'], v['value_max'], v.get('kernels_ms_overlapped'), v['verified']['ok'])"
+    done
+  done
+done
