@@ -243,10 +243,12 @@ def test_corrupted_frames_are_flagged_not_dropped(oracle, product):
     rx.close()
 
 
-@pytest.mark.parametrize("rate", [0.5, 0.37, 0.8, 0.2, 0.11, 2.0, 1.5, 4.0, 6.3])
+@pytest.mark.parametrize("rate", [0.5, 0.37, 0.8, 0.2, 0.11, 2.0, 1.5, 4.0, 6.3, 0.25, 0.45, 0.06])
 def test_msresamp_front_end_matches_oracle(oracle, product, rate):
     """Front-end resampler (BASELINE config 3 uses r = 0.5; its input is made with the transmit side's r = 2.0,
-    src/flexframe_tx.cc:170): GPU output == oracle within 1e-5, including when the input arrives in uneven pieces."""
+    src/flexframe_tx.cc:170): GPU output == oracle within 1e-5, including when the input arrives in uneven pieces.
+    Below 1/2 the last half-band decimator runs inside the arbitrary stage's kernel (round 6): 0.37 / 0.45 one folded stage and an
+    arbitrary rate, 0.25 / 0.2 the fixed-tap build behind it (0.5, 0.8), 0.11 / 0.06 two and three stand-alone stages in front."""
     torch = _torch()
     rng = np.random.RandomState(int(rate * 1000))
     n = 64 * 1024

@@ -476,3 +476,32 @@ def test_surprises_while_the_empty_launches_are_on_their_own_stream(oracle, prod
     assert len(ora.frames) >= 2 * N * (len(seq) - 1)
     check_frames(rx.frames, ora.frames)
     rx.close()
+
+
+def test_kernel_timing_is_recorded_on_request_only(product):
+    """mcrx_hip_kernel_timing (round 6): a new receiver records no timing events (ten packets per push less on its streams); the
+    statistics count exactly the launches enqueued while it was switched on, and switching changes no result."""
+    import torch
+    N, M, cp, tp = 8, 64, 8, 4
+    tx = product.multichanneltx(N, M, cp, tp)
+    x, _ = tx.generate(6, 300, mod=40, fec1=6, seed=77)
+    tx.close()
+    n = int(x.numel()) // (32 * N) * (32 * N)
+    x = x[:n]
+    got = []
+    for on in (False, True):
+        rx = product.multichannelrx(N, M, cp, tp, max_payload_len=320)
+        assert rx.kernel_timing(on) is False            # off in a new receiver
+        for _ in range(3):
+            rx.Execute(x); rx.Flush()
+        st = rx.kernel_stats()
+        if on:
+            assert st["channelizer_kernel"][1] == 3 and st["channelizer_kernel"][0] > 0.0 and st["payload_kernel"][1] == 3
+            assert rx.kernel_timing(False) is True
+            rx.Execute(x); rx.Flush()
+            assert rx.kernel_stats()["channelizer_kernel"][1] == 3     # the fourth launch was not timed
+        else:
+            assert all(v == (0.0, 0) for v in st.values()), st
+        got.append([(f.channel, f.end_sample, f.header, f.payload, f.payload_valid) for f in rx.frames[:6 * N * 3]])
+        rx.close()
+    assert len(got[0]) >= 6 * N and got[0] == got[1]
