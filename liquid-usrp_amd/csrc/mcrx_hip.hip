@@ -986,8 +986,15 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
         // workers (kernels.h, split_rest).  Everything of the push is finished when THAT stream is; a change of mode orders the two.
         const bool split = sw == q->s_work && q->s_side && q->h_hint && q->d_hint && q->list_seen[0] == 0 && q->list_seen[2] == 0 &&
                            q->seq >= 8 && a.frames_hint != ~0u && a.frames_hint < 2048u && sync_payload_splits(a);
+        // Round 6: while frames arrive on the general decoder's list (the K = 7 code: 0.25-0.3 ms of trellis per 800 frames, one wave per
+        // frame) THAT launch goes to the fourth stream behind this push's decoder, so that the next push's workers do not queue behind it:
+        // the work stream carried workers + decoder + trellis = 0.47 ms per push of an 8-channel receiver, now 0.2 | 0.3 side by side.  All
+        // general-decoder launches of such a phase follow each other on that one stream (they share the K = 7 scratch).
+        const bool gen_side = !split && sw == q->s_work && q->s_side && q->h_hint && q->d_hint && q->list_seen[2] != 0 && q->seq >= 8 &&
+                              !devel_env("MCRX_NO_GEN_SIDE");
         hipStream_t sd = sw;
         if (split) { a.split_rest = 1; a.dec_phase = 1; sd = q->s_side; }
+        else if (gen_side) sd = q->s_side;
         else if (q->side_last) HIPCHK(hipStreamWaitEvent(sw, q->ev_side_last, 0));       // (back in one line: behind what the other stream still holds)
         RC(q->ev_begin(3, sw));
         HIPCHK(sync_launch_payload(a, 1, sw));
@@ -1000,11 +1007,14 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
             HIPCHK(sync_launch_payload(a, 4, sd));
             a.dec_phase = 2;
             HIPCHK(sync_launch_payload(a, 2, sd));
+        } else if (gen_side) {
+            HIPCHK(hipEventRecord(q->ev_side[slot], sw));
+            HIPCHK(hipStreamWaitEvent(sd, q->ev_side[slot], 0));
         }
         HIPCHK(sync_launch_payload(a, 3, sd));
         RC(q->ev_end(4, sd));
-        if (split) HIPCHK(hipEventRecord(q->ev_side_last, sd));
-        q->side_last = split;
+        if (split || gen_side) HIPCHK(hipEventRecord(q->ev_side_last, sd));
+        q->side_last = split || gen_side;
         sw = sd;
     }
     HIPCHK(hipEventRecord(q->ev_done[slot], sw));

@@ -505,3 +505,43 @@ def test_kernel_timing_is_recorded_on_request_only(product):
         got.append([(f.channel, f.end_sample, f.header, f.payload, f.payload_valid) for f in rx.frames[:6 * N * 3]])
         rx.close()
     assert len(got[0]) >= 6 * N and got[0] == got[1]
+
+
+def test_general_decoder_on_the_fourth_stream_and_back(oracle, product):
+    """Round 6: while frames with the K = 7 code arrive at a receiver of few channels, the general decoder's launch (their trellis) runs on
+    the handle's fourth stream behind the push's decoder instead of in front of the next push's workers (mcrx_hip.hip: gen_side, from the
+    eighth launch on).  90 pushes of one streaming receiver: K = 7 frames (the mode switches on), 70 pushes of Hamming frames (after 64
+    launches with an empty general list the normally-empty launches move to that stream instead: split mode), K = 7 frames again, found
+    by the launches of the other mode first.  Every frame of every push equals the oracle's on the same samples."""
+    import torch
+    N, M, cp, tp = 8, 64, 8, 4
+    tx = product.multichanneltx(N, M, cp, tp)
+    slabs = []
+    plan = [(11, 10), (6, 70), (11, 6), (7, 4)]
+    for fec1, count in plan:
+        for i in range(count):
+            x, _ = tx.generate(3, 90 + 7 * (len(slabs) % 5), mod=40, fec1=fec1, seed=1000 + len(slabs), gain=0.5 / N)
+            n = int(x.numel()) // (32 * N) * (32 * N)
+            slabs.append(x[:n])
+    tx.close()
+    rx = product.multichannelrx(N, M, cp, tp, max_payload_len=160)
+    for x in slabs:
+        rx.Execute(x); rx.Poll()
+    rx.Flush()
+    got = {}
+    for f in rx.frames: got.setdefault(f.channel, []).append(f)
+    rx.close()
+    o = oracle.MultiChannelRx(N, M, cp, tp)
+    o.execute(torch.cat(slabs).cpu().numpy())
+    want = {}
+    for f in o.frames: want.setdefault(f.channel, []).append(f)
+    assert sum(len(v) for v in want.values()) >= 3 * N * len(slabs) - N
+    assert sorted(got) == sorted(want)
+    nk7 = 0
+    for ch in want:
+        assert len(got[ch]) == len(want[ch]), (ch, len(got[ch]), len(want[ch]))
+        for fg, fo in zip(got[ch], want[ch]):
+            assert (fg.header_valid, fg.payload_valid, fg.header, fg.payload) == (fo.header_valid, fo.payload_valid, fo.header, fo.payload)
+            assert fo.payload_valid
+            nk7 += fo.fec1 == 11
+    assert nk7 >= 3 * N * 15
