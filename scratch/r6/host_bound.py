@@ -10,7 +10,7 @@ dev = torch.device("cuda:0")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 fec1 = int(sys.argv[3]) if len(sys.argv) > 3 else 6
-M, cp, taper, plen, mod = 64, 8, 4, 1200, 40
+M, cp, taper, plen, mod = int(os.environ.get("HB_M", 64)), int(os.environ.get("HB_CP", 8)), 4, 1200, int(os.environ.get("HB_MOD", 40))
 tx = prod.multichanneltx(N, M, cp, taper)
 base = int(prod.lib().mctx_hip_blocks_for(tx._h, frames, plen, mod, 1, fec1))
 slabs = [tx.generate(frames, plen, mod=mod, fec1=fec1, seed=0xBEEF + 7919 * i, nblocks=base + (0, 48)[i], device=dev)[0] for i in range(2)]

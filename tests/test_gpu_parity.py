@@ -301,10 +301,11 @@ def test_resampled_front_end_feeds_the_receiver(oracle, product):
     rx.close(); rs.close()
 
 
-def test_record_pool_overflow_is_counted_not_fatal(product):
+@pytest.mark.parametrize("M,cp", [(64, 8), (256, 32)])
+def test_record_pool_overflow_is_counted_not_fatal(product, M, cp):
     """More frames than `max_frames`: the placement kernel's sequential path delivers the ones that fit,
     counts the rest in frames_dropped, and the handle keeps working."""
-    N, M, cp = 8, 64, 8
+    N = 8
     tx = product.multichanneltx(N, M, cp, 4)
     iq, sent = tx.generate(3, 100, seed=5)
     n = int(iq.numel()) // (32 * N) * (32 * N)

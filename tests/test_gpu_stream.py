@@ -153,13 +153,16 @@ def test_discard_keeps_the_stream_going(product):
     rx.close()
 
 
+@pytest.mark.parametrize("M,cp", [(64, 8), (256, 32), (128, 16)])
 @pytest.mark.parametrize("defer", [0, 4096])
-def test_frames_straddling_pushes(oracle, product, defer):
+def test_frames_straddling_pushes(oracle, product, defer, M, cp):
     """Pushes that cut every frame somewhere.  defer_samples = 0: the tail kernel walks a straddling payload across
     the boundary; > 0: the lean scout rewinds and the next push acquires the frame again, whole.  Either way the
-    frames are the oracle's, in order -- and with deferral nearly nothing is left to the serial walk."""
+    frames are the oracle's, in order -- and with deferral nearly nothing is left to the serial walk.
+    M = 256 (round 6): symbols of more than two samples per lane have no lean scout and no tail launches -- their scout is the whole state
+    machine, which carries a payload in progress across the boundary by itself (mcrx_hip.hip: `tails`)."""
     torch = _torch()
-    N, M, cp, nf, plen = 8, 64, 8, 6, 300
+    N, nf, plen = 8, 6, 300
     (iq, sent), = _slabs(product, N, M, cp, 1, nf, plen, (16,))
     x = iq.cpu().numpy()
     ora = oracle.MultiChannelRx(N, M, cp, 4)
@@ -545,3 +548,40 @@ def test_general_decoder_on_the_fourth_stream_and_back(oracle, product):
             assert fo.payload_valid
             nk7 += fo.fec1 == 11
     assert nk7 >= 3 * N * 15
+
+
+@pytest.mark.parametrize("M,cp", [(64, 8), (256, 32)])
+def test_frames_longer_than_the_receiver_was_made_for(product, M, cp):
+    """A payload beyond max_payload_len cannot be handed to a worker: the channel's scout walks its symbols itself (pushes cut them) and
+    the frame is delivered with its header and no payload; the frames behind it decode as ever.  Lean scout + tail launches at M = 64,
+    the whole state machine as scout and no tail launches at M = 256."""
+    import torch
+    N = 4
+    tx = product.multichanneltx(N, M, cp, 4)
+    parts, kinds = [], []
+    for i, plen in enumerate((80, 300, 80, 300, 300, 80)):
+        x, sent = tx.generate(2, plen, seed=40 + i, gain=0.5 / N)
+        parts.append(x); kinds.append((plen, sent))
+    tx.close()
+    iq = torch.cat(parts)
+    n = int(iq.numel()) // (32 * N) * (32 * N)
+    rx = product.multichannelrx(N, M, cp, 4, max_payload_len=100, defer_samples=0)
+    K = 2 * N
+    step = product.TILE * 37 * K
+    for i in range(0, n, step):
+        rx.Execute(iq[i:min(i + step, n)])
+    rx.Flush()
+    per = {c: [f for f in rx.frames if f.channel == c] for c in range(N)}
+    for c in range(N):
+        want = [plen for plen, _ in kinds for _ in range(2)]
+        assert len(per[c]) == len(want), (c, len(per[c]))
+        k = 0
+        for plen, sent in kinds:
+            for _ in range(2):
+                f = per[c][k]; k += 1
+                assert f.header_valid
+                if plen <= 100:
+                    assert f.payload_valid and sent[c][(f.header[0] << 8) | f.header[1]] == (f.header, f.payload)
+                else:
+                    assert not f.payload_valid and len(f.payload) == 0 and sent[c][(f.header[0] << 8) | f.header[1]][0] == f.header
+    rx.close()
