@@ -870,15 +870,10 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
         // segment wave stood in their exact state.
         SyncArgs t = a;
         t.tail_only = 1; t.pred = nullptr; t.pred_n = nullptr; t.spec_cap = 0; t.nseg = 0; t.spec_hint = nullptr; t.stats = nullptr;
-        // Symbols wider than two samples per lane (M >= 256) have no lean scout: theirs is the whole state machine (ofdmsync.hip: sy_launch_width,
-        // SYK_WALK / SYK_LEAN -> sync_kernel), which walks a payload in progress by itself -- at its entry and to the end of the buffer -- so the two
-        // tail launches have nothing to do there, ever, and are not made.  They were not free: the tail "kernel" of those widths is the same
-        // 212-256-register state machine, and each of the two normally empty launches waited 0.1-0.2 ms per push for a SIMD that the previous push's
-        // workers (2 x 204 registers) would let it onto (round 6, scratch/r6/evt_timeline.py: acquisition stream 0.48 ms per push of a 64-channel
-        // M = 256 receiver against 0.22 for its kernels alone).  A channel that IS in mid-payload at a push's entry gets no segment waves
-        // (run_seg: go = !mid_payload); its scout walks the push alone -- slower, not different.
-        const bool tails = q->sc.E <= 2 || devel_env("MCRX_WIDE_TAILS");
-        if (tails) HIPCHK(sync_launch_tail(t, sa));
+        // (Symbols wider than two samples per lane have no lean scout: theirs is the whole state machine, which carries a payload in progress
+        //  across pushes by itself, and the two tail launches never find anything to do there.  Leaving them out was measured -- round 6, alternating
+        //  runs of a development build, configs[2]: 105.2-106.8 without against 106.7-109.4 Gsample/s with them -- and is not done.)
+        HIPCHK(sync_launch_tail(t, sa));
         // How many segments: enough waves to fill the chip and short chains (a wave's frames are acquired one after the other),
         // but every segment costs two acquisitions that produce nothing (its first frame, taken from an arbitrary state, and the
         // frame that links it to the next segment), and its share of the channel's MCRX_SPEC_MAX slots must hold its frames.
@@ -969,7 +964,7 @@ static int launch_sync(mcrx_hip_t q, const float2 *chan, unsigned stride, unsign
         a.seg_phase = 0;
         if (q->lean_build == 1) HIPCHK(sync_launch_walk(a, sa)); else HIPCHK(sync_launch_lean(a, sa));
         // a frame the lean scout could neither hand off nor defer runs past the end of this buffer: walked up to there
-        if (tails) HIPCHK(sync_launch_tail(t, sa));
+        HIPCHK(sync_launch_tail(t, sa));
     } else {
         HIPCHK(sync_launch(a, sa));           // general configurations: one wave per channel walks everything
     }

@@ -159,8 +159,8 @@ def test_frames_straddling_pushes(oracle, product, defer, M, cp):
     """Pushes that cut every frame somewhere.  defer_samples = 0: the tail kernel walks a straddling payload across
     the boundary; > 0: the lean scout rewinds and the next push acquires the frame again, whole.  Either way the
     frames are the oracle's, in order -- and with deferral nearly nothing is left to the serial walk.
-    M = 256 (round 6): symbols of more than two samples per lane have no lean scout and no tail launches -- their scout is the whole state
-    machine, which carries a payload in progress across the boundary by itself (mcrx_hip.hip: `tails`)."""
+    M = 256 (round 6): symbols of more than two samples per lane have no lean scout -- theirs is the whole state machine, which carries a
+    payload in progress across the boundary by itself (the tail launches find nothing to do there)."""
     torch = _torch()
     N, nf, plen = 8, 6, 300
     (iq, sent), = _slabs(product, N, M, cp, 1, nf, plen, (16,))
@@ -553,8 +553,8 @@ def test_general_decoder_on_the_fourth_stream_and_back(oracle, product):
 @pytest.mark.parametrize("M,cp", [(64, 8), (256, 32)])
 def test_frames_longer_than_the_receiver_was_made_for(product, M, cp):
     """A payload beyond max_payload_len cannot be handed to a worker: the channel's scout walks its symbols itself (pushes cut them) and
-    the frame is delivered with its header and no payload; the frames behind it decode as ever.  Lean scout + tail launches at M = 64,
-    the whole state machine as scout and no tail launches at M = 256."""
+    the frame is delivered with its header and no payload; the frames behind it decode as ever.  Lean scout + tail kernel at M = 64,
+    the whole state machine as scout at M = 256."""
     import torch
     N = 4
     tx = product.multichanneltx(N, M, cp, 4)
